@@ -1,0 +1,170 @@
+"""TEST INFRASTRUCTURE -- CPU oracle, part 1: per-pool arbitrage subproblems (NumPy, fp64).
+
+PARITY UNPINNED: the reference (/root/reference, four cvxpy scripts) holds no expected
+outputs and cvxpy is not installable here; this file is pinned instead against
+(i) the SciPy primal NLP of oracle/primal_scipy.py, which states the reference model
+verbatim, and (ii) the survey-derived known answers in tests/golden/.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may use oracle/.
+
+For given local prices p > 0 every pool solves, independently,
+
+    arb_i(p) = max  p'(L - D)
+               s.t. phi_i(R + gamma*D - L) >= phi_i(R),  D, L >= 0
+
+which is the per-pool piece of the reference's model: variables
+/root/reference/arbitrage.py:51-52, post-trade reserves :60, trading-function constraints
+:63-74 (weighted geo-mean :65, Uniswap v2 :68-70, constant sum :73-74).  Every function
+returns y = L - D (pool-local order; negative = tendered, positive = received) and the
+value arb = p'y.  By the envelope theorem y is the gradient of arb_i wrt p.
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------
+# weighted geometric mean, 2 assets (constant product is wa == wb)      arbitrage.py:65,68
+# --------------------------------------------------------------------------------------
+def arb_geomean2(Ra, Rb, gamma, wa, wb, pa, pb):
+    """Vectorised over pools.  Direction a->b (tender a, receive b) is active iff
+    gamma*wa*pb*Rb > wb*pa*Ra; b->a iff gamma*wb*pa*Ra > wa*pb*Rb; never both (gamma<=1).
+    With eta = w_in/w_out the new reserve of the tendered token is
+        x = (gamma * eta * (p_out/p_in) * R_out * R_in**eta) ** (1/(eta+1))
+    """
+    Ra, Rb, gamma, wa, wb, pa, pb = map(np.asarray, (Ra, Rb, gamma, wa, wb, pa, pb))
+    ya = np.zeros(np.broadcast(Ra, pa).shape)
+    yb = np.zeros_like(ya)
+
+    def one_dir(Rin, Rout, win, wout, pin, pout):
+        eta = win / wout
+        act = gamma * win * pout * Rout > wout * pin * Rin
+        with np.errstate(all="ignore"):
+            x = np.exp((np.log(gamma * eta * (pout / pin) * Rout) + eta * np.log(Rin)) / (eta + 1.0))
+            x = np.where(eta == 1.0, np.sqrt(gamma * (pout / pin) * Rin * Rout), x)
+            d_in = (x - Rin) / gamma
+            l_out = np.where(eta == 1.0, Rout - Rin * Rout / x, Rout * (1.0 - (Rin / x) ** eta))
+        return act, np.where(act, -d_in, 0.0), np.where(act, l_out, 0.0)
+
+    act_ab, ya_ab, yb_ab = one_dir(Ra, Rb, wa, wb, pa, pb)
+    act_ba, yb_ba, ya_ba = one_dir(Rb, Ra, wb, wa, pb, pa)
+    ya = ya_ab + ya_ba
+    yb = yb_ab + yb_ba
+    return ya, yb, pa * ya + pb * yb
+
+
+# --------------------------------------------------------------------------------------
+# weighted geometric mean, n assets                                  arbitrage.py:65
+# --------------------------------------------------------------------------------------
+def arb_geomean_n(R, w, gamma, p):
+    """One pool, n_i assets, w normalised.  KKT with multiplier mu:
+        x_k(mu) = clip(R_k, mu*gamma*w_k/p_k, mu*w_k/p_k)
+    and sum_k w_k log x_k(mu) = sum_k w_k log R_k.  In t = log mu, a_k = log(R_k p_k/w_k),
+    lg = log gamma <= 0 the residual is the piecewise-linear non-decreasing function
+        F(t) = sum_k w_k f(t - a_k),  f(u) = u (u<0) | 0 (0<=u<=-lg) | u+lg (u>-lg)
+    solved exactly by scanning its 2 n_i breakpoints.
+    """
+    R = np.asarray(R, float); w = np.asarray(w, float); p = np.asarray(p, float)
+    lg = np.log(gamma)
+    a = np.log(R * p / w)
+
+    def F(t):
+        u = t - a
+        return float(np.sum(w * np.where(u < 0, u, np.where(u > -lg, u + lg, 0.0))))
+
+    bps = np.sort(np.concatenate([a, a - lg]))
+    Fv = np.array([F(t) for t in bps])
+    # no-trade plateau: some breakpoint interval where F == 0 with everything in the dead zone
+    lo_i = np.where(Fv <= 0)[0].max()         # F(bps[0]) <= 0 always
+    hi_i = np.where(Fv >= 0)[0].min()         # F(bps[-1]) >= 0 always
+    if Fv[lo_i] == 0.0 or Fv[hi_i] == 0.0 or hi_i <= lo_i:
+        t = bps[lo_i] if Fv[lo_i] == 0.0 else bps[hi_i]
+    else:
+        t0, t1, f0, f1 = bps[lo_i], bps[hi_i], Fv[lo_i], Fv[hi_i]
+        t = t0 - f0 * (t1 - t0) / (f1 - f0)
+    mu = np.exp(t)
+    x = np.clip(R, mu * gamma * w / p, mu * w / p)
+    y = np.where(x < R, R - x, (R - x) / gamma)
+    return y, float(p @ y)
+
+
+# --------------------------------------------------------------------------------------
+# constant sum                                                       arbitrage.py:73-74
+# --------------------------------------------------------------------------------------
+def arb_sum(R, gamma, p):
+    """LP: tender the cheapest token a = argmin p; withdraw every b with gamma*p_b > p_a
+    completely.  Piecewise linear in p: on the kink gamma*p_b == p_a any fill fraction of
+    that leg is optimal (handled by the caller's primal recovery)."""
+    R = np.asarray(R, float); p = np.asarray(p, float)
+    a = int(np.argmin(p))
+    y = np.zeros_like(R)
+    take = gamma * p > p[a]
+    take[a] = False
+    y[take] = R[take]
+    y[a] = -R[take].sum() / gamma
+    return y, float(p @ y)
+
+
+# --------------------------------------------------------------------------------------
+# Curve-style 2-asset pool: phi(x, y) = x + y - alpha/(x*y)            (not in reference)
+# --------------------------------------------------------------------------------------
+def curve_alpha_from_A(Ra, Rb, A):
+    """alpha such that phi_alpha(x) >= phi_alpha(R) is the on-chain 2-coin StableSwap
+    invariant D(x) >= D(R):  4A(x+y) + D = 4AD + D^3/(4xy)  <=>  x + y - (D^3/16A)/(xy) = D(1-1/4A)."""
+    S = Ra + Rb
+    D = S
+    for _ in range(64):
+        f = 4 * A * S + D - 4 * A * D - D ** 3 / (4 * Ra * Rb)
+        df = 1 - 4 * A - 3 * D ** 2 / (4 * Ra * Rb)
+        Dn = D - f / df
+        if abs(Dn - D) <= 1e-15 * D:
+            D = Dn
+            break
+        D = Dn
+    return D ** 3 / (16 * A)
+
+
+def _curve_y(x, C, alpha):
+    # positive root of  x y^2 + (x^2 - C x) y - alpha = 0
+    b = C - x
+    return 0.5 * (b + np.sqrt(b * b + 4.0 * alpha / x))
+
+
+def arb_curve2(Ra, Rb, gamma, alpha, pa, pb, iters=60):
+    """One pool.  Marginal price of a in units of b at reserves (x,y):
+        m(x,y) = phi_x/phi_y = (1 + alpha/(x^2 y)) / (1 + alpha/(x y^2)).
+    Tender a iff m(R) > pa/(gamma pb); then solve m(x, y(x)) = pa/(gamma pb) for x > Ra
+    (bisection here: the oracle favours certainty over speed)."""
+    C = Ra + Rb - alpha / (Ra * Rb)
+
+    def solve(Rin, Rout, pin, pout):
+        rho = pin / (gamma * pout)
+        m0 = (1 + alpha / (Rin * Rin * Rout)) / (1 + alpha / (Rin * Rout * Rout))
+        if not m0 > rho:
+            return None
+
+        def h(x):
+            y = _curve_y(x, C, alpha)
+            return (1 + alpha / (x * x * y)) / (1 + alpha / (x * y * y)) - rho
+        lo, hi = Rin, Rin * 2.0
+        while h(hi) > 0:
+            hi *= 2.0
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            if h(mid) > 0:
+                lo = mid
+            else:
+                hi = mid
+            if hi - lo <= 1e-16 * hi:
+                break
+        x = 0.5 * (lo + hi)
+        return -(x - Rin) / gamma, Rout - _curve_y(x, C, alpha)
+
+    s = solve(Ra, Rb, pa, pb)
+    if s is not None:
+        ya, yb = s
+    else:
+        s = solve(Rb, Ra, pb, pa)
+        if s is not None:
+            yb, ya = s
+        else:
+            ya = yb = 0.0
+    return np.array([ya, yb]), float(pa * ya + pb * yb)
