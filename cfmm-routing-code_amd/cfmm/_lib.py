@@ -1,0 +1,226 @@
+"""ctypes binding of libcfmm_hip.so (include/cfmm.h).  No CPU fallback: if the HIP extension
+is not built, or no gfx950 device is visible, every entry point raises."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcfmm_hip.so")
+_CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+
+POOL_CP2, POOL_W2, POOL_SUM2, POOL_CURVE2 = 0, 1, 2, 3
+GE, EQ, FREE = 0, 1, 2
+MAX_POOL_SIZE = 8
+STATUS = {1: "optimal", 2: "stalled", 3: "max_evals"}
+
+
+class CfmmError(RuntimeError):
+    pass
+
+
+class Opts(C.Structure):
+    _fields_ = [("tol_gap", C.c_double), ("tol_infeas", C.c_double), ("armijo", C.c_double),
+                ("max_step", C.c_double), ("max_evals", C.c_int32), ("memory", C.c_int32),
+                ("iters_per_graph", C.c_int32), ("pg_rule", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("evals", C.c_int32), ("iters", C.c_int32), ("status", C.c_int32), ("n_ranks", C.c_int32),
+                ("dual_value", C.c_double), ("primal_value", C.c_double), ("gap", C.c_double),
+                ("infeas", C.c_double), ("wall_seconds", C.c_double), ("device_seconds", C.c_double),
+                ("pg", C.c_double), ("pool_subproblems", C.c_int64)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in ("cfmm_hip.hip", "kernels.hpp", "pool_math.hpp")]
+    srcs.append(os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "cfmm.h"))
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-C", _CSRC, "-s"])
+    return _SO
+
+
+_lib = None
+
+SYMBOLS = ["cfmm_create", "cfmm_destroy", "cfmm_last_error", "cfmm_backend", "cfmm_default_opts",
+           "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_set_pool_flags", "cfmm_set_utility",
+           "cfmm_set_ties", "cfmm_eval_dual", "cfmm_solve", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
+           "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_comm_unique_id", "cfmm_comm_init",
+           "cfmm_time_eval_kernel", "cfmm_pool_count", "cfmm_stream"]
+
+
+def lib():
+    """Load libcfmm_hip.so (does not need a GPU; creating a context does)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise CfmmError(f"{_SO} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        f"or `make -C {_CSRC}`; there is no CPU fallback")
+    L = C.CDLL(_SO)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+    L.cfmm_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.cfmm_destroy.argtypes = [vp]
+    L.cfmm_last_error.restype = C.c_char_p; L.cfmm_last_error.argtypes = [vp]
+    L.cfmm_backend.restype = C.c_char_p; L.cfmm_backend.argtypes = [vp]
+    L.cfmm_default_opts.restype = None; L.cfmm_default_opts.argtypes = [C.POINTER(Opts)]
+    L.cfmm_upload_pools2.argtypes = [vp, C.c_int, C.c_int64, dp, dp, dp, dp, ip, ip]
+    L.cfmm_upload_poolsN.argtypes = [vp, C.c_int, C.c_int64, ip, dp, dp, dp]
+    L.cfmm_set_pool_flags.argtypes = [vp, C.c_int, ip]
+    L.cfmm_set_utility.argtypes = [vp, dp, dp, ip]
+    L.cfmm_set_ties.argtypes = [vp, C.c_int, ip, dp]
+    L.cfmm_eval_dual.argtypes = [vp, dp, dp, dp, dp]
+    L.cfmm_solve.argtypes = [vp, dp, C.POINTER(Opts), C.POINTER(Stats)]
+    L.cfmm_get_nu.argtypes = [vp, dp]; L.cfmm_set_nu.argtypes = [vp, dp]; L.cfmm_get_psi.argtypes = [vp, dp]
+    L.cfmm_get_trades2.argtypes = [vp, C.c_int, dp, dp]
+    L.cfmm_get_tradesN.argtypes = [vp, C.c_int, dp, dp]
+    L.cfmm_comm_unique_id.argtypes = [C.c_void_p]
+    L.cfmm_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
+    L.cfmm_time_eval_kernel.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.cfmm_pool_count.restype = C.c_int64; L.cfmm_pool_count.argtypes = [vp]
+    L.cfmm_stream.restype = vp; L.cfmm_stream.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Context:
+    """Thin object wrapper over one cfmm_ctx (one GPU)."""
+
+    def __init__(self, n_tokens, device=0):
+        self.L = lib()
+        self.n = int(n_tokens)
+        h = C.c_void_p()
+        rc = self.L.cfmm_create(int(device), self.n, C.byref(h))
+        if rc != 0:
+            raise CfmmError(f"cfmm_create failed ({rc}): {self.L.cfmm_last_error(None).decode()}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cfmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise CfmmError(f"libcfmm_hip error {rc}: {self.L.cfmm_last_error(self.h).decode()}")
+
+    @property
+    def backend(self):
+        return self.L.cfmm_backend(self.h).decode()
+
+    def upload_pools2(self, kind, Ra, Rb, fee, ia, ib, param=None):
+        Ra, Rb, fee, param, ia, ib = f64(Ra), f64(Rb), f64(fee), f64(param), i32(ia), i32(ib)
+        self._chk(self.L.cfmm_upload_pools2(self.h, kind, len(Ra), _d(Ra), _d(Rb), _d(fee), _d(param), _i(ia), _i(ib)))
+
+    def upload_poolsN(self, idx, R, w, fee):
+        idx, R, w, fee = i32(idx), f64(R), f64(w), f64(fee)
+        k, m = R.shape
+        self._chk(self.L.cfmm_upload_poolsN(self.h, k, m, _i(idx), _d(R), _d(w), _d(fee)))
+
+    def set_pool_flags(self, kind, flags):
+        flags = i32(flags)
+        self._chk(self.L.cfmm_set_pool_flags(self.h, kind, _i(flags)))
+
+    def set_utility(self, c, h=None, ctype=None):
+        c, h, ctype = f64(c), f64(h), i32(ctype)
+        self._chk(self.L.cfmm_set_utility(self.h, _d(c), _d(h), _i(ctype)))
+
+    def set_ties(self, grp=None, off=None):
+        if grp is None:
+            self._chk(self.L.cfmm_set_ties(self.h, 0, None, None))
+        else:
+            grp, off = i32(grp), f64(off)
+            self._chk(self.L.cfmm_set_ties(self.h, int(grp.max()) + 1, _i(grp), _d(off)))
+
+    def eval_dual(self, nu, want_diag=False):
+        nu = f64(nu)
+        psi = np.zeros(self.n)
+        diag = np.zeros(self.n) if want_diag else None
+        arb = C.c_double()
+        self._chk(self.L.cfmm_eval_dual(self.h, _d(nu), C.byref(arb), _d(psi), _d(diag)))
+        return (arb.value, psi, diag) if want_diag else (arb.value, psi)
+
+    def default_opts(self):
+        o = Opts()
+        self.L.cfmm_default_opts(C.byref(o))
+        return o
+
+    def solve(self, nu0=None, **kw):
+        o = self.default_opts()
+        if "tol" in kw:
+            o.tol_gap = o.tol_infeas = kw.pop("tol")
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown solver option {k!r}")
+            setattr(o, k, v)
+        st = Stats()
+        nu0 = f64(nu0)
+        self._chk(self.L.cfmm_solve(self.h, _d(nu0), C.byref(o), C.byref(st)))
+        return st.asdict()
+
+    def get_nu(self):
+        a = np.zeros(self.n); self._chk(self.L.cfmm_get_nu(self.h, _d(a))); return a
+
+    def set_nu(self, nu):
+        nu = f64(nu); self._chk(self.L.cfmm_set_nu(self.h, _d(nu)))
+
+    def get_psi(self):
+        a = np.zeros(self.n); self._chk(self.L.cfmm_get_psi(self.h, _d(a))); return a
+
+    def get_trades2(self, kind, m):
+        d = np.zeros((2, m)); l = np.zeros((2, m))
+        if m:
+            self._chk(self.L.cfmm_get_trades2(self.h, kind, _d(d), _d(l)))
+        return d, l
+
+    def get_tradesN(self, k, m):
+        d = np.zeros((k, m)); l = np.zeros((k, m))
+        if m:
+            self._chk(self.L.cfmm_get_tradesN(self.h, k, _d(d), _d(l)))
+        return d, l
+
+    def comm_init(self, n_ranks, rank, uid):
+        buf = C.create_string_buffer(bytes(uid), 128)
+        self._chk(self.L.cfmm_comm_init(self.h, n_ranks, rank, buf))
+
+    def time_eval_kernel(self, kind, reps=20):
+        s = C.c_double()
+        self._chk(self.L.cfmm_time_eval_kernel(self.h, kind, reps, C.byref(s)))
+        return s.value
+
+    def pool_count(self):
+        return int(self.L.cfmm_pool_count(self.h))
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    rc = lib().cfmm_comm_unique_id(buf)
+    if rc != 0:
+        raise CfmmError(f"cfmm_comm_unique_id failed ({rc}): {lib().cfmm_last_error(None).decode()}")
+    return bytes(buf.raw)

@@ -1,0 +1,502 @@
+"""Host-side mirror of the reference's problem object and of its `cp.Problem(...).solve()` call.
+
+The reference (/root/reference/arbitrage.py, liquidation.py, two-asset.py) has no functions or
+classes: a "problem" is the module-level data `local_indices`, `reserves`, `fees`
+(arbitrage.py:6-28), the constraint lines that pick a trading function per pool
+(arbitrage.py:63-74), and a utility (arbitrage.py:57,77 / liquidation.py:57,77-80 /
+two-asset.py:66,86); the result surface is `prob.value`, `psi.value`, `deltas[i].value`,
+`lambdas[i].value` (arbitrage.py:84, two-asset.py:94-100).  `Problem` keeps exactly that
+vocabulary and hands the work to libcfmm_hip.so (include/cfmm.h).  There is no CPU path here:
+without the HIP extension and a gfx950 device `solve()` raises.
+
+Host logic that stays in Python (tiny, O(n) or O(#constant-sum pools)):
+  * packing pools into per-kind SoA buckets (the dense A_i of arbitrage.py:42-48 become int32 ids);
+  * start prices for utilities that do not name a price for every token;
+  * constant-sum pools on their kink: tying the two prices (a linear equality in log-price),
+    re-solving on the device, and recovering the fill fraction (primal recovery).
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import GE, EQ, FREE, POOL_CP2, POOL_W2, POOL_SUM2, POOL_CURVE2, MAX_POOL_SIZE, CfmmError
+
+KIND2 = dict(cp2=POOL_CP2, w2=POOL_W2, sum2=POOL_SUM2, curve2=POOL_CURVE2)
+
+
+# ------------------------------------------------------------------------------- utilities
+class Utility:
+    """maximise c'psi  s.t.  psi_k + h_k >= 0 (GE) | = 0 (EQ) | unconstrained (FREE)."""
+
+    def __init__(self, c, h=None, ctype=None):
+        self.c = np.asarray(c, dtype=np.float64)
+        n = len(self.c)
+        self.h = np.zeros(n) if h is None else np.asarray(h, dtype=np.float64)
+        self.ctype = np.zeros(n, dtype=np.int32) if ctype is None else np.asarray(ctype, dtype=np.int32)
+
+
+def Arbitrage(market_value):
+    """max market_value @ psi, psi >= 0                      (arbitrage.py:57,77)"""
+    return Utility(market_value)
+
+
+def Liquidate(current_assets, target):
+    """max psi[target], psi[k] + current_assets[k] == 0, k != target   (liquidation.py:57,77-80)"""
+    h = np.asarray(current_assets, dtype=np.float64).copy()
+    n = len(h)
+    c = np.zeros(n); c[target] = 1.0
+    h[target] = 0.0
+    ctype = np.full(n, EQ, dtype=np.int32); ctype[target] = FREE
+    return Utility(c, h, ctype)
+
+
+def Swap(current_assets, target):
+    """max psi[target], psi + current_assets >= 0            (two-asset.py:66,86)"""
+    h = np.asarray(current_assets, dtype=np.float64)
+    c = np.zeros(len(h)); c[target] = 1.0
+    return Utility(c, h)
+
+
+# ------------------------------------------------------------------------------- packing
+def pack(n_tokens, local_indices, reserves, fees, kinds=None, weights=None, params=None):
+    """Ragged pool list (reference vocabulary) -> SoA buckets + `where[i] = (bucket, position)`.
+
+    kinds[i]: "geomean" (default) | "sum" | "curve";  weights[i]: geo-mean exponents (None =
+    equal, i.e. Uniswap v2 for two assets);  params[i]: alpha of a curve pool."""
+    m = len(local_indices)
+    kinds = ["geomean"] * m if kinds is None else list(kinds)
+    weights = [None] * m if weights is None else list(weights)
+    params = [None] * m if params is None else list(params)
+    rows = dict(cp2=[], w2=[], sum2=[], curve2=[])
+    rows_n = {}
+    where = []
+    for i in range(m):
+        l = np.asarray(local_indices[i], dtype=np.int64)
+        R = np.asarray(reserves[i], dtype=np.float64)
+        k = len(l)
+        if len(R) != k:
+            raise ValueError(f"pool {i}: {k} indices but {len(R)} reserves")
+        if len(set(l.tolist())) != k or l.min() < 0 or l.max() >= n_tokens:
+            raise ValueError(f"pool {i}: token ids must be distinct and in [0, {n_tokens})")
+        if not np.all(R > 0) or not (0 < fees[i] <= 1):
+            raise ValueError(f"pool {i}: reserves must be > 0 and the fee in (0, 1]")
+        kind = kinds[i]
+        if kind == "geomean":
+            w = np.ones(k) if weights[i] is None else np.asarray(weights[i], dtype=np.float64)
+            if len(w) != k or not np.all(w > 0):
+                raise ValueError(f"pool {i}: bad weights")
+            w = w / w.sum()
+            if k == 2:
+                if w[0] == w[1]:
+                    where.append(("cp2", len(rows["cp2"])))
+                    rows["cp2"].append((R[0], R[1], fees[i], 0.0, l[0], l[1]))
+                else:
+                    where.append(("w2", len(rows["w2"])))
+                    rows["w2"].append((R[0], R[1], fees[i], w[0], l[0], l[1]))
+            elif 3 <= k <= MAX_POOL_SIZE:
+                b = rows_n.setdefault(k, [])
+                where.append((k, len(b)))
+                b.append((l, R, w, fees[i]))
+            else:
+                raise ValueError(f"pool {i}: geo-mean pools hold 2..{MAX_POOL_SIZE} tokens, got {k}")
+        elif kind == "sum":
+            if k != 2:
+                raise ValueError(f"pool {i}: constant-sum pools are two-asset (as in the reference)")
+            where.append(("sum2", len(rows["sum2"])))
+            rows["sum2"].append((R[0], R[1], fees[i], 0.0, l[0], l[1]))
+        elif kind == "curve":
+            if k != 2 or params[i] is None:
+                raise ValueError(f"pool {i}: curve pools are two-asset and need params[i] = alpha")
+            where.append(("curve2", len(rows["curve2"])))
+            rows["curve2"].append((R[0], R[1], fees[i], float(params[i]), l[0], l[1]))
+        else:
+            raise ValueError(f"pool {i}: unknown kind {kind!r}")
+    net = dict(n_tokens=int(n_tokens))
+    pname = dict(cp2=None, w2="wa", sum2=None, curve2="alpha")
+    for key, rr in rows.items():
+        if not rr:
+            continue
+        a = np.array(rr, dtype=np.float64)
+        b = dict(Ra=a[:, 0].copy(), Rb=a[:, 1].copy(), fee=a[:, 2].copy(),
+                 ia=a[:, 4].astype(np.int32), ib=a[:, 5].astype(np.int32))
+        if pname[key]:
+            b[pname[key]] = a[:, 3].copy()
+        net[key] = b
+    if rows_n:
+        net["gn"] = {}
+        for k, rr in rows_n.items():
+            net["gn"][k] = dict(idx=np.array([r[0] for r in rr], dtype=np.int32).T.copy(),
+                                R=np.array([r[1] for r in rr]).T.copy(),
+                                w=np.array([r[2] for r in rr]).T.copy(),
+                                fee=np.array([r[3] for r in rr], dtype=np.float64))
+    return net, where
+
+
+def network_pool_count(net):
+    m = sum(len(net[k]["Ra"]) for k in KIND2 if k in net)
+    m += sum(b["R"].shape[1] for b in net.get("gn", {}).values())
+    return m
+
+
+def shard_network(net, rank, world):
+    """Pool-sharding: contiguous equal-count slices of every bucket; tokens,
+    prices and the utility stay replicated."""
+    out = {k: v for k, v in net.items() if k not in KIND2 and k != "gn"}
+
+    def sl(m):
+        lo = (m * rank) // world
+        hi = (m * (rank + 1)) // world
+        return slice(lo, hi)
+    for key in KIND2:
+        if key in net:
+            b = net[key]; s = sl(len(b["Ra"]))
+            out[key] = {c: v[s] for c, v in b.items()}
+    if "gn" in net:
+        out["gn"] = {}
+        for k, b in net["gn"].items():
+            s = sl(b["R"].shape[1])
+            out["gn"][k] = dict(idx=b["idx"][:, s], R=b["R"][:, s], w=b["w"][:, s], fee=b["fee"][s])
+    return out
+
+
+# ------------------------------------------------------------------------------- start prices
+def start_prices(net, util):
+    """Prices for every token: c where the utility names one, otherwise propagated through the
+    pools' marginal prices at their current reserves (breadth-first, averaged in log space)."""
+    n = net["n_tokens"]
+    c = util.c
+    known = c > 0
+    if known.all():
+        return c.copy()
+    logp = np.where(known, np.log(np.where(known, c, 1.0)), 0.0)
+    eu, ev, elr = [], [], []          # log p_u - log p_v = lr
+    for key in ("cp2", "w2", "sum2", "curve2"):
+        if key not in net:
+            continue
+        b = net[key]
+        if key == "cp2":
+            lr = np.log(b["Rb"] / b["Ra"])
+        elif key == "w2":
+            lr = np.log(b["wa"] * b["Rb"] / ((1 - b["wa"]) * b["Ra"]))
+        elif key == "sum2":
+            lr = np.zeros(len(b["Ra"]))
+        else:
+            x, y, al = b["Ra"], b["Rb"], b["alpha"]
+            lr = np.log((1 + al / (x * x * y)) / (1 + al / (x * y * y)))
+        eu.append(b["ia"]); ev.append(b["ib"]); elr.append(lr)
+    for k, b in net.get("gn", {}).items():
+        for j in range(1, k):
+            eu.append(b["idx"][j]); ev.append(b["idx"][0])
+            elr.append(np.log(b["w"][j] * b["R"][0] / (b["w"][0] * b["R"][j])))
+    if not eu:
+        return np.where(known, c, 1.0)
+    eu = np.concatenate(eu); ev = np.concatenate(ev); elr = np.concatenate(elr)
+    for _ in range(64):
+        if known.all():
+            break
+        f1 = known[ev] & ~known[eu]
+        f2 = known[eu] & ~known[ev]
+        if not (f1.any() or f2.any()):
+            break
+        tok = np.concatenate([eu[f1], ev[f2]])
+        val = np.concatenate([logp[ev[f1]] + elr[f1], logp[eu[f2]] - elr[f2]])
+        cnt = np.bincount(tok, minlength=n)
+        s = np.bincount(tok, weights=val, minlength=n)
+        new = cnt > 0
+        logp[new] = s[new] / cnt[new]
+        known = known | new
+    return np.exp(logp)
+
+
+# ------------------------------------------------------------------------------- ties (kinks)
+class _Ties:
+    """Weighted union-find over tokens: log nu_j = s[group(j)] + off[j]."""
+
+    def __init__(self, n):
+        self.parent = np.arange(n)
+        self.off = np.zeros(n)           # log nu_j - log nu_root(j)
+
+    def find(self, j):
+        path = []
+        while self.parent[j] != j:
+            path.append(j); j = self.parent[j]
+        root = j
+        # compress, accumulating offsets from the top of the path down
+        for node in reversed(path):
+            p = self.parent[node]
+            if p != root:
+                self.off[node] += self.off[p]
+            self.parent[node] = root
+        return root
+
+    def tie(self, a, b, delta):
+        """impose log nu_a - log nu_b = delta; False if it contradicts existing ties"""
+        ra, rb = self.find(a), self.find(b)
+        if ra == rb:
+            return abs((self.off[a] - self.off[b]) - delta) < 1e-12
+        # attach ra under rb: off[ra] = log nu_ra - log nu_rb
+        self.off[ra] = delta + self.off[b] - self.off[a]
+        self.parent[ra] = rb
+        return True
+
+    def groups(self):
+        n = len(self.parent)
+        roots = np.array([self.find(j) for j in range(n)])
+        uniq, grp = np.unique(roots, return_inverse=True)
+        return grp.astype(np.int32), self.off.copy(), len(uniq)
+
+
+# ------------------------------------------------------------------------------- Problem
+class Problem:
+    """Drop-in for the reference's `prob = cp.Problem(obj, cons); prob.solve()`.
+
+        p = Problem(n_tokens, local_indices, reserves, fees, kinds, weights, utility=Arbitrage(mv))
+        p.solve()            # -> objective value (what arbitrage.py:84 prints)
+        p.value, p.status, p.psi, p.deltas[i], p.lambdas[i], p.nu, p.gap, p.stats
+    """
+
+    def __init__(self, n_tokens, local_indices=None, reserves=None, fees=None, kinds=None, weights=None,
+                 params=None, utility=None, device=0, network=None):
+        self.n = int(n_tokens)
+        if network is not None:
+            self.net, self.where = network, None
+        else:
+            self.net, self.where = pack(self.n, local_indices, reserves, fees, kinds, weights, params)
+        self.m = network_pool_count(self.net)
+        self.utility = utility
+        self.device = device
+        self.ctx = None
+        self._uploaded = False
+        self.value = None; self.status = None; self.psi = None; self.nu = None
+        self.gap = None; self.infeas = None; self.dual_value = None; self.stats = None
+        self._theta = {}
+        self._trade_cache = None
+        self._comm = None
+
+    @classmethod
+    def from_network(cls, net, utility=None, device=0):
+        return cls(net["n_tokens"], utility=utility, device=device, network=net)
+
+    # -- device plumbing ---------------------------------------------------------------------
+    def _ensure_ctx(self):
+        if self.ctx is None:
+            self.ctx = _lib.Context(self.n, self.device)      # raises without HIP lib / gfx950
+        if not self._uploaded:
+            for key, kind in KIND2.items():
+                if key in self.net:
+                    b = self.net[key]
+                    param = b.get("wa") if key == "w2" else (b.get("alpha") if key == "curve2" else None)
+                    self.ctx.upload_pools2(kind, b["Ra"], b["Rb"], b["fee"], b["ia"], b["ib"], param)
+            for k, b in self.net.get("gn", {}).items():
+                self.ctx.upload_poolsN(b["idx"], b["R"], b["w"], b["fee"])
+            self._uploaded = True
+        return self.ctx
+
+    def set_utility(self, utility):
+        self.utility = utility
+
+    def init_comm(self, n_ranks, rank, uid):
+        """pool-sharding: this process holds one shard; see cfmm.distributed"""
+        self._ensure_ctx().comm_init(n_ranks, rank, uid)
+        self._comm = (n_ranks, rank)
+
+    def eval_dual(self, nu, want_diag=False):
+        return self._ensure_ctx().eval_dual(nu, want_diag)
+
+    # -- solve -------------------------------------------------------------------------------
+    def solve(self, tol=1e-6, nu0=None, max_evals=2000, memory=8, iters_per_graph=8, kink_tol=1e-3,
+              max_rounds=6, warm_start=False):
+        if self.utility is None:
+            raise ValueError("no utility set")
+        ctx = self._ensure_ctx()
+        u = self.utility
+        ctx.set_utility(u.c, u.h, u.ctype)
+        ctx.set_ties(None, None)
+        if "sum2" in self.net:
+            ctx.set_pool_flags(POOL_SUM2, None)
+        if nu0 is None:
+            nu0 = self.nu if (warm_start and self.nu is not None) else start_prices(self.net, u)
+        self._theta = {}
+        self._trade_cache = None
+        kw = dict(max_evals=max_evals, memory=memory, iters_per_graph=iters_per_graph)
+        has_sum = "sum2" in self.net
+        # a partially filled constant-sum pool makes the untied dual non-smooth: do not burn the
+        # whole budget before looking for kinks
+        kw1 = dict(kw, max_evals=min(max_evals, 200)) if has_sum else kw
+        st = ctx.solve(nu0, tol=tol, **kw1)
+        total = dict(evals=st["evals"], iters=st["iters"], wall_seconds=st["wall_seconds"],
+                     device_seconds=st["device_seconds"], rounds=1)
+        nu, psi = ctx.get_nu(), ctx.get_psi()
+        if st["status"] != 1 and has_sum:
+            st, nu, psi = self._solve_kinks(ctx, st, nu, psi, tol, kw, kink_tol, max_rounds, total)
+        self._finish(st, nu, psi, total)
+        return self.value
+
+    def _kink_candidates(self, nu, kink_tol, skip):
+        b = self.net["sum2"]
+        r = np.log(nu[b["ia"]]) - np.log(nu[b["ib"]])
+        lg = np.log(b["fee"])
+        out = {}
+        for i in range(len(r)):
+            if i in skip:
+                continue
+            if abs(r[i] - lg[i]) < kink_tol:
+                out[i] = +1          # a->b kink: log nu_a - log nu_b = log gamma
+            elif abs(r[i] + lg[i]) < kink_tol:
+                out[i] = -1          # b->a kink: log nu_a - log nu_b = -log gamma
+        return out
+
+    def _solve_kinks(self, ctx, st, nu, psi, tol, kw, kink_tol, max_rounds, total):
+        """Constant-sum pools whose optimum is a partial fill sit on a kink of the dual; tie their
+        two prices, re-solve the (now smooth) reduced dual on the device, recover the fills."""
+        b = self.net["sum2"]
+        m2 = len(b["Ra"])
+        tied = {}
+        released = set()
+        for _ in range(max_rounds):
+            new = self._kink_candidates(nu, kink_tol, released | set(tied))
+            if not new and not tied:       # no kink in sight: plain continuation with the full budget
+                st = ctx.solve(nu, tol=tol, **kw)
+                total["evals"] += st["evals"]; total["iters"] += st["iters"]; total["rounds"] += 1
+                total["wall_seconds"] += st["wall_seconds"]; total["device_seconds"] += st["device_seconds"]
+                nu, psi = ctx.get_nu(), ctx.get_psi()
+                if st["status"] == 1:
+                    return st, nu, psi
+                new = self._kink_candidates(nu, kink_tol, released)
+                if not new:
+                    return st, nu, psi
+            tied.update(new)
+            ties = _Ties(self.n)
+            flags = np.zeros(m2, dtype=np.int32)
+            for i, sgn in list(tied.items()):
+                if ties.tie(int(b["ia"][i]), int(b["ib"][i]), sgn * np.log(b["fee"][i])):
+                    flags[i] = 1
+                else:
+                    del tied[i]; released.add(i)
+            grp, off, ng = ties.groups()
+            ctx.set_ties(grp, off)
+            ctx.set_pool_flags(POOL_SUM2, flags)
+            st = ctx.solve(nu, tol=0.01 * tol, pg_rule=1, **kw)
+            total["evals"] += st["evals"]; total["iters"] += st["iters"]; total["rounds"] += 1
+            total["wall_seconds"] += st["wall_seconds"]; total["device_seconds"] += st["device_seconds"]
+            nu, psi = ctx.get_nu(), ctx.get_psi()
+            theta, ok = self._recover_fills(nu, psi, tied, tol)
+            bad = [i for i in tied if not (1e-9 < theta[i] < 1 - 1e-9)]
+            if ok and not bad:
+                self._theta = {i: (tied[i], theta[i]) for i in tied}
+                st = dict(st); st["status"] = 1 if st["status"] == 1 else st["status"]
+                return st, nu, psi
+            if not bad:           # residual not matched: widen the search for further kinks
+                kink_tol *= 10
+                continue
+            for i in bad:         # the pool is fully on / fully off after all: let it go bang-bang
+                del tied[i]; released.add(i)
+            if not tied:
+                ctx.set_ties(None, None); ctx.set_pool_flags(POOL_SUM2, None)
+                st = ctx.solve(nu, tol=tol, **kw)
+                total["evals"] += st["evals"]; total["iters"] += st["iters"]; total["rounds"] += 1
+                nu, psi = ctx.get_nu(), ctx.get_psi()
+                if st["status"] == 1:
+                    return st, nu, psi
+        return st, nu, psi
+
+    def _fill_vector(self, i, sgn):
+        b = self.net["sum2"]
+        d = np.zeros(self.n)
+        a, bb, g = int(b["ia"][i]), int(b["ib"][i]), b["fee"][i]
+        if sgn > 0:    # tender a, drain b
+            d[a] = -b["Rb"][i] / g; d[bb] = b["Rb"][i]
+        else:          # tender b, drain a
+            d[bb] = -b["Ra"][i] / g; d[a] = b["Ra"][i]
+        return d
+
+    def _recover_fills(self, nu, psi, tied, tol):
+        """theta in [0,1]^K with  (psi + h + sum_k theta_k d_k)_j = 0 on every token that must balance
+        (EQ tokens, GE tokens priced above their bound) and >= 0 on GE tokens at their bound."""
+        u = self.utility
+        keys = list(tied)
+        D = np.stack([self._fill_vector(i, tied[i]) for i in keys], axis=1)       # n x K
+        r = psi + u.h
+        at_bound = (u.ctype == GE) & (nu <= u.c * (1 + 1e-9))
+        must = (u.ctype == EQ) | ((u.ctype == GE) & ~at_bound)
+        touched = np.abs(D).sum(axis=1) > 0
+        rows = must & touched
+        A = D[rows] * nu[rows, None]
+        rhs = -r[rows] * nu[rows]
+        if A.shape[0] == 0:
+            th = np.full(len(keys), 0.5)
+        else:
+            try:
+                from scipy.optimize import lsq_linear
+                th = lsq_linear(A, rhs, bounds=(0.0, 1.0), tol=1e-14).x
+            except Exception:
+                th = np.clip(np.linalg.lstsq(A, rhs, rcond=None)[0], 0.0, 1.0)
+        tot = r + D @ th
+        scale = max(1.0, float(np.abs(nu * (np.abs(psi) + np.abs(u.h))).sum()))
+        res_eq = np.abs(nu[must] * tot[must]).sum() / scale if must.any() else 0.0
+        ge_b = at_bound
+        res_ge = np.maximum(-(nu[ge_b] * tot[ge_b]), 0.0).sum() / scale if ge_b.any() else 0.0
+        ok = (res_eq <= 10 * tol) and (res_ge <= 10 * tol)
+        return dict(zip(keys, th)), ok
+
+    def _finish(self, st, nu, psi, total):
+        u = self.utility
+        psi = psi.copy()
+        for i, (sgn, th) in self._theta.items():
+            psi += th * self._fill_vector(i, sgn)
+        r = psi + u.h
+        # sum_i arb_i = nu'psi_pools; tied pools trade value-neutrally at their kink prices
+        self.dual_value = float((nu - u.c) @ u.h + nu @ psi)
+        self.value = float(u.c @ psi)
+        self.gap = abs(float((nu - u.c) @ r)) / max(1.0, abs(self.dual_value))
+        viol = np.where(u.ctype == GE, np.maximum(-r, 0.0), np.where(u.ctype == EQ, np.abs(r), 0.0))
+        self.infeas = float(viol.max() / max(np.abs(psi).max(), np.abs(u.h).max(), 1e-300))
+        self.nu, self.psi = nu, psi
+        self.status = _lib.STATUS.get(st["status"], f"error {st['status']}")
+        if self._theta and self.gap <= 10 * max(st.get("tol", 0), 1e-6) and self.infeas <= 1e-5:
+            self.status = "optimal"
+        self.stats = dict(st)
+        self.stats.update(total)
+        self.stats["pool_subproblems"] = total["evals"] * self.m
+        return self
+
+    # -- result read-back (arbitrage.py:84, two-asset.py:94-100) --------------------------------
+    def _trades(self):
+        if self._trade_cache is None:
+            ctx = self._ensure_ctx()
+            tr = {}
+            for key, kind in KIND2.items():
+                if key in self.net:
+                    tr[key] = ctx.get_trades2(kind, len(self.net[key]["Ra"]))
+            for k, b in self.net.get("gn", {}).items():
+                tr[k] = ctx.get_tradesN(k, b["R"].shape[1])
+            if self._theta:
+                d, l = tr["sum2"]
+                for i, (sgn, th) in self._theta.items():
+                    full = self._fill_vector(i, sgn)
+                    a, bb = int(self.net["sum2"]["ia"][i]), int(self.net["sum2"]["ib"][i])
+                    y = th * np.array([full[a], full[bb]])
+                    d[:, i] = np.maximum(-y, 0.0); l[:, i] = np.maximum(y, 0.0)
+            self._trade_cache = tr
+        return self._trade_cache
+
+    def bucket_trades(self, key):
+        """(delta, lambda), slot-major [k][m], of one bucket ('cp2', 'w2', 'sum2', 'curve2' or a pool size)"""
+        return self._trades()[key]
+
+    def _per_pool(self, which):
+        if self.where is None:
+            raise CfmmError("per-pool lists need a Problem built from pool lists; use bucket_trades()")
+        tr = self._trades()
+        return [tr[key][which][:, pos].copy() for key, pos in self.where]
+
+    @property
+    def deltas(self):
+        return self._per_pool(0)
+
+    @property
+    def lambdas(self):
+        return self._per_pool(1)
+
+    def close(self):
+        if self.ctx is not None:
+            self.ctx.close(); self.ctx = None; self._uploaded = False

@@ -1,0 +1,735 @@
+// libcfmm_hip.so -- host side of the C-ABI declared in include/cfmm.h (gfx950 only).
+//
+// Replaces everything below `prob.solve()` (/root/reference/arbitrage.py:82) for this problem
+// class.  One ctx = one GPU = one stream; the outer iteration is captured as a hipGraph
+// (evaluation kernels -> [RCCL all-reduce] -> update kernel, `iters_per_graph` times) and the
+// host only polls a status word, one replay behind, so the device never waits for the host.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cfmm.h"
+#include "kernels.hpp"
+
+using namespace cfmm;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// ---- minimal RCCL surface, resolved at run time so that the library loads (and single-GPU
+// solves run) on a box without RCCL, and so that a process that already holds RCCL (torch)
+// shares that copy --------------------------------------------------------------------------
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load(std::string &err)
+    {
+        if (h) return true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD); if (h) break; }
+        if (!h) for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+        if (!h) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+        AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { err = "librccl lacks nccl symbols"; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0;
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+};
+
+}  // namespace
+
+struct cfmm_ctx {
+    int device = 0, n = 0, ng = 0;
+    int cus = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string backend;
+
+    // pools
+    Bucket2 b2[CFMM_POOL_KINDS2] = {};
+    std::vector<void *> b2mem[CFMM_POOL_KINDS2];
+    BucketN bn[CFMM_MAX_POOL_SIZE + 1] = {};
+    std::vector<void *> bnmem[CFMM_MAX_POOL_SIZE + 1];
+
+    // tokens / state (device)
+    double *c = nullptr, *h = nullptr, *off = nullptr, *glo = nullptr, *ghi = nullptr;
+    int *ctype = nullptr, *grp = nullptr;
+    double *nu = nullptr, *nu_acc = nullptr, *psi_acc = nullptr, *psi_t = nullptr, *nu0 = nullptr;
+    double *s = nullptr, *s_t = nullptr, *Gs = nullptr, *Gs_t = nullptr, *d = nullptr, *Ds = nullptr;
+    double *S = nullptr, *Y = nullptr, *rho = nullptr;
+    double *acc = nullptr;
+    DevState *st = nullptr;
+    DevState *hst = nullptr;          // pinned, 2 slots
+    hipEvent_t ev[2] = {nullptr, nullptr}, ev_t0 = nullptr, ev_t1 = nullptr;
+    int nslices = 16;
+    int eval_grid_mult = 1;
+    bool have_utility = false, have_nu = false;
+    // host copies needed to derive bounds
+    std::vector<double> hc, hh, hoff;
+    std::vector<int> hctype, hgrp;
+
+    // graph cache
+    hipGraphExec_t gexec = nullptr;
+    int g_iters = 0, g_memory = 0;
+    cfmm_opts g_opts = {};
+    bool g_valid = false;
+
+    // RCCL
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1, rank = 0;
+};
+
+namespace {
+
+int fail(cfmm_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail(ctx, CFMM_E_HIP, "%s -> %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <class T>
+int dev_upload(cfmm_ctx *ctx, T **dst, const T *src, size_t count, std::vector<void *> *track)
+{
+    T *p = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&p, count * sizeof(T) + 16));
+    if (src) HIP_TRY(ctx, hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    else HIP_TRY(ctx, hipMemsetAsync(p, 0, count * sizeof(T), ctx->stream));
+    if (track) track->push_back(p);
+    *dst = p;
+    return CFMM_OK;
+}
+
+void free_all(std::vector<void *> &v)
+{
+    for (void *p : v) (void)hipFree(p);
+    v.clear();
+}
+
+size_t eval_lds_bytes(int n, bool with_d) { return (size_t)((with_d ? 3 : 2) * n + 16) * sizeof(double); }
+size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 16 * 8) * sizeof(double); }
+
+int eval_grid(cfmm_ctx *ctx, long long m, int threads)
+{
+    long long need = (m + threads - 1) / threads;
+    long long cap = (long long)ctx->cus * ctx->eval_grid_mult * (EVAL_THREADS / threads);
+    return (int)(need < cap ? (need < 1 ? 1 : need) : cap);
+}
+
+template <int KIND, bool WITH_D>
+void launch_eval2(cfmm_ctx *ctx, const DevState *st)
+{
+    const Bucket2 &b = ctx->b2[KIND];
+    if (b.m == 0) return;
+    hipLaunchKernelGGL((eval2_kernel<KIND, WITH_D>), dim3(eval_grid(ctx, b.m, EVAL_THREADS)), dim3(EVAL_THREADS),
+                       eval_lds_bytes(ctx->n, WITH_D), ctx->stream, b, ctx->nu, ctx->n, ctx->acc, ctx->nslices, st);
+}
+template <int K, bool WITH_D>
+void launch_evaln(cfmm_ctx *ctx, const DevState *st)
+{
+    const BucketN &b = ctx->bn[K];
+    if (b.m == 0) return;
+    hipLaunchKernelGGL((evaln_kernel<K, WITH_D>), dim3(eval_grid(ctx, b.m, EVALN_THREADS)), dim3(EVALN_THREADS),
+                       eval_lds_bytes(ctx->n, WITH_D), ctx->stream, b, ctx->nu, ctx->n, ctx->acc, ctx->nslices, st);
+}
+
+// one dual evaluation of every bucket, heaviest kernels first
+template <bool WITH_D>
+void launch_all_evals(cfmm_ctx *ctx, const DevState *st)
+{
+    launch_evaln<8, WITH_D>(ctx, st); launch_evaln<7, WITH_D>(ctx, st); launch_evaln<6, WITH_D>(ctx, st);
+    launch_evaln<5, WITH_D>(ctx, st); launch_evaln<4, WITH_D>(ctx, st); launch_evaln<3, WITH_D>(ctx, st);
+    launch_eval2<CFMM_POOL_CURVE2, WITH_D>(ctx, st);
+    launch_eval2<CFMM_POOL_W2, WITH_D>(ctx, st);
+    launch_eval2<CFMM_POOL_CP2, WITH_D>(ctx, st);
+    launch_eval2<CFMM_POOL_SUM2, WITH_D>(ctx, st);
+}
+
+template <class F>
+int set_lds_attr(cfmm_ctx *ctx, F f, size_t bytes)
+{
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return CFMM_OK;
+}
+
+int set_all_lds_attrs(cfmm_ctx *ctx)
+{
+    const size_t e0 = eval_lds_bytes(ctx->n, false), e1 = eval_lds_bytes(ctx->n, true);
+    int rc;
+#define SET2(K) if ((rc = set_lds_attr(ctx, eval2_kernel<K, false>, e0))) return rc; if ((rc = set_lds_attr(ctx, eval2_kernel<K, true>, e1))) return rc;
+#define SETN(K) if ((rc = set_lds_attr(ctx, evaln_kernel<K, false>, e0))) return rc; if ((rc = set_lds_attr(ctx, evaln_kernel<K, true>, e1))) return rc;
+    SET2(0) SET2(1) SET2(2) SET2(3)
+    SETN(3) SETN(4) SETN(5) SETN(6) SETN(7) SETN(8)
+#undef SET2
+#undef SETN
+    if ((rc = set_lds_attr(ctx, update_kernel, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, start_kernel, upd_lds_bytes(ctx->n)))) return rc;
+    return CFMM_OK;
+}
+
+UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
+{
+    UpdArgs a;
+    a.n = ctx->n; a.ng = ctx->ng; a.M = o.memory; a.nslices = ctx->n_ranks > 1 ? 1 : ctx->nslices;
+    a.acc = ctx->acc;
+    a.c = ctx->c; a.h = ctx->h; a.off = ctx->off; a.glo = ctx->glo; a.ghi = ctx->ghi;
+    a.ctype = ctx->ctype; a.grp = ctx->grp;
+    a.nu = ctx->nu; a.nu_acc = ctx->nu_acc; a.psi_acc = ctx->psi_acc; a.psi_t = ctx->psi_t;
+    a.s = ctx->s; a.s_t = ctx->s_t; a.Gs = ctx->Gs; a.Gs_t = ctx->Gs_t; a.d = ctx->d; a.Ds = ctx->Ds;
+    a.S = ctx->S; a.Y = ctx->Y; a.rho = ctx->rho;
+    a.st = ctx->st;
+    a.tol_gap = o.tol_gap; a.tol_infeas = o.tol_infeas; a.armijo = o.armijo; a.max_step = o.max_step;
+    a.max_evals = o.max_evals; a.pg_rule = o.pg_rule;
+    return a;
+}
+
+// evaluation -> [fold + all-reduce] -> update : one outer iteration, enqueued on ctx->stream
+template <bool WITH_D>
+int enqueue_iteration(cfmm_ctx *ctx, const UpdArgs &ua)
+{
+    launch_all_evals<WITH_D>(ctx, ctx->st);
+    if (ctx->n_ranks > 1) {
+        const int len = WITH_D ? acc_stride(ctx->n) : ctx->n + 1;
+        hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, ctx->n,
+                           ctx->nslices, WITH_D ? 1 : 0, (const DevState *)nullptr);
+        int rc = g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
+        if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    }
+    hipLaunchKernelGGL(update_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua);
+    return CFMM_OK;
+}
+
+int recompute_bounds(cfmm_ctx *ctx)
+{
+    const int n = ctx->n, ng = ctx->ng;
+    std::vector<double> lo(ng, -INFINITY), hi(ng, INFINITY);
+    for (int j = 0; j < n; ++j) {
+        const int r = ctx->hgrp[j];
+        double l = -INFINITY, u = INFINITY;
+        if (ctx->hctype[j] == CFMM_GE) l = ctx->hc[j] > 0.0 ? std::log(ctx->hc[j]) : -INFINITY;
+        else if (ctx->hctype[j] == CFMM_FREE) {
+            if (!(ctx->hc[j] > 0.0)) return fail(ctx, CFMM_E_ARG, "token %d: CFMM_FREE needs c > 0", j);
+            l = u = std::log(ctx->hc[j]);
+        }
+        l -= ctx->hoff[j]; u -= ctx->hoff[j];
+        if (l > lo[r]) lo[r] = l;
+        if (u < hi[r]) hi[r] = u;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->glo, lo.data(), ng * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ghi, hi.data(), ng * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->g_valid = false;
+    return CFMM_OK;
+}
+
+void drop_graph(cfmm_ctx *ctx)
+{
+    if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
+    ctx->g_valid = false;
+}
+
+int build_graph(cfmm_ctx *ctx, const cfmm_opts &o)
+{
+    drop_graph(ctx);
+    const UpdArgs ua = make_upd_args(ctx, o);
+    hipGraph_t graph = nullptr;
+    HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    int rc = CFMM_OK;
+    for (int it = 0; it < o.iters_per_graph && rc == CFMM_OK; ++it) rc = enqueue_iteration<false>(ctx, ua);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (rc != CFMM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "hipStreamEndCapture -> %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&ctx->gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "hipGraphInstantiate -> %s", hipGetErrorString(e));
+    ctx->g_opts = o; ctx->g_valid = true;
+    return CFMM_OK;
+}
+
+bool same_opts(const cfmm_opts &a, const cfmm_opts &b) { return std::memcmp(&a, &b, sizeof(cfmm_opts)) == 0; }
+
+}  // namespace
+
+// =================================================================================== C-ABI
+
+extern "C" {
+
+void cfmm_default_opts(cfmm_opts *o)
+{
+    std::memset(o, 0, sizeof *o);
+    o->tol_gap = 1e-6; o->tol_infeas = 1e-6; o->armijo = 1e-4; o->max_step = 2.0;
+    o->max_evals = 2000; o->memory = 8; o->iters_per_graph = 8;
+}
+
+const char *cfmm_last_error(cfmm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *cfmm_backend(cfmm_ctx *ctx) { return ctx ? ctx->backend.c_str() : "none"; }
+void *cfmm_stream(cfmm_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
+{
+    if (!out || n_tokens < 1) return fail(nullptr, CFMM_E_ARG, "cfmm_create: bad arguments");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, CFMM_E_HIP, "cfmm_create: no HIP device visible (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(nullptr, CFMM_E_ARG, "cfmm_create: device %d of %d", device, count);
+    cfmm_ctx *ctx = new cfmm_ctx();
+    ctx->device = device; ctx->n = n_tokens; ctx->ng = n_tokens;
+    auto bail = [&](int rc) { g_create_error = ctx->err; cfmm_destroy(ctx); return rc; };
+#define TRY_C(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(ctx, CFMM_E_HIP, "%s -> %s", #call, hipGetErrorString(e_)); return bail(CFMM_E_HIP); } } while (0)
+    TRY_C(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    TRY_C(hipGetDeviceProperties(&prop, device));
+    ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->backend = std::string("hip:") + prop.gcnArchName;
+    if (ctx->backend.find("gfx950") == std::string::npos) {
+        fail(ctx, CFMM_E_HIP, "cfmm_create: device is %s, this build is gfx950-only", prop.gcnArchName);
+        return bail(CFMM_E_HIP);
+    }
+    if (eval_lds_bytes(n_tokens, true) > 160 * 1024) {
+        fail(ctx, CFMM_E_LIMIT, "cfmm_create: %d tokens exceed the LDS-staged limit (%d)", n_tokens, (int)((160 * 1024 / 8 - 16) / 3));
+        return bail(CFMM_E_LIMIT);
+    }
+    TRY_C(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    if (const char *s = getenv("CFMM_SLICES")) ctx->nslices = std::max(1, atoi(s));
+    if (const char *s = getenv("CFMM_EVAL_GRID_MULT")) ctx->eval_grid_mult = std::max(1, atoi(s));
+    const int n = n_tokens;
+    int rc = 0;
+    rc |= dev_upload<double>(ctx, &ctx->c, nullptr, n, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->h, nullptr, n, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->off, nullptr, n, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->glo, nullptr, n, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->ghi, nullptr, n, nullptr);
+    rc |= dev_upload<int>(ctx, &ctx->ctype, nullptr, n, nullptr);
+    rc |= dev_upload<int>(ctx, &ctx->grp, nullptr, n, nullptr);
+    double **vecs[] = {&ctx->nu, &ctx->nu_acc, &ctx->psi_acc, &ctx->psi_t, &ctx->nu0, &ctx->s, &ctx->s_t,
+                       &ctx->Gs, &ctx->Gs_t, &ctx->d, &ctx->Ds};
+    for (auto v : vecs) rc |= dev_upload<double>(ctx, v, nullptr, n, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->S, nullptr, (size_t)MAX_MEMORY * n, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->Y, nullptr, (size_t)MAX_MEMORY * n, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->rho, nullptr, MAX_MEMORY, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->acc, nullptr, (size_t)ctx->nslices * acc_stride(n), nullptr);
+    rc |= dev_upload<DevState>(ctx, &ctx->st, nullptr, 1, nullptr);
+    if (rc) return bail(CFMM_E_HIP);
+    TRY_C(hipHostMalloc((void **)&ctx->hst, 2 * sizeof(DevState), hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) TRY_C(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
+    TRY_C(hipEventCreate(&ctx->ev_t0));
+    TRY_C(hipEventCreate(&ctx->ev_t1));
+    if ((rc = set_all_lds_attrs(ctx))) return bail(rc);
+    // default utility state: identity groups
+    ctx->hc.assign(n, 0.0); ctx->hh.assign(n, 0.0); ctx->hoff.assign(n, 0.0);
+    ctx->hctype.assign(n, CFMM_GE); ctx->hgrp.resize(n);
+    for (int j = 0; j < n; ++j) ctx->hgrp[j] = j;
+    TRY_C(hipMemcpyAsync(ctx->grp, ctx->hgrp.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    TRY_C(hipStreamSynchronize(ctx->stream));
+#undef TRY_C
+    *out = ctx;
+    return CFMM_OK;
+}
+
+int cfmm_destroy(cfmm_ctx *ctx)
+{
+    if (!ctx) return CFMM_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    drop_graph(ctx);
+    if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    for (auto &v : ctx->b2mem) free_all(v);
+    for (auto &v : ctx->bnmem) free_all(v);
+    void *ptrs[] = {ctx->c, ctx->h, ctx->off, ctx->glo, ctx->ghi, ctx->ctype, ctx->grp, ctx->nu, ctx->nu_acc, ctx->psi_acc,
+                    ctx->psi_t, ctx->nu0, ctx->s, ctx->s_t, ctx->Gs, ctx->Gs_t, ctx->d, ctx->Ds, ctx->S, ctx->Y, ctx->rho,
+                    ctx->acc, ctx->st};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (ctx->hst) (void)hipHostFree(ctx->hst);
+    for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
+    if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CFMM_OK;
+}
+
+int64_t cfmm_pool_count(cfmm_ctx *ctx)
+{
+    if (!ctx) return 0;
+    int64_t m = 0;
+    for (auto &b : ctx->b2) m += b.m;
+    for (auto &b : ctx->bn) m += b.m;
+    return m;
+}
+
+int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, const double *Rb, const double *fee,
+                       const double *param, const int32_t *ia, const int32_t *ib)
+{
+    if (!ctx) return CFMM_E_ARG;
+    if (kind < 0 || kind >= CFMM_POOL_KINDS2 || m < 0) return fail(ctx, CFMM_E_ARG, "upload_pools2: kind %d, m %lld", kind, (long long)m);
+    if (m > 0 && (!Ra || !Rb || !fee || !ia || !ib)) return fail(ctx, CFMM_E_ARG, "upload_pools2: NULL column");
+    if (m > 0 && (kind == CFMM_POOL_W2 || kind == CFMM_POOL_CURVE2) && !param) return fail(ctx, CFMM_E_ARG, "upload_pools2: kind %d needs param", kind);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int64_t i = 0; i < m; ++i)
+        if (ia[i] < 0 || ia[i] >= ctx->n || ib[i] < 0 || ib[i] >= ctx->n || ia[i] == ib[i])
+            return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has token ids (%d, %d) outside [0,%d) or equal", (long long)i, ia[i], ib[i], ctx->n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_all(ctx->b2mem[kind]);
+    Bucket2 b = {};
+    b.m = m;
+    if (m > 0) {
+        auto &tr = ctx->b2mem[kind];
+        int rc = 0;
+        rc |= dev_upload<double>(ctx, (double **)&b.Ra, Ra, m, &tr);
+        rc |= dev_upload<double>(ctx, (double **)&b.Rb, Rb, m, &tr);
+        rc |= dev_upload<double>(ctx, (double **)&b.fee, fee, m, &tr);
+        if (param) rc |= dev_upload<double>(ctx, (double **)&b.param, param, m, &tr);
+        rc |= dev_upload<int>(ctx, (int **)&b.ia, ia, m, &tr);
+        rc |= dev_upload<int>(ctx, (int **)&b.ib, ib, m, &tr);
+        if (rc) return CFMM_E_HIP;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->b2[kind] = b;
+    ctx->g_valid = false;
+    return CFMM_OK;
+}
+
+int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, const double *R, const double *w, const double *fee)
+{
+    if (!ctx) return CFMM_E_ARG;
+    if (k < 3 || k > CFMM_MAX_POOL_SIZE || m < 0) return fail(ctx, CFMM_E_LIMIT, "upload_poolsN: pool size %d outside 3..%d", k, CFMM_MAX_POOL_SIZE);
+    if (m > 0 && (!idx || !R || !w || !fee)) return fail(ctx, CFMM_E_ARG, "upload_poolsN: NULL column");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int64_t i = 0; i < (int64_t)k * m; ++i)
+        if (idx[i] < 0 || idx[i] >= ctx->n) return fail(ctx, CFMM_E_ARG, "upload_poolsN: token id %d outside [0,%d)", idx[i], ctx->n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_all(ctx->bnmem[k]);
+    BucketN b = {};
+    b.m = m;
+    if (m > 0) {
+        auto &tr = ctx->bnmem[k];
+        int rc = 0;
+        rc |= dev_upload<int>(ctx, (int **)&b.idx, idx, (size_t)k * m, &tr);
+        rc |= dev_upload<double>(ctx, (double **)&b.R, R, (size_t)k * m, &tr);
+        rc |= dev_upload<double>(ctx, (double **)&b.w, w, (size_t)k * m, &tr);
+        rc |= dev_upload<double>(ctx, (double **)&b.fee, fee, m, &tr);
+        if (rc) return CFMM_E_HIP;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->bn[k] = b;
+    ctx->g_valid = false;
+    return CFMM_OK;
+}
+
+int cfmm_set_pool_flags(cfmm_ctx *ctx, int kind, const int32_t *flags)
+{
+    if (!ctx) return CFMM_E_ARG;
+    if (kind != CFMM_POOL_SUM2) return fail(ctx, CFMM_E_ARG, "set_pool_flags: only CFMM_POOL_SUM2 pools can be tied");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Bucket2 &b = ctx->b2[kind];
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!flags) { b.flags = nullptr; ctx->g_valid = false; return CFMM_OK; }
+    if (b.m == 0) return CFMM_OK;
+    int *p = nullptr;
+    int rc = dev_upload<int>(ctx, &p, flags, b.m, &ctx->b2mem[kind]);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b.flags = p;
+    ctx->g_valid = false;
+    return CFMM_OK;
+}
+
+int cfmm_set_utility(cfmm_ctx *ctx, const double *c, const double *h, const int32_t *ctype)
+{
+    if (!ctx || !c) return ctx ? fail(ctx, CFMM_E_ARG, "set_utility: c is NULL") : CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n = ctx->n;
+    for (int j = 0; j < n; ++j) {
+        if (!(c[j] >= 0.0)) return fail(ctx, CFMM_E_ARG, "set_utility: c[%d] < 0 or NaN", j);
+        if (ctype && (ctype[j] < 0 || ctype[j] > 2)) return fail(ctx, CFMM_E_ARG, "set_utility: ctype[%d] = %d", j, ctype[j]);
+    }
+    ctx->hc.assign(c, c + n);
+    if (h) ctx->hh.assign(h, h + n); else ctx->hh.assign(n, 0.0);
+    if (ctype) ctx->hctype.assign(ctype, ctype + n); else ctx->hctype.assign(n, CFMM_GE);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->c, ctx->hc.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h, ctx->hh.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ctype, ctx->hctype.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ctx->have_utility = true;
+    return recompute_bounds(ctx);
+}
+
+int cfmm_set_ties(cfmm_ctx *ctx, int n_groups, const int32_t *grp, const double *off)
+{
+    if (!ctx) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n = ctx->n;
+    if (!grp) {
+        ctx->ng = n;
+        for (int j = 0; j < n; ++j) { ctx->hgrp[j] = j; ctx->hoff[j] = 0.0; }
+    } else {
+        if (n_groups < 1 || n_groups > n || !off) return fail(ctx, CFMM_E_ARG, "set_ties: n_groups %d", n_groups);
+        for (int j = 0; j < n; ++j) if (grp[j] < 0 || grp[j] >= n_groups) return fail(ctx, CFMM_E_ARG, "set_ties: grp[%d] = %d", j, grp[j]);
+        ctx->ng = n_groups;
+        ctx->hgrp.assign(grp, grp + n); ctx->hoff.assign(off, off + n);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->grp, ctx->hgrp.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->off, ctx->hoff.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return recompute_bounds(ctx);
+}
+
+int cfmm_set_nu(cfmm_ctx *ctx, const double *nu)
+{
+    if (!ctx || !nu) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int j = 0; j < ctx->n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "set_nu: nu[%d] = %g is not a positive finite price", j, nu[j]);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu_acc, nu, ctx->n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_nu = true;
+    return CFMM_OK;
+}
+
+int cfmm_get_nu(cfmm_ctx *ctx, double *nu)
+{
+    if (!ctx || !nu) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(nu, ctx->nu_acc, ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CFMM_OK;
+}
+
+int cfmm_get_psi(cfmm_ctx *ctx, double *psi)
+{
+    if (!ctx || !psi) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(psi, ctx->psi_acc, ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CFMM_OK;
+}
+
+int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi, double *diag)
+{
+    if (!ctx || !nu) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n = ctx->n;
+    for (int j = 0; j < n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "eval_dual: nu[%d] = %g is not a positive finite price", j, nu[j]);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, nu, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
+    if (diag) launch_all_evals<true>(ctx, nullptr); else launch_all_evals<false>(ctx, nullptr);
+    const int len = acc_stride(n);
+    hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, n, ctx->nslices, 1, (const DevState *)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->n_ranks > 1) {
+        int rc = g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
+        if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed (%d)", rc);
+    }
+    std::vector<double> host(len);
+    HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->acc, len * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)len * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (psi) std::memcpy(psi, host.data(), n * sizeof(double));
+    if (arb_sum) *arb_sum = host[n];
+    if (diag) std::memcpy(diag, host.data() + n + 8, n * sizeof(double));
+    return CFMM_OK;
+}
+
+int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_stats *out)
+{
+    if (!ctx || !out) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    cfmm_opts o;
+    if (opts_in) o = *opts_in; else cfmm_default_opts(&o);
+    if (o.memory < 1 || o.memory > MAX_MEMORY || o.iters_per_graph < 1 || o.iters_per_graph > 256 || o.max_evals < 1)
+        return fail(ctx, CFMM_E_ARG, "solve: memory %d, iters_per_graph %d, max_evals %d", o.memory, o.iters_per_graph, o.max_evals);
+    if (!ctx->have_utility) return fail(ctx, CFMM_E_STATE, "solve: cfmm_set_utility has not been called");
+    if (cfmm_pool_count(ctx) == 0) return fail(ctx, CFMM_E_STATE, "solve: no pools uploaded");
+    const int n = ctx->n;
+    if (nu0) { int rc = cfmm_set_nu(ctx, nu0); if (rc) return rc; }
+    if (!ctx->have_nu) return fail(ctx, CFMM_E_STATE, "solve: no start prices (pass nu0 or call cfmm_set_nu)");
+    if (!ctx->g_valid || !same_opts(o, ctx->g_opts)) { int rc = build_graph(ctx, o); if (rc) return rc; }
+    const UpdArgs ua = make_upd_args(ctx, o);
+
+    // ---- timed region: the outer loop (upload and trade read-back excluded) ----------------
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu0, ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(start_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu0);
+    { int rc = enqueue_iteration<true>(ctx, ua); if (rc) return rc; }      // first evaluation also builds the metric
+    HIP_TRY(ctx, hipGetLastError());
+    const int max_chunks = (o.max_evals + o.iters_per_graph - 1) / o.iters_per_graph + 1;
+    int status = 0;
+    for (int cidx = 0; cidx < max_chunks; ++cidx) {
+        HIP_TRY(ctx, hipGraphLaunch(ctx->gexec, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&ctx->hst[cidx & 1], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[cidx & 1], ctx->stream));
+        if (cidx >= 1) {                       // poll one replay behind: the device never idles
+            HIP_TRY(ctx, hipEventSynchronize(ctx->ev[(cidx - 1) & 1]));
+            status = ctx->hst[(cidx - 1) & 1].status;
+            if (status != 0) break;
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&ctx->hst[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+
+    const DevState &st = ctx->hst[0];
+    std::memset(out, 0, sizeof *out);
+    out->evals = st.evals; out->iters = st.iters; out->status = st.status ? st.status : 3;
+    out->n_ranks = ctx->n_ranks;
+    out->dual_value = st.f; out->primal_value = st.primal; out->gap = st.gap; out->infeas = st.infeas;
+    out->wall_seconds = std::chrono::duration<double>(t1 - t0).count();
+    out->device_seconds = ms * 1e-3;
+    out->pg = st.pg;
+    out->pool_subproblems = (int64_t)st.evals * cfmm_pool_count(ctx);
+    if (!std::isfinite(st.f)) { out->status = CFMM_E_NUMERIC; return fail(ctx, CFMM_E_NUMERIC, "solve: dual value is not finite"); }
+    return CFMM_OK;
+}
+
+int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda)
+{
+    if (!ctx || kind < 0 || kind >= CFMM_POOL_KINDS2) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const Bucket2 &b = ctx->b2[kind];
+    if (b.m == 0) return CFMM_OK;
+    double *dd = nullptr, *dl = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&dd, 2 * b.m * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void **)&dl, 2 * b.m * sizeof(double)));
+    const dim3 grid((unsigned)((b.m + 255) / 256)), blk(256);
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(trades2_kernel<0>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;
+    case 1: hipLaunchKernelGGL(trades2_kernel<1>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;
+    case 2: hipLaunchKernelGGL(trades2_kernel<2>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;
+    default: hipLaunchKernelGGL(trades2_kernel<3>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && delta) e = hipMemcpyAsync(delta, dd, 2 * b.m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && lambda) e = hipMemcpyAsync(lambda, dl, 2 * b.m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dd); (void)hipFree(dl);
+    if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "get_trades2 -> %s", hipGetErrorString(e));
+    return CFMM_OK;
+}
+
+int cfmm_get_tradesN(cfmm_ctx *ctx, int k, double *delta, double *lambda)
+{
+    if (!ctx || k < 3 || k > CFMM_MAX_POOL_SIZE) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const BucketN &b = ctx->bn[k];
+    if (b.m == 0) return CFMM_OK;
+    const size_t cnt = (size_t)k * b.m;
+    double *dd = nullptr, *dl = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&dd, cnt * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void **)&dl, cnt * sizeof(double)));
+    const dim3 grid((unsigned)((b.m + 255) / 256)), blk(256);
+    const double *nu = ctx->nu_acc;
+    switch (k) {
+    case 3: hipLaunchKernelGGL(tradesn_kernel<3>, grid, blk, 0, ctx->stream, b, nu, dd, dl); break;
+    case 4: hipLaunchKernelGGL(tradesn_kernel<4>, grid, blk, 0, ctx->stream, b, nu, dd, dl); break;
+    case 5: hipLaunchKernelGGL(tradesn_kernel<5>, grid, blk, 0, ctx->stream, b, nu, dd, dl); break;
+    case 6: hipLaunchKernelGGL(tradesn_kernel<6>, grid, blk, 0, ctx->stream, b, nu, dd, dl); break;
+    case 7: hipLaunchKernelGGL(tradesn_kernel<7>, grid, blk, 0, ctx->stream, b, nu, dd, dl); break;
+    default: hipLaunchKernelGGL(tradesn_kernel<8>, grid, blk, 0, ctx->stream, b, nu, dd, dl); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && delta) e = hipMemcpyAsync(delta, dd, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && lambda) e = hipMemcpyAsync(lambda, dl, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dd); (void)hipFree(dl);
+    if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "get_tradesN -> %s", hipGetErrorString(e));
+    return CFMM_OK;
+}
+
+int cfmm_comm_unique_id(void *uid128)
+{
+    if (!uid128) return CFMM_E_ARG;
+    std::string err;
+    if (!g_rccl.load(err)) return fail(nullptr, CFMM_E_RCCL, "%s", err.c_str());
+    ncclUniqueId id;
+    int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) return fail(nullptr, CFMM_E_RCCL, "ncclGetUniqueId failed (%d)", rc);
+    std::memcpy(uid128, &id, sizeof id);
+    return CFMM_OK;
+}
+
+int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128)
+{
+    if (!ctx || n_ranks < 1 || rank < 0 || rank >= n_ranks || !uid128) return ctx ? fail(ctx, CFMM_E_ARG, "comm_init: bad arguments") : CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    if (!g_rccl.load(err)) return fail(ctx, CFMM_E_RCCL, "%s", err.c_str());
+    ncclUniqueId id;
+    std::memcpy(&id, uid128, sizeof id);
+    int rc = g_rccl.CommInitRank(&ctx->comm, n_ranks, id, rank);
+    if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclCommInitRank -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    ctx->n_ranks = n_ranks; ctx->rank = rank;
+    ctx->g_valid = false;
+    return CFMM_OK;
+}
+
+int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_launch)
+{
+    if (!ctx || reps < 1 || !sec_per_launch) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->have_nu) return fail(ctx, CFMM_E_STATE, "time_eval_kernel: no prices set");
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, ctx->nu_acc, ctx->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    auto launch = [&]() {
+        switch (kind) {
+        case 0: launch_eval2<0, false>(ctx, nullptr); break;
+        case 1: launch_eval2<1, false>(ctx, nullptr); break;
+        case 2: launch_eval2<2, false>(ctx, nullptr); break;
+        case 3: launch_eval2<3, false>(ctx, nullptr); break;
+        case -3: launch_evaln<3, false>(ctx, nullptr); break;
+        case -4: launch_evaln<4, false>(ctx, nullptr); break;
+        case -5: launch_evaln<5, false>(ctx, nullptr); break;
+        case -6: launch_evaln<6, false>(ctx, nullptr); break;
+        case -7: launch_evaln<7, false>(ctx, nullptr); break;
+        case -8: launch_evaln<8, false>(ctx, nullptr); break;
+        default: break;
+        }
+    };
+    for (int i = 0; i < 3; ++i) launch();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+    for (int i = 0; i < reps; ++i) launch();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(ctx->n) * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+    *sec_per_launch = ms * 1e-3 / reps;
+    return CFMM_OK;
+}
+
+}  // extern "C"

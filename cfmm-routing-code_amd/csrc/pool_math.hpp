@@ -1,0 +1,175 @@
+// Per-pool arbitrage subproblems, fp64, device side.  gfx950 only.
+//
+// For local prices p > 0 each pool independently solves
+//     arb_i(p) = max p'(L - D)  s.t.  phi_i(R + gamma D - L) >= phi_i(R),  D, L >= 0
+// i.e. one pool's share of the reference model: variables /root/reference/arbitrage.py:51-52,
+// post-trade reserves :60, trading-function constraint :63-74.  Every function returns
+// y = L - D per leg (negative = tendered, positive = received); arb = p'y.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cfmm {
+
+struct Y2 { double ya, yb; };
+
+// Constant product sqrt(xy)  (Uniswap v2: arbitrage.py:68-70, equal-weight cp.geo_mean).
+// Tender `in`, receive `out` iff gamma * p_out R_out > p_in R_in; the new reserve of the
+// tendered token is x = sqrt(gamma (p_out/p_in) R_in R_out).
+__device__ __forceinline__ Y2 pool_cp2(double Ra, double Rb, double g, double pa, double pb)
+{
+    const double va = pa * Ra, vb = pb * Rb;
+    const bool ab = g * vb > va;
+    const bool ba = g * va > vb;
+    const double pin = ab ? pa : pb, pout = ab ? pb : pa;
+    const double Rin = ab ? Ra : Rb, Rout = ab ? Rb : Ra;
+    const double k = Ra * Rb;
+    const double x = sqrt(g * (pout / pin) * k);
+    const double yin = -(x - Rin) / g;
+    const double yout = Rout - k / x;
+    Y2 r;
+    r.ya = ab ? yin : (ba ? yout : 0.0);
+    r.yb = ab ? yout : (ba ? yin : 0.0);
+    return r;
+}
+
+// Weighted geometric mean x^wa y^(1-wa) (2-asset Balancer: arbitrage.py:65 with two tokens).
+// eta = w_in/w_out;  x = (gamma eta (p_out/p_in) R_out R_in^eta)^(1/(eta+1)).
+__device__ __forceinline__ Y2 pool_w2(double Ra, double Rb, double g, double wa, double pa, double pb)
+{
+    const double wb = 1.0 - wa;
+    const double va = wb * pa * Ra, vb = wa * pb * Rb;
+    const bool ab = g * vb > va;
+    const bool ba = g * va > vb;
+    Y2 r; r.ya = 0.0; r.yb = 0.0;
+    if (ab | ba) {
+        const double pin = ab ? pa : pb, pout = ab ? pb : pa;
+        const double Rin = ab ? Ra : Rb, Rout = ab ? Rb : Ra;
+        const double eta = ab ? wa / wb : wb / wa;
+        const double lRin = log(Rin);
+        const double lx = (log(g * eta * (pout / pin) * Rout) + eta * lRin) / (eta + 1.0);
+        const double x = exp(lx);
+        const double yin = -(x - Rin) / g;
+        const double yout = Rout * (-expm1(eta * (lRin - lx)));      // Rout (1 - (Rin/x)^eta)
+        r.ya = ab ? yin : yout;
+        r.yb = ab ? yout : yin;
+    }
+    return r;
+}
+
+// Constant sum x + y with x, y >= 0 (arbitrage.py:73-74): bang-bang LP.
+__device__ __forceinline__ Y2 pool_sum2(double Ra, double Rb, double g, double pa, double pb)
+{
+    Y2 r; r.ya = 0.0; r.yb = 0.0;
+    if (g * pb > pa)      { r.ya = -Rb / g; r.yb = Rb; }
+    else if (g * pa > pb) { r.yb = -Ra / g; r.ya = Ra; }
+    return r;
+}
+
+// Curve-style x + y - alpha/(xy) (not in the reference; BASELINE config 5).  y(x) on the level
+// set is the positive root of x y^2 + (x^2 - C x) y - alpha = 0; the optimum equates the
+// marginal price m = phi_x/phi_y with p_in/(gamma p_out): safeguarded Newton in x.
+__device__ __forceinline__ double curve_y(double x, double C, double al)
+{
+    const double b = C - x;
+    return 0.5 * (b + sqrt(b * b + 4.0 * al / x));
+}
+
+__device__ __forceinline__ bool curve_dir(double Rin, double Rout, double g, double al, double C,
+                                          double pin, double pout, double &yin, double &yout)
+{
+    const double rho = pin / (g * pout);
+    const double m0 = (1.0 + al / (Rin * Rin * Rout)) / (1.0 + al / (Rin * Rout * Rout));
+    if (!(m0 > rho)) return false;
+    double lo = Rin, hi = Rin * 2.0;
+    for (int it = 0; it < 200; ++it) {
+        const double yy = curve_y(hi, C, al);
+        const double hh = (1.0 + al / (hi * hi * yy)) / (1.0 + al / (hi * yy * yy)) - rho;
+        if (hh <= 0.0) break;
+        lo = hi; hi *= 2.0;
+    }
+    double x = lo;
+    for (int it = 0; it < 100; ++it) {
+        const double yy = curve_y(x, C, al);
+        const double fx = 1.0 + al / (x * x * yy), fy = 1.0 + al / (x * yy * yy);
+        const double hx = fx / fy - rho;
+        if (hx > 0.0) lo = x; else hi = x;
+        const double yp = -fx / fy;
+        const double dfx = -2.0 * al / (x * x * x * yy) - al / (x * x * yy * yy) * yp;
+        const double dfy = -al / (x * x * yy * yy) - 2.0 * al / (x * yy * yy * yy) * yp;
+        const double dh = (dfx * fy - fx * dfy) / (fy * fy);
+        double xn = x - hx / dh;
+        if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+        const bool done = fabs(xn - x) <= 4e-16 * x;
+        x = xn;
+        if (done) break;
+    }
+    yin = -(x - Rin) / g;
+    yout = Rout - curve_y(x, C, al);
+    return true;
+}
+
+__device__ __forceinline__ Y2 pool_curve2(double Ra, double Rb, double g, double al, double pa, double pb)
+{
+    const double C = Ra + Rb - al / (Ra * Rb);
+    Y2 r; r.ya = 0.0; r.yb = 0.0;
+    if (curve_dir(Ra, Rb, g, al, C, pa, pb, r.ya, r.yb)) return r;
+    curve_dir(Rb, Ra, g, al, C, pb, pa, r.yb, r.ya);
+    return r;
+}
+
+// d y_k / d log p_k at the no-trade point: the pool's share of the static diagonal metric
+__device__ __forceinline__ void curve_diag(double Ra, double Rb, double al, double pa, double pb,
+                                           double &da, double &db)
+{
+    const double x = Ra, yy = Rb;
+    const double fx = 1.0 + al / (x * x * yy), fy = 1.0 + al / (x * yy * yy);
+    const double yp = -fx / fy;
+    const double dfx = -2.0 * al / (x * x * x * yy) - al / (x * x * yy * yy) * yp;
+    const double dfy = -al / (x * x * yy * yy) - 2.0 * al / (x * yy * yy * yy) * yp;
+    const double dm = (dfx * fy - fx * dfy) / (fy * fy);
+    const double dxdl = (fx / fy) / fabs(dm);
+    da = pa * dxdl;
+    db = pb * dxdl * (fx / fy);
+}
+
+// K-asset weighted geometric mean (Balancer: arbitrage.py:65, liquidation.py:65, two-asset.py:74).
+// KKT: x_j(mu) = clip(R_j, mu gamma w_j/p_j, mu w_j/p_j) with sum_j w_j log x_j = sum_j w_j log R_j.
+// In t = log mu, a_j = log(R_j p_j / w_j), lg = log gamma the residual
+//     F(t) = sum_j w_j f(t - a_j),   f(u) = u (u<0) | 0 (0<=u<=-lg) | u + lg (u>-lg)
+// is piecewise linear and non-decreasing: evaluate it at its 2K breakpoints, keep the bracketing
+// pair, interpolate.  O(K^2) flops, K logs, 1 exp, no sort, no data-dependent loop.
+template <int K>
+__device__ __forceinline__ void pool_geomean_n(const double (&R)[K], const double (&w)[K], double g,
+                                               const double (&p)[K], double (&y)[K])
+{
+    double a[K];
+    const double lg = log(g);
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = log(R[j] * p[j] / w[j]);
+    double tL = -1.7976931348623157e308, fL = 0.0, tR = 1.7976931348623157e308, fR = 0.0;
+#pragma unroll
+    for (int b = 0; b < 2 * K; ++b) {
+        const double t = (b < K) ? a[b % K] : a[b % K] - lg;
+        double f = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const double u = t - a[j];
+            f += w[j] * (u < 0.0 ? u : (u > -lg ? u + lg : 0.0));
+        }
+        if (f <= 0.0 && t > tL) { tL = t; fL = f; }
+        if (f >= 0.0 && t < tR) { tR = t; fR = f; }
+    }
+    double t;
+    if (fL == 0.0) t = tL;
+    else if (fR == 0.0) t = tR;
+    else t = tL - fL * (tR - tL) / (fR - fL);
+    const double mu = exp(t);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const double hi = mu * w[j] / p[j], lo = g * hi;
+        const double x = R[j] < lo ? lo : (R[j] > hi ? hi : R[j]);
+        y[j] = (x < R[j]) ? (R[j] - x) : (R[j] - x) / g;
+    }
+}
+
+}  // namespace cfmm

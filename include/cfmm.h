@@ -1,0 +1,138 @@
+/* cfmm.h -- C-ABI of libcfmm_hip.so: the MI355X-native replacement for the cvxpy call pair
+ *
+ *        prob = cp.Problem(obj, cons); prob.solve()
+ *
+ * at /root/reference/arbitrage.py:81-82, liquidation.py:84-85 and two-asset.py:90-91, plus the
+ * result read-back at arbitrage.py:84, liquidation.py:87, two-asset.py:94-100.
+ *
+ * The reference has no FFI / plugin interface of its own (it is four Python scripts that call
+ * cvxpy); this header is the boundary a maintainer binds with ctypes (INTEGRATION.md shows the
+ * stub).  Conventions: every entry point returns 0 on success or a negative CFMM_E* code;
+ * cfmm_last_error() gives the message; no exceptions, no callbacks; the caller owns every host
+ * buffer (the library copies to HBM at upload and back at get); one ctx = one GPU = one host
+ * thread at a time.  All floating point is fp64 (NumPy's default in arbitrage.py:14-20), all
+ * indices int32.
+ *
+ * Model (the reference's, arbitrage.py:51-78):
+ *      maximise   U(psi)
+ *      subject to psi = sum_i A_i (Lambda_i - Delta_i)                      arbitrage.py:54
+ *                 phi_i(R_i + gamma_i Delta_i - Lambda_i) >= phi_i(R_i)      arbitrage.py:60,63-74
+ *                 Delta_i, Lambda_i >= 0                                     arbitrage.py:51-52
+ * solved in its dual-decomposition form: for prices nu every pool is an independent
+ * closed-form / Newton subproblem (the HIP kernels), psi(nu) is their scatter-sum, and nu is
+ * driven by an on-device projected quasi-Newton iteration in log-prices.
+ */
+#ifndef CFMM_H
+#define CFMM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cfmm_ctx cfmm_ctx;
+
+enum {
+    CFMM_OK = 0,
+    CFMM_E_ARG = -1,        /* bad argument                                   */
+    CFMM_E_HIP = -2,        /* a HIP runtime call failed                      */
+    CFMM_E_STATE = -3,      /* call order (e.g. solve before upload)          */
+    CFMM_E_LIMIT = -4,      /* size beyond what this build supports           */
+    CFMM_E_RCCL = -5,       /* an RCCL call failed                            */
+    CFMM_E_NUMERIC = -6     /* non-finite value met during the iteration      */
+};
+
+/* two-asset pool families: one SoA bucket each (`param` = per-pool 4th column) */
+enum {
+    CFMM_POOL_CP2 = 0,      /* constant product sqrt(xy)          arbitrage.py:68-70; param = NULL  */
+    CFMM_POOL_W2 = 1,       /* weighted geo-mean x^wa y^(1-wa)    arbitrage.py:65 (2 assets); param = wa */
+    CFMM_POOL_SUM2 = 2,     /* constant sum x+y, x,y >= 0         arbitrage.py:73-74; param = NULL  */
+    CFMM_POOL_CURVE2 = 3,   /* x + y - alpha/(xy) (StableSwap at fixed D)  not in reference; param = alpha */
+    CFMM_POOL_KINDS2 = 4
+};
+#define CFMM_MAX_POOL_SIZE 8    /* n-asset geo-mean pools: 3..8 assets, one bucket per size */
+
+/* token constraint types of the unified utility  max c'psi :  psi_k + h_k (>=, =, free) 0 */
+enum { CFMM_GE = 0, CFMM_EQ = 1, CFMM_FREE = 2 };
+
+typedef struct {
+    double tol_gap;         /* stop when |(nu-c)'(psi+h)| / max(1,|g|)      <= tol_gap     (1e-6) */
+    double tol_infeas;      /*      and  max violation / max(|psi|,|h|)     <= tol_infeas  (1e-6) */
+    double armijo;          /* sufficient-decrease constant (1e-4)                                 */
+    double max_step;        /* cap on one step in log-price (2.0)                                  */
+    int32_t max_evals;      /* cap on dual evaluations (2000)                                      */
+    int32_t memory;         /* L-BFGS pairs kept, 1..16 (8)                                        */
+    int32_t iters_per_graph;/* outer iterations captured per hipGraph replay (8)                   */
+    int32_t pg_rule;        /* 1: stop on the projected-gradient value <= tol_gap instead (used when
+                               constant-sum pools are tied: psi then lacks their fill)           */
+} cfmm_opts;
+
+typedef struct {
+    int32_t evals;          /* dual evaluations done = passes of every pool through its kernel     */
+    int32_t iters;          /* accepted quasi-Newton steps                                         */
+    int32_t status;         /* 1 converged, 2 stalled (line search), 3 max_evals, <0 error         */
+    int32_t n_ranks;
+    double dual_value;      /* g(nu)            upper bound                                        */
+    double primal_value;    /* c'psi(nu)        the reference's prob.value (arbitrage.py:84)       */
+    double gap, infeas;     /* the two certificates above                                          */
+    double wall_seconds;    /* host clock around the outer loop (upload / read-back excluded)      */
+    double device_seconds;  /* HIP events around the same region                                   */
+    double pg;              /* sum |projected reduced gradient| / max(1,|g|)                       */
+    int64_t pool_subproblems;   /* evals * pools on this rank                                      */
+} cfmm_stats;
+
+/* lifetime ------------------------------------------------------------------------------ */
+int cfmm_create(int device, int n_tokens, cfmm_ctx **out);
+int cfmm_destroy(cfmm_ctx *ctx);
+const char *cfmm_last_error(cfmm_ctx *ctx);       /* ctx may be NULL: last error of cfmm_create */
+const char *cfmm_backend(cfmm_ctx *ctx);          /* "hip:gfx950"                               */
+void cfmm_default_opts(cfmm_opts *o);
+
+/* problem object: replaces local_indices / reserves / fees (arbitrage.py:6-28) and the dense
+ * A_i matrices (arbitrage.py:42-48: never materialised -- `ia/ib/idx` ARE A_i) ------------- */
+int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, const double *Rb,
+                       const double *fee, const double *param, const int32_t *ia, const int32_t *ib);
+/* k-asset weighted geo-mean pools (arbitrage.py:65), slot-major: x[j*m + i] = slot j of pool i;
+ * weights normalised to sum 1 per pool */
+int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, const double *R,
+                       const double *w, const double *fee);
+/* constant-sum pools sitting on their kink are `tied` (flag 1): they are skipped by the
+ * kernels and their fill fraction is assigned by the host's primal recovery */
+int cfmm_set_pool_flags(cfmm_ctx *ctx, int kind, const int32_t *flags /* [m] or NULL */);
+
+/* utility: replaces obj + the psi constraints (arbitrage.py:57,77; liquidation.py:57,77-80;
+ * two-asset.py:66,86).  ctype NULL = all CFMM_GE, h NULL = 0. */
+int cfmm_set_utility(cfmm_ctx *ctx, const double *c, const double *h, const int32_t *ctype);
+/* price ties: log nu_j = s[grp[j]] + off[j]; NULL, NULL = none */
+int cfmm_set_ties(cfmm_ctx *ctx, int n_groups, const int32_t *grp, const double *off);
+
+/* one dual evaluation = every pool's subproblem once + the reduction:  psi(nu), sum_i arb_i,
+ * optionally the diagonal metric.  This is the unit BASELINE.json's metric counts. */
+int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi, double *diag /* or NULL */);
+
+/* prob.solve(): nu0 = start prices (NULL: use cfmm_set_nu / previous solution) */
+int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts, cfmm_stats *out);
+
+/* read-back (arbitrage.py:84 prob.value is stats.primal_value; psi.value; deltas/lambdas.value) */
+int cfmm_get_nu(cfmm_ctx *ctx, double *nu);
+int cfmm_set_nu(cfmm_ctx *ctx, const double *nu);
+int cfmm_get_psi(cfmm_ctx *ctx, double *psi);
+/* tenders at the accepted prices; slot-major [2][m] / [k][m]; either pointer may be NULL */
+int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda);
+int cfmm_get_tradesN(cfmm_ctx *ctx, int k, double *delta, double *lambda);
+
+/* pool-sharding over the GPUs of a node: one process per GPU, one RCCL all-reduce of
+ * [psi | sum arb] per dual evaluation.  `uid` is the 128-byte ncclUniqueId made by rank 0. */
+int cfmm_comm_unique_id(void *uid128);
+int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128);
+
+/* measurement hooks (bench.py): time `reps` back-to-back launches of the dominant kernel of
+ * bucket `kind` (or -k for the k-asset bucket) with HIP events on the library's stream;
+ * returns the average seconds per launch in *sec_per_launch. */
+int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_launch);
+int64_t cfmm_pool_count(cfmm_ctx *ctx);
+void *cfmm_stream(cfmm_ctx *ctx);                 /* the hipStream_t the library launches on */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

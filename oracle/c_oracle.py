@@ -22,13 +22,14 @@ def build(force=False):
 
 class Opts(C.Structure):
     _fields_ = [("tol_gap", C.c_double), ("tol_infeas", C.c_double), ("armijo", C.c_double),
-                ("max_step", C.c_double), ("max_evals", C.c_int), ("memory", C.c_int)]
+                ("max_step", C.c_double), ("max_evals", C.c_int), ("memory", C.c_int),
+                ("pg_rule", C.c_int), ("pad", C.c_int)]
 
 
 class Stats(C.Structure):
     _fields_ = [("evals", C.c_int), ("iters", C.c_int), ("status", C.c_int),
                 ("dual_value", C.c_double), ("primal_value", C.c_double), ("gap", C.c_double),
-                ("infeas", C.c_double), ("seconds", C.c_double)]
+                ("infeas", C.c_double), ("seconds", C.c_double), ("pg", C.c_double)]
 
 
 _lib = None
@@ -147,12 +148,12 @@ class Oracle:
         self.L.oracle_tradesN(self.h, b, _d(nu), _d(y))
         return y
 
-    def solve(self, nu0, tol=1e-6, max_evals=2000, memory=8, armijo=1e-4, max_step=2.0):
+    def solve(self, nu0, tol=1e-6, max_evals=2000, memory=8, armijo=1e-4, max_step=2.0, pg_rule=0):
         nu0 = np.ascontiguousarray(nu0, dtype=np.float64)
-        o = Opts(tol, tol, armijo, max_step, max_evals, memory)
+        o = Opts(tol, tol, armijo, max_step, max_evals, memory, pg_rule, 0)
         st = Stats()
         nu = np.zeros(self.n); psi = np.zeros(self.n)
         self.L.oracle_solve(self.h, _d(nu0), C.byref(o), C.byref(st), _d(nu), _d(psi))
         return dict(nu=nu, psi=psi, evals=st.evals, iters=st.iters, status=st.status,
                     dual_value=st.dual_value, primal_value=st.primal_value, gap=st.gap,
-                    infeas=st.infeas, seconds=st.seconds)
+                    infeas=st.infeas, seconds=st.seconds, pg=st.pg)

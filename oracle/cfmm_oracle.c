@@ -208,7 +208,7 @@ typedef struct {
     double *s, *s_t, *Gs, *Gs_t, *d, *Ds, *nu, *psi, *diag, *q, *r, *alpha;
     double f, t_step, f_t;
     int iter, evals, status, first;
-    double gap, infeas;
+    double gap, infeas, pg;
     int nthreads;
 } oracle_t;
 
@@ -372,13 +372,13 @@ void oracle_tradesN(oracle_t *o, int b, const double *nu, double *y /* [k][m] */
 
 typedef struct {
     double tol_gap, tol_infeas, armijo, max_step;
-    int max_evals, memory;
+    int max_evals, memory, pg_rule, pad;
 } oracle_opts_t;
 
 typedef struct {
     int evals, iters, status;      /* status: 0 running, 1 converged, 2 stalled, 3 max evals */
     double dual_value, primal_value, gap, infeas;
-    double seconds;
+    double seconds, pg;
 } oracle_stats_t;
 
 static double dotn(int n, const double *a, const double *b) { double s = 0; for (int i = 0; i < n; ++i) s += a[i] * b[i]; return s; }
@@ -467,7 +467,18 @@ int oracle_step(oracle_t *o, double f_pools, const double *psi, const double *di
         o->f = f_t; o->first = 0;
         o->gap = fabs(gapv) / fmax(1.0, fabs(f_t));
         o->infeas = viol / fmax(scale, 1e-300);
-        if (o->gap <= opt->tol_gap && o->infeas <= opt->tol_infeas) { o->status = 1; return o->status; }
+        {   /* value of the projected reduced gradient: sum_r |P(Gs)_r| / max(1,|f|) (>= gap) */
+            double pg = 0.0;
+            for (int r = 0; r < ng; ++r) {
+                double G = o->Gs[r], v = G;
+                if (o->glo[r] == o->ghi[r]) v = 0.0;
+                else if (o->s[r] <= o->glo[r] + 1e-14) v = fmin(G, 0.0);
+                else if (o->s[r] >= o->ghi[r] - 1e-14) v = fmax(G, 0.0);
+                pg += fabs(v);
+            }
+            o->pg = pg / fmax(1.0, fabs(f_t));
+        }
+        if (opt->pg_rule ? (o->pg <= opt->tol_gap) : (o->gap <= opt->tol_gap && o->infeas <= opt->tol_infeas)) { o->status = 1; return o->status; }
         /* new direction */
         double *q = o->q, *rr = o->r;
         for (int r = 0; r < ng; ++r) {
@@ -539,7 +550,7 @@ int oracle_solve(oracle_t *o, const double *nu0, const oracle_opts_t *opt, oracl
     }
     st->seconds = now_s() - t0;
     st->evals = o->evals; st->iters = o->iter; st->status = o->status;
-    st->dual_value = o->f; st->gap = o->gap; st->infeas = o->infeas;
+    st->dual_value = o->f; st->gap = o->gap; st->infeas = o->infeas; st->pg = o->pg;
     double pv = 0.0;
     for (int j = 0; j < n; ++j) { nu_out[j] = exp(o->s[o->grp[j]] + o->off[j]); psi_out[j] = o->psi[j]; pv += o->c[j] * o->psi[j]; }
     st->primal_value = pv;

@@ -1,0 +1,61 @@
+"""TEST INFRASTRUCTURE -- regenerates tests/golden/shipped_instances.json.
+
+    python -B oracle/make_golden.py
+
+Two independent sources per instance, both stored:
+  * "primal": the reference's primal model (arbitrage.py:51-78 etc.) solved by SciPy SLSQP
+              (oracle/primal_scipy.py) -- the objective is good to ~1e-9, trades to ~1e-6;
+  * "survey": the known answers of SURVEY.md Appendix B (derived in the survey session by SLSQP
+              and by closed-form dual decomposition + L-BFGS-B, agreeing to >= 9 digits).
+Neither is cvxpy output: cvxpy and every conic solver are absent from this container, so the
+reference itself cannot be run here (PARITY UNPINNED by the reference; it holds no expected values).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import instances as I          # noqa: E402
+from oracle.primal_scipy import solve_primal   # noqa: E402
+
+SURVEY = {
+    "arbitrage": dict(value=21.4998087639, psi=[0, 1.174978045, 0, 3.2500094379],
+                      nu=[3.01634, 10, 3.003003, 3],
+                      y=[[-4.2335229132, 2.1355390109, -0.1310881388, 1.9283766914], [4.2335229132, -0.7363701675],
+                         [-0.2241907984, 0.9134241780], [-4.6458358656, 5.1889999400], [3.8634998263, -3.8673671935]]),
+    "liquidation": dict(value=15.8830108411, psi=[-2, -1, -3, -5, 15.8830108411],
+                        nu=[0.2026491, 0.4646974, 0.3308995, 0.999, 1],
+                        y=[[-7.2041541969, 0.0884031414, -0.1119111126, 3.0902355673, 3.5455728673],
+                           [5.2041541969, -1.0884031414], [-2.8880888874, 3.7111490778],
+                           [-4.6906436729, 5.2338077425], [-7.1107409722, 7.1036302313]]),
+    "two_asset_0": dict(value=6.2330001314, nu=[1.0899570, 10.6037357, 1]),
+    "two_asset_1": dict(value=7.3149009798, nu=[1.0294433, 10.2551254, 1]),
+    "two_asset_10": dict(value=16.5943392089, nu=[1.0101010, 10.0210811, 1]),
+    "two_asset_25": dict(value=31.4283406169, nu=[0.8189059, 8.9142302, 1]),
+    "two_asset_49": dict(value=44.1820204014, nu=[0.3310097, 5.9262250, 1]),
+}
+
+
+def main():
+    out = {}
+    cases = [("arbitrage", I.arbitrage()), ("liquidation", I.liquidation())]
+    sweep = I.two_asset_sweep()
+    for j in (0, 1, 10, 25, 49):
+        cases.append((f"two_asset_{j}", I.two_asset(sweep[j])))
+    for name, inst in cases:
+        r = solve_primal(I.normalise(inst))
+        out[name] = dict(
+            primal=dict(value=r["value"], psi=r["psi"].tolist(), y=[v.tolist() for v in r["y"]]),
+            survey=SURVEY[name],
+            t=inst["utility"].get("h", [0])[0] if inst["name"] == "two_asset" else None)
+        print(name, r["value"], SURVEY[name]["value"])
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "shipped_instances.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
