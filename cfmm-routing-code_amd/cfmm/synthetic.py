@@ -31,7 +31,7 @@ def _pairs(rng, n, m, zipf_s=None):
 
 
 def make_network(n_tokens, m_cp2=0, m_w2=0, m_gn=0, m_curve2=0, seed=0, zipf_s=None,
-                 gn_sizes=(3, 8), mispricing=0.02):
+                 gn_sizes=(3, 8), mispricing=0.02, pool_seed=None):
     """Returns a dict of SoA buckets:
 
       prices   : latent pi[n]
@@ -49,6 +49,8 @@ def make_network(n_tokens, m_cp2=0, m_w2=0, m_gn=0, m_curve2=0, seed=0, zipf_s=N
         pi = pi[(np.arange(n) // 4) * 4] * np.exp(rng.normal(0.0, 0.002, n))
     c = pi * np.exp(rng.normal(0.0, 0.01, n))
     out = dict(n_tokens=n, prices=pi, c=c, seed=seed)
+    if pool_seed is not None:      # same tokens / prices / market values, a different draw of pools
+        rng = np.random.default_rng([seed, 7919, int(pool_seed)])   # (one shard of a sharded network)
 
     def value(m):
         return np.exp(rng.normal(np.log(1e3), 1.5, m))
@@ -122,9 +124,11 @@ def curve_alpha_from_A(Ra, Rb, A, iters=64):
     return D ** 3 / (16 * A)
 
 
-def config(name, seed=0, scale=1.0):
+def config(name, seed=0, scale=1.0, pool_seed=None):
     """BASELINE.json configs 2-5 (config 1 is the shipped script)."""
     s = lambda m: max(1, int(round(m * scale)))
+    import functools
+    make_network = functools.partial(globals()["make_network"], pool_seed=pool_seed)
     if name == "C2":      # 1e4 constant-product pools, 100 tokens
         return make_network(100, m_cp2=s(10_000), seed=seed)
     if name == "C3":      # 1e6 mixed Uniswap-v2 + Balancer pools, 1000 tokens

@@ -1,0 +1,84 @@
+import json
+import os
+
+import numpy as np
+
+import cfmm
+from oracle import instances as I
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shipped_instances.json")
+
+
+def golden():
+    with open(GOLDEN) as f:
+        return json.load(f)
+
+
+def utility_of(inst):
+    u = inst["utility"]
+    if u["type"] == "arbitrage":
+        return cfmm.Arbitrage(u["c"])
+    if u["type"] == "liquidate":
+        return cfmm.Liquidate(u["h"], u["t"])
+    return cfmm.Swap(u["h"], u["t"])
+
+
+def problem_of(inst, ctx=None):
+    p = cfmm.Problem(inst["n_tokens"], inst["local_indices"], inst["reserves"], inst["fees"], inst["kinds"],
+                     inst["weights"], params=inst.get("params"), utility=utility_of(inst))
+    if ctx is not None:
+        p.ctx = ctx
+    return p
+
+
+def shipped_cases():
+    sweep = I.two_asset_sweep()
+    cases = [("arbitrage", I.arbitrage()), ("liquidation", I.liquidation())]
+    for j in (0, 1, 10, 25, 49):
+        cases.append((f"two_asset_{j}", I.two_asset(sweep[j])))
+    return cases
+
+
+def random_instance(seed, n_tokens=6, n_pools=12, with_sum=True, with_curve=False, utility="arbitrage"):
+    """small random instance in the reference's vocabulary, connected enough to be interesting"""
+    rng = np.random.default_rng(seed)
+    price = np.exp(rng.normal(0, 0.5, n_tokens))
+    L, R, F, K, W, P = [], [], [], [], [], []
+    for i in range(n_pools):
+        r = rng.random()
+        if r < 0.2 and n_tokens >= 3:
+            k = int(rng.integers(3, min(5, n_tokens) + 1))
+            kind = "geomean"
+        else:
+            k = 2
+            kind = "sum" if (with_sum and r > 0.9) else ("curve" if (with_curve and r > 0.75) else "geomean")
+        l = rng.choice(n_tokens, size=k, replace=False)
+        val = np.exp(rng.normal(3, 1))
+        if kind == "geomean":
+            w = rng.integers(1, 5, size=k).astype(float)
+            if k == 2 and rng.random() < 0.6:
+                w = np.ones(2)
+            res = val * (w / w.sum()) / price[l] * np.exp(rng.normal(0, 0.1, k))
+            W.append(w); P.append(None)
+        elif kind == "sum":
+            res = val / price[l].mean() * np.exp(rng.normal(0, 0.1, k)); W.append(None); P.append(None)
+        else:
+            res = val / price[l].mean() * np.exp(rng.normal(0, 0.05, k)); W.append(None)
+            P.append(float(cfmm.synthetic.curve_alpha_from_A(res[0], res[1], 20.0)))
+        L.append(l.tolist()); R.append(res.tolist()); F.append(float(rng.choice([0.997, 0.999, 0.99]))); K.append(kind)
+    inst = dict(name=f"rand{seed}", n_tokens=n_tokens, local_indices=L, reserves=R, fees=F, kinds=K, weights=W, params=P)
+    if utility == "arbitrage":
+        inst["utility"] = dict(type="arbitrage", c=(price * np.exp(rng.normal(0, 0.05, n_tokens))).tolist())
+    elif utility == "swap":
+        h = np.zeros(n_tokens); h[0] = float(np.exp(rng.normal(1, 0.5)))
+        inst["utility"] = dict(type="swap", h=h.tolist(), t=n_tokens - 1)
+    else:
+        h = np.exp(rng.normal(0, 0.5, n_tokens)); h[n_tokens - 1] = 0
+        inst["utility"] = dict(type="liquidate", h=h.tolist(), t=n_tokens - 1)
+    return inst
+
+
+def normalise_with_params(inst):
+    out = I.normalise(inst)
+    out["params"] = inst.get("params", [None] * len(inst["local_indices"]))
+    return out

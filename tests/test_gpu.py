@@ -1,0 +1,204 @@
+"""GPU suite (-m gpu): the HIP path through the C-ABI against the oracle on the same seeded inputs,
+against the golden fixtures, and -- at BASELINE's full sizes -- through size-independent
+properties.  Tolerances: per-pool trades and psi 1e-11 relative to the reserves / to |psi|_inf
+(fp64, different libm + summation order); objectives 1e-6 relative (the north-star bar)."""
+import numpy as np
+import pytest
+
+import cfmm
+from cfmm import synthetic, _lib
+from oracle import instances as I
+from helpers import golden, shipped_cases, problem_of, random_instance, normalise_with_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_for(oracle_lib, net, threads=4):
+    o = oracle_lib.Oracle(net["n_tokens"], threads=threads)
+    o.add_network(net)
+    o.set_utility(net["c"])
+    return o
+
+
+def test_backend_is_gfx950():
+    ctx = _lib.Context(8)
+    assert ctx.backend.startswith("hip:gfx950")
+    ctx.close()
+
+
+@pytest.mark.parametrize("cfg,scale", [("C2", 1.0), ("C3", 0.05), ("C5", 0.05), ("C4shard", 0.1)])
+def test_eval_dual_matches_oracle(oracle_lib, cfg, scale):
+    net = synthetic.config(cfg, scale=scale, seed=1)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    o = _oracle_for(oracle_lib, net)
+    rng = np.random.default_rng(2)
+    for sig in (0.0, 0.03, 0.3):
+        nu = net["c"] * np.exp(rng.normal(0, sig, net["n_tokens"]))
+        f1, psi1, d1 = p.eval_dual(nu, want_diag=True)
+        f0, psi0, d0 = o.eval(nu, want_diag=True)
+        # scale of the terms summed into psi_j: the gross flow, not the (cancelling) net
+        assert abs(f1 - f0) <= 1e-11 * max(abs(f0), 1.0)
+        gross = max(np.abs(psi0).max(), 1.0)
+        assert np.abs(psi1 - psi0).max() <= 1e-10 * gross * 10
+        assert np.abs(d1 - d0).max() <= 1e-11 * np.abs(d0).max()
+    p.close()
+
+
+def test_trades_match_oracle_pool_by_pool(oracle_lib):
+    net = synthetic.config("C3", scale=0.02, seed=4)
+    cv = synthetic.config("C5", scale=0.01, seed=4)
+    net["curve2"] = cv["curve2"]
+    net["curve2"]["ia"] = net["curve2"]["ia"] % net["n_tokens"]; net["curve2"]["ib"] = net["curve2"]["ib"] % net["n_tokens"]
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    o = _oracle_for(oracle_lib, net)
+    nu = net["c"] * np.exp(np.random.default_rng(3).normal(0, 0.05, net["n_tokens"]))
+    p._ensure_ctx().set_nu(nu)
+    names = [k for k, _ in o.b2]
+    for key in ("cp2", "w2", "curve2"):
+        d, l = p.bucket_trades(key)
+        ya, yb = o.trades2(names.index(key), nu)
+        b = net[key]
+        assert np.all(d >= 0) and np.all(l >= 0) and np.all(d * l == 0)
+        tol = (1e-9 if key == "curve2" else 1e-12) * (b["Ra"] + b["Rb"])
+        assert np.all(np.abs((l - d)[0] - ya) <= tol) and np.all(np.abs((l - d)[1] - yb) <= tol), key
+    sizes = [k for k, _ in o.bn]
+    for k in net["gn"]:
+        d, l = p.bucket_trades(k)
+        y = o.tradesN(sizes.index(k), nu)
+        assert np.abs((l - d) - y).max() <= 1e-12 * net["gn"][k]["R"].max()
+    p.close()
+
+
+def test_invariants_preserved_and_psi_is_scatter_of_trades():
+    """size-independent properties at BASELINE config 3's full size (1e6 pools / 1000 tokens)"""
+    net = synthetic.config("C3", seed=0)
+    n = net["n_tokens"]
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    v = p.solve(tol=1e-6)
+    assert p.status == "optimal" and p.gap <= 1e-6 and p.infeas <= 1e-6
+    assert p.stats["evals"] < 200
+    psi = np.zeros(n)
+    value = 0.0
+    for key in ("cp2", "w2"):
+        b = net[key]
+        d, l = p.bucket_trades(key)
+        y = l - d
+        assert np.all(d * l == 0)
+        psi += np.bincount(b["ia"], weights=y[0], minlength=n) + np.bincount(b["ib"], weights=y[1], minlength=n)
+        wa = b["wa"] if key == "w2" else 0.5
+        xa = b["Ra"] + b["fee"] * d[0] - l[0]; xb = b["Rb"] + b["fee"] * d[1] - l[1]
+        inv = wa * np.log(xa / b["Ra"]) + (1 - wa) * np.log(xb / b["Rb"])
+        assert np.abs(inv).max() <= 1e-12            # phi(R + gamma D - L) == phi(R)
+        assert np.all(p.nu[b["ia"]] * y[0] + p.nu[b["ib"]] * y[1] >= -1e-9)   # arb_i >= 0
+    for k, b in net["gn"].items():
+        d, l = p.bucket_trades(k)
+        y = l - d
+        for j in range(k):
+            psi += np.bincount(b["idx"][j], weights=y[j], minlength=n)
+        x = b["R"] + b["fee"][None, :] * d - l
+        assert np.abs((b["w"] * np.log(x / b["R"])).sum(0)).max() <= 1e-12
+    assert np.abs(psi - p.psi).max() <= 1e-9 * max(1.0, np.abs(psi).max())
+    assert abs(net["c"] @ psi - v) <= 1e-9 * abs(v)
+    # certificate: weak duality sandwich
+    assert p.dual_value >= v - 1e-9 * abs(v)
+    assert (p.dual_value - v) <= 2e-6 * abs(v)
+    p.close()
+
+
+@pytest.mark.parametrize("cfg,scale", [("C2", 1.0), ("C3", 0.1), ("C4shard", 0.2)])
+def test_solve_matches_oracle_solver(oracle_lib, cfg, scale):
+    net = synthetic.config(cfg, scale=scale, seed=0)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    o = _oracle_for(oracle_lib, net)
+    v = p.solve(tol=1e-6)
+    r = o.solve(net["c"], tol=1e-6)
+    assert p.status == "optimal" and r["status"] == 1
+    assert abs(v - r["primal_value"]) <= 2e-6 * abs(v)
+    assert abs(p.dual_value - r["dual_value"]) <= 2e-6 * abs(v)
+    assert p.stats["evals"] <= 2 * r["evals"] + 16
+    # tighter tolerance: both converge to the same prices
+    v9 = p.solve(tol=1e-9)
+    r9 = o.solve(net["c"], tol=1e-9)
+    assert abs(v9 - r9["primal_value"]) <= 1e-8 * abs(v9)
+    assert np.abs(p.nu / r9["nu"] - 1).max() <= 1e-6
+    p.close()
+
+
+@pytest.mark.parametrize("name,inst", shipped_cases())
+def test_shipped_instances_through_hip(name, inst):
+    """arbitrage.py / liquidation.py / two-asset.py on the GPU: objective, psi, every pool's tenders"""
+    g = golden()[name]
+    p = problem_of(inst)
+    v = p.solve(tol=1e-10)
+    assert p.status == "optimal"
+    assert abs(v - g["survey"]["value"]) <= 1e-6 * max(1, abs(v))          # the north-star tolerance
+    assert abs(v - g["survey"]["value"]) <= 1e-8 * max(1, abs(v))          # ... and what we actually reach
+    assert np.abs(p.psi - np.asarray(g["primal"]["psi"])).max() <= 2e-5
+    ys = g["survey"].get("y") or g["primal"]["y"]
+    for d, l, y in zip(p.deltas, p.lambdas, ys):
+        assert np.all(d >= 0) and np.all(l >= 0) and np.all(d * l == 0)
+        assert np.abs((l - d) - np.asarray(y)).max() <= 2e-5
+    p.close()
+
+
+def test_two_asset_sweep_warm_started():
+    """two-asset.py:40-100 -- the 50-point sweep, each solve warm-started from its neighbour"""
+    p = problem_of(I.two_asset(0.0))
+    vals = []
+    for t in I.two_asset_sweep():
+        p.set_utility(cfmm.Swap([t, 0, 0], 2))
+        vals.append(p.solve(tol=1e-9, warm_start=True))
+        assert p.status == "optimal"
+    vals = np.array(vals)
+    g = golden()
+    for j in (0, 1, 10, 25, 49):
+        assert abs(vals[j] - g[f"two_asset_{j}"]["survey"]["value"]) <= 1e-7
+    assert np.all(np.diff(vals) > 0)
+    p.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_small_instances_vs_primal(seed):
+    from oracle.primal_scipy import solve_primal
+    util = ["arbitrage", "swap", "liquidate"][seed % 3]
+    inst = random_instance(200 + seed, n_tokens=6, n_pools=14, with_sum=True, with_curve=True, utility=util)
+    p = problem_of(inst)
+    v = p.solve(tol=1e-9)
+    r = solve_primal(normalise_with_params(inst))
+    assert abs(v - r["value"]) <= 2e-6 * max(1, abs(v)), (p.status, v, r["value"])
+    p.close()
+
+
+def test_error_behaviour():
+    ctx = _lib.Context(4)
+    with pytest.raises(cfmm.CfmmError, match="token ids"):
+        ctx.upload_pools2(_lib.POOL_CP2, [1.0], [1.0], [0.99], [0], [7])
+    with pytest.raises(cfmm.CfmmError, match="pool size"):
+        ctx.upload_poolsN(np.zeros((9, 1), dtype=np.int32), np.ones((9, 1)), np.ones((9, 1)) / 9, [0.99])
+    with pytest.raises(cfmm.CfmmError, match="set_utility"):
+        ctx.solve(np.ones(4))
+    ctx.set_utility(np.ones(4))
+    with pytest.raises(cfmm.CfmmError, match="no pools"):
+        ctx.solve(np.ones(4))
+    ctx.upload_pools2(_lib.POOL_CP2, [1.0], [1.0], [0.99], [0], [1])
+    with pytest.raises(cfmm.CfmmError, match="positive finite"):
+        ctx.solve(np.array([1.0, -1.0, 1.0, 1.0]))
+    # empty bucket upload is allowed and clears the bucket
+    ctx.upload_pools2(_lib.POOL_W2, [], [], [], [], [], param=[])
+    assert ctx.pool_count() == 1
+    ctx.close()
+    with pytest.raises(cfmm.CfmmError, match="LDS-staged limit"):
+        _lib.Context(50_000)
+
+
+def test_hub_tokens_zipf_stress(oracle_lib):
+    """heavy-tailed token popularity: most pools touch a few hub tokens (LDS atomic contention)"""
+    net = synthetic.make_network(500, m_cp2=200_000, seed=5, zipf_s=1.1)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    o = _oracle_for(oracle_lib, net)
+    nu = net["c"] * np.exp(np.random.default_rng(0).normal(0, 0.02, 500))
+    f1, psi1 = p.eval_dual(nu)
+    f0, psi0 = o.eval(nu)
+    assert abs(f1 - f0) <= 1e-11 * abs(f0)
+    assert np.abs(psi1 - psi0).max() <= 1e-9 * np.abs(psi0).max()
+    p.close()

@@ -1,0 +1,114 @@
+"""CPU suite, part 1: the oracle is pinned -- against the survey-derived known answers (golden
+fixture), against the independent SciPy primal model, and C against NumPy pool by pool."""
+import numpy as np
+import pytest
+
+import cfmm
+from cfmm import synthetic
+from oracle import instances as I
+from oracle import pools_np as P
+from oracle.primal_scipy import solve_primal
+from helpers import golden, shipped_cases, random_instance, normalise_with_params
+
+
+@pytest.mark.parametrize("name,inst", shipped_cases())
+def test_primal_model_matches_known_answers(name, inst):
+    g = golden()[name]
+    r = solve_primal(I.normalise(inst))
+    assert abs(r["value"] - g["survey"]["value"]) <= 2e-8 * max(1, abs(r["value"]))
+    assert abs(r["value"] - g["primal"]["value"]) <= 1e-9 * max(1, abs(r["value"]))
+    if "y" in g["survey"]:
+        for y, ys in zip(r["y"], g["survey"]["y"]):
+            assert np.abs(y - np.asarray(ys)).max() < 5e-6
+
+
+def test_c_pools_match_numpy(oracle_lib):
+    net = synthetic.config("C3", scale=0.003, seed=3)
+    o = oracle_lib.Oracle(net["n_tokens"]); o.add_network(net); o.set_utility(net["c"])
+    nu = net["c"] * np.exp(np.random.default_rng(1).normal(0, 0.05, net["n_tokens"]))
+    b = net["cp2"]
+    ya, yb, _ = P.arb_geomean2(b["Ra"], b["Rb"], b["fee"], 0.5, 0.5, nu[b["ia"]], nu[b["ib"]])
+    ca, cb = o.trades2(0, nu)
+    tol = 1e-13 * (np.abs(b["Ra"]) + np.abs(b["Rb"]))
+    assert np.all(np.abs(ya - ca) <= tol) and np.all(np.abs(yb - cb) <= tol)
+    b = net["w2"]
+    ya, yb, _ = P.arb_geomean2(b["Ra"], b["Rb"], b["fee"], b["wa"], 1 - b["wa"], nu[b["ia"]], nu[b["ib"]])
+    ca, cb = o.trades2(1, nu)
+    tol = 1e-12 * (np.abs(b["Ra"]) + np.abs(b["Rb"]))
+    assert np.all(np.abs(ya - ca) <= tol) and np.all(np.abs(yb - cb) <= tol)
+    for bi, (k, d) in enumerate(o.bn):
+        y = o.tradesN(bi, nu)
+        for i in range(0, d["R"].shape[1], 7):
+            yy, _ = P.arb_geomean_n(d["R"][:, i], d["w"][:, i], d["fee"][i], nu[d["idx"][:, i]])
+            assert np.abs(yy - y[:, i]).max() <= 1e-12 * d["R"][:, i].max()
+
+
+def test_geomean_n_reduces_to_two_asset():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        R = np.exp(rng.normal(0, 1, 2)); w = rng.integers(1, 5, 2).astype(float); w /= w.sum()
+        p = np.exp(rng.normal(0, 1, 2)); g = rng.choice([0.99, 0.997, 1.0])
+        y, v = P.arb_geomean_n(R, w, g, p)
+        ya, yb, v2 = P.arb_geomean2(R[0], R[1], g, w[0], w[1], p[0], p[1])
+        assert abs(y[0] - ya) <= 1e-12 * R[0] and abs(y[1] - yb) <= 1e-12 * R[1]
+
+
+def test_pool_kkt_properties(oracle_lib):
+    """trading-function value preserved, complementarity, envelope theorem (grad arb = y)"""
+    rng = np.random.default_rng(5)
+    for _ in range(100):
+        k = int(rng.integers(2, 7))
+        R = np.exp(rng.normal(0, 1, k)); w = rng.integers(1, 5, k).astype(float); w /= w.sum()
+        p = np.exp(rng.normal(0, 0.3, k)) * w / R * R.mean()
+        g = 0.997
+        y, v = P.arb_geomean_n(R, w, g, p)
+        D = np.maximum(-y, 0); Lm = np.maximum(y, 0)
+        x = R + g * D - Lm
+        assert abs(np.sum(w * np.log(x)) - np.sum(w * np.log(R))) < 1e-12
+        assert v >= -1e-12
+        eps = 1e-6
+        for j in range(k):
+            pp = p.copy(); pp[j] *= 1 + eps; pm = p.copy(); pm[j] *= 1 - eps
+            fd = (P.arb_geomean_n(R, w, g, pp)[1] - P.arb_geomean_n(R, w, g, pm)[1]) / (2 * eps * p[j])
+            assert abs(fd - y[j]) <= 1e-5 * (abs(y[j]) + R[j] * 1e-3)
+
+
+def test_curve_pool_properties(oracle_lib):
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        Ra, Rb = np.exp(rng.normal(3, 0.2, 2)); A = float(rng.choice([10, 100]))
+        al = float(synthetic.curve_alpha_from_A(Ra, Rb, A)); g = 0.999
+        pa, pb = np.exp(rng.normal(0, 0.02, 2))
+        y, v = P.arb_curve2(Ra, Rb, g, al, pa, pb)
+        D = np.maximum(-y, 0); Lm = np.maximum(y, 0)
+        x = np.array([Ra, Rb]) + g * D - Lm
+        phi = lambda z: z[0] + z[1] - al / (z[0] * z[1])
+        assert abs(phi(x) - phi([Ra, Rb])) <= 1e-10 * (Ra + Rb)
+        o = oracle_lib.Oracle(2); o.add_pools2("curve2", [Ra], [Rb], [g], [0], [1], param=[al])
+        ca, cb = o.trades2(0, np.array([pa, pb]))
+        assert abs(ca[0] - y[0]) <= 1e-9 * Ra and abs(cb[0] - y[1]) <= 1e-9 * Rb
+
+
+@pytest.mark.parametrize("cfg,scale", [("C2", 1.0), ("C3", 0.05), ("C4shard", 0.02)])
+def test_c_oracle_solver_certificates(oracle_lib, cfg, scale):
+    net = synthetic.config(cfg, scale=scale)
+    o = oracle_lib.Oracle(net["n_tokens"], threads=2); o.add_network(net); o.set_utility(net["c"])
+    r = o.solve(net["c"], tol=1e-6)
+    assert r["status"] == 1 and r["gap"] <= 1e-6 and r["infeas"] <= 1e-6
+    assert r["evals"] < 400
+    # weak duality: primal <= dual, and they agree to the gap
+    assert abs(r["dual_value"] - r["primal_value"]) <= 2e-6 * max(1, abs(r["dual_value"]))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dual_oracle_vs_primal_on_random_instances(oracle_lib, seed):
+    """dual decomposition (C oracle through the host logic) == primal NLP on small random instances"""
+    from oracle_ctx import OracleContext
+    from helpers import problem_of
+    util = ["arbitrage", "swap", "liquidate"][seed % 3]
+    inst = random_instance(seed, with_sum=False, with_curve=(seed % 2 == 0), utility=util)
+    p = problem_of(inst, OracleContext(inst["n_tokens"]))
+    v = p.solve(tol=1e-9)
+    r = solve_primal(normalise_with_params(inst))
+    assert p.status == "optimal"
+    assert abs(v - r["value"]) <= 1e-6 * max(1, abs(v)), (v, r["value"])
