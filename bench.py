@@ -129,15 +129,16 @@ def main():
     if rank == 0:
         rows = kernel_table(prob, args.kernel_reps)
         dom = rows[0]
+        mix = ", ".join(f"{k}={len(net[k]['Ra'])}" for k in ("cp2", "w2", "curve2", "sum2") if k in net)
+        if "gn" in net:
+            mix += ", gn3-8=" + str(sum(b["R"].shape[1] for b in net["gn"].values()))
         out = {
             "metric": "pool-subproblems/sec to 1e-6 rel-gap; 1e6 pools / 1k tokens; 1/2/4/8 GPU",
             "value": value, "unit": "pool-subproblems/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {prob.m} pools per GPU "
-                                   f"({', '.join(f'{k}={len(net[k]['Ra'])}' for k in ('cp2', 'w2', 'curve2', 'sum2') if k in net)}"
-                                   f"{', gn3-8=' + str(sum(b['R'].shape[1] for b in net['gn'].values())) if 'gn' in net else ''}) "
-                                   f"/ {net['n_tokens']} tokens, linear-utility arbitrage, cold-start solve to gap,infeas <= {args.tol:g}",
+            "config": {"workload": f"{args.config}: {prob.m} pools per GPU ({mix}) / {net['n_tokens']} tokens, "
+                                   f"linear-utility arbitrage, cold-start solve to gap,infeas <= {args.tol:g}",
                        "pools_per_gpu": prob.m, "tokens": net["n_tokens"], "seed": 0,
                        "parallelism": f"pool-sharding x{world}" if world > 1 else "single GPU"},
             "evals_per_solve": evals / args.steps,

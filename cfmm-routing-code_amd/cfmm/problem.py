@@ -318,85 +318,88 @@ class Problem:
         self._theta = {}
         self._trade_cache = None
         kw = dict(max_evals=max_evals, memory=memory, iters_per_graph=iters_per_graph)
-        has_sum = "sum2" in self.net
-        # a partially filled constant-sum pool makes the untied dual non-smooth: do not burn the
-        # whole budget before looking for kinks
-        kw1 = dict(kw, max_evals=min(max_evals, 200)) if has_sum else kw
-        st = ctx.solve(nu0, tol=tol, **kw1)
-        total = dict(evals=st["evals"], iters=st["iters"], wall_seconds=st["wall_seconds"],
-                     device_seconds=st["device_seconds"], rounds=1)
-        nu, psi = ctx.get_nu(), ctx.get_psi()
-        if st["status"] != 1 and has_sum:
-            st, nu, psi = self._solve_kinks(ctx, st, nu, psi, tol, kw, kink_tol, max_rounds, total)
+        total = dict(evals=0, iters=0, wall_seconds=0.0, device_seconds=0.0, rounds=0)
+        if "sum2" not in self.net:
+            st = self._run(ctx, nu0, total, tol=tol, **kw)
+            nu, psi = ctx.get_nu(), ctx.get_psi()
+        else:
+            st, nu, psi = self._solve_kinks(ctx, nu0, tol, kw, kink_tol, max_rounds, total)
         self._finish(st, nu, psi, total)
         return self.value
 
-    def _kink_candidates(self, nu, kink_tol, skip):
+    @staticmethod
+    def _run(ctx, nu, total, **kw):
+        st = ctx.solve(nu, **kw)
+        total["evals"] += st["evals"]; total["iters"] += st["iters"]; total["rounds"] += 1
+        total["wall_seconds"] += st["wall_seconds"]; total["device_seconds"] += st["device_seconds"]
+        return st
+
+    def _kink_candidates(self, nu, kink_tol, banned, tied):
         b = self.net["sum2"]
         r = np.log(nu[b["ia"]]) - np.log(nu[b["ib"]])
         lg = np.log(b["fee"])
         out = {}
         for i in range(len(r)):
-            if i in skip:
+            if i in tied:
                 continue
-            if abs(r[i] - lg[i]) < kink_tol:
+            if abs(r[i] - lg[i]) < kink_tol and (i, +1) not in banned:
                 out[i] = +1          # a->b kink: log nu_a - log nu_b = log gamma
-            elif abs(r[i] + lg[i]) < kink_tol:
+            elif abs(r[i] + lg[i]) < kink_tol and (i, -1) not in banned:
                 out[i] = -1          # b->a kink: log nu_a - log nu_b = -log gamma
         return out
 
-    def _solve_kinks(self, ctx, st, nu, psi, tol, kw, kink_tol, max_rounds, total):
-        """Constant-sum pools whose optimum is a partial fill sit on a kink of the dual; tie their
-        two prices, re-solve the (now smooth) reduced dual on the device, recover the fills."""
+    def _solve_kinks(self, ctx, nu, tol, kw, kink_tol, max_rounds, total):
+        """A constant-sum pool whose optimum is a partial fill sits on a kink of the dual (all three
+        shipped scripts do this).  Active-set loop: solve untied with a small budget; tie the two
+        prices of every pool found on a kink (a linear equality in log-price) and skip it in the
+        kernels; re-solve the now smooth reduced dual on the device; recover the fill fractions;
+        release ties whose fill leaves (0,1)."""
         b = self.net["sum2"]
         m2 = len(b["Ra"])
-        tied = {}
-        released = set()
-        for _ in range(max_rounds):
-            new = self._kink_candidates(nu, kink_tol, released | set(tied))
-            if not new and not tied:       # no kink in sight: plain continuation with the full budget
-                st = ctx.solve(nu, tol=tol, **kw)
-                total["evals"] += st["evals"]; total["iters"] += st["iters"]; total["rounds"] += 1
-                total["wall_seconds"] += st["wall_seconds"]; total["device_seconds"] += st["device_seconds"]
+        tied, banned = {}, set()
+        budget = min(kw["max_evals"], 200)
+        st = None
+        for _ in range(4 * max_rounds):
+            if not tied:
+                ctx.set_ties(None, None); ctx.set_pool_flags(POOL_SUM2, None)
+                st = self._run(ctx, nu, total, tol=tol, **dict(kw, max_evals=budget))
                 nu, psi = ctx.get_nu(), ctx.get_psi()
                 if st["status"] == 1:
                     return st, nu, psi
-                new = self._kink_candidates(nu, kink_tol, released)
+                new = self._kink_candidates(nu, kink_tol, banned, tied)
                 if not new:
-                    return st, nu, psi
-            tied.update(new)
+                    if st["status"] == 3 and budget < kw["max_evals"]:
+                        budget = min(kw["max_evals"], 4 * budget)      # no kink in sight: keep going
+                    elif kink_tol < 0.05:
+                        kink_tol *= 10
+                    else:
+                        return st, nu, psi
+                    continue
+                tied.update(new)
             ties = _Ties(self.n)
             flags = np.zeros(m2, dtype=np.int32)
             for i, sgn in list(tied.items()):
                 if ties.tie(int(b["ia"][i]), int(b["ib"][i]), sgn * np.log(b["fee"][i])):
                     flags[i] = 1
                 else:
-                    del tied[i]; released.add(i)
+                    del tied[i]; banned.add((i, sgn))
             grp, off, ng = ties.groups()
             ctx.set_ties(grp, off)
             ctx.set_pool_flags(POOL_SUM2, flags)
-            st = ctx.solve(nu, tol=0.01 * tol, pg_rule=1, **kw)
-            total["evals"] += st["evals"]; total["iters"] += st["iters"]; total["rounds"] += 1
-            total["wall_seconds"] += st["wall_seconds"]; total["device_seconds"] += st["device_seconds"]
+            st = self._run(ctx, nu, total, tol=0.01 * tol, pg_rule=1, **kw)
             nu, psi = ctx.get_nu(), ctx.get_psi()
             theta, ok = self._recover_fills(nu, psi, tied, tol)
             bad = [i for i in tied if not (1e-9 < theta[i] < 1 - 1e-9)]
             if ok and not bad:
                 self._theta = {i: (tied[i], theta[i]) for i in tied}
-                st = dict(st); st["status"] = 1 if st["status"] == 1 else st["status"]
                 return st, nu, psi
-            if not bad:           # residual not matched: widen the search for further kinks
-                kink_tol *= 10
-                continue
-            for i in bad:         # the pool is fully on / fully off after all: let it go bang-bang
-                del tied[i]; released.add(i)
-            if not tied:
-                ctx.set_ties(None, None); ctx.set_pool_flags(POOL_SUM2, None)
-                st = ctx.solve(nu, tol=tol, **kw)
-                total["evals"] += st["evals"]; total["iters"] += st["iters"]; total["rounds"] += 1
-                nu, psi = ctx.get_nu(), ctx.get_psi()
-                if st["status"] == 1:
+            for i in bad:             # fully on / fully off after all: back to bang-bang
+                banned.add((i, tied[i])); del tied[i]
+            if not bad:               # balance not met: some other pool must be on a kink too
+                new = self._kink_candidates(nu, 10 * kink_tol, banned, tied)
+                if not new:
                     return st, nu, psi
+                tied.update(new)
         return st, nu, psi
 
     def _fill_vector(self, i, sgn):

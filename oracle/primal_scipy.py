@@ -66,7 +66,9 @@ def solve_primal(inst, x0=None, ftol=1e-15, maxiter=2000):
                 out.extend(xi)                                   # new reserves >= 0
             elif K[i] == "curve":
                 al = P[i]
-                out.append(np.sum(xi) - al / np.prod(xi) - (np.sum(Ri) - al / np.prod(Ri)))
+                xp = np.maximum(xi, 1e-9 * Ri)                   # inv_prod's domain is x > 0
+                out.append(np.sum(xi) - al / np.prod(xp) - (np.sum(Ri) - al / np.prod(Ri)))
+                out.extend(xi - 1e-9 * Ri)
             else:
                 raise ValueError(K[i])
         psi = psi_of(z)
@@ -94,7 +96,11 @@ def solve_primal(inst, x0=None, ftol=1e-15, maxiter=2000):
                     rows.append(row_from(e))
             elif K[i] == "curve":
                 al = P[i]
-                rows.append(row_from(1.0 + al / (np.prod(xi) * xi)))
+                xp = np.maximum(xi, 1e-9 * R[i])
+                rows.append(row_from(1.0 + al / (np.prod(xp) * xp)))
+                for k in range(sizes[i]):
+                    e = np.zeros(sizes[i]); e[k] = 1.0
+                    rows.append(row_from(e))
         for k in np.where(ctype == 0)[0]:
             r = np.zeros(2 * nnz)
             sel = gidx == k

@@ -4,6 +4,7 @@ import os
 import numpy as np
 
 import cfmm
+from cfmm import synthetic as _syn
 from oracle import instances as I
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shipped_instances.json")
@@ -64,7 +65,7 @@ def random_instance(seed, n_tokens=6, n_pools=12, with_sum=True, with_curve=Fals
             res = val / price[l].mean() * np.exp(rng.normal(0, 0.1, k)); W.append(None); P.append(None)
         else:
             res = val / price[l].mean() * np.exp(rng.normal(0, 0.05, k)); W.append(None)
-            P.append(float(cfmm.synthetic.curve_alpha_from_A(res[0], res[1], 20.0)))
+            P.append(float(_syn.curve_alpha_from_A(res[0], res[1], 20.0)))
         L.append(l.tolist()); R.append(res.tolist()); F.append(float(rng.choice([0.997, 0.999, 0.99]))); K.append(kind)
     inst = dict(name=f"rand{seed}", n_tokens=n_tokens, local_indices=L, reserves=R, fees=F, kinds=K, weights=W, params=P)
     if utility == "arbitrage":
