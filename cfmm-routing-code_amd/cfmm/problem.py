@@ -317,6 +317,7 @@ class Problem:
             nu0 = self.nu if (warm_start and self.nu is not None) else start_prices(self.net, u)
         self._theta = {}
         self._trade_cache = None
+        self._tol = tol
         kw = dict(max_evals=max_evals, memory=memory, iters_per_graph=iters_per_graph)
         total = dict(evals=0, iters=0, wall_seconds=0.0, device_seconds=0.0, rounds=0)
         if "sum2" not in self.net:
@@ -335,6 +336,8 @@ class Problem:
         return st
 
     def _kink_candidates(self, nu, kink_tol, banned, tied):
+        """constant-sum pools whose price ratio sits on one of their two kinks
+        (log nu_a - log nu_b = +-log gamma): nearest kink, within kink_tol and well inside its half"""
         b = self.net["sum2"]
         r = np.log(nu[b["ia"]]) - np.log(nu[b["ib"]])
         lg = np.log(b["fee"])
@@ -342,40 +345,27 @@ class Problem:
         for i in range(len(r)):
             if i in tied:
                 continue
-            if abs(r[i] - lg[i]) < kink_tol and (i, +1) not in banned:
-                out[i] = +1          # a->b kink: log nu_a - log nu_b = log gamma
-            elif abs(r[i] + lg[i]) < kink_tol and (i, -1) not in banned:
-                out[i] = -1          # b->a kink: log nu_a - log nu_b = -log gamma
+            sgn = +1 if r[i] < 0 else -1          # a->b kink at r = lg < 0, b->a kink at r = -lg > 0
+            dist = abs(r[i] - sgn * lg[i])
+            if dist < kink_tol and (dist < 0.5 * abs(lg[i]) or lg[i] == 0.0) and (i, sgn) not in banned:
+                out[i] = sgn
         return out
 
     def _solve_kinks(self, ctx, nu, tol, kw, kink_tol, max_rounds, total):
         """A constant-sum pool whose optimum is a partial fill sits on a kink of the dual (all three
-        shipped scripts do this).  Active-set loop: solve untied with a small budget; tie the two
+        shipped scripts do this).  Active-set loop: run the device solver in short legs; tie the two
         prices of every pool found on a kink (a linear equality in log-price) and skip it in the
-        kernels; re-solve the now smooth reduced dual on the device; recover the fill fractions;
+        kernels; once the (now smooth) reduced dual has converged recover the fill fractions;
         release ties whose fill leaves (0,1)."""
         b = self.net["sum2"]
         m2 = len(b["Ra"])
         tied, banned = {}, set()
-        budget = min(kw["max_evals"], 200)
+        budget = min(kw["max_evals"], 100)
         st = None
-        for _ in range(4 * max_rounds):
-            if not tied:
-                ctx.set_ties(None, None); ctx.set_pool_flags(POOL_SUM2, None)
-                st = self._run(ctx, nu, total, tol=tol, **dict(kw, max_evals=budget))
-                nu, psi = ctx.get_nu(), ctx.get_psi()
-                if st["status"] == 1:
-                    return st, nu, psi
-                new = self._kink_candidates(nu, kink_tol, banned, tied)
-                if not new:
-                    if st["status"] == 3 and budget < kw["max_evals"]:
-                        budget = min(kw["max_evals"], 4 * budget)      # no kink in sight: keep going
-                    elif kink_tol < 0.05:
-                        kink_tol *= 10
-                    else:
-                        return st, nu, psi
-                    continue
-                tied.update(new)
+        psi = None
+        for _ in range(8 * max_rounds):
+            if total["evals"] >= 4 * kw["max_evals"]:
+                break
             ties = _Ties(self.n)
             flags = np.zeros(m2, dtype=np.int32)
             for i, sgn in list(tied.items()):
@@ -383,23 +373,36 @@ class Problem:
                     flags[i] = 1
                 else:
                     del tied[i]; banned.add((i, sgn))
-            grp, off, ng = ties.groups()
-            ctx.set_ties(grp, off)
-            ctx.set_pool_flags(POOL_SUM2, flags)
-            st = self._run(ctx, nu, total, tol=0.01 * tol, pg_rule=1, **kw)
+            if tied:
+                grp, off, ng = ties.groups()
+                ctx.set_ties(grp, off); ctx.set_pool_flags(POOL_SUM2, flags)
+                st = self._run(ctx, nu, total, tol=0.01 * tol, pg_rule=1, **dict(kw, max_evals=budget))
+            else:
+                ctx.set_ties(None, None); ctx.set_pool_flags(POOL_SUM2, None)
+                st = self._run(ctx, nu, total, tol=tol, **dict(kw, max_evals=budget))
             nu, psi = ctx.get_nu(), ctx.get_psi()
-            theta, ok = self._recover_fills(nu, psi, tied, tol)
-            bad = [i for i in tied if not (1e-9 < theta[i] < 1 - 1e-9)]
-            if ok and not bad:
-                self._theta = {i: (tied[i], theta[i]) for i in tied}
-                return st, nu, psi
-            for i in bad:             # fully on / fully off after all: back to bang-bang
-                banned.add((i, tied[i])); del tied[i]
-            if not bad:               # balance not met: some other pool must be on a kink too
-                new = self._kink_candidates(nu, 10 * kink_tol, banned, tied)
-                if not new:
+            if st["status"] == 1:
+                if not tied:
                     return st, nu, psi
+                theta, ok = self._recover_fills(nu, psi, tied, tol)
+                bad = [i for i in tied if not (1e-9 < theta[i] < 1 - 1e-9)]
+                if ok and not bad:
+                    self._theta = {i: (tied[i], theta[i]) for i in tied}
+                    return st, nu, psi
+                if bad:                   # fully on / fully off after all: back to bang-bang
+                    for i in bad:
+                        banned.add((i, tied[i])); del tied[i]
+                    continue
+            new = self._kink_candidates(nu, kink_tol, banned, tied)
+            if new:
                 tied.update(new)
+                banned = {bn for bn in banned if bn[0] in new}     # bans expire when the active set changes
+            elif st["status"] == 3 and budget < kw["max_evals"]:
+                budget = min(kw["max_evals"], 2 * budget)           # no kink in sight: longer legs
+            elif kink_tol < 0.05:
+                kink_tol *= 10
+            else:
+                break
         return st, nu, psi
 
     def _fill_vector(self, i, sgn):
@@ -455,8 +458,14 @@ class Problem:
         self.infeas = float(viol.max() / max(np.abs(psi).max(), np.abs(u.h).max(), 1e-300))
         self.nu, self.psi = nu, psi
         self.status = _lib.STATUS.get(st["status"], f"error {st['status']}")
-        if self._theta and self.gap <= 10 * max(st.get("tol", 0), 1e-6) and self.infeas <= 1e-5:
+        tolx = 10 * max(self._tol, 1e-12)
+        if self.gap <= tolx and self.infeas <= tolx:
             self.status = "optimal"
+        elif self.status == "optimal":
+            # the device met its stopping rule but the certificates computed here do not hold: a token
+            # that must be traded away has no pool willing to take it (its price collapses to 0)
+            collapsed = (u.h > 0) & (nu < 1e-12 * nu.max())
+            self.status = "infeasible" if collapsed.any() else "inaccurate"
         self.stats = dict(st)
         self.stats.update(total)
         self.stats["pool_subproblems"] = total["evals"] * self.m

@@ -342,7 +342,7 @@ update_kernel(UpdArgs a)
     if (!accept) {
         st.t_step *= 0.5;
         st.nrej += 1;
-        if (st.t_step < 1e-12) st.status = 2;
+        if (st.t_step < 1e-9) st.status = 2;
     } else {
         // ---- C. curvature pair, move the accepted point ----------------------------------
         if (!st.first) {

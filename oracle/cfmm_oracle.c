@@ -453,7 +453,7 @@ int oracle_step(oracle_t *o, double f_pools, const double *psi, const double *di
     }
     if (!accept) {
         o->t_step *= 0.5;
-        if (o->t_step < 1e-12) { o->status = 2; return o->status; }
+        if (o->t_step < 1e-9) { o->status = 2; return o->status; }
     } else {
         if (!o->first) {
             double *sv = o->S + (size_t)o->head * n, *yv = o->Y + (size_t)o->head * n;

@@ -165,6 +165,9 @@ def test_random_small_instances_vs_primal(seed):
     p = problem_of(inst)
     v = p.solve(tol=1e-9)
     r = solve_primal(normalise_with_params(inst))
+    if p.status == "infeasible":          # a token to sell that no pool lists: SLSQP fails on it too
+        assert not r["success"]
+        return
     assert p.status == "optimal" and p.gap <= 1e-8 and p.infeas <= 1e-8       # self-certifying
     assert r["value"] <= v + 2e-6 * max(1, abs(v))                            # weak duality vs SLSQP's point
     if r["success"]:

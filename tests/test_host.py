@@ -134,6 +134,9 @@ def test_random_instances_with_constant_sum_pools(oracle_lib, seed):
     p = problem_of(inst, OracleContext(inst["n_tokens"]))
     v = p.solve(tol=1e-9)
     r = solve_primal(normalise_with_params(inst))
+    if p.status == "infeasible":          # a token to sell that no pool lists: SLSQP fails on it too
+        assert not r["success"]
+        return
     assert p.status == "optimal" and p.gap <= 1e-8 and p.infeas <= 1e-8
     assert r["value"] <= v + 2e-6 * max(1, abs(v))
     if r["success"]:
