@@ -32,28 +32,37 @@ for p in (ROOT, os.path.join(ROOT, "cfmm-routing-code_amd")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
+# HBM bytes per eval_kernel launch on the C3 workload from the rocprofv3 PMC passes committed under
+# profiles/ (FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM, + WRITE_SIZE); None until measured
+TRAFFIC_BYTES = None
+TRAFFIC_NOTE = ("C3's 42.6 MB working set fits the 256 MiB Infinity Cache: back-to-back launches are cache-served; "
+                "profiles/ holds the PMC traffic and the HBM-streaming (>= 1e7 pools) variant")
 
 BYTES_PER_POOL = {"cp2": 32, "w2": 40, "sum2": 32, "curve2": 40}     # SURVEY 8(d); k-asset: 12 + 20 k
 KIND_ID = {"cp2": 0, "w2": 1, "sum2": 2, "curve2": 3}
 
 
 def kernel_table(prob, reps):
-    """time every bucket's evaluation kernel; returns rows sorted by time per dual evaluation"""
-    rows = []
+    """the fused evaluation kernel timed live with HIP events on the library's stream: row 0 is the
+    launch one dual evaluation makes (every bucket); the other rows restrict it to one bucket"""
+    from cfmm import _lib
     net = prob.net
+    parts = []
     for key in ("cp2", "w2", "sum2", "curve2"):
         if key in net:
             m = len(net[key]["Ra"])
-            sec = prob.ctx.time_eval_kernel(KIND_ID[key], reps)
-            rows.append(dict(kernel=f"eval2_kernel<{key}>", pools=m, bytes=m * BYTES_PER_POOL[key], seconds=sec))
-    for k, b in net.get("gn", {}).items():
+            parts.append((f"eval_kernel[{key} only]", KIND_ID[key], m, m * BYTES_PER_POOL[key]))
+    for k, b in sorted(net.get("gn", {}).items()):
         m = b["R"].shape[1]
-        sec = prob.ctx.time_eval_kernel(-k, reps)
-        rows.append(dict(kernel=f"evaln_kernel<{k}>", pools=m, bytes=m * (12 + 20 * k), seconds=sec))
+        parts.append((f"eval_kernel[gn{k} only]", -k, m, m * (12 + 20 * k)))
+    rows = [dict(kernel="eval_kernel", pools=sum(p[2] for p in parts), bytes=sum(p[3] for p in parts),
+                 seconds=prob.ctx.time_eval_kernel(_lib.TIME_ALL, reps))]
+    for name, code, m, nbytes in parts:
+        rows.append(dict(kernel=name, pools=m, bytes=nbytes, seconds=prob.ctx.time_eval_kernel(code, reps)))
     for r in rows:
         r["GBps"] = r["bytes"] / r["seconds"] / 1e9
         r["pools_per_s"] = r["pools"] / r["seconds"]
-    rows.sort(key=lambda r: -r["seconds"])
+        r["us"] = r["seconds"] * 1e6
     return rows
 
 
@@ -146,10 +155,9 @@ def main():
             "us_per_eval": 1e6 * dt / max(evals, 1),
             "gap": prob.gap, "infeas": prob.infeas, "objective": prob.value,
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES,
                          "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": dom["seconds"] * 1e6,
-                         "note": "working set fits the 256 MiB Infinity Cache: repeated launches are cache-served; "
-                                 "see profiles/ for the HBM-streaming (>= 1e7 pools) variant and PMC traffic",
+                         "note": TRAFFIC_NOTE,
                          "all_kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]},
         }
         if world == 1 and not args.no_cpu:

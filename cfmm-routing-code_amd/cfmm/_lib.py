@@ -6,10 +6,12 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libcfmm_hip.so")
+# CFMM_LIB selects another build of the same library (kernel-tuning variants under cfmm/variants/)
+_SO = os.environ.get("CFMM_LIB") or os.path.join(_HERE, "libcfmm_hip.so")
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
 POOL_CP2, POOL_W2, POOL_SUM2, POOL_CURVE2 = 0, 1, 2, 3
+TIME_ALL = 100
 GE, EQ, FREE = 0, 1, 2
 MAX_POOL_SIZE = 8
 STATUS = {1: "optimal", 2: "stalled", 3: "max_evals"}

@@ -87,6 +87,8 @@ struct cfmm_ctx {
     hipEvent_t ev[2] = {nullptr, nullptr}, ev_t0 = nullptr, ev_t1 = nullptr;
     int nslices = 16;
     int eval_grid_mult = 1;
+    int eval_blocks_per_cu = 1;        // resident EVAL_THREADS-workgroups per CU (occupancy query at create)
+    bool upd_generic = false;          // CFMM_UPDATE_GENERIC=1: force the generic update kernel (A/B testing)
     bool have_utility = false, have_nu = false;
     // host copies needed to derive bounds
     std::vector<double> hc, hh, hoff;
@@ -138,42 +140,59 @@ void free_all(std::vector<void *> &v)
 }
 
 size_t eval_lds_bytes(int n, bool with_d) { return (size_t)((with_d ? 3 : 2) * n + 16) * sizeof(double); }
-size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 16 * 8) * sizeof(double); }
+size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 16 * 8 + 8) * sizeof(double); }
 
-int eval_grid(cfmm_ctx *ctx, long long m, int threads)
+// processing order of the fused evaluation kernel (heaviest first): bucket code = -k for the
+// k-asset geo-mean buckets, CFMM_POOL_* for the two-asset ones
+const int kOrder[N_BUCKETS] = {-8, -7, -6, -5, -4, -3, CFMM_POOL_CURVE2, CFMM_POOL_W2, CFMM_POOL_CP2, CFMM_POOL_SUM2};
+
+// `only` = a bucket code to evaluate that bucket alone (measurement hook), or 0x7fffffff for all
+EvalArgs make_eval_args(cfmm_ctx *ctx, const DevState *st, int only = 0x7fffffff)
 {
-    long long need = (m + threads - 1) / threads;
-    long long cap = (long long)ctx->cus * ctx->eval_grid_mult * (EVAL_THREADS / threads);
-    return (int)(need < cap ? (need < 1 ? 1 : need) : cap);
+    EvalArgs a = {};
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) a.b2[k] = ctx->b2[k];
+    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) a.bn[k - 3] = ctx->bn[k];
+    long long tiles = 0;
+    for (int q = 0; q < N_BUCKETS; ++q) {
+        const int code = kOrder[q];
+        const long long m = code < 0 ? ctx->bn[-code].m : ctx->b2[code].m;
+        const int wt = code < 0 ? WTN : WT2;
+        if (only == 0x7fffffff || only == code) tiles += (m + wt - 1) / wt;
+        a.tile_end[q] = (int)tiles;
+    }
+    a.ntiles = (int)tiles;
+    a.n = ctx->n; a.nslices = ctx->nslices;
+    a.nu = ctx->nu; a.acc = ctx->acc; a.st = st;
+    return a;
 }
 
-template <int KIND, bool WITH_D>
-void launch_eval2(cfmm_ctx *ctx, const DevState *st)
+// launch geometry: at most 2 workgroups of 8 waves per CU; small problems get narrower
+// workgroups so that every CU still receives tiles
+void eval_geometry(cfmm_ctx *ctx, int ntiles, int &grid, int &threads)
 {
-    const Bucket2 &b = ctx->b2[KIND];
-    if (b.m == 0) return;
-    hipLaunchKernelGGL((eval2_kernel<KIND, WITH_D>), dim3(eval_grid(ctx, b.m, EVAL_THREADS)), dim3(EVAL_THREADS),
-                       eval_lds_bytes(ctx->n, WITH_D), ctx->stream, b, ctx->nu, ctx->n, ctx->acc, ctx->nslices, st);
-}
-template <int K, bool WITH_D>
-void launch_evaln(cfmm_ctx *ctx, const DevState *st)
-{
-    const BucketN &b = ctx->bn[K];
-    if (b.m == 0) return;
-    hipLaunchKernelGGL((evaln_kernel<K, WITH_D>), dim3(eval_grid(ctx, b.m, EVALN_THREADS)), dim3(EVALN_THREADS),
-                       eval_lds_bytes(ctx->n, WITH_D), ctx->stream, b, ctx->nu, ctx->n, ctx->acc, ctx->nslices, st);
+    const int slots = ctx->cus * ctx->eval_blocks_per_cu * ctx->eval_grid_mult;
+    int wpb = (ntiles + slots - 1) / slots;
+    wpb = wpb < 1 ? 1 : (wpb > EVAL_THREADS / 64 ? EVAL_THREADS / 64 : wpb);
+    threads = 64 * wpb;
+    grid = (ntiles + wpb - 1) / wpb;
+    if (grid > slots) grid = slots;
+    if (grid < 1) grid = 1;
 }
 
-// one dual evaluation of every bucket, heaviest kernels first
+template <bool WITH_D>
+void launch_eval(cfmm_ctx *ctx, const EvalArgs &a)
+{
+    if (a.ntiles == 0) return;
+    int grid, threads;
+    eval_geometry(ctx, a.ntiles, grid, threads);
+    hipLaunchKernelGGL((eval_kernel<WITH_D>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), ctx->stream, a);
+}
+
+// one dual evaluation of every bucket
 template <bool WITH_D>
 void launch_all_evals(cfmm_ctx *ctx, const DevState *st)
 {
-    launch_evaln<8, WITH_D>(ctx, st); launch_evaln<7, WITH_D>(ctx, st); launch_evaln<6, WITH_D>(ctx, st);
-    launch_evaln<5, WITH_D>(ctx, st); launch_evaln<4, WITH_D>(ctx, st); launch_evaln<3, WITH_D>(ctx, st);
-    launch_eval2<CFMM_POOL_CURVE2, WITH_D>(ctx, st);
-    launch_eval2<CFMM_POOL_W2, WITH_D>(ctx, st);
-    launch_eval2<CFMM_POOL_CP2, WITH_D>(ctx, st);
-    launch_eval2<CFMM_POOL_SUM2, WITH_D>(ctx, st);
+    launch_eval<WITH_D>(ctx, make_eval_args(ctx, st));
 }
 
 template <class F>
@@ -187,13 +206,11 @@ int set_all_lds_attrs(cfmm_ctx *ctx)
 {
     const size_t e0 = eval_lds_bytes(ctx->n, false), e1 = eval_lds_bytes(ctx->n, true);
     int rc;
-#define SET2(K) if ((rc = set_lds_attr(ctx, eval2_kernel<K, false>, e0))) return rc; if ((rc = set_lds_attr(ctx, eval2_kernel<K, true>, e1))) return rc;
-#define SETN(K) if ((rc = set_lds_attr(ctx, evaln_kernel<K, false>, e0))) return rc; if ((rc = set_lds_attr(ctx, evaln_kernel<K, true>, e1))) return rc;
-    SET2(0) SET2(1) SET2(2) SET2(3)
-    SETN(3) SETN(4) SETN(5) SETN(6) SETN(7) SETN(8)
-#undef SET2
-#undef SETN
+    if ((rc = set_lds_attr(ctx, eval_kernel<false>, e0))) return rc;
+    if ((rc = set_lds_attr(ctx, eval_kernel<true>, e1))) return rc;
     if ((rc = set_lds_attr(ctx, update_kernel, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, update_reg_kernel<256>, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, update_reg_kernel<512>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, start_kernel, upd_lds_bytes(ctx->n)))) return rc;
     return CFMM_OK;
 }
@@ -214,6 +231,19 @@ UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
     return a;
 }
 
+// the nu update: register-resident kernel up to 2048 tokens, the generic one beyond
+void launch_update(cfmm_ctx *ctx, const UpdArgs &ua)
+{
+    const int n = ctx->n;
+    const int threads = 64 * ((n + 64 * UPD_EPT - 1) / (64 * UPD_EPT));
+    if (ctx->upd_generic || threads > 512)
+        hipLaunchKernelGGL(update_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua);
+    else if (threads <= 256)
+        hipLaunchKernelGGL(update_reg_kernel<256>, dim3(1), dim3(threads), upd_lds_bytes(ctx->ng), ctx->stream, ua);
+    else
+        hipLaunchKernelGGL(update_reg_kernel<512>, dim3(1), dim3(threads), upd_lds_bytes(ctx->ng), ctx->stream, ua);
+}
+
 // evaluation -> [fold + all-reduce] -> update : one outer iteration, enqueued on ctx->stream
 template <bool WITH_D>
 int enqueue_iteration(cfmm_ctx *ctx, const UpdArgs &ua)
@@ -226,7 +256,7 @@ int enqueue_iteration(cfmm_ctx *ctx, const UpdArgs &ua)
         int rc = g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
         if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
     }
-    hipLaunchKernelGGL(update_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua);
+    launch_update(ctx, ua);
     return CFMM_OK;
 }
 
@@ -325,6 +355,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     TRY_C(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     if (const char *s = getenv("CFMM_SLICES")) ctx->nslices = std::max(1, atoi(s));
     if (const char *s = getenv("CFMM_EVAL_GRID_MULT")) ctx->eval_grid_mult = std::max(1, atoi(s));
+    if (const char *s = getenv("CFMM_UPDATE_GENERIC")) ctx->upd_generic = atoi(s) != 0;
     const int n = n_tokens;
     int rc = 0;
     rc |= dev_upload<double>(ctx, &ctx->c, nullptr, n, nullptr);
@@ -348,6 +379,12 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     TRY_C(hipEventCreate(&ctx->ev_t0));
     TRY_C(hipEventCreate(&ctx->ev_t1));
     if ((rc = set_all_lds_attrs(ctx))) return bail(rc);
+    {
+        int nb = 0;
+        TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eval_kernel<false>, EVAL_THREADS, eval_lds_bytes(n, false)));
+        ctx->eval_blocks_per_cu = nb < 1 ? 1 : nb;
+    }
+    if (ctx->nslices > 64) ctx->nslices = 64;
     // default utility state: identity groups
     ctx->hc.assign(n, 0.0); ctx->hh.assign(n, 0.0); ctx->hoff.assign(n, 0.0);
     ctx->hctype.assign(n, CFMM_GE); ctx->hgrp.resize(n);
@@ -704,21 +741,9 @@ int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_lau
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_nu) return fail(ctx, CFMM_E_STATE, "time_eval_kernel: no prices set");
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, ctx->nu_acc, ctx->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    auto launch = [&]() {
-        switch (kind) {
-        case 0: launch_eval2<0, false>(ctx, nullptr); break;
-        case 1: launch_eval2<1, false>(ctx, nullptr); break;
-        case 2: launch_eval2<2, false>(ctx, nullptr); break;
-        case 3: launch_eval2<3, false>(ctx, nullptr); break;
-        case -3: launch_evaln<3, false>(ctx, nullptr); break;
-        case -4: launch_evaln<4, false>(ctx, nullptr); break;
-        case -5: launch_evaln<5, false>(ctx, nullptr); break;
-        case -6: launch_evaln<6, false>(ctx, nullptr); break;
-        case -7: launch_evaln<7, false>(ctx, nullptr); break;
-        case -8: launch_evaln<8, false>(ctx, nullptr); break;
-        default: break;
-        }
-    };
+    const EvalArgs ea = make_eval_args(ctx, nullptr, kind == CFMM_TIME_ALL ? 0x7fffffff : kind);
+    if (ea.ntiles == 0) return fail(ctx, CFMM_E_ARG, "time_eval_kernel: bucket %d is empty", kind);
+    auto launch = [&]() { launch_eval<false>(ctx, ea); };
     for (int i = 0; i < 3; ++i) launch();
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
     for (int i = 0; i < reps; ++i) launch();

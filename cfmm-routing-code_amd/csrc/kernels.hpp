@@ -14,10 +14,22 @@
 
 namespace cfmm {
 
-constexpr int EVAL_THREADS = 1024;    // two-asset kernels: <= 128 VGPRs is plenty
-constexpr int EVALN_THREADS = 512;    // K-asset kernels: K-sized register arrays want up to 256 VGPRs
+#ifndef EVAL_THREADS_DEF
+#define EVAL_THREADS_DEF 512
+#endif
+constexpr int EVAL_THREADS = EVAL_THREADS_DEF;     // fused evaluation kernel: waves per workgroup x 64
+#ifndef EVAL_WAVES_PER_SIMD
+#define EVAL_WAVES_PER_SIMD 2             // min waves per SIMD the register allocator must leave room for
+#endif
 constexpr int UPD_THREADS = 1024;
-constexpr int MAX_MEMORY = 16;
+constexpr int MAX_MEMORY = 8;         // L-BFGS pairs kept (register-resident in update_kernel)
+
+// the fused evaluation kernel walks "wave-tiles": WT2 consecutive pools of a two-asset bucket (two
+// per lane) or WTN consecutive pools of a K-asset bucket (one per lane); buckets are laid out in
+// the tile space heaviest first, so the light tiles fill the tail of the launch
+constexpr int WT2 = 128;
+constexpr int WTN = 64;
+constexpr int N_BUCKETS = 10;         // gn8 gn7 gn6 gn5 gn4 gn3 curve2 w2 cp2 sum2 (processing order)
 
 struct DevState {
     int status, evals, iters, first, hist, head, nrej, pad;
@@ -36,6 +48,16 @@ struct BucketN {
     const double *R, *w, *fee;
 };
 
+struct EvalArgs {
+    Bucket2 b2[4];                    // indexed by CFMM_POOL_* kind
+    BucketN bn[6];                    // bn[k - 3], k = 3..8
+    int tile_end[N_BUCKETS];          // cumulative wave-tile counts in processing order
+    int ntiles, n, nslices, pad;
+    const double *nu;
+    double *acc;
+    const DevState *st;
+};
+
 // accumulator slice layout: [0,n) psi | [n] sum arb | [n+8, 2n+8) diag
 __host__ __device__ inline int acc_stride(int n) { return 2 * n + 8; }
 
@@ -51,35 +73,155 @@ __device__ __forceinline__ double wave_max(double v)
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
     return v;
 }
+// butterfly forms: every lane ends up with the result
+__device__ __forceinline__ double wave_allsum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_allmax(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
 
 // ------------------------------------------------------------------------------------------
-// Prologue / epilogue shared by the evaluation kernels
-// LDS: nu_s[n] | psi_s[n] | (diag_s[n]) | fpart[16]
+// one wave-tile of a two-asset bucket: lane l solves pools i0 + l and i0 + 64 + l.  All ten
+// column loads are issued before the first use (5 x 512 B coalesced per wave and pool row).
+// 32 B (CP2, SUM2) or 40 B (W2, CURVE2) of HBM per pool, read once.
+// ------------------------------------------------------------------------------------------
+template <int KIND, bool WITH_D>
+__device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, const double *nu_s,
+                                      double *psi_s, double *diag_s, double &fsum)
+{
+    constexpr int U = WT2 / 64;
+    double Ra[U], Rb[U], g[U], prm[U];
+    int ia[U], ib[U], fl[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        long long i = i0 + u * 64 + lane;
+        live[u] = i < b.m;
+        i = live[u] ? i : b.m - 1;
+        Ra[u] = b.Ra[i]; Rb[u] = b.Rb[i]; g[u] = b.fee[i];
+        ia[u] = b.ia[i]; ib[u] = b.ib[i];
+        prm[u] = (KIND == 1 || KIND == 3) ? b.param[i] : 0.0;
+        fl[u] = (KIND == 2 && b.flags) ? b.flags[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const double pa = nu_s[ia[u]], pb = nu_s[ib[u]];
+        Y2 y;
+        if (KIND == 0) y = pool_cp2(Ra[u], Rb[u], g[u], pa, pb);
+        else if (KIND == 1) y = pool_w2(Ra[u], Rb[u], g[u], prm[u], pa, pb);
+        else if (KIND == 2) { y = pool_sum2(Ra[u], Rb[u], g[u], pa, pb); if (fl[u]) { y.ya = 0.0; y.yb = 0.0; } }
+        else y = pool_curve2(Ra[u], Rb[u], g[u], prm[u], pa, pb);
+        if (live[u] && (y.ya != 0.0 || y.yb != 0.0)) {
+            unsafeAtomicAdd(&psi_s[ia[u]], y.ya);
+            unsafeAtomicAdd(&psi_s[ib[u]], y.yb);
+            fsum += pa * y.ya + pb * y.yb;
+        }
+        if (WITH_D && live[u] && KIND != 2) {
+            double da = 0.0, db = 0.0;
+            if (KIND == 0) { da = 0.5 * pa * Ra[u]; db = 0.5 * pb * Rb[u]; }
+            else if (KIND == 1) { da = (1.0 - prm[u]) * pa * Ra[u]; db = prm[u] * pb * Rb[u]; }
+            else curve_diag(Ra[u], Rb[u], prm[u], pa, pb, da, db);
+            unsafeAtomicAdd(&diag_s[ia[u]], da);
+            unsafeAtomicAdd(&diag_s[ib[u]], db);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// one wave-tile of a K-asset geo-mean bucket, slot-major ("size-class SoA"): column j of pool i
+// at [j*m + i], so each of the 3K loads per lane is coalesced across the wave; 12 + 20 K bytes
+// per pool.
+// ------------------------------------------------------------------------------------------
+template <int K, bool WITH_D>
+__device__ __forceinline__ void tilen(const BucketN &b, long long i0, int lane, const double *nu_s,
+                                      double *psi_s, double *diag_s, double &fsum)
+{
+    long long i = i0 + lane;
+    const bool live = i < b.m;
+    i = live ? i : b.m - 1;
+    double R[K], w[K], y[K];
+    int t[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        t[j] = b.idx[(size_t)j * b.m + i];
+        R[j] = b.R[(size_t)j * b.m + i];
+        w[j] = b.w[(size_t)j * b.m + i];
+    }
+    const double g = b.fee[i];
+    // prices are gathered from LDS twice (here and for the scatter) instead of being held in
+    // registers across the solve: an LDS read is cheaper than 2K live VGPRs
+    pool_geomean_n<K>(R, w, g, [&](int j) { return nu_s[t[j]]; }, y);
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const double pj = nu_s[t[j]];
+            if (y[j] != 0.0) { unsafeAtomicAdd(&psi_s[t[j]], y[j]); fsum += pj * y[j]; }
+            if (WITH_D) unsafeAtomicAdd(&diag_s[t[j]], (1.0 - w[j]) * pj * R[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The dual evaluation, ONE launch for every bucket:  psi(nu) = sum_i A_i (L_i - D_i),
+// sum_i arb_i(A_i' nu), optionally the diagonal metric.                reference: arbitrage.py:54
+//
+// LDS: nu_s[n] | psi_s[n] | (diag_s[n]) | fpart[8].  Every wave walks its own wave-tiles
+// (tile = pass * W + wave_in_block * gridDim + block, W = waves in the grid): the waves of one
+// workgroup take tiles W/8 apart, so each CU holds the same mix of ALU-heavy geo-mean tiles and
+// streaming constant-product tiles; no barrier between the prologue and the epilogue.  The
+// epilogue flushes the workgroup's psi tile into accumulator slice blockIdx % nslices
+// (global_atomic_add_f64).
 // ------------------------------------------------------------------------------------------
 template <bool WITH_D>
-__device__ __forceinline__ void eval_prologue(double *lds, const double *__restrict__ nu, int n,
-                                              double *&nu_s, double *&psi_s, double *&diag_s)
+__global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
+eval_kernel(EvalArgs a)
 {
-    nu_s = lds;
-    psi_s = lds + n;
-    diag_s = lds + 2 * n;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (a.st && a.st->status != 0) return;
+    const int n = a.n;
+    double *nu_s = lds, *psi_s = lds + n, *diag_s = lds + 2 * n;
+    double *fpart = lds + (WITH_D ? 3 : 2) * n;
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
-        nu_s[j] = nu[j];
+        nu_s[j] = a.nu[j];
         psi_s[j] = 0.0;
         if (WITH_D) diag_s[j] = 0.0;
     }
     __syncthreads();
-}
 
-template <bool WITH_D>
-__device__ __forceinline__ void eval_epilogue(double fsum, double *psi_s, double *diag_s, double *fpart,
-                                              int n, double *__restrict__ acc, int nslices)
-{
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = gridDim.x * (blockDim.x >> 6);
+    double fsum = 0.0;
+    for (int t = wib * gridDim.x + blockIdx.x; t < a.ntiles; t += W) {
+        int bk = 0;
+#pragma unroll
+        for (int q = 0; q < N_BUCKETS - 1; ++q) bk += (t >= a.tile_end[q]) ? 1 : 0;
+        const int tb = t - (bk ? a.tile_end[bk - 1] : 0);
+        switch (bk) {
+        case 0: tilen<8, WITH_D>(a.bn[5], (long long)tb * WTN, lane, nu_s, psi_s, diag_s, fsum); break;
+        case 1: tilen<7, WITH_D>(a.bn[4], (long long)tb * WTN, lane, nu_s, psi_s, diag_s, fsum); break;
+        case 2: tilen<6, WITH_D>(a.bn[3], (long long)tb * WTN, lane, nu_s, psi_s, diag_s, fsum); break;
+        case 3: tilen<5, WITH_D>(a.bn[2], (long long)tb * WTN, lane, nu_s, psi_s, diag_s, fsum); break;
+        case 4: tilen<4, WITH_D>(a.bn[1], (long long)tb * WTN, lane, nu_s, psi_s, diag_s, fsum); break;
+        case 5: tilen<3, WITH_D>(a.bn[0], (long long)tb * WTN, lane, nu_s, psi_s, diag_s, fsum); break;
+        case 6: tile2<3, WITH_D>(a.b2[3], (long long)tb * WT2, lane, nu_s, psi_s, diag_s, fsum); break;
+        case 7: tile2<1, WITH_D>(a.b2[1], (long long)tb * WT2, lane, nu_s, psi_s, diag_s, fsum); break;
+        case 8: tile2<0, WITH_D>(a.b2[0], (long long)tb * WT2, lane, nu_s, psi_s, diag_s, fsum); break;
+        default: tile2<2, WITH_D>(a.b2[2], (long long)tb * WT2, lane, nu_s, psi_s, diag_s, fsum); break;
+        }
+    }
     fsum = wave_sum(fsum);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    if (lane == 0) fpart[wave] = fsum;
+    if (lane == 0) fpart[wib] = fsum;
     __syncthreads();
-    double *base = acc + (size_t)(blockIdx.x % nslices) * acc_stride(n);
+
+    double *base = a.acc + (size_t)(blockIdx.x % a.nslices) * acc_stride(n);
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const double v = psi_s[j];
         if (v != 0.0) unsafeAtomicAdd(&base[j], v);
@@ -90,91 +232,9 @@ __device__ __forceinline__ void eval_epilogue(double fsum, double *psi_s, double
     }
     if (threadIdx.x == 0) {
         double f = 0.0;
-        for (int w = 0; w < nw; ++w) f += fpart[w];
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) f += fpart[w];
         if (f != 0.0) unsafeAtomicAdd(&base[n], f);
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// two-asset buckets: one lane = one pool; 32 B (CP2, SUM2) or 40 B (W2, CURVE2) per pool
-// ------------------------------------------------------------------------------------------
-template <int KIND, bool WITH_D>
-__global__ void __launch_bounds__(EVAL_THREADS)
-eval2_kernel(Bucket2 b, const double *__restrict__ nu, int n, double *__restrict__ acc, int nslices,
-             const DevState *__restrict__ st)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (st && st->status != 0) return;
-    double *nu_s, *psi_s, *diag_s;
-    eval_prologue<WITH_D>(lds, nu, n, nu_s, psi_s, diag_s);
-    double *fpart = lds + (WITH_D ? 3 : 2) * n;
-
-    double fsum = 0.0;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < b.m; i += stride) {
-        const double Ra = b.Ra[i], Rb = b.Rb[i], g = b.fee[i];
-        const int ia = b.ia[i], ib = b.ib[i];
-        const double pa = nu_s[ia], pb = nu_s[ib];
-        Y2 y;
-        if (KIND == 0) y = pool_cp2(Ra, Rb, g, pa, pb);
-        else if (KIND == 1) y = pool_w2(Ra, Rb, g, b.param[i], pa, pb);
-        else if (KIND == 2) { y = pool_sum2(Ra, Rb, g, pa, pb); if (b.flags && b.flags[i]) { y.ya = 0.0; y.yb = 0.0; } }
-        else y = pool_curve2(Ra, Rb, g, b.param[i], pa, pb);
-        if (y.ya != 0.0 || y.yb != 0.0) {
-            unsafeAtomicAdd(&psi_s[ia], y.ya);
-            unsafeAtomicAdd(&psi_s[ib], y.yb);
-            fsum += pa * y.ya + pb * y.yb;
-        }
-        if (WITH_D) {
-            double da = 0.0, db = 0.0;
-            if (KIND == 0) { da = 0.5 * pa * Ra; db = 0.5 * pb * Rb; }
-            else if (KIND == 1) { const double wa = b.param[i]; da = (1.0 - wa) * pa * Ra; db = wa * pb * Rb; }
-            else if (KIND == 3) curve_diag(Ra, Rb, b.param[i], pa, pb, da, db);
-            if (KIND != 2) { unsafeAtomicAdd(&diag_s[ia], da); unsafeAtomicAdd(&diag_s[ib], db); }
-        }
-    }
-    __syncthreads();
-    eval_epilogue<WITH_D>(fsum, psi_s, diag_s, fpart, n, acc, nslices);
-}
-
-// ------------------------------------------------------------------------------------------
-// K-asset geo-mean buckets, slot-major ("size-class SoA"): column j of pool i at [j*m + i], so
-// each of the 3K loads per lane is coalesced across the wave; 12 + 20 K bytes per pool.
-// ------------------------------------------------------------------------------------------
-template <int K, bool WITH_D>
-__global__ void __launch_bounds__(EVALN_THREADS)
-evaln_kernel(BucketN b, const double *__restrict__ nu, int n, double *__restrict__ acc, int nslices,
-             const DevState *__restrict__ st)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (st && st->status != 0) return;
-    double *nu_s, *psi_s, *diag_s;
-    eval_prologue<WITH_D>(lds, nu, n, nu_s, psi_s, diag_s);
-    double *fpart = lds + (WITH_D ? 3 : 2) * n;
-
-    double fsum = 0.0;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < b.m; i += stride) {
-        double R[K], w[K], p[K], y[K];
-        int t[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            t[j] = b.idx[(size_t)j * b.m + i];
-            R[j] = b.R[(size_t)j * b.m + i];
-            w[j] = b.w[(size_t)j * b.m + i];
-        }
-        const double g = b.fee[i];
-#pragma unroll
-        for (int j = 0; j < K; ++j) p[j] = nu_s[t[j]];
-        pool_geomean_n<K>(R, w, g, p, y);
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            if (y[j] != 0.0) { unsafeAtomicAdd(&psi_s[t[j]], y[j]); fsum += p[j] * y[j]; }
-            if (WITH_D) unsafeAtomicAdd(&diag_s[t[j]], (1.0 - w[j]) * p[j] * R[j]);
-        }
-    }
-    __syncthreads();
-    eval_epilogue<WITH_D>(fsum, psi_s, diag_s, fpart, n, acc, nslices);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -210,7 +270,7 @@ tradesn_kernel(BucketN b, const double *__restrict__ nu, double *__restrict__ de
         w[j] = b.w[(size_t)j * b.m + i];
         p[j] = nu[b.idx[(size_t)j * b.m + i]];
     }
-    pool_geomean_n<K>(R, w, b.fee[i], p, y);
+    pool_geomean_n<K>(R, w, b.fee[i], [&](int j) { return p[j]; }, y);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         delta[(size_t)j * b.m + i] = fmax(-y[j], 0.0);
@@ -463,6 +523,325 @@ update_kernel(UpdArgs a)
         }
         __syncthreads();
         for (int j = tid; j < n; j += nt) a.nu[j] = exp(a.s_t[a.grp[j]] + a.off[j]);
+        if (st.evals >= a.max_evals) st.status = 3;
+    }
+    if (tid == 0) *a.st = st;
+}
+
+// ------------------------------------------------------------------------------------------
+// The nu update, register-resident form (n <= UPD_EPT * 512 = 2048 tokens): the same iteration as
+// update_kernel above (and oracle/cfmm_oracle.c:oracle_step), but every thread owns UPD_EPT
+// group variables and the whole L-BFGS history of those variables in registers; all global
+// loads (state, history, accumulator slices) are issued before the first use, and every dot
+// product is one wave butterfly + one LDS exchange + ONE barrier.  blockDim = 64 * ceil(n / (64 * UPD_EPT)).
+// ------------------------------------------------------------------------------------------
+constexpr int UPD_EPT = 4;
+
+struct BlockRed {
+    double *scratch;            // [2][NRED][16]
+    int parity, wave, lane, nw;
+    static constexpr int NRED = 4;
+    __device__ __forceinline__ BlockRed(double *s) : scratch(s), parity(0)
+    {
+        wave = threadIdx.x >> 6; lane = threadIdx.x & 63; nw = blockDim.x >> 6;
+    }
+    // NS sums followed by NM maxima; result in every thread
+    template <int NS, int NM>
+    __device__ __forceinline__ void run(double (&v)[NS + NM])
+    {
+        static_assert(NS + NM <= NRED, "BlockRed: too many values");
+        double *sl = scratch + parity * (NRED * 16);
+        parity ^= 1;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[k] = wave_allsum(v[k]);
+#pragma unroll
+        for (int k = NS; k < NS + NM; ++k) v[k] = wave_allmax(v[k]);
+        if (nw == 1) return;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NS + NM; ++k) sl[k * 16 + wave] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { double r = 0.0; for (int w = 0; w < nw; ++w) r += sl[k * 16 + w]; v[k] = r; }
+#pragma unroll
+        for (int k = NS; k < NS + NM; ++k) { double r = sl[k * 16]; for (int w = 1; w < nw; ++w) r = fmax(r, sl[k * 16 + w]); v[k] = r; }
+    }
+    __device__ __forceinline__ double sum(double x) { double v[1] = {x}; run<1, 0>(v); return v[0]; }
+};
+
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT)
+update_reg_kernel(UpdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int E = UPD_EPT;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int n = a.n, ng = a.ng, M = a.M;
+    double *q = lds;                         // [ng]
+    double *q2 = lds + ng;                   // [ng]
+    BlockRed red(lds + 2 * ng);              // [2][4][16]
+    const int stride = acc_stride(n);
+    const bool ties = (ng != n);
+
+    DevState st = *a.st;
+    if (st.status != 0) return;
+
+    // ---- loads, all issued up front ----------------------------------------------------------
+    bool gin[E], tin[E];
+    int gr[E], tj[E];
+    double s[E], s_t[E], Gs[E], d[E], Ds[E], glo[E], ghi[E];
+    double Sx[MAX_MEMORY][E], Yx[MAX_MEMORY][E], rho_old[MAX_MEMORY];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        gr[e] = tid + e * nt; gin[e] = gr[e] < ng;
+        const int r = gin[e] ? gr[e] : 0;
+        s[e] = a.s[r]; s_t[e] = a.s_t[r]; Gs[e] = a.Gs[r]; d[e] = a.d[r]; Ds[e] = a.Ds[r];
+        glo[e] = a.glo[r]; ghi[e] = a.ghi[r];
+    }
+#pragma unroll
+    for (int k = 0; k < MAX_MEMORY; ++k) {
+        const bool have = k < st.hist;
+        const int slot = have ? (st.head - 1 - k + 2 * M) % M : 0;
+        rho_old[k] = have ? a.rho[slot] : 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int r = gin[e] ? gr[e] : 0;
+            Sx[k][e] = have ? a.S[(size_t)slot * n + r] : 0.0;
+            Yx[k][e] = have ? a.Y[(size_t)slot * n + r] : 0.0;
+        }
+    }
+    double psi[E], dg[E], nuj[E], hj[E], cj[E], offj[E];
+    int ct[E], grp[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        tj[e] = tid + e * nt; tin[e] = tj[e] < n;
+        const int j = tin[e] ? tj[e] : 0;
+        nuj[e] = a.nu[j]; hj[e] = a.h[j]; cj[e] = a.c[j]; offj[e] = a.off[j]; ct[e] = a.ctype[j]; grp[e] = a.grp[j];
+        psi[e] = 0.0; dg[e] = 0.0;
+    }
+    for (int sl = 0; sl < a.nslices; ++sl) {
+        const double *base = a.acc + (size_t)sl * stride;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int j = tin[e] ? tj[e] : 0;
+            psi[e] += base[j];
+            if (st.first) dg[e] += base[n + 8 + j];
+        }
+    }
+    double fpools = 0.0;
+    if (tid < a.nslices) fpools = a.acc[(size_t)tid * stride + n];
+    // the accumulators are consumed: clear them for the next evaluation
+    for (int sl = 0; sl < a.nslices; ++sl) {
+        double *base = a.acc + (size_t)sl * stride;
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (tin[e]) { base[tj[e]] = 0.0; if (st.first) base[n + 8 + tj[e]] = 0.0; }
+    }
+    if (tid < a.nslices) a.acc[(size_t)tid * stride + n] = 0.0;
+
+    // ---- A. residuals, group gradient at the trial point -----------------------------------------
+    if (ties) {
+        for (int r = tid; r < ng; r += nt) { q[r] = 0.0; q2[r] = 0.0; }
+        __syncthreads();
+    }
+    double Gs_t[E];
+    double A[4] = {fpools, 0.0, 0.0, 0.0};       // f_lin, gapv | viol, scale
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        Gs_t[e] = 0.0;
+        if (tin[e]) {
+            const double rj = psi[e] + hj[e];
+            A[0] += (nuj[e] - cj[e]) * hj[e];
+            A[1] += (nuj[e] - cj[e]) * rj;
+            A[2] = fmax(A[2], ct[e] == 0 ? fmax(-rj, 0.0) : (ct[e] == 1 ? fabs(rj) : 0.0));
+            A[3] = fmax(A[3], fmax(fabs(psi[e]), fabs(hj[e])));
+            if (ties) {
+                unsafeAtomicAdd(&q[grp[e]], nuj[e] * rj);
+                if (st.first) unsafeAtomicAdd(&q2[grp[e]], dg[e]);
+            } else {
+                Gs_t[e] = nuj[e] * rj;
+                if (st.first) Ds[e] = dg[e];
+            }
+        }
+    }
+    red.run<2, 2>(A);
+    if (ties) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (gin[e]) { Gs_t[e] = q[gr[e]]; if (st.first) Ds[e] = q2[gr[e]]; }
+        __syncthreads();
+    }
+    const double f_t = A[0], gapv = A[1], viol = A[2], scale = A[3];
+    st.evals += 1;
+
+    // ---- B. accept test ------------------------------------------------------------------------
+    bool accept = st.first != 0;
+    double sv[E], yv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { sv[e] = gin[e] ? s_t[e] - s[e] : 0.0; yv[e] = gin[e] ? Gs_t[e] - Gs[e] : 0.0; }
+    double B[4] = {0.0, 0.0, 0.0, 0.0};           // Gs.ds, Gs_t.ds | s.y, (unused)
+    if (!st.first) {
+        double C[3] = {0.0, 0.0, 0.0};            // s.s, y.y folded into a second reduction below
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (gin[e]) {
+            B[0] += Gs[e] * sv[e]; B[1] += Gs_t[e] * sv[e]; B[2] += sv[e] * yv[e]; B[3] += sv[e] * sv[e];
+            C[0] += yv[e] * yv[e];
+        }
+        red.run<4, 0>(B);
+        accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * B[0]) ||
+                                  (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && B[1] <= 0.8 * fabs(B[0])));
+        if (accept) {
+            const double yy = red.sum(C[0]);
+            C[1] = yy;
+            B[1] = yy;                            // keep: B[2] = s.y, B[3] = s.s, B[1] = y.y
+        }
+    }
+
+    bool new_dir = false;
+    if (!accept) {
+        st.t_step *= 0.5;
+        st.nrej += 1;
+        if (st.t_step < 1e-9) st.status = 2;
+    } else {
+        // ---- C. curvature pair, move the accepted point ---------------------------------------
+        bool pair_ok = false;
+        double rho_new = 0.0;
+        if (!st.first) {
+            double *svg = a.S + (size_t)st.head * n, *yvg = a.Y + (size_t)st.head * n;
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (gin[e]) { svg[gr[e]] = sv[e]; yvg[gr[e]] = yv[e]; }
+            if (B[2] > 1e-12 * sqrt(B[3]) * sqrt(B[1])) {
+                pair_ok = true;
+                rho_new = 1.0 / B[2];
+                if (tid == 0) a.rho[st.head] = rho_new;
+                st.head = (st.head + 1) % M;
+                if (st.hist < M) st.hist += 1;
+            }
+            st.iters += 1;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (gin[e]) { s[e] = s_t[e]; Gs[e] = Gs_t[e]; a.s[gr[e]] = s[e]; a.Gs[gr[e]] = Gs[e]; if (st.first) a.Ds[gr[e]] = Ds[e]; }
+            if (tin[e]) { a.psi_acc[tj[e]] = psi[e]; a.nu_acc[tj[e]] = nuj[e]; }
+        }
+        st.f = f_t;
+        st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
+        st.infeas = viol / fmax(scale, 1e-300);
+        st.primal = f_t - gapv;                   // c'psi = g - (nu - c)'(psi + h)
+        bool act[E];
+        double D0[3] = {0.0, 0.0, 0.0};           // pg, |q|^2
+        double qv[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            act[e] = true; qv[e] = 0.0;
+            if (gin[e]) {
+                const double G = Gs[e];
+                double v = G;
+                if (glo[e] == ghi[e]) v = 0.0;
+                else if (s[e] <= glo[e] + 1e-14) v = fmin(G, 0.0);
+                else if (s[e] >= ghi[e] - 1e-14) v = fmax(G, 0.0);
+                D0[0] += fabs(v);
+                act[e] = is_active(s[e], glo[e], ghi[e], G);
+                qv[e] = act[e] ? 0.0 : G;
+                D0[1] += qv[e] * qv[e];
+            }
+        }
+        { double t2[2] = {D0[0], D0[1]}; red.run<2, 0>(t2); D0[0] = t2[0]; D0[1] = t2[1]; }
+        st.pg = D0[0] / fmax(1.0, fabs(f_t));
+        const double gp_sq = D0[1];
+        const bool was_first = st.first != 0;
+        st.first = 0;
+        const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
+        if (conv) {
+            st.status = 1;
+        } else {
+            // ---- D. two-loop recursion with the diagonal metric; pair 0 = the new pair ------------
+            new_dir = true;
+            // how many of the prefetched (old) pairs are still in the window
+            const int old_hist = was_first ? 0 : (pair_ok ? (st.hist - 1) : st.hist);
+            double alpha_new = 0.0, alpha[MAX_MEMORY];
+            if (pair_ok) {
+                double dt = 0.0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) dt += sv[e] * qv[e];
+                alpha_new = rho_new * red.sum(dt);
+#pragma unroll
+                for (int e = 0; e < E; ++e) qv[e] -= alpha_new * yv[e];
+            }
+#pragma unroll
+            for (int k = 0; k < MAX_MEMORY; ++k) {
+                alpha[k] = 0.0;
+                if (k < old_hist) {
+                    double dt = 0.0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) dt += Sx[k][e] * qv[e];
+                    alpha[k] = rho_old[k] * red.sum(dt);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) qv[e] -= alpha[k] * Yx[k][e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double H = Ds[e] + fmax(Gs[e], 0.0);
+                qv[e] = (gin[e] && H > 0.0) ? qv[e] / H : 0.0;
+            }
+#pragma unroll
+            for (int k = MAX_MEMORY - 1; k >= 0; --k) {
+                if (k < old_hist) {
+                    double dt = 0.0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) dt += Yx[k][e] * qv[e];
+                    const double beta = rho_old[k] * red.sum(dt);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) qv[e] += Sx[k][e] * (alpha[k] - beta);
+                }
+            }
+            if (pair_ok) {
+                double dt = 0.0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) dt += yv[e] * qv[e];
+                const double beta = rho_new * red.sum(dt);
+#pragma unroll
+                for (int e = 0; e < E; ++e) qv[e] += sv[e] * (alpha_new - beta);
+            }
+            double F[2] = {0.0, 0.0};              // d.G | max |d|
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                d[e] = (gin[e] && !act[e]) ? -qv[e] : 0.0;
+                F[0] += d[e] * Gs[e]; F[1] = fmax(F[1], fabs(d[e]));
+            }
+            red.run<1, 1>(F);
+            if (!(F[0] < 0.0) && gp_sq > 0.0) {       // not a descent direction: restart from the metric
+                st.hist = 0;
+                double mx[1] = {0.0};
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const double H = Ds[e] + fmax(Gs[e], 0.0);
+                    d[e] = (!gin[e] || act[e] || !(H > 0.0)) ? 0.0 : -Gs[e] / H;
+                    mx[0] = fmax(mx[0], fabs(d[e]));
+                }
+                red.run<0, 1>(mx);
+                F[1] = mx[0];
+            }
+            st.t_step = (F[1] > a.max_step) ? a.max_step / F[1] : 1.0;
+        }
+    }
+
+    // ---- E. next trial point -----------------------------------------------------------------
+    if (st.status == 0) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (gin[e]) {
+            double v = s[e] + st.t_step * d[e];
+            v = fmax(v, glo[e]);
+            v = fmin(v, ghi[e]);
+            a.s_t[gr[e]] = v;
+            q[gr[e]] = v;
+            if (new_dir) a.d[gr[e]] = d[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (tin[e]) a.nu[tj[e]] = exp(q[grp[e]] + offj[e]);
         if (st.evals >= a.max_evals) st.status = 3;
     }
     if (tid == 0) *a.st = st;

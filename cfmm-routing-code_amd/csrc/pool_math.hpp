@@ -10,6 +10,10 @@
 
 namespace cfmm {
 
+#ifndef GM_SCHED_BARRIER
+#define GM_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 struct Y2 { double ya, yb; };
 
 // Constant product sqrt(xy)  (Uniswap v2: arbitrage.py:68-70, equal-weight cp.geo_mean).
@@ -138,14 +142,14 @@ __device__ __forceinline__ void curve_diag(double Ra, double Rb, double al, doub
 //     F(t) = sum_j w_j f(t - a_j),   f(u) = u (u<0) | 0 (0<=u<=-lg) | u + lg (u>-lg)
 // is piecewise linear and non-decreasing: evaluate it at its 2K breakpoints, keep the bracketing
 // pair, interpolate.  O(K^2) flops, K logs, 1 exp, no sort, no data-dependent loop.
-template <int K>
+template <int K, class PriceOf>
 __device__ __forceinline__ void pool_geomean_n(const double (&R)[K], const double (&w)[K], double g,
-                                               const double (&p)[K], double (&y)[K])
+                                               PriceOf price, double (&y)[K])
 {
     double a[K];
     const double lg = log(g);
 #pragma unroll
-    for (int j = 0; j < K; ++j) a[j] = log(R[j] * p[j] / w[j]);
+    for (int j = 0; j < K; ++j) { a[j] = log(R[j] * price(j) / w[j]); GM_SCHED_BARRIER(); }
     double tL = -1.7976931348623157e308, fL = 0.0, tR = 1.7976931348623157e308, fR = 0.0;
 #pragma unroll
     for (int b = 0; b < 2 * K; ++b) {
@@ -158,6 +162,7 @@ __device__ __forceinline__ void pool_geomean_n(const double (&R)[K], const doubl
         }
         if (f <= 0.0 && t > tL) { tL = t; fL = f; }
         if (f >= 0.0 && t < tR) { tR = t; fR = f; }
+        GM_SCHED_BARRIER();
     }
     double t;
     if (fL == 0.0) t = tL;
@@ -166,9 +171,10 @@ __device__ __forceinline__ void pool_geomean_n(const double (&R)[K], const doubl
     const double mu = exp(t);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        const double hi = mu * w[j] / p[j], lo = g * hi;
+        const double hi = mu * w[j] / price(j), lo = g * hi;
         const double x = R[j] < lo ? lo : (R[j] > hi ? hi : R[j]);
         y[j] = (x < R[j]) ? (R[j] - x) : (R[j] - x) / g;
+        GM_SCHED_BARRIER();
     }
 }
 

@@ -60,7 +60,7 @@ typedef struct {
     double armijo;          /* sufficient-decrease constant (1e-4)                                 */
     double max_step;        /* cap on one step in log-price (2.0)                                  */
     int32_t max_evals;      /* cap on dual evaluations (2000)                                      */
-    int32_t memory;         /* L-BFGS pairs kept, 1..16 (8)                                        */
+    int32_t memory;         /* L-BFGS pairs kept, 1..8 (8)                                         */
     int32_t iters_per_graph;/* outer iterations captured per hipGraph replay (8)                   */
     int32_t pg_rule;        /* 1: stop on the projected-gradient value <= tol_gap instead (used when
                                constant-sum pools are tied: psi then lacks their fill)           */
@@ -125,9 +125,11 @@ int cfmm_get_tradesN(cfmm_ctx *ctx, int k, double *delta, double *lambda);
 int cfmm_comm_unique_id(void *uid128);
 int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128);
 
-/* measurement hooks (bench.py): time `reps` back-to-back launches of the dominant kernel of
- * bucket `kind` (or -k for the k-asset bucket) with HIP events on the library's stream;
- * returns the average seconds per launch in *sec_per_launch. */
+/* measurement hooks (bench.py): time `reps` back-to-back launches of the fused evaluation kernel
+ * with HIP events on the library's stream, over every bucket (kind = CFMM_TIME_ALL: exactly the
+ * launch one dual evaluation makes) or restricted to one bucket (kind = CFMM_POOL_*, or -k for
+ * the k-asset bucket); returns the average seconds per launch in *sec_per_launch. */
+#define CFMM_TIME_ALL 100
 int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_launch);
 int64_t cfmm_pool_count(cfmm_ctx *ctx);
 void *cfmm_stream(cfmm_ctx *ctx);                 /* the hipStream_t the library launches on */
