@@ -38,7 +38,7 @@ TRAFFIC_BYTES = None
 TRAFFIC_NOTE = ("C3's 42.6 MB working set fits the 256 MiB Infinity Cache: back-to-back launches are cache-served; "
                 "profiles/ holds the PMC traffic and the HBM-streaming (>= 1e7 pools) variant")
 
-BYTES_PER_POOL = {"cp2": 32, "w2": 40, "sum2": 32, "curve2": 40}     # SURVEY 8(d); k-asset: 12 + 20 k
+BYTES_PER_POOL = {"cp2": 32, "w2": 40, "sum2": 32, "curve2": 40}     # SURVEY 8(d); k-asset: 20 + 20 k (+ log fee)
 KIND_ID = {"cp2": 0, "w2": 1, "sum2": 2, "curve2": 3}
 
 
@@ -54,7 +54,7 @@ def kernel_table(prob, reps):
             parts.append((f"eval_kernel[{key} only]", KIND_ID[key], m, m * BYTES_PER_POOL[key]))
     for k, b in sorted(net.get("gn", {}).items()):
         m = b["R"].shape[1]
-        parts.append((f"eval_kernel[gn{k} only]", -k, m, m * (12 + 20 * k)))
+        parts.append((f"eval_kernel[gn{k} only]", -k, m, m * (20 + 20 * k)))
     rows = [dict(kernel="eval_kernel", pools=sum(p[2] for p in parts), bytes=sum(p[3] for p in parts),
                  seconds=prob.ctx.time_eval_kernel(_lib.TIME_ALL, reps))]
     for name, code, m, nbytes in parts:

@@ -303,7 +303,7 @@ class Problem:
         return self._ensure_ctx().eval_dual(nu, want_diag)
 
     # -- solve -------------------------------------------------------------------------------
-    def solve(self, tol=1e-6, nu0=None, max_evals=2000, memory=8, iters_per_graph=8, kink_tol=1e-3,
+    def solve(self, tol=1e-6, nu0=None, max_evals=2000, memory=0, iters_per_graph=8, kink_tol=1e-3,
               max_rounds=6, warm_start=False):
         if self.utility is None:
             raise ValueError("no utility set")

@@ -83,9 +83,10 @@ struct cfmm_ctx {
     double *S = nullptr, *Y = nullptr, *rho = nullptr;
     double *acc = nullptr;
     DevState *st = nullptr;
+    long long *ts = nullptr;           // phase timers (tuning builds)
     DevState *hst = nullptr;          // pinned, 2 slots
     hipEvent_t ev[2] = {nullptr, nullptr}, ev_t0 = nullptr, ev_t1 = nullptr;
-    int nslices = 16;
+    int nslices = 4;
     int eval_grid_mult = 1;
     int eval_blocks_per_cu = 1;        // resident EVAL_THREADS-workgroups per CU (occupancy query at create)
     bool upd_generic = false;          // CFMM_UPDATE_GENERIC=1: force the generic update kernel (A/B testing)
@@ -139,15 +140,15 @@ void free_all(std::vector<void *> &v)
     v.clear();
 }
 
-size_t eval_lds_bytes(int n, bool with_d) { return (size_t)((with_d ? 3 : 2) * n + 16) * sizeof(double); }
-size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 16 * 8 + 8) * sizeof(double); }
+size_t eval_lds_bytes(int n, bool with_d) { return (size_t)eval_lds_doubles(n, with_d) * sizeof(double) + (size_t)(EVAL_THREADS / 64) * 64 * 16; }
+size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 2 * 12 * 16 + 8) * sizeof(double); }
 
 // processing order of the fused evaluation kernel (heaviest first): bucket code = -k for the
 // k-asset geo-mean buckets, CFMM_POOL_* for the two-asset ones
 const int kOrder[N_BUCKETS] = {-8, -7, -6, -5, -4, -3, CFMM_POOL_CURVE2, CFMM_POOL_W2, CFMM_POOL_CP2, CFMM_POOL_SUM2};
 
 // `only` = a bucket code to evaluate that bucket alone (measurement hook), or 0x7fffffff for all
-EvalArgs make_eval_args(cfmm_ctx *ctx, const DevState *st, int only = 0x7fffffff)
+EvalArgs make_eval_args(cfmm_ctx *ctx, int only = 0x7fffffff)
 {
     EvalArgs a = {};
     for (int k = 0; k < CFMM_POOL_KINDS2; ++k) a.b2[k] = ctx->b2[k];
@@ -156,13 +157,13 @@ EvalArgs make_eval_args(cfmm_ctx *ctx, const DevState *st, int only = 0x7fffffff
     for (int q = 0; q < N_BUCKETS; ++q) {
         const int code = kOrder[q];
         const long long m = code < 0 ? ctx->bn[-code].m : ctx->b2[code].m;
-        const int wt = code < 0 ? WTN : WT2;
+        const int wt = wave_tile_pools(code);
         if (only == 0x7fffffff || only == code) tiles += (m + wt - 1) / wt;
         a.tile_end[q] = (int)tiles;
     }
     a.ntiles = (int)tiles;
     a.n = ctx->n; a.nslices = ctx->nslices;
-    a.nu = ctx->nu; a.acc = ctx->acc; a.st = st;
+    a.nu = ctx->nu; a.acc = ctx->acc; a.ts = ctx->ts;
     return a;
 }
 
@@ -190,9 +191,9 @@ void launch_eval(cfmm_ctx *ctx, const EvalArgs &a)
 
 // one dual evaluation of every bucket
 template <bool WITH_D>
-void launch_all_evals(cfmm_ctx *ctx, const DevState *st)
+void launch_all_evals(cfmm_ctx *ctx)
 {
-    launch_eval<WITH_D>(ctx, make_eval_args(ctx, st));
+    launch_eval<WITH_D>(ctx, make_eval_args(ctx));
 }
 
 template <class F>
@@ -227,7 +228,7 @@ UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
     a.S = ctx->S; a.Y = ctx->Y; a.rho = ctx->rho;
     a.st = ctx->st;
     a.tol_gap = o.tol_gap; a.tol_infeas = o.tol_infeas; a.armijo = o.armijo; a.max_step = o.max_step;
-    a.max_evals = o.max_evals; a.pg_rule = o.pg_rule;
+    a.max_evals = o.max_evals; a.pg_rule = o.pg_rule; a.ts = ctx->ts;
     return a;
 }
 
@@ -248,7 +249,7 @@ void launch_update(cfmm_ctx *ctx, const UpdArgs &ua)
 template <bool WITH_D>
 int enqueue_iteration(cfmm_ctx *ctx, const UpdArgs &ua)
 {
-    launch_all_evals<WITH_D>(ctx, ctx->st);
+    launch_all_evals<WITH_D>(ctx);
     if (ctx->n_ranks > 1) {
         const int len = WITH_D ? acc_stride(ctx->n) : ctx->n + 1;
         hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, ctx->n,
@@ -319,7 +320,7 @@ void cfmm_default_opts(cfmm_opts *o)
 {
     std::memset(o, 0, sizeof *o);
     o->tol_gap = 1e-6; o->tol_infeas = 1e-6; o->armijo = 1e-4; o->max_step = 2.0;
-    o->max_evals = 2000; o->memory = 8; o->iters_per_graph = 8;
+    o->max_evals = 2000; o->memory = 0; o->iters_per_graph = 8;
 }
 
 const char *cfmm_last_error(cfmm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -367,12 +368,13 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     rc |= dev_upload<int>(ctx, &ctx->grp, nullptr, n, nullptr);
     double **vecs[] = {&ctx->nu, &ctx->nu_acc, &ctx->psi_acc, &ctx->psi_t, &ctx->nu0, &ctx->s, &ctx->s_t,
                        &ctx->Gs, &ctx->Gs_t, &ctx->d, &ctx->Ds};
-    for (auto v : vecs) rc |= dev_upload<double>(ctx, v, nullptr, n, nullptr);
+    for (auto v : vecs) rc |= dev_upload<double>(ctx, v, nullptr, n + 1, nullptr);     // nu[n] = stop flag
     rc |= dev_upload<double>(ctx, &ctx->S, nullptr, (size_t)MAX_MEMORY * n, nullptr);
     rc |= dev_upload<double>(ctx, &ctx->Y, nullptr, (size_t)MAX_MEMORY * n, nullptr);
     rc |= dev_upload<double>(ctx, &ctx->rho, nullptr, MAX_MEMORY, nullptr);
     rc |= dev_upload<double>(ctx, &ctx->acc, nullptr, (size_t)ctx->nslices * acc_stride(n), nullptr);
     rc |= dev_upload<DevState>(ctx, &ctx->st, nullptr, 1, nullptr);
+    rc |= dev_upload<long long>(ctx, &ctx->ts, nullptr, 64 + 8 * 4096, nullptr);
     if (rc) return bail(CFMM_E_HIP);
     TRY_C(hipHostMalloc((void **)&ctx->hst, 2 * sizeof(DevState), hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) TRY_C(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
@@ -407,7 +409,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     for (auto &v : ctx->bnmem) free_all(v);
     void *ptrs[] = {ctx->c, ctx->h, ctx->off, ctx->glo, ctx->ghi, ctx->ctype, ctx->grp, ctx->nu, ctx->nu_acc, ctx->psi_acc,
                     ctx->psi_t, ctx->nu0, ctx->s, ctx->s_t, ctx->Gs, ctx->Gs_t, ctx->d, ctx->Ds, ctx->S, ctx->Y, ctx->rho,
-                    ctx->acc, ctx->st};
+                    ctx->acc, ctx->st, ctx->ts};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->hst) (void)hipHostFree(ctx->hst);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -474,10 +476,23 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
     if (m > 0) {
         auto &tr = ctx->bnmem[k];
         int rc = 0;
-        rc |= dev_upload<int>(ctx, (int **)&b.idx, idx, (size_t)k * m, &tr);
-        rc |= dev_upload<double>(ctx, (double **)&b.R, R, (size_t)k * m, &tr);
-        rc |= dev_upload<double>(ctx, (double **)&b.w, w, (size_t)k * m, &tr);
+        // the ABI hands columns slot-major [k][m]; the device layout is pool-major [m][k] (leg per lane)
+        std::vector<int32_t> tidx((size_t)k * m);
+        std::vector<double> tR((size_t)k * m), tw((size_t)k * m);
+        for (int j = 0; j < k; ++j)
+            for (int64_t i = 0; i < m; ++i) {
+                tidx[(size_t)i * k + j] = idx[(size_t)j * m + i];
+                tR[(size_t)i * k + j] = R[(size_t)j * m + i];
+                tw[(size_t)i * k + j] = w[(size_t)j * m + i];
+            }
+        rc |= dev_upload<int>(ctx, (int **)&b.idx, tidx.data(), (size_t)k * m, &tr);
+        rc |= dev_upload<double>(ctx, (double **)&b.R, tR.data(), (size_t)k * m, &tr);
+        rc |= dev_upload<double>(ctx, (double **)&b.w, tw.data(), (size_t)k * m, &tr);
+        if (!rc) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the staging vectors die at scope end
         rc |= dev_upload<double>(ctx, (double **)&b.fee, fee, m, &tr);
+        std::vector<double> lf(m);
+        for (int64_t i = 0; i < m; ++i) lf[i] = std::log(fee[i]);
+        rc |= dev_upload<double>(ctx, (double **)&b.lfee, lf.data(), m, &tr);
         if (rc) return CFMM_E_HIP;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -578,8 +593,9 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
     const int n = ctx->n;
     for (int j = 0; j < n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "eval_dual: nu[%d] = %g is not a positive finite price", j, nu[j]);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, nu, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->nu + n, 0, sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
-    if (diag) launch_all_evals<true>(ctx, nullptr); else launch_all_evals<false>(ctx, nullptr);
+    if (diag) launch_all_evals<true>(ctx); else launch_all_evals<false>(ctx);
     const int len = acc_stride(n);
     hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, n, ctx->nslices, 1, (const DevState *)nullptr);
     HIP_TRY(ctx, hipGetLastError());
@@ -603,6 +619,7 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     cfmm_opts o;
     if (opts_in) o = *opts_in; else cfmm_default_opts(&o);
+    if (o.memory == 0) o.memory = ctx->n <= 32 ? 8 : 4;      // auto: tiny problems afford (nearly) full quasi-Newton memory
     if (o.memory < 1 || o.memory > MAX_MEMORY || o.iters_per_graph < 1 || o.iters_per_graph > 256 || o.max_evals < 1)
         return fail(ctx, CFMM_E_ARG, "solve: memory %d, iters_per_graph %d, max_evals %d", o.memory, o.iters_per_graph, o.max_evals);
     if (!ctx->have_utility) return fail(ctx, CFMM_E_STATE, "solve: cfmm_set_utility has not been called");
@@ -735,13 +752,25 @@ int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128)
     return CFMM_OK;
 }
 
+int cfmm_debug_timers(cfmm_ctx *ctx, int64_t *out64)
+{
+    if (!ctx || !out64) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out64, ctx->ts, (64 + 8 * 4096) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemset(ctx->ts, 0, (64 + 8 * 4096) * sizeof(int64_t)));
+    HIP_TRY(ctx, hipMemset(ctx->ts + 40, 0xff, sizeof(int64_t)));      // slot 40 is an atomicMin target
+    return CFMM_OK;
+}
+
 int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_launch)
 {
     if (!ctx || reps < 1 || !sec_per_launch) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_nu) return fail(ctx, CFMM_E_STATE, "time_eval_kernel: no prices set");
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, ctx->nu_acc, ctx->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    const EvalArgs ea = make_eval_args(ctx, nullptr, kind == CFMM_TIME_ALL ? 0x7fffffff : kind);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->nu + ctx->n, 0, sizeof(double), ctx->stream));
+    const EvalArgs ea = make_eval_args(ctx, kind == CFMM_TIME_ALL ? 0x7fffffff : kind);
     if (ea.ntiles == 0) return fail(ctx, CFMM_E_ARG, "time_eval_kernel: bucket %d is empty", kind);
     auto launch = [&]() { launch_eval<false>(ctx, ea); };
     for (int i = 0; i < 3; ++i) launch();

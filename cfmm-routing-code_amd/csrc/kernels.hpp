@@ -14,21 +14,34 @@
 
 namespace cfmm {
 
+// phase timers for kernel tuning (variant builds with -DCFMM_PHASE_TIMERS): thread 0 of block 0
+// stamps {shader cycles, 100 MHz wall clock} pairs into a debug buffer read by cfmm_debug_timers()
+#ifdef CFMM_PHASE_TIMERS
+#define PHASE_STAMP(buf, i) do { if ((buf) && blockIdx.x == 0 && threadIdx.x == 0) { (buf)[2 * (i)] = clock64(); (buf)[2 * (i) + 1] = wall_clock64(); } } while (0)
+#else
+#define PHASE_STAMP(buf, i) do { } while (0)
+#endif
+
 #ifndef EVAL_THREADS_DEF
-#define EVAL_THREADS_DEF 512
+#define EVAL_THREADS_DEF 1024
 #endif
 constexpr int EVAL_THREADS = EVAL_THREADS_DEF;     // fused evaluation kernel: waves per workgroup x 64
 #ifndef EVAL_WAVES_PER_SIMD
-#define EVAL_WAVES_PER_SIMD 2             // min waves per SIMD the register allocator must leave room for
+#define EVAL_WAVES_PER_SIMD 4             // min waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
 #endif
 constexpr int UPD_THREADS = 1024;
 constexpr int MAX_MEMORY = 8;         // L-BFGS pairs kept (register-resident in update_kernel)
 
-// the fused evaluation kernel walks "wave-tiles": WT2 consecutive pools of a two-asset bucket (two
-// per lane) or WTN consecutive pools of a K-asset bucket (one per lane); buckets are laid out in
+// the fused evaluation kernel walks "wave-tiles": WT_LIGHT / WT_HEAVY consecutive pools of a two-asset bucket
+// (two / one per lane) or 64 / K consecutive pools of a K-asset bucket (one LEG per lane); buckets are laid out in
 // the tile space heaviest first, so the light tiles fill the tail of the launch
-constexpr int WT2 = 128;
-constexpr int WTN = 64;
+constexpr int WT_LIGHT = 128;         // cp2, sum2: two pools per lane
+constexpr int WT_HEAVY = 64;          // w2, curve2: one pool per lane
+__host__ __device__ constexpr int wave_tile_pools(int code)     // code: CFMM_POOL_* kind, or -k
+{
+    return code < 0 ? 64 / (-code)                     // k-asset geo-mean: one LEG per lane
+                    : ((code == 0 || code == 2) ? WT_LIGHT : WT_HEAVY);
+}
 constexpr int N_BUCKETS = 10;         // gn8 gn7 gn6 gn5 gn4 gn3 curve2 w2 cp2 sum2 (processing order)
 
 struct DevState {
@@ -46,6 +59,7 @@ struct BucketN {
     long long m;
     const int *idx;
     const double *R, *w, *fee;
+    const double *lfee;               // log(fee), computed once at upload (+8 B/pool instead of one log per wave-tile)
 };
 
 struct EvalArgs {
@@ -53,50 +67,78 @@ struct EvalArgs {
     BucketN bn[6];                    // bn[k - 3], k = 3..8
     int tile_end[N_BUCKETS];          // cumulative wave-tile counts in processing order
     int ntiles, n, nslices, pad;
-    const double *nu;
+    const double *nu;                 // [n + 1]: prices, then the stop flag (non-zero = solve has ended)
     double *acc;
-    const DevState *st;
+    long long *ts;                    // phase timers (tuning builds only)
 };
+
+// LDS carve of eval_kernel (doubles), 16-byte aligned pieces; then 64 double2 per wave
+__host__ __device__ inline int eval_lds_doubles(int n, bool with_d) { return (((with_d ? 3 : 2) * n + 2 + 16) + 1) & ~1; }
 
 // accumulator slice layout: [0,n) psi | [n] sum arb | [n+8, 2n+8) diag
 __host__ __device__ inline int acc_stride(int n) { return 2 * n + 8; }
 
-__device__ __forceinline__ double wave_sum(double v)
+// wave64 butterflies on the VALU cross-lane paths (DPP within a row of 16 lanes, then gfx950's
+// v_permlane16_swap / v_permlane32_swap across rows): every lane ends up with the result, no LDS
+// traffic (the __shfl_xor forms compile to ds_bpermute_b32 pairs, ~6x the latency)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max(double v)
+// the two halves of an xor-16 / xor-32 exchange: x = own-or-partner, y = partner-or-own
+__device__ __forceinline__ void swap16_f64(double v, double &x, double &y)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-    return v;
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    x = __hiloint2double(b[0], a[0]); y = __hiloint2double(b[1], a[1]);
 }
-// butterfly forms: every lane ends up with the result
+__device__ __forceinline__ void swap32_f64(double v, double &x, double &y)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    x = __hiloint2double(b[0], a[0]); y = __hiloint2double(b[1], a[1]);
+}
 __device__ __forceinline__ double wave_allsum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    double x, y;
+    v += dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]   lane ^ 1
+    v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]   lane ^ 2
+    v += dpp_f64<0x141>(v);     // row_half_mirror       lane ^ 4 (quads are uniform by now)
+    v += dpp_f64<0x140>(v);     // row_mirror            lane ^ 8
+    swap16_f64(v, x, y); v = x + y;
+    swap32_f64(v, x, y); v = x + y;
     return v;
 }
 __device__ __forceinline__ double wave_allmax(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    double x, y;
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x140>(v));
+    swap16_f64(v, x, y); v = fmax(x, y);
+    swap32_f64(v, x, y); v = fmax(x, y);
     return v;
 }
+__device__ __forceinline__ double wave_sum(double v) { return wave_allsum(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_allmax(v); }
 
 // ------------------------------------------------------------------------------------------
-// one wave-tile of a two-asset bucket: lane l solves pools i0 + l and i0 + 64 + l.  All ten
-// column loads are issued before the first use (5 x 512 B coalesced per wave and pool row).
+// one wave-tile of a two-asset bucket: lane l solves pools i0 + l + 64 u, u < U.  All 5U column
+// loads are issued before the first use (each 512 B coalesced per wave).
 // 32 B (CP2, SUM2) or 40 B (W2, CURVE2) of HBM per pool, read once.
 // ------------------------------------------------------------------------------------------
 template <int KIND, bool WITH_D>
 __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, const double *nu_s,
                                       double *psi_s, double *diag_s, double &fsum)
 {
-    constexpr int U = WT2 / 64;
+    constexpr int U = wave_tile_pools(KIND) / 64;
     double Ra[U], Rb[U], g[U], prm[U];
     int ia[U], ib[U], fl[U];
     bool live[U];
@@ -135,36 +177,70 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
 }
 
 // ------------------------------------------------------------------------------------------
-// one wave-tile of a K-asset geo-mean bucket, slot-major ("size-class SoA"): column j of pool i
-// at [j*m + i], so each of the 3K loads per lane is coalesced across the wave; 12 + 20 K bytes
-// per pool.
+// one wave-tile of a K-asset geo-mean bucket, LEG PER LANE: the K legs of a pool sit on K
+// consecutive lanes (64 / K pools per wave) and are stored pool-major ("CSR with constant row
+// length": leg j of pool i at [i*K + j]), so a wave's idx / R / w loads are three fully coalesced
+// 256-512 B transactions for ANY K; 20 + 20 K bytes per pool (fee, log fee, K x {id, R, w}), read once.
+//
+// KKT (pool_math.hpp): x_j(t) = R_j e^{f(t - a_j)}, a_j = log(R_j p_j / w_j), and the residual
+// F(t) = sum_j w_j f(t - a_j) is non-decreasing, so leg j is WITHDRAWN at the root t* iff
+// F(a_j) > 0 and DEPOSITED iff F(a_j - lg) < 0: every lane evaluates F at its own two kinks
+// (K terms each, the (a, w) pairs of its pool exchanged through a wave-private LDS strip), learns
+// its own membership, and the root follows from one K-lane sum:
+//     t* = [sum_W w_j a_j + sum_D w_j (a_j - lg)] / [sum_W w_j + sum_D w_j].
+// No sort, no bracket scan, no data-dependent loop, ~40 VGPRs; the serial chain per wave is
+// ~350 instructions instead of ~2000 for one-pool-per-lane at K = 8.
 // ------------------------------------------------------------------------------------------
+template <int K>
+__host__ __device__ constexpr int pools_per_wave() { return 64 / K; }
+
 template <int K, bool WITH_D>
-__device__ __forceinline__ void tilen(const BucketN &b, long long i0, int lane, const double *nu_s,
-                                      double *psi_s, double *diag_s, double &fsum)
+__device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, const double *nu_s,
+                                      double *psi_s, double *diag_s, double2 *xs, double &fsum)
 {
-    long long i = i0 + lane;
-    const bool live = i < b.m;
-    i = live ? i : b.m - 1;
-    double R[K], w[K], y[K];
-    int t[K];
+    constexpr int P = pools_per_wave<K>();
+    const int g = lane / K, j = lane - g * K;
+    const long long pool = tb * P + g;
+    const bool live = (g < P) && (pool < b.m);
+    const long long leg = live ? pool * K + j : 0;
+    const int tok = b.idx[leg];
+    const double R = b.R[leg], w = b.w[leg];
+    const double fee = b.fee[live ? pool : 0];
+    const double lg = b.lfee[live ? pool : 0];
+    const double p = nu_s[tok];
+    const double a = log(R * p * rcp_nr(w));
+    const int gb = (g < P ? g : 0) * K;
+    xs[lane] = make_double2(a, w);                     // ds_write_b128; same-wave LDS ops stay in order
+    __builtin_amdgcn_wave_barrier();
+    const double t1 = a, t2 = a - lg;
+    double f1 = 0.0, f2 = 0.0;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        t[j] = b.idx[(size_t)j * b.m + i];
-        R[j] = b.R[(size_t)j * b.m + i];
-        w[j] = b.w[(size_t)j * b.m + i];
+    for (int k = 0; k < K; ++k) {
+        const double2 v = xs[gb + k];
+        const double u1 = t1 - v.x, u2 = t2 - v.x;
+        f1 += v.y * (fmin(u1, 0.0) + fmax(u1 + lg, 0.0));
+        f2 += v.y * (fmin(u2, 0.0) + fmax(u2 + lg, 0.0));
     }
-    const double g = b.fee[i];
-    // prices are gathered from LDS twice (here and for the scatter) instead of being held in
-    // registers across the solve: an LDS read is cheaper than 2K live VGPRs
-    pool_geomean_n<K>(R, w, g, [&](int j) { return nu_s[t[j]]; }, y);
-    if (live) {
+    const bool wd = f1 > 0.0;                           // withdrawn at the root: t* < a_j
+    const bool dp = f2 < 0.0;                           // deposited at the root: t* > a_j - lg
+    const double den_j = (wd || dp) ? w : 0.0;
+    const double num_j = wd ? w * t1 : (dp ? w * t2 : 0.0);
+    __builtin_amdgcn_wave_barrier();
+    xs[lane] = make_double2(num_j, den_j);
+    __builtin_amdgcn_wave_barrier();
+    double num = 0.0, den = 0.0;
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const double pj = nu_s[t[j]];
-            if (y[j] != 0.0) { unsafeAtomicAdd(&psi_s[t[j]], y[j]); fsum += pj * y[j]; }
-            if (WITH_D) unsafeAtomicAdd(&diag_s[t[j]], (1.0 - w[j]) * pj * R[j]);
-        }
+    for (int k = 0; k < K; ++k) { const double2 v = xs[gb + k]; num += v.x; den += v.y; }
+    __builtin_amdgcn_wave_barrier();
+    double y = 0.0;
+    if (den > 0.0 && (wd || dp)) {
+        const double t = num * rcp_nr(den);
+        const double rx = -R * expm1(wd ? t - t1 : t - t2);    // R - x,  x = R e^{f(t - a_j)}
+        y = wd ? rx : rx * rcp_nr(fee);
+    }
+    if (live) {
+        if (y != 0.0) { unsafeAtomicAdd(&psi_s[tok], y); fsum += p * y; }
+        if (WITH_D) unsafeAtomicAdd(&diag_s[tok], (1.0 - w) * p * R);
     }
 }
 
@@ -172,7 +248,7 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long i0, int lane, 
 // The dual evaluation, ONE launch for every bucket:  psi(nu) = sum_i A_i (L_i - D_i),
 // sum_i arb_i(A_i' nu), optionally the diagonal metric.                reference: arbitrage.py:54
 //
-// LDS: nu_s[n] | psi_s[n] | (diag_s[n]) | fpart[8].  Every wave walks its own wave-tiles
+// LDS: psi_s[n] | (diag_s[n]) | nu_s[n + 1] | fpart[16] | wave-private exchange strips 64 x 16 B.  Every wave walks its own wave-tiles
 // (tile = pass * W + wave_in_block * gridDim + block, W = waves in the grid): the waves of one
 // workgroup take tiles W/8 apart, so each CU holds the same mix of ALU-heavy geo-mean tiles and
 // streaming constant-product tiles; no barrier between the prologue and the epilogue.  The
@@ -184,42 +260,64 @@ __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 eval_kernel(EvalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (a.st && a.st->status != 0) return;
+    PHASE_STAMP(a.ts, 0);
+#ifdef CFMM_PHASE_TIMERS
+    if (a.ts && threadIdx.x == 0) atomicMin((unsigned long long *)&a.ts[40], (unsigned long long)wall_clock64());    // first block start
+#endif
     const int n = a.n;
-    double *nu_s = lds, *psi_s = lds + n, *diag_s = lds + 2 * n;
-    double *fpart = lds + (WITH_D ? 3 : 2) * n;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    double *psi_s = lds, *diag_s = lds + n;
+    double *nu_s = lds + (WITH_D ? 2 : 1) * n;          // [n + 1]
+    double *fpart = nu_s + n + 2;                       // [16]
+    double2 *xs = reinterpret_cast<double2 *>(lds + eval_lds_doubles(n, WITH_D)) + 64 * (threadIdx.x >> 6);   // wave-private [64]
+    // prices and the stop flag arrive in ONE round trip (the flag rides behind the prices)
+    for (int j = threadIdx.x; j <= n; j += blockDim.x) {
         nu_s[j] = a.nu[j];
-        psi_s[j] = 0.0;
-        if (WITH_D) diag_s[j] = 0.0;
+        if (j < n) { psi_s[j] = 0.0; if (WITH_D) diag_s[j] = 0.0; }
     }
     __syncthreads();
+    if (nu_s[n] != 0.0) return;
+    PHASE_STAMP(a.ts, 1);
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = gridDim.x * (blockDim.x >> 6);
     double fsum = 0.0;
+#ifdef CFMM_PHASE_TIMERS
+    int nlog = 0;
+#endif
     for (int t = wib * gridDim.x + blockIdx.x; t < a.ntiles; t += W) {
         int bk = 0;
 #pragma unroll
         for (int q = 0; q < N_BUCKETS - 1; ++q) bk += (t >= a.tile_end[q]) ? 1 : 0;
         const int tb = t - (bk ? a.tile_end[bk - 1] : 0);
+#ifdef CFMM_PHASE_TIMERS
+        const long long tc0 = clock64();
+#endif
         switch (bk) {
-        case 0: tilen<8, WITH_D>(a.bn[5], (long long)tb * WTN, lane, nu_s, psi_s, diag_s, fsum); break;
-        case 1: tilen<7, WITH_D>(a.bn[4], (long long)tb * WTN, lane, nu_s, psi_s, diag_s, fsum); break;
-        case 2: tilen<6, WITH_D>(a.bn[3], (long long)tb * WTN, lane, nu_s, psi_s, diag_s, fsum); break;
-        case 3: tilen<5, WITH_D>(a.bn[2], (long long)tb * WTN, lane, nu_s, psi_s, diag_s, fsum); break;
-        case 4: tilen<4, WITH_D>(a.bn[1], (long long)tb * WTN, lane, nu_s, psi_s, diag_s, fsum); break;
-        case 5: tilen<3, WITH_D>(a.bn[0], (long long)tb * WTN, lane, nu_s, psi_s, diag_s, fsum); break;
-        case 6: tile2<3, WITH_D>(a.b2[3], (long long)tb * WT2, lane, nu_s, psi_s, diag_s, fsum); break;
-        case 7: tile2<1, WITH_D>(a.b2[1], (long long)tb * WT2, lane, nu_s, psi_s, diag_s, fsum); break;
-        case 8: tile2<0, WITH_D>(a.b2[0], (long long)tb * WT2, lane, nu_s, psi_s, diag_s, fsum); break;
-        default: tile2<2, WITH_D>(a.b2[2], (long long)tb * WT2, lane, nu_s, psi_s, diag_s, fsum); break;
+        case 0: tilen<8, WITH_D>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
+        case 1: tilen<7, WITH_D>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
+        case 2: tilen<6, WITH_D>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
+        case 3: tilen<5, WITH_D>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
+        case 4: tilen<4, WITH_D>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
+        case 5: tilen<3, WITH_D>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
+        case 6: tile2<3, WITH_D>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum); break;
+        case 7: tile2<1, WITH_D>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum); break;
+        case 8: tile2<0, WITH_D>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum); break;
+        default: tile2<2, WITH_D>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum); break;
         }
+#ifdef CFMM_PHASE_TIMERS
+        if (a.ts && lane == 0) {                       // per-wave tile log: ts[64 + 8 gw + i] = bucket << 48 | cycles
+            const int gw = blockIdx.x * (blockDim.x >> 6) + wib;
+            if (gw < 4096 && nlog < 8) a.ts[64 + 8 * gw + nlog] = ((long long)(bk + 1) << 48) | (clock64() - tc0);
+            ++nlog;
+        }
+#endif
     }
+    PHASE_STAMP(a.ts, 2);
     fsum = wave_sum(fsum);
     if (lane == 0) fpart[wib] = fsum;
     __syncthreads();
+    PHASE_STAMP(a.ts, 3);
 
     double *base = a.acc + (size_t)(blockIdx.x % a.nslices) * acc_stride(n);
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
@@ -235,6 +333,11 @@ eval_kernel(EvalArgs a)
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) f += fpart[w];
         if (f != 0.0) unsafeAtomicAdd(&base[n], f);
     }
+    PHASE_STAMP(a.ts, 4);
+#ifdef CFMM_PHASE_TIMERS
+    __syncthreads();
+    if (a.ts && threadIdx.x == 0) atomicMax((unsigned long long *)&a.ts[41], (unsigned long long)wall_clock64());    // last block end
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -265,14 +368,14 @@ tradesn_kernel(BucketN b, const double *__restrict__ nu, double *__restrict__ de
     if (i >= b.m) return;
     double R[K], w[K], p[K], y[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        R[j] = b.R[(size_t)j * b.m + i];
-        w[j] = b.w[(size_t)j * b.m + i];
-        p[j] = nu[b.idx[(size_t)j * b.m + i]];
+    for (int j = 0; j < K; ++j) {                      // device layout is pool-major (leg j of pool i at i*K + j)
+        R[j] = b.R[i * K + j];
+        w[j] = b.w[i * K + j];
+        p[j] = nu[b.idx[i * K + j]];
     }
     pool_geomean_n<K>(R, w, b.fee[i], [&](int j) { return p[j]; }, y);
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
+    for (int j = 0; j < K; ++j) {                      // results slot-major, as the C-ABI hands them out
         delta[(size_t)j * b.m + i] = fmax(-y[j], 0.0);
         lambda[(size_t)j * b.m + i] = fmax(y[j], 0.0);
     }
@@ -309,6 +412,7 @@ struct UpdArgs {
     DevState *st;
     double tol_gap, tol_infeas, armijo, max_step;
     int max_evals, pg_rule;
+    long long *ts;                    // phase timers (tuning builds only)
 };
 
 // block-wide reduction of NV sums and NM maxima at once; result broadcast to every thread
@@ -525,7 +629,7 @@ update_kernel(UpdArgs a)
         for (int j = tid; j < n; j += nt) a.nu[j] = exp(a.s_t[a.grp[j]] + a.off[j]);
         if (st.evals >= a.max_evals) st.status = 3;
     }
-    if (tid == 0) *a.st = st;
+    if (tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -540,7 +644,7 @@ constexpr int UPD_EPT = 4;
 struct BlockRed {
     double *scratch;            // [2][NRED][16]
     int parity, wave, lane, nw;
-    static constexpr int NRED = 4;
+    static constexpr int NRED = 12;
     __device__ __forceinline__ BlockRed(double *s) : scratch(s), parity(0)
     {
         wave = threadIdx.x >> 6; lane = threadIdx.x & 63; nw = blockDim.x >> 6;
@@ -580,12 +684,19 @@ update_reg_kernel(UpdArgs a)
     const int n = a.n, ng = a.ng, M = a.M;
     double *q = lds;                         // [ng]
     double *q2 = lds + ng;                   // [ng]
-    BlockRed red(lds + 2 * ng);              // [2][4][16]
+    BlockRed red(lds + 2 * ng);              // [2][12][16]
     const int stride = acc_stride(n);
     const bool ties = (ng != n);
 
+#ifdef CFMM_PHASE_TIMERS
+    const long long c8 = clock64(), w8 = wall_clock64();
+#endif
     DevState st = *a.st;
     if (st.status != 0) return;
+#ifdef CFMM_PHASE_TIMERS
+    if (a.ts && threadIdx.x == 0) { a.ts[16] = c8; a.ts[17] = w8; }
+#endif
+    PHASE_STAMP(a.ts, 9);
 
     // ---- loads, all issued up front ----------------------------------------------------------
     bool gin[E], tin[E];
@@ -607,8 +718,8 @@ update_reg_kernel(UpdArgs a)
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int r = gin[e] ? gr[e] : 0;
-            Sx[k][e] = have ? a.S[(size_t)slot * n + r] : 0.0;
-            Yx[k][e] = have ? a.Y[(size_t)slot * n + r] : 0.0;
+            Sx[k][e] = (have && gin[e]) ? a.S[(size_t)slot * n + r] : 0.0;     // 0 outside: the dots run over all E
+            Yx[k][e] = (have && gin[e]) ? a.Y[(size_t)slot * n + r] : 0.0;
         }
     }
     double psi[E], dg[E], nuj[E], hj[E], cj[E], offj[E];
@@ -620,13 +731,25 @@ update_reg_kernel(UpdArgs a)
         nuj[e] = a.nu[j]; hj[e] = a.h[j]; cj[e] = a.c[j]; offj[e] = a.off[j]; ct[e] = a.ctype[j]; grp[e] = a.grp[j];
         psi[e] = 0.0; dg[e] = 0.0;
     }
-    for (int sl = 0; sl < a.nslices; ++sl) {
-        const double *base = a.acc + (size_t)sl * stride;
+    for (int sl0 = 0; sl0 < a.nslices; sl0 += 4) {     // 4 slices per trip: 4E loads in flight
+        double pp[4][E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int j = tin[e] ? tj[e] : 0;
-            psi[e] += base[j];
-            if (st.first) dg[e] += base[n + 8 + j];
+        for (int u = 0; u < 4; ++u) {
+            const bool on = sl0 + u < a.nslices;
+            const double *base = a.acc + (size_t)(on ? sl0 + u : 0) * stride;
+#pragma unroll
+            for (int e = 0; e < E; ++e) pp[u][e] = on ? base[tin[e] ? tj[e] : 0] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < E; ++e) psi[e] += pp[u][e];
+    }
+    if (st.first) {                                    // first evaluation of a solve: the diagonal metric
+        for (int sl = 0; sl < a.nslices; ++sl) {
+            const double *base = a.acc + (size_t)sl * stride + n + 8;
+#pragma unroll
+            for (int e = 0; e < E; ++e) dg[e] += base[tin[e] ? tj[e] : 0];
         }
     }
     double fpools = 0.0;
@@ -639,22 +762,21 @@ update_reg_kernel(UpdArgs a)
     }
     if (tid < a.nslices) a.acc[(size_t)tid * stride + n] = 0.0;
 
+    PHASE_STAMP(a.ts, 10);
     // ---- A. residuals, group gradient at the trial point -----------------------------------------
     if (ties) {
         for (int r = tid; r < ng; r += nt) { q[r] = 0.0; q2[r] = 0.0; }
         __syncthreads();
     }
+    // every scalar the accept test, the stopping rule and the pair need comes out of ONE batched
+    // reduction: the quantities of the accepted branch (pg, |q|^2, act) are computed speculatively
+    // at the trial point, which costs a few FMAs and saves three barrier round trips
     double Gs_t[E];
-    double A[4] = {fpools, 0.0, 0.0, 0.0};       // f_lin, gapv | viol, scale
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         Gs_t[e] = 0.0;
         if (tin[e]) {
             const double rj = psi[e] + hj[e];
-            A[0] += (nuj[e] - cj[e]) * hj[e];
-            A[1] += (nuj[e] - cj[e]) * rj;
-            A[2] = fmax(A[2], ct[e] == 0 ? fmax(-rj, 0.0) : (ct[e] == 1 ? fabs(rj) : 0.0));
-            A[3] = fmax(A[3], fmax(fabs(psi[e]), fabs(hj[e])));
             if (ties) {
                 unsafeAtomicAdd(&q[grp[e]], nuj[e] * rj);
                 if (st.first) unsafeAtomicAdd(&q2[grp[e]], dg[e]);
@@ -664,39 +786,53 @@ update_reg_kernel(UpdArgs a)
             }
         }
     }
-    red.run<2, 2>(A);
     if (ties) {
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < E; ++e) if (gin[e]) { Gs_t[e] = q[gr[e]]; if (st.first) Ds[e] = q2[gr[e]]; }
         __syncthreads();
     }
-    const double f_t = A[0], gapv = A[1], viol = A[2], scale = A[3];
+    // 0 f_lin  1 gapv  2 Gs.ds  3 Gs_t.ds  4 s.y  5 s.s  6 y.y  7 pg  8 |q|^2  |  9 viol  10 scale
+    double A[11] = {fpools, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double sv[E], yv[E], qv[E];
+    bool act[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (tin[e]) {
+            const double rj = psi[e] + hj[e];
+            A[0] += (nuj[e] - cj[e]) * hj[e];
+            A[1] += (nuj[e] - cj[e]) * rj;
+            A[9] = fmax(A[9], ct[e] == 0 ? fmax(-rj, 0.0) : (ct[e] == 1 ? fabs(rj) : 0.0));
+            A[10] = fmax(A[10], fmax(fabs(psi[e]), fabs(hj[e])));
+        }
+        sv[e] = 0.0; yv[e] = 0.0; qv[e] = 0.0; act[e] = true;
+        if (gin[e]) {
+            sv[e] = s_t[e] - s[e]; yv[e] = Gs_t[e] - Gs[e];
+            A[2] += Gs[e] * sv[e]; A[3] += Gs_t[e] * sv[e];
+            A[4] += sv[e] * yv[e]; A[5] += sv[e] * sv[e]; A[6] += yv[e] * yv[e];
+            const double G = Gs_t[e], sr = s_t[e];
+            double v = G;
+            if (glo[e] == ghi[e]) v = 0.0;
+            else if (sr <= glo[e] + 1e-14) v = fmin(G, 0.0);
+            else if (sr >= ghi[e] - 1e-14) v = fmax(G, 0.0);
+            A[7] += fabs(v);
+            act[e] = is_active(sr, glo[e], ghi[e], G);
+            qv[e] = act[e] ? 0.0 : G;
+            A[8] += qv[e] * qv[e];
+        }
+    }
+    red.run<9, 2>(A);
+    const double f_t = A[0], gapv = A[1], viol = A[9], scale = A[10];
     st.evals += 1;
+    PHASE_STAMP(a.ts, 11);
 
     // ---- B. accept test ------------------------------------------------------------------------
     bool accept = st.first != 0;
-    double sv[E], yv[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) { sv[e] = gin[e] ? s_t[e] - s[e] : 0.0; yv[e] = gin[e] ? Gs_t[e] - Gs[e] : 0.0; }
-    double B[4] = {0.0, 0.0, 0.0, 0.0};           // Gs.ds, Gs_t.ds | s.y, (unused)
-    if (!st.first) {
-        double C[3] = {0.0, 0.0, 0.0};            // s.s, y.y folded into a second reduction below
-#pragma unroll
-        for (int e = 0; e < E; ++e) if (gin[e]) {
-            B[0] += Gs[e] * sv[e]; B[1] += Gs_t[e] * sv[e]; B[2] += sv[e] * yv[e]; B[3] += sv[e] * sv[e];
-            C[0] += yv[e] * yv[e];
-        }
-        red.run<4, 0>(B);
-        accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * B[0]) ||
-                                  (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && B[1] <= 0.8 * fabs(B[0])));
-        if (accept) {
-            const double yy = red.sum(C[0]);
-            C[1] = yy;
-            B[1] = yy;                            // keep: B[2] = s.y, B[3] = s.s, B[1] = y.y
-        }
-    }
+    if (!st.first)
+        accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * A[2]) ||
+                                  (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && A[3] <= 0.8 * fabs(A[2])));
 
+    PHASE_STAMP(a.ts, 12);
     bool new_dir = false;
     if (!accept) {
         st.t_step *= 0.5;
@@ -710,9 +846,9 @@ update_reg_kernel(UpdArgs a)
             double *svg = a.S + (size_t)st.head * n, *yvg = a.Y + (size_t)st.head * n;
 #pragma unroll
             for (int e = 0; e < E; ++e) if (gin[e]) { svg[gr[e]] = sv[e]; yvg[gr[e]] = yv[e]; }
-            if (B[2] > 1e-12 * sqrt(B[3]) * sqrt(B[1])) {
+            if (A[4] > 1e-12 * sqrt(A[5]) * sqrt(A[6])) {
                 pair_ok = true;
-                rho_new = 1.0 / B[2];
+                rho_new = 1.0 / A[4];
                 if (tid == 0) a.rho[st.head] = rho_new;
                 st.head = (st.head + 1) % M;
                 if (st.hist < M) st.hist += 1;
@@ -728,33 +864,15 @@ update_reg_kernel(UpdArgs a)
         st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
         st.infeas = viol / fmax(scale, 1e-300);
         st.primal = f_t - gapv;                   // c'psi = g - (nu - c)'(psi + h)
-        bool act[E];
-        double D0[3] = {0.0, 0.0, 0.0};           // pg, |q|^2
-        double qv[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            act[e] = true; qv[e] = 0.0;
-            if (gin[e]) {
-                const double G = Gs[e];
-                double v = G;
-                if (glo[e] == ghi[e]) v = 0.0;
-                else if (s[e] <= glo[e] + 1e-14) v = fmin(G, 0.0);
-                else if (s[e] >= ghi[e] - 1e-14) v = fmax(G, 0.0);
-                D0[0] += fabs(v);
-                act[e] = is_active(s[e], glo[e], ghi[e], G);
-                qv[e] = act[e] ? 0.0 : G;
-                D0[1] += qv[e] * qv[e];
-            }
-        }
-        { double t2[2] = {D0[0], D0[1]}; red.run<2, 0>(t2); D0[0] = t2[0]; D0[1] = t2[1]; }
-        st.pg = D0[0] / fmax(1.0, fabs(f_t));
-        const double gp_sq = D0[1];
+        st.pg = A[7] / fmax(1.0, fabs(f_t));
+        const double gp_sq = A[8];
         const bool was_first = st.first != 0;
         st.first = 0;
         const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
         if (conv) {
             st.status = 1;
         } else {
+            PHASE_STAMP(a.ts, 13);
             // ---- D. two-loop recursion with the diagonal metric; pair 0 = the new pair ------------
             new_dir = true;
             // how many of the prefetched (old) pairs are still in the window
@@ -828,6 +946,7 @@ update_reg_kernel(UpdArgs a)
     }
 
     // ---- E. next trial point -----------------------------------------------------------------
+    PHASE_STAMP(a.ts, 14);
     if (st.status == 0) {
         __syncthreads();
 #pragma unroll
@@ -844,7 +963,8 @@ update_reg_kernel(UpdArgs a)
         for (int e = 0; e < E; ++e) if (tin[e]) a.nu[tj[e]] = exp(q[grp[e]] + offj[e]);
         if (st.evals >= a.max_evals) st.status = 3;
     }
-    if (tid == 0) *a.st = st;
+    if (tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; }
+    PHASE_STAMP(a.ts, 15);
 }
 
 // start of a solve: group variable = mean over members of (log nu0_j - off_j), clamped
@@ -876,6 +996,7 @@ start_kernel(UpdArgs a, const double *__restrict__ nu0)
         st.status = 0; st.evals = 0; st.iters = 0; st.first = 1; st.hist = 0; st.head = 0; st.nrej = 0; st.pad = 0;
         st.f = 0.0; st.t_step = 1.0; st.gap = 0.0; st.infeas = 0.0; st.primal = 0.0; st.pg = 0.0;
         *a.st = st;
+        a.nu[n] = 0.0;
     }
 }
 

@@ -16,48 +16,70 @@ namespace cfmm {
 
 struct Y2 { double ya, yb; };
 
+// 1/x and 1/sqrt(x) from the quarter-rate hardware seeds plus two Newton steps (<= ~1 ulp for
+// normal positive inputs: reserves, prices, fees); ~6-8 instructions instead of the 11-20 of the
+// IEEE sequences, which matters because the evaluation kernel is fp64-issue bound
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+    y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+    return y;
+}
+
 // Constant product sqrt(xy)  (Uniswap v2: arbitrage.py:68-70, equal-weight cp.geo_mean).
-// Tender `in`, receive `out` iff gamma * p_out R_out > p_in R_in; the new reserve of the
-// tendered token is x = sqrt(gamma (p_out/p_in) R_in R_out).
+// With v = p R (the value of a reserve) the pool tenders `in` for `out` iff
+//     rho = gamma v_out / v_in > 1,
+// the new reserve of the tendered token is R_in sqrt(rho), so
+//     y_in = -R_in (sqrt(rho) - 1) / gamma,     y_out = R_out (1 - 1/sqrt(rho)).
+// One rsqrt serves both; gamma <= 1 makes the two directions exclusive.
 __device__ __forceinline__ Y2 pool_cp2(double Ra, double Rb, double g, double pa, double pb)
 {
     const double va = pa * Ra, vb = pb * Rb;
     const bool ab = g * vb > va;
     const bool ba = g * va > vb;
-    const double pin = ab ? pa : pb, pout = ab ? pb : pa;
+    const double vin = ab ? va : vb, vout = ab ? vb : va;
     const double Rin = ab ? Ra : Rb, Rout = ab ? Rb : Ra;
-    const double k = Ra * Rb;
-    const double x = sqrt(g * (pout / pin) * k);
-    const double yin = -(x - Rin) / g;
-    const double yout = Rout - k / x;
-    Y2 r;
-    r.ya = ab ? yin : (ba ? yout : 0.0);
-    r.yb = ab ? yout : (ba ? yin : 0.0);
-    return r;
+    const double rho = g * vout * rcp_nr(vin);
+    const double r = rsqrt_nr(rho);
+    const double yin = -Rin * fma(rho, r, -1.0) * rcp_nr(g);
+    const double yout = Rout * (1.0 - r);
+    Y2 y;
+    y.ya = ab ? yin : (ba ? yout : 0.0);
+    y.yb = ab ? yout : (ba ? yin : 0.0);
+    return y;
 }
 
 // Weighted geometric mean x^wa y^(1-wa) (2-asset Balancer: arbitrage.py:65 with two tokens).
-// eta = w_in/w_out;  x = (gamma eta (p_out/p_in) R_out R_in^eta)^(1/(eta+1)).
+// With weighted values va = w_b p_a R_a, vb = w_a p_b R_b the pool tenders `in` iff
+//     rho = gamma v_out / v_in > 1,   and with L = log rho:
+//     x / R_in = rho^{w_out}:  y_in = -R_in expm1(w_out L) / gamma,   y_out = -R_out expm1(-w_in L).
+// One log and two expm1, all on the well-conditioned quantity L (no x - R_in cancellation).
 __device__ __forceinline__ Y2 pool_w2(double Ra, double Rb, double g, double wa, double pa, double pb)
 {
     const double wb = 1.0 - wa;
     const double va = wb * pa * Ra, vb = wa * pb * Rb;
     const bool ab = g * vb > va;
     const bool ba = g * va > vb;
-    Y2 r; r.ya = 0.0; r.yb = 0.0;
+    Y2 y; y.ya = 0.0; y.yb = 0.0;
     if (ab | ba) {
-        const double pin = ab ? pa : pb, pout = ab ? pb : pa;
+        const double vin = ab ? va : vb, vout = ab ? vb : va;
         const double Rin = ab ? Ra : Rb, Rout = ab ? Rb : Ra;
-        const double eta = ab ? wa / wb : wb / wa;
-        const double lRin = log(Rin);
-        const double lx = (log(g * eta * (pout / pin) * Rout) + eta * lRin) / (eta + 1.0);
-        const double x = exp(lx);
-        const double yin = -(x - Rin) / g;
-        const double yout = Rout * (-expm1(eta * (lRin - lx)));      // Rout (1 - (Rin/x)^eta)
-        r.ya = ab ? yin : yout;
-        r.yb = ab ? yout : yin;
+        const double win = ab ? wa : wb, wout = ab ? wb : wa;
+        const double L = log(g * vout * rcp_nr(vin));
+        const double yin = -Rin * expm1(wout * L) * rcp_nr(g);
+        const double yout = -Rout * expm1(-win * L);
+        y.ya = ab ? yin : yout;
+        y.yb = ab ? yout : yin;
     }
-    return r;
+    return y;
 }
 
 // Constant sum x + y with x, y >= 0 (arbitrage.py:73-74): bang-bang LP.

@@ -60,7 +60,7 @@ typedef struct {
     double armijo;          /* sufficient-decrease constant (1e-4)                                 */
     double max_step;        /* cap on one step in log-price (2.0)                                  */
     int32_t max_evals;      /* cap on dual evaluations (2000)                                      */
-    int32_t memory;         /* L-BFGS pairs kept, 1..8 (8)                                         */
+    int32_t memory;         /* L-BFGS pairs kept, 1..8; 0 = auto (8 up to 32 tokens, else 4: fewer evaluations AND a cheaper update)                                        */
     int32_t iters_per_graph;/* outer iterations captured per hipGraph replay (8)                   */
     int32_t pg_rule;        /* 1: stop on the projected-gradient value <= tol_gap instead (used when
                                constant-sum pools are tied: psi then lacks their fill)           */
@@ -131,6 +131,10 @@ int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128);
  * the k-asset bucket); returns the average seconds per launch in *sec_per_launch. */
 #define CFMM_TIME_ALL 100
 int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_launch);
+/* kernel-tuning hook: 32 {shader-cycle, 100 MHz wall-clock} stamp pairs written by the last
+ * evaluation / update kernels of a build made with -DCFMM_PHASE_TIMERS (zeros otherwise), then a
+ * per-wave tile log of the last evaluation; `out` holds 64 + 8 * 4096 int64 */
+int cfmm_debug_timers(cfmm_ctx *ctx, int64_t *out);
 int64_t cfmm_pool_count(cfmm_ctx *ctx);
 void *cfmm_stream(cfmm_ctx *ctx);                 /* the hipStream_t the library launches on */
 

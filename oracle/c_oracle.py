@@ -148,8 +148,10 @@ class Oracle:
         self.L.oracle_tradesN(self.h, b, _d(nu), _d(y))
         return y
 
-    def solve(self, nu0, tol=1e-6, max_evals=2000, memory=8, armijo=1e-4, max_step=2.0, pg_rule=0):
+    def solve(self, nu0, tol=1e-6, max_evals=2000, memory=0, armijo=1e-4, max_step=2.0, pg_rule=0):
         nu0 = np.ascontiguousarray(nu0, dtype=np.float64)
+        if memory == 0:                     # same auto rule as cfmm_solve
+            memory = 8 if self.n <= 32 else 4
         o = Opts(tol, tol, armijo, max_step, max_evals, memory, pg_rule, 0)
         st = Stats()
         nu = np.zeros(self.n); psi = np.zeros(self.n)

@@ -58,7 +58,7 @@ class OracleContext:
     def eval_dual(self, nu, want_diag=False):
         return self._build().eval(nu, want_diag)
 
-    def solve(self, nu0=None, tol=1e-6, max_evals=2000, memory=8, iters_per_graph=8, pg_rule=0, **kw):
+    def solve(self, nu0=None, tol=1e-6, max_evals=2000, memory=0, iters_per_graph=8, pg_rule=0, **kw):
         o = self._build()
         r = o.solve(nu0 if nu0 is not None else self._nu, tol=tol, max_evals=max_evals, memory=memory, pg_rule=pg_rule)
         self._nu, self._psi = r["nu"], r["psi"]

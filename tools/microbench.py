@@ -47,4 +47,25 @@ out["wall_us_per_eval"] = 1e6 * wall / ev
 out["eval_all_us"] = 1e6 * prob.ctx.time_eval_kernel(_lib.TIME_ALL, args.reps)
 if args.buckets:
     out["buckets"] = {r["kernel"]: round(r["us"], 2) for r in bench.kernel_table(prob, args.reps)[1:]}
+prob.ctx.debug_timers()            # clears the logs
+prob.ctx.time_eval_kernel(_lib.TIME_ALL, 1)
+prob.ctx.debug_timers()
+prob.ctx.time_eval_kernel(_lib.TIME_ALL, 20)      # 3 warm-up + 20 timed launches
+ts, tl = prob.ctx.debug_timers()
+if ts.any():
+    import numpy as np
+    names = ["gn8", "gn7", "gn6", "gn5", "gn4", "gn3", "curve2", "w2", "cp2", "sum2"]
+    bk = (tl >> 48) - 1
+    cyc = tl & ((1 << 48) - 1)
+    out["tile_us(avg,max,count)"] = {nm: (round(float(cyc[bk == q].mean()) / 2400.0, 2), round(float(cyc[bk == q].max()) / 2400.0, 2),
+                                          int((bk == q).sum())) for q, nm in enumerate(names) if (bk == q).any()}
+    per_wave = cyc.sum(axis=1) / 2400.0
+    out["wave_busy_us(min,mean,max)"] = [round(float(x), 2) for x in (per_wave[per_wave > 0].min(), per_wave[per_wave > 0].mean(), per_wave.max())]
+    prob.solve(tol=1e-6, max_evals=12)
+    tu, _ = prob.ctx.debug_timers()
+    d = lambda t, i, j: (int(t[j, 0] - t[i, 0]), round((t[j, 1] - t[i, 1]) * 0.01, 2))   # (cycles, us)
+    out["eval_span_us(first start..last end over 23 launches)/23"] = round(float(ts[20, 1] - ts[20, 0]) * 0.01 / 23, 2)
+    out["eval_phases(cyc,us)"] = dict(prologue=d(ts, 0, 1), tiles=d(ts, 1, 2), reduce=d(ts, 2, 3), flush=d(ts, 3, 4))
+    out["upd_phases(cyc,us)"] = dict(st=d(tu, 8, 9), loads=d(tu, 9, 10), A=d(tu, 10, 11), B=d(tu, 11, 12), C=d(tu, 12, 13),
+                                     D=d(tu, 13, 14), E=d(tu, 14, 15), total=d(tu, 8, 15))
 print(json.dumps(out), flush=True)
