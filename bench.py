@@ -98,12 +98,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     net = synthetic.config(args.config, seed=0, scale=args.scale, pool_seed=(rank if world > 1 else None))
-    prob = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]), device=local_rank)
+    # weak scaling: every rank generates its OWN 1e6-pool shard (same tokens / prices / utility)
+    prob = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=local_rank, shard=False)
     prob._ensure_ctx()
-    if world > 1:
-        uid = [_lib.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        prob.init_comm(world, rank, uid[0])
 
     def sync():
         if world > 1:

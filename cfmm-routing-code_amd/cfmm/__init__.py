@@ -5,6 +5,7 @@ Drop-in for the `cp.Problem(obj, cons).solve()` call of angeris/cfmm-routing-cod
 """
 from .problem import Problem, Utility, Arbitrage, Liquidate, Swap, pack, shard_network, start_prices
 from ._lib import CfmmError, GE, EQ, FREE
+from . import distributed
 
 __all__ = ["Problem", "Utility", "Arbitrage", "Liquidate", "Swap", "pack", "shard_network",
-           "start_prices", "CfmmError", "GE", "EQ", "FREE"]
+           "start_prices", "CfmmError", "GE", "EQ", "FREE", "distributed"]

@@ -218,9 +218,9 @@ class Context:
         return s.value
 
     def debug_timers(self):
-        a = np.zeros(64 + 8 * 4096, dtype=np.int64)
+        a = np.zeros(64 + 8 * 4096 + 2048, dtype=np.int64)
         self._chk(self.L.cfmm_debug_timers(self.h, a.ctypes.data_as(C.POINTER(C.c_int64))))
-        return a[:64].reshape(32, 2), a[64:].reshape(4096, 8)
+        return a[:64].reshape(32, 2), a[64:64 + 8 * 4096].reshape(4096, 8), a[64 + 8 * 4096:].reshape(1024, 2)
 
     def pool_count(self):
         return int(self.L.cfmm_pool_count(self.h))

@@ -1,0 +1,50 @@
+"""Pool-sharding over the GPUs of one node: one process per GPU.
+
+Given nu every pool subproblem is independent (the pools couple only through psi,
+/root/reference/arbitrage.py:54), so rank r holds a contiguous slice of every SoA bucket, tokens /
+prices / utility are replicated, and the ONLY exchange is one all-reduce of [psi | sum arb] per
+dual evaluation.  On the GPUs that all-reduce is RCCL, enqueued by libcfmm_hip.so on its own stream
+inside the captured outer iteration (cfmm_comm_init, include/cfmm.h); torch.distributed is used
+only to agree on the 128-byte ncclUniqueId, for barriers and for the max-over-ranks clock.
+"""
+import os
+
+from .problem import Problem, shard_network
+
+
+def env_world():
+    """(rank, local_rank, world) from the torch.distributed.run environment (1 process: 0, 0, 1)"""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def rank_network(net, rank, world):
+    """this rank's shard of a bucketed network: contiguous equal-count slices of every bucket"""
+    return shard_network(net, rank, world)
+
+
+def broadcast_unique_id(dist, make_id, src=0):
+    """rank `src` makes the communicator id (cfmm._lib.comm_unique_id), everyone receives it"""
+    box = [make_id() if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    uid = bytes(box[0])
+    if len(uid) != 128:
+        raise ValueError(f"communicator id has {len(uid)} bytes, expected 128")
+    return uid
+
+
+def sharded_problem(net, utility, dist=None, device=None, shard=True):
+    """Problem over this rank's shard, with the library's RCCL communicator initialised.
+
+    net: the FULL network (shard=True: it is sliced here) or this rank's own pools (shard=False,
+    e.g. bench.py's weak-scaling shards).  dist: an initialised torch.distributed (nccl) module."""
+    rank, local_rank, world = env_world()
+    if dist is not None:
+        rank, world = dist.get_rank(), dist.get_world_size()
+    part = rank_network(net, rank, world) if (shard and world > 1) else net
+    prob = Problem.from_network(part, utility=utility, device=local_rank if device is None else device)
+    if world > 1:
+        from . import _lib
+        prob._ensure_ctx()
+        prob.init_comm(world, rank, broadcast_unique_id(dist, _lib.comm_unique_id))
+    return prob

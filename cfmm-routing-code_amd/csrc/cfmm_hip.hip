@@ -374,7 +374,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     rc |= dev_upload<double>(ctx, &ctx->rho, nullptr, MAX_MEMORY, nullptr);
     rc |= dev_upload<double>(ctx, &ctx->acc, nullptr, (size_t)ctx->nslices * acc_stride(n), nullptr);
     rc |= dev_upload<DevState>(ctx, &ctx->st, nullptr, 1, nullptr);
-    rc |= dev_upload<long long>(ctx, &ctx->ts, nullptr, 64 + 8 * 4096, nullptr);
+    rc |= dev_upload<long long>(ctx, &ctx->ts, nullptr, 64 + 8 * 4096 + 2048, nullptr);
     if (rc) return bail(CFMM_E_HIP);
     TRY_C(hipHostMalloc((void **)&ctx->hst, 2 * sizeof(DevState), hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) TRY_C(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
@@ -440,6 +440,13 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
     for (int64_t i = 0; i < m; ++i)
         if (ia[i] < 0 || ia[i] >= ctx->n || ib[i] < 0 || ib[i] >= ctx->n || ia[i] == ib[i])
             return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has token ids (%d, %d) outside [0,%d) or equal", (long long)i, ia[i], ib[i], ctx->n);
+    for (int64_t i = 0; i < m; ++i) {
+        if (!(Ra[i] > 0.0) || !(Rb[i] > 0.0) || !std::isfinite(Ra[i]) || !std::isfinite(Rb[i]))
+            return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has a reserve that is not positive and finite", (long long)i);
+        if (!(fee[i] > 0.0 && fee[i] <= 1.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has fee %g outside (0, 1]", (long long)i, fee[i]);
+        if (kind == CFMM_POOL_W2 && !(param[i] > 0.0 && param[i] < 1.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has weight %g outside (0, 1)", (long long)i, param[i]);
+        if (kind == CFMM_POOL_CURVE2 && !(param[i] > 0.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has alpha %g <= 0", (long long)i, param[i]);
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_all(ctx->b2mem[kind]);
     Bucket2 b = {};
@@ -469,6 +476,11 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int64_t i = 0; i < (int64_t)k * m; ++i)
         if (idx[i] < 0 || idx[i] >= ctx->n) return fail(ctx, CFMM_E_ARG, "upload_poolsN: token id %d outside [0,%d)", idx[i], ctx->n);
+    for (int64_t i = 0; i < (int64_t)k * m; ++i)
+        if (!(R[i] > 0.0) || !std::isfinite(R[i]) || !(w[i] > 0.0 && w[i] < 1.0))
+            return fail(ctx, CFMM_E_ARG, "upload_poolsN: leg %lld has reserve %g / weight %g (need R > 0, 0 < w < 1)", (long long)i, R[i], w[i]);
+    for (int64_t i = 0; i < m; ++i)
+        if (!(fee[i] > 0.0 && fee[i] <= 1.0)) return fail(ctx, CFMM_E_ARG, "upload_poolsN: pool %lld has fee %g outside (0, 1]", (long long)i, fee[i]);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_all(ctx->bnmem[k]);
     BucketN b = {};
@@ -757,9 +769,8 @@ int cfmm_debug_timers(cfmm_ctx *ctx, int64_t *out64)
     if (!ctx || !out64) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out64, ctx->ts, (64 + 8 * 4096) * sizeof(int64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemset(ctx->ts, 0, (64 + 8 * 4096) * sizeof(int64_t)));
-    HIP_TRY(ctx, hipMemset(ctx->ts + 40, 0xff, sizeof(int64_t)));      // slot 40 is an atomicMin target
+    HIP_TRY(ctx, hipMemcpy(out64, ctx->ts, (64 + 8 * 4096 + 2048) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemset(ctx->ts, 0, (64 + 8 * 4096 + 2048) * sizeof(int64_t)));
     return CFMM_OK;
 }
 

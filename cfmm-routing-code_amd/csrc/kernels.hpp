@@ -262,7 +262,7 @@ eval_kernel(EvalArgs a)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     PHASE_STAMP(a.ts, 0);
 #ifdef CFMM_PHASE_TIMERS
-    if (a.ts && threadIdx.x == 0) atomicMin((unsigned long long *)&a.ts[40], (unsigned long long)wall_clock64());    // first block start
+    if (a.ts && threadIdx.x == 0 && blockIdx.x < 1024) a.ts[64 + 8 * 4096 + 2 * blockIdx.x] = wall_clock64();    // block start
 #endif
     const int n = a.n;
     double *psi_s = lds, *diag_s = lds + n;
@@ -336,7 +336,7 @@ eval_kernel(EvalArgs a)
     PHASE_STAMP(a.ts, 4);
 #ifdef CFMM_PHASE_TIMERS
     __syncthreads();
-    if (a.ts && threadIdx.x == 0) atomicMax((unsigned long long *)&a.ts[41], (unsigned long long)wall_clock64());    // last block end
+    if (a.ts && threadIdx.x == 0 && blockIdx.x < 1024) a.ts[64 + 8 * 4096 + 2 * blockIdx.x + 1] = wall_clock64();    // block end
 #endif
 }
 

@@ -133,7 +133,8 @@ int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128);
 int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_launch);
 /* kernel-tuning hook: 32 {shader-cycle, 100 MHz wall-clock} stamp pairs written by the last
  * evaluation / update kernels of a build made with -DCFMM_PHASE_TIMERS (zeros otherwise), then a
- * per-wave tile log of the last evaluation; `out` holds 64 + 8 * 4096 int64 */
+ * per-wave tile log and per-block start/end clocks of the last evaluation; `out` holds
+ * 64 + 8 * 4096 + 2048 int64 */
 int cfmm_debug_timers(cfmm_ctx *ctx, int64_t *out);
 int64_t cfmm_pool_count(cfmm_ctx *ctx);
 void *cfmm_stream(cfmm_ctx *ctx);                 /* the hipStream_t the library launches on */

@@ -51,6 +51,9 @@ def lib():
         L.oracle_eval.restype = C.c_double; L.oracle_eval.argtypes = [vp, dp, dp, dp]
         L.oracle_trades2.argtypes = [vp, C.c_int, dp, dp, dp]
         L.oracle_tradesN.argtypes = [vp, C.c_int, dp, dp]
+        L.oracle_start.restype = None; L.oracle_start.argtypes = [vp, dp, C.c_int]
+        L.oracle_step.restype = C.c_int; L.oracle_step.argtypes = [vp, C.c_double, dp, dp, C.POINTER(Opts)]
+        L.oracle_get.restype = None; L.oracle_get.argtypes = [vp, dp, dp, C.POINTER(Stats)]
         L.oracle_solve.restype = C.c_int
         L.oracle_solve.argtypes = [vp, dp, C.POINTER(Opts), C.POINTER(Stats), dp, dp]
         _lib = L
@@ -147,6 +150,34 @@ class Oracle:
         y = np.zeros_like(d["R"])
         self.L.oracle_tradesN(self.h, b, _d(nu), _d(y))
         return y
+
+    def solve_sharded(self, nu0, allreduce, tol=1e-6, max_evals=2000, memory=0, armijo=1e-4, max_step=2.0):
+        """the pool-sharded outer loop, exactly as the GPU library runs it: every rank evaluates ITS
+        pools, `allreduce(vec)` sums [psi | sum arb | diag] over the ranks in place, and every rank
+        takes the identical step.  `self` holds this rank's shard only."""
+        nu0 = np.ascontiguousarray(nu0, dtype=np.float64)
+        if memory == 0:
+            memory = 8 if self.n <= 32 else 4
+        o = Opts(tol, tol, armijo, max_step, max_evals, memory, 0, 0)
+        n = self.n
+        self.L.oracle_start(self.h, _d(nu0), memory)
+        nu = np.zeros(n); buf = np.zeros(2 * n + 1)
+        st = Stats()
+        first, status = True, 0
+        while status == 0:
+            self.L.oracle_get(self.h, _d(nu), None, None)               # the trial prices
+            psi = np.zeros(n); diag = np.zeros(n)
+            f = self.L.oracle_eval(self.h, _d(nu), _d(psi), _d(diag) if first else None)
+            buf[:n] = psi; buf[n] = f; buf[n + 1:] = diag if first else 0.0
+            allreduce(buf)
+            psi = np.ascontiguousarray(buf[:n]); diag = np.ascontiguousarray(buf[n + 1:])
+            status = self.L.oracle_step(self.h, float(buf[n]), _d(psi), _d(diag), C.byref(o))
+            first = False
+        nu_acc = np.zeros(n); psi_acc = np.zeros(n)
+        self.L.oracle_get(self.h, None, _d(nu_acc), C.byref(st))
+        self.L.oracle_get(self.h, None, None, None)
+        return dict(nu=nu_acc, evals=st.evals, iters=st.iters, status=st.status, dual_value=st.dual_value,
+                    primal_value=st.primal_value, gap=st.gap, infeas=st.infeas)
 
     def solve(self, nu0, tol=1e-6, max_evals=2000, memory=0, armijo=1e-4, max_step=2.0, pg_rule=0):
         nu0 = np.ascontiguousarray(nu0, dtype=np.float64)

@@ -537,6 +537,22 @@ static double now_s(void)
 #endif
 }
 
+/* read-out for callers that drive oracle_start / oracle_eval / oracle_step themselves (the
+ * pool-sharded loop of tests/test_distributed.py): trial prices, accepted prices, statistics */
+void oracle_get(oracle_t *o, double *nu_trial, double *nu_acc, oracle_stats_t *st)
+{
+    const int n = o->n;
+    if (nu_trial) memcpy(nu_trial, o->nu, 8 * n);
+    if (nu_acc) for (int j = 0; j < n; ++j) nu_acc[j] = exp(o->s[o->grp[j]] + o->off[j]);
+    if (st) {
+        st->evals = o->evals; st->iters = o->iter; st->status = o->status;
+        st->dual_value = o->f; st->gap = o->gap; st->infeas = o->infeas; st->pg = o->pg; st->seconds = 0.0;
+        double pv = 0.0;
+        for (int j = 0; j < n; ++j) pv += o->c[j] * o->psi[j];
+        st->primal_value = pv;
+    }
+}
+
 /* prob.solve() (arbitrage.py:82).  nu0 = start prices; on return nu = accepted prices. */
 int oracle_solve(oracle_t *o, const double *nu0, const oracle_opts_t *opt, oracle_stats_t *st, double *nu_out, double *psi_out)
 {

@@ -189,6 +189,14 @@ def test_error_behaviour():
     ctx.upload_pools2(_lib.POOL_CP2, [1.0], [1.0], [0.99], [0], [1])
     with pytest.raises(cfmm.CfmmError, match="positive finite"):
         ctx.solve(np.array([1.0, -1.0, 1.0, 1.0]))
+    with pytest.raises(cfmm.CfmmError, match="fee"):
+        ctx.upload_pools2(_lib.POOL_CP2, [1.0], [1.0], [1.5], [0], [1])
+    with pytest.raises(cfmm.CfmmError, match="reserve"):
+        ctx.upload_pools2(_lib.POOL_CP2, [1.0], [-2.0], [0.99], [0], [1])
+    with pytest.raises(cfmm.CfmmError, match="weight"):
+        ctx.upload_pools2(_lib.POOL_W2, [1.0], [1.0], [0.99], [0], [1], param=[1.0])
+    with pytest.raises(cfmm.CfmmError, match="reserve|weight"):
+        ctx.upload_poolsN(np.array([[0], [1], [2]], dtype=np.int32), np.array([[1.0], [0.0], [1.0]]), np.ones((3, 1)) / 3, [0.99])
     # empty bucket upload is allowed and clears the bucket
     ctx.upload_pools2(_lib.POOL_W2, [], [], [], [], [], param=[])
     assert ctx.pool_count() == 1

@@ -25,6 +25,7 @@ ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--buckets", action="store_true")
 args = ap.parse_args()
 
+import numpy as np  # noqa: E402
 import cfmm  # noqa: E402
 from cfmm import synthetic, _lib  # noqa: E402
 import bench  # noqa: E402
@@ -48,12 +49,11 @@ out["eval_all_us"] = 1e6 * prob.ctx.time_eval_kernel(_lib.TIME_ALL, args.reps)
 if args.buckets:
     out["buckets"] = {r["kernel"]: round(r["us"], 2) for r in bench.kernel_table(prob, args.reps)[1:]}
 prob.ctx.debug_timers()            # clears the logs
-prob.ctx.time_eval_kernel(_lib.TIME_ALL, 1)
-prob.ctx.debug_timers()
-prob.ctx.time_eval_kernel(_lib.TIME_ALL, 20)      # 3 warm-up + 20 timed launches
-ts, tl = prob.ctx.debug_timers()
+prob.eval_dual(prob.nu)            # ONE launch: its in-kernel span (first block start .. last block end)
+_, _, tb = prob.ctx.debug_timers()
+prob.ctx.time_eval_kernel(_lib.TIME_ALL, 20)
+ts, tl, _ = prob.ctx.debug_timers()
 if ts.any():
-    import numpy as np
     names = ["gn8", "gn7", "gn6", "gn5", "gn4", "gn3", "curve2", "w2", "cp2", "sum2"]
     bk = (tl >> 48) - 1
     cyc = tl & ((1 << 48) - 1)
@@ -62,9 +62,14 @@ if ts.any():
     per_wave = cyc.sum(axis=1) / 2400.0
     out["wave_busy_us(min,mean,max)"] = [round(float(x), 2) for x in (per_wave[per_wave > 0].min(), per_wave[per_wave > 0].mean(), per_wave.max())]
     prob.solve(tol=1e-6, max_evals=12)
-    tu, _ = prob.ctx.debug_timers()
+    tu, _, _ = prob.ctx.debug_timers()
     d = lambda t, i, j: (int(t[j, 0] - t[i, 0]), round((t[j, 1] - t[i, 1]) * 0.01, 2))   # (cycles, us)
-    out["eval_span_us(first start..last end over 23 launches)/23"] = round(float(ts[20, 1] - ts[20, 0]) * 0.01 / 23, 2)
+    tb = tb[tb[:, 1] > 0]
+    t0 = tb[:, 0].min()
+    st_, en_ = (tb[:, 0] - t0) * 0.01, (tb[:, 1] - t0) * 0.01
+    out["eval_blocks"] = dict(n=len(tb), span_us=round(float(en_.max()), 2), start_pct=[round(float(x), 2) for x in np.percentile(st_, [0, 50, 90, 100])],
+                              end_pct=[round(float(x), 2) for x in np.percentile(en_, [0, 10, 50, 90, 100])],
+                              dur_pct=[round(float(x), 2) for x in np.percentile(en_ - st_, [0, 50, 90, 100])])
     out["eval_phases(cyc,us)"] = dict(prologue=d(ts, 0, 1), tiles=d(ts, 1, 2), reduce=d(ts, 2, 3), flush=d(ts, 3, 4))
     out["upd_phases(cyc,us)"] = dict(st=d(tu, 8, 9), loads=d(tu, 9, 10), A=d(tu, 10, 11), B=d(tu, 11, 12), C=d(tu, 12, 13),
                                      D=d(tu, 13, 14), E=d(tu, 14, 15), total=d(tu, 8, 15))
