@@ -51,7 +51,7 @@ _lib = None
 SYMBOLS = ["cfmm_create", "cfmm_destroy", "cfmm_last_error", "cfmm_backend", "cfmm_default_opts",
            "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_set_pool_flags", "cfmm_set_utility",
            "cfmm_set_ties", "cfmm_eval_dual", "cfmm_solve", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
-           "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_comm_unique_id", "cfmm_comm_init",
+           "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_comm_unique_id", "cfmm_comm_init",
            "cfmm_time_eval_kernel", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
 
 
@@ -78,6 +78,7 @@ def lib():
     L.cfmm_eval_dual.argtypes = [vp, dp, dp, dp, dp]
     L.cfmm_solve.argtypes = [vp, dp, C.POINTER(Opts), C.POINTER(Stats)]
     L.cfmm_get_nu.argtypes = [vp, dp]; L.cfmm_set_nu.argtypes = [vp, dp]; L.cfmm_get_psi.argtypes = [vp, dp]
+    L.cfmm_get_solution.argtypes = [vp, dp, dp]
     L.cfmm_get_trades2.argtypes = [vp, C.c_int, dp, dp]
     L.cfmm_get_tradesN.argtypes = [vp, C.c_int, dp, dp]
     L.cfmm_comm_unique_id.argtypes = [C.c_void_p]
@@ -195,6 +196,11 @@ class Context:
 
     def get_psi(self):
         a = np.zeros(self.n); self._chk(self.L.cfmm_get_psi(self.h, _d(a))); return a
+
+    def get_solution(self):
+        nu = np.zeros(self.n); psi = np.zeros(self.n)
+        self._chk(self.L.cfmm_get_solution(self.h, _d(nu), _d(psi)))
+        return nu, psi
 
     def get_trades2(self, kind, m):
         d = np.zeros((2, m)); l = np.zeros((2, m))

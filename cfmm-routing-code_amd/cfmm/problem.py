@@ -271,6 +271,8 @@ class Problem:
         self._theta = {}
         self._trade_cache = None
         self._comm = None
+        self._dev_utility = None       # the Utility object whose data sits on the device
+        self._dev_ties = False         # price ties / pool flags are set on the device
 
     @classmethod
     def from_network(cls, net, utility=None, device=0):
@@ -292,7 +294,8 @@ class Problem:
         return self.ctx
 
     def set_utility(self, utility):
-        self.utility = utility
+        self.utility = utility       # (a new object, or the same object mutated: call this to re-send it)
+        self._dev_utility = None
 
     def init_comm(self, n_ranks, rank, uid):
         """pool-sharding: this process holds one shard; see cfmm.distributed"""
@@ -309,10 +312,15 @@ class Problem:
             raise ValueError("no utility set")
         ctx = self._ensure_ctx()
         u = self.utility
-        ctx.set_utility(u.c, u.h, u.ctype)
-        ctx.set_ties(None, None)
-        if "sum2" in self.net:
-            ctx.set_pool_flags(POOL_SUM2, None)
+        # device-side utility / tie state is re-sent only when it changed (each call is a synchronisation)
+        if self._dev_utility is not u:
+            ctx.set_utility(u.c, u.h, u.ctype)
+            self._dev_utility = u
+        if self._dev_ties:
+            ctx.set_ties(None, None)
+            if "sum2" in self.net:
+                ctx.set_pool_flags(POOL_SUM2, None)
+            self._dev_ties = False
         if nu0 is None:
             nu0 = self.nu if (warm_start and self.nu is not None) else start_prices(self.net, u)
         self._theta = {}
@@ -322,7 +330,7 @@ class Problem:
         total = dict(evals=0, iters=0, wall_seconds=0.0, device_seconds=0.0, rounds=0)
         if "sum2" not in self.net:
             st = self._run(ctx, nu0, total, tol=tol, **kw)
-            nu, psi = ctx.get_nu(), ctx.get_psi()
+            nu, psi = ctx.get_solution()
         else:
             st, nu, psi = self._solve_kinks(ctx, nu0, tol, kw, kink_tol, max_rounds, total)
         self._finish(st, nu, psi, total)
@@ -373,6 +381,7 @@ class Problem:
                     flags[i] = 1
                 else:
                     del tied[i]; banned.add((i, sgn))
+            self._dev_ties = True
             if tied:
                 grp, off, ng = ties.groups()
                 ctx.set_ties(grp, off); ctx.set_pool_flags(POOL_SUM2, flags)
@@ -380,7 +389,7 @@ class Problem:
             else:
                 ctx.set_ties(None, None); ctx.set_pool_flags(POOL_SUM2, None)
                 st = self._run(ctx, nu, total, tol=tol, **dict(kw, max_evals=budget))
-            nu, psi = ctx.get_nu(), ctx.get_psi()
+            nu, psi = ctx.get_solution()
             if st["status"] == 1:
                 if not tied:
                     return st, nu, psi
@@ -512,3 +521,4 @@ class Problem:
     def close(self):
         if self.ctx is not None:
             self.ctx.close(); self.ctx = None; self._uploaded = False
+            self._dev_utility = None; self._dev_ties = False

@@ -320,7 +320,7 @@ void cfmm_default_opts(cfmm_opts *o)
 {
     std::memset(o, 0, sizeof *o);
     o->tol_gap = 1e-6; o->tol_infeas = 1e-6; o->armijo = 1e-4; o->max_step = 2.0;
-    o->max_evals = 2000; o->memory = 0; o->iters_per_graph = 8;
+    o->max_evals = 2000; o->memory = 0; o->iters_per_graph = 4;
 }
 
 const char *cfmm_last_error(cfmm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -594,6 +594,16 @@ int cfmm_get_psi(cfmm_ctx *ctx, double *psi)
     if (!ctx || !psi) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(psi, ctx->psi_acc, ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CFMM_OK;
+}
+
+int cfmm_get_solution(cfmm_ctx *ctx, double *nu, double *psi)
+{
+    if (!ctx || (!nu && !psi)) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (nu) HIP_TRY(ctx, hipMemcpyAsync(nu, ctx->nu_acc, ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (psi) HIP_TRY(ctx, hipMemcpyAsync(psi, ctx->psi_acc, ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CFMM_OK;
 }

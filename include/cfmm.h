@@ -61,7 +61,7 @@ typedef struct {
     double max_step;        /* cap on one step in log-price (2.0)                                  */
     int32_t max_evals;      /* cap on dual evaluations (2000)                                      */
     int32_t memory;         /* L-BFGS pairs kept, 1..8; 0 = auto (8 up to 32 tokens, else 4: fewer evaluations AND a cheaper update)                                        */
-    int32_t iters_per_graph;/* outer iterations captured per hipGraph replay (8)                   */
+    int32_t iters_per_graph;/* outer iterations captured per hipGraph replay (4)                   */
     int32_t pg_rule;        /* 1: stop on the projected-gradient value <= tol_gap instead (used when
                                constant-sum pools are tied: psi then lacks their fill)           */
 } cfmm_opts;
@@ -116,6 +116,7 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts, cfmm_sta
 int cfmm_get_nu(cfmm_ctx *ctx, double *nu);
 int cfmm_set_nu(cfmm_ctx *ctx, const double *nu);
 int cfmm_get_psi(cfmm_ctx *ctx, double *psi);
+int cfmm_get_solution(cfmm_ctx *ctx, double *nu, double *psi);     /* both with one synchronisation; either may be NULL */
 /* tenders at the accepted prices; slot-major [2][m] / [k][m]; either pointer may be NULL */
 int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda);
 int cfmm_get_tradesN(cfmm_ctx *ctx, int k, double *delta, double *lambda);

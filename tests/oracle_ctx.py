@@ -75,6 +75,9 @@ class OracleContext:
     def get_psi(self):
         return self._psi.copy()
 
+    def get_solution(self):
+        return self._nu.copy(), self._psi.copy()
+
     def get_trades2(self, kind, m):
         o = self._build()
         ya, yb = o.trades2(self.order2.index(kind), self._nu)

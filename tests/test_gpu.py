@@ -2,6 +2,7 @@
 against the golden fixtures, and -- at BASELINE's full sizes -- through size-independent
 properties.  Tolerances: per-pool trades and psi 1e-11 relative to the reserves / to |psi|_inf
 (fp64, different libm + summation order); objectives 1e-6 relative (the north-star bar)."""
+import os
 import numpy as np
 import pytest
 
@@ -216,3 +217,18 @@ def test_hub_tokens_zipf_stress(oracle_lib):
     assert abs(f1 - f0) <= 1e-11 * abs(f0)
     assert np.abs(psi1 - psi0).max() <= 1e-9 * np.abs(psi0).max()
     p.close()
+
+
+def test_integration_md_ctypes_stub_runs():
+    """the raw ctypes stub printed in INTEGRATION.md section 3 is executed verbatim"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, re.S)
+    stub = [b for b in blocks if "cfmm_create" in b]
+    assert len(stub) == 1
+    ns = {}
+    exec(stub[0].replace("<repo>", root), ns)
+    st = ns["st"]
+    assert st.status == 1 and st.gap <= 1e-6 and st.infeas <= 1e-6 and st.primal_value > 1.0
+    assert np.all(ns["psi"] >= -1e-6 * np.abs(ns["psi"]).max())

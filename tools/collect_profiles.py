@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""Copies the judged summaries of the last `tools/gpu_profile.sh` run (gpurun_out/p, scratch) into profiles/
+(tracked): bench line, rocprofv3 --kernel-trace --stats tables, per-kernel PMC medians."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "p")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+DST = os.path.join(ROOT, "profiles")
+os.makedirs(DST, exist_ok=True)
+
+shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{tag}_bench.json"))
+for d in sorted(glob.glob(os.path.join(SRC, "trace_*"))):
+    name = os.path.basename(d)[len("trace_"):]
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(DST, f"{tag}_rocprofv3_kernel_stats_{name}.csv"))
+rows = []
+for f in sorted(glob.glob(os.path.join(SRC, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+    cfg = os.path.basename(os.path.dirname(f) if os.path.basename(os.path.dirname(f)).startswith("pmc_") else os.path.dirname(os.path.dirname(f)))
+    cfg = [p for p in f.split(os.sep) if p.startswith("pmc_")][0].split("_")[1]
+    agg = {}
+    for r in csv.DictReader(open(f)):
+        agg.setdefault((r["Kernel_Name"], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    for (kn, cn), v in sorted(agg.items()):
+        v.sort()
+        rows.append(dict(config=cfg, kernel=kn, counter=cn, dispatches=len(v), median=v[len(v) // 2], min=v[0], max=v[-1]))
+with open(os.path.join(DST, f"{tag}_rocprofv3_pmc_medians.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=["config", "kernel", "counter", "dispatches", "median", "min", "max"])
+    w.writeheader(); w.writerows(rows)
+print("profiles/:", sorted(os.listdir(DST)))
