@@ -89,6 +89,7 @@ struct cfmm_ctx {
     int nslices = 4;
     int eval_grid_mult = 1;
     int eval_blocks_per_cu = 1;        // resident EVAL_THREADS-workgroups per CU (occupancy query at create)
+    int upd_variant = 0;               // CFMM_UPDATE_VARIANT: A/B choice among the register-resident instantiations
     bool upd_generic = false;          // CFMM_UPDATE_GENERIC=1: force the generic update kernel (A/B testing)
     bool have_utility = false, have_nu = false;
     // host copies needed to derive bounds
@@ -210,8 +211,9 @@ int set_all_lds_attrs(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, eval_kernel<false>, e0))) return rc;
     if ((rc = set_lds_attr(ctx, eval_kernel<true>, e1))) return rc;
     if ((rc = set_lds_attr(ctx, update_kernel, upd_lds_bytes(ctx->n)))) return rc;
-    if ((rc = set_lds_attr(ctx, update_reg_kernel<256>, upd_lds_bytes(ctx->n)))) return rc;
-    if ((rc = set_lds_attr(ctx, update_reg_kernel<512>, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 8, 2>, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 4, 4>, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, update_reg_kernel<256, 8, 4>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, start_kernel, upd_lds_bytes(ctx->n)))) return rc;
     return CFMM_OK;
 }
@@ -232,17 +234,21 @@ UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
     return a;
 }
 
-// the nu update: register-resident kernel up to 2048 tokens, the generic one beyond
+// the nu update: register-resident kernel up to 2048 tokens (2 per thread), the generic one beyond
 void launch_update(cfmm_ctx *ctx, const UpdArgs &ua)
 {
     const int n = ctx->n;
-    const int threads = 64 * ((n + 64 * UPD_EPT - 1) / (64 * UPD_EPT));
-    if (ctx->upd_generic || threads > 512)
-        hipLaunchKernelGGL(update_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua);
-    else if (threads <= 256)
-        hipLaunchKernelGGL(update_reg_kernel<256>, dim3(1), dim3(threads), upd_lds_bytes(ctx->ng), ctx->stream, ua);
+    const size_t lds = upd_lds_bytes(ctx->ng);
+    auto thr = [n](int E) { return 64 * ((n + 64 * E - 1) / (64 * E)); };
+    const int v = ctx->upd_generic ? 9 : ctx->upd_variant;
+    if (v == 0 && n <= 1024)                        // 2 variables per thread, <= 8 waves, any memory
+        hipLaunchKernelGGL((update_reg_kernel<512, 8, 2>), dim3(1), dim3(thr(2)), lds, ctx->stream, ua);
+    else if ((v == 0 || v == 1) && n <= 2048 && ua.M <= 4)   // 4 per thread, <= 8 waves, memory <= 4
+        hipLaunchKernelGGL((update_reg_kernel<512, 4, 4>), dim3(1), dim3(thr(4)), lds, ctx->stream, ua);
+    else if (v == 2 && n <= 1024)                   // (A/B) 4 per thread, <= 4 waves
+        hipLaunchKernelGGL((update_reg_kernel<256, 8, 4>), dim3(1), dim3(thr(4)), lds, ctx->stream, ua);
     else
-        hipLaunchKernelGGL(update_reg_kernel<512>, dim3(1), dim3(threads), upd_lds_bytes(ctx->ng), ctx->stream, ua);
+        hipLaunchKernelGGL(update_kernel, dim3(1), dim3(UPD_THREADS), lds, ctx->stream, ua);
 }
 
 // evaluation -> [fold + all-reduce] -> update : one outer iteration, enqueued on ctx->stream
@@ -251,7 +257,7 @@ int enqueue_iteration(cfmm_ctx *ctx, const UpdArgs &ua)
 {
     launch_all_evals<WITH_D>(ctx);
     if (ctx->n_ranks > 1) {
-        const int len = WITH_D ? acc_stride(ctx->n) : ctx->n + 1;
+        const int len = WITH_D ? acc_stride(ctx->n) : acc_arb(ctx->n) + 1;
         hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, ctx->n,
                            ctx->nslices, WITH_D ? 1 : 0, (const DevState *)nullptr);
         int rc = g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
@@ -357,22 +363,23 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if (const char *s = getenv("CFMM_SLICES")) ctx->nslices = std::max(1, atoi(s));
     if (const char *s = getenv("CFMM_EVAL_GRID_MULT")) ctx->eval_grid_mult = std::max(1, atoi(s));
     if (const char *s = getenv("CFMM_UPDATE_GENERIC")) ctx->upd_generic = atoi(s) != 0;
+    if (const char *s = getenv("CFMM_UPDATE_VARIANT")) ctx->upd_variant = atoi(s);
     const int n = n_tokens;
     int rc = 0;
-    rc |= dev_upload<double>(ctx, &ctx->c, nullptr, n, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->h, nullptr, n, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->off, nullptr, n, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->glo, nullptr, n, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->ghi, nullptr, n, nullptr);
-    rc |= dev_upload<int>(ctx, &ctx->ctype, nullptr, n, nullptr);
-    rc |= dev_upload<int>(ctx, &ctx->grp, nullptr, n, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->c, nullptr, n + 4, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->h, nullptr, n + 4, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->off, nullptr, n + 4, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->glo, nullptr, n + 4, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->ghi, nullptr, n + 4, nullptr);
+    rc |= dev_upload<int>(ctx, &ctx->ctype, nullptr, n + 4, nullptr);
+    rc |= dev_upload<int>(ctx, &ctx->grp, nullptr, n + 4, nullptr);
     double **vecs[] = {&ctx->nu, &ctx->nu_acc, &ctx->psi_acc, &ctx->psi_t, &ctx->nu0, &ctx->s, &ctx->s_t,
                        &ctx->Gs, &ctx->Gs_t, &ctx->d, &ctx->Ds};
-    for (auto v : vecs) rc |= dev_upload<double>(ctx, v, nullptr, n + 1, nullptr);     // nu[n] = stop flag
-    rc |= dev_upload<double>(ctx, &ctx->S, nullptr, (size_t)MAX_MEMORY * n, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->Y, nullptr, (size_t)MAX_MEMORY * n, nullptr);
+    for (auto v : vecs) rc |= dev_upload<double>(ctx, v, nullptr, n + 4, nullptr);     // nu[n] = stop flag; +1: pair loads
+    rc |= dev_upload<double>(ctx, &ctx->S, nullptr, (size_t)MAX_MEMORY * hist_stride(n) + 4, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->Y, nullptr, (size_t)MAX_MEMORY * hist_stride(n) + 4, nullptr);
     rc |= dev_upload<double>(ctx, &ctx->rho, nullptr, MAX_MEMORY, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->acc, nullptr, (size_t)ctx->nslices * acc_stride(n), nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->acc, nullptr, (size_t)ctx->nslices * acc_stride(n) + 4, nullptr);
     rc |= dev_upload<DevState>(ctx, &ctx->st, nullptr, 1, nullptr);
     rc |= dev_upload<long long>(ctx, &ctx->ts, nullptr, 64 + 8 * 4096 + 2048, nullptr);
     if (rc) return bail(CFMM_E_HIP);
@@ -630,8 +637,8 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
     HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)len * sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (psi) std::memcpy(psi, host.data(), n * sizeof(double));
-    if (arb_sum) *arb_sum = host[n];
-    if (diag) std::memcpy(diag, host.data() + n + 8, n * sizeof(double));
+    if (arb_sum) *arb_sum = host[acc_arb(n)];
+    if (diag) std::memcpy(diag, host.data() + acc_diag(n), n * sizeof(double));
     return CFMM_OK;
 }
 

@@ -73,10 +73,15 @@ struct EvalArgs {
 };
 
 // LDS carve of eval_kernel (doubles), 16-byte aligned pieces; then 64 double2 per wave
-__host__ __device__ inline int eval_lds_doubles(int n, bool with_d) { return (((with_d ? 3 : 2) * n + 2 + 16) + 1) & ~1; }
+__host__ __device__ inline int eval_lds_doubles(int n, bool with_d) { return (((with_d ? 3 : 2) * n + 2 + 16 + 2) + 1) & ~1; }
 
-// accumulator slice layout: [0,n) psi | [n] sum arb | [n+8, 2n+8) diag
-__host__ __device__ inline int acc_stride(int n) { return 2 * n + 8; }
+// accumulator slice layout (np = n rounded up to even, so that every piece is 16-byte aligned):
+//   [0,n) psi | [np] sum arb | [np+8, np+8+n) diag
+__host__ __device__ inline int acc_arb(int n) { return (n + 1) & ~1; }
+__host__ __device__ inline int acc_diag(int n) { return acc_arb(n) + 8; }
+__host__ __device__ inline int acc_stride(int n) { return acc_diag(n) + acc_arb(n); }
+// row stride of the L-BFGS history (rows 16-byte aligned)
+__host__ __device__ inline int hist_stride(int n) { return (n + 1) & ~1; }
 
 // wave64 butterflies on the VALU cross-lane paths (DPP within a row of 16 lanes, then gfx950's
 // v_permlane16_swap / v_permlane32_swap across rows): every lane ends up with the result, no LDS
@@ -248,7 +253,7 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
 // The dual evaluation, ONE launch for every bucket:  psi(nu) = sum_i A_i (L_i - D_i),
 // sum_i arb_i(A_i' nu), optionally the diagonal metric.                reference: arbitrage.py:54
 //
-// LDS: psi_s[n] | (diag_s[n]) | nu_s[n + 1] | fpart[16] | wave-private exchange strips 64 x 16 B.  Every wave walks its own wave-tiles
+// LDS: psi_s[n] | (diag_s[n]) | nu_s[n + 1] | fpart[16] | ticket | wave-private exchange strips 64 x 16 B.  Every wave walks its own wave-tiles
 // (tile = pass * W + wave_in_block * gridDim + block, W = waves in the grid): the waves of one
 // workgroup take tiles W/8 apart, so each CU holds the same mix of ALU-heavy geo-mean tiles and
 // streaming constant-product tiles; no barrier between the prologue and the epilogue.  The
@@ -268,6 +273,8 @@ eval_kernel(EvalArgs a)
     double *psi_s = lds, *diag_s = lds + n;
     double *nu_s = lds + (WITH_D ? 2 : 1) * n;          // [n + 1]
     double *fpart = nu_s + n + 2;                       // [16]
+    int *next_tile = reinterpret_cast<int *>(fpart + 16);   // the workgroup's tile ticket counter
+    if (threadIdx.x == 0) *next_tile = 0;
     double2 *xs = reinterpret_cast<double2 *>(lds + eval_lds_doubles(n, WITH_D)) + 64 * (threadIdx.x >> 6);   // wave-private [64]
     // prices and the stop flag arrive in ONE round trip (the flag rides behind the prices)
     for (int j = threadIdx.x; j <= n; j += blockDim.x) {
@@ -280,18 +287,30 @@ eval_kernel(EvalArgs a)
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int W = gridDim.x * (blockDim.x >> 6);
     double fsum = 0.0;
 #ifdef CFMM_PHASE_TIMERS
     int nlog = 0;
+    long long t_prev = clock64(), t_out = 0;         // time spent between tiles (ticket, bucket search, dispatch)
 #endif
-    for (int t = wib * gridDim.x + blockIdx.x; t < a.ntiles; t += W) {
+    // Workgroup b owns the tiles {b + gridDim * i}: every workgroup sees the same mix of buckets, heaviest
+    // first.  Its waves draw i from an LDS ticket counter (ds_add_rtn, ~100 cycles against >= 1 us per
+    // tile), so they all finish within one tile of each other however uneven the tile costs are.
+    const int ntiles = a.ntiles, tstride = gridDim.x;
+    int ticket = 0;
+    if (lane == 0) ticket = atomicAdd(next_tile, 1);
+    for (;;) {
+        const int t = blockIdx.x + tstride * __builtin_amdgcn_readfirstlane(ticket);
+        if (t >= ntiles) break;
+        // the NEXT ticket is drawn before this tile's work, so its LDS round trip (behind the
+        // previous tile's scatter atomics) overlaps the tile instead of separating two tiles
+        if (lane == 0) ticket = atomicAdd(next_tile, 1);
         int bk = 0;
 #pragma unroll
         for (int q = 0; q < N_BUCKETS - 1; ++q) bk += (t >= a.tile_end[q]) ? 1 : 0;
         const int tb = t - (bk ? a.tile_end[bk - 1] : 0);
 #ifdef CFMM_PHASE_TIMERS
         const long long tc0 = clock64();
+        t_out += tc0 - t_prev;
 #endif
         switch (bk) {
         case 0: tilen<8, WITH_D>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
@@ -308,11 +327,18 @@ eval_kernel(EvalArgs a)
 #ifdef CFMM_PHASE_TIMERS
         if (a.ts && lane == 0) {                       // per-wave tile log: ts[64 + 8 gw + i] = bucket << 48 | cycles
             const int gw = blockIdx.x * (blockDim.x >> 6) + wib;
-            if (gw < 4096 && nlog < 8) a.ts[64 + 8 * gw + nlog] = ((long long)(bk + 1) << 48) | (clock64() - tc0);
+            t_prev = clock64();
+            if (gw < 4096 && nlog < 7) a.ts[64 + 8 * gw + nlog] = ((long long)(bk + 1) << 48) | (t_prev - tc0);
             ++nlog;
         }
 #endif
     }
+#ifdef CFMM_PHASE_TIMERS
+    if (a.ts && lane == 0) {
+        const int gw = blockIdx.x * (blockDim.x >> 6) + wib;
+        if (gw < 4096) a.ts[64 + 8 * gw + 7] = (15ll << 48) | (t_out + (clock64() - t_prev));
+    }
+#endif
     PHASE_STAMP(a.ts, 2);
     fsum = wave_sum(fsum);
     if (lane == 0) fpart[wib] = fsum;
@@ -325,13 +351,13 @@ eval_kernel(EvalArgs a)
         if (v != 0.0) unsafeAtomicAdd(&base[j], v);
         if (WITH_D) {
             const double dv = diag_s[j];
-            if (dv != 0.0) unsafeAtomicAdd(&base[n + 8 + j], dv);
+            if (dv != 0.0) unsafeAtomicAdd(&base[acc_diag(n) + j], dv);
         }
     }
     if (threadIdx.x == 0) {
         double f = 0.0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) f += fpart[w];
-        if (f != 0.0) unsafeAtomicAdd(&base[n], f);
+        if (f != 0.0) unsafeAtomicAdd(&base[acc_arb(n)], f);
     }
     PHASE_STAMP(a.ts, 4);
 #ifdef CFMM_PHASE_TIMERS
@@ -387,7 +413,7 @@ tradesn_kernel(BucketN b, const double *__restrict__ nu, double *__restrict__ de
 __global__ void fold_kernel(double *__restrict__ acc, int n, int nslices, int with_d, const DevState *st)
 {
     if (st && st->status != 0) return;
-    const int len = with_d ? acc_stride(n) : n + 1;
+    const int len = with_d ? acc_stride(n) : acc_arb(n) + 1;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= len) return;
     double v = acc[j];
@@ -461,7 +487,7 @@ update_kernel(UpdArgs a)
         for (int sl = 0; sl < a.nslices; ++sl) {
             double *base = a.acc + (size_t)sl * stride;
             psi += base[j]; base[j] = 0.0;
-            if (st.first) { dg += base[n + 8 + j]; base[n + 8 + j] = 0.0; }
+            if (st.first) { dg += base[acc_diag(n) + j]; base[acc_diag(n) + j] = 0.0; }
         }
         a.psi_t[j] = psi;
         const double nuj = a.nu[j], hj = a.h[j], cj = a.c[j];
@@ -481,7 +507,7 @@ update_kernel(UpdArgs a)
     }
     double fpools = 0.0;
     if (tid == 0) {
-        for (int sl = 0; sl < a.nslices; ++sl) { double *base = a.acc + (size_t)sl * stride; fpools += base[n]; base[n] = 0.0; }
+        for (int sl = 0; sl < a.nslices; ++sl) { double *base = a.acc + (size_t)sl * stride; fpools += base[acc_arb(n)]; base[acc_arb(n)] = 0.0; }
     }
     sums[0] += fpools;                       // f_t = sum arb + (nu - c)'h
     block_reduce<2, 2>(sums, maxs, scratch);
@@ -510,7 +536,7 @@ update_kernel(UpdArgs a)
     } else {
         // ---- C. curvature pair, move the accepted point ----------------------------------
         if (!st.first) {
-            double *sv = a.S + (size_t)st.head * n, *yv = a.Y + (size_t)st.head * n;
+            double *sv = a.S + (size_t)st.head * hist_stride(n), *yv = a.Y + (size_t)st.head * hist_stride(n);
             double t3[3] = {0.0, 0.0, 0.0};
             double dummy[1] = {0.0};
             for (int r = tid; r < ng; r += nt) {
@@ -567,7 +593,7 @@ update_kernel(UpdArgs a)
             for (int k = 0; k < MAX_MEMORY; ++k) {
                 if (k < st.hist) {
                     const int i = (st.head - 1 - k + 2 * M) % M;
-                    const double *sv = a.S + (size_t)i * n, *yv = a.Y + (size_t)i * n;
+                    const double *sv = a.S + (size_t)i * hist_stride(n), *yv = a.Y + (size_t)i * hist_stride(n);
                     double dt[1] = {0.0};
                     for (int r = tid; r < ng; r += nt) dt[0] += sv[r] * q[r];
                     block_reduce<1, 0>(dt, dummy, scratch);
@@ -584,7 +610,7 @@ update_kernel(UpdArgs a)
             for (int k = MAX_MEMORY - 1; k >= 0; --k) {
                 if (k < st.hist) {
                     const int i = (st.head - 1 - k + 2 * M) % M;
-                    const double *sv = a.S + (size_t)i * n, *yv = a.Y + (size_t)i * n;
+                    const double *sv = a.S + (size_t)i * hist_stride(n), *yv = a.Y + (size_t)i * hist_stride(n);
                     double dt[1] = {0.0};
                     for (int r = tid; r < ng; r += nt) dt[0] += yv[r] * q[r];
                     block_reduce<1, 0>(dt, dummy, scratch);
@@ -633,13 +659,17 @@ update_kernel(UpdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// The nu update, register-resident form (n <= UPD_EPT * 512 = 2048 tokens): the same iteration as
-// update_kernel above (and oracle/cfmm_oracle.c:oracle_step), but every thread owns UPD_EPT
-// group variables and the whole L-BFGS history of those variables in registers; all global
-// loads (state, history, accumulator slices) are issued before the first use, and every dot
-// product is one wave butterfly + one LDS exchange + ONE barrier.  blockDim = 64 * ceil(n / (64 * UPD_EPT)).
+// The nu update, register-resident form (n <= 2048 tokens): the same iteration as update_kernel
+// above (and oracle/cfmm_oracle.c:oracle_step).  Every thread owns TWO adjacent variables and
+// their whole L-BFGS history in registers; every vector is read with one 16-byte load per thread
+// (a wave has at most 63 loads in flight, so 8-byte loads of ~25 vectors x 4 elements stalled the
+// old 4-wave form twice); all loads are issued before the first use; every scalar the accept
+// test, the stopping rule and the curvature pair need comes out of ONE batched block reduction;
+// then 2m + 1 sequential dot products (wave butterflies on DPP / v_permlane*_swap, one LDS
+// exchange, one barrier each).  blockDim = 64 * ceil(ceil(n / E) / 64); the instantiations are
+// chosen by the register budget (cfmm_hip.hip: launch_update).
 // ------------------------------------------------------------------------------------------
-constexpr int UPD_EPT = 4;
+constexpr int UPD_E = 2;
 
 struct BlockRed {
     double *scratch;            // [2][NRED][16]
@@ -674,19 +704,64 @@ struct BlockRed {
     __device__ __forceinline__ double sum(double x) { double v[1] = {x}; run<1, 0>(v); return v[0]; }
 };
 
-template <int MAXT>
+// E adjacent doubles / ints starting at element `first` (a multiple of E, E even): 16-byte loads
+template <int E>
+__device__ __forceinline__ double dotE(const double (&a)[E], const double (&b)[E])
+{
+    double r = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) r += a[e] * b[e];
+    return r;
+}
+template <int E>
+__device__ __forceinline__ void ldv(const double *p, int first, double (&v)[E])
+{
+#pragma unroll
+    for (int k = 0; k < E / 2; ++k) {
+        const double2 t = reinterpret_cast<const double2 *>(p + first)[k];
+        v[2 * k] = t.x; v[2 * k + 1] = t.y;
+    }
+}
+template <int E>
+__device__ __forceinline__ void ldvi(const int *p, int first, int (&v)[E])
+{
+#pragma unroll
+    for (int k = 0; k < E / 2; ++k) {
+        const int2 t = reinterpret_cast<const int2 *>(p + first)[k];
+        v[2 * k] = t.x; v[2 * k + 1] = t.y;
+    }
+}
+// store E adjacent doubles starting at element `first`, never touching index >= len
+template <int E>
+__device__ __forceinline__ void stv(double *p, int first, int len, const double (&v)[E])
+{
+#pragma unroll
+    for (int k = 0; k < E / 2; ++k) {
+        const int i = first + 2 * k;
+        if (i + 1 < len) reinterpret_cast<double2 *>(p + i)[0] = make_double2(v[2 * k], v[2 * k + 1]);
+        else if (i < len) p[i] = v[2 * k];
+    }
+}
+
+template <int MAXT, int MM, int E>          // <= MAXT threads (register budget), <= MM history pairs, E variables per thread
 __global__ void __launch_bounds__(MAXT)
 update_reg_kernel(UpdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int E = UPD_EPT;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x;
     const int n = a.n, ng = a.ng, M = a.M;
+    const int hs = hist_stride(n);
     double *q = lds;                         // [ng]
     double *q2 = lds + ng;                   // [ng]
     BlockRed red(lds + 2 * ng);              // [2][12][16]
     const int stride = acc_stride(n);
     const bool ties = (ng != n);
+    // this thread's E adjacent variables; threads past the end load from 0 and are masked out
+    const int r0 = tid * E;                  // first element (stores)
+    const int pr = (r0 < n) ? r0 : 0;        // first element (loads)
+    bool gin[E], tin[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { gin[e] = r0 + e < ng; tin[e] = r0 + e < n; }
 
 #ifdef CFMM_PHASE_TIMERS
     const long long c8 = clock64(), w8 = wall_clock64();
@@ -698,47 +773,38 @@ update_reg_kernel(UpdArgs a)
 #endif
     PHASE_STAMP(a.ts, 9);
 
-    // ---- loads, all issued up front ----------------------------------------------------------
-    bool gin[E], tin[E];
-    int gr[E], tj[E];
+    // ---- loads, all issued up front (one 16-byte load per vector and thread) ---------------------
     double s[E], s_t[E], Gs[E], d[E], Ds[E], glo[E], ghi[E];
-    double Sx[MAX_MEMORY][E], Yx[MAX_MEMORY][E], rho_old[MAX_MEMORY];
+    ldv<E>(a.s, pr, s); ldv<E>(a.s_t, pr, s_t); ldv<E>(a.Gs, pr, Gs); ldv<E>(a.d, pr, d); ldv<E>(a.Ds, pr, Ds);
+    ldv<E>(a.glo, pr, glo); ldv<E>(a.ghi, pr, ghi);
+    double Sx[MM][E], Yx[MM][E], rho_old[MM];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        gr[e] = tid + e * nt; gin[e] = gr[e] < ng;
-        const int r = gin[e] ? gr[e] : 0;
-        s[e] = a.s[r]; s_t[e] = a.s_t[r]; Gs[e] = a.Gs[r]; d[e] = a.d[r]; Ds[e] = a.Ds[r];
-        glo[e] = a.glo[r]; ghi[e] = a.ghi[r];
-    }
-#pragma unroll
-    for (int k = 0; k < MAX_MEMORY; ++k) {
+    for (int k = 0; k < MM; ++k) {
         const bool have = k < st.hist;
         const int slot = have ? (st.head - 1 - k + 2 * M) % M : 0;
         rho_old[k] = have ? a.rho[slot] : 0.0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int r = gin[e] ? gr[e] : 0;
-            Sx[k][e] = (have && gin[e]) ? a.S[(size_t)slot * n + r] : 0.0;     // 0 outside: the dots run over all E
-            Yx[k][e] = (have && gin[e]) ? a.Y[(size_t)slot * n + r] : 0.0;
-        }
+        for (int e = 0; e < E; ++e) { Sx[k][e] = 0.0; Yx[k][e] = 0.0; }
+        if (have) { ldv<E>(a.S + (size_t)slot * hs, pr, Sx[k]); ldv<E>(a.Y + (size_t)slot * hs, pr, Yx[k]); }
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (!gin[e]) { Sx[k][e] = 0.0; Yx[k][e] = 0.0; }     // the dots run over all E
     }
-    double psi[E], dg[E], nuj[E], hj[E], cj[E], offj[E];
+    double nuj[E], hj[E], cj[E], offj[E];
     int ct[E], grp[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        tj[e] = tid + e * nt; tin[e] = tj[e] < n;
-        const int j = tin[e] ? tj[e] : 0;
-        nuj[e] = a.nu[j]; hj[e] = a.h[j]; cj[e] = a.c[j]; offj[e] = a.off[j]; ct[e] = a.ctype[j]; grp[e] = a.grp[j];
-        psi[e] = 0.0; dg[e] = 0.0;
-    }
-    for (int sl0 = 0; sl0 < a.nslices; sl0 += 4) {     // 4 slices per trip: 4E loads in flight
+    for (int e = 0; e < E; ++e) { offj[e] = 0.0; grp[e] = 0; }
+    ldv<E>(a.nu, pr, nuj); ldv<E>(a.h, pr, hj); ldv<E>(a.c, pr, cj); ldvi<E>(a.ctype, pr, ct);
+    if (ties) { ldv<E>(a.off, pr, offj); ldvi<E>(a.grp, pr, grp); }
+    double psi[E], dg[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { psi[e] = 0.0; dg[e] = 0.0; }
+    for (int sl0 = 0; sl0 < a.nslices; sl0 += 4) {     // 4 slices per trip
         double pp[4][E];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bool on = sl0 + u < a.nslices;
-            const double *base = a.acc + (size_t)(on ? sl0 + u : 0) * stride;
 #pragma unroll
-            for (int e = 0; e < E; ++e) pp[u][e] = on ? base[tin[e] ? tj[e] : 0] : 0.0;
+            for (int e = 0; e < E; ++e) pp[u][e] = 0.0;
+            if (sl0 + u < a.nslices) ldv<E>(a.acc + (size_t)(sl0 + u) * stride, pr, pp[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -747,30 +813,32 @@ update_reg_kernel(UpdArgs a)
     }
     if (st.first) {                                    // first evaluation of a solve: the diagonal metric
         for (int sl = 0; sl < a.nslices; ++sl) {
-            const double *base = a.acc + (size_t)sl * stride + n + 8;
+            double t2[E];
+            ldv<E>(a.acc + (size_t)sl * stride + acc_diag(n), pr, t2);
 #pragma unroll
-            for (int e = 0; e < E; ++e) dg[e] += base[tin[e] ? tj[e] : 0];
+            for (int e = 0; e < E; ++e) dg[e] += t2[e];
         }
     }
     double fpools = 0.0;
-    if (tid < a.nslices) fpools = a.acc[(size_t)tid * stride + n];
+    if (tid < a.nslices) fpools = a.acc[(size_t)tid * stride + acc_arb(n)];
     // the accumulators are consumed: clear them for the next evaluation
-    for (int sl = 0; sl < a.nslices; ++sl) {
-        double *base = a.acc + (size_t)sl * stride;
+    {
+        double zero[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) if (tin[e]) { base[tj[e]] = 0.0; if (st.first) base[n + 8 + tj[e]] = 0.0; }
+        for (int e = 0; e < E; ++e) zero[e] = 0.0;
+        for (int sl = 0; sl < a.nslices; ++sl) {
+            double *base = a.acc + (size_t)sl * stride;
+            if (r0 < n) { stv<E>(base, r0, n, zero); if (st.first) stv<E>(base + acc_diag(n), r0, n, zero); }
+        }
+        if (tid < a.nslices) a.acc[(size_t)tid * stride + acc_arb(n)] = 0.0;
     }
-    if (tid < a.nslices) a.acc[(size_t)tid * stride + n] = 0.0;
-
     PHASE_STAMP(a.ts, 10);
+
     // ---- A. residuals, group gradient at the trial point -----------------------------------------
     if (ties) {
-        for (int r = tid; r < ng; r += nt) { q[r] = 0.0; q2[r] = 0.0; }
+        for (int r = tid; r < ng; r += blockDim.x) { q[r] = 0.0; q2[r] = 0.0; }
         __syncthreads();
     }
-    // every scalar the accept test, the stopping rule and the pair need comes out of ONE batched
-    // reduction: the quantities of the accepted branch (pg, |q|^2, act) are computed speculatively
-    // at the trial point, which costs a few FMAs and saves three barrier round trips
     double Gs_t[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -789,9 +857,11 @@ update_reg_kernel(UpdArgs a)
     if (ties) {
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < E; ++e) if (gin[e]) { Gs_t[e] = q[gr[e]]; if (st.first) Ds[e] = q2[gr[e]]; }
+        for (int e = 0; e < E; ++e) if (gin[e]) { Gs_t[e] = q[r0 + e]; if (st.first) Ds[e] = q2[r0 + e]; }
         __syncthreads();
     }
+    // ONE batched reduction; the quantities of the accepted branch (pg, |q|^2, act) are computed
+    // speculatively at the trial point:
     // 0 f_lin  1 gapv  2 Gs.ds  3 Gs_t.ds  4 s.y  5 s.s  6 y.y  7 pg  8 |q|^2  |  9 viol  10 scale
     double A[11] = {fpools, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     double sv[E], yv[E], qv[E];
@@ -831,8 +901,8 @@ update_reg_kernel(UpdArgs a)
     if (!st.first)
         accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * A[2]) ||
                                   (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && A[3] <= 0.8 * fabs(A[2])));
-
     PHASE_STAMP(a.ts, 12);
+
     bool new_dir = false;
     if (!accept) {
         st.t_step *= 0.5;
@@ -843,9 +913,7 @@ update_reg_kernel(UpdArgs a)
         bool pair_ok = false;
         double rho_new = 0.0;
         if (!st.first) {
-            double *svg = a.S + (size_t)st.head * n, *yvg = a.Y + (size_t)st.head * n;
-#pragma unroll
-            for (int e = 0; e < E; ++e) if (gin[e]) { svg[gr[e]] = sv[e]; yvg[gr[e]] = yv[e]; }
+            if (r0 < ng) { stv<E>(a.S + (size_t)st.head * hs, r0, ng, sv); stv<E>(a.Y + (size_t)st.head * hs, r0, ng, yv); }
             if (A[4] > 1e-12 * sqrt(A[5]) * sqrt(A[6])) {
                 pair_ok = true;
                 rho_new = 1.0 / A[4];
@@ -856,10 +924,9 @@ update_reg_kernel(UpdArgs a)
             st.iters += 1;
         }
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (gin[e]) { s[e] = s_t[e]; Gs[e] = Gs_t[e]; a.s[gr[e]] = s[e]; a.Gs[gr[e]] = Gs[e]; if (st.first) a.Ds[gr[e]] = Ds[e]; }
-            if (tin[e]) { a.psi_acc[tj[e]] = psi[e]; a.nu_acc[tj[e]] = nuj[e]; }
-        }
+        for (int e = 0; e < E; ++e) if (gin[e]) { s[e] = s_t[e]; Gs[e] = Gs_t[e]; }
+        if (r0 < ng) { stv<E>(a.s, r0, ng, s); stv<E>(a.Gs, r0, ng, Gs); if (st.first) stv<E>(a.Ds, r0, ng, Ds); }
+        if (r0 < n) { stv<E>(a.psi_acc, r0, n, psi); stv<E>(a.nu_acc, r0, n, nuj); }
         st.f = f_t;
         st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
         st.infeas = viol / fmax(scale, 1e-300);
@@ -877,23 +944,17 @@ update_reg_kernel(UpdArgs a)
             new_dir = true;
             // how many of the prefetched (old) pairs are still in the window
             const int old_hist = was_first ? 0 : (pair_ok ? (st.hist - 1) : st.hist);
-            double alpha_new = 0.0, alpha[MAX_MEMORY];
+            double alpha_new = 0.0, alpha[MM];
             if (pair_ok) {
-                double dt = 0.0;
-#pragma unroll
-                for (int e = 0; e < E; ++e) dt += sv[e] * qv[e];
-                alpha_new = rho_new * red.sum(dt);
+                alpha_new = rho_new * red.sum(dotE<E>(sv, qv));
 #pragma unroll
                 for (int e = 0; e < E; ++e) qv[e] -= alpha_new * yv[e];
             }
 #pragma unroll
-            for (int k = 0; k < MAX_MEMORY; ++k) {
+            for (int k = 0; k < MM; ++k) {
                 alpha[k] = 0.0;
                 if (k < old_hist) {
-                    double dt = 0.0;
-#pragma unroll
-                    for (int e = 0; e < E; ++e) dt += Sx[k][e] * qv[e];
-                    alpha[k] = rho_old[k] * red.sum(dt);
+                    alpha[k] = rho_old[k] * red.sum(dotE<E>(Sx[k], qv));
 #pragma unroll
                     for (int e = 0; e < E; ++e) qv[e] -= alpha[k] * Yx[k][e];
                 }
@@ -904,21 +965,15 @@ update_reg_kernel(UpdArgs a)
                 qv[e] = (gin[e] && H > 0.0) ? qv[e] / H : 0.0;
             }
 #pragma unroll
-            for (int k = MAX_MEMORY - 1; k >= 0; --k) {
+            for (int k = MM - 1; k >= 0; --k) {
                 if (k < old_hist) {
-                    double dt = 0.0;
-#pragma unroll
-                    for (int e = 0; e < E; ++e) dt += Yx[k][e] * qv[e];
-                    const double beta = rho_old[k] * red.sum(dt);
+                    const double beta = rho_old[k] * red.sum(dotE<E>(Yx[k], qv));
 #pragma unroll
                     for (int e = 0; e < E; ++e) qv[e] += Sx[k][e] * (alpha[k] - beta);
                 }
             }
             if (pair_ok) {
-                double dt = 0.0;
-#pragma unroll
-                for (int e = 0; e < E; ++e) dt += yv[e] * qv[e];
-                const double beta = rho_new * red.sum(dt);
+                const double beta = rho_new * red.sum(dotE<E>(yv, qv));
 #pragma unroll
                 for (int e = 0; e < E; ++e) qv[e] += sv[e] * (alpha_new - beta);
             }
@@ -948,19 +1003,27 @@ update_reg_kernel(UpdArgs a)
     // ---- E. next trial point -----------------------------------------------------------------
     PHASE_STAMP(a.ts, 14);
     if (st.status == 0) {
-        __syncthreads();
+        double v[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) if (gin[e]) {
-            double v = s[e] + st.t_step * d[e];
-            v = fmax(v, glo[e]);
-            v = fmin(v, ghi[e]);
-            a.s_t[gr[e]] = v;
-            q[gr[e]] = v;
-            if (new_dir) a.d[gr[e]] = d[e];
+        for (int e = 0; e < E; ++e) {
+            v[e] = s[e] + st.t_step * d[e];
+            v[e] = fmax(v[e], glo[e]);
+            v[e] = fmin(v[e], ghi[e]);
         }
-        __syncthreads();
+        if (r0 < ng) { stv<E>(a.s_t, r0, ng, v); if (new_dir) stv<E>(a.d, r0, ng, d); }
+        double nn[E];
+        if (ties) {
+            __syncthreads();
 #pragma unroll
-        for (int e = 0; e < E; ++e) if (tin[e]) a.nu[tj[e]] = exp(q[grp[e]] + offj[e]);
+            for (int e = 0; e < E; ++e) if (gin[e]) q[r0 + e] = v[e];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) nn[e] = tin[e] ? exp(q[grp[e]] + offj[e]) : 0.0;
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) nn[e] = exp(v[e]);
+        }
+        if (r0 < n) stv<E>(a.nu, r0, n, nn);
         if (st.evals >= a.max_evals) st.status = 3;
     }
     if (tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; }

@@ -59,6 +59,8 @@ if ts.any():
     cyc = tl & ((1 << 48) - 1)
     out["tile_us(avg,max,count)"] = {nm: (round(float(cyc[bk == q].mean()) / 2400.0, 2), round(float(cyc[bk == q].max()) / 2400.0, 2),
                                           int((bk == q).sum())) for q, nm in enumerate(names) if (bk == q).any()}
+    out["between_tiles_us(mean,max)"] = [round(float(cyc[:, 7][bk[:, 7] == 14].mean()) / 2400.0, 2), round(float(cyc[:, 7].max()) / 2400.0, 2)]
+    cyc = cyc[:, :7]; bk = bk[:, :7]
     per_wave = cyc.sum(axis=1) / 2400.0
     out["wave_busy_us(min,mean,max)"] = [round(float(x), 2) for x in (per_wave[per_wave > 0].min(), per_wave[per_wave > 0].mean(), per_wave.max())]
     prob.solve(tol=1e-6, max_evals=12)
