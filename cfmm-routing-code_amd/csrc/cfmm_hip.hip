@@ -327,6 +327,7 @@ void cfmm_default_opts(cfmm_opts *o)
     std::memset(o, 0, sizeof *o);
     o->tol_gap = 1e-6; o->tol_infeas = 1e-6; o->armijo = 1e-4; o->max_step = 2.0;
     o->max_evals = 2000; o->memory = 0; o->iters_per_graph = 4;
+    if (const char *s = getenv("CFMM_ITERS_PER_GRAPH")) o->iters_per_graph = std::max(1, atoi(s));     // tuning knob
 }
 
 const char *cfmm_last_error(cfmm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }

@@ -232,3 +232,68 @@ def test_integration_md_ctypes_stub_runs():
     st = ns["st"]
     assert st.status == 1 and st.gap <= 1e-6 and st.infeas <= 1e-6 and st.primal_value > 1.0
     assert np.all(ns["psi"] >= -1e-6 * np.abs(ns["psi"]).max())
+
+
+def test_full_size_c4_single_gpu_streams_from_hbm():
+    """BASELINE config 4's whole pool set (1e7 constant-product pools / 2000 tokens, 320 MB: larger than
+    the Infinity Cache) on ONE GPU: solve to the certificates, then size-independent checks"""
+    net = synthetic.config("C4", seed=0)
+    n = net["n_tokens"]
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    v = p.solve(tol=1e-6)
+    assert p.status == "optimal" and p.gap <= 1e-6 and p.infeas <= 1e-6 and p.stats["evals"] < 200
+    b = net["cp2"]
+    d, l = p.bucket_trades("cp2")
+    y = l - d
+    assert np.all(d * l == 0) and np.all(d >= 0) and np.all(l >= 0)
+    psi = np.bincount(b["ia"], weights=y[0], minlength=n) + np.bincount(b["ib"], weights=y[1], minlength=n)
+    assert np.abs(psi - p.psi).max() <= 1e-9 * np.abs(psi).max()
+    xa = b["Ra"] + b["fee"] * d[0] - l[0]; xb = b["Rb"] + b["fee"] * d[1] - l[1]
+    assert np.abs(0.5 * np.log(xa / b["Ra"]) + 0.5 * np.log(xb / b["Rb"])).max() <= 1e-12
+    assert 0 <= p.dual_value - v <= 2e-6 * abs(v)
+    p.close()
+
+
+@pytest.mark.parametrize("kind", ["liquidate", "swap"])
+def test_basket_utilities_at_scale_match_oracle(oracle_lib, kind):
+    """liquidation.py:57,77-80 / two-asset.py:66,86 utilities on a 1e5-pool mixed network"""
+    net = synthetic.config("C3", scale=0.1, seed=2)
+    n = net["n_tokens"]
+    rng = np.random.default_rng(7)
+    h = np.zeros(n); idx = rng.choice(n, 10, replace=False)
+    h[idx] = np.exp(rng.normal(2, 0.5, 10)) / net["prices"][idx] * 10
+    t = int(rng.integers(0, n)); h[t] = 0.0
+    u = cfmm.Liquidate(h, t) if kind == "liquidate" else cfmm.Swap(h, t)
+    p = cfmm.Problem.from_network(net, utility=u)
+    v = p.solve(tol=1e-7)
+    o = oracle_lib.Oracle(n, threads=4); o.add_network(net); o.set_utility(u.c, u.h, u.ctype)
+    r = o.solve(cfmm.start_prices(net, u), tol=1e-7)
+    assert p.status == "optimal" and r["status"] == 1
+    assert abs(v - r["primal_value"]) <= 2e-6 * abs(v)
+    res = p.psi + u.h
+    if kind == "liquidate":
+        mask = np.arange(n) != t
+        assert np.abs(res[mask]).max() <= 1e-6 * max(np.abs(p.psi).max(), h.max())
+    else:
+        assert res.min() >= -1e-6 * max(np.abs(p.psi).max(), h.max())
+    p.close()
+
+
+def test_virtual_shards_on_the_gpu_sum_to_the_unsharded_evaluation():
+    """pool-sharding without a second GPU: S shards evaluated one after the other on
+    the device and summed on the host equal the unsharded dual evaluation"""
+    net = synthetic.config("C3", scale=0.05, seed=4)
+    n = net["n_tokens"]
+    nu = net["c"] * np.exp(np.random.default_rng(0).normal(0, 0.02, n))
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    f, psi = p.eval_dual(nu)
+    p.close()
+    for S in (2, 8):
+        fs, ps = 0.0, np.zeros(n)
+        for r in range(S):
+            q = cfmm.Problem.from_network(cfmm.distributed.rank_network(net, r, S), utility=cfmm.Arbitrage(net["c"]))
+            fr, pr = q.eval_dual(nu)
+            fs += fr; ps += pr
+            q.close()
+        assert abs(fs - f) <= 1e-11 * abs(f)
+        assert np.abs(ps - psi).max() <= 1e-10 * np.abs(psi).max()
