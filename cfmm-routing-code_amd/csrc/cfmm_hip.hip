@@ -89,6 +89,9 @@ struct cfmm_ctx {
     int nslices = 4;
     int eval_grid_mult = 1;
     int eval_blocks_per_cu = 1;        // resident EVAL_THREADS-workgroups per CU (occupancy query at create)
+    int upd_grid = 1;
+    bool no_graph = false;             // CFMM_NO_GRAPH=1: eager enqueue on a single GPU too (exercises the pool-sharded control flow)
+    bool multi_graph = false;          // CFMM_MULTI_GRAPH=1: capture the pool-sharded iteration (with its all-reduce) too
     int upd_variant = 0;               // CFMM_UPDATE_VARIANT: A/B choice among the register-resident instantiations
     bool upd_generic = false;          // CFMM_UPDATE_GENERIC=1: force the generic update kernel (A/B testing)
     bool have_utility = false, have_nu = false;
@@ -240,11 +243,12 @@ void launch_update(cfmm_ctx *ctx, const UpdArgs &ua)
     const int n = ctx->n;
     const size_t lds = upd_lds_bytes(ctx->ng);
     auto thr = [n](int E) { return 64 * ((n + 64 * E - 1) / (64 * E)); };
+    const int ug = ctx->upd_grid;                   // (tuning probe) identical redundant workgroups
     const int v = ctx->upd_generic ? 9 : ctx->upd_variant;
     if (v == 0 && n <= 1024)                        // 2 variables per thread, <= 8 waves, any memory
-        hipLaunchKernelGGL((update_reg_kernel<512, 8, 2>), dim3(1), dim3(thr(2)), lds, ctx->stream, ua);
+        hipLaunchKernelGGL((update_reg_kernel<512, 8, 2>), dim3(ug), dim3(thr(2)), lds, ctx->stream, ua);
     else if ((v == 0 || v == 1) && n <= 2048 && ua.M <= 4)   // 4 per thread, <= 8 waves, memory <= 4
-        hipLaunchKernelGGL((update_reg_kernel<512, 4, 4>), dim3(1), dim3(thr(4)), lds, ctx->stream, ua);
+        hipLaunchKernelGGL((update_reg_kernel<512, 4, 4>), dim3(ug), dim3(thr(4)), lds, ctx->stream, ua);
     else if (v == 2 && n <= 1024)                   // (A/B) 4 per thread, <= 4 waves
         hipLaunchKernelGGL((update_reg_kernel<256, 8, 4>), dim3(1), dim3(thr(4)), lds, ctx->stream, ua);
     else
@@ -365,6 +369,9 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if (const char *s = getenv("CFMM_EVAL_GRID_MULT")) ctx->eval_grid_mult = std::max(1, atoi(s));
     if (const char *s = getenv("CFMM_UPDATE_GENERIC")) ctx->upd_generic = atoi(s) != 0;
     if (const char *s = getenv("CFMM_UPDATE_VARIANT")) ctx->upd_variant = atoi(s);
+    if (const char *s = getenv("CFMM_UPD_GRID")) ctx->upd_grid = std::max(1, atoi(s));
+    if (const char *s = getenv("CFMM_MULTI_GRAPH")) ctx->multi_graph = atoi(s) != 0;
+    if (const char *s = getenv("CFMM_NO_GRAPH")) ctx->no_graph = atoi(s) != 0;
     const int n = n_tokens;
     int rc = 0;
     rc |= dev_upload<double>(ctx, &ctx->c, nullptr, n + 4, nullptr);
@@ -657,7 +664,11 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     const int n = ctx->n;
     if (nu0) { int rc = cfmm_set_nu(ctx, nu0); if (rc) return rc; }
     if (!ctx->have_nu) return fail(ctx, CFMM_E_STATE, "solve: no start prices (pass nu0 or call cfmm_set_nu)");
-    if (!ctx->g_valid || !same_opts(o, ctx->g_opts)) { int rc = build_graph(ctx, o); if (rc) return rc; }
+    // Single GPU: `iters_per_graph` iterations are replayed from one captured hipGraph.  Pool-sharded
+    // (RCCL all-reduce inside every iteration): the same iterations are enqueued eagerly, the way RCCL
+    // is conventionally driven (CFMM_MULTI_GRAPH=1 opts into capturing them too).
+    const bool use_graph = (ctx->n_ranks == 1 || ctx->multi_graph) && !ctx->no_graph;
+    if (use_graph && (!ctx->g_valid || !same_opts(o, ctx->g_opts))) { int rc = build_graph(ctx, o); if (rc) return rc; }
     const UpdArgs ua = make_upd_args(ctx, o);
 
     // ---- timed region: the outer loop (upload and trade read-back excluded) ----------------
@@ -672,10 +683,15 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     const int max_chunks = (o.max_evals + o.iters_per_graph - 1) / o.iters_per_graph + 1;
     int status = 0;
     for (int cidx = 0; cidx < max_chunks; ++cidx) {
-        HIP_TRY(ctx, hipGraphLaunch(ctx->gexec, ctx->stream));
+        if (use_graph) {
+            HIP_TRY(ctx, hipGraphLaunch(ctx->gexec, ctx->stream));
+        } else {
+            for (int it = 0; it < o.iters_per_graph; ++it) { int rc = enqueue_iteration<false>(ctx, ua); if (rc) return rc; }
+            HIP_TRY(ctx, hipGetLastError());
+        }
         HIP_TRY(ctx, hipMemcpyAsync(&ctx->hst[cidx & 1], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev[cidx & 1], ctx->stream));
-        if (cidx >= 1) {                       // poll one replay behind: the device never idles
+        if (cidx >= 1) {                       // poll one chunk behind: the device never idles
             HIP_TRY(ctx, hipEventSynchronize(ctx->ev[(cidx - 1) & 1]));
             status = ctx->hst[(cidx - 1) & 1].status;
             if (status != 0) break;
@@ -779,6 +795,11 @@ int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128)
     if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclCommInitRank -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
     ctx->n_ranks = n_ranks; ctx->rank = rank;
     ctx->g_valid = false;
+    // one all-reduce outside any timed or captured region: RCCL sets up its channels / buffers on first use.
+    // (the accumulators are all zero here, and stay zero)
+    rc = g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)acc_stride(ctx->n), NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
+    if (rc != 0) return fail(ctx, CFMM_E_RCCL, "warm-up ncclAllReduce -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CFMM_OK;
 }
 

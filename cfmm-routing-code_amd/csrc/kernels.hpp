@@ -757,6 +757,9 @@ update_reg_kernel(UpdArgs a)
     const int tid = threadIdx.x;
     const int n = a.n, ng = a.ng, M = a.M;
     const int hs = hist_stride(n);
+    // (tuning probe) the kernel may be launched with several identical workgroups: only workgroup 0 stores
+    const bool wr = blockIdx.x == 0;
+    const int nS = wr ? n : 0, ngS = wr ? ng : 0;
     double *q = lds;                         // [ng]
     double *q2 = lds + ng;                   // [ng]
     BlockRed red(lds + 2 * ng);              // [2][12][16]
@@ -772,29 +775,13 @@ update_reg_kernel(UpdArgs a)
 #ifdef CFMM_PHASE_TIMERS
     const long long c8 = clock64(), w8 = wall_clock64();
 #endif
-    DevState st = *a.st;
-    if (st.status != 0) return;
-#ifdef CFMM_PHASE_TIMERS
-    if (a.ts && threadIdx.x == 0) { a.ts[16] = c8; a.ts[17] = w8; }
-#endif
-    PHASE_STAMP(a.ts, 9);
-
+    const DevState *stp = a.st;
+    DevState st;
+    st = *stp;                                        // (consumed below, after the first batch of loads is in flight)
     // ---- loads, all issued up front (one 16-byte load per vector and thread) ---------------------
     double s[E], s_t[E], Gs[E], d[E], Ds[E], glo[E], ghi[E];
     ldv<E>(a.s, pr, s); ldv<E>(a.s_t, pr, s_t); ldv<E>(a.Gs, pr, Gs); ldv<E>(a.d, pr, d); ldv<E>(a.Ds, pr, Ds);
     ldv<E>(a.glo, pr, glo); ldv<E>(a.ghi, pr, ghi);
-    double Sx[MM][E], Yx[MM][E], rho_old[MM];
-#pragma unroll
-    for (int k = 0; k < MM; ++k) {
-        const bool have = k < st.hist;
-        const int slot = have ? (st.head - 1 - k + 2 * M) % M : 0;
-        rho_old[k] = have ? a.rho[slot] : 0.0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) { Sx[k][e] = 0.0; Yx[k][e] = 0.0; }
-        if (have) { ldv<E>(a.S + (size_t)slot * hs, pr, Sx[k]); ldv<E>(a.Y + (size_t)slot * hs, pr, Yx[k]); }
-#pragma unroll
-        for (int e = 0; e < E; ++e) if (!gin[e]) { Sx[k][e] = 0.0; Yx[k][e] = 0.0; }     // the dots run over all E
-    }
     double nuj[E], hj[E], cj[E], offj[E];
     int ct[E], grp[E];
 #pragma unroll
@@ -817,6 +804,11 @@ update_reg_kernel(UpdArgs a)
 #pragma unroll
             for (int e = 0; e < E; ++e) psi[e] += pp[u][e];
     }
+    if (st.status != 0) return;
+#ifdef CFMM_PHASE_TIMERS
+    if (a.ts && threadIdx.x == 0) { a.ts[16] = c8; a.ts[17] = w8; }
+#endif
+    PHASE_STAMP(a.ts, 9);
     if (st.first) {                                    // first evaluation of a solve: the diagonal metric
         for (int sl = 0; sl < a.nslices; ++sl) {
             double t2[E];
@@ -824,6 +816,19 @@ update_reg_kernel(UpdArgs a)
 #pragma unroll
             for (int e = 0; e < E; ++e) dg[e] += t2[e];
         }
+    }
+    // history last (it is needed last): ages are resolved to physical slots here, after st has arrived
+    double Sx[MM][E], Yx[MM][E], rho_old[MM];
+#pragma unroll
+    for (int k = 0; k < MM; ++k) {
+        const bool have = k < st.hist;
+        const int slot = have ? (st.head - 1 - k + 2 * M) % M : 0;
+        rho_old[k] = have ? a.rho[slot] : 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { Sx[k][e] = 0.0; Yx[k][e] = 0.0; }
+        if (have) { ldv<E>(a.S + (size_t)slot * hs, pr, Sx[k]); ldv<E>(a.Y + (size_t)slot * hs, pr, Yx[k]); }
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (!gin[e]) { Sx[k][e] = 0.0; Yx[k][e] = 0.0; }     // the dots run over all E
     }
     double fpools = 0.0;
     if (tid < a.nslices) fpools = a.acc[(size_t)tid * stride + acc_arb(n)];
@@ -834,9 +839,9 @@ update_reg_kernel(UpdArgs a)
         for (int e = 0; e < E; ++e) zero[e] = 0.0;
         for (int sl = 0; sl < a.nslices; ++sl) {
             double *base = a.acc + (size_t)sl * stride;
-            if (r0 < n) { stv<E>(base, r0, n, zero); if (st.first) stv<E>(base + acc_diag(n), r0, n, zero); }
+            if (r0 < n) { stv<E>(base, r0, nS, zero); if (st.first) stv<E>(base + acc_diag(n), r0, nS, zero); }
         }
-        if (tid < a.nslices) a.acc[(size_t)tid * stride + acc_arb(n)] = 0.0;
+        if (wr && tid < a.nslices) a.acc[(size_t)tid * stride + acc_arb(n)] = 0.0;
     }
     PHASE_STAMP(a.ts, 10);
 
@@ -919,11 +924,11 @@ update_reg_kernel(UpdArgs a)
         bool pair_ok = false;
         double rho_new = 0.0;
         if (!st.first) {
-            if (r0 < ng) { stv<E>(a.S + (size_t)st.head * hs, r0, ng, sv); stv<E>(a.Y + (size_t)st.head * hs, r0, ng, yv); }
+            if (r0 < ng) { stv<E>(a.S + (size_t)st.head * hs, r0, ngS, sv); stv<E>(a.Y + (size_t)st.head * hs, r0, ngS, yv); }
             if (A[4] > 1e-12 * sqrt(A[5]) * sqrt(A[6])) {
                 pair_ok = true;
                 rho_new = 1.0 / A[4];
-                if (tid == 0) a.rho[st.head] = rho_new;
+                if (wr && tid == 0) a.rho[st.head] = rho_new;
                 st.head = (st.head + 1) % M;
                 if (st.hist < M) st.hist += 1;
             }
@@ -931,8 +936,8 @@ update_reg_kernel(UpdArgs a)
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) if (gin[e]) { s[e] = s_t[e]; Gs[e] = Gs_t[e]; }
-        if (r0 < ng) { stv<E>(a.s, r0, ng, s); stv<E>(a.Gs, r0, ng, Gs); if (st.first) stv<E>(a.Ds, r0, ng, Ds); }
-        if (r0 < n) { stv<E>(a.psi_acc, r0, n, psi); stv<E>(a.nu_acc, r0, n, nuj); }
+        if (r0 < ng) { stv<E>(a.s, r0, ngS, s); stv<E>(a.Gs, r0, ngS, Gs); if (st.first) stv<E>(a.Ds, r0, ngS, Ds); }
+        if (r0 < n) { stv<E>(a.psi_acc, r0, nS, psi); stv<E>(a.nu_acc, r0, nS, nuj); }
         st.f = f_t;
         st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
         st.infeas = viol / fmax(scale, 1e-300);
@@ -1016,7 +1021,7 @@ update_reg_kernel(UpdArgs a)
             v[e] = fmax(v[e], glo[e]);
             v[e] = fmin(v[e], ghi[e]);
         }
-        if (r0 < ng) { stv<E>(a.s_t, r0, ng, v); if (new_dir) stv<E>(a.d, r0, ng, d); }
+        if (r0 < ng) { stv<E>(a.s_t, r0, ngS, v); if (new_dir) stv<E>(a.d, r0, ngS, d); }
         double nn[E];
         if (ties) {
             __syncthreads();
@@ -1029,10 +1034,10 @@ update_reg_kernel(UpdArgs a)
 #pragma unroll
             for (int e = 0; e < E; ++e) nn[e] = exp(v[e]);
         }
-        if (r0 < n) stv<E>(a.nu, r0, n, nn);
+        if (r0 < n) stv<E>(a.nu, r0, nS, nn);
         if (st.evals >= a.max_evals) st.status = 3;
     }
-    if (tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; }
+    if (wr && tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; }
     PHASE_STAMP(a.ts, 15);
 }
 

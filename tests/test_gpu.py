@@ -297,3 +297,22 @@ def test_virtual_shards_on_the_gpu_sum_to_the_unsharded_evaluation():
             q.close()
         assert abs(fs - f) <= 1e-11 * abs(f)
         assert np.abs(ps - psi).max() <= 1e-10 * np.abs(psi).max()
+
+
+def test_eager_iteration_path_matches_graph_path(tmp_path):
+    """the pool-sharded build enqueues its iterations eagerly (RCCL between the kernels) instead of
+    replaying a captured graph; CFMM_NO_GRAPH=1 drives the same control flow on one GPU"""
+    import subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json; sys.path[:0] = [%r, %r]; import cfmm; from cfmm import synthetic; "
+            "net = synthetic.config('C3', scale=0.05, seed=0); p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net['c'])); "
+            "v = p.solve(tol=1e-6); print(json.dumps(dict(v=v, status=p.status, evals=p.stats['evals'], nu=p.nu.tolist())))"
+            % (root, os.path.join(root, "cfmm-routing-code_amd")))
+    out = {}
+    for mode in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CFMM_NO_GRAPH=mode), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["0"]["status"] == out["1"]["status"] == "optimal"
+    assert out["0"]["evals"] == out["1"]["evals"]
+    assert abs(out["0"]["v"] - out["1"]["v"]) <= 1e-9 * abs(out["0"]["v"])
