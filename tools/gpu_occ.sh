@@ -1,6 +1,19 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-for ug in 1 8 64 256; do
-echo -n "upd_grid=$ug "; CFMM_UPD_GRID=$ug python tools/microbench.py --config C3 --solves 10 | python -c "
-import sys, json; r = json.loads(sys.stdin.read()); print(r['status'], 'evals', r['evals'], 'solve_wall_ms %.3f dev_us/eval %.1f eval %.1f' % (r['solve_wall_ms'], r['dev_us_per_eval'], r['eval_all_us']))"
-done
+python - <<'PY'
+import sys, json
+sys.path[:0] = ['.', 'cfmm-routing-code_amd']
+import numpy as np
+import cfmm
+from cfmm import synthetic, _lib
+for name, kw in (("uniform", dict()), ("zipf1.1", dict(zipf_s=1.1)), ("zipf1.5", dict(zipf_s=1.5))):
+    net = synthetic.make_network(1000, m_cp2=1_000_000, seed=0, **kw)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    ctx = p._ensure_ctx()
+    ctx.set_nu(net["c"] * np.exp(np.random.default_rng(0).normal(0, 0.01, 1000)))
+    us = ctx.time_eval_kernel(_lib.TIME_ALL, 30) * 1e6
+    cnt = np.bincount(net["cp2"]["ia"], minlength=1000)
+    v = p.solve(tol=1e-6)
+    print(name, "eval_us %.2f" % us, "max token share %.3f" % (cnt.max() / cnt.sum()), "solve", p.status, p.stats["evals"], "dev_us/eval %.1f" % (1e6 * p.stats["device_seconds"] / p.stats["evals"]))
+    p.close()
+PY
