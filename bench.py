@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--cpu-solves", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--kernel-reps", type=int, default=50)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the pool-sharded code path (process group, RCCL communicator, all-reduce per evaluation) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,7 +94,10 @@ def main():
     from cfmm import synthetic, _lib
 
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_dist
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -104,7 +109,7 @@ def main():
     prob._ensure_ctx()
 
     def sync():
-        if world > 1:
+        if sharded:
             import torch
             torch.cuda.synchronize()
             dist.barrier()
@@ -124,7 +129,7 @@ def main():
             raise SystemExit(f"rank {rank}: solve ended with status {prob.status} (gap {prob.gap:.2e}, infeas {prob.infeas:.2e})")
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -188,7 +193,7 @@ def main():
                                    "evals_per_solve": ce / ns, "objective": r["primal_value"],
                                    "single_evaluation_ms": eval_s * 1e3}
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -43,7 +43,7 @@ def sharded_problem(net, utility, dist=None, device=None, shard=True):
         rank, world = dist.get_rank(), dist.get_world_size()
     part = rank_network(net, rank, world) if (shard and world > 1) else net
     prob = Problem.from_network(part, utility=utility, device=local_rank if device is None else device)
-    if world > 1:
+    if dist is not None:                 # (a process group of one rank runs the same path)
         from . import _lib
         prob._ensure_ctx()
         prob.init_comm(world, rank, broadcast_unique_id(dist, _lib.comm_unique_id))

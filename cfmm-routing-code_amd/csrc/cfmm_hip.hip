@@ -224,7 +224,7 @@ int set_all_lds_attrs(cfmm_ctx *ctx)
 UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
 {
     UpdArgs a;
-    a.n = ctx->n; a.ng = ctx->ng; a.M = o.memory; a.nslices = ctx->n_ranks > 1 ? 1 : ctx->nslices;
+    a.n = ctx->n; a.ng = ctx->ng; a.M = o.memory; a.nslices = ctx->comm ? 1 : ctx->nslices;
     a.acc = ctx->acc;
     a.c = ctx->c; a.h = ctx->h; a.off = ctx->off; a.glo = ctx->glo; a.ghi = ctx->ghi;
     a.ctype = ctx->ctype; a.grp = ctx->grp;
@@ -260,7 +260,7 @@ template <bool WITH_D>
 int enqueue_iteration(cfmm_ctx *ctx, const UpdArgs &ua)
 {
     launch_all_evals<WITH_D>(ctx);
-    if (ctx->n_ranks > 1) {
+    if (ctx->comm) {                            // pool-sharded (a communicator of one rank runs the same path)
         const int len = WITH_D ? acc_stride(ctx->n) : acc_arb(ctx->n) + 1;
         hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, ctx->n,
                            ctx->nslices, WITH_D ? 1 : 0, (const DevState *)nullptr);
@@ -636,7 +636,7 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
     const int len = acc_stride(n);
     hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, n, ctx->nslices, 1, (const DevState *)nullptr);
     HIP_TRY(ctx, hipGetLastError());
-    if (ctx->n_ranks > 1) {
+    if (ctx->comm) {                            // pool-sharded (a communicator of one rank runs the same path)
         int rc = g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
         if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed (%d)", rc);
     }
@@ -667,7 +667,7 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     // Single GPU: `iters_per_graph` iterations are replayed from one captured hipGraph.  Pool-sharded
     // (RCCL all-reduce inside every iteration): the same iterations are enqueued eagerly, the way RCCL
     // is conventionally driven (CFMM_MULTI_GRAPH=1 opts into capturing them too).
-    const bool use_graph = (ctx->n_ranks == 1 || ctx->multi_graph) && !ctx->no_graph;
+    const bool use_graph = (!ctx->comm || ctx->multi_graph) && !ctx->no_graph;
     if (use_graph && (!ctx->g_valid || !same_opts(o, ctx->g_opts))) { int rc = build_graph(ctx, o); if (rc) return rc; }
     const UpdArgs ua = make_upd_args(ctx, o);
 

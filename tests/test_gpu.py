@@ -316,3 +316,38 @@ def test_eager_iteration_path_matches_graph_path(tmp_path):
     assert out["0"]["status"] == out["1"]["status"] == "optimal"
     assert out["0"]["evals"] == out["1"]["evals"]
     assert abs(out["0"]["v"] - out["1"]["v"]) <= 1e-9 * abs(out["0"]["v"])
+
+
+def test_pool_sharded_path_with_a_one_rank_communicator():
+    """the whole N > 1 code path on ONE GPU: torch.distributed(nccl) rendezvous, communicator id broadcast,
+    cfmm_comm_init (RCCL resolved at run time, warm-up all-reduce), eager iterations with fold + ncclAllReduce
+    + update -- a communicator of one rank runs exactly what every rank of an 8-GPU job runs"""
+    import subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, os, json
+sys.path[:0] = [%r, %r]
+import torch, torch.distributed as dist
+import cfmm
+from cfmm import synthetic
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+net = synthetic.config("C3", scale=0.05, seed=0)
+p = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=0)
+v = p.solve(tol=1e-6)
+f, psi = p.eval_dual(p.nu)
+q = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+w = q.solve(tol=1e-6)
+f2, psi2 = q.eval_dual(p.nu)
+print(json.dumps(dict(v=v, w=w, status=p.status, evals=p.stats["evals"], evals1=q.stats["evals"], ranks=p.stats["n_ranks"],
+                      df=abs(f - f2) / abs(f2), dpsi=float(abs(psi - psi2).max() / abs(psi2).max()))))
+dist.destroy_process_group()
+''' % (root, os.path.join(root, "cfmm-routing-code_amd"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["status"] == "optimal" and out["ranks"] == 1
+    assert out["evals"] == out["evals1"]
+    assert abs(out["v"] - out["w"]) <= 1e-9 * abs(out["w"])
+    assert out["df"] <= 1e-12 and out["dpsi"] <= 1e-10
