@@ -48,7 +48,7 @@ def build(force=False):
 
 _lib = None
 
-SYMBOLS = ["cfmm_create", "cfmm_destroy", "cfmm_last_error", "cfmm_backend", "cfmm_default_opts",
+SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm_backend", "cfmm_default_opts",
            "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_set_pool_flags", "cfmm_set_utility",
            "cfmm_set_ties", "cfmm_eval_dual", "cfmm_solve", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_comm_unique_id", "cfmm_comm_init",
@@ -66,6 +66,7 @@ def lib():
     L = C.CDLL(_SO)
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
     L.cfmm_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.cfmm_clone.argtypes = [vp, C.POINTER(vp)]
     L.cfmm_destroy.argtypes = [vp]
     L.cfmm_last_error.restype = C.c_char_p; L.cfmm_last_error.argtypes = [vp]
     L.cfmm_backend.restype = C.c_char_p; L.cfmm_backend.argtypes = [vp]
@@ -110,14 +111,23 @@ def i32(a):
 class Context:
     """Thin object wrapper over one cfmm_ctx (one GPU)."""
 
-    def __init__(self, n_tokens, device=0):
+    def __init__(self, n_tokens, device=0, _handle=None):
         self.L = lib()
         self.n = int(n_tokens)
+        if _handle is not None:
+            self.h = _handle
+            return
         h = C.c_void_p()
         rc = self.L.cfmm_create(int(device), self.n, C.byref(h))
         if rc != 0:
             raise CfmmError(f"cfmm_create failed ({rc}): {self.L.cfmm_last_error(None).decode()}")
         self.h = h
+
+    def clone(self):
+        """a context sharing this one's resident pools, with its own stream / utility / solver state"""
+        h = C.c_void_p()
+        self._chk(self.L.cfmm_clone(self.h, C.byref(h)))
+        return Context(self.n, _handle=h)
 
     def close(self):
         if getattr(self, "h", None):

@@ -278,6 +278,58 @@ class Problem:
     def from_network(cls, net, utility=None, device=0):
         return cls(net["n_tokens"], utility=utility, device=device, network=net)
 
+    def clone(self, utility=None):
+        """A Problem over the SAME pools -- they stay where they are in HBM, nothing is uploaded again --
+        with its own utility, prices and solver state (cfmm_clone).  Clones may be solved concurrently from
+        different host threads: `solve_many`."""
+        ctx = self._ensure_ctx()
+        q = Problem(self.n, utility=utility if utility is not None else self.utility, device=self.device, network=self.net)
+        q.where = self.where
+        q.ctx = ctx.clone()
+        q._uploaded = True
+        return q
+
+    def solve_many(self, utilities, concurrency=2, nu0s=None, warm_start=False, **kw):
+        """Solve the same pools under many utilities (the two-asset.py:34-100 sweep; independent baskets).
+        `concurrency` clones work through the list from as many host threads; while one solve is inside its
+        single-workgroup nu update, the evaluation kernels of another fill the GPU.  Returns one dict per
+        utility, in order: value, status, psi, nu, gap, infeas, stats.  With warm_start each worker starts
+        a solve from the prices of its previous one."""
+        import threading
+        utilities = list(utilities)
+        workers = [self] + [self.clone() for _ in range(max(1, int(concurrency)) - 1)]
+        results = [None] * len(utilities)
+        errors = []
+        lock = threading.Lock()
+        nxt = [0]
+
+        def run(p):
+            try:
+                first = True
+                while True:
+                    with lock:
+                        i = nxt[0]; nxt[0] += 1
+                    if i >= len(utilities):
+                        return
+                    p.set_utility(utilities[i])
+                    p.solve(nu0=None if nu0s is None else nu0s[i], warm_start=warm_start and not first, **kw)
+                    first = False
+                    results[i] = dict(value=p.value, status=p.status, psi=p.psi, nu=p.nu, gap=p.gap, infeas=p.infeas,
+                                      dual_value=p.dual_value, stats=p.stats)
+            except Exception as e:       # surfaced in the caller's thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=run, args=(p,)) for p in workers]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for p in workers[1:]:
+            p.close()
+        if errors:
+            raise errors[0]
+        return results
+
     # -- device plumbing ---------------------------------------------------------------------
     def _ensure_ctx(self):
         if self.ctx is None:

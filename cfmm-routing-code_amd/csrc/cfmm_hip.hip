@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -62,6 +63,19 @@ struct DevBuf {
 
 }  // namespace
 
+// the pool columns in HBM; shared (reference-counted) between a context and its clones
+struct PoolStore {
+    Bucket2 b2[CFMM_POOL_KINDS2] = {};
+    std::vector<void *> b2mem[CFMM_POOL_KINDS2];
+    BucketN bn[CFMM_MAX_POOL_SIZE + 1] = {};
+    std::vector<void *> bnmem[CFMM_MAX_POOL_SIZE + 1];
+    ~PoolStore()
+    {
+        for (auto &v : b2mem) for (void *q : v) (void)hipFree(q);
+        for (auto &v : bnmem) for (void *q : v) (void)hipFree(q);
+    }
+};
+
 struct cfmm_ctx {
     int device = 0, n = 0, ng = 0;
     int cus = 256;
@@ -69,11 +83,9 @@ struct cfmm_ctx {
     std::string err;
     std::string backend;
 
-    // pools
-    Bucket2 b2[CFMM_POOL_KINDS2] = {};
-    std::vector<void *> b2mem[CFMM_POOL_KINDS2];
-    BucketN bn[CFMM_MAX_POOL_SIZE + 1] = {};
-    std::vector<void *> bnmem[CFMM_MAX_POOL_SIZE + 1];
+    // pools (shared with clones); the tied-pool flags of the constant-sum bucket are per context
+    std::shared_ptr<PoolStore> pools = std::make_shared<PoolStore>();
+    int *flags2 = nullptr;
 
     // tokens / state (device)
     double *c = nullptr, *h = nullptr, *off = nullptr, *glo = nullptr, *ghi = nullptr;
@@ -155,12 +167,13 @@ const int kOrder[N_BUCKETS] = {-8, -7, -6, -5, -4, -3, CFMM_POOL_CURVE2, CFMM_PO
 EvalArgs make_eval_args(cfmm_ctx *ctx, int only = 0x7fffffff)
 {
     EvalArgs a = {};
-    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) a.b2[k] = ctx->b2[k];
-    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) a.bn[k - 3] = ctx->bn[k];
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) a.b2[k] = ctx->pools->b2[k];
+    a.b2[CFMM_POOL_SUM2].flags = ctx->flags2;
+    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) a.bn[k - 3] = ctx->pools->bn[k];
     long long tiles = 0;
     for (int q = 0; q < N_BUCKETS; ++q) {
         const int code = kOrder[q];
-        const long long m = code < 0 ? ctx->bn[-code].m : ctx->b2[code].m;
+        const long long m = code < 0 ? ctx->pools->bn[-code].m : ctx->pools->b2[code].m;
         const int wt = wave_tile_pools(code);
         if (only == 0x7fffffff || only == code) tiles += (m + wt - 1) / wt;
         a.tile_end[q] = (int)tiles;
@@ -413,6 +426,18 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     return CFMM_OK;
 }
 
+int cfmm_clone(cfmm_ctx *src, cfmm_ctx **out)
+{
+    if (!src || !out) return CFMM_E_ARG;
+    cfmm_ctx *c = nullptr;
+    int rc = cfmm_create(src->device, src->n, &c);
+    if (rc) { src->err = g_create_error; return rc; }
+    c->pools = src->pools;                 // the pool columns are shared: no copy, no second upload
+    c->nslices = src->nslices <= c->nslices ? src->nslices : c->nslices;
+    *out = c;
+    return CFMM_OK;
+}
+
 int cfmm_destroy(cfmm_ctx *ctx)
 {
     if (!ctx) return CFMM_OK;
@@ -420,8 +445,8 @@ int cfmm_destroy(cfmm_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     drop_graph(ctx);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
-    for (auto &v : ctx->b2mem) free_all(v);
-    for (auto &v : ctx->bnmem) free_all(v);
+    ctx->pools.reset();
+    if (ctx->flags2) (void)hipFree(ctx->flags2);
     void *ptrs[] = {ctx->c, ctx->h, ctx->off, ctx->glo, ctx->ghi, ctx->ctype, ctx->grp, ctx->nu, ctx->nu_acc, ctx->psi_acc,
                     ctx->psi_t, ctx->nu0, ctx->s, ctx->s_t, ctx->Gs, ctx->Gs_t, ctx->d, ctx->Ds, ctx->S, ctx->Y, ctx->rho,
                     ctx->acc, ctx->st, ctx->ts};
@@ -439,8 +464,8 @@ int64_t cfmm_pool_count(cfmm_ctx *ctx)
 {
     if (!ctx) return 0;
     int64_t m = 0;
-    for (auto &b : ctx->b2) m += b.m;
-    for (auto &b : ctx->bn) m += b.m;
+    for (auto &b : ctx->pools->b2) m += b.m;
+    for (auto &b : ctx->pools->bn) m += b.m;
     return m;
 }
 
@@ -462,12 +487,14 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
         if (kind == CFMM_POOL_W2 && !(param[i] > 0.0 && param[i] < 1.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has weight %g outside (0, 1)", (long long)i, param[i]);
         if (kind == CFMM_POOL_CURVE2 && !(param[i] > 0.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has alpha %g <= 0", (long long)i, param[i]);
     }
+    if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_pools2: the pools are shared with a clone (cfmm_clone); destroy the clones first");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    free_all(ctx->b2mem[kind]);
+    free_all(ctx->pools->b2mem[kind]);
+    if (kind == CFMM_POOL_SUM2 && ctx->flags2) { (void)hipFree(ctx->flags2); ctx->flags2 = nullptr; }
     Bucket2 b = {};
     b.m = m;
     if (m > 0) {
-        auto &tr = ctx->b2mem[kind];
+        auto &tr = ctx->pools->b2mem[kind];
         int rc = 0;
         rc |= dev_upload<double>(ctx, (double **)&b.Ra, Ra, m, &tr);
         rc |= dev_upload<double>(ctx, (double **)&b.Rb, Rb, m, &tr);
@@ -478,7 +505,7 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
         if (rc) return CFMM_E_HIP;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    ctx->b2[kind] = b;
+    ctx->pools->b2[kind] = b;
     ctx->g_valid = false;
     return CFMM_OK;
 }
@@ -496,12 +523,13 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
             return fail(ctx, CFMM_E_ARG, "upload_poolsN: leg %lld has reserve %g / weight %g (need R > 0, 0 < w < 1)", (long long)i, R[i], w[i]);
     for (int64_t i = 0; i < m; ++i)
         if (!(fee[i] > 0.0 && fee[i] <= 1.0)) return fail(ctx, CFMM_E_ARG, "upload_poolsN: pool %lld has fee %g outside (0, 1]", (long long)i, fee[i]);
+    if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_poolsN: the pools are shared with a clone (cfmm_clone); destroy the clones first");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    free_all(ctx->bnmem[k]);
+    free_all(ctx->pools->bnmem[k]);
     BucketN b = {};
     b.m = m;
     if (m > 0) {
-        auto &tr = ctx->bnmem[k];
+        auto &tr = ctx->pools->bnmem[k];
         int rc = 0;
         // the ABI hands columns slot-major [k][m]; the device layout is pool-major [m][k] (leg per lane)
         std::vector<int32_t> tidx((size_t)k * m);
@@ -523,7 +551,7 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
         if (rc) return CFMM_E_HIP;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    ctx->bn[k] = b;
+    ctx->pools->bn[k] = b;
     ctx->g_valid = false;
     return CFMM_OK;
 }
@@ -533,16 +561,14 @@ int cfmm_set_pool_flags(cfmm_ctx *ctx, int kind, const int32_t *flags)
     if (!ctx) return CFMM_E_ARG;
     if (kind != CFMM_POOL_SUM2) return fail(ctx, CFMM_E_ARG, "set_pool_flags: only CFMM_POOL_SUM2 pools can be tied");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    Bucket2 &b = ctx->b2[kind];
+    const Bucket2 &b = ctx->pools->b2[kind];
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (!flags) { b.flags = nullptr; ctx->g_valid = false; return CFMM_OK; }
-    if (b.m == 0) return CFMM_OK;
-    int *p = nullptr;
-    int rc = dev_upload<int>(ctx, &p, flags, b.m, &ctx->b2mem[kind]);
+    if (ctx->flags2) { (void)hipFree(ctx->flags2); ctx->flags2 = nullptr; }
+    ctx->g_valid = false;
+    if (!flags || b.m == 0) return CFMM_OK;
+    int rc = dev_upload<int>(ctx, &ctx->flags2, flags, b.m, nullptr);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    b.flags = p;
-    ctx->g_valid = false;
     return CFMM_OK;
 }
 
@@ -721,7 +747,8 @@ int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda)
 {
     if (!ctx || kind < 0 || kind >= CFMM_POOL_KINDS2) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const Bucket2 &b = ctx->b2[kind];
+    Bucket2 b = ctx->pools->b2[kind];
+    if (kind == CFMM_POOL_SUM2) b.flags = ctx->flags2;
     if (b.m == 0) return CFMM_OK;
     double *dd = nullptr, *dl = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&dd, 2 * b.m * sizeof(double)));
@@ -746,7 +773,7 @@ int cfmm_get_tradesN(cfmm_ctx *ctx, int k, double *delta, double *lambda)
 {
     if (!ctx || k < 3 || k > CFMM_MAX_POOL_SIZE) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const BucketN &b = ctx->bn[k];
+    const BucketN &b = ctx->pools->bn[k];
     if (b.m == 0) return CFMM_OK;
     const size_t cnt = (size_t)k * b.m;
     double *dd = nullptr, *dl = nullptr;

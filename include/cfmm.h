@@ -83,6 +83,12 @@ typedef struct {
 /* lifetime ------------------------------------------------------------------------------ */
 int cfmm_create(int device, int n_tokens, cfmm_ctx **out);
 int cfmm_destroy(cfmm_ctx *ctx);
+/* A second context on the same GPU that SHARES the pool columns already resident in HBM (reference-counted,
+ * no copy) but has its own stream, utility, prices and solver state: several solves over one pool set --
+ * the parameter sweep of two-asset.py:34-100, or independent utilities -- can then be in flight at once
+ * (one per host thread), one solve's single-workgroup nu update overlapping another's evaluation kernels.
+ * Pools cannot be re-uploaded while clones exist. */
+int cfmm_clone(cfmm_ctx *src, cfmm_ctx **out);
 const char *cfmm_last_error(cfmm_ctx *ctx);       /* ctx may be NULL: last error of cfmm_create */
 const char *cfmm_backend(cfmm_ctx *ctx);          /* "hip:gfx950"                               */
 void cfmm_default_opts(cfmm_opts *o);

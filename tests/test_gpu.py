@@ -351,3 +351,32 @@ dist.destroy_process_group()
     assert out["evals"] == out["evals1"]
     assert abs(out["v"] - out["w"]) <= 1e-9 * abs(out["w"])
     assert out["df"] <= 1e-12 and out["dpsi"] <= 1e-10
+
+
+def test_clones_share_pools_and_solve_many_matches_sequential():
+    """cfmm_clone: several solves in flight over ONE resident pool set give the same answers as one after
+    the other; re-uploading pools while clones exist is refused"""
+    net = synthetic.config("C3", scale=0.1, seed=3)
+    n = net["n_tokens"]
+    rng = np.random.default_rng(11)
+    utils = [cfmm.Arbitrage(net["c"] * np.exp(rng.normal(0, 0.01, n))) for _ in range(6)]
+    h = np.zeros(n); idx = rng.choice(n, 5, replace=False); h[idx] = 50.0 / net["prices"][idx]
+    utils.append(cfmm.Swap(h, int(rng.integers(0, n))))
+    p = cfmm.Problem.from_network(net, utility=utils[0])
+    seq = []
+    for u in utils:
+        p.set_utility(u); p.solve(tol=1e-7)
+        seq.append((p.value, p.status, p.psi.copy()))
+    for conc in (1, 3):
+        res = p.solve_many(utils, concurrency=conc, tol=1e-7)
+        for (v, st, psi), r in zip(seq, res):
+            assert r["status"] == st == "optimal"
+            # (fp64 atomics are order-nondeterministic: two runs agree to the solver tolerance, not bitwise)
+            assert abs(r["value"] - v) <= 5e-7 * abs(v)
+            assert np.abs(r["psi"] - psi).max() <= 1e-4 * np.abs(psi).max()
+    q = p.clone()
+    with pytest.raises(cfmm.CfmmError, match="shared with a clone"):
+        p.ctx.upload_pools2(_lib.POOL_CP2, [1.0], [1.0], [0.99], [0], [1])
+    q.close()
+    p.ctx.upload_pools2(_lib.POOL_SUM2, [1.0], [1.0], [0.99], [0], [1])      # fine again once the clone is gone
+    p.close()

@@ -23,6 +23,7 @@ ap.add_argument("--tag", default="")
 ap.add_argument("--solves", type=int, default=5)
 ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--buckets", action="store_true")
+ap.add_argument("--many", type=int, default=0, help="also time N solves through solve_many at concurrency 1, 2, 3")
 args = ap.parse_args()
 
 import numpy as np  # noqa: E402
@@ -46,6 +47,18 @@ out["solve_wall_ms"] = 1e3 * (time.perf_counter() - t0) / args.solves
 out["dev_us_per_eval"] = 1e6 * dev / ev
 out["wall_us_per_eval"] = 1e6 * wall / ev
 out["eval_all_us"] = 1e6 * prob.ctx.time_eval_kernel(_lib.TIME_ALL, args.reps)
+if args.many:
+    rng = np.random.default_rng(5)
+    utils = [cfmm.Arbitrage(net["c"] * np.exp(rng.normal(0, 0.005, net["n_tokens"]))) for _ in range(args.many)]
+    out["solve_many"] = {}
+    for conc in (1, 2, 3, 4):
+        prob.solve_many(utils[:4], concurrency=conc, tol=1e-6)
+        t0 = time.perf_counter()
+        res = prob.solve_many(utils, concurrency=conc, tol=1e-6)
+        dt = time.perf_counter() - t0
+        ev = sum(r["stats"]["evals"] for r in res)
+        out["solve_many"][conc] = dict(ms_per_solve=round(1e3 * dt / len(utils), 3), pool_subproblems_per_s=ev * prob.m / dt,
+                                       all_optimal=all(r["status"] == "optimal" for r in res))
 if args.buckets:
     out["buckets"] = {r["kernel"]: round(r["us"], 2) for r in bench.kernel_table(prob, args.reps)[1:]}
 prob.ctx.debug_timers()            # clears the logs
