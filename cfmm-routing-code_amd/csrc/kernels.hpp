@@ -312,9 +312,6 @@ eval_kernel(EvalArgs a)
         const long long tc0 = clock64();
         t_out += tc0 - t_prev;
 #endif
-#ifdef CFMM_SKIP_TILES          // tuning probe: loop + scheduling overhead only
-        if (bk > 100)
-#endif
         switch (bk) {
         case 0: tilen<8, WITH_D>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
         case 1: tilen<7, WITH_D>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
@@ -349,9 +346,6 @@ eval_kernel(EvalArgs a)
     PHASE_STAMP(a.ts, 3);
 
     double *base = a.acc + (size_t)(blockIdx.x % a.nslices) * acc_stride(n);
-#ifdef CFMM_SKIP_FLUSH          // tuning probe: everything but the global flush
-    if (blockIdx.x > 100000)
-#endif
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const double v = psi_s[j];
         if (v != 0.0) unsafeAtomicAdd(&base[j], v);
