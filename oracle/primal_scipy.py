@@ -6,7 +6,7 @@ restatement of /root/reference/arbitrage.py:51-78 (variables :51-52, psi :54, ob
 new reserves :60, trading-function constraints :63-74, utility constraints :77), of
 liquidation.py:57,77-80 and of two-asset.py:66,74,86 -- handed to SciPy's SLSQP instead of
 cvxpy/ECOS.  It shares no code and no algorithm with the dual-decomposition path
-(oracle/dual_np.py, oracle/cfmm_oracle.c, the HIP kernels), which is what makes the
+(oracle/pools_np.py, oracle/cfmm_oracle.c, the HIP kernels), which is what makes the
 agreement of the two a meaningful check.  Practical up to ~50 pools.
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may use oracle/.

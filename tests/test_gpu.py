@@ -380,3 +380,18 @@ def test_clones_share_pools_and_solve_many_matches_sequential():
     q.close()
     p.ctx.upload_pools2(_lib.POOL_SUM2, [1.0], [1.0], [0.99], [0], [1])      # fine again once the clone is gone
     p.close()
+
+
+@pytest.mark.parametrize("n_tokens,memory", [(700, 8), (1500, 0), (2000, 8), (3000, 0)])
+def test_every_update_kernel_instantiation_agrees_with_the_oracle(oracle_lib, n_tokens, memory):
+    """the nu update runs as update_reg_kernel<512,8,2> (<= 1024 tokens), <512,4,4> (<= 2048 tokens, memory <= 4)
+    or the generic update_kernel (everything else): same iteration, same answer as oracle_step"""
+    net = synthetic.make_network(n_tokens, m_cp2=60_000, m_w2=20_000, m_gn=10_000, seed=9)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    v = p.solve(tol=1e-7, memory=memory)
+    o = _oracle_for(oracle_lib, net)
+    r = o.solve(net["c"], tol=1e-7, memory=memory)
+    assert p.status == "optimal" and r["status"] == 1
+    assert abs(v - r["primal_value"]) <= 2e-7 * abs(v)
+    assert abs(p.stats["evals"] - r["evals"]) <= max(6, r["evals"] // 3)     # same algorithm, fp-noise apart
+    p.close()
