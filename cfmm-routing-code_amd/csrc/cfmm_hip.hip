@@ -86,6 +86,8 @@ struct cfmm_ctx {
     // pools (shared with clones); the tied-pool flags of the constant-sum bucket are per context
     std::shared_ptr<PoolStore> pools = std::make_shared<PoolStore>();
     int *flags2 = nullptr;
+    double *trade_buf = nullptr;       // grow-only scratch for cfmm_get_trades* (delta | lambda)
+    size_t trade_cap = 0;
 
     // tokens / state (device)
     double *c = nullptr, *h = nullptr, *off = nullptr, *glo = nullptr, *ghi = nullptr;
@@ -123,6 +125,22 @@ struct cfmm_ctx {
 };
 
 namespace {
+
+int fail(cfmm_ctx *ctx, int code, const char *fmt, ...);
+
+// scratch for 2 * count doubles, reused across read-backs (hipMalloc / hipFree per call cost 5-25 ms)
+int trade_scratch(cfmm_ctx *ctx, size_t count, double **delta, double **lambda)
+{
+    if (2 * count > ctx->trade_cap) {
+        if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
+        ctx->trade_buf = nullptr; ctx->trade_cap = 0;
+        hipError_t e = hipMalloc((void **)&ctx->trade_buf, 2 * count * sizeof(double));
+        if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "trade scratch: hipMalloc(%zu) -> %s", 2 * count * sizeof(double), hipGetErrorString(e));
+        ctx->trade_cap = 2 * count;
+    }
+    *delta = ctx->trade_buf; *lambda = ctx->trade_buf + count;
+    return CFMM_OK;
+}
 
 int fail(cfmm_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -447,6 +465,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     ctx->pools.reset();
     if (ctx->flags2) (void)hipFree(ctx->flags2);
+    if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
     void *ptrs[] = {ctx->c, ctx->h, ctx->off, ctx->glo, ctx->ghi, ctx->ctype, ctx->grp, ctx->nu, ctx->nu_acc, ctx->psi_acc,
                     ctx->psi_t, ctx->nu0, ctx->s, ctx->s_t, ctx->Gs, ctx->Gs_t, ctx->d, ctx->Ds, ctx->S, ctx->Y, ctx->rho,
                     ctx->acc, ctx->st, ctx->ts};
@@ -751,8 +770,7 @@ int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda)
     if (kind == CFMM_POOL_SUM2) b.flags = ctx->flags2;
     if (b.m == 0) return CFMM_OK;
     double *dd = nullptr, *dl = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&dd, 2 * b.m * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void **)&dl, 2 * b.m * sizeof(double)));
+    { int rc = trade_scratch(ctx, 2 * (size_t)b.m, &dd, &dl); if (rc) return rc; }
     const dim3 grid((unsigned)((b.m + 255) / 256)), blk(256);
     switch (kind) {
     case 0: hipLaunchKernelGGL(trades2_kernel<0>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;
@@ -764,7 +782,6 @@ int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda)
     if (e == hipSuccess && delta) e = hipMemcpyAsync(delta, dd, 2 * b.m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && lambda) e = hipMemcpyAsync(lambda, dl, 2 * b.m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dd); (void)hipFree(dl);
     if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "get_trades2 -> %s", hipGetErrorString(e));
     return CFMM_OK;
 }
@@ -777,8 +794,7 @@ int cfmm_get_tradesN(cfmm_ctx *ctx, int k, double *delta, double *lambda)
     if (b.m == 0) return CFMM_OK;
     const size_t cnt = (size_t)k * b.m;
     double *dd = nullptr, *dl = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&dd, cnt * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void **)&dl, cnt * sizeof(double)));
+    { int rc = trade_scratch(ctx, cnt, &dd, &dl); if (rc) return rc; }
     const dim3 grid((unsigned)((b.m + 255) / 256)), blk(256);
     const double *nu = ctx->nu_acc;
     switch (k) {
@@ -793,7 +809,6 @@ int cfmm_get_tradesN(cfmm_ctx *ctx, int k, double *delta, double *lambda)
     if (e == hipSuccess && delta) e = hipMemcpyAsync(delta, dd, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && lambda) e = hipMemcpyAsync(lambda, dl, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dd); (void)hipFree(dl);
     if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "get_tradesN -> %s", hipGetErrorString(e));
     return CFMM_OK;
 }
