@@ -99,6 +99,8 @@ struct cfmm_ctx {
     DevState *st = nullptr;
     long long *ts = nullptr;           // phase timers (tuning builds)
     DevState *hst = nullptr;          // pinned, 2 slots
+    double *hsol = nullptr;           // pinned [2][n]: nu | psi of the last solve (saves cfmm_get_solution a synchronisation)
+    bool hsol_valid = false;
     hipEvent_t ev[2] = {nullptr, nullptr}, ev_t0 = nullptr, ev_t1 = nullptr;
     int nslices = 4;
     int eval_grid_mult = 1;
@@ -423,6 +425,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     rc |= dev_upload<long long>(ctx, &ctx->ts, nullptr, 64 + 8 * 4096 + 2048, nullptr);
     if (rc) return bail(CFMM_E_HIP);
     TRY_C(hipHostMalloc((void **)&ctx->hst, 2 * sizeof(DevState), hipHostMallocDefault));
+    TRY_C(hipHostMalloc((void **)&ctx->hsol, 2 * (size_t)n * sizeof(double), hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) TRY_C(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
     TRY_C(hipEventCreate(&ctx->ev_t0));
     TRY_C(hipEventCreate(&ctx->ev_t1));
@@ -471,6 +474,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
                     ctx->acc, ctx->st, ctx->ts};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->hst) (void)hipHostFree(ctx->hst);
+    if (ctx->hsol) (void)hipHostFree(ctx->hsol);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
@@ -635,8 +639,8 @@ int cfmm_set_nu(cfmm_ctx *ctx, const double *nu)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int j = 0; j < ctx->n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "set_nu: nu[%d] = %g is not a positive finite price", j, nu[j]);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu_acc, nu, ctx->n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->have_nu = true;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the caller's (pageable) buffer may go away after we return
+    ctx->have_nu = true; ctx->hsol_valid = false;
     return CFMM_OK;
 }
 
@@ -661,6 +665,11 @@ int cfmm_get_psi(cfmm_ctx *ctx, double *psi)
 int cfmm_get_solution(cfmm_ctx *ctx, double *nu, double *psi)
 {
     if (!ctx || (!nu && !psi)) return CFMM_E_ARG;
+    if (ctx->hsol_valid) {                 // the last solve left both in pinned host memory
+        if (nu) std::memcpy(nu, ctx->hsol, ctx->n * sizeof(double));
+        if (psi) std::memcpy(psi, ctx->hsol + ctx->n, ctx->n * sizeof(double));
+        return CFMM_OK;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (nu) HIP_TRY(ctx, hipMemcpyAsync(nu, ctx->nu_acc, ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (psi) HIP_TRY(ctx, hipMemcpyAsync(psi, ctx->psi_acc, ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -744,7 +753,10 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(&ctx->hst[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hsol, ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hsol + n, ctx->psi_acc, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->hsol_valid = true;
     const auto t1 = std::chrono::steady_clock::now();
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
