@@ -177,7 +177,7 @@ void free_all(std::vector<void *> &v)
 }
 
 size_t eval_lds_bytes(int n, bool with_d) { return (size_t)eval_lds_doubles(n, with_d) * sizeof(double) + (size_t)(EVAL_THREADS / 64) * 64 * 16; }
-size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 2 * 12 * 16 + 8) * sizeof(double); }
+size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 16 * 64 + 64 + 32 + 2 * 12 * 16 + 8) * sizeof(double); }
 
 // processing order of the fused evaluation kernel (heaviest first): bucket code = -k for the
 // k-asset geo-mean buckets, CFMM_POOL_* for the two-asset ones
@@ -250,6 +250,7 @@ int set_all_lds_attrs(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 8, 2>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 4, 4>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_reg_kernel<256, 8, 4>, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, update_gram_kernel<512, 2>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, start_kernel, upd_lds_bytes(ctx->n)))) return rc;
     return CFMM_OK;
 }
@@ -278,9 +279,13 @@ void launch_update(cfmm_ctx *ctx, const UpdArgs &ua)
     auto thr = [n](int E) { return 64 * ((n + 64 * E - 1) / (64 * E)); };
     const int ug = ctx->upd_grid;                   // (tuning probe) identical redundant workgroups
     const int v = ctx->upd_generic ? 9 : ctx->upd_variant;
-    if (v == 0 && n <= 1024)                        // 2 variables per thread, <= 8 waves, any memory
+    // Gram form (two-loop recursion on scalars after ONE batched reduction): <= 1024 tokens, memory <= 4; with 4
+    // variables per thread (<= 2048 tokens) its 64-value batch spills and loses to the sequential form (18.8 vs 14.8 us)
+    if (v == 0 && n <= 1024 && ua.M <= GRAM_MM)
+        hipLaunchKernelGGL((update_gram_kernel<512, 2>), dim3(ug), dim3(thr(2)), lds, ctx->stream, ua);
+    else if ((v == 0 || v == 3) && n <= 1024)       // 2 variables per thread, <= 8 waves, any memory
         hipLaunchKernelGGL((update_reg_kernel<512, 8, 2>), dim3(ug), dim3(thr(2)), lds, ctx->stream, ua);
-    else if ((v == 0 || v == 1) && n <= 2048 && ua.M <= 4)   // 4 per thread, <= 8 waves, memory <= 4
+    else if ((v == 0 || v == 1 || v == 3) && n <= 2048 && ua.M <= 4)   // 4 per thread, <= 8 waves, memory <= 4
         hipLaunchKernelGGL((update_reg_kernel<512, 4, 4>), dim3(ug), dim3(thr(4)), lds, ctx->stream, ua);
     else if (v == 2 && n <= 1024)                   // (A/B) 4 per thread, <= 4 waves
         hipLaunchKernelGGL((update_reg_kernel<256, 8, 4>), dim3(1), dim3(thr(4)), lds, ctx->stream, ua);

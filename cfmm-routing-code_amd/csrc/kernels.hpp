@@ -1035,6 +1035,399 @@ update_reg_kernel(UpdArgs a)
     PHASE_STAMP(a.ts, 15);
 }
 
+// ------------------------------------------------------------------------------------------
+// The nu update, "Gram" form (memory <= 4, n <= 2048): identical iteration, but the two-loop
+// recursion runs on scalars.  Every dot product it needs,
+//     u_k = s_k.q0,  v_k = y_k.(H0 q0),  SY[k][j] = s_k.y_j (k > j),  YHY[k][j] = y_k.H0 y_j,
+// is independent of the alphas, so all of them -- together with the scalars of the accept test, the
+// stopping rule and the curvature pair -- come out of ONE batched reduction (46 values).  The batch is
+// a 6-step reduce-scatter over the wave (v_permlane32/16_swap, DPP row_ror / quad_perm, one
+// ds_swizzle step): 63 exchange-adds instead of 46 x 6 butterfly steps, lane l ends up with the
+// wave total of value l; two LDS exchanges finish it across waves.  Then
+//     alpha_k = rho_k (u_k - sum_{j<k} alpha_j SY[k][j])
+//     beta_k  = rho_k (v_k - sum_j alpha_j YHY[k][j] + sum_{j>k} gamma_j SY[j][k]),  gamma = alpha - beta
+//     d = -(H0 (q0 - sum_j alpha_j y_j) + sum_k gamma_k s_k)       (pairs newest first, invalid pairs rho = 0)
+// replaces 2m + 1 sequential block reductions (0.45 us each) by scalar code.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dppd_ror8(double v) { return dpp_f64<0x128>(v); }       // lane ^ 8 within a row of 16
+__device__ __forceinline__ double swz_xor4(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_swizzle(lo, 0x101F);       // bit mode: and 0x1f, or 0, xor 4
+    hi = __builtin_amdgcn_ds_swizzle(hi, 0x101F);
+    return __hiloint2double(hi, lo);
+}
+
+// v[0..63]: per-lane partials of 64 quantities; returns the wave total of quantity `lane`
+__device__ __forceinline__ double wave_reduce_scatter64(double (&v)[64], int lane)
+{
+    double x, y;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {                      // lanes 32..63 take over quantities 32..63
+        const int l0 = __double2loint(v[i]), h0 = __double2hiint(v[i]);
+        const int l1 = __double2loint(v[i + 32]), h1 = __double2hiint(v[i + 32]);
+        const auto a = __builtin_amdgcn_permlane32_swap(l0, l1, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(h0, h1, false, false);
+        x = __hiloint2double(b[0], a[0]); y = __hiloint2double(b[1], a[1]);
+        v[i] = x + y;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                      // odd rows take over quantities +16
+        const int l0 = __double2loint(v[i]), h0 = __double2hiint(v[i]);
+        const int l1 = __double2loint(v[i + 16]), h1 = __double2hiint(v[i + 16]);
+        const auto a = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(h0, h1, false, false);
+        x = __hiloint2double(b[0], a[0]); y = __hiloint2double(b[1], a[1]);
+        v[i] = x + y;
+    }
+    const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                       // lanes with bit 3 take over +8
+        const double keep = b8 ? v[i + 8] : v[i], send = b8 ? v[i] : v[i + 8];
+        v[i] = keep + dppd_ror8(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double keep = b4 ? v[i + 4] : v[i], send = b4 ? v[i] : v[i + 4];
+        v[i] = keep + swz_xor4(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double keep = b2 ? v[i + 2] : v[i], send = b2 ? v[i] : v[i + 2];
+        v[i] = keep + dpp_f64<0x4E>(send);
+    }
+    {
+        const double keep = b1 ? v[1] : v[0], send = b1 ? v[0] : v[1];
+        v[0] = keep + dpp_f64<0xB1>(send);
+    }
+    return v[0];
+}
+
+constexpr int GRAM_MM = 4;                  // history pairs kept by the Gram form
+constexpr int GRAM_P = GRAM_MM + 1;         // + the new pair
+
+template <int MAXT, int E>
+__global__ void __launch_bounds__(MAXT)
+update_gram_kernel(UpdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int MM = GRAM_MM, P = GRAM_P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int n = a.n, ng = a.ng, M = a.M;
+    const int hs = hist_stride(n);
+    double *q = lds;                         // [ng]
+    double *q2 = lds + ng;                   // [ng]
+    double *xw = lds + 2 * ng;               // [16][64] per-wave sums | then [64] totals at xw + 16*64 | [16][2] maxima
+    double *xt = xw + 16 * 64;
+    double *xm = xt + 64;
+    BlockRed red(xm + 32);                   // [2][12][16] for the small closing reduction
+    const int stride = acc_stride(n);
+    const bool ties = (ng != n);
+    const bool wr = blockIdx.x == 0;
+    const int nS = wr ? n : 0, ngS = wr ? ng : 0;
+    const int r0 = tid * E;
+    const int pr = (r0 < n) ? r0 : 0;
+    bool gin[E], tin[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { gin[e] = r0 + e < ng; tin[e] = r0 + e < n; }
+
+#ifdef CFMM_PHASE_TIMERS
+    const long long c8 = clock64(), w8 = wall_clock64();
+#endif
+    DevState st = *a.st;
+    // ---- loads, all issued up front (16-byte loads), first-needed first -------------------------------
+    double s[E], s_t[E], Gs[E], d[E], Ds[E], glo[E], ghi[E];
+    ldv<E>(a.s, pr, s); ldv<E>(a.s_t, pr, s_t); ldv<E>(a.Gs, pr, Gs); ldv<E>(a.d, pr, d); ldv<E>(a.Ds, pr, Ds);
+    ldv<E>(a.glo, pr, glo); ldv<E>(a.ghi, pr, ghi);
+    double nuj[E], hj[E], cj[E], offj[E];
+    int ct[E], grp[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { offj[e] = 0.0; grp[e] = 0; }
+    ldv<E>(a.nu, pr, nuj); ldv<E>(a.h, pr, hj); ldv<E>(a.c, pr, cj); ldvi<E>(a.ctype, pr, ct);
+    if (ties) { ldv<E>(a.off, pr, offj); ldvi<E>(a.grp, pr, grp); }
+    double psi[E], dg[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { psi[e] = 0.0; dg[e] = 0.0; }
+    for (int sl0 = 0; sl0 < a.nslices; sl0 += 4) {
+        double pp[4][E];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) pp[u][e] = 0.0;
+            if (sl0 + u < a.nslices) ldv<E>(a.acc + (size_t)(sl0 + u) * stride, pr, pp[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < E; ++e) psi[e] += pp[u][e];
+    }
+    if (st.status != 0) return;
+#ifdef CFMM_PHASE_TIMERS
+    if (a.ts && threadIdx.x == 0) { a.ts[16] = c8; a.ts[17] = w8; }
+#endif
+    PHASE_STAMP(a.ts, 9);
+    if (st.first) {
+        for (int sl = 0; sl < a.nslices; ++sl) {
+            double t2[E];
+            ldv<E>(a.acc + (size_t)sl * stride + acc_diag(n), pr, t2);
+#pragma unroll
+            for (int e = 0; e < E; ++e) dg[e] += t2[e];
+        }
+    }
+    // pairs, newest first: index 0 is the pair this very step may create, 1..MM the stored ones
+    double Sx[P][E], Yx[P][E], rho[P];
+#pragma unroll
+    for (int k = 0; k < MM; ++k) {
+        const bool have = k < st.hist;
+        const int slot = have ? (st.head - 1 - k + 2 * M) % M : 0;
+        rho[k + 1] = have ? a.rho[slot] : 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { Sx[k + 1][e] = 0.0; Yx[k + 1][e] = 0.0; }
+        if (have) { ldv<E>(a.S + (size_t)slot * hs, pr, Sx[k + 1]); ldv<E>(a.Y + (size_t)slot * hs, pr, Yx[k + 1]); }
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (!gin[e]) { Sx[k + 1][e] = 0.0; Yx[k + 1][e] = 0.0; }
+    }
+    double fpools = 0.0;
+    if (tid < a.nslices) fpools = a.acc[(size_t)tid * stride + acc_arb(n)];
+    {
+        double zero[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) zero[e] = 0.0;
+        for (int sl = 0; sl < a.nslices; ++sl) {
+            double *base = a.acc + (size_t)sl * stride;
+            if (r0 < n) { stv<E>(base, r0, nS, zero); if (st.first) stv<E>(base + acc_diag(n), r0, nS, zero); }
+        }
+        if (wr && tid < a.nslices) a.acc[(size_t)tid * stride + acc_arb(n)] = 0.0;
+    }
+    PHASE_STAMP(a.ts, 10);
+
+    // ---- A. group gradient at the trial point ----------------------------------------------------------
+    if (ties) {
+        for (int r = tid; r < ng; r += blockDim.x) { q[r] = 0.0; q2[r] = 0.0; }
+        __syncthreads();
+    }
+    double Gs_t[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        Gs_t[e] = 0.0;
+        if (tin[e]) {
+            const double rj = psi[e] + hj[e];
+            if (ties) {
+                unsafeAtomicAdd(&q[grp[e]], nuj[e] * rj);
+                if (st.first) unsafeAtomicAdd(&q2[grp[e]], dg[e]);
+            } else {
+                Gs_t[e] = nuj[e] * rj;
+                if (st.first) Ds[e] = dg[e];
+            }
+        }
+    }
+    if (ties) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (gin[e]) { Gs_t[e] = q[r0 + e]; if (st.first) Ds[e] = q2[r0 + e]; }
+        __syncthreads();
+    }
+    // ---- the batch.  0 f_lin 1 gapv 2 Gs.ds 3 Gs_t.ds 4 s.y 5 s.s 6 y.y 7 pg 8 |q0|^2
+    //      9..13 u_k | 14..18 v_k | 19..28 SY[k][j], k > j | 29..43 YHY[k][j], k >= j | maxima: viol, scale
+    double V[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) V[i] = 0.0;
+    V[0] = fpools;
+    double mx[2] = {0.0, 0.0};
+    double q0[E], H0[E];
+    bool act[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (tin[e]) {
+            const double rj = psi[e] + hj[e];
+            V[0] += (nuj[e] - cj[e]) * hj[e];
+            V[1] += (nuj[e] - cj[e]) * rj;
+            mx[0] = fmax(mx[0], ct[e] == 0 ? fmax(-rj, 0.0) : (ct[e] == 1 ? fabs(rj) : 0.0));
+            mx[1] = fmax(mx[1], fmax(fabs(psi[e]), fabs(hj[e])));
+        }
+        Sx[0][e] = 0.0; Yx[0][e] = 0.0; q0[e] = 0.0; H0[e] = 0.0; act[e] = true;
+        if (gin[e]) {
+            Sx[0][e] = s_t[e] - s[e]; Yx[0][e] = Gs_t[e] - Gs[e];
+            V[2] += Gs[e] * Sx[0][e]; V[3] += Gs_t[e] * Sx[0][e];
+            V[4] += Sx[0][e] * Yx[0][e]; V[5] += Sx[0][e] * Sx[0][e]; V[6] += Yx[0][e] * Yx[0][e];
+            const double G = Gs_t[e], sr = s_t[e];
+            double v = G;
+            if (glo[e] == ghi[e]) v = 0.0;
+            else if (sr <= glo[e] + 1e-14) v = fmin(G, 0.0);
+            else if (sr >= ghi[e] - 1e-14) v = fmax(G, 0.0);
+            V[7] += fabs(v);
+            act[e] = is_active(sr, glo[e], ghi[e], G);
+            q0[e] = act[e] ? 0.0 : G;
+            V[8] += q0[e] * q0[e];
+            const double H = Ds[e] + fmax(G, 0.0);
+            H0[e] = H > 0.0 ? rcp_nr(H) : 0.0;
+        }
+    }
+    if (st.first) {                               // no pair yet on the very first step
+#pragma unroll
+        for (int e = 0; e < E; ++e) { Sx[0][e] = 0.0; Yx[0][e] = 0.0; }
+        V[2] = V[3] = V[4] = V[5] = V[6] = 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double hq = H0[e] * q0[e];
+        int c = 19, c2 = 29;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            V[9 + k] += Sx[k][e] * q0[e];
+            V[14 + k] += Yx[k][e] * hq;
+            const double hy = H0[e] * Yx[k][e];
+#pragma unroll
+            for (int j = 0; j < k; ++j) V[c++] += Sx[k][e] * Yx[j][e];
+#pragma unroll
+            for (int j = 0; j <= k; ++j) V[c2++] += hy * Yx[j][e];
+        }
+    }
+    const double mine = wave_reduce_scatter64(V, lane);
+    mx[0] = wave_allmax(mx[0]); mx[1] = wave_allmax(mx[1]);
+    xw[wave * 64 + lane] = mine;
+    if (lane == 0) { xm[wave * 2] = mx[0]; xm[wave * 2 + 1] = mx[1]; }
+    __syncthreads();
+    if (wave == 0) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += xw[w * 64 + lane];
+        xt[lane] = t;
+    }
+    __syncthreads();
+    double T[44];
+#pragma unroll
+    for (int i = 0; i < 44; ++i) T[i] = xt[i];
+    double viol = 0.0, scale = 0.0;
+    for (int w = 0; w < nw; ++w) { viol = fmax(viol, xm[w * 2]); scale = fmax(scale, xm[w * 2 + 1]); }
+    const double f_t = T[0], gapv = T[1];
+    st.evals += 1;
+    PHASE_STAMP(a.ts, 11);
+
+    // ---- B. accept test ---------------------------------------------------------------------------------
+    bool accept = st.first != 0;
+    if (!st.first)
+        accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * T[2]) ||
+                                  (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && T[3] <= 0.8 * fabs(T[2])));
+    PHASE_STAMP(a.ts, 12);
+
+    bool new_dir = false;
+    if (!accept) {
+        st.t_step *= 0.5;
+        st.nrej += 1;
+        if (st.t_step < 1e-9) st.status = 2;
+    } else {
+        // ---- C. curvature pair, move the accepted point ------------------------------------------------
+        bool pair_ok = false;
+        const int old_hist0 = st.hist;
+        if (!st.first) {
+            if (r0 < ng) { stv<E>(a.S + (size_t)st.head * hs, r0, ngS, Sx[0]); stv<E>(a.Y + (size_t)st.head * hs, r0, ngS, Yx[0]); }
+            if (T[4] > 1e-12 * sqrt(T[5]) * sqrt(T[6])) {
+                pair_ok = true;
+                if (wr && tid == 0) a.rho[st.head] = 1.0 / T[4];
+                st.head = (st.head + 1) % M;
+                if (st.hist < M) st.hist += 1;
+            }
+            st.iters += 1;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (gin[e]) { s[e] = s_t[e]; Gs[e] = Gs_t[e]; }
+        if (r0 < ng) { stv<E>(a.s, r0, ngS, s); stv<E>(a.Gs, r0, ngS, Gs); if (st.first) stv<E>(a.Ds, r0, ngS, Ds); }
+        if (r0 < n) { stv<E>(a.psi_acc, r0, nS, psi); stv<E>(a.nu_acc, r0, nS, nuj); }
+        st.f = f_t;
+        st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
+        st.infeas = viol / fmax(scale, 1e-300);
+        st.primal = f_t - gapv;
+        st.pg = T[7] / fmax(1.0, fabs(f_t));
+        const double gp_sq = T[8];
+        const bool was_first = st.first != 0;
+        st.first = 0;
+        const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
+        if (conv) {
+            st.status = 1;
+        } else {
+            PHASE_STAMP(a.ts, 13);
+            // ---- D. the two-loop recursion on scalars ---------------------------------------------------
+            new_dir = true;
+            // which pairs are in the window: the new one if it passed, then the newest stored ones
+            const int keep_old = was_first ? 0 : (pair_ok ? (old_hist0 < M ? old_hist0 : M - 1) : old_hist0);
+            rho[0] = pair_ok ? 1.0 / T[4] : 0.0;
+#pragma unroll
+            for (int k = 1; k < P; ++k) if (k - 1 >= keep_old) rho[k] = 0.0;
+            double al[P], ga[P];
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                double t = T[9 + k];
+#pragma unroll
+                for (int j = 0; j < k; ++j) t -= al[j] * T[19 + k * (k - 1) / 2 + j];
+                al[k] = rho[k] * t;
+            }
+#pragma unroll
+            for (int k = P - 1; k >= 0; --k) {
+                double t = T[14 + k];
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    const int hi = j > k ? j : k, lo = j > k ? k : j;
+                    t -= al[j] * T[29 + hi * (hi + 1) / 2 + lo];
+                }
+#pragma unroll
+                for (int j = k + 1; j < P; ++j) t += ga[j] * T[19 + j * (j - 1) / 2 + k];
+                ga[k] = al[k] - rho[k] * t;
+            }
+            double F[2] = {0.0, 0.0};              // d.G | max |d|
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                double qm = q0[e], rs = 0.0;
+#pragma unroll
+                for (int k = 0; k < P; ++k) { qm -= al[k] * Yx[k][e]; rs += ga[k] * Sx[k][e]; }
+                d[e] = (gin[e] && !act[e]) ? -(H0[e] * qm + rs) : 0.0;
+                F[0] += d[e] * Gs[e]; F[1] = fmax(F[1], fabs(d[e]));
+            }
+            red.run<1, 1>(F);
+            if (!(F[0] < 0.0) && gp_sq > 0.0) {       // not a descent direction: restart from the metric
+                st.hist = 0;
+                double m1[1] = {0.0};
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    d[e] = (!gin[e] || act[e]) ? 0.0 : -Gs[e] * H0[e];
+                    m1[0] = fmax(m1[0], fabs(d[e]));
+                }
+                red.run<0, 1>(m1);
+                F[1] = m1[0];
+            }
+            st.t_step = (F[1] > a.max_step) ? a.max_step / F[1] : 1.0;
+        }
+    }
+
+    // ---- E. next trial point ----------------------------------------------------------------------------
+    PHASE_STAMP(a.ts, 14);
+    if (st.status == 0) {
+        double v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            v[e] = s[e] + st.t_step * d[e];
+            v[e] = fmax(v[e], glo[e]);
+            v[e] = fmin(v[e], ghi[e]);
+        }
+        if (r0 < ng) { stv<E>(a.s_t, r0, ngS, v); if (new_dir) stv<E>(a.d, r0, ngS, d); }
+        double nn[E];
+        if (ties) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (gin[e]) q[r0 + e] = v[e];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) nn[e] = tin[e] ? exp(q[grp[e]] + offj[e]) : 0.0;
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) nn[e] = exp(v[e]);
+        }
+        if (r0 < n) stv<E>(a.nu, r0, nS, nn);
+        if (st.evals >= a.max_evals) st.status = 3;
+    }
+    if (wr && tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; }
+    PHASE_STAMP(a.ts, 15);
+}
+
 // start of a solve: group variable = mean over members of (log nu0_j - off_j), clamped
 __global__ void __launch_bounds__(UPD_THREADS)
 start_kernel(UpdArgs a, const double *__restrict__ nu0)
