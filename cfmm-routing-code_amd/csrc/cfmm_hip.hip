@@ -1,9 +1,11 @@
 // libcfmm_hip.so -- host side of the C-ABI declared in include/cfmm.h (gfx950 only).
 //
 // Replaces everything below `prob.solve()` (/root/reference/arbitrage.py:82) for this problem
-// class.  One ctx = one GPU = one stream; the outer iteration is captured as a hipGraph
-// (evaluation kernels -> [RCCL all-reduce] -> update kernel, `iters_per_graph` times) and the
-// host only polls a status word, one replay behind, so the device never waits for the host.
+// class.  One ctx = one GPU = one stream; the outer iteration (evaluation kernel -> [fold ->
+// RCCL all-reduce] -> update kernel) is replayed from a captured hipGraph, `iters_per_graph`
+// iterations at a time (enqueued eagerly when pool-sharded), and the host only polls a status
+// word, one chunk behind, so the device never waits for the host.  Contexts made by cfmm_clone
+// share the pool columns (PoolStore) and can solve concurrently from different host threads.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <algorithm>

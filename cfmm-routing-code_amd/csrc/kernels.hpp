@@ -1,14 +1,18 @@
 // HIP kernels of the dual-decomposition hot path (gfx950 / MI355X, wave64, fp64, no MFMA).
 //
-//   eval2_kernel<KIND>, evaln_kernel<K>   one dual evaluation of a pool bucket: stream the SoA
-//        columns (coalesced, once), gather nu from an LDS copy, solve the pool, scatter-add
-//        A_i(L_i - D_i) into an LDS tile of psi (ds_add_f64), then flush the tile to one of
-//        `nslices` global accumulators (global_atomic_add_f64).        reference: arbitrage.py:54
-//   update_kernel                         consumes the accumulators (after the all-reduce when
-//        pool-sharded) and performs one step of the projected L-BFGS iteration on log-prices:
-//        the on-device "nu update".                                     reference: arbitrage.py:82
+//   eval_kernel<WITH_D>      ONE launch = one dual evaluation of every pool bucket: stream the SoA
+//        columns (coalesced, once), gather nu from an LDS copy, solve the pool (pool_math.hpp; K-asset
+//        pools leg-per-lane), scatter-add A_i(L_i - D_i) into an LDS tile of psi (ds_add_f64), flush
+//        the tile to one of `nslices` global accumulators (global_atomic_add_f64).
+//                                                                        reference: arbitrage.py:54
+//   update_gram_kernel / update_reg_kernel / update_kernel     consume the accumulators (after the
+//        all-reduce when pool-sharded) and take one step of the projected L-BFGS iteration on
+//        log-prices -- the on-device "nu update": Gram form (<= 1024 tokens, memory <= 4),
+//        register-resident sequential form (<= 2048 tokens), generic form.
+//                                                                        reference: arbitrage.py:82
 //   trades2_kernel / tradesn_kernel       materialise Delta_i, Lambda_i at the accepted prices
 //        (once per solve).                                              reference: two-asset.py:94,98
+//   fold_kernel, start_kernel             slice fold before the RCCL all-reduce; start of a solve.
 #pragma once
 #include "pool_math.hpp"
 
