@@ -185,8 +185,9 @@ size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 16 * 64 + 64 + 32 + 2 * 
 // k-asset geo-mean buckets, CFMM_POOL_* for the two-asset ones
 const int kOrder[N_BUCKETS] = {-8, -7, -6, -5, -4, -3, CFMM_POOL_CURVE2, CFMM_POOL_W2, CFMM_POOL_CP2, CFMM_POOL_SUM2};
 
-// `only` = a bucket code to evaluate that bucket alone (measurement hook), or 0x7fffffff for all
-EvalArgs make_eval_args(cfmm_ctx *ctx, int only = 0x7fffffff)
+// `only` = a bucket code to evaluate that bucket alone (measurement hook), or 0x7fffffff for all;
+// `stable` selects the tile space of eval_kernel<.., STABLE>: the stableswap bucket alone, or everything else
+EvalArgs make_eval_args(cfmm_ctx *ctx, bool stable, int only = 0x7fffffff)
 {
     EvalArgs a = {};
     for (int k = 0; k < CFMM_POOL_KINDS2; ++k) a.b2[k] = ctx->pools->b2[k];
@@ -197,7 +198,7 @@ EvalArgs make_eval_args(cfmm_ctx *ctx, int only = 0x7fffffff)
         const int code = kOrder[q];
         const long long m = code < 0 ? ctx->pools->bn[-code].m : ctx->pools->b2[code].m;
         const int wt = wave_tile_pools(code);
-        if (only == 0x7fffffff || only == code) tiles += (m + wt - 1) / wt;
+        if ((only == 0x7fffffff || only == code) && ((code == CFMM_POOL_CURVE2) == stable)) tiles += (m + wt - 1) / wt;
         a.tile_end[q] = (int)tiles;
     }
     a.ntiles = (int)tiles;
@@ -219,20 +220,21 @@ void eval_geometry(cfmm_ctx *ctx, int ntiles, int &grid, int &threads)
     if (grid < 1) grid = 1;
 }
 
-template <bool WITH_D>
+template <bool WITH_D, bool STABLE>
 void launch_eval(cfmm_ctx *ctx, const EvalArgs &a)
 {
     if (a.ntiles == 0) return;
     int grid, threads;
     eval_geometry(ctx, a.ntiles, grid, threads);
-    hipLaunchKernelGGL((eval_kernel<WITH_D>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), ctx->stream, a);
+    hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), ctx->stream, a);
 }
 
-// one dual evaluation of every bucket
+// one dual evaluation of every bucket: one launch, plus one for the stableswap bucket when there is one
 template <bool WITH_D>
 void launch_all_evals(cfmm_ctx *ctx)
 {
-    launch_eval<WITH_D>(ctx, make_eval_args(ctx));
+    launch_eval<WITH_D, false>(ctx, make_eval_args(ctx, false));
+    if (ctx->pools->b2[CFMM_POOL_CURVE2].m > 0) launch_eval<WITH_D, true>(ctx, make_eval_args(ctx, true));
 }
 
 template <class F>
@@ -246,8 +248,10 @@ int set_all_lds_attrs(cfmm_ctx *ctx)
 {
     const size_t e0 = eval_lds_bytes(ctx->n, false), e1 = eval_lds_bytes(ctx->n, true);
     int rc;
-    if ((rc = set_lds_attr(ctx, eval_kernel<false>, e0))) return rc;
-    if ((rc = set_lds_attr(ctx, eval_kernel<true>, e1))) return rc;
+    if ((rc = set_lds_attr(ctx, eval_kernel<false, false>, e0))) return rc;
+    if ((rc = set_lds_attr(ctx, eval_kernel<true, false>, e1))) return rc;
+    if ((rc = set_lds_attr(ctx, eval_kernel<false, true>, e0))) return rc;
+    if ((rc = set_lds_attr(ctx, eval_kernel<true, true>, e1))) return rc;
     if ((rc = set_lds_attr(ctx, update_kernel, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 8, 2>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 4, 4>, upd_lds_bytes(ctx->n)))) return rc;
@@ -439,7 +443,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if ((rc = set_all_lds_attrs(ctx))) return bail(rc);
     {
         int nb = 0;
-        TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eval_kernel<false>, EVAL_THREADS, eval_lds_bytes(n, false)));
+        TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eval_kernel<false, false>, EVAL_THREADS, eval_lds_bytes(n, false)));
         ctx->eval_blocks_per_cu = nb < 1 ? 1 : nb;
     }
     if (ctx->nslices > 64) ctx->nslices = 64;
@@ -881,9 +885,10 @@ int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_lau
     if (!ctx->have_nu) return fail(ctx, CFMM_E_STATE, "time_eval_kernel: no prices set");
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, ctx->nu_acc, ctx->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->nu + ctx->n, 0, sizeof(double), ctx->stream));
-    const EvalArgs ea = make_eval_args(ctx, kind == CFMM_TIME_ALL ? 0x7fffffff : kind);
-    if (ea.ntiles == 0) return fail(ctx, CFMM_E_ARG, "time_eval_kernel: bucket %d is empty", kind);
-    auto launch = [&]() { launch_eval<false>(ctx, ea); };
+    const int only = kind == CFMM_TIME_ALL ? 0x7fffffff : kind;
+    const EvalArgs ea = make_eval_args(ctx, false, only), es = make_eval_args(ctx, true, only);
+    if (ea.ntiles + es.ntiles == 0) return fail(ctx, CFMM_E_ARG, "time_eval_kernel: bucket %d is empty", kind);
+    auto launch = [&]() { launch_eval<false, false>(ctx, ea); launch_eval<false, true>(ctx, es); };
     for (int i = 0; i < 3; ++i) launch();
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
     for (int i = 0; i < reps; ++i) launch();

@@ -148,6 +148,7 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
                                       double *psi_s, double *diag_s, double &fsum)
 {
     constexpr int U = wave_tile_pools(KIND) / 64;
+    asm volatile("" : "+v"(lane));              // (opaque: keeps per-kind lane arithmetic from being hoisted out of the tile loop)
     double Ra[U], Rb[U], g[U], prm[U];
     int ia[U], ib[U], fl[U];
     bool live[U];
@@ -208,6 +209,9 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
                                       double *psi_s, double *diag_s, double2 *xs, double &fsum)
 {
     constexpr int P = pools_per_wave<K>();
+    // (opaque copy: otherwise the lane / K, lane % K and strip addresses of all six instantiations are hoisted out of
+    //  the tile loop and stay live across it -- ~20 VGPRs on a kernel that sits on a register cliff)
+    asm volatile("" : "+v"(lane));
     const int g = lane / K, j = lane - g * K;
     const long long pool = tb * P + g;
     const bool live = (g < P) && (pool < b.m);
@@ -217,7 +221,9 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
     const double fee = b.fee[live ? pool : 0];
     const double lg = b.lfee[live ? pool : 0];
     const double p = nu_s[tok];
+    SCHED_FENCE();
     const double a = log(R * p * rcp_nr(w));
+    SCHED_FENCE();
     const int gb = (g < P ? g : 0) * K;
     xs[lane] = make_double2(a, w);                     // ds_write_b128; same-wave LDS ops stay in order
     __builtin_amdgcn_wave_barrier();
@@ -230,6 +236,7 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
         f1 += v.y * (fmin(u1, 0.0) + fmax(u1 + lg, 0.0));
         f2 += v.y * (fmin(u2, 0.0) + fmax(u2 + lg, 0.0));
     }
+    SCHED_FENCE();
     const bool wd = f1 > 0.0;                           // withdrawn at the root: t* < a_j
     const bool dp = f2 < 0.0;                           // deposited at the root: t* > a_j - lg
     const double den_j = (wd || dp) ? w : 0.0;
@@ -241,12 +248,14 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
 #pragma unroll
     for (int k = 0; k < K; ++k) { const double2 v = xs[gb + k]; num += v.x; den += v.y; }
     __builtin_amdgcn_wave_barrier();
+    SCHED_FENCE();
     double y = 0.0;
     if (den > 0.0 && (wd || dp)) {
         const double t = num * rcp_nr(den);
-        const double rx = -R * expm1(wd ? t - t1 : t - t2);    // R - x,  x = R e^{f(t - a_j)}
+        const double rx = -R * expm1_wave(wd ? t - t1 : t - t2);    // R - x,  x = R e^{f(t - a_j)}
         y = wd ? rx : rx * rcp_nr(fee);
     }
+    SCHED_FENCE();
     if (live) {
         if (y != 0.0) { unsafeAtomicAdd(&psi_s[tok], y); fsum += p * y; }
         if (WITH_D) unsafeAtomicAdd(&diag_s[tok], (1.0 - w) * p * R);
@@ -264,7 +273,9 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
 // epilogue flushes the workgroup's psi tile into accumulator slice blockIdx % nslices
 // (global_atomic_add_f64).
 // ------------------------------------------------------------------------------------------
-template <bool WITH_D>
+// STABLE = false: every bucket but the stableswap one; STABLE = true: the stableswap bucket alone (its Newton loops need
+// ~20 more VGPRs than anything else: kept out of the main instantiation, it lets that one run at 6 waves per SIMD)
+template <bool WITH_D, bool STABLE>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 eval_kernel(EvalArgs a)
 {
@@ -317,16 +328,16 @@ eval_kernel(EvalArgs a)
         t_out += tc0 - t_prev;
 #endif
         switch (bk) {
-        case 0: tilen<8, WITH_D>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
-        case 1: tilen<7, WITH_D>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
-        case 2: tilen<6, WITH_D>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
-        case 3: tilen<5, WITH_D>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
-        case 4: tilen<4, WITH_D>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
-        case 5: tilen<3, WITH_D>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum); break;
-        case 6: tile2<3, WITH_D>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum); break;
-        case 7: tile2<1, WITH_D>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum); break;
-        case 8: tile2<0, WITH_D>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum); break;
-        default: tile2<2, WITH_D>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum); break;
+        case 0: if constexpr (!STABLE) { tilen<8, WITH_D>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
+        case 1: if constexpr (!STABLE) { tilen<7, WITH_D>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
+        case 2: if constexpr (!STABLE) { tilen<6, WITH_D>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
+        case 3: if constexpr (!STABLE) { tilen<5, WITH_D>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
+        case 4: if constexpr (!STABLE) { tilen<4, WITH_D>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
+        case 5: if constexpr (!STABLE) { tilen<3, WITH_D>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
+        case 6: if constexpr (STABLE) { tile2<3, WITH_D>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum); } break;
+        case 7: if constexpr (!STABLE) { tile2<1, WITH_D>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum); } break;
+        case 8: if constexpr (!STABLE) { tile2<0, WITH_D>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum); } break;
+        default: if constexpr (!STABLE) { tile2<2, WITH_D>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum); } break;
         }
 #ifdef CFMM_PHASE_TIMERS
         if (a.ts && lane == 0) {                       // per-wave tile log: ts[64 + 8 gw + i] = bucket << 48 | cycles

@@ -16,6 +16,8 @@ namespace cfmm {
 
 struct Y2 { double ya, yb; };
 
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 // 1/x and 1/sqrt(x) from the quarter-rate hardware seeds plus two Newton steps (<= ~1 ulp for
 // normal positive inputs: reserves, prices, fees); ~6-8 instructions instead of the 11-20 of the
 // IEEE sequences, which matters because the evaluation kernel is fp64-issue bound
@@ -32,6 +34,32 @@ __device__ __forceinline__ double rsqrt_nr(double x)
     y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
     y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
     return y;
+}
+
+// log1p and expm1 for the small arguments that dominate here (a pool a few per cent off the market):
+// short series, taken only when EVERY active lane of the wave is in range (wave-uniform branch, no
+// divergence); otherwise the library routines.  Relative error < 2e-16 inside the ranges below.
+__device__ __forceinline__ double log1p_wave(double d)        // log(1 + d)
+{
+    if (__all(fabs(d) < 0.125)) {
+        const double s = d * rcp_nr(2.0 + d), z = s * s;           // log(1+d) = 2 atanh(d / (2 + d))
+        double p = 1.0 / 13.0;
+        p = fma(p, z, 1.0 / 11.0); p = fma(p, z, 1.0 / 9.0); p = fma(p, z, 1.0 / 7.0);
+        p = fma(p, z, 1.0 / 5.0); p = fma(p, z, 1.0 / 3.0);
+        return 2.0 * fma(s * z, p, s);
+    }
+    return log1p(d);
+}
+__device__ __forceinline__ double expm1_wave(double x)
+{
+    if (__all(fabs(x) < 0.0625)) {                                   // Taylor to x^11 / 11!
+        double p = 1.0 / 39916800.0;
+        p = fma(p, x, 1.0 / 3628800.0); p = fma(p, x, 1.0 / 362880.0); p = fma(p, x, 1.0 / 40320.0);
+        p = fma(p, x, 1.0 / 5040.0); p = fma(p, x, 1.0 / 720.0); p = fma(p, x, 1.0 / 120.0);
+        p = fma(p, x, 1.0 / 24.0); p = fma(p, x, 1.0 / 6.0); p = fma(p, x, 0.5);
+        return fma(x * x, p, x);
+    }
+    return expm1(x);
 }
 
 // Constant product sqrt(xy)  (Uniswap v2: arbitrage.py:68-70, equal-weight cp.geo_mean).
@@ -73,9 +101,13 @@ __device__ __forceinline__ Y2 pool_w2(double Ra, double Rb, double g, double wa,
         const double vin = ab ? va : vb, vout = ab ? vb : va;
         const double Rin = ab ? Ra : Rb, Rout = ab ? Rb : Ra;
         const double win = ab ? wa : wb, wout = ab ? wb : wa;
-        const double L = log(g * vout * rcp_nr(vin));
-        const double yin = -Rin * expm1(wout * L) * rcp_nr(g);
-        const double yout = -Rout * expm1(-win * L);
+        // (scheduling fences: interleaving the three library routines costs ~30 VGPRs and the kernel sits on a register cliff)
+        const double L = log1p_wave(fma(g, vout, -vin) * rcp_nr(vin));      // log rho; rho - 1 formed without cancellation
+        SCHED_FENCE();
+        const double yin = -Rin * expm1_wave(wout * L) * rcp_nr(g);
+        SCHED_FENCE();
+        const double yout = -Rout * expm1_wave(-win * L);
+        SCHED_FENCE();
         y.ya = ab ? yin : yout;
         y.yb = ab ? yout : yin;
     }
@@ -112,6 +144,7 @@ __device__ __forceinline__ bool curve_dir(double Rin, double Rout, double g, dou
         const double hh = (1.0 + al / (hi * hi * yy)) / (1.0 + al / (hi * yy * yy)) - rho;
         if (hh <= 0.0) break;
         lo = hi; hi *= 2.0;
+        SCHED_FENCE();
     }
     double x = lo;
     for (int it = 0; it < 100; ++it) {
@@ -128,6 +161,7 @@ __device__ __forceinline__ bool curve_dir(double Rin, double Rout, double g, dou
         const bool done = fabs(xn - x) <= 4e-16 * x;
         x = xn;
         if (done) break;
+        SCHED_FENCE();
     }
     yin = -(x - Rin) / g;
     yout = Rout - curve_y(x, C, al);

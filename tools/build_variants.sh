@@ -7,9 +7,8 @@ build() { make -s variant TAG=$1 DEFS="$2" & }
 build t1024w4 "-DEVAL_THREADS_DEF=1024 -DEVAL_WAVES_PER_SIMD=4"
 build t640w5 "-DEVAL_THREADS_DEF=640 -DEVAL_WAVES_PER_SIMD=5"
 build t768w6 "-DEVAL_THREADS_DEF=768 -DEVAL_WAVES_PER_SIMD=6"
+build t512w6 "-DEVAL_THREADS_DEF=512 -DEVAL_WAVES_PER_SIMD=6"
 build t384w6 "-DEVAL_THREADS_DEF=384 -DEVAL_WAVES_PER_SIMD=6"
-build t512w8 "-DEVAL_THREADS_DEF=512 -DEVAL_WAVES_PER_SIMD=8"
-build t512w4 "-DEVAL_THREADS_DEF=512 -DEVAL_WAVES_PER_SIMD=4"
 build timers "-DCFMM_PHASE_TIMERS"
 wait
 ls ../cfmm/variants/

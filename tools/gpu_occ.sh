@@ -1,17 +1,8 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-python - <<'PY'
-import sys, time
-sys.path[:0] = ['.', 'cfmm-routing-code_amd']
-import numpy as np
-import cfmm
-from cfmm import synthetic
-net = synthetic.config("C3", seed=0)
-for rep in range(3):
-    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
-    t0 = time.perf_counter(); p._ensure_ctx(); t1 = time.perf_counter()
-    v = p.solve(tol=1e-6); t2 = time.perf_counter()
-    d = p.bucket_trades("cp2"); t3 = time.perf_counter()
-    print("create+upload %.2f ms  first solve %.2f ms  trades(cp2) %.2f ms" % (1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2)))
-    p.close()
-PY
+V=$PWD/cfmm-routing-code_amd/cfmm/variants
+python -m pytest tests -m gpu -q -x 2>&1 | tail -2
+for cfg in C3 C4shard; do
+for lib in t1024w4 t640w5 t768w6 t512w6 t384w6; do
+echo -n "$lib "; CFMM_LIB=$V/libcfmm_hip_$lib.so python tools/profile_eval.py --config $cfg | cut -c1-112
+done; done
