@@ -34,8 +34,8 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
 # HBM bytes per eval_kernel launch on the C3 workload from the rocprofv3 PMC passes committed under
 # profiles/ (FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM, + WRITE_SIZE); None until measured
-TRAFFIC_BYTES = (2 * 23092 + 4056) * 1024      # profiles/r01c_rocprofv3_pmc_medians.csv, config C3
-TRAFFIC_NOTE = ("C3's 42.6 MB working set fits the 256 MiB Infinity Cache: back-to-back launches are cache-served; "
+TRAFFIC_BYTES = (2 * 22898 + 2008) * 1024      # profiles/r01c_rocprofv3_pmc_medians.csv, config C3
+TRAFFIC_NOTE = ("C3's 43.4 MB working set fits the 256 MiB Infinity Cache: back-to-back launches are cache-served; "
                 "profiles/ holds the PMC traffic and the HBM-streaming (>= 1e7 pools) variant")
 
 BYTES_PER_POOL = {"cp2": 32, "w2": 40, "sum2": 32, "curve2": 40}     # SURVEY 8(d); k-asset: 20 + 20 k (+ log fee)
