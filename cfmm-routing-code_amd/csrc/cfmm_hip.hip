@@ -868,6 +868,22 @@ int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128)
     return CFMM_OK;
 }
 
+int cfmm_selftest(cfmm_ctx *ctx)
+{
+    if (!ctx) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int *d = nullptr, h = -1;
+    HIP_TRY(ctx, hipMalloc((void **)&d, sizeof(int)));
+    HIP_TRY(ctx, hipMemsetAsync(d, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
+    hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "selftest -> %s", hipGetErrorString(e));
+    if (h != 0) return fail(ctx, CFMM_E_NUMERIC, "selftest: %d lane results of the cross-lane reductions are wrong on this device / ROCm", h);
+    return CFMM_OK;
+}
+
 int cfmm_debug_timers(cfmm_ctx *ctx, int64_t *out64)
 {
     if (!ctx || !out64) return CFMM_E_ARG;

@@ -1443,6 +1443,31 @@ update_gram_kernel(UpdArgs a)
     PHASE_STAMP(a.ts, 15);
 }
 
+// ------------------------------------------------------------------------------------------
+// self-test of the cross-lane primitives the update kernels rest on (cfmm_selftest): the butterflies
+// must leave the wave total / maximum in every lane, the reduce-scatter the total of quantity l in
+// lane l.  Inputs are small integers, so every sum is exact and the comparison is bitwise.
+// out[0] = number of mismatching lanes (0 = pass).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+selftest_kernel(int *out)
+{
+    const int lane = threadIdx.x;
+    int bad = 0;
+    const double x = (double)((lane * 37 + 11) % 101) - 50.0;
+    double ts = 0.0, tm = -1e300;
+    for (int l = 0; l < 64; ++l) { const double v = (double)((l * 37 + 11) % 101) - 50.0; ts += v; tm = fmax(tm, v); }
+    if (wave_allsum(x) != ts) ++bad;
+    if (wave_allmax(x) != tm) ++bad;
+    double V[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) V[i] = (double)(((lane + 3) * (i + 5)) % 23) - 7.0;
+    double want = 0.0;
+    for (int l = 0; l < 64; ++l) want += (double)(((l + 3) * (lane + 5)) % 23) - 7.0;      // total of quantity `lane`
+    if (wave_reduce_scatter64(V, lane) != want) ++bad;
+    atomicAdd(out, bad);
+}
+
 // start of a solve: group variable = mean over members of (log nu0_j - off_j), clamped
 __global__ void __launch_bounds__(UPD_THREADS)
 start_kernel(UpdArgs a, const double *__restrict__ nu0)

@@ -138,6 +138,9 @@ int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128);
  * the k-asset bucket); returns the average seconds per launch in *sec_per_launch. */
 #define CFMM_TIME_ALL 100
 int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_launch);
+/* checks the cross-lane primitives of the update kernels (DPP / v_permlane*_swap / ds_swizzle butterflies and the
+ * 64-value reduce-scatter) against exact integer sums on this device; 0 = pass */
+int cfmm_selftest(cfmm_ctx *ctx);
 /* kernel-tuning hook: 32 {shader-cycle, 100 MHz wall-clock} stamp pairs written by the last
  * evaluation / update kernels of a build made with -DCFMM_PHASE_TIMERS (zeros otherwise), then a
  * per-wave tile log and per-block start/end clocks of the last evaluation; `out` holds

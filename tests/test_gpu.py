@@ -21,6 +21,13 @@ def _oracle_for(oracle_lib, net, threads=4):
     return o
 
 
+def test_cross_lane_primitives_selftest():
+    """wave butterflies (DPP, v_permlane16/32_swap) and the 64-value reduce-scatter, exact integer sums"""
+    ctx = _lib.Context(8)
+    ctx.selftest()
+    ctx.close()
+
+
 def test_backend_is_gfx950():
     ctx = _lib.Context(8)
     assert ctx.backend.startswith("hip:gfx950")
