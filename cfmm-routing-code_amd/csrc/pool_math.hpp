@@ -10,12 +10,11 @@
 
 namespace cfmm {
 
-#ifndef GM_SCHED_BARRIER
-#define GM_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 struct Y2 { double ya, yb; };
 
+// scheduling fence: keeps the compiler from interleaving independent library-routine expansions (log, expm1, ...),
+// which multiplies their temporaries; the evaluation kernel is register-budget sensitive
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // 1/x and 1/sqrt(x) from the quarter-rate hardware seeds plus two Newton steps (<= ~1 ulp for
@@ -205,7 +204,7 @@ __device__ __forceinline__ void pool_geomean_n(const double (&R)[K], const doubl
     double a[K];
     const double lg = log(g);
 #pragma unroll
-    for (int j = 0; j < K; ++j) { a[j] = log(R[j] * price(j) / w[j]); GM_SCHED_BARRIER(); }
+    for (int j = 0; j < K; ++j) { a[j] = log(R[j] * price(j) / w[j]); SCHED_FENCE(); }
     double tL = -1.7976931348623157e308, fL = 0.0, tR = 1.7976931348623157e308, fR = 0.0;
 #pragma unroll
     for (int b = 0; b < 2 * K; ++b) {
@@ -218,7 +217,7 @@ __device__ __forceinline__ void pool_geomean_n(const double (&R)[K], const doubl
         }
         if (f <= 0.0 && t > tL) { tL = t; fL = f; }
         if (f >= 0.0 && t < tR) { tR = t; fR = f; }
-        GM_SCHED_BARRIER();
+        SCHED_FENCE();
     }
     double t;
     if (fL == 0.0) t = tL;
@@ -230,7 +229,7 @@ __device__ __forceinline__ void pool_geomean_n(const double (&R)[K], const doubl
         const double hi = mu * w[j] / price(j), lo = g * hi;
         const double x = R[j] < lo ? lo : (R[j] > hi ? hi : R[j]);
         y[j] = (x < R[j]) ? (R[j] - x) : (R[j] - x) / g;
-        GM_SCHED_BARRIER();
+        SCHED_FENCE();
     }
 }
 
