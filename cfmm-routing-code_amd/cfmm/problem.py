@@ -401,14 +401,14 @@ class Problem:
         b = self.net["sum2"]
         r = np.log(nu[b["ia"]]) - np.log(nu[b["ib"]])
         lg = np.log(b["fee"])
+        sgn = np.where(r < 0, 1, -1)                 # a->b kink at r = lg < 0, b->a kink at r = -lg > 0
+        dist = np.abs(r - sgn * lg)
+        near = (dist < kink_tol) & ((dist < 0.5 * np.abs(lg)) | (lg == 0.0))
         out = {}
-        for i in range(len(r)):
-            if i in tied:
-                continue
-            sgn = +1 if r[i] < 0 else -1          # a->b kink at r = lg < 0, b->a kink at r = -lg > 0
-            dist = abs(r[i] - sgn * lg[i])
-            if dist < kink_tol and (dist < 0.5 * abs(lg[i]) or lg[i] == 0.0) and (i, sgn) not in banned:
-                out[i] = sgn
+        for i in np.flatnonzero(near):               # (only the pools on a kink: the scan itself is vectorised)
+            i = int(i)
+            if i not in tied and (i, int(sgn[i])) not in banned:
+                out[i] = int(sgn[i])
         return out
 
     def _solve_kinks(self, ctx, nu, tol, kw, kink_tol, max_rounds, total):
