@@ -1244,6 +1244,7 @@ update_gram_kernel(UpdArgs a)
     }
     // ---- the batch.  0 f_lin 1 gapv 2 Gs.ds 3 Gs_t.ds 4 s.y 5 s.s 6 y.y 7 pg 8 |q0|^2
     //      9..13 u_k | 14..18 v_k | 19..28 SY[k][j], k > j | 29..43 YHY[k][j], k >= j | maxima: viol, scale
+    PHASE_STAMP(a.ts, 19);
     double V[64];
 #pragma unroll
     for (int i = 0; i < 64; ++i) V[i] = 0.0;
@@ -1298,7 +1299,9 @@ update_gram_kernel(UpdArgs a)
             for (int j = 0; j <= k; ++j) V[c2++] += hy * Yx[j][e];
         }
     }
+    PHASE_STAMP(a.ts, 20);
     const double mine = wave_reduce_scatter64(V, lane);
+    PHASE_STAMP(a.ts, 21);
     mx[0] = wave_allmax(mx[0]); mx[1] = wave_allmax(mx[1]);
     xw[wave * 64 + lane] = mine;
     if (lane == 0) { xm[wave * 2] = mx[0]; xm[wave * 2 + 1] = mx[1]; }
@@ -1312,6 +1315,7 @@ update_gram_kernel(UpdArgs a)
     double T[44];
 #pragma unroll
     for (int i = 0; i < 44; ++i) T[i] = xt[i];
+    PHASE_STAMP(a.ts, 22);
     double viol = 0.0, scale = 0.0;
     for (int w = 0; w < nw; ++w) { viol = fmax(viol, xm[w * 2]); scale = fmax(scale, xm[w * 2 + 1]); }
     const double f_t = T[0], gapv = T[1];

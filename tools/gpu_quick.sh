@@ -16,7 +16,7 @@ import json
 for l in open('gpurun_out/q/sweep.jsonl'):
     r = json.loads(l)
     print(r['tag'], r['config'], r['status'], 'evals', r['evals'], 'dev_us/eval %.1f eval_all_us %.2f solve_ms %.3f' % (r['dev_us_per_eval'], r['eval_all_us'], r['solve_wall_ms']), r.get('buckets', ''))
-    for k in ('eval_blocks', 'eval_phases(cyc,us)', 'upd_phases(cyc,us)', 'tile_us(avg,max,count)', 'wave_busy_us(min,mean,max)', 'between_tiles_us(mean,max)'):
+    for k in ('eval_blocks', 'eval_phases(cyc,us)', 'upd_phases(cyc,us)', 'upd_A_detail(cyc,us)', 'tile_us(avg,max,count)', 'wave_busy_us(min,mean,max)', 'between_tiles_us(mean,max)'):
         if k in r: print('    ', k, r[k])
 PY
 tail -3 $O/sweep.err

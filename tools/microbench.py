@@ -88,4 +88,6 @@ if ts.any():
     out["eval_phases(cyc,us)"] = dict(prologue=d(ts, 0, 1), tiles=d(ts, 1, 2), reduce=d(ts, 2, 3), flush=d(ts, 3, 4))
     out["upd_phases(cyc,us)"] = dict(st=d(tu, 8, 9), loads=d(tu, 9, 10), A=d(tu, 10, 11), B=d(tu, 11, 12), C=d(tu, 12, 13),
                                      D=d(tu, 13, 14), E=d(tu, 14, 15), total=d(tu, 8, 15))
+    if tu[19].any():
+        out["upd_A_detail(cyc,us)"] = dict(grad=d(tu, 10, 19), partials=d(tu, 19, 20), reduce_scatter=d(tu, 20, 21), lds_exchange=d(tu, 21, 22), tail=d(tu, 22, 11))
 print(json.dumps(out), flush=True)
