@@ -24,14 +24,19 @@ class CfmmError(RuntimeError):
 class Opts(C.Structure):
     _fields_ = [("tol_gap", C.c_double), ("tol_infeas", C.c_double), ("armijo", C.c_double),
                 ("max_step", C.c_double), ("max_evals", C.c_int32), ("memory", C.c_int32),
-                ("iters_per_graph", C.c_int32), ("pg_rule", C.c_int32)]
+                ("iters_per_graph", C.c_int32), ("pg_rule", C.c_int32),
+                ("method", C.c_int32), ("max_newton", C.c_int32), ("barrier_shrink", C.c_double)]
+
+
+METHODS = {"auto": 0, "lbfgs": 1, "newton": 2}
 
 
 class Stats(C.Structure):
     _fields_ = [("evals", C.c_int32), ("iters", C.c_int32), ("status", C.c_int32), ("n_ranks", C.c_int32),
                 ("dual_value", C.c_double), ("primal_value", C.c_double), ("gap", C.c_double),
                 ("infeas", C.c_double), ("wall_seconds", C.c_double), ("device_seconds", C.c_double),
-                ("pg", C.c_double), ("pool_subproblems", C.c_int64)]
+                ("pg", C.c_double), ("pool_subproblems", C.c_int64),
+                ("barrier_mu", C.c_double), ("newton_steps", C.c_int32), ("method", C.c_int32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -39,7 +44,7 @@ class Stats(C.Structure):
 
 def build(force=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("cfmm_hip.hip", "kernels.hpp", "pool_math.hpp")]
+    srcs = [os.path.join(_CSRC, f) for f in ("cfmm_hip.hip", "kernels.hpp", "pool_math.hpp", "smooth.hpp", "chol.hpp")]
     srcs.append(os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "cfmm.h"))
     if force or not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _CSRC, "-s"])
@@ -50,7 +55,7 @@ _lib = None
 
 SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm_backend", "cfmm_default_opts",
            "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_set_pool_flags", "cfmm_set_utility",
-           "cfmm_set_ties", "cfmm_eval_dual", "cfmm_solve", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
+           "cfmm_set_ties", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_solve", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_comm_unique_id", "cfmm_comm_init",
            "cfmm_time_eval_kernel", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
 
@@ -77,6 +82,8 @@ def lib():
     L.cfmm_set_utility.argtypes = [vp, dp, dp, ip]
     L.cfmm_set_ties.argtypes = [vp, C.c_int, ip, dp]
     L.cfmm_eval_dual.argtypes = [vp, dp, dp, dp, dp]
+    L.cfmm_eval_smooth.argtypes = [vp, dp, C.c_double, dp, dp, dp, dp]
+    L.cfmm_debug_cholesky.argtypes = [vp, C.c_int, dp, dp, dp, ip]
     L.cfmm_solve.argtypes = [vp, dp, C.POINTER(Opts), C.POINTER(Stats)]
     L.cfmm_get_nu.argtypes = [vp, dp]; L.cfmm_set_nu.argtypes = [vp, dp]; L.cfmm_get_psi.argtypes = [vp, dp]
     L.cfmm_get_solution.argtypes = [vp, dp, dp]
@@ -111,6 +118,7 @@ def i32(a):
 
 class Context:
     """Thin object wrapper over one cfmm_ctx (one GPU)."""
+    second_order = True        # cfmm_solve offers CFMM_METHOD_NEWTON
 
     def __init__(self, n_tokens, device=0, _handle=None):
         self.L = lib()
@@ -181,6 +189,22 @@ class Context:
         self._chk(self.L.cfmm_eval_dual(self.h, _d(nu), C.byref(arb), _d(psi), _d(diag)))
         return (arb.value, psi, diag) if want_diag else (arb.value, psi)
 
+    def eval_smooth(self, nu, mu, want_hessian=False):
+        """barrier-smoothed evaluation (two-asset pools): value, nu'(L - D), psi_mu[, lower-triangular H]"""
+        nu = f64(nu)
+        psi = np.zeros(self.n)
+        H = np.zeros((self.n, self.n), order="F") if want_hessian else None
+        val, tr = C.c_double(), C.c_double()
+        self._chk(self.L.cfmm_eval_smooth(self.h, _d(nu), float(mu), C.byref(val), C.byref(tr), _d(psi), _d(H)))
+        return (val.value, tr.value, psi, H) if want_hessian else (val.value, tr.value, psi)
+
+    def debug_cholesky(self, A, b):
+        """solve A x = b with the library's dense Cholesky (A: n x n SPD, n = this context's token count)"""
+        A = np.asfortranarray(A, dtype=np.float64); b = f64(b)
+        x = np.zeros(self.n); info = C.c_int32()
+        self._chk(self.L.cfmm_debug_cholesky(self.h, self.n, _d(A), _d(b), _d(x), C.byref(info)))
+        return x, info.value
+
     def default_opts(self):
         o = Opts()
         self.L.cfmm_default_opts(C.byref(o))
@@ -190,6 +214,8 @@ class Context:
         o = self.default_opts()
         if "tol" in kw:
             o.tol_gap = o.tol_infeas = kw.pop("tol")
+        if isinstance(kw.get("method"), str):
+            kw["method"] = METHODS[kw["method"]]
         for k, v in kw.items():
             if not hasattr(o, k):
                 raise TypeError(f"unknown solver option {k!r}")

@@ -359,7 +359,11 @@ class Problem:
 
     # -- solve -------------------------------------------------------------------------------
     def solve(self, tol=1e-6, nu0=None, max_evals=2000, memory=0, iters_per_graph=8, kink_tol=1e-3,
-              max_rounds=6, warm_start=False):
+              max_rounds=6, warm_start=False, method="auto"):
+        """`method`: "lbfgs" (first order, on-device), "newton" (barrier-smoothed second order: networks of
+        two-asset pools, the remedy for constant-sum / stableswap pools at scale) or "auto" (second order when the
+        network holds near-linear pools and only two-asset pools; otherwise first order, with the host-side
+        active-set loop for constant-sum kinks)."""
         if self.utility is None:
             raise ValueError("no utility set")
         ctx = self._ensure_ctx()
@@ -380,10 +384,21 @@ class Problem:
         self._tol = tol
         kw = dict(max_evals=max_evals, memory=memory, iters_per_graph=iters_per_graph)
         total = dict(evals=0, iters=0, wall_seconds=0.0, device_seconds=0.0, rounds=0)
-        if "sum2" not in self.net:
-            st = self._run(ctx, nu0, total, tol=tol, **kw)
+        two_asset_only = not self.net.get("gn")
+        near_linear = ("sum2" in self.net) or ("curve2" in self.net)
+        sharded = bool(self._comm) and self._comm[0] > 1
+        if method not in _lib.METHODS:
+            raise ValueError(f"method {method!r}: expected one of {sorted(_lib.METHODS)}")
+        second_order = method == "newton" or (method == "auto" and two_asset_only and near_linear and not sharded
+                                               and getattr(ctx, "second_order", False))
+        if second_order:
+            st = self._run(ctx, nu0, total, tol=tol, method=_lib.METHODS["newton"], **kw)
+            nu, psi = ctx.get_solution()
+        elif "sum2" not in self.net:
+            st = self._run(ctx, nu0, total, tol=tol, method=_lib.METHODS[method], **kw)
             nu, psi = ctx.get_solution()
         else:
+            kw["method"] = _lib.METHODS["lbfgs"]
             st, nu, psi = self._solve_kinks(ctx, nu0, tol, kw, kink_tol, max_rounds, total)
         self._finish(st, nu, psi, total)
         return self.value
@@ -511,10 +526,16 @@ class Problem:
         for i, (sgn, th) in self._theta.items():
             psi += th * self._fill_vector(i, sgn)
         r = psi + u.h
-        # sum_i arb_i = nu'psi_pools; tied pools trade value-neutrally at their kink prices
-        self.dual_value = float((nu - u.c) @ u.h + nu @ psi)
         self.value = float(u.c @ psi)
-        self.gap = abs(float((nu - u.c) @ r)) / max(1.0, abs(self.dual_value))
+        if st.get("method") == _lib.METHODS["newton"]:
+            # psi is the barrier-smoothed primal point (strictly inside every pool's trading set); the dual value
+            # and the gap against it were computed on the device from an exact evaluation at nu
+            self.dual_value = float(st["dual_value"])
+            self.gap = abs(float(st["gap"]))
+        else:
+            # sum_i arb_i = nu'psi_pools; tied pools trade value-neutrally at their kink prices
+            self.dual_value = float((nu - u.c) @ u.h + nu @ psi)
+            self.gap = abs(float((nu - u.c) @ r)) / max(1.0, abs(self.dual_value))
         viol = np.where(u.ctype == GE, np.maximum(-r, 0.0), np.where(u.ctype == EQ, np.abs(r), 0.0))
         self.infeas = float(viol.max() / max(np.abs(psi).max(), np.abs(u.h).max(), 1e-300))
         self.nu, self.psi = nu, psi

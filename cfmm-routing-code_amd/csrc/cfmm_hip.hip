@@ -21,6 +21,8 @@
 
 #include "../../include/cfmm.h"
 #include "kernels.hpp"
+#include "smooth.hpp"
+#include "chol.hpp"
 
 using namespace cfmm;
 
@@ -126,6 +128,11 @@ struct cfmm_ctx {
     // RCCL
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
+
+    // second-order method (allocated on first use)
+    double *sm_out = nullptr, *sm_vec = nullptr, *H = nullptr;
+    int *sm_mask = nullptr, *sm_info = nullptr;
+    double mu_last = 0.0;              // barrier weight of the last solve (0: first-order, exact tenders)
 };
 
 namespace {
@@ -366,6 +373,273 @@ bool same_opts(const cfmm_opts &a, const cfmm_opts &b) { return std::memcmp(&a, 
 
 }  // namespace
 
+extern "C" int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi, double *diag);
+extern "C" int64_t cfmm_pool_count(cfmm_ctx *ctx);
+
+// ---------------------------------------------------------------------------------------------
+// Second-order outer iteration (CFMM_METHOD_NEWTON): barrier-smoothed dual Newton, smooth.hpp.
+// The host drives it (a few dozen steps, each dominated by the n x n Cholesky): per step one smoothed
+// evaluation with Hessian, one exact evaluation for the certificates, one dense Cholesky (chol.hpp), and a
+// back-tracking line search of smoothed evaluations.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+int hess_ld(int n) { return (n + CH_NB - 1) / CH_NB * CH_NB; }
+
+// in-place Cholesky of the lower triangle of ctx->H (ld = hess_ld(n)); *info (device) = 0 or 1 + the first block
+// column with a non-positive pivot
+int launch_cholesky(cfmm_ctx *ctx, int n)
+{
+    const int ld = hess_ld(n);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->sm_info, 0, sizeof(int), ctx->stream));
+    for (int k0 = 0; k0 < ld; k0 += CH_NB) {
+        const int below = n - k0 - CH_NB;
+        const int wgs = below > 0 ? (below + 63) / 64 : 1;
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(wgs), dim3(64), 0, ctx->stream, ctx->H, ld, n, k0, ctx->sm_info);
+        if (below > 0) {
+            const int T = (below + 63) / 64;
+            hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, ctx->stream, ctx->H, ld, n, k0);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return CFMM_OK;
+}
+
+int launch_chol_solve(cfmm_ctx *ctx, int n, double *rhs)
+{
+    const int ld = hess_ld(n);
+    hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(CH_SOLVE_THREADS), (size_t)(ld + CH_NB) * sizeof(double), ctx->stream,
+                       (const double *)ctx->H, ld, n, rhs);
+    HIP_TRY(ctx, hipGetLastError());
+    return CFMM_OK;
+}
+
+bool newton_supported(cfmm_ctx *ctx, const char **why)
+{
+    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k)
+        if (ctx->pools->bn[k].m) { *why = "k-asset pools are present (the smoothed evaluation covers two-asset pools)"; return false; }
+    if (ctx->ng != ctx->n) { *why = "price ties are set"; return false; }
+    if (ctx->comm && ctx->n_ranks > 1) { *why = "the pools are sharded over several ranks"; return false; }
+    if ((size_t)(2 * ctx->n + 32) * sizeof(double) > 160 * 1024) { *why = "too many tokens for the LDS tile"; return false; }
+    *why = "";
+    return true;
+}
+
+bool near_linear_pools(cfmm_ctx *ctx) { return ctx->pools->b2[CFMM_POOL_SUM2].m + ctx->pools->b2[CFMM_POOL_CURVE2].m > 0; }
+
+int smooth_buffers(cfmm_ctx *ctx, bool hess)
+{
+    const int n = ctx->n;
+    if (!ctx->sm_out) {
+        int rc = dev_upload<double>(ctx, &ctx->sm_out, nullptr, n + 4, nullptr); if (rc) return rc;
+        rc = dev_upload<double>(ctx, &ctx->sm_vec, nullptr, 2 * (size_t)n + 4, nullptr); if (rc) return rc;
+        rc = dev_upload<int>(ctx, &ctx->sm_mask, nullptr, n + 4, nullptr); if (rc) return rc;
+        const size_t lds = (size_t)(2 * n + 32) * sizeof(double);
+        if ((rc = set_lds_attr(ctx, smooth_kernel<false>, lds))) return rc;
+        if ((rc = set_lds_attr(ctx, smooth_kernel<true>, lds))) return rc;
+    }
+    if (hess && !ctx->H) {
+        const size_t ld = hess_ld(n);
+        int rc = dev_upload<double>(ctx, &ctx->H, nullptr, ld * ld, nullptr); if (rc) return rc;
+        rc = dev_upload<int>(ctx, &ctx->sm_info, nullptr, 4, nullptr); if (rc) return rc;
+        if ((rc = set_lds_attr(ctx, chol_solve_kernel, (ld + CH_NB) * sizeof(double)))) return rc;
+    }
+    return CFMM_OK;
+}
+
+// one smoothed evaluation at the prices already in ctx->nu (device)
+int launch_smooth(cfmm_ctx *ctx, double mu, bool hess)
+{
+    const int n = ctx->n;
+    SmoothArgs a = {};
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) a.b2[k] = ctx->pools->b2[k];
+    a.b2[CFMM_POOL_SUM2].flags = ctx->flags2;
+    const int order[4] = {CFMM_POOL_CURVE2, CFMM_POOL_W2, CFMM_POOL_CP2, CFMM_POOL_SUM2};
+    long long tiles = 0;
+    for (int q = 0; q < 4; ++q) { tiles += (a.b2[order[q]].m + 63) / 64; a.tile_end[q] = (int)tiles; }
+    a.ntiles = (int)tiles; a.n = n; a.nu = ctx->nu; a.mu = mu; a.out = ctx->sm_out; a.H = hess ? ctx->H : nullptr; a.ldh = hess_ld(n);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->sm_out, 0, (size_t)(n + 2) * sizeof(double), ctx->stream));
+    if (hess) HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, (size_t)hess_ld(n) * hess_ld(n) * sizeof(double), ctx->stream));
+    const int per_block = SMOOTH_THREADS / 64;
+    long long grid = (tiles + per_block - 1) / per_block;
+    if (grid > 2LL * ctx->cus) grid = 2LL * ctx->cus;
+    if (grid < 1) grid = 1;
+    const size_t lds = (size_t)(2 * n + 32) * sizeof(double);
+    if (hess) hipLaunchKernelGGL(smooth_kernel<true>, dim3((unsigned)grid), dim3(SMOOTH_THREADS), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(smooth_kernel<false>, dim3((unsigned)grid), dim3(SMOOTH_THREADS), lds, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return CFMM_OK;
+}
+
+struct SmoothEval { std::vector<double> psi; double value = 0.0, trade = 0.0; };
+
+int smooth_eval_host(cfmm_ctx *ctx, const std::vector<double> &nu, double mu, bool hess, SmoothEval &e)
+{
+    const int n = ctx->n;
+    int rc = smooth_buffers(ctx, hess); if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, nu.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_smooth(ctx, mu, hess))) return rc;
+    e.psi.resize(n + 2);
+    HIP_TRY(ctx, hipMemcpyAsync(e.psi.data(), ctx->sm_out, (size_t)(n + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    e.value = e.psi[n]; e.trade = e.psi[n + 1];
+    e.psi.resize(n);
+    return CFMM_OK;
+}
+
+int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_before)
+{
+    const char *why = "";
+    if (!newton_supported(ctx, &why)) return fail(ctx, CFMM_E_UNSUPPORTED, "solve: the second-order method cannot take this problem: %s", why);
+    const int n = ctx->n;
+    int rc = smooth_buffers(ctx, true); if (rc) return rc;
+    const std::vector<double> &c = ctx->hc, &h = ctx->hh;
+    const std::vector<int> &ct = ctx->hctype;
+
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+
+    std::vector<double> s(n), nu(n), d(n), G(n), Hd(n), rhs(n), s2(n), nu2(n), psi_x(n);
+    std::vector<int> mask(n);
+    HIP_TRY(ctx, hipMemcpyAsync(nu.data(), ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    long long nbar = 0;
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) nbar += 2 * ctx->pools->b2[k].m;
+    nbar += 2 * ctx->pools->b2[CFMM_POOL_SUM2].m;
+    for (int j = 0; j < n; ++j) {
+        mask[j] = ct[j] == CFMM_FREE;
+        if (ct[j] == CFMM_GE) nbar += 1;
+        double sj = std::log(nu[j]);
+        if (ct[j] == CFMM_FREE) {
+            if (!(c[j] > 0.0)) return fail(ctx, CFMM_E_ARG, "solve: token %d is unconstrained (CFMM_FREE) with c = 0: unbounded", j);
+            sj = std::log(c[j]);
+        } else if (ct[j] == CFMM_GE && c[j] > 0.0) sj = std::max(sj, std::log(c[j]) + 1e-3);      // strictly inside nu > c
+        s[j] = sj; nu[j] = std::exp(sj);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, mask.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+
+    int evals = evals_before, steps = 0, status = 0;
+    double arb_x = 0.0;
+    auto exact = [&](const std::vector<double> &p) { ++evals; return cfmm_eval_dual(ctx, p.data(), &arb_x, psi_x.data(), nullptr); };
+    // smoothed dual value and its gradient in log-prices at (s, nu) from one smoothed evaluation
+    auto assemble = [&](const std::vector<double> &p, const SmoothEval &e, double mu, std::vector<double> *grad, std::vector<double> *hdiag) {
+        double g = e.value;
+        for (int j = 0; j < n; ++j) {
+            g += (p[j] - c[j]) * h[j];
+            double Gj = p[j] * (e.psi[j] + h[j]), hj = 0.0;
+            if (ct[j] == CFMM_GE) {
+                const double slack = p[j] - c[j];
+                g -= mu * std::log(slack);
+                Gj -= mu * p[j] / slack;
+                hj = mu * p[j] * c[j] / (slack * slack);
+            }
+            if (grad) (*grad)[j] = mask[j] ? 0.0 : Gj;
+            if (hdiag) (*hdiag)[j] = std::max(Gj, 0.0) + hj;
+        }
+        return g;
+    };
+
+    if ((rc = exact(nu))) return rc;
+    double dual = arb_x;
+    for (int j = 0; j < n; ++j) dual += (nu[j] - c[j]) * h[j];
+    double mu = 0.1 * std::max(std::fabs(dual), 1e-300) / (double)std::max<long long>(nbar, 1);
+    const double sigma = (o.barrier_shrink > 0.0 && o.barrier_shrink < 1.0) ? o.barrier_shrink : 0.2;
+    const int max_newton = o.max_newton > 0 ? o.max_newton : 200;
+    double gap = 1.0, infeas = 1.0, primal = 0.0, reg = 0.0;
+    SmoothEval e, e2;
+    for (;;) {
+        if ((rc = smooth_eval_host(ctx, nu, mu, true, e))) return rc;
+        ++evals;
+        const double gmu = assemble(nu, e, mu, &G, &Hd);
+        if (!std::isfinite(gmu)) { status = CFMM_E_NUMERIC; break; }
+        // certificates: exact dual value (an upper bound) against the smoothed, pool-feasible primal point
+        if (steps > 0 && (rc = exact(nu))) return rc;
+        dual = arb_x; primal = 0.0;
+        double cs = 0.0, viol = 0.0, scale = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double r = e.psi[j] + h[j];
+            dual += (nu[j] - c[j]) * h[j];
+            primal += c[j] * e.psi[j];
+            cs += (nu[j] - c[j]) * r;
+            viol = std::max(viol, ct[j] == CFMM_GE ? std::max(-r, 0.0) : (ct[j] == CFMM_EQ ? std::fabs(r) : 0.0));
+            scale = std::max(scale, std::max(std::fabs(e.psi[j]), std::fabs(h[j])));
+        }
+        gap = ((arb_x - e.trade) + cs) / std::max(1.0, std::fabs(dual));
+        infeas = viol / std::max(scale, 1e-300);
+        if (std::fabs(gap) <= o.tol_gap && infeas <= o.tol_infeas) { status = 1; break; }
+        if (steps >= max_newton || evals - evals_before >= o.max_evals) { status = 3; break; }
+
+        // Newton direction: (H + diag) d = -G on the unpinned tokens
+        for (int j = 0; j < n; ++j) { rhs[j] = -G[j]; Hd[j] += reg; }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, Hd.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec + n, rhs.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, hess_ld(n), (const double *)ctx->sm_vec, (const int *)ctx->sm_mask);
+        HIP_TRY(ctx, hipGetLastError());
+        if ((rc = launch_cholesky(ctx, n))) return rc;
+        int info = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&info, ctx->sm_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (info != 0) {                       // not positive definite: shift the diagonal and assemble again
+            double md = 0.0;
+            for (int j = 0; j < n; ++j) md = std::max(md, Hd[j]);
+            reg = reg == 0.0 ? 1e-12 * std::max(md, 1e-300) : reg * 100.0;
+            if (!(reg < 1e300)) { status = CFMM_E_NUMERIC; break; }
+            continue;
+        }
+        if ((rc = launch_chol_solve(ctx, n, ctx->sm_vec + n))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(d.data(), ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ++steps;
+        reg = 0.0;
+        double dec = 0.0, dmax = 0.0;
+        for (int j = 0; j < n; ++j) { if (mask[j]) d[j] = 0.0; dec -= G[j] * d[j]; dmax = std::max(dmax, std::fabs(d[j])); }
+        if (!std::isfinite(dec) || !std::isfinite(dmax)) { status = CFMM_E_NUMERIC; break; }
+        // step length: cap on the log-price move, fraction to the boundary nu > c, Armijo back-tracking on the smoothed dual
+        double t = std::min(1.0, o.max_step / std::max(dmax, 1e-300));
+        for (int j = 0; j < n; ++j)
+            if (ct[j] == CFMM_GE && c[j] > 0.0 && d[j] < 0.0) t = std::min(t, 0.9 * (s[j] - std::log(c[j])) / -d[j]);
+        const double t_first = t;
+        bool moved = false;
+        for (int ls = 0; ls < 40; ++ls) {
+            for (int j = 0; j < n; ++j) { s2[j] = s[j] + t * d[j]; nu2[j] = mask[j] ? nu[j] : std::exp(s2[j]); }
+            if ((rc = smooth_eval_host(ctx, nu2, mu, false, e2))) return rc;
+            ++evals;
+            const double g2 = assemble(nu2, e2, mu, nullptr, nullptr);
+            if (g2 <= gmu - o.armijo * t * dec || dec <= 1e-13 * std::fabs(gmu)) { moved = true; break; }
+            t *= 0.5;
+        }
+        if (!moved) { status = 2; break; }
+        s = s2; nu = nu2;
+        if (std::fabs(gap) <= o.tol_gap) continue;                     // the gap is there: finish centring at this weight
+        if (dec < 10.0 * mu * (double)nbar && (t == t_first || dec < 1e-3 * mu * (double)nbar)) mu *= sigma;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+    // leave the solution where the read-backs expect it: prices, the smoothed psi, the barrier weight for the tenders
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu_acc, nu.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if ((int)e.psi.size() == n) HIP_TRY(ctx, hipMemcpyAsync(ctx->psi_acc, e.psi.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(ctx->hsol, nu.data(), n * sizeof(double));
+    if ((int)e.psi.size() == n) std::memcpy(ctx->hsol + n, e.psi.data(), n * sizeof(double));
+    ctx->hsol_valid = true; ctx->have_nu = true;
+    ctx->mu_last = mu;
+    const auto t1 = std::chrono::steady_clock::now();
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+    std::memset(out, 0, sizeof *out);
+    out->evals = evals; out->iters = steps; out->status = status;
+    out->n_ranks = ctx->n_ranks;
+    out->dual_value = dual; out->primal_value = primal; out->gap = gap; out->infeas = infeas;
+    out->wall_seconds = std::chrono::duration<double>(t1 - t0).count();
+    out->device_seconds = ms * 1e-3;
+    out->pool_subproblems = (int64_t)evals * cfmm_pool_count(ctx);
+    out->barrier_mu = mu; out->newton_steps = steps; out->method = CFMM_METHOD_NEWTON;
+    if (status == CFMM_E_NUMERIC) return fail(ctx, CFMM_E_NUMERIC, "solve: non-finite value in the second-order iteration");
+    return CFMM_OK;
+}
+
+}  // namespace
+
 // =================================================================================== C-ABI
 
 extern "C" {
@@ -375,6 +649,7 @@ void cfmm_default_opts(cfmm_opts *o)
     std::memset(o, 0, sizeof *o);
     o->tol_gap = 1e-6; o->tol_infeas = 1e-6; o->armijo = 1e-4; o->max_step = 2.0;
     o->max_evals = 2000; o->memory = 0; o->iters_per_graph = 4;
+    o->method = CFMM_METHOD_AUTO; o->max_newton = 200; o->barrier_shrink = 0.2;
     if (const char *s = getenv("CFMM_ITERS_PER_GRAPH")) o->iters_per_graph = std::max(1, atoi(s));     // tuning knob
 }
 
@@ -480,6 +755,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     ctx->pools.reset();
     if (ctx->flags2) (void)hipFree(ctx->flags2);
     if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
+    for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
     void *ptrs[] = {ctx->c, ctx->h, ctx->off, ctx->glo, ctx->ghi, ctx->ctype, ctx->grp, ctx->nu, ctx->nu_acc, ctx->psi_acc,
                     ctx->psi_t, ctx->nu0, ctx->s, ctx->s_t, ctx->Gs, ctx->Gs_t, ctx->d, ctx->Ds, ctx->S, ctx->Y, ctx->rho,
                     ctx->acc, ctx->st, ctx->ts};
@@ -651,7 +927,7 @@ int cfmm_set_nu(cfmm_ctx *ctx, const double *nu)
     for (int j = 0; j < ctx->n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "set_nu: nu[%d] = %g is not a positive finite price", j, nu[j]);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu_acc, nu, ctx->n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the caller's (pageable) buffer may go away after we return
-    ctx->have_nu = true; ctx->hsol_valid = false;
+    ctx->have_nu = true; ctx->hsol_valid = false; ctx->mu_last = 0.0;
     return CFMM_OK;
 }
 
@@ -715,6 +991,54 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
     return CFMM_OK;
 }
 
+int cfmm_debug_cholesky(cfmm_ctx *ctx, int n, const double *A, const double *b, double *x, int32_t *info)
+{
+    if (!ctx || !A || !b || !x || n != ctx->n) return ctx ? fail(ctx, CFMM_E_ARG, "debug_cholesky: n must equal the context's token count") : CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = smooth_buffers(ctx, true); if (rc) return rc;
+    const int ld = hess_ld(n);
+    std::vector<double> hd(n, 0.0);
+    std::vector<int> mask(n, 0);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, (size_t)ld * ld * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->H, (size_t)ld * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, hd.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec + n, b, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, mask.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, ld, (const double *)ctx->sm_vec, (const int *)ctx->sm_mask);
+    if ((rc = launch_cholesky(ctx, n))) return rc;
+    if ((rc = launch_chol_solve(ctx, n, ctx->sm_vec + n))) return rc;
+    int inf = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&inf, ctx->sm_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(x, ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (info) *info = inf;
+    return CFMM_OK;
+}
+
+int cfmm_eval_smooth(cfmm_ctx *ctx, const double *nu, double mu, double *value, double *trade, double *psi, double *H)
+{
+    if (!ctx || !nu || !(mu > 0.0)) return ctx ? fail(ctx, CFMM_E_ARG, "eval_smooth: nu is NULL or mu <= 0") : CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const char *why = "";
+    if (!newton_supported(ctx, &why)) return fail(ctx, CFMM_E_UNSUPPORTED, "eval_smooth: %s", why);
+    const int n = ctx->n;
+    for (int j = 0; j < n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "eval_smooth: nu[%d] = %g is not a positive finite price", j, nu[j]);
+    SmoothEval e;
+    std::vector<double> p(nu, nu + n);
+    int rc = smooth_eval_host(ctx, p, mu, H != nullptr, e); if (rc) return rc;
+    if (value) *value = e.value;
+    if (trade) *trade = e.trade;
+    if (psi) std::memcpy(psi, e.psi.data(), n * sizeof(double));
+    if (H) {
+        HIP_TRY(ctx, hipMemcpy2DAsync(H, (size_t)n * sizeof(double), ctx->H, (size_t)hess_ld(n) * sizeof(double), (size_t)n * sizeof(double), n,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return CFMM_OK;
+}
+
+static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out);
+
 int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_stats *out)
 {
     if (!ctx || !out) return CFMM_E_ARG;
@@ -724,11 +1048,32 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     if (o.memory == 0) o.memory = ctx->n <= 32 ? 8 : 4;      // auto: tiny problems afford (nearly) full quasi-Newton memory
     if (o.memory < 1 || o.memory > MAX_MEMORY || o.iters_per_graph < 1 || o.iters_per_graph > 256 || o.max_evals < 1)
         return fail(ctx, CFMM_E_ARG, "solve: memory %d, iters_per_graph %d, max_evals %d", o.memory, o.iters_per_graph, o.max_evals);
+    if (o.method < CFMM_METHOD_AUTO || o.method > CFMM_METHOD_NEWTON) return fail(ctx, CFMM_E_ARG, "solve: method %d", o.method);
     if (!ctx->have_utility) return fail(ctx, CFMM_E_STATE, "solve: cfmm_set_utility has not been called");
     if (cfmm_pool_count(ctx) == 0) return fail(ctx, CFMM_E_STATE, "solve: no pools uploaded");
-    const int n = ctx->n;
     if (nu0) { int rc = cfmm_set_nu(ctx, nu0); if (rc) return rc; }
     if (!ctx->have_nu) return fail(ctx, CFMM_E_STATE, "solve: no start prices (pass nu0 or call cfmm_set_nu)");
+    const char *why = "";
+    const bool can_newton = newton_supported(ctx, &why);
+    if (o.method == CFMM_METHOD_NEWTON || (o.method == CFMM_METHOD_AUTO && can_newton && near_linear_pools(ctx) && !o.pg_rule))
+        return solve_newton(ctx, o, out, 0);
+    cfmm_opts ol = o;
+    ol.method = 0; ol.max_newton = 0; ol.barrier_shrink = 0.0;            // (not part of the captured iteration: keep the graph cache key stable)
+    int rc = solve_lbfgs(ctx, ol, out);
+    if (rc || o.method == CFMM_METHOD_LBFGS || out->status == 1 || !can_newton || o.pg_rule) return rc;
+    // first order ended without its certificates: hand the prices it reached to the second-order method
+    const cfmm_stats first = *out;
+    cfmm_opts o2 = o;
+    o2.max_evals = std::max(1, o.max_evals - first.evals);
+    rc = solve_newton(ctx, o2, out, first.evals);
+    out->wall_seconds += first.wall_seconds; out->device_seconds += first.device_seconds;
+    return rc;
+}
+
+static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out)
+{
+    const int n = ctx->n;
+    ctx->mu_last = 0.0;
     // Single GPU: `iters_per_graph` iterations are replayed from one captured hipGraph.  Pool-sharded
     // (RCCL all-reduce inside every iteration): the same iterations are enqueued eagerly, the way RCCL
     // is conventionally driven (CFMM_MULTI_GRAPH=1 opts into capturing them too).
@@ -781,6 +1126,7 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     out->device_seconds = ms * 1e-3;
     out->pg = st.pg;
     out->pool_subproblems = (int64_t)st.evals * cfmm_pool_count(ctx);
+    out->method = CFMM_METHOD_LBFGS;
     if (!std::isfinite(st.f)) { out->status = CFMM_E_NUMERIC; return fail(ctx, CFMM_E_NUMERIC, "solve: dual value is not finite"); }
     return CFMM_OK;
 }
@@ -795,6 +1141,15 @@ int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda)
     double *dd = nullptr, *dl = nullptr;
     { int rc = trade_scratch(ctx, 2 * (size_t)b.m, &dd, &dl); if (rc) return rc; }
     const dim3 grid((unsigned)((b.m + 255) / 256)), blk(256);
+    if (ctx->mu_last > 0.0) {              // after a second-order solve: the smoothed primal point
+        const double mu = ctx->mu_last;
+        switch (kind) {
+        case 0: hipLaunchKernelGGL(smooth_trades_kernel<0>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, mu, dd, dl); break;
+        case 1: hipLaunchKernelGGL(smooth_trades_kernel<1>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, mu, dd, dl); break;
+        case 2: hipLaunchKernelGGL(smooth_trades_kernel<2>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, mu, dd, dl); break;
+        default: hipLaunchKernelGGL(smooth_trades_kernel<3>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, mu, dd, dl); break;
+        }
+    } else
     switch (kind) {
     case 0: hipLaunchKernelGGL(trades2_kernel<0>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;
     case 1: hipLaunchKernelGGL(trades2_kernel<1>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;

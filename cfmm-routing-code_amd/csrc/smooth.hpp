@@ -1,0 +1,276 @@
+// Barrier-smoothed pool subproblems and the dense dual Hessian: the second-order outer iteration
+// for networks of near-linear pools (constant sum, stableswap near its peg -- BASELINE config 5),
+// where the dual is almost piecewise linear and the projected quasi-Newton iteration crawls.
+// gfx950 only.
+//
+// The reference hands the whole program to a primal-dual interior-point solver (cp.Problem.solve(),
+// /root/reference/arbitrage.py:81-82).  Here the same log-barrier is put on the sign constraints
+// Delta, Lambda >= 0 (arbitrage.py:51-52) *inside* the dual decomposition: for prices nu and a
+// barrier weight mu every two-asset pool splits into two one-directional trades, each the 1-D problem
+//
+//     arb_mu(nu) = max_{D > 0}  nu_out L(D) - nu_in D + mu log D          L = forward exchange function,
+//
+// L(D) = R_out - Y(R_in + gamma D) on the pool's level set (arbitrage.py:60,63-74).  Its optimum is
+// interior, so arb_mu is smooth in nu, with gradient (-D, L) and the rank-one Hessian
+//     kappa (1, -L')(1, -L')',   kappa = 1 / (mu / D^2 - nu_out L''(D)).
+// One launch solves both directions of every pool, scatter-adds psi_mu = sum (L - D) through an LDS
+// tile (as the exact evaluation kernel does) and, when asked, the n x n Hessian in log-prices through
+// global fp64 atomics (three per pool: two diagonal entries and the lower off-diagonal one).
+#pragma once
+#include "kernels.hpp"
+
+namespace cfmm {
+
+struct Fwd { double L, L1, L2; };       // L(D), L'(D), L''(D)
+
+__device__ __forceinline__ double curve_y_stable(double x, double C, double al)
+{
+    const double b = C - x, q = 4.0 * al / x;
+    const double sq = sqrt(fma(b, b, q));
+    return b >= 0.0 ? 0.5 * (b + sq) : 0.5 * q / (sq - b);
+}
+
+// KIND 0 constant product | 1 weighted (r = w_in / w_out) | 3 stableswap (r = alpha, C = level)
+template <int KIND>
+__device__ __forceinline__ Fwd fwd2(double D, double Rin, double Rout, double g, double r, double C)
+{
+    Fwd o;
+    const double x = fma(g, D, Rin);
+    if (KIND == 0) {
+        const double ix = 1.0 / x;
+        const double gy = g * Rout * ix;                   // gamma y / ... : L = gamma D R_out / x  (no cancellation)
+        o.L = D * gy;
+        o.L1 = gy * Rin * ix;                              // gamma k / x^2
+        o.L2 = -2.0 * g * o.L1 * ix;
+    } else if (KIND == 1) {
+        const double ix = 1.0 / x;
+        const double lq = -r * log1p(g * D / Rin);         // log (R_in / x)^r
+        const double q = exp(lq);
+        o.L = -Rout * expm1(lq);
+        o.L1 = g * Rout * r * q * ix;
+        o.L2 = -g * (r + 1.0) * o.L1 * ix;
+    } else {
+        const double al = r;
+        const double y = curve_y_stable(x, C, al);
+        const double ixy = 1.0 / (x * y);
+        const double t = al * ixy;                         // alpha / (x y)
+        const double fx = 1.0 + t / x, fy = 1.0 + t / y;
+        const double y1 = -fx / fy;
+        const double fxx = -2.0 * t / (x * x), fxy = -t * ixy, fyy = -2.0 * t / (y * y);
+        const double y2 = -(fxx + 2.0 * fxy * y1 + fyy * y1 * y1) / fy;
+        o.L = Rout - y;
+        o.L1 = -g * y1;
+        o.L2 = -g * g * y2;
+    }
+    return o;
+}
+
+struct Branch { double D, L, L1, kappa, val; };
+
+// root of  a D^2 + b D + mu = 0  (a < 0, mu > 0) in D > 0, without cancellation
+__device__ __forceinline__ double barrier_root(double a, double b, double mu)
+{
+    const double rt = sqrt(fma(b, b, -4.0 * a * mu));
+    return b > 0.0 ? (b + rt) / (-2.0 * a) : 2.0 * mu / (rt - b);
+}
+
+// one direction of a two-asset pool: tender `in`, receive `out`.  Safeguarded iteration on
+//     F(D) = A(D) + mu / D = 0,   A(D) = nu_out L'(D) - nu_in  (decreasing),
+// each step linearises A only and keeps the barrier term exact (one step is exact whenever A is locally
+// linear, in particular deep inside the no-trade band where D ~ mu / |A|); a step is taken only if it
+// lands inside the bracket and at least halves the previous one, otherwise the bracket is bisected
+// (the stableswap A is flat, then falls off a knee: plain Newton cycles across it).
+template <int KIND>
+__device__ __forceinline__ Branch smooth_branch(double Rin, double Rout, double g, double r, double C,
+                                                double ni, double no, double mu)
+{
+    Branch o;
+    double D;
+    {
+        double De = 0.0;
+        if (KIND == 0) De = (sqrt(g * no * Rin * Rout / ni) - Rin) / g;
+        if (KIND == 1) De = Rin * expm1(log(g * no * Rout * r / (ni * Rin)) / (r + 1.0)) / g;
+        if (De > 0.0) D = De;
+        else {
+            const Fwd f0 = fwd2<KIND>(0.0, Rin, Rout, g, r, C);
+            D = barrier_root(fmin(no * f0.L2, -1e-300), no * f0.L1 - ni, mu);
+        }
+    }
+    double lo = 0.0, hi = 1.7976931348623157e308, dprev = 1.7976931348623157e308;
+    for (int it = 0; it < 120; ++it) {
+        const Fwd f = fwd2<KIND>(D, Rin, Rout, g, r, C);
+        const double A = no * f.L1 - ni, A1 = fmin(no * f.L2, -1e-300);
+        const double F = A + mu / D;
+        if (F > 0.0) lo = D; else hi = D;
+        double Dn = barrier_root(A1, A - A1 * D, mu);
+        const double stepc = fabs(Dn - D);
+        const bool conv = stepc <= 1e-13 * fmax(Dn, D);
+        const bool ok = conv || (Dn > lo && Dn < hi && stepc < 0.5 * dprev);
+        if (!ok) Dn = hi < 1e308 ? 0.5 * (lo + hi) : 2.0 * D;
+        dprev = fabs(Dn - D);
+        D = Dn;
+        if (conv || dprev <= 1e-13 * D) break;
+    }
+    const Fwd f = fwd2<KIND>(D, Rin, Rout, g, r, C);
+    o.D = D; o.L = f.L; o.L1 = f.L1;
+    o.kappa = 1.0 / (mu / (D * D) - no * f.L2);
+    o.val = no * f.L - ni * D + mu * log(D);
+    return o;
+}
+
+// constant sum (arbitrage.py:73-74): L = gamma D with D <= R_out / gamma, a barrier on both ends:
+//     max  s D + mu log D + mu log(cap - D),  s = gamma nu_out - nu_in      closed form
+__device__ __forceinline__ Branch smooth_branch_sum(double Rout, double g, double ni, double no, double mu)
+{
+    Branch o;
+    const double cap = Rout / g, s = g * no - ni;
+    const double sc = s * cap;
+    const double disc = sqrt(fma(sc, sc, 4.0 * mu * mu));
+    const double b1 = sc - 2.0 * mu, b2 = -sc - 2.0 * mu;
+    const double D = b1 > 0.0 ? (b1 + disc) / (2.0 * s) : 2.0 * mu * cap / (disc - b1);
+    const double E = b2 > 0.0 ? (b2 + disc) / (-2.0 * s) : 2.0 * mu * cap / (disc - b2);     // cap - D
+    o.D = D; o.L = g * D; o.L1 = g;
+    o.kappa = 1.0 / (mu / (D * D) + mu / (E * E));
+    o.val = s * D + mu * (log(D) + log(E));
+    return o;
+}
+
+struct SmoothArgs {
+    Bucket2 b2[4];
+    int tile_end[4];            // cumulative wave-tiles (64 pools) in the order curve2, w2, cp2, sum2
+    int ntiles, n;
+    const double *nu;           // [n] prices
+    double mu;
+    double *out;                // [n] psi_mu | [n] sum of branch values | [n + 1] sum nu'(L - D)   (zeroed by the host)
+    double *H;                  // [n x n] column-major, lower triangle gets the pools' part (zeroed by the host); may be null
+    int ldh;
+};
+
+template <int KIND>
+__device__ __forceinline__ void smooth_pool(const Bucket2 &b, long long i, double pa, double pb, double mu,
+                                            Branch &ab, Branch &ba)
+{
+    const double Ra = b.Ra[i], Rb = b.Rb[i], g = b.fee[i];
+    if (KIND == 2) {
+        ab = smooth_branch_sum(Rb, g, pa, pb, mu);
+        ba = smooth_branch_sum(Ra, g, pb, pa, mu);
+    } else {
+        const double prm = KIND == 0 ? 0.0 : b.param[i];
+        const double C = KIND == 3 ? Ra + Rb - prm / (Ra * Rb) : 0.0;
+        const double rab = KIND == 1 ? prm / (1.0 - prm) : prm, rba = KIND == 1 ? (1.0 - prm) / prm : prm;
+        constexpr int K = KIND == 2 ? 0 : KIND;
+        ab = smooth_branch<K>(Ra, Rb, g, rab, C, pa, pb, mu);      // tender a, receive b
+        ba = smooth_branch<K>(Rb, Ra, g, rba, C, pb, pa, mu);      // tender b, receive a
+    }
+}
+
+template <int KIND, bool HESS>
+__device__ __forceinline__ void smooth_tile(const Bucket2 &b, long long i0, int lane, const double *nu_s, double *psi_s,
+                                            const SmoothArgs &a, double &vsum, double &tsum)
+{
+    long long i = i0 + lane;
+    const bool live = i < b.m && !(KIND == 2 && b.flags && b.flags[i]);
+    i = i < b.m ? i : b.m - 1;
+    const int ia = b.ia[i], ib = b.ib[i];
+    const double pa = nu_s[ia], pb = nu_s[ib];
+    Branch ab, ba;
+    smooth_pool<KIND>(b, i, pa, pb, a.mu, ab, ba);
+    if (!live) return;
+    const double ya = ba.L - ab.D, yb = ab.L - ba.D;
+    unsafeAtomicAdd(&psi_s[ia], ya);
+    unsafeAtomicAdd(&psi_s[ib], yb);
+    vsum += ab.val + ba.val;
+    tsum += pa * ya + pb * yb;
+    if (HESS) {
+        // in log-prices: branch ab moves (a, b) along (pa, -L1 pb), branch ba along (-L1 pa, pb)
+        const double u1 = pa, v1 = -ab.L1 * pb, u2 = -ba.L1 * pa, v2 = pb;
+        const double haa = ab.kappa * u1 * u1 + ba.kappa * u2 * u2;
+        const double hbb = ab.kappa * v1 * v1 + ba.kappa * v2 * v2;
+        const double hab = ab.kappa * u1 * v1 + ba.kappa * u2 * v2;
+        const int row = ia > ib ? ia : ib, col = ia > ib ? ib : ia;
+        unsafeAtomicAdd(&a.H[(size_t)ia * a.ldh + ia], haa);
+        unsafeAtomicAdd(&a.H[(size_t)ib * a.ldh + ib], hbb);
+        unsafeAtomicAdd(&a.H[(size_t)col * a.ldh + row], hab);
+    }
+}
+
+constexpr int SMOOTH_THREADS = 512;
+
+// LDS: psi_s[n] | nu_s[n] | red[2 * 8] | ticket
+template <bool HESS>
+__global__ void __launch_bounds__(SMOOTH_THREADS)
+smooth_kernel(SmoothArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = a.n;
+    double *psi_s = lds, *nu_s = lds + n, *red = lds + 2 * n;
+    int *next_tile = reinterpret_cast<int *>(red + 16);
+    if (threadIdx.x == 0) *next_tile = 0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) { nu_s[j] = a.nu[j]; psi_s[j] = 0.0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    double vsum = 0.0, tsum = 0.0;
+    int ticket = 0;
+    if (lane == 0) ticket = atomicAdd(next_tile, 1);
+    for (;;) {
+        const int t = blockIdx.x + gridDim.x * __builtin_amdgcn_readfirstlane(ticket);
+        if (t >= a.ntiles) break;
+        if (lane == 0) ticket = atomicAdd(next_tile, 1);
+        int bk = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bk += (t >= a.tile_end[q]) ? 1 : 0;
+        const long long i0 = (long long)(t - (bk ? a.tile_end[bk - 1] : 0)) * 64;
+        switch (bk) {
+        case 0: smooth_tile<3, HESS>(a.b2[3], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
+        case 1: smooth_tile<1, HESS>(a.b2[1], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
+        case 2: smooth_tile<0, HESS>(a.b2[0], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
+        default: smooth_tile<2, HESS>(a.b2[2], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
+        }
+    }
+    vsum = wave_allsum(vsum); tsum = wave_allsum(tsum);
+    if (lane == 0) { red[wib] = vsum; red[8 + wib] = tsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = 0.0, t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { v += red[w]; t += red[8 + w]; }
+        unsafeAtomicAdd(&a.out[n], v);
+        unsafeAtomicAdd(&a.out[n + 1], t);
+    }
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const double v = psi_s[j];
+        if (v != 0.0) unsafeAtomicAdd(&a.out[j], v);
+    }
+}
+
+// tenders of the smoothed solution, slot-major [2][m] like trades2_kernel: what cfmm_get_trades2 returns after a
+// second-order solve -- the primal point the certificates were computed on.  Both directions are (slightly) open,
+// so a pool both tenders and receives each token, as the reference's Delta_i, Lambda_i >= 0 allow (arbitrage.py:51-52).
+template <int KIND>
+__global__ void __launch_bounds__(256)
+smooth_trades_kernel(Bucket2 b, const double *__restrict__ nu, double mu, double *__restrict__ delta, double *__restrict__ lambda)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < b.m; i += (long long)gridDim.x * blockDim.x) {
+        Branch ab, ba;
+        ab.D = ab.L = ba.D = ba.L = 0.0;
+        if (!(KIND == 2 && b.flags && b.flags[i])) smooth_pool<KIND>(b, i, nu[b.ia[i]], nu[b.ib[i]], mu, ab, ba);
+        delta[i] = ab.D;   delta[b.m + i] = ba.D;
+        lambda[i] = ba.L;  lambda[b.m + i] = ab.L;
+    }
+}
+
+// H <- H + diag(hd), rows / columns of the pinned tokens (mask != 0) and of the padding (>= n, up to ld)
+// replaced by the identity.  Only the lower triangle is referenced by the factorisation.
+__global__ void __launch_bounds__(256)
+hess_finish_kernel(double *__restrict__ H, int n, int ldh, const double *__restrict__ hd, const int *__restrict__ mask)
+{
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < (long long)ldh * ldh; e += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(e % ldh), col = (int)(e / ldh);
+        if (row < col) continue;
+        double v;
+        if (row >= n || col >= n || mask[row] || mask[col]) v = row == col ? 1.0 : 0.0;
+        else v = H[(size_t)col * ldh + row] + (row == col ? hd[row] : 0.0);
+        H[(size_t)col * ldh + row] = v;
+    }
+}
+
+}  // namespace cfmm

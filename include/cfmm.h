@@ -38,7 +38,17 @@ enum {
     CFMM_E_STATE = -3,      /* call order (e.g. solve before upload)          */
     CFMM_E_LIMIT = -4,      /* size beyond what this build supports           */
     CFMM_E_RCCL = -5,       /* an RCCL call failed                            */
-    CFMM_E_NUMERIC = -6     /* non-finite value met during the iteration      */
+    CFMM_E_NUMERIC = -6,    /* non-finite value met during the iteration      */
+    CFMM_E_UNSUPPORTED = -7 /* the requested method cannot take this problem  */
+};
+
+/* outer iteration of cfmm_solve */
+enum {
+    CFMM_METHOD_AUTO = 0,       /* second order when the network holds constant-sum / stableswap pools and only
+                                   two-asset pools (the near-linear case the first-order iteration crawls on), else
+                                   first order; a first-order run that ends without its certificates is handed on  */
+    CFMM_METHOD_LBFGS = 1,      /* projected L-BFGS in log-prices, fully on-device (hipGraph)                       */
+    CFMM_METHOD_NEWTON = 2      /* barrier-smoothed dual Newton: dense n x n Hessian, blocked Cholesky on-device    */
 };
 
 /* two-asset pool families: one SoA bucket each (`param` = per-pool 4th column) */
@@ -64,6 +74,9 @@ typedef struct {
     int32_t iters_per_graph;/* outer iterations captured per hipGraph replay (4)                   */
     int32_t pg_rule;        /* 1: stop on the projected-gradient value <= tol_gap instead (used when
                                constant-sum pools are tied: psi then lacks their fill)           */
+    int32_t method;         /* CFMM_METHOD_*  (0 = auto)                                                            */
+    int32_t max_newton;     /* cap on second-order steps (200)                                                      */
+    double barrier_shrink;  /* factor applied to the barrier weight once a step lands near the central path (0.2)   */
 } cfmm_opts;
 
 typedef struct {
@@ -78,6 +91,10 @@ typedef struct {
     double device_seconds;  /* HIP events around the same region                                   */
     double pg;              /* sum |projected reduced gradient| / max(1,|g|)                       */
     int64_t pool_subproblems;   /* evals * pools on this rank                                      */
+    double barrier_mu;      /* final barrier weight of a second-order solve (0 after a first-order one): psi and the
+                               tenders read back are then those of the smoothed, strictly feasible primal point     */
+    int32_t newton_steps;   /* second-order steps taken (Hessian assemblies + Cholesky factorisations)             */
+    int32_t method;         /* CFMM_METHOD_LBFGS or CFMM_METHOD_NEWTON: what produced the result                    */
 } cfmm_stats;
 
 /* lifetime ------------------------------------------------------------------------------ */
@@ -114,6 +131,16 @@ int cfmm_set_ties(cfmm_ctx *ctx, int n_groups, const int32_t *grp, const double 
 /* one dual evaluation = every pool's subproblem once + the reduction:  psi(nu), sum_i arb_i,
  * optionally the diagonal metric.  This is the unit BASELINE.json's metric counts. */
 int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi, double *diag /* or NULL */);
+
+/* the barrier-smoothed evaluation behind CFMM_METHOD_NEWTON (two-asset pools only): every pool direction solves
+ *      max_{D > 0}  nu_out L(D) - nu_in D + mu log D        (constant sum: + mu log(R_out/gamma - D))
+ * value = sum of those optima, trade = sum nu'(L - D), psi[n] = sum A_i (L - D), and -- if H is not NULL -- the
+ * n x n Hessian of `value` in log-prices minus its diag(nu * psi) term, column-major, LOWER triangle only. */
+int cfmm_eval_smooth(cfmm_ctx *ctx, const double *nu, double mu, double *value, double *trade, double *psi, double *H);
+
+/* test hook: the dense Cholesky solve of the second-order method on a caller-supplied SPD system (A: n x n
+ * column-major, lower triangle read; n must equal the context's token count); *info != 0 flags a non-positive pivot */
+int cfmm_debug_cholesky(cfmm_ctx *ctx, int n, const double *A, const double *b, double *x, int32_t *info);
 
 /* prob.solve(): nu0 = start prices (NULL: use cfmm_set_nu / previous solution) */
 int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts, cfmm_stats *out);
