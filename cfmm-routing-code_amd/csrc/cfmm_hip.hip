@@ -130,7 +130,8 @@ struct cfmm_ctx {
     int n_ranks = 1, rank = 0;
 
     // second-order method (allocated on first use)
-    double *sm_out = nullptr, *sm_vec = nullptr, *H = nullptr;
+    double *sm_out = nullptr, *sm_vec = nullptr, *H = nullptr, *Dinv = nullptr;
+    double *sm_ws[CFMM_POOL_KINDS2] = {};   // warm starts of the smoothed per-direction solves
     int *sm_mask = nullptr, *sm_info = nullptr;
     double mu_last = 0.0;              // barrier weight of the last solve (0: first-order, exact tenders)
 };
@@ -384,32 +385,25 @@ extern "C" int64_t cfmm_pool_count(cfmm_ctx *ctx);
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-int hess_ld(int n) { return (n + CH_NB - 1) / CH_NB * CH_NB; }
+int hess_nr(int n) { return (n + CH_NB - 1) / CH_NB * CH_NB; }      // tokens rounded up to the Cholesky block
+int hess_ld(int n) { return hess_nr(n) + CH_NB; }                   // + the block row that carries the right-hand side
 
-// in-place Cholesky of the lower triangle of ctx->H (ld = hess_ld(n)); *info (device) = 0 or 1 + the first block
-// column with a non-positive pivot
-int launch_cholesky(cfmm_ctx *ctx, int n)
+// in-place Cholesky of the lower triangle of ctx->H with the right-hand side in row nr (chol.hpp), then the back
+// substitution into `x`; *sm_info (device) = 0 or 1 + the first block column with a non-positive pivot
+int launch_cholesky(cfmm_ctx *ctx, int n, double *x)
 {
-    const int ld = hess_ld(n);
+    const int nr = hess_nr(n), ld = hess_ld(n), nrows = nr + 1;
     HIP_TRY(ctx, hipMemsetAsync(ctx->sm_info, 0, sizeof(int), ctx->stream));
-    for (int k0 = 0; k0 < ld; k0 += CH_NB) {
-        const int below = n - k0 - CH_NB;
-        const int wgs = below > 0 ? (below + 63) / 64 : 1;
-        hipLaunchKernelGGL(chol_panel_kernel, dim3(wgs), dim3(64), 0, ctx->stream, ctx->H, ld, n, k0, ctx->sm_info);
-        if (below > 0) {
+    for (int k0 = 0; k0 < nr; k0 += CH_NB) {
+        const int below = nrows - k0 - CH_NB;
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(1 + (below + 63) / 64), dim3(256), 0, ctx->stream, ctx->H, ld, nrows, k0, ctx->Dinv, ctx->sm_info);
+        if (nr - k0 - CH_NB > 0) {
             const int T = (below + 63) / 64;
-            hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, ctx->stream, ctx->H, ld, n, k0);
+            hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, ctx->stream, ctx->H, ld, nrows, nr, k0);
         }
     }
-    HIP_TRY(ctx, hipGetLastError());
-    return CFMM_OK;
-}
-
-int launch_chol_solve(cfmm_ctx *ctx, int n, double *rhs)
-{
-    const int ld = hess_ld(n);
-    hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(CH_SOLVE_THREADS), (size_t)(ld + CH_NB) * sizeof(double), ctx->stream,
-                       (const double *)ctx->H, ld, n, rhs);
+    hipLaunchKernelGGL(chol_back_kernel, dim3(1), dim3(CH_SOLVE_THREADS), (size_t)(nr + CH_NB) * sizeof(double), ctx->stream,
+                       (const double *)ctx->H, ld, nr, n, (const double *)ctx->Dinv, x);
     HIP_TRY(ctx, hipGetLastError());
     return CFMM_OK;
 }
@@ -437,29 +431,33 @@ int smooth_buffers(cfmm_ctx *ctx, bool hess)
         const size_t lds = (size_t)(2 * n + 32) * sizeof(double);
         if ((rc = set_lds_attr(ctx, smooth_kernel<false>, lds))) return rc;
         if ((rc = set_lds_attr(ctx, smooth_kernel<true>, lds))) return rc;
+        for (int k : {CFMM_POOL_CP2, CFMM_POOL_W2, CFMM_POOL_CURVE2})
+            if (ctx->pools->b2[k].m) { rc = dev_upload<double>(ctx, &ctx->sm_ws[k], nullptr, 2 * (size_t)ctx->pools->b2[k].m, nullptr); if (rc) return rc; }
     }
     if (hess && !ctx->H) {
-        const size_t ld = hess_ld(n);
-        int rc = dev_upload<double>(ctx, &ctx->H, nullptr, ld * ld, nullptr); if (rc) return rc;
+        const size_t ld = hess_ld(n), nr = hess_nr(n);
+        int rc = dev_upload<double>(ctx, &ctx->H, nullptr, ld * nr, nullptr); if (rc) return rc;
+        rc = dev_upload<double>(ctx, &ctx->Dinv, nullptr, nr * CH_NB, nullptr); if (rc) return rc;
         rc = dev_upload<int>(ctx, &ctx->sm_info, nullptr, 4, nullptr); if (rc) return rc;
-        if ((rc = set_lds_attr(ctx, chol_solve_kernel, (ld + CH_NB) * sizeof(double)))) return rc;
+        if ((rc = set_lds_attr(ctx, chol_back_kernel, (nr + CH_NB) * sizeof(double)))) return rc;
     }
     return CFMM_OK;
 }
 
 // one smoothed evaluation at the prices already in ctx->nu (device)
-int launch_smooth(cfmm_ctx *ctx, double mu, bool hess)
+int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm)
 {
     const int n = ctx->n;
     SmoothArgs a = {};
     for (int k = 0; k < CFMM_POOL_KINDS2; ++k) a.b2[k] = ctx->pools->b2[k];
     a.b2[CFMM_POOL_SUM2].flags = ctx->flags2;
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) a.ws[k] = warm ? ctx->sm_ws[k] : nullptr;
     const int order[4] = {CFMM_POOL_CURVE2, CFMM_POOL_W2, CFMM_POOL_CP2, CFMM_POOL_SUM2};
     long long tiles = 0;
     for (int q = 0; q < 4; ++q) { tiles += (a.b2[order[q]].m + 63) / 64; a.tile_end[q] = (int)tiles; }
     a.ntiles = (int)tiles; a.n = n; a.nu = ctx->nu; a.mu = mu; a.out = ctx->sm_out; a.H = hess ? ctx->H : nullptr; a.ldh = hess_ld(n);
     HIP_TRY(ctx, hipMemsetAsync(ctx->sm_out, 0, (size_t)(n + 2) * sizeof(double), ctx->stream));
-    if (hess) HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, (size_t)hess_ld(n) * hess_ld(n) * sizeof(double), ctx->stream));
+    if (hess) HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, (size_t)hess_ld(n) * hess_nr(n) * sizeof(double), ctx->stream));
     const int per_block = SMOOTH_THREADS / 64;
     long long grid = (tiles + per_block - 1) / per_block;
     if (grid > 2LL * ctx->cus) grid = 2LL * ctx->cus;
@@ -473,12 +471,12 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess)
 
 struct SmoothEval { std::vector<double> psi; double value = 0.0, trade = 0.0; };
 
-int smooth_eval_host(cfmm_ctx *ctx, const std::vector<double> &nu, double mu, bool hess, SmoothEval &e)
+int smooth_eval_host(cfmm_ctx *ctx, const std::vector<double> &nu, double mu, bool hess, SmoothEval &e, bool warm = true)
 {
     const int n = ctx->n;
     int rc = smooth_buffers(ctx, hess); if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, nu.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = launch_smooth(ctx, mu, hess))) return rc;
+    if ((rc = launch_smooth(ctx, mu, hess, warm))) return rc;
     e.psi.resize(n + 2);
     HIP_TRY(ctx, hipMemcpyAsync(e.psi.data(), ctx->sm_out, (size_t)(n + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -540,6 +538,8 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         return g;
     };
 
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k)
+        if (ctx->sm_ws[k]) HIP_TRY(ctx, hipMemsetAsync(ctx->sm_ws[k], 0, 2 * (size_t)ctx->pools->b2[k].m * sizeof(double), ctx->stream));
     if ((rc = exact(nu))) return rc;
     double dual = arb_x;
     for (int j = 0; j < n; ++j) dual += (nu[j] - c[j]) * h[j];
@@ -547,26 +547,43 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     const double sigma = (o.barrier_shrink > 0.0 && o.barrier_shrink < 1.0) ? o.barrier_shrink : 0.2;
     const int max_newton = o.max_newton > 0 ? o.max_newton : 200;
     double gap = 1.0, infeas = 1.0, primal = 0.0, reg = 0.0;
+    const bool trace = getenv("CFMM_NEWTON_TRACE") != nullptr;
+    int stalled = 0;
     SmoothEval e, e2;
     for (;;) {
         if ((rc = smooth_eval_host(ctx, nu, mu, true, e))) return rc;
         ++evals;
         const double gmu = assemble(nu, e, mu, &G, &Hd);
         if (!std::isfinite(gmu)) { status = CFMM_E_NUMERIC; break; }
-        // certificates: exact dual value (an upper bound) against the smoothed, pool-feasible primal point
-        if (steps > 0 && (rc = exact(nu))) return rc;
-        dual = arb_x; primal = 0.0;
-        double cs = 0.0, viol = 0.0, scale = 0.0;
+        // certificates: exact dual value (an upper bound) against the smoothed, pool-feasible primal point.  Each
+        // barrier term costs at most mu of pool value, so sum_i arb_i(nu) <= nu'(L - D) + mu nbar: while that bound
+        // is still far from the tolerance the exact evaluation is skipped and the bound reported instead.
+        primal = 0.0;
+        double cs = 0.0, viol = 0.0, scale = 0.0, lin = 0.0;
         for (int j = 0; j < n; ++j) {
             const double r = e.psi[j] + h[j];
-            dual += (nu[j] - c[j]) * h[j];
+            lin += (nu[j] - c[j]) * h[j];
             primal += c[j] * e.psi[j];
             cs += (nu[j] - c[j]) * r;
             viol = std::max(viol, ct[j] == CFMM_GE ? std::max(-r, 0.0) : (ct[j] == CFMM_EQ ? std::fabs(r) : 0.0));
             scale = std::max(scale, std::max(std::fabs(e.psi[j]), std::fabs(h[j])));
         }
-        gap = ((arb_x - e.trade) + cs) / std::max(1.0, std::fabs(dual));
         infeas = viol / std::max(scale, 1e-300);
+        // sub = sum_i arb_i(nu) - nu'(L - D) >= 0 is the part of the gap the barrier weight controls (<= mu nbar);
+        // the rest, the complementarity term cs, vanishes with the centring.  The weight stops shrinking as soon as
+        // sub alone fits the tolerance: pushing it further only stiffens the smoothed dual (flows then react to price
+        // changes below fp64 resolution and the feasibility of psi_mu stops improving).
+        double sub = mu * (double)nbar;
+        dual = lin + e.trade + sub;
+        if (steps == 0 || sub <= 10.0 * o.tol_gap * std::max(1.0, std::fabs(dual))) {
+            if (steps > 0 && (rc = exact(nu))) return rc;
+            dual = lin + arb_x;
+            sub = std::max(arb_x - e.trade, 0.0);
+        }
+        gap = (sub + cs) / std::max(1.0, std::fabs(dual));
+        const bool final_mu = sub <= 0.5 * o.tol_gap * std::max(1.0, std::fabs(dual));
+        if (trace) fprintf(stderr, "[newton] step %d evals %d mu %.3e g_mu %.10g dual %.10g primal %.10g gap %.2e infeas %.2e reg %.1e\n",
+                           steps, evals, mu, gmu, dual, primal, gap, infeas, reg);
         if (std::fabs(gap) <= o.tol_gap && infeas <= o.tol_infeas) { status = 1; break; }
         if (steps >= max_newton || evals - evals_before >= o.max_evals) { status = 3; break; }
 
@@ -574,22 +591,21 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         for (int j = 0; j < n; ++j) { rhs[j] = -G[j]; Hd[j] += reg; }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, Hd.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec + n, rhs.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, hess_ld(n), (const double *)ctx->sm_vec, (const int *)ctx->sm_mask);
+        hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, hess_nr(n), hess_ld(n), (const double *)ctx->sm_vec,
+                           (const int *)ctx->sm_mask, (const double *)(ctx->sm_vec + n));
         HIP_TRY(ctx, hipGetLastError());
-        if ((rc = launch_cholesky(ctx, n))) return rc;
+        if ((rc = launch_cholesky(ctx, n, ctx->sm_vec + n))) return rc;
         int info = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&info, ctx->sm_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d.data(), ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (info != 0) {                       // not positive definite: shift the diagonal and assemble again
             double md = 0.0;
-            for (int j = 0; j < n; ++j) md = std::max(md, Hd[j]);
+            for (int j = 0; j < n; ++j) md = std::max(md, std::max(Hd[j], std::fabs(G[j])));
             reg = reg == 0.0 ? 1e-12 * std::max(md, 1e-300) : reg * 100.0;
             if (!(reg < 1e300)) { status = CFMM_E_NUMERIC; break; }
             continue;
         }
-        if ((rc = launch_chol_solve(ctx, n, ctx->sm_vec + n))) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(d.data(), ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ++steps;
         reg = 0.0;
         double dec = 0.0, dmax = 0.0;
@@ -609,9 +625,14 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             if (g2 <= gmu - o.armijo * t * dec || dec <= 1e-13 * std::fabs(gmu)) { moved = true; break; }
             t *= 0.5;
         }
+        if (trace) fprintf(stderr, "[newton]    dec %.3e |d| %.3e t %.3e (first %.3e) moved %d\n", dec, dmax, t, t_first, (int)moved);
         if (!moved) { status = 2; break; }
         s = s2; nu = nu2;
-        if (std::fabs(gap) <= o.tol_gap) continue;                     // the gap is there: finish centring at this weight
+        if (final_mu) {                                                // the weight is small enough: finish centring at it
+            stalled = (dec <= 1e-15 * std::max(1.0, std::fabs(gmu))) ? stalled + 1 : 0;
+            if (stalled >= 3) { status = 2; break; }                   // fp64 resolution of the prices reached
+            continue;
+        }
         if (dec < 10.0 * mu * (double)nbar && (t == t_first || dec < 1e-3 * mu * (double)nbar)) mu *= sigma;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
@@ -755,7 +776,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     ctx->pools.reset();
     if (ctx->flags2) (void)hipFree(ctx->flags2);
     if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
-    for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
     void *ptrs[] = {ctx->c, ctx->h, ctx->off, ctx->glo, ctx->ghi, ctx->ctype, ctx->grp, ctx->nu, ctx->nu_acc, ctx->psi_acc,
                     ctx->psi_t, ctx->nu0, ctx->s, ctx->s_t, ctx->Gs, ctx->Gs_t, ctx->d, ctx->Ds, ctx->S, ctx->Y, ctx->rho,
                     ctx->acc, ctx->st, ctx->ts};
@@ -999,14 +1020,14 @@ int cfmm_debug_cholesky(cfmm_ctx *ctx, int n, const double *A, const double *b, 
     const int ld = hess_ld(n);
     std::vector<double> hd(n, 0.0);
     std::vector<int> mask(n, 0);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, (size_t)ld * ld * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, (size_t)ld * hess_nr(n) * sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipMemcpy2DAsync(ctx->H, (size_t)ld * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, hd.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec + n, b, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, mask.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, ld, (const double *)ctx->sm_vec, (const int *)ctx->sm_mask);
-    if ((rc = launch_cholesky(ctx, n))) return rc;
-    if ((rc = launch_chol_solve(ctx, n, ctx->sm_vec + n))) return rc;
+    hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, hess_nr(n), ld, (const double *)ctx->sm_vec,
+                       (const int *)ctx->sm_mask, (const double *)(ctx->sm_vec + n));
+    if ((rc = launch_cholesky(ctx, n, ctx->sm_vec + n))) return rc;
     int inf = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&inf, ctx->sm_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(x, ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1025,7 +1046,7 @@ int cfmm_eval_smooth(cfmm_ctx *ctx, const double *nu, double mu, double *value, 
     for (int j = 0; j < n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "eval_smooth: nu[%d] = %g is not a positive finite price", j, nu[j]);
     SmoothEval e;
     std::vector<double> p(nu, nu + n);
-    int rc = smooth_eval_host(ctx, p, mu, H != nullptr, e); if (rc) return rc;
+    int rc = smooth_eval_host(ctx, p, mu, H != nullptr, e, false); if (rc) return rc;
     if (value) *value = e.value;
     if (trade) *trade = e.trade;
     if (psi) std::memcpy(psi, e.psi.data(), n * sizeof(double));

@@ -3,15 +3,20 @@
 // at this size the vendor path costs ~3.5 ms per factorisation (and minutes of one-time library
 // initialisation on a fresh box) where the problem is launch-latency bound at a few hundred microseconds.
 //
-// Layout: column-major, lower triangle, leading dimension ld = n rounded up to the block size (the
-// padding rows / columns carry an identity diagonal).  Right-looking, block size 32, two launches per
-// block column:
-//   chol_panel_kernel   every wave factors the 32 x 32 diagonal block itself, row-per-lane in registers
-//                       (cross-lane traffic through v_readlane: no LDS, no barrier), then solves its own
-//                       64 rows of the panel against it; wave 0 of workgroup 0 writes the factor back.
-//   chol_update_kernel  trailing update C_ij -= P_i P_j' on the lower 64 x 64 tiles, panel staged in LDS.
-// chol_solve_kernel: one workgroup, forward substitution in axpy form and backward substitution in dot
-// form, so that every pass over L reads contiguous columns.
+// Layout: column-major, lower triangle.  nr = n rounded up to the block size 32 (padding rows / columns
+// carry an identity diagonal); the right-hand side rides along as ONE EXTRA ROW at index nr, so the
+// factorisation forward-substitutes it for free (row nr of L is y = L^-1 b); ld = nr + 32.
+// Right-looking, two launches per block column:
+//   chol_panel_kernel   every workgroup (256 threads) factors the 32 x 32 diagonal block itself, operands in
+//                       registers, one column exchanged through LDS per elimination step, then solves its
+//                       own 64 rows of the panel against it column by column.  Workgroup 0 writes the factor
+//                       back and leaves the inverse of the diagonal block in `Dinv` for the back substitution.
+//                       (A one-wave variant with row-per-lane registers and v_readlane broadcasts needed no
+//                       barrier but issued ~3300 instructions from a single wave: 24 us per launch.)
+//   chol_update_kernel  trailing update C_ij -= P_i P_j' on the lower 64 x 64 tiles (C prefetched into
+//                       registers before the panel is staged in LDS).
+// chol_back_kernel: L' x = y, one workgroup, dot form (every pass over L reads contiguous columns: wave w
+// owns two columns of the block), the diagonal block applied as a 32 x 32 mat-vec with its inverse.
 #pragma once
 #include "kernels.hpp"
 
@@ -26,69 +31,85 @@ __device__ __forceinline__ double lane_bcast(double v, int l)        // l unifor
     return __hiloint2double(hi, lo);
 }
 
-// lanes r and r + 32 both hold row r of the diagonal block (a[c] = A[r][c], c <= r): in-register Cholesky.
-// Returns false on a non-positive pivot (the block is then garbage).
-__device__ __forceinline__ bool diag_factor(double (&a)[CH_NB], int r)
+// one block column: diagonal factor + panel solve, 256 threads, operands in registers, one LDS column
+// exchanged per elimination step (one barrier per step).  Workgroup 0 is the diagonal block's: it writes the
+// factor back and leaves the block's inverse in `Dinv` (row-major [i][c]) for the back substitution;
+// workgroup w >= 1 owns panel rows k0 + 32 + 64 (w - 1) .. + 63 and redoes the (cheap) factorisation itself
+// instead of waiting for another launch.
+__global__ void __launch_bounds__(256)
+chol_panel_kernel(double *__restrict__ A, int ld, int nrows, int k0, double *__restrict__ Dinv, int *__restrict__ info)
 {
-    bool ok = true;
+    __shared__ double Lc[CH_NB][CH_NB + 1];      // Lc[j][r]: column j of the block, rows r >= j (unscaled while factoring)
+    __shared__ double Xs[CH_NB][64 + 1];         // Xs[j][row]: solved column j of this workgroup's panel rows
+    __shared__ double piv[CH_NB];                // 1 / L[j][j]
+    const int tid = threadIdx.x;
+    // ---- factor.  thread (r, g) keeps the block's elements (r, c = g + 8 q), q = 0..3
+    {
+        const int r = tid & 31, g = tid >> 5;
+        double a[4];
 #pragma unroll
-    for (int j = 0; j < CH_NB; ++j) {
-        const double ajj = lane_bcast(a[j], j);
-        if (!(ajj > 0.0)) ok = false;
-        const double inv = 1.0 / sqrt(ajj > 0.0 ? ajj : 1.0);
-        a[j] = a[j] * inv;                                   // column j final (lane j: sqrt(ajj))
+        for (int q = 0; q < 4; ++q) { const int c = g + 8 * q; const double v = A[(size_t)(k0 + c) * ld + k0 + r]; a[q] = (c <= r) ? v : 0.0; }
+        if (g == 0) Lc[0][r] = a[0];
+        __syncthreads();
+        bool ok = true;
 #pragma unroll
-        for (int c = j + 1; c < CH_NB; ++c) a[c] = fma(-a[j], lane_bcast(a[j], c), a[c]);
-        SCHED_FENCE();                                       // (keeps the scalar broadcasts of later columns from being hoisted and spilled)
-    }
-    return ok;
-}
-
-// one block column: diagonal factor + panel solve.  64 threads per workgroup; workgroup w owns panel rows
-// k0 + 32 + 64 w + lane.
-__global__ void __launch_bounds__(64)
-chol_panel_kernel(double *__restrict__ A, int ld, int n, int k0, int *__restrict__ info)
-{
-    const int lane = threadIdx.x, r = lane & 31;
-    double l[CH_NB];
+        for (int j = 0; j < CH_NB; ++j) {
+            const double p = Lc[j][j];
+            const bool pos = p > 0.0 && p < 1.7976931348623157e308;
+            ok = ok && pos;
+            const double lrj = Lc[j][r] * rcp_nr(pos ? p : 1.0);
 #pragma unroll
-    for (int c = 0; c < CH_NB; ++c) { const double v = A[(size_t)(k0 + c) * ld + k0 + r]; l[c] = (c <= r) ? v : 0.0; }   // (unconditional loads: no exec-mask juggling)
-    const bool ok = diag_factor(l, r);
-    if (blockIdx.x == 0) {
-        if (!ok && lane == 0) atomicMax(info, k0 + 1);
-        if (lane < 32) {
+            for (int q = 0; q < 4; ++q) { const int c = g + 8 * q; if (c > j && c <= r) a[q] = fma(-lrj, Lc[j][c], a[q]); }
+            if (j + 1 < CH_NB && g == ((j + 1) & 7)) Lc[j + 1][r] = a[(j + 1) >> 3];     // column j + 1 is final: publish it
+            __syncthreads();
+        }
+        if (tid < CH_NB) { const double p = Lc[tid][tid]; piv[tid] = rsqrt_nr(p > 0.0 && p < 1.7976931348623157e308 ? p : 1.0); }
+        __syncthreads();
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) A[(size_t)(k0 + c) * ld + k0 + r] = (c <= r) ? l[c] : 0.0;
+        for (int q = 0; q < 4; ++q) { const int c = g + 8 * q; if (c < r) Lc[c][r] *= piv[c]; }      // L[r][c]
+        if (g == 0) Lc[r][r] *= piv[r];                                                              // sqrt(p)
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            if (!ok && tid == 0) atomicMax(info, k0 + 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int c = g + 8 * q; A[(size_t)(k0 + c) * ld + k0 + r] = (c <= r) ? Lc[c][r] : 0.0; }
         }
     }
-    // (opaque copy: otherwise the 496 scalar broadcasts of the factorisation are kept alive for the solve below -- ~1000 spilled SGPRs)
+    // ---- solve X L' = B for 64 rows (workgroup 0: B = I on 32 rows, giving X = L^-T, i.e. the inverse transposed).
+    //      thread (rr, h) keeps x[rr][c = h + 4 q], q = 0..7
+    const int rr = tid & 63, h = tid >> 6;
+    const int row = k0 + CH_NB + 64 * ((int)blockIdx.x - 1) + rr;
+    const bool diag_wg = blockIdx.x == 0;
+    const bool live = diag_wg ? rr < CH_NB : row < nrows;
+    double x[8];
 #pragma unroll
-    for (int c = 0; c < CH_NB; ++c) asm volatile("" : "+v"(l[c]));
-    const int row = k0 + CH_NB + 64 * blockIdx.x + lane;
-    if (k0 + CH_NB + 64 * (int)blockIdx.x >= n) return;        // (uniform) nothing below the diagonal block for this workgroup
-    const bool live = row < n;
-    const size_t rr = live ? row : (size_t)k0;
-    double x[CH_NB];
+    for (int q = 0; q < 8; ++q) {
+        const int c = h + 4 * q;
+        if (diag_wg) x[q] = (c == rr) ? 1.0 : 0.0;
+        else x[q] = A[(size_t)(k0 + c) * ld + (live ? row : k0)];
+    }
 #pragma unroll
-    for (int c = 0; c < CH_NB; ++c) x[c] = A[(size_t)(k0 + c) * ld + rr];
-    // x L' = a  ->  x[c] = (a[c] - sum_{j<c} x[j] L[c][j]) / L[c][c];  L[c][j] sits in lane c, register j
+    for (int j = 0; j < CH_NB; ++j) {
+        if (h == (j & 3)) { const double xj = x[j >> 2] * piv[j]; x[j >> 2] = xj; Xs[j][rr] = xj; }
+        __syncthreads();
+        const double xj = Xs[j][rr];
 #pragma unroll
-    for (int c = 0; c < CH_NB; ++c) {
-        double acc = x[c];
-#pragma unroll
-        for (int j = 0; j < c; ++j) acc = fma(-x[j], lane_bcast(l[j], c), acc);
-        x[c] = acc / lane_bcast(l[c], c);
-        SCHED_FENCE();
+        for (int q = 0; q < 8; ++q) { const int c = h + 4 * q; if (c > j) x[q] = fma(-xj, Lc[j][c], x[q]); }
     }
     if (live) {
 #pragma unroll
-        for (int c = 0; c < CH_NB; ++c) A[(size_t)(k0 + c) * ld + row] = x[c];
+        for (int q = 0; q < 8; ++q) {
+            const int c = h + 4 * q;
+            if (diag_wg) Dinv[(size_t)(k0 / CH_NB) * CH_NB * CH_NB + c * CH_NB + rr] = x[q];      // Linv[c][rr] = X[rr][c]
+            else A[(size_t)(k0 + c) * ld + row] = x[q];
+        }
     }
 }
 
-// trailing update after block column k0: tile (ti, tj), ti >= tj, of 64 x 64 over rows / columns >= k0 + 32
+// trailing update after block column k0: tile (ti, tj), ti >= tj, of 64 x 64 over rows >= k0 + 32 (< nrows) and
+// columns >= k0 + 32 (< ncols)
 __global__ void __launch_bounds__(256)
-chol_update_kernel(double *__restrict__ A, int ld, int n, int k0)
+chol_update_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k0)
 {
     __shared__ double Pi[CH_NB][64 + 1], Pj[CH_NB][64 + 1];
     // linear tile index -> (ti, tj) in the lower triangle
@@ -97,18 +118,21 @@ chol_update_kernel(double *__restrict__ A, int ld, int n, int k0)
     const int tj = t;
     const int base = k0 + CH_NB;
     const int i0 = base + 64 * ti, j0 = base + 64 * tj;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // rows tx + 16 u, columns ty + 16 v
+    double cv[4][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = i0 + tx + 16 * u, col = j0 + ty + 16 * v;
+            cv[u][v] = (row < nrows && col < ncols && row >= col) ? A[(size_t)col * ld + row] : 0.0;
+        }
     for (int e = threadIdx.x; e < CH_NB * 64; e += 256) {
         const int c = e >> 6, rr = e & 63;
-        Pi[c][rr] = (i0 + rr < n) ? A[(size_t)(k0 + c) * ld + i0 + rr] : 0.0;
-        Pj[c][rr] = (j0 + rr < n) ? A[(size_t)(k0 + c) * ld + j0 + rr] : 0.0;
+        Pi[c][rr] = (i0 + rr < nrows) ? A[(size_t)(k0 + c) * ld + i0 + rr] : 0.0;
+        Pj[c][rr] = (j0 + rr < ncols) ? A[(size_t)(k0 + c) * ld + j0 + rr] : 0.0;
     }
     __syncthreads();
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // rows tx + 16 u, columns ty + 16 v
-    double acc[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
 #pragma unroll 8
     for (int c = 0; c < CH_NB; ++c) {
         double pi[4], pj[4];
@@ -117,7 +141,7 @@ chol_update_kernel(double *__restrict__ A, int ld, int n, int k0)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[u][v] = fma(pi[u], pj[v], acc[u][v]);
+            for (int v = 0; v < 4; ++v) cv[u][v] = fma(-pi[u], pj[v], cv[u][v]);
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -125,89 +149,54 @@ chol_update_kernel(double *__restrict__ A, int ld, int n, int k0)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = i0 + tx + 16 * u;
-            if (row < n && col < n && row >= col) A[(size_t)col * ld + row] -= acc[u][v];
+            if (row < nrows && col < ncols && row >= col) A[(size_t)col * ld + row] = cv[u][v];
         }
     }
 }
 
-// L L' x = b in place (b has room for ld entries).  One workgroup.  LDS: y[ld] | d[32]
+// L' x = y with y = row nr of the factored array; x -> out[0..n).  One workgroup of 1024.  LDS: x[nr] | d[32]
 constexpr int CH_SOLVE_THREADS = 1024;
 __global__ void __launch_bounds__(CH_SOLVE_THREADS)
-chol_solve_kernel(const double *__restrict__ L, int ld, int n, double *__restrict__ b)
+chol_back_kernel(const double *__restrict__ L, int ld, int nr, int n, const double *__restrict__ Dinv, double *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *y = lds, *dsum = lds + ld;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31;
-    const int nblk = ld / CH_NB;
-    for (int i = tid; i < ld; i += blockDim.x) y[i] = i < n ? b[i] : 0.0;
+    double *x = lds, *dsum = lds + nr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < nr; i += blockDim.x) x[i] = L[(size_t)i * ld + nr];
     __syncthreads();
-    // ---- forward: L y = b, block column by block column (axpy form)
-    for (int kb = 0; kb < nblk; ++kb) {
-        const int k0 = kb * CH_NB;
-        if (wave == 0) {
-            double l[CH_NB];
-#pragma unroll
-            for (int c = 0; c < CH_NB; ++c) { const double v = L[(size_t)(k0 + c) * ld + k0 + r]; l[c] = (c <= r) ? v : 0.0; }
-            double t = y[k0 + r];
-            double mine = 0.0;
-#pragma unroll
-            for (int j = 0; j < CH_NB; ++j) {
-                const double yj = lane_bcast(t, j) / lane_bcast(l[j], j);
-                if (r == j) mine = yj;
-                t = fma(-l[j], yj, t);               // lanes r > j (l[j] = 0 above the diagonal)
+    for (int k0 = nr - CH_NB; k0 >= 0; k0 -= CH_NB) {
+        // wave w: columns k0 + 2 w, k0 + 2 w + 1 of L dotted with the part of x already solved
+        {
+            const int c0 = k0 + 2 * wave;
+            double p0 = 0.0, p1 = 0.0;
+            const double *L0 = L + (size_t)c0 * ld, *L1 = L0 + ld;
+            int j = k0 + CH_NB + lane;
+            for (; j + 192 < nr; j += 256) {              // four independent row strips in flight per pass
+                const double a0 = L0[j], a1 = L0[j + 64], a2 = L0[j + 128], a3 = L0[j + 192];
+                const double b0 = L1[j], b1 = L1[j + 64], b2 = L1[j + 128], b3 = L1[j + 192];
+                p0 = fma(a0, x[j], p0); p0 = fma(a1, x[j + 64], p0); p0 = fma(a2, x[j + 128], p0); p0 = fma(a3, x[j + 192], p0);
+                p1 = fma(b0, x[j], p1); p1 = fma(b1, x[j + 64], p1); p1 = fma(b2, x[j + 128], p1); p1 = fma(b3, x[j + 192], p1);
             }
-            if (lane < 32) y[k0 + r] = mine;
+            for (; j < nr; j += 64) {
+                const double xj = x[j];
+                p0 = fma(L0[j], xj, p0);
+                p1 = fma(L1[j], xj, p1);
+            }
+            p0 = wave_allsum(p0); p1 = wave_allsum(p1);
+            if (lane == 0) { dsum[2 * wave] = p0; dsum[2 * wave + 1] = p1; }
         }
         __syncthreads();
-        for (int i = k0 + CH_NB + tid; i < ld; i += blockDim.x) {
+        if (wave == 0 && lane < CH_NB) {
+            // x_r = sum_{c >= r} Linv[c][r] (y_c - d_c)
+            const double *D = Dinv + (size_t)(k0 / CH_NB) * CH_NB * CH_NB;
             double acc = 0.0;
 #pragma unroll 8
-            for (int c = 0; c < CH_NB; ++c) acc = fma(L[(size_t)(k0 + c) * ld + i], y[k0 + c], acc);
-            y[i] -= acc;
+            for (int c = 0; c < CH_NB; ++c) acc = fma(D[c * CH_NB + lane], x[k0 + c] - dsum[c], acc);
+            x[k0 + lane] = acc;
         }
         __syncthreads();
     }
-    // ---- backward: L' x = y, block column by block column from the last (dot form)
-    for (int kb = nblk - 1; kb >= 0; --kb) {
-        const int k0 = kb * CH_NB;
-        if (tid < CH_NB) dsum[tid] = 0.0;
-        __syncthreads();
-        if (k0 + CH_NB < ld) {
-            double p[CH_NB];
-#pragma unroll
-            for (int c = 0; c < CH_NB; ++c) p[c] = 0.0;
-            for (int j = k0 + CH_NB + tid; j < ld; j += blockDim.x) {
-                const double xj = y[j];
-#pragma unroll
-                for (int c = 0; c < CH_NB; ++c) p[c] = fma(L[(size_t)(k0 + c) * ld + j], xj, p[c]);
-            }
-            if (k0 + CH_NB + wave * 64 < ld) {                 // (uniform per wave) waves with no row skip the reduction
-#pragma unroll
-                for (int c = 0; c < CH_NB; ++c) {
-                    const double s = wave_allsum(p[c]);
-                    if (lane == 0) unsafeAtomicAdd(&dsum[c], s);
-                }
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            // lane c holds column c of the diagonal block: a[j] = L[j][c], j >= c
-            double a[CH_NB];
-#pragma unroll
-            for (int j = 0; j < CH_NB; ++j) { const double v = L[(size_t)(k0 + r) * ld + k0 + j]; a[j] = (j >= r) ? v : 0.0; }
-            double t = y[k0 + r] - dsum[r];
-            double mine = 0.0;
-#pragma unroll
-            for (int j = CH_NB - 1; j >= 0; --j) {
-                const double xj = lane_bcast(t, j) / lane_bcast(a[j], j);
-                if (r == j) mine = xj;
-                t = fma(-a[j], xj, t);               // lanes c < j
-            }
-            if (lane < 32) y[k0 + r] = mine;
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < n; i += blockDim.x) b[i] = y[i];
+    for (int i = tid; i < n; i += blockDim.x) out[i] = x[i];
 }
 
 }  // namespace cfmm

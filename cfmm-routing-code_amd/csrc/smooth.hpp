@@ -80,13 +80,16 @@ __device__ __forceinline__ double barrier_root(double a, double b, double mu)
 // linear, in particular deep inside the no-trade band where D ~ mu / |A|); a step is taken only if it
 // lands inside the bracket and at least halves the previous one, otherwise the bracket is bisected
 // (the stableswap A is flat, then falls off a knee: plain Newton cycles across it).
+// `Dws` > 0: the root found by the previous evaluation of this direction, used as the starting point (prices and
+// barrier weight move little between consecutive evaluations of the outer iteration).
 template <int KIND>
 __device__ __forceinline__ Branch smooth_branch(double Rin, double Rout, double g, double r, double C,
-                                                double ni, double no, double mu)
+                                                double ni, double no, double mu, double Dws)
 {
     Branch o;
     double D;
-    {
+    if (Dws > 0.0 && Dws < 1e300) D = Dws;
+    else {
         double De = 0.0;
         if (KIND == 0) De = (sqrt(g * no * Rin * Rout / ni) - Rin) / g;
         if (KIND == 1) De = Rin * expm1(log(g * no * Rout * r / (ni * Rin)) / (r + 1.0)) / g;
@@ -137,6 +140,7 @@ __device__ __forceinline__ Branch smooth_branch_sum(double Rout, double g, doubl
 
 struct SmoothArgs {
     Bucket2 b2[4];
+    double *ws[4];              // per kind: [2][m] roots of the previous evaluation (warm start), or null
     int tile_end[4];            // cumulative wave-tiles (64 pools) in the order curve2, w2, cp2, sum2
     int ntiles, n;
     const double *nu;           // [n] prices
@@ -148,7 +152,7 @@ struct SmoothArgs {
 
 template <int KIND>
 __device__ __forceinline__ void smooth_pool(const Bucket2 &b, long long i, double pa, double pb, double mu,
-                                            Branch &ab, Branch &ba)
+                                            Branch &ab, Branch &ba, double *ws = nullptr)
 {
     const double Ra = b.Ra[i], Rb = b.Rb[i], g = b.fee[i];
     if (KIND == 2) {
@@ -159,8 +163,9 @@ __device__ __forceinline__ void smooth_pool(const Bucket2 &b, long long i, doubl
         const double C = KIND == 3 ? Ra + Rb - prm / (Ra * Rb) : 0.0;
         const double rab = KIND == 1 ? prm / (1.0 - prm) : prm, rba = KIND == 1 ? (1.0 - prm) / prm : prm;
         constexpr int K = KIND == 2 ? 0 : KIND;
-        ab = smooth_branch<K>(Ra, Rb, g, rab, C, pa, pb, mu);      // tender a, receive b
-        ba = smooth_branch<K>(Rb, Ra, g, rba, C, pb, pa, mu);      // tender b, receive a
+        ab = smooth_branch<K>(Ra, Rb, g, rab, C, pa, pb, mu, ws ? ws[i] : 0.0);          // tender a, receive b
+        ba = smooth_branch<K>(Rb, Ra, g, rba, C, pb, pa, mu, ws ? ws[b.m + i] : 0.0);    // tender b, receive a
+        if (ws) { ws[i] = ab.D; ws[b.m + i] = ba.D; }
     }
 }
 
@@ -174,7 +179,7 @@ __device__ __forceinline__ void smooth_tile(const Bucket2 &b, long long i0, int 
     const int ia = b.ia[i], ib = b.ib[i];
     const double pa = nu_s[ia], pb = nu_s[ib];
     Branch ab, ba;
-    smooth_pool<KIND>(b, i, pa, pb, a.mu, ab, ba);
+    smooth_pool<KIND>(b, i, pa, pb, a.mu, ab, ba, (KIND != 2 && i0 + lane < b.m) ? a.ws[KIND] : nullptr);
     if (!live) return;
     const double ya = ba.L - ab.D, yb = ab.L - ba.D;
     unsafeAtomicAdd(&psi_s[ia], ya);
@@ -258,16 +263,20 @@ smooth_trades_kernel(Bucket2 b, const double *__restrict__ nu, double mu, double
     }
 }
 
-// H <- H + diag(hd), rows / columns of the pinned tokens (mask != 0) and of the padding (>= n, up to ld)
-// replaced by the identity.  Only the lower triangle is referenced by the factorisation.
+// Finish the linear system in place: H <- H + diag(hd); rows / columns of the pinned tokens (mask != 0) and of
+// the padding (n .. nr) replaced by the identity; the right-hand side written as row nr (chol.hpp's layout).
+// Only the lower triangle is referenced by the factorisation.
 __global__ void __launch_bounds__(256)
-hess_finish_kernel(double *__restrict__ H, int n, int ldh, const double *__restrict__ hd, const int *__restrict__ mask)
+hess_finish_kernel(double *__restrict__ H, int n, int nr, int ldh, const double *__restrict__ hd, const int *__restrict__ mask,
+                   const double *__restrict__ rhs)
 {
-    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < (long long)ldh * ldh; e += (long long)gridDim.x * blockDim.x) {
-        const int row = (int)(e % ldh), col = (int)(e / ldh);
+    const long long total = (long long)(nr + 1) * nr;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(e % (nr + 1)), col = (int)(e / (nr + 1));
         if (row < col) continue;
         double v;
-        if (row >= n || col >= n || mask[row] || mask[col]) v = row == col ? 1.0 : 0.0;
+        if (row == nr) v = (col < n && !mask[col]) ? rhs[col] : 0.0;
+        else if (row >= n || col >= n || mask[row] || mask[col]) v = row == col ? 1.0 : 0.0;
         else v = H[(size_t)col * ldh + row] + (row == col ? hd[row] : 0.0);
         H[(size_t)col * ldh + row] = v;
     }

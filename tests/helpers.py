@@ -40,14 +40,14 @@ def shipped_cases():
     return cases
 
 
-def random_instance(seed, n_tokens=6, n_pools=12, with_sum=True, with_curve=False, utility="arbitrage"):
+def random_instance(seed, n_tokens=6, n_pools=12, with_sum=True, with_curve=False, utility="arbitrage", two_asset_only=False):
     """small random instance in the reference's vocabulary, connected enough to be interesting"""
     rng = np.random.default_rng(seed)
     price = np.exp(rng.normal(0, 0.5, n_tokens))
     L, R, F, K, W, P = [], [], [], [], [], []
     for i in range(n_pools):
         r = rng.random()
-        if r < 0.2 and n_tokens >= 3:
+        if r < 0.2 and n_tokens >= 3 and not two_asset_only:
             k = int(rng.integers(3, min(5, n_tokens) + 1))
             kind = "geomean"
         else:

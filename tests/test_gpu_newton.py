@@ -1,0 +1,206 @@
+"""GPU suite (-m gpu), second-order path (CFMM_METHOD_NEWTON): the barrier-smoothed evaluation against its NumPy
+restatement (oracle/barrier_np.py), the dense Cholesky against LAPACK, and the solves it drives against the SciPy
+primal, the first-order solver and -- at BASELINE config 5's full size -- size-independent properties.
+Tolerances: smoothed values / psi / Hessian 1e-9 relative to their own scale (fp64, different inner solvers:
+bisection + Newton on the CPU, a safeguarded barrier-exact iteration on the device); objectives 1e-6 relative."""
+import numpy as np
+import pytest
+
+import cfmm
+from cfmm import synthetic, _lib
+from oracle import barrier_np
+from helpers import problem_of, random_instance, normalise_with_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _basket(net, seed=1, k=10):
+    n = net["n_tokens"]
+    rng = np.random.default_rng(seed)
+    h = np.zeros(n); idx = rng.choice(n, min(k, n - 1), replace=False)
+    h[idx] = np.exp(rng.normal(2, 0.5, len(idx))) / net["prices"][idx] * 10
+    tgt = int(rng.integers(0, n)); h[tgt] = 0
+    return h, tgt
+
+
+def _mixed_network(seed=0, n=60, m=1500):
+    """every two-asset family, constant-sum pools between equal-priced tokens of a peg group"""
+    net = synthetic.make_network(n, m_cp2=m, m_w2=m, m_curve2=m, seed=seed)
+    rng = np.random.default_rng(seed + 99)
+    ms = m // 2
+    ia = rng.integers(0, n, ms); ib = (ia // 4) * 4 + (ia % 4 + rng.integers(1, 4, ms)) % 4
+    ib = np.minimum(ib, n - 1); ib = np.where(ib == ia, (ia // 4) * 4, ib)
+    keep = ia != ib
+    ia, ib = ia[keep].astype(np.int32), ib[keep].astype(np.int32)
+    L = np.exp(rng.normal(np.log(1e3), 1.0, len(ia)))
+    net["sum2"] = dict(Ra=L / net["prices"][ia], Rb=L / net["prices"][ia] * np.exp(rng.normal(0, 0.05, len(ia))),
+                       fee=np.full(len(ia), 0.999), ia=ia, ib=ib)
+    return net
+
+
+@pytest.mark.parametrize("n", [37, 256, 1000])
+def test_dense_cholesky_against_lapack(n):
+    rng = np.random.default_rng(n)
+    M = rng.normal(size=(n, max(4, n // 8)))
+    A = M @ M.T + np.diag(rng.uniform(0.5, 2.0, n))
+    b = rng.normal(size=n)
+    ctx = _lib.Context(n)
+    x, info = ctx.debug_cholesky(A, b)
+    xr = np.linalg.solve(A, b)
+    assert info == 0
+    assert np.abs(x - xr).max() <= 1e-10 * np.abs(xr).max()
+    # badly scaled but positive definite: the log-price Hessian spans many orders of magnitude
+    s = np.exp(rng.normal(0, 6, n))
+    A2 = A * s[:, None] * s[None, :]
+    x2, info2 = ctx.debug_cholesky(A2, b)
+    assert info2 == 0
+    assert np.abs(x2 * s - np.linalg.solve(A, b / s)).max() <= 1e-8 * np.abs(np.linalg.solve(A, b / s)).max()
+    # indefinite: flagged, not silently factored
+    _, info3 = ctx.debug_cholesky(A - 1e3 * np.eye(n), b)
+    assert info3 != 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("mu", [1e-1, 1e-5, 1e-10])
+def test_smoothed_evaluation_matches_numpy_restatement(mu):
+    net = _mixed_network()
+    n = net["n_tokens"]
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    ctx = p._ensure_ctx()
+    rng = np.random.default_rng(5)
+    nu = net["prices"] * np.exp(rng.normal(0, 0.03, n))
+    val, tr, psi, H = ctx.eval_smooth(nu, mu, want_hessian=True)
+    o = barrier_np.smooth_eval(net, nu, mu, hessian=True)
+    assert abs(val - o["value"]) <= 1e-10 * max(1.0, abs(o["value"]))
+    assert abs(tr - o["trade"]) <= 1e-10 * max(1.0, abs(o["trade"]))
+    assert np.abs(psi - o["psi"]).max() <= 1e-10 * np.abs(o["psi"]).max()
+    Hl, Ho = np.tril(H), np.tril(o["H"])
+    assert np.abs(Hl - Ho).max() <= 1e-8 * np.abs(Ho).max()
+    assert np.all(np.triu(H, 1) == 0.0)
+    # the smoothed trade value never exceeds the exact optimum, and is within mu per barrier term of it
+    arb, _ = ctx.eval_dual(nu)
+    nbar = 2 * sum(len(net[k]["Ra"]) for k in ("cp2", "w2", "curve2")) + 4 * len(net["sum2"]["Ra"])
+    assert -1e-9 * abs(arb) <= arb - tr <= mu * nbar * (1 + 1e-9) + 1e-9 * abs(arb)
+    p.close()
+
+
+def test_smoothed_tenders_stay_inside_every_trading_set():
+    """the primal point of a second-order solve: Delta, Lambda > 0 and phi(R + gamma Delta - Lambda) >= phi(R)"""
+    net = _mixed_network(seed=3)
+    h, t = _basket(net)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Liquidate(h, t))
+    p.solve(method="newton")
+    assert p.status == "optimal" and p.stats["method"] == _lib.METHODS["newton"] and p.stats["barrier_mu"] > 0
+    psi = np.zeros(net["n_tokens"])
+    for key in ("cp2", "w2", "curve2", "sum2"):
+        b = net[key]
+        d, l = p.bucket_trades(key)
+        assert d.min() > 0 and l.min() > 0
+        xa = b["Ra"] + b["fee"] * d[0] - l[0]; xb = b["Rb"] + b["fee"] * d[1] - l[1]
+        assert xa.min() > 0 and xb.min() > 0
+        if key == "cp2":
+            before, after = np.log(b["Ra"]) + np.log(b["Rb"]), np.log(xa) + np.log(xb)
+        elif key == "w2":
+            before = b["wa"] * np.log(b["Ra"]) + (1 - b["wa"]) * np.log(b["Rb"]); after = b["wa"] * np.log(xa) + (1 - b["wa"]) * np.log(xb)
+        elif key == "curve2":
+            before = b["Ra"] + b["Rb"] - b["alpha"] / (b["Ra"] * b["Rb"]); after = xa + xb - b["alpha"] / (xa * xb)
+        else:
+            before, after = b["Ra"] + b["Rb"], xa + xb
+        assert np.all(after >= before - 1e-9 * np.abs(before)), key
+        np.add.at(psi, b["ia"], l[0] - d[0]); np.add.at(psi, b["ib"], l[1] - d[1])
+    assert np.abs(psi - p.psi).max() <= 1e-9 * np.abs(p.psi).max()       # psi IS the scatter-sum of the tenders
+    assert p.dual_value >= p.value - 1e-9 * abs(p.value)
+    p.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_second_order_small_instances_vs_primal(seed):
+    from oracle.primal_scipy import solve_primal
+    util = ["liquidate", "swap", "arbitrage"][seed % 3]
+    inst = random_instance(400 + seed, n_tokens=6, n_pools=14, with_sum=True, with_curve=True, utility=util, two_asset_only=True)
+    p = problem_of(inst)
+    v = p.solve(tol=1e-8, method="newton")
+    r = solve_primal(normalise_with_params(inst))
+    if p.status != "optimal":                 # a token to sell that no pool lists: SLSQP fails on it too
+        assert not r["success"], (p.status, p.gap, p.infeas)
+        return
+    assert p.gap <= 1e-7 and p.infeas <= 1e-7
+    assert r["value"] <= p.dual_value + 2e-6 * max(1, abs(v))                 # weak duality vs SLSQP's point
+    if r["success"]:
+        assert abs(v - r["value"]) <= 2e-6 * max(1, abs(v)), (v, r["value"])
+    p.close()
+
+
+@pytest.mark.parametrize("util", ["arbitrage", "swap", "liquidate"])
+def test_second_order_agrees_with_first_order_on_constant_product_pools(util):
+    net = synthetic.config("C2")
+    if util == "arbitrage":
+        u = cfmm.Arbitrage(net["c"])
+    else:
+        h, t = _basket(net, seed=7, k=5)
+        u = cfmm.Swap(h, t) if util == "swap" else cfmm.Liquidate(h, t)
+    p = cfmm.Problem.from_network(net, utility=u)
+    v1 = p.solve(method="lbfgs"); s1 = p.status; psi1 = p.psi.copy()
+    v2 = p.solve(method="newton"); s2 = p.status
+    assert s1 == "optimal" and s2 == "optimal"
+    assert p.stats["method"] == _lib.METHODS["newton"] and p.stats["newton_steps"] > 0
+    assert abs(v1 - v2) <= 2e-6 * max(1.0, abs(v1)), (v1, v2)
+    assert np.abs(psi1 - p.psi).max() <= 2e-4 * max(np.abs(psi1).max(), np.abs(u.h).max())
+    p.close()
+
+
+def test_config5_full_size_second_order():
+    """BASELINE config 5: 5e5 stableswap pools (+ 5e4 constant-product), 1000 tokens, basket liquidation.
+    The first-order iteration does not reach its certificates here in thousands of evaluations."""
+    net = synthetic.config("C5")
+    h, t = _basket(net)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Liquidate(h, t))
+    v = p.solve()                                        # auto picks the second-order method for this network
+    st = p.stats
+    assert p.status == "optimal" and st["method"] == _lib.METHODS["newton"]
+    assert p.gap <= 1e-6 and p.infeas <= 1e-6
+    assert st["newton_steps"] <= 60 and st["evals"] <= 300
+    r = p.psi + h
+    assert np.abs(np.delete(r, t)).max() <= 1e-6 * max(np.abs(p.psi).max(), h.max())       # the basket is sold, nothing else moves
+    assert v > 0 and p.dual_value >= v * (1 - 1e-9) and (p.dual_value - v) <= 1e-6 * p.dual_value
+    # same optimum from a different barrier schedule and a perturbed start (the certificates are self-contained)
+    nu0 = cfmm.start_prices(net, p.utility) * np.exp(np.random.default_rng(0).normal(0, 0.05, net["n_tokens"]))
+    ctx = p._ensure_ctx()
+    ctx.set_utility(p.utility.c, p.utility.h, p.utility.ctype)
+    st2 = ctx.solve(nu0, method="newton", barrier_shrink=0.5)
+    assert st2["status"] == 1 and abs(st2["primal_value"] - v) <= 2e-6 * v
+    p.close()
+
+
+def test_many_constant_sum_pools_second_order():
+    """2000 constant-sum pools among 20000: beyond what the host-side active-set loop over kinks handles"""
+    rng = np.random.default_rng(11)
+    n = 200
+    net = synthetic.make_network(n, m_cp2=18000, seed=11)
+    m = 2000
+    ia = rng.integers(0, n, m); ib = (ia + rng.integers(1, n, m)) % n
+    L = np.exp(rng.normal(np.log(1e3), 1.0, m)); pi = net["prices"]
+    # a constant-sum pool quotes 1:1: express both reserves in units of equal value so that it sits near the market
+    scale_a, scale_b = 1.0 / pi[ia], 1.0 / pi[ib]
+    net["sum2"] = dict(Ra=L * scale_a, Rb=L * scale_b, fee=np.full(m, 0.999), ia=ia.astype(np.int32), ib=ib.astype(np.int32))
+    net["prices"] = pi
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    v = p.solve()
+    assert p.stats["method"] == _lib.METHODS["newton"]
+    assert p.status == "optimal" and p.gap <= 1e-6 and p.infeas <= 1e-6
+    assert v >= 0 and p.dual_value >= v - 1e-9 * abs(v)
+    p.close()
+
+
+def test_second_order_refuses_what_it_cannot_take():
+    net = synthetic.config("C3", scale=0.01)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    with pytest.raises(cfmm.CfmmError, match="k-asset"):
+        p.solve(method="newton")
+    with pytest.raises(ValueError):
+        p.solve(method="simplex")
+    assert p.solve(method="auto") > 0 and p.stats["method"] == _lib.METHODS["lbfgs"]       # falls back to first order
+    ctx = p._ensure_ctx()
+    with pytest.raises(cfmm.CfmmError):
+        ctx.eval_smooth(net["prices"], 1e-3)
+    p.close()

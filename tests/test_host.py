@@ -30,6 +30,37 @@ def test_cabi_library_exports_header_symbols():
     assert names == set(_lib.SYMBOLS)
 
 
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """cfmm_opts / cfmm_stats as bound by cfmm/_lib.py AND by the verbatim stub in INTEGRATION.md have the size and
+    field offsets the C compiler gives the header's structs (a mismatch corrupts memory silently)"""
+    import subprocess
+    src = tmp_path / "layout.c"
+    fields_o = [f for f, _ in _lib.Opts._fields_]
+    fields_s = [f for f, _ in _lib.Stats._fields_]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cfmm.h"', 'int main(void) {',
+             'printf("%zu %zu\\n", sizeof(cfmm_opts), sizeof(cfmm_stats));']
+    lines += [f'printf("%zu\\n", offsetof(cfmm_opts, {f}));' for f in fields_o]
+    lines += [f'printf("%zu\\n", offsetof(cfmm_stats, {f}));' for f in fields_s]
+    lines += ['return 0; }']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert int(out[0]) == ctypes.sizeof(_lib.Opts) and int(out[1]) == ctypes.sizeof(_lib.Stats)
+    offs = [int(x) for x in out[2:]]
+    assert offs[:len(fields_o)] == [getattr(_lib.Opts, f).offset for f in fields_o]
+    assert offs[len(fields_o):] == [getattr(_lib.Stats, f).offset for f in fields_s]
+    # the stub in INTEGRATION.md declares the same two structs by hand
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = md[md.index("import ctypes as C, numpy as np"):]
+    stub = stub[:stub.index("```")]
+    decl = stub[stub.index("class Opts"):stub.index("L.cfmm_last_error.restype")]
+    ns = {"C": ctypes}
+    exec(decl, ns)
+    assert [f for f, _ in ns["Opts"]._fields_] == fields_o and ctypes.sizeof(ns["Opts"]) == ctypes.sizeof(_lib.Opts)
+    assert [f for f, _ in ns["Stats"]._fields_] == fields_s and ctypes.sizeof(ns["Stats"]) == ctypes.sizeof(_lib.Stats)
+
+
 def test_product_fails_loudly_without_gpu():
     try:
         import torch

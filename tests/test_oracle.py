@@ -112,3 +112,73 @@ def test_dual_oracle_vs_primal_on_random_instances(oracle_lib, seed):
     r = solve_primal(normalise_with_params(inst))
     assert p.status == "optimal"
     assert abs(v - r["value"]) <= 1e-6 * max(1, abs(v)), (v, r["value"])
+
+
+# ---------------------------------------------------------------------------------------------
+# the NumPy restatement of the barrier-smoothed evaluation (oracle/barrier_np.py): pinned by finite differences of
+# itself and by its mu -> 0 limit against the exact pool solutions
+# ---------------------------------------------------------------------------------------------
+def _small_two_asset_network():
+    from cfmm import synthetic
+    net = synthetic.make_network(12, m_cp2=40, m_w2=40, m_curve2=40, seed=2)
+    rng = np.random.default_rng(3)
+    ia = rng.integers(0, 12, 15); ib = (ia + rng.integers(1, 12, 15)) % 12
+    L = np.exp(rng.normal(5, 1, 15))
+    net["sum2"] = dict(Ra=L / net["prices"][ia], Rb=L / net["prices"][ib], fee=np.full(15, 0.999),
+                       ia=ia.astype(np.int32), ib=ib.astype(np.int32))
+    return net
+
+
+@pytest.mark.parametrize("mu", [1e-1, 1e-4])
+def test_barrier_oracle_gradient_and_hessian_by_finite_differences(mu):
+    from oracle import barrier_np
+    net = _small_two_asset_network()
+    n = net["n_tokens"]
+    rng = np.random.default_rng(0)
+    s0 = np.log(net["prices"]) + rng.normal(0, 0.02, n)
+    f = lambda s: barrier_np.smooth_eval(net, np.exp(s), mu)["value"]
+    e0 = barrier_np.smooth_eval(net, np.exp(s0), mu, hessian=True)
+    grad = np.exp(s0) * e0["psi"]                         # d value / d log nu = nu * psi   (envelope theorem)
+    hess = e0["H"] + np.diag(grad)
+    eps = 1e-5
+    for j in range(n):
+        d = np.zeros(n); d[j] = eps
+        gfd = (f(s0 + d) - f(s0 - d)) / (2 * eps)
+        assert abs(gfd - grad[j]) <= 1e-6 * max(1.0, np.abs(grad).max()), (j, gfd, grad[j])
+        gp = np.exp(s0 + d) * barrier_np.smooth_eval(net, np.exp(s0 + d), mu)["psi"]
+        gm = np.exp(s0 - d) * barrier_np.smooth_eval(net, np.exp(s0 - d), mu)["psi"]
+        hfd = (gp - gm) / (2 * eps)
+        assert np.abs(hfd - hess[:, j]).max() <= 1e-5 * np.abs(hess).max(), j
+    assert np.all(np.linalg.eigvalsh(e0["H"]) >= -1e-9 * np.abs(e0["H"]).max())      # a sum of rank-one PSD terms
+
+
+def test_barrier_oracle_tends_to_the_exact_pool_solutions():
+    from oracle import barrier_np, pools_np
+    net = _small_two_asset_network()
+    nu = net["prices"] * np.exp(np.random.default_rng(1).normal(0, 0.05, net["n_tokens"]))
+    n = net["n_tokens"]
+    exact_psi = np.zeros(n)
+    for key in ("cp2", "w2"):
+        b = net[key]
+        wa = b["wa"] if key == "w2" else np.full(len(b["Ra"]), 0.5)
+        ya, yb, _ = pools_np.arb_geomean2(b["Ra"], b["Rb"], b["fee"], wa, 1 - wa, nu[b["ia"]], nu[b["ib"]])
+        np.add.at(exact_psi, b["ia"], ya); np.add.at(exact_psi, b["ib"], yb)
+    b = net["curve2"]
+    for i in range(len(b["Ra"])):
+        y, _ = pools_np.arb_curve2(b["Ra"][i], b["Rb"][i], b["fee"][i], b["alpha"][i], nu[b["ia"][i]], nu[b["ib"][i]])
+        exact_psi[b["ia"][i]] += y[0]; exact_psi[b["ib"][i]] += y[1]
+    b = net["sum2"]
+    for i in range(len(b["Ra"])):
+        y, _ = pools_np.arb_sum([b["Ra"][i], b["Rb"][i]], b["fee"][i], nu[[b["ia"][i], b["ib"][i]]])
+        exact_psi[b["ia"][i]] += y[0]; exact_psi[b["ib"][i]] += y[1]
+    exact_arb = float(nu @ exact_psi)
+    nbar = 2 * sum(len(net[k]["Ra"]) for k in ("cp2", "w2", "curve2")) + 4 * len(net["sum2"]["Ra"])
+    prev = None
+    for mu in (1e-2, 1e-4, 1e-6, 1e-8):
+        e = barrier_np.smooth_eval(net, nu, mu)
+        sub = exact_arb - e["trade"]
+        assert -1e-9 * abs(exact_arb) <= sub <= mu * nbar * (1 + 1e-9)
+        if prev is not None:
+            assert sub <= prev * (1 + 1e-9)
+        prev = sub
+    assert np.abs(e["psi"] - exact_psi).max() <= 1e-4 * np.abs(exact_psi).max()
