@@ -611,6 +611,10 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         double dec = 0.0, dmax = 0.0;
         for (int j = 0; j < n; ++j) { if (mask[j]) d[j] = 0.0; dec -= G[j] * d[j]; dmax = std::max(dmax, std::fabs(d[j])); }
         if (!std::isfinite(dec) || !std::isfinite(dmax)) { status = CFMM_E_NUMERIC; break; }
+        if (final_mu) {                        // centring at the final weight: stop (before moving, so that nu, psi and the
+            stalled = (dec <= 1e-15 * std::max(1.0, std::fabs(gmu))) ? stalled + 1 : 0;     // certificates stay those of one point)
+            if (stalled >= 3) { status = 2; break; }                   // once the steps fall below the fp64 resolution of the prices
+        }
         // step length: cap on the log-price move, fraction to the boundary nu > c, Armijo back-tracking on the smoothed dual
         double t = std::min(1.0, o.max_step / std::max(dmax, 1e-300));
         for (int j = 0; j < n; ++j)
@@ -628,11 +632,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         if (trace) fprintf(stderr, "[newton]    dec %.3e |d| %.3e t %.3e (first %.3e) moved %d\n", dec, dmax, t, t_first, (int)moved);
         if (!moved) { status = 2; break; }
         s = s2; nu = nu2;
-        if (final_mu) {                                                // the weight is small enough: finish centring at it
-            stalled = (dec <= 1e-15 * std::max(1.0, std::fabs(gmu))) ? stalled + 1 : 0;
-            if (stalled >= 3) { status = 2; break; }                   // fp64 resolution of the prices reached
-            continue;
-        }
+        if (final_mu) continue;                                        // the weight is small enough: finish centring at it
         if (dec < 10.0 * mu * (double)nbar && (t == t_first || dec < 1e-3 * mu * (double)nbar)) mu *= sigma;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));

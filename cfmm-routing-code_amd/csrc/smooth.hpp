@@ -23,11 +23,15 @@ namespace cfmm {
 
 struct Fwd { double L, L1, L2; };       // L(D), L'(D), L''(D)
 
-__device__ __forceinline__ double curve_y_stable(double x, double C, double al)
+// (reciprocals and square roots through rcp_nr / rsqrt_nr, pool_math.hpp: <= ~1 ulp, a third of the
+//  instructions of the IEEE sequences -- this path is fp64-issue bound like the exact evaluation)
+__device__ __forceinline__ double sqrt_nr(double v) { return v > 0.0 ? v * rsqrt_nr(v) : 0.0; }
+
+__device__ __forceinline__ double curve_y_stable(double x, double ix, double C, double al)
 {
-    const double b = C - x, q = 4.0 * al / x;
-    const double sq = sqrt(fma(b, b, q));
-    return b >= 0.0 ? 0.5 * (b + sq) : 0.5 * q / (sq - b);
+    const double b = C - x, q = 4.0 * al * ix;
+    const double sq = sqrt_nr(fma(b, b, q));
+    return b >= 0.0 ? 0.5 * (b + sq) : 0.5 * q * rcp_nr(sq - b);
 }
 
 // KIND 0 constant product | 1 weighted (r = w_in / w_out) | 3 stableswap (r = alpha, C = level)
@@ -36,28 +40,28 @@ __device__ __forceinline__ Fwd fwd2(double D, double Rin, double Rout, double g,
 {
     Fwd o;
     const double x = fma(g, D, Rin);
+    const double ix = rcp_nr(x);
     if (KIND == 0) {
-        const double ix = 1.0 / x;
-        const double gy = g * Rout * ix;                   // gamma y / ... : L = gamma D R_out / x  (no cancellation)
+        const double gy = g * Rout * ix;                   // L = gamma D R_out / x  (no cancellation)
         o.L = D * gy;
         o.L1 = gy * Rin * ix;                              // gamma k / x^2
         o.L2 = -2.0 * g * o.L1 * ix;
     } else if (KIND == 1) {
-        const double ix = 1.0 / x;
-        const double lq = -r * log1p(g * D / Rin);         // log (R_in / x)^r
+        const double lq = -r * log1p(g * D * rcp_nr(Rin)); // log (R_in / x)^r
         const double q = exp(lq);
         o.L = -Rout * expm1(lq);
         o.L1 = g * Rout * r * q * ix;
         o.L2 = -g * (r + 1.0) * o.L1 * ix;
     } else {
         const double al = r;
-        const double y = curve_y_stable(x, C, al);
-        const double ixy = 1.0 / (x * y);
-        const double t = al * ixy;                         // alpha / (x y)
-        const double fx = 1.0 + t / x, fy = 1.0 + t / y;
-        const double y1 = -fx / fy;
-        const double fxx = -2.0 * t / (x * x), fxy = -t * ixy, fyy = -2.0 * t / (y * y);
-        const double y2 = -(fxx + 2.0 * fxy * y1 + fyy * y1 * y1) / fy;
+        const double y = curve_y_stable(x, ix, C, al);
+        const double iy = rcp_nr(y);
+        const double t = al * ix * iy;                     // alpha / (x y)
+        const double fx = fma(t, ix, 1.0), fy = fma(t, iy, 1.0);
+        const double ify = rcp_nr(fy);
+        const double y1 = -fx * ify;
+        const double fxx = -2.0 * t * ix * ix, fxy = -t * ix * iy, fyy = -2.0 * t * iy * iy;
+        const double y2 = -(fxx + 2.0 * fxy * y1 + fyy * y1 * y1) * ify;
         o.L = Rout - y;
         o.L1 = -g * y1;
         o.L2 = -g * g * y2;
@@ -70,8 +74,8 @@ struct Branch { double D, L, L1, kappa, val; };
 // root of  a D^2 + b D + mu = 0  (a < 0, mu > 0) in D > 0, without cancellation
 __device__ __forceinline__ double barrier_root(double a, double b, double mu)
 {
-    const double rt = sqrt(fma(b, b, -4.0 * a * mu));
-    return b > 0.0 ? (b + rt) / (-2.0 * a) : 2.0 * mu / (rt - b);
+    const double rt = sqrt_nr(fma(b, b, -4.0 * a * mu));
+    return b > 0.0 ? (b + rt) * rcp_nr(-2.0 * a) : 2.0 * mu * rcp_nr(rt - b);
 }
 
 // one direction of a two-asset pool: tender `in`, receive `out`.  Safeguarded iteration on
@@ -91,7 +95,7 @@ __device__ __forceinline__ Branch smooth_branch(double Rin, double Rout, double 
     if (Dws > 0.0 && Dws < 1e300) D = Dws;
     else {
         double De = 0.0;
-        if (KIND == 0) De = (sqrt(g * no * Rin * Rout / ni) - Rin) / g;
+        if (KIND == 0) De = (sqrt_nr(g * no * Rin * Rout * rcp_nr(ni)) - Rin) * rcp_nr(g);
         if (KIND == 1) De = Rin * expm1(log(g * no * Rout * r / (ni * Rin)) / (r + 1.0)) / g;
         if (De > 0.0) D = De;
         else {
@@ -103,7 +107,7 @@ __device__ __forceinline__ Branch smooth_branch(double Rin, double Rout, double 
     for (int it = 0; it < 120; ++it) {
         const Fwd f = fwd2<KIND>(D, Rin, Rout, g, r, C);
         const double A = no * f.L1 - ni, A1 = fmin(no * f.L2, -1e-300);
-        const double F = A + mu / D;
+        const double F = fma(mu, rcp_nr(D), A);
         if (F > 0.0) lo = D; else hi = D;
         double Dn = barrier_root(A1, A - A1 * D, mu);
         const double stepc = fabs(Dn - D);
@@ -116,7 +120,7 @@ __device__ __forceinline__ Branch smooth_branch(double Rin, double Rout, double 
     }
     const Fwd f = fwd2<KIND>(D, Rin, Rout, g, r, C);
     o.D = D; o.L = f.L; o.L1 = f.L1;
-    o.kappa = 1.0 / (mu / (D * D) - no * f.L2);
+    { const double iD = rcp_nr(D); o.kappa = rcp_nr(fma(mu * iD, iD, -no * f.L2)); }
     o.val = no * f.L - ni * D + mu * log(D);
     return o;
 }

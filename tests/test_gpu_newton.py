@@ -106,7 +106,7 @@ def test_smoothed_tenders_stay_inside_every_trading_set():
             before = b["Ra"] + b["Rb"] - b["alpha"] / (b["Ra"] * b["Rb"]); after = xa + xb - b["alpha"] / (xa * xb)
         else:
             before, after = b["Ra"] + b["Rb"], xa + xb
-        assert np.all(after >= before - 1e-9 * np.abs(before)), key
+        assert np.all(after >= before - 1e-9 * np.abs(before)), (key, float(((before - after) / np.abs(before)).max()))
         np.add.at(psi, b["ia"], l[0] - d[0]); np.add.at(psi, b["ib"], l[1] - d[1])
     assert np.abs(psi - p.psi).max() <= 1e-9 * np.abs(p.psi).max()       # psi IS the scatter-sum of the tenders
     assert p.dual_value >= p.value - 1e-9 * abs(p.value)
