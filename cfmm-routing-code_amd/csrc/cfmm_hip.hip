@@ -419,7 +419,10 @@ bool newton_supported(cfmm_ctx *ctx, const char **why)
     return true;
 }
 
-bool near_linear_pools(cfmm_ctx *ctx) { return ctx->pools->b2[CFMM_POOL_SUM2].m + ctx->pools->b2[CFMM_POOL_CURVE2].m > 0; }
+// stableswap pools: the first-order iteration needs thousands of evaluations; constant-sum pools alone are
+// left to the first-order path (the host's active-set loop over kinks is quicker while it copes) with the second-order
+// method as the fall-back
+bool near_linear_pools(cfmm_ctx *ctx) { return ctx->pools->b2[CFMM_POOL_CURVE2].m > 0; }
 
 int smooth_buffers(cfmm_ctx *ctx, bool hess)
 {

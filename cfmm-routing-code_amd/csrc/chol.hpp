@@ -162,28 +162,26 @@ chol_back_kernel(const double *__restrict__ L, int ld, int nr, int n, const doub
     for (int i = tid; i < nr; i += blockDim.x) x[i] = L[(size_t)i * ld + nr];
     __syncthreads();
     for (int k0 = nr - NB; k0 >= 0; k0 -= NB) {
-        // wave w: columns k0 + CW w .. + CW - 1 of L dotted with the part of x already solved
+        // wave w: columns k0 + 2 w, k0 + 2 w + 1 of L dotted with the part of x already solved
         {
-            double p[CW];
-            const double *Lw[CW];
-#pragma unroll
-            for (int u = 0; u < CW; ++u) { p[u] = 0.0; Lw[u] = L + (size_t)(k0 + CW * wave + u) * ld; }
+            static_assert(CW == 2, "two columns per wave");
+            const int c0 = k0 + 2 * wave;
+            double p0 = 0.0, p1 = 0.0;
+            const double *L0 = L + (size_t)c0 * ld, *L1 = L0 + ld;
             int j = k0 + NB + lane;
-            for (; j + 64 < nr; j += 128) {               // two independent row strips (2 CW loads) in flight per pass
-                const double x0 = x[j], x1 = x[j + 64];
-                double a0[CW], a1[CW];
-#pragma unroll
-                for (int u = 0; u < CW; ++u) { a0[u] = Lw[u][j]; a1[u] = Lw[u][j + 64]; }
-#pragma unroll
-                for (int u = 0; u < CW; ++u) { p[u] = fma(a0[u], x0, p[u]); p[u] = fma(a1[u], x1, p[u]); }
+            for (; j + 192 < nr; j += 256) {              // four independent row strips in flight per pass
+                const double a0 = L0[j], a1 = L0[j + 64], a2 = L0[j + 128], a3 = L0[j + 192];
+                const double b0 = L1[j], b1 = L1[j + 64], b2 = L1[j + 128], b3 = L1[j + 192];
+                p0 = fma(a0, x[j], p0); p0 = fma(a1, x[j + 64], p0); p0 = fma(a2, x[j + 128], p0); p0 = fma(a3, x[j + 192], p0);
+                p1 = fma(b0, x[j], p1); p1 = fma(b1, x[j + 64], p1); p1 = fma(b2, x[j + 128], p1); p1 = fma(b3, x[j + 192], p1);
             }
             for (; j < nr; j += 64) {
                 const double xj = x[j];
-#pragma unroll
-                for (int u = 0; u < CW; ++u) p[u] = fma(Lw[u][j], xj, p[u]);
+                p0 = fma(L0[j], xj, p0);
+                p1 = fma(L1[j], xj, p1);
             }
-#pragma unroll
-            for (int u = 0; u < CW; ++u) { const double s = wave_allsum(p[u]); if (lane == 0) dsum[CW * wave + u] = s; }
+            p0 = wave_allsum(p0); p1 = wave_allsum(p1);
+            if (lane == 0) { dsum[2 * wave] = p0; dsum[2 * wave + 1] = p1; }
         }
         __syncthreads();
         if (wave == 0 && lane < NB) {

@@ -44,9 +44,9 @@ enum {
 
 /* outer iteration of cfmm_solve */
 enum {
-    CFMM_METHOD_AUTO = 0,       /* second order when the network holds constant-sum / stableswap pools and only
-                                   two-asset pools (the near-linear case the first-order iteration crawls on), else
-                                   first order; a first-order run that ends without its certificates is handed on  */
+    CFMM_METHOD_AUTO = 0,       /* second order when the network holds stableswap pools and only two-asset pools (the
+                                   near-linear case the first-order iteration crawls on), else first order; a
+                                   first-order run that ends without its certificates is handed on when possible    */
     CFMM_METHOD_LBFGS = 1,      /* projected L-BFGS in log-prices, fully on-device (hipGraph)                       */
     CFMM_METHOD_NEWTON = 2      /* barrier-smoothed dual Newton: dense n x n Hessian, blocked Cholesky on-device    */
 };

@@ -172,8 +172,9 @@ def test_config5_full_size_second_order():
     p.close()
 
 
-def test_many_constant_sum_pools_second_order():
-    """2000 constant-sum pools among 20000: beyond what the host-side active-set loop over kinks handles"""
+def test_many_constant_sum_pools_both_paths_agree():
+    """2000 constant-sum pools among 20000: the first-order path (host-side active-set loop over the kinks) and the
+    second-order path (closed-form smoothed fills, no host loop) reach the same optimum"""
     rng = np.random.default_rng(11)
     n = 200
     net = synthetic.make_network(n, m_cp2=18000, seed=11)
@@ -181,14 +182,18 @@ def test_many_constant_sum_pools_second_order():
     ia = rng.integers(0, n, m); ib = (ia + rng.integers(1, n, m)) % n
     L = np.exp(rng.normal(np.log(1e3), 1.0, m)); pi = net["prices"]
     # a constant-sum pool quotes 1:1: express both reserves in units of equal value so that it sits near the market
-    scale_a, scale_b = 1.0 / pi[ia], 1.0 / pi[ib]
-    net["sum2"] = dict(Ra=L * scale_a, Rb=L * scale_b, fee=np.full(m, 0.999), ia=ia.astype(np.int32), ib=ib.astype(np.int32))
-    net["prices"] = pi
+    net["sum2"] = dict(Ra=L / pi[ia], Rb=L / pi[ib], fee=np.full(m, 0.999), ia=ia.astype(np.int32), ib=ib.astype(np.int32))
     p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
-    v = p.solve()
+    v2 = p.solve(method="newton")
     assert p.stats["method"] == _lib.METHODS["newton"]
     assert p.status == "optimal" and p.gap <= 1e-6 and p.infeas <= 1e-6
-    assert v >= 0 and p.dual_value >= v - 1e-9 * abs(v)
+    assert v2 >= 0 and p.dual_value >= v2 - 1e-9 * abs(v2)
+    d, l = p.bucket_trades("sum2")
+    b = net["sum2"]
+    assert d.min() > 0 and (b["Ra"] + b["fee"] * d[0] - l[0]).min() > 0 and (b["Rb"] + b["fee"] * d[1] - l[1]).min() > 0
+    v1 = p.solve()                                       # auto: constant-sum pools alone stay first order
+    assert p.stats["method"] == _lib.METHODS["lbfgs"] and p.status == "optimal"
+    assert abs(v1 - v2) <= 2e-6 * abs(v1), (v1, v2)
     p.close()
 
 
