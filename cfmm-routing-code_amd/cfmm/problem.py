@@ -246,6 +246,9 @@ class _Ties:
 
 
 # ------------------------------------------------------------------------------- Problem
+AUTO_NEWTON_MIN_STABLE = 4096      # include/cfmm.h: CFMM_AUTO_NEWTON_MIN_STABLE
+
+
 class Problem:
     """Drop-in for the reference's `prob = cp.Problem(obj, cons); prob.solve()`.
 
@@ -360,10 +363,10 @@ class Problem:
     # -- solve -------------------------------------------------------------------------------
     def solve(self, tol=1e-6, nu0=None, max_evals=2000, memory=0, iters_per_graph=8, kink_tol=1e-3,
               max_rounds=6, warm_start=False, method="auto"):
-        """`method`: "lbfgs" (first order, on-device), "newton" (barrier-smoothed second order: networks of
-        two-asset pools, the remedy for stableswap / constant-sum pools at scale) or "auto" (second order when the
-        network holds stableswap pools and only two-asset pools; otherwise first order, with the host-side
-        active-set loop for constant-sum kinks and the second-order method as its fall-back)."""
+        """`method`: "lbfgs" (first order, on-device), "newton" (barrier-smoothed second order: the remedy for
+        stableswap / constant-sum pools at scale; k-asset pools enter it unsmoothed) or "auto" (second order when the
+        network holds stableswap pools; otherwise first order, with the host-side active-set loop for constant-sum
+        kinks and the second-order method as its fall-back)."""
         if self.utility is None:
             raise ValueError("no utility set")
         ctx = self._ensure_ctx()
@@ -384,22 +387,25 @@ class Problem:
         self._tol = tol
         kw = dict(max_evals=max_evals, memory=memory, iters_per_graph=iters_per_graph)
         total = dict(evals=0, iters=0, wall_seconds=0.0, device_seconds=0.0, rounds=0)
-        can_second = (not self.net.get("gn")) and not (bool(self._comm) and self._comm[0] > 1) and getattr(ctx, "second_order", False)
+        can_second = not (bool(self._comm) and self._comm[0] > 1) and getattr(ctx, "second_order", False)
         if method not in _lib.METHODS:
             raise ValueError(f"method {method!r}: expected one of {sorted(_lib.METHODS)}")
-        # auto: stableswap pools -> second order straight away (first order needs thousands of evaluations there);
-        # constant-sum pools alone -> first order with the active-set loop over kinks, second order if that fails
-        second_order = method == "newton" or (method == "auto" and can_second and "curve2" in self.net)
+        # auto: many stableswap pools -> second order straight away (first order needs thousands of evaluations there);
+        # otherwise first order (with the active-set loop over constant-sum kinks), second order if that fails
+        many_stable = "curve2" in self.net and len(self.net["curve2"]["Ra"]) >= AUTO_NEWTON_MIN_STABLE
+        second_order = method == "newton" or (method == "auto" and can_second and many_stable)
         if not second_order:
             if "sum2" not in self.net:
-                st = self._run(ctx, nu0, total, tol=tol, method=_lib.METHODS[method], **kw)
+                st = self._run(ctx, nu0, total, tol=tol, method=_lib.METHODS["lbfgs"], **kw)
                 nu, psi = ctx.get_solution()
             else:
                 st, nu, psi = self._solve_kinks(ctx, nu0, tol, dict(kw, method=_lib.METHODS["lbfgs"]), kink_tol, max_rounds, total)
-                if method == "auto" and can_second and st["status"] != 1:
-                    second_order = True
+            if method == "auto" and can_second and st["status"] != 1:
+                second_order = True
+                if self._dev_ties:
                     ctx.set_ties(None, None); ctx.set_pool_flags(POOL_SUM2, None)
-                    self._dev_ties = False; self._theta = {}
+                    self._dev_ties = False
+                self._theta = {}
         if second_order:
             st = self._run(ctx, nu0, total, tol=tol, method=_lib.METHODS["newton"], **kw)
             nu, psi = ctx.get_solution()

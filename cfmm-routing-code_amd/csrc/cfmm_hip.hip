@@ -410,8 +410,6 @@ int launch_cholesky(cfmm_ctx *ctx, int n, double *x)
 
 bool newton_supported(cfmm_ctx *ctx, const char **why)
 {
-    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k)
-        if (ctx->pools->bn[k].m) { *why = "k-asset pools are present (the smoothed evaluation covers two-asset pools)"; return false; }
     if (ctx->ng != ctx->n) { *why = "price ties are set"; return false; }
     if (ctx->comm && ctx->n_ranks > 1) { *why = "the pools are sharded over several ranks"; return false; }
     if ((size_t)(2 * ctx->n + 32) * sizeof(double) > 160 * 1024) { *why = "too many tokens for the LDS tile"; return false; }
@@ -419,10 +417,10 @@ bool newton_supported(cfmm_ctx *ctx, const char **why)
     return true;
 }
 
-// stableswap pools: the first-order iteration needs thousands of evaluations; constant-sum pools alone are
+// many stableswap pools: the first-order iteration needs thousands of evaluations; a few of them, and constant-sum pools, are
 // left to the first-order path (the host's active-set loop over kinks is quicker while it copes) with the second-order
 // method as the fall-back
-bool near_linear_pools(cfmm_ctx *ctx) { return ctx->pools->b2[CFMM_POOL_CURVE2].m > 0; }
+bool near_linear_pools(cfmm_ctx *ctx) { return ctx->pools->b2[CFMM_POOL_CURVE2].m >= CFMM_AUTO_NEWTON_MIN_STABLE; }
 
 int smooth_buffers(cfmm_ctx *ctx, bool hess)
 {
@@ -466,8 +464,24 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm)
     if (grid > 2LL * ctx->cus) grid = 2LL * ctx->cus;
     if (grid < 1) grid = 1;
     const size_t lds = (size_t)(2 * n + 32) * sizeof(double);
-    if (hess) hipLaunchKernelGGL(smooth_kernel<true>, dim3((unsigned)grid), dim3(SMOOTH_THREADS), lds, ctx->stream, a);
-    else hipLaunchKernelGGL(smooth_kernel<false>, dim3((unsigned)grid), dim3(SMOOTH_THREADS), lds, ctx->stream, a);
+    if (tiles > 0) {
+        if (hess) hipLaunchKernelGGL(smooth_kernel<true>, dim3((unsigned)grid), dim3(SMOOTH_THREADS), lds, ctx->stream, a);
+        else hipLaunchKernelGGL(smooth_kernel<false>, dim3((unsigned)grid), dim3(SMOOTH_THREADS), lds, ctx->stream, a);
+    }
+    // k-asset geo-mean pools: exact solutions and their exact Hessian blocks on top
+    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) {
+        const BucketN &bn = ctx->pools->bn[k];
+        if (!bn.m) continue;
+        const dim3 g2((unsigned)std::min<long long>((bn.m + 255) / 256, 8LL * ctx->cus)), blk(256);
+        const double *nup = ctx->nu;
+#define GN_LAUNCH(KK) do { if (hess) hipLaunchKernelGGL((gn_newton_kernel<KK, true>), g2, blk, 0, ctx->stream, bn, nup, ctx->sm_out, n, ctx->H, a.ldh); \
+                           else hipLaunchKernelGGL((gn_newton_kernel<KK, false>), g2, blk, 0, ctx->stream, bn, nup, ctx->sm_out, n, (double *)nullptr, a.ldh); } while (0)
+        switch (k) {
+        case 3: GN_LAUNCH(3); break; case 4: GN_LAUNCH(4); break; case 5: GN_LAUNCH(5); break;
+        case 6: GN_LAUNCH(6); break; case 7: GN_LAUNCH(7); break; default: GN_LAUNCH(8); break;
+        }
+#undef GN_LAUNCH
+    }
     HIP_TRY(ctx, hipGetLastError());
     return CFMM_OK;
 }

@@ -251,6 +251,74 @@ smooth_kernel(SmoothArgs a)
     }
 }
 
+// k-asset weighted geo-mean pools (arbitrage.py:65) inside the second-order iteration: strictly curved, so they are
+// NOT smoothed -- exact solution (pool_math.hpp's KKT: x_j = R_j e^{f(t - a_j)}), exact (generalised) Hessian.  With
+// A the legs that trade at the root t, the pool's value has, in log-prices and without its diag(nu * psi) term,
+//     H_jk = e^t (w_j delta_jk - w_j w_k / sum_A w),   j, k in A
+// (a leg's traded value is p_j c_j x_j = w_j e^t on either side of the fee; d t / d log p_k = w_k / sum_A w).
+// One pool per thread, psi / value through global atomics: this kernel runs a few dozen times per solve, the
+// leg-per-lane machinery of the exact evaluation kernel is not worth repeating here.
+template <int K, bool HESS>
+__global__ void __launch_bounds__(256)
+gn_newton_kernel(BucketN b, const double *__restrict__ nu, double *__restrict__ out, int n, double *__restrict__ H, int ldh)
+{
+    double vsum = 0.0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < b.m; i += (long long)gridDim.x * blockDim.x) {
+        double R[K], w[K], p[K], a[K];
+        int tok[K];
+        const double g = b.fee[i], lg = b.lfee[i];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            R[j] = b.R[i * K + j]; w[j] = b.w[i * K + j]; tok[j] = b.idx[i * K + j];
+            p[j] = nu[tok[j]];
+            a[j] = log(R[j] * p[j] / w[j]);
+        }
+        // root of the piecewise-linear residual F(t) = sum_j w_j f(t - a_j): bracket among its 2K breakpoints
+        double tL = -1.7976931348623157e308, fL = 0.0, tR = 1.7976931348623157e308, fR = 0.0;
+#pragma unroll
+        for (int q = 0; q < 2 * K; ++q) {
+            const double t = (q < K) ? a[q % K] : a[q % K] - lg;
+            double f = 0.0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) { const double u = t - a[j]; f += w[j] * (u < 0.0 ? u : (u > -lg ? u + lg : 0.0)); }
+            if (f <= 0.0 && t > tL) { tL = t; fL = f; }
+            if (f >= 0.0 && t < tR) { tR = t; fR = f; }
+        }
+        const double t = fL == 0.0 ? tL : (fR == 0.0 ? tR : tL - fL * (tR - tL) / (fR - fL));
+        const double et = exp(t);
+        double wa = 0.0, val = 0.0;
+        bool act[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const double u = t - a[j];
+            const bool wd = u < 0.0, dp = u > -lg;                 // withdrawn / deposited
+            act[j] = wd || dp;
+            double y = 0.0;
+            if (wd) y = -R[j] * expm1(u);                          // R - x,  x = R e^u
+            if (dp) y = -R[j] * expm1(u + lg) / g;                 // (R - x) / gamma,  x = R e^{u + lg}
+            if (y != 0.0) { unsafeAtomicAdd(&out[tok[j]], y); val += p[j] * y; }
+            if (act[j]) wa += w[j];
+        }
+        vsum += val;
+        if (HESS && wa > 0.0) {
+            const double s = et / wa;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (!act[j]) continue;
+#pragma unroll
+                for (int k = 0; k <= j; ++k) {
+                    if (!act[k]) continue;
+                    const double h = (j == k) ? et * w[j] - s * w[j] * w[j] : -s * w[j] * w[k];
+                    const int row = tok[j] > tok[k] ? tok[j] : tok[k], col = tok[j] > tok[k] ? tok[k] : tok[j];
+                    unsafeAtomicAdd(&H[(size_t)col * ldh + row], h);
+                }
+            }
+        }
+    }
+    vsum = wave_allsum(vsum);
+    if ((threadIdx.x & 63) == 0 && vsum != 0.0) { unsafeAtomicAdd(&out[n], vsum); unsafeAtomicAdd(&out[n + 1], vsum); }
+}
+
 // tenders of the smoothed solution, slot-major [2][m] like trades2_kernel: what cfmm_get_trades2 returns after a
 // second-order solve -- the primal point the certificates were computed on.  Both directions are (slightly) open,
 // so a pool both tenders and receives each token, as the reference's Delta_i, Lambda_i >= 0 allow (arbitrage.py:51-52).

@@ -42,11 +42,12 @@ enum {
     CFMM_E_UNSUPPORTED = -7 /* the requested method cannot take this problem  */
 };
 
+#define CFMM_AUTO_NEWTON_MIN_STABLE 4096
 /* outer iteration of cfmm_solve */
 enum {
-    CFMM_METHOD_AUTO = 0,       /* second order when the network holds stableswap pools and only two-asset pools (the
-                                   near-linear case the first-order iteration crawls on), else first order; a
-                                   first-order run that ends without its certificates is handed on when possible    */
+    CFMM_METHOD_AUTO = 0,       /* second order when the network holds >= CFMM_AUTO_NEWTON_MIN_STABLE stableswap pools
+                                   (the near-linear case the first-order iteration crawls on at scale), else first
+                                   order; a first-order run that ends without its certificates is handed on         */
     CFMM_METHOD_LBFGS = 1,      /* projected L-BFGS in log-prices, fully on-device (hipGraph)                       */
     CFMM_METHOD_NEWTON = 2      /* barrier-smoothed dual Newton: dense n x n Hessian, blocked Cholesky on-device    */
 };
@@ -132,8 +133,9 @@ int cfmm_set_ties(cfmm_ctx *ctx, int n_groups, const int32_t *grp, const double 
  * optionally the diagonal metric.  This is the unit BASELINE.json's metric counts. */
 int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi, double *diag /* or NULL */);
 
-/* the barrier-smoothed evaluation behind CFMM_METHOD_NEWTON (two-asset pools only): every pool direction solves
+/* the barrier-smoothed evaluation behind CFMM_METHOD_NEWTON: every direction of every two-asset pool solves
  *      max_{D > 0}  nu_out L(D) - nu_in D + mu log D        (constant sum: + mu log(R_out/gamma - D))
+ * (k-asset geo-mean pools enter unsmoothed, with their exact solution and generalised Hessian);
  * value = sum of those optima, trade = sum nu'(L - D), psi[n] = sum A_i (L - D), and -- if H is not NULL -- the
  * n x n Hessian of `value` in log-prices minus its diag(nu * psi) term, column-major, LOWER triangle only. */
 int cfmm_eval_smooth(cfmm_ctx *ctx, const double *nu, double mu, double *value, double *trade, double *psi, double *H);

@@ -11,7 +11,8 @@ both solve the same one-dimensional problem
 
     max_{D > 0}  nu_out L(D) - nu_in D + mu log D          (constant sum: + mu log(R_out/gamma - D))
 
-per pool direction, L = forward exchange function of the pool (arbitrage.py:60,63-74).
+per pool direction, L = forward exchange function of the pool (arbitrage.py:60,63-74).  k-asset geo-mean pools
+(arbitrage.py:65) enter unsmoothed, with their exact solution and generalised Hessian.
 
 PARITY UNPINNED by the reference (it has no smoothed evaluation to compare with): the smoothed quantities are
 pinned against finite differences of themselves and, through the solves they drive, against the SciPy primal
@@ -116,10 +117,28 @@ def smooth_eval(net, nu, mu, hessian=False, flags=None):
     psi = np.bincount(to, L, n) - np.bincount(ti, D, n)
     trade = float((nu[to] * L - nu[ti] * D).sum())
     out = dict(value=float(val.sum()), trade=trade, psi=psi, D=D, L=L, branches=br)
+    H = np.zeros((n, n)) if hessian else None
     if hessian:
         wi = nu[ti]; wo = -L1 * nu[to]
-        H = np.zeros((n, n))
         np.add.at(H, (ti, ti), kappa * wi * wi); np.add.at(H, (to, to), kappa * wo * wo)
         np.add.at(H, (ti, to), kappa * wi * wo); np.add.at(H, (to, ti), kappa * wi * wo)
+    # k-asset geo-mean pools (arbitrage.py:65) are not smoothed: exact solution, exact generalised Hessian.  With A
+    # the legs that trade, p_j c_j x_j = w_j m on either side of the fee (m = the KKT multiplier), so the block is
+    # m (diag(w_A) - w_A w_A' / sum w_A); m is recovered here from the traded legs themselves.
+    from oracle import pools_np
+    for k, b in net.get("gn", {}).items():
+        for i in range(b["R"].shape[1]):
+            tok = b["idx"][:, i]; R = b["R"][:, i]; w = b["w"][:, i]; g = b["fee"][i]; p = nu[tok]
+            y, v = pools_np.arb_geomean_n(R, w, g, p)
+            np.add.at(out["psi"], tok, y)
+            out["value"] += v; out["trade"] += v
+            act = y != 0
+            if hessian and act.any():
+                x = np.where(y > 0, R - y, R - g * y)
+                m = np.mean((p * x / np.where(y > 0, 1.0, g) / w)[act])
+                wa = np.where(act, w, 0.0)
+                blk = m * (np.diag(wa) - np.outer(wa, wa) / wa.sum())
+                H[np.ix_(tok, tok)] += blk
+    if hessian:
         out["H"] = H
     return out

@@ -198,14 +198,64 @@ def test_many_constant_sum_pools_both_paths_agree():
 
 
 def test_second_order_refuses_what_it_cannot_take():
-    net = synthetic.config("C3", scale=0.01)
+    net = synthetic.config("C2", scale=0.1)
     p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
-    with pytest.raises(cfmm.CfmmError, match="k-asset"):
-        p.solve(method="newton")
     with pytest.raises(ValueError):
         p.solve(method="simplex")
-    assert p.solve(method="auto") > 0 and p.stats["method"] == _lib.METHODS["lbfgs"]       # falls back to first order
     ctx = p._ensure_ctx()
+    ctx.set_utility(net["c"])
+    n = net["n_tokens"]
+    grp = np.arange(n, dtype=np.int32); grp[1] = 0; grp[2:] -= 1         # tokens 0 and 1 tied
+    ctx.set_ties(grp, np.zeros(n))
+    with pytest.raises(cfmm.CfmmError, match="ties"):
+        ctx.solve(net["prices"], method="newton")
     with pytest.raises(cfmm.CfmmError):
         ctx.eval_smooth(net["prices"], 1e-3)
+    ctx.set_ties(None, None)
+    with pytest.raises(cfmm.CfmmError):
+        ctx.eval_smooth(net["prices"], 0.0)                              # mu must be positive
+    assert ctx.solve(net["prices"], method="newton")["status"] == 1
+    p.close()
+
+
+@pytest.mark.parametrize("mu", [1e-2, 1e-8])
+def test_smoothed_evaluation_with_k_asset_pools(mu):
+    """k-asset geo-mean pools ride along unsmoothed: exact solution, exact generalised Hessian"""
+    net = synthetic.make_network(40, m_cp2=300, m_w2=200, m_gn=400, m_curve2=200, seed=8)
+    n = net["n_tokens"]
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    ctx = p._ensure_ctx()
+    nu = net["prices"] * np.exp(np.random.default_rng(2).normal(0, 0.05, n))
+    val, tr, psi, H = ctx.eval_smooth(nu, mu, want_hessian=True)
+    o = barrier_np.smooth_eval(net, nu, mu, hessian=True)
+    assert abs(val - o["value"]) <= 1e-10 * max(1.0, abs(o["value"]))
+    assert abs(tr - o["trade"]) <= 1e-10 * max(1.0, abs(o["trade"]))
+    assert np.abs(psi - o["psi"]).max() <= 1e-10 * np.abs(o["psi"]).max()
+    assert np.abs(np.tril(H) - np.tril(o["H"])).max() <= 1e-8 * np.abs(o["H"]).max()
+    p.close()
+
+
+def test_shipped_instances_through_the_second_order_path():
+    """arbitrage.py / liquidation.py / two-asset.py as shipped (Balancer + Uniswap-v2 + a constant-sum pool each)
+    against the golden optima (tests/golden/shipped_instances.json)"""
+    from helpers import golden, shipped_cases
+    g = golden()
+    for name, inst in shipped_cases():
+        p = problem_of(inst)
+        v = p.solve(tol=1e-7, method="newton")
+        want = g[name]["survey"]["value"]
+        assert p.stats["method"] == _lib.METHODS["newton"], name
+        assert p.status == "optimal", (name, p.status, p.gap, p.infeas)
+        assert abs(v - want) <= 2e-6 * max(1.0, abs(want)), (name, v, want)
+        p.close()
+
+
+def test_second_order_on_the_mixed_config3_network():
+    """C3 at 5 % (Uniswap-v2 + 2-asset Balancer + 3..8-asset Balancer pools): both methods, same optimum"""
+    net = synthetic.config("C3", scale=0.05)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    v1 = p.solve(method="lbfgs"); s1 = p.status
+    v2 = p.solve(method="newton"); s2 = p.status
+    assert s1 == "optimal" and s2 == "optimal" and p.stats["method"] == _lib.METHODS["newton"]
+    assert abs(v1 - v2) <= 2e-6 * max(1.0, abs(v1)), (v1, v2)
     p.close()

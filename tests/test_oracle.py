@@ -182,3 +182,23 @@ def test_barrier_oracle_tends_to_the_exact_pool_solutions():
             assert sub <= prev * (1 + 1e-9)
         prev = sub
     assert np.abs(e["psi"] - exact_psi).max() <= 1e-4 * np.abs(exact_psi).max()
+
+
+def test_barrier_oracle_k_asset_block_by_finite_differences():
+    """the unsmoothed k-asset geo-mean part of oracle/barrier_np.py: gradient nu * psi and the generalised Hessian
+    m (diag(w_A) - w_A w_A' / sum w_A) against central differences (a generic point: no leg sits on a kink)"""
+    from oracle import barrier_np
+    from cfmm import synthetic
+    net = synthetic.make_network(10, m_cp2=5, m_gn=60, seed=4, gn_sizes=(3, 6))
+    n = net["n_tokens"]
+    s0 = np.log(net["prices"]) + np.random.default_rng(7).normal(0, 0.05, n)
+    mu = 1e-3
+    e0 = barrier_np.smooth_eval(net, np.exp(s0), mu, hessian=True)
+    grad = np.exp(s0) * e0["psi"]
+    hess = e0["H"] + np.diag(grad)
+    eps = 1e-6
+    for j in range(n):
+        d = np.zeros(n); d[j] = eps
+        gp = np.exp(s0 + d) * barrier_np.smooth_eval(net, np.exp(s0 + d), mu)["psi"]
+        gm = np.exp(s0 - d) * barrier_np.smooth_eval(net, np.exp(s0 - d), mu)["psi"]
+        assert np.abs((gp - gm) / (2 * eps) - hess[:, j]).max() <= 2e-5 * np.abs(hess).max(), j
