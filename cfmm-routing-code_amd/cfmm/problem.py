@@ -387,7 +387,7 @@ class Problem:
         self._tol = tol
         kw = dict(max_evals=max_evals, memory=memory, iters_per_graph=iters_per_graph)
         total = dict(evals=0, iters=0, wall_seconds=0.0, device_seconds=0.0, rounds=0)
-        can_second = not (bool(self._comm) and self._comm[0] > 1) and getattr(ctx, "second_order", False)
+        can_second = getattr(ctx, "second_order", False)
         if method not in _lib.METHODS:
             raise ValueError(f"method {method!r}: expected one of {sorted(_lib.METHODS)}")
         # auto: many stableswap pools -> second order straight away (first order needs thousands of evaluations there);

@@ -411,7 +411,6 @@ int launch_cholesky(cfmm_ctx *ctx, int n, double *x)
 bool newton_supported(cfmm_ctx *ctx, const char **why)
 {
     if (ctx->ng != ctx->n) { *why = "price ties are set"; return false; }
-    if (ctx->comm && ctx->n_ranks > 1) { *why = "the pools are sharded over several ranks"; return false; }
     if ((size_t)(2 * ctx->n + 32) * sizeof(double) > 160 * 1024) { *why = "too many tokens for the LDS tile"; return false; }
     *why = "";
     return true;
@@ -483,6 +482,11 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm)
 #undef GN_LAUNCH
     }
     HIP_TRY(ctx, hipGetLastError());
+    if (ctx->comm) {                        // pool-sharded: every rank needs the whole [psi | value | trade] and the whole Hessian
+        int rc = g_rccl.AllReduce(ctx->sm_out, ctx->sm_out, (size_t)(n + 2), NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
+        if (rc == 0 && hess) rc = g_rccl.AllReduce(ctx->H, ctx->H, (size_t)hess_ld(n) * hess_nr(n), NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
+        if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed (%d)", rc);
+    }
     return CFMM_OK;
 }
 
@@ -533,6 +537,16 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         s[j] = sj; nu[j] = std::exp(sj);
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, mask.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->comm) {                        // the barrier terms of the pools of every rank (the utility's are replicated)
+        long long ge = 0;
+        for (int j = 0; j < n; ++j) ge += ct[j] == CFMM_GE;
+        double cnt = (double)(nbar - ge);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, &cnt, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if (g_rccl.AllReduce(ctx->sm_vec, ctx->sm_vec, 1, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream) != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed");
+        HIP_TRY(ctx, hipMemcpyAsync(&cnt, ctx->sm_vec, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        nbar = (long long)cnt + ge;
+    }
 
     int evals = evals_before, steps = 0, status = 0;
     double arb_x = 0.0;

@@ -259,3 +259,39 @@ def test_second_order_on_the_mixed_config3_network():
     assert s1 == "optimal" and s2 == "optimal" and p.stats["method"] == _lib.METHODS["newton"]
     assert abs(v1 - v2) <= 2e-6 * max(1.0, abs(v1)), (v1, v2)
     p.close()
+
+
+def test_second_order_pool_sharded_path_with_a_one_rank_communicator():
+    """the pool-sharded second-order control flow on ONE GPU: RCCL all-reduce of [psi | value | trade], of the dense
+    Hessian and of the barrier count, on the library's stream -- a communicator of one rank runs exactly what every
+    rank of an 8-GPU job runs; same optimum as the unsharded solve"""
+    import subprocess, sys, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, os, json
+sys.path[:0] = [%r, %r, %r]
+import numpy as np
+import torch, torch.distributed as dist
+import cfmm
+from cfmm import synthetic
+from test_gpu_newton import _basket
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+net = synthetic.config("C5", scale=0.02)
+h, t = _basket(net)
+u = cfmm.Liquidate(h, t)
+p = cfmm.distributed.sharded_problem(net, u, dist=dist, device=0)
+v = p.solve(method="newton")
+q = cfmm.Problem.from_network(net, utility=u)
+w = q.solve(method="newton")
+print(json.dumps(dict(v=v, w=w, status=p.status, method=p.stats["method"], steps=p.stats["newton_steps"], steps1=q.stats["newton_steps"],
+                      ranks=p.stats["n_ranks"], gap=p.gap, infeas=p.infeas)))
+dist.destroy_process_group()
+''' % (root, os.path.join(root, "cfmm-routing-code_amd"), os.path.join(root, "tests"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["status"] == "optimal" and out["ranks"] == 1 and out["method"] == _lib.METHODS["newton"]
+    assert out["gap"] <= 1e-6 and out["infeas"] <= 1e-6
+    assert abs(out["v"] - out["w"]) <= 1e-6 * abs(out["w"])
