@@ -125,45 +125,60 @@ __device__ __forceinline__ Y2 pool_sum2(double Ra, double Rb, double g, double p
 // Curve-style x + y - alpha/(xy) (not in the reference; BASELINE config 5).  y(x) on the level
 // set is the positive root of x y^2 + (x^2 - C x) y - alpha = 0; the optimum equates the
 // marginal price m = phi_x/phi_y with p_in/(gamma p_out): safeguarded Newton in x.
-__device__ __forceinline__ double curve_y(double x, double C, double al)
+// (reciprocals / square roots from the hardware seeds, rcp_nr / rsqrt_nr: the IEEE sequences made this bucket 224 us
+//  for 5e5 pools)
+__device__ __forceinline__ double sqrt_nr(double v) { return v > 0.0 ? v * rsqrt_nr(v) : 0.0; }
+
+__device__ __forceinline__ double curve_y(double x, double ix, double C, double al)
 {
-    const double b = C - x;
-    return 0.5 * (b + sqrt(b * b + 4.0 * al / x));
+    const double b = C - x, q = 4.0 * al * ix;
+    const double sq = sqrt_nr(fma(b, b, q));
+    return b >= 0.0 ? 0.5 * (b + sq) : 0.5 * q * rcp_nr(sq - b);        // (no cancellation past the knee, x > C)
+}
+
+// marginal price m(x) = phi_x / phi_y on the level set minus rho, and its derivative along the curve
+__device__ __forceinline__ void curve_price(double x, double C, double al, double rho, double &h, double &dh, double &y)
+{
+    const double ix = rcp_nr(x);
+    y = curve_y(x, ix, C, al);
+    const double iy = rcp_nr(y);
+    const double t = al * ix * iy;                       // alpha / (x y)
+    const double fx = fma(t, ix, 1.0), fy = fma(t, iy, 1.0);
+    const double ify = rcp_nr(fy);
+    const double m = fx * ify;
+    h = m - rho;
+    const double dfx = -t * ix * fma(-iy, m, 2.0 * ix);  // y' = -m
+    const double dfy = -t * iy * fma(-2.0 * iy, m, ix);
+    dh = (dfx * fy - fx * dfy) * ify * ify;
 }
 
 __device__ __forceinline__ bool curve_dir(double Rin, double Rout, double g, double al, double C,
                                           double pin, double pout, double &yin, double &yout)
 {
-    const double rho = pin / (g * pout);
-    const double m0 = (1.0 + al / (Rin * Rin * Rout)) / (1.0 + al / (Rin * Rout * Rout));
-    if (!(m0 > rho)) return false;
+    const double rho = pin * rcp_nr(g * pout);
+    double h, dh, y;
+    curve_price(Rin, C, al, rho, h, dh, y);
+    if (!(h > 0.0)) return false;
     double lo = Rin, hi = Rin * 2.0;
     for (int it = 0; it < 200; ++it) {
-        const double yy = curve_y(hi, C, al);
-        const double hh = (1.0 + al / (hi * hi * yy)) / (1.0 + al / (hi * yy * yy)) - rho;
-        if (hh <= 0.0) break;
+        curve_price(hi, C, al, rho, h, dh, y);
+        if (h <= 0.0) break;
         lo = hi; hi *= 2.0;
         SCHED_FENCE();
     }
     double x = lo;
     for (int it = 0; it < 100; ++it) {
-        const double yy = curve_y(x, C, al);
-        const double fx = 1.0 + al / (x * x * yy), fy = 1.0 + al / (x * yy * yy);
-        const double hx = fx / fy - rho;
-        if (hx > 0.0) lo = x; else hi = x;
-        const double yp = -fx / fy;
-        const double dfx = -2.0 * al / (x * x * x * yy) - al / (x * x * yy * yy) * yp;
-        const double dfy = -al / (x * x * yy * yy) - 2.0 * al / (x * yy * yy * yy) * yp;
-        const double dh = (dfx * fy - fx * dfy) / (fy * fy);
-        double xn = x - hx / dh;
+        curve_price(x, C, al, rho, h, dh, y);
+        if (h > 0.0) lo = x; else hi = x;
+        double xn = x - h * rcp_nr(dh);
         if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-        const bool done = fabs(xn - x) <= 4e-16 * x;
+        const bool done = fabs(xn - x) <= 2e-15 * x;
         x = xn;
         if (done) break;
         SCHED_FENCE();
     }
-    yin = -(x - Rin) / g;
-    yout = Rout - curve_y(x, C, al);
+    yin = -(x - Rin) * rcp_nr(g);
+    yout = Rout - curve_y(x, rcp_nr(x), C, al);
     return true;
 }
 

@@ -25,7 +25,6 @@ struct Fwd { double L, L1, L2; };       // L(D), L'(D), L''(D)
 
 // (reciprocals and square roots through rcp_nr / rsqrt_nr, pool_math.hpp: <= ~1 ulp, a third of the
 //  instructions of the IEEE sequences -- this path is fp64-issue bound like the exact evaluation)
-__device__ __forceinline__ double sqrt_nr(double v) { return v > 0.0 ? v * rsqrt_nr(v) : 0.0; }
 
 __device__ __forceinline__ double curve_y_stable(double x, double ix, double C, double al)
 {
