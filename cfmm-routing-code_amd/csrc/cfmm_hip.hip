@@ -132,6 +132,8 @@ struct cfmm_ctx {
     // second-order method (allocated on first use)
     double *sm_out = nullptr, *sm_vec = nullptr, *H = nullptr, *Dinv = nullptr;
     double *sm_ws[CFMM_POOL_KINDS2] = {};   // warm starts of the smoothed per-direction solves
+    double *sm_slo = nullptr;               // low-order log-prices of the last second-order solve (smooth.hpp)
+    bool slo_active = false;
     int *sm_mask = nullptr, *sm_info = nullptr;
     double mu_last = 0.0;              // barrier weight of the last solve (0: first-order, exact tenders)
 };
@@ -428,6 +430,7 @@ int smooth_buffers(cfmm_ctx *ctx, bool hess)
         int rc = dev_upload<double>(ctx, &ctx->sm_out, nullptr, n + 4, nullptr); if (rc) return rc;
         rc = dev_upload<double>(ctx, &ctx->sm_vec, nullptr, 2 * (size_t)n + 4, nullptr); if (rc) return rc;
         rc = dev_upload<int>(ctx, &ctx->sm_mask, nullptr, n + 4, nullptr); if (rc) return rc;
+        rc = dev_upload<double>(ctx, &ctx->sm_slo, nullptr, n + 4, nullptr); if (rc) return rc;
         const size_t lds = (size_t)(2 * n + 32) * sizeof(double);
         if ((rc = set_lds_attr(ctx, smooth_kernel<false>, lds))) return rc;
         if ((rc = set_lds_attr(ctx, smooth_kernel<true>, lds))) return rc;
@@ -445,7 +448,7 @@ int smooth_buffers(cfmm_ctx *ctx, bool hess)
 }
 
 // one smoothed evaluation at the prices already in ctx->nu (device)
-int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm)
+int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm, bool with_slo)
 {
     const int n = ctx->n;
     SmoothArgs a = {};
@@ -455,12 +458,13 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm)
     const int order[4] = {CFMM_POOL_CURVE2, CFMM_POOL_W2, CFMM_POOL_CP2, CFMM_POOL_SUM2};
     long long tiles = 0;
     for (int q = 0; q < 4; ++q) { tiles += (a.b2[order[q]].m + 63) / 64; a.tile_end[q] = (int)tiles; }
-    a.ntiles = (int)tiles; a.n = n; a.nu = ctx->nu; a.mu = mu; a.out = ctx->sm_out; a.H = hess ? ctx->H : nullptr; a.ldh = hess_ld(n);
+    a.ntiles = (int)tiles; a.n = n; a.nu = ctx->nu; a.slo = with_slo ? ctx->sm_slo : nullptr; a.mu = mu; a.out = ctx->sm_out; a.H = hess ? ctx->H : nullptr; a.ldh = hess_ld(n);
     HIP_TRY(ctx, hipMemsetAsync(ctx->sm_out, 0, (size_t)(n + 2) * sizeof(double), ctx->stream));
     if (hess) HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, (size_t)hess_ld(n) * hess_nr(n) * sizeof(double), ctx->stream));
     const int per_block = SMOOTH_THREADS / 64;
     long long grid = (tiles + per_block - 1) / per_block;
-    if (grid > 2LL * ctx->cus) grid = 2LL * ctx->cus;
+    static const int grid_mult = getenv("CFMM_SMOOTH_GRID_MULT") ? std::max(1, atoi(getenv("CFMM_SMOOTH_GRID_MULT"))) : 1;     // tuning knob
+    if (grid > (long long)grid_mult * ctx->cus) grid = (long long)grid_mult * ctx->cus;
     if (grid < 1) grid = 1;
     const size_t lds = (size_t)(2 * n + 32) * sizeof(double);
     if (tiles > 0) {
@@ -473,8 +477,8 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm)
         if (!bn.m) continue;
         const dim3 g2((unsigned)std::min<long long>((bn.m + 255) / 256, 8LL * ctx->cus)), blk(256);
         const double *nup = ctx->nu;
-#define GN_LAUNCH(KK) do { if (hess) hipLaunchKernelGGL((gn_newton_kernel<KK, true>), g2, blk, 0, ctx->stream, bn, nup, ctx->sm_out, n, ctx->H, a.ldh); \
-                           else hipLaunchKernelGGL((gn_newton_kernel<KK, false>), g2, blk, 0, ctx->stream, bn, nup, ctx->sm_out, n, (double *)nullptr, a.ldh); } while (0)
+#define GN_LAUNCH(KK) do { if (hess) hipLaunchKernelGGL((gn_newton_kernel<KK, true>), g2, blk, 0, ctx->stream, bn, nup, a.slo, ctx->sm_out, n, ctx->H, a.ldh); \
+                           else hipLaunchKernelGGL((gn_newton_kernel<KK, false>), g2, blk, 0, ctx->stream, bn, nup, a.slo, ctx->sm_out, n, (double *)nullptr, a.ldh); } while (0)
         switch (k) {
         case 3: GN_LAUNCH(3); break; case 4: GN_LAUNCH(4); break; case 5: GN_LAUNCH(5); break;
         case 6: GN_LAUNCH(6); break; case 7: GN_LAUNCH(7); break; default: GN_LAUNCH(8); break;
@@ -492,12 +496,14 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm)
 
 struct SmoothEval { std::vector<double> psi; double value = 0.0, trade = 0.0; };
 
-int smooth_eval_host(cfmm_ctx *ctx, const std::vector<double> &nu, double mu, bool hess, SmoothEval &e, bool warm = true)
+int smooth_eval_host(cfmm_ctx *ctx, const std::vector<double> &nu, double mu, bool hess, SmoothEval &e, bool warm = true,
+                     const std::vector<double> *slo = nullptr)
 {
     const int n = ctx->n;
     int rc = smooth_buffers(ctx, hess); if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, nu.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = launch_smooth(ctx, mu, hess, warm))) return rc;
+    if (slo) HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_slo, slo->data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_smooth(ctx, mu, hess, warm, slo != nullptr))) return rc;
     e.psi.resize(n + 2);
     HIP_TRY(ctx, hipMemcpyAsync(e.psi.data(), ctx->sm_out, (size_t)(n + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -574,15 +580,19 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     if ((rc = exact(nu))) return rc;
     double dual = arb_x;
     for (int j = 0; j < n; ++j) dual += (nu[j] - c[j]) * h[j];
-    double mu = 0.1 * std::max(std::fabs(dual), 1e-300) / (double)std::max<long long>(nbar, 1);
+    static const double mu0_scale = getenv("CFMM_NEWTON_MU0") ? atof(getenv("CFMM_NEWTON_MU0")) : 0.1;                      // tuning knob
+    double mu = mu0_scale * std::max(std::fabs(dual), 1e-300) / (double)std::max<long long>(nbar, 1);
     const double sigma = (o.barrier_shrink > 0.0 && o.barrier_shrink < 1.0) ? o.barrier_shrink : 0.2;
     const int max_newton = o.max_newton > 0 ? o.max_newton : 200;
     double gap = 1.0, infeas = 1.0, primal = 0.0, reg = 0.0;
     const bool trace = getenv("CFMM_NEWTON_TRACE") != nullptr;
     int stalled = 0;
+    double best_infeas = 1.7976931348623157e308;
+    std::vector<double> slo(n, 0.0), slo2(n, 0.0);       // low-order log-prices (smooth.hpp: apply_slo)
+    bool slo_on = false;
     SmoothEval e, e2;
     for (;;) {
-        if ((rc = smooth_eval_host(ctx, nu, mu, true, e))) return rc;
+        if ((rc = smooth_eval_host(ctx, nu, mu, true, e, true, slo_on ? &slo : nullptr))) return rc;
         ++evals;
         const double gmu = assemble(nu, e, mu, &G, &Hd);
         if (!std::isfinite(gmu)) { status = CFMM_E_NUMERIC; break; }
@@ -642,9 +652,9 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         double dec = 0.0, dmax = 0.0;
         for (int j = 0; j < n; ++j) { if (mask[j]) d[j] = 0.0; dec -= G[j] * d[j]; dmax = std::max(dmax, std::fabs(d[j])); }
         if (!std::isfinite(dec) || !std::isfinite(dmax)) { status = CFMM_E_NUMERIC; break; }
-        if (final_mu) {                        // centring at the final weight: stop (before moving, so that nu, psi and the
-            stalled = (dec <= 1e-15 * std::max(1.0, std::fabs(gmu))) ? stalled + 1 : 0;     // certificates stay those of one point)
-            if (stalled >= 3) { status = 2; break; }                   // once the steps fall below the fp64 resolution of the prices
+        if (final_mu) {                        // centring at the final weight: give up (before moving, so that nu, psi and the
+            if (infeas < 0.5 * best_infeas) { best_infeas = infeas; stalled = 0; } else ++stalled;     // certificates stay those of
+            if (stalled >= 4) { status = 2; break; }                                                   // one point) once it stops helping
         }
         // step length: cap on the log-price move, fraction to the boundary nu > c, Armijo back-tracking on the smoothed dual
         double t = std::min(1.0, o.max_step / std::max(dmax, 1e-300));
@@ -652,9 +662,18 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             if (ct[j] == CFMM_GE && c[j] > 0.0 && d[j] < 0.0) t = std::min(t, 0.9 * (s[j] - std::log(c[j])) / -d[j]);
         const double t_first = t;
         bool moved = false;
+        bool slo2_on = false;
         for (int ls = 0; ls < 40; ++ls) {
-            for (int j = 0; j < n; ++j) { s2[j] = s[j] + t * d[j]; nu2[j] = mask[j] ? nu[j] : std::exp(s2[j]); }
-            if ((rc = smooth_eval_host(ctx, nu2, mu, false, e2))) return rc;
+            // steps below the fp64 resolution of the log-prices go into their low-order part (smooth.hpp: apply_slo)
+            double lo_max = 0.0;
+            for (int j = 0; j < n; ++j) lo_max = std::max(lo_max, std::fabs(slo[j] + t * d[j]));
+            const bool small = final_mu && t * dmax < 1e-11 && lo_max < 1e-10;
+            for (int j = 0; j < n; ++j) {
+                if (small) { s2[j] = s[j]; nu2[j] = nu[j]; slo2[j] = mask[j] ? 0.0 : slo[j] + t * d[j]; }
+                else { s2[j] = s[j] + slo[j] + t * d[j]; nu2[j] = mask[j] ? nu[j] : std::exp(s2[j]); slo2[j] = 0.0; }
+            }
+            slo2_on = small;
+            if ((rc = smooth_eval_host(ctx, nu2, mu, false, e2, true, slo2_on ? &slo2 : nullptr))) return rc;
             ++evals;
             const double g2 = assemble(nu2, e2, mu, nullptr, nullptr);
             if (g2 <= gmu - o.armijo * t * dec || dec <= 1e-13 * std::fabs(gmu)) { moved = true; break; }
@@ -662,7 +681,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         }
         if (trace) fprintf(stderr, "[newton]    dec %.3e |d| %.3e t %.3e (first %.3e) moved %d\n", dec, dmax, t, t_first, (int)moved);
         if (!moved) { status = 2; break; }
-        s = s2; nu = nu2;
+        s = s2; nu = nu2; slo = slo2; slo_on = slo2_on;
         if (final_mu) continue;                                        // the weight is small enough: finish centring at it
         if (dec < 10.0 * mu * (double)nbar && (t == t_first || dec < 1e-3 * mu * (double)nbar)) mu *= sigma;
     }
@@ -675,6 +694,8 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     if ((int)e.psi.size() == n) std::memcpy(ctx->hsol + n, e.psi.data(), n * sizeof(double));
     ctx->hsol_valid = true; ctx->have_nu = true;
     ctx->mu_last = mu;
+    ctx->slo_active = slo_on;
+    if (slo_on) { HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_slo, slo.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
     const auto t1 = std::chrono::steady_clock::now();
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
@@ -807,7 +828,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     ctx->pools.reset();
     if (ctx->flags2) (void)hipFree(ctx->flags2);
     if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
-    for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
     void *ptrs[] = {ctx->c, ctx->h, ctx->off, ctx->glo, ctx->ghi, ctx->ctype, ctx->grp, ctx->nu, ctx->nu_acc, ctx->psi_acc,
                     ctx->psi_t, ctx->nu0, ctx->s, ctx->s_t, ctx->Gs, ctx->Gs_t, ctx->d, ctx->Ds, ctx->S, ctx->Y, ctx->rho,
                     ctx->acc, ctx->st, ctx->ts};
@@ -979,7 +1000,7 @@ int cfmm_set_nu(cfmm_ctx *ctx, const double *nu)
     for (int j = 0; j < ctx->n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "set_nu: nu[%d] = %g is not a positive finite price", j, nu[j]);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu_acc, nu, ctx->n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the caller's (pageable) buffer may go away after we return
-    ctx->have_nu = true; ctx->hsol_valid = false; ctx->mu_last = 0.0;
+    ctx->have_nu = true; ctx->hsol_valid = false; ctx->mu_last = 0.0; ctx->slo_active = false;
     return CFMM_OK;
 }
 
@@ -1195,11 +1216,12 @@ int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda)
     const dim3 grid((unsigned)((b.m + 255) / 256)), blk(256);
     if (ctx->mu_last > 0.0) {              // after a second-order solve: the smoothed primal point
         const double mu = ctx->mu_last;
+        const double *slo = ctx->slo_active ? ctx->sm_slo : nullptr;
         switch (kind) {
-        case 0: hipLaunchKernelGGL(smooth_trades_kernel<0>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, mu, dd, dl); break;
-        case 1: hipLaunchKernelGGL(smooth_trades_kernel<1>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, mu, dd, dl); break;
-        case 2: hipLaunchKernelGGL(smooth_trades_kernel<2>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, mu, dd, dl); break;
-        default: hipLaunchKernelGGL(smooth_trades_kernel<3>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, mu, dd, dl); break;
+        case 0: hipLaunchKernelGGL(smooth_trades_kernel<0>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, slo, mu, dd, dl); break;
+        case 1: hipLaunchKernelGGL(smooth_trades_kernel<1>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, slo, mu, dd, dl); break;
+        case 2: hipLaunchKernelGGL(smooth_trades_kernel<2>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, slo, mu, dd, dl); break;
+        default: hipLaunchKernelGGL(smooth_trades_kernel<3>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, slo, mu, dd, dl); break;
         }
     } else
     switch (kind) {

@@ -147,6 +147,7 @@ struct SmoothArgs {
     int tile_end[4];            // cumulative wave-tiles (64 pools) in the order curve2, w2, cp2, sum2
     int ntiles, n;
     const double *nu;           // [n] prices
+    const double *slo;          // [n] low-order part of the log-prices (see smooth_tile), or null
     double mu;
     double *out;                // [n] psi_mu | [n] sum of branch values | [n + 1] sum nu'(L - D)   (zeroed by the host)
     double *H;                  // [n x n] column-major, lower triangle gets the pools' part (zeroed by the host); may be null
@@ -172,6 +173,17 @@ __device__ __forceinline__ void smooth_pool(const Bucket2 &b, long long i, doubl
     }
 }
 
+// Low-order log-prices.  Near-linear pools react to price changes far below the fp64 resolution of log nu (a
+// partially filled constant-sum pool sets its fill through a price difference of ~1e-13), so the last Newton steps
+// cannot be added to the log-prices themselves.  They are carried in a separate vector s_lo instead and enter every
+// pool direction through its own exact first-order response  dD = -kappa (u, v).(s_lo_in, s_lo_out),  dL = L' dD.
+__device__ __forceinline__ void apply_slo(Branch &br, double u, double v, double din, double dout)
+{
+    const double dD = -br.kappa * fma(u, din, v * dout);
+    br.D += dD;
+    br.L = fma(br.L1, dD, br.L);
+}
+
 template <int KIND, bool HESS>
 __device__ __forceinline__ void smooth_tile(const Bucket2 &b, long long i0, int lane, const double *nu_s, double *psi_s,
                                             const SmoothArgs &a, double &vsum, double &tsum)
@@ -184,6 +196,11 @@ __device__ __forceinline__ void smooth_tile(const Bucket2 &b, long long i0, int 
     Branch ab, ba;
     smooth_pool<KIND>(b, i, pa, pb, a.mu, ab, ba, (KIND != 2 && i0 + lane < b.m) ? a.ws[KIND] : nullptr);
     if (!live) return;
+    if (a.slo) {
+        const double da = a.slo[ia], db = a.slo[ib];
+        apply_slo(ab, pa, -ab.L1 * pb, da, db);
+        apply_slo(ba, pb, -ba.L1 * pa, db, da);
+    }
     const double ya = ba.L - ab.D, yb = ab.L - ba.D;
     unsafeAtomicAdd(&psi_s[ia], ya);
     unsafeAtomicAdd(&psi_s[ib], yb);
@@ -259,7 +276,8 @@ smooth_kernel(SmoothArgs a)
 // leg-per-lane machinery of the exact evaluation kernel is not worth repeating here.
 template <int K, bool HESS>
 __global__ void __launch_bounds__(256)
-gn_newton_kernel(BucketN b, const double *__restrict__ nu, double *__restrict__ out, int n, double *__restrict__ H, int ldh)
+gn_newton_kernel(BucketN b, const double *__restrict__ nu, const double *__restrict__ slo, double *__restrict__ out, int n,
+                 double *__restrict__ H, int ldh)
 {
     double vsum = 0.0;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < b.m; i += (long long)gridDim.x * blockDim.x) {
@@ -285,18 +303,24 @@ gn_newton_kernel(BucketN b, const double *__restrict__ nu, double *__restrict__ 
         }
         const double t = fL == 0.0 ? tL : (fR == 0.0 ? tR : tL - fL * (tR - tL) / (fR - fL));
         const double et = exp(t);
-        double wa = 0.0, val = 0.0;
+        double wa = 0.0, val = 0.0, dt = 0.0;
         bool act[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const double u = t - a[j];
-            const bool wd = u < 0.0, dp = u > -lg;                 // withdrawn / deposited
-            act[j] = wd || dp;
+            act[j] = u < 0.0 || u > -lg;                           // withdrawn / deposited
+            if (act[j]) { wa += w[j]; if (slo) dt += w[j] * slo[tok[j]]; }
+        }
+        if (wa > 0.0) dt /= wa;                                    // first-order move of the root under the low-order log-prices
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const double u = t - a[j];
+            const bool wd = u < 0.0, dp = u > -lg;
             double y = 0.0;
             if (wd) y = -R[j] * expm1(u);                          // R - x,  x = R e^u
             if (dp) y = -R[j] * expm1(u + lg) / g;                 // (R - x) / gamma,  x = R e^{u + lg}
+            if (slo && act[j]) y -= w[j] * et / p[j] * (dt - slo[tok[j]]);      // dy_j = -(c_j x_j)(dt - s_lo_j), c_j x_j = w_j e^t / p_j
             if (y != 0.0) { unsafeAtomicAdd(&out[tok[j]], y); val += p[j] * y; }
-            if (act[j]) wa += w[j];
         }
         vsum += val;
         if (HESS && wa > 0.0) {
@@ -323,12 +347,18 @@ gn_newton_kernel(BucketN b, const double *__restrict__ nu, double *__restrict__ 
 // so a pool both tenders and receives each token, as the reference's Delta_i, Lambda_i >= 0 allow (arbitrage.py:51-52).
 template <int KIND>
 __global__ void __launch_bounds__(256)
-smooth_trades_kernel(Bucket2 b, const double *__restrict__ nu, double mu, double *__restrict__ delta, double *__restrict__ lambda)
+smooth_trades_kernel(Bucket2 b, const double *__restrict__ nu, const double *__restrict__ slo, double mu,
+                     double *__restrict__ delta, double *__restrict__ lambda)
 {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < b.m; i += (long long)gridDim.x * blockDim.x) {
         Branch ab, ba;
         ab.D = ab.L = ba.D = ba.L = 0.0;
-        if (!(KIND == 2 && b.flags && b.flags[i])) smooth_pool<KIND>(b, i, nu[b.ia[i]], nu[b.ib[i]], mu, ab, ba);
+        if (!(KIND == 2 && b.flags && b.flags[i])) {
+            const int ia = b.ia[i], ib = b.ib[i];
+            const double pa = nu[ia], pb = nu[ib];
+            smooth_pool<KIND>(b, i, pa, pb, mu, ab, ba);
+            if (slo) { apply_slo(ab, pa, -ab.L1 * pb, slo[ia], slo[ib]); apply_slo(ba, pb, -ba.L1 * pa, slo[ib], slo[ia]); }
+        }
         delta[i] = ab.D;   delta[b.m + i] = ba.D;
         lambda[i] = ba.L;  lambda[b.m + i] = ab.L;
     }
