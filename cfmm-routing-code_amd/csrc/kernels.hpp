@@ -13,6 +13,7 @@
 //   trades2_kernel / tradesn_kernel       materialise Delta_i, Lambda_i at the accepted prices
 //        (once per solve).                                              reference: two-asset.py:94,98
 //   fold_kernel, start_kernel             slice fold before the RCCL all-reduce; start of a solve.
+// The second-order outer iteration lives in smooth.hpp (barrier-smoothed evaluation, Hessian) and chol.hpp (dense solve).
 #pragma once
 #include "pool_math.hpp"
 

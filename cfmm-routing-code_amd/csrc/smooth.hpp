@@ -16,6 +16,12 @@
 // One launch solves both directions of every pool, scatter-adds psi_mu = sum (L - D) through an LDS
 // tile (as the exact evaluation kernel does) and, when asked, the n x n Hessian in log-prices through
 // global fp64 atomics (three per pool: two diagonal entries and the lower off-diagonal one).
+//
+//   smooth_kernel<HESS>        the smoothed evaluation of the four two-asset buckets (warm-started roots)
+//   gn_newton_kernel<K, HESS>  k-asset geo-mean pools: exact solution + exact generalised Hessian (not smoothed)
+//   apply_slo                  low-order log-prices: Newton steps below the fp64 resolution of log nu
+//   smooth_trades_kernel       the interior tenders cfmm_get_trades2 returns after a second-order solve
+//   hess_finish_kernel         diagonal terms, pinned tokens, padding, right-hand side -> chol.hpp's layout
 #pragma once
 #include "kernels.hpp"
 
