@@ -1064,6 +1064,22 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
     return CFMM_OK;
 }
 
+#ifdef CFMM_SMOOTH_HIST
+int cfmm_debug_smooth_hist(cfmm_ctx *ctx, uint64_t *out128, int reset)
+{
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpyFromSymbol(out128, HIP_SYMBOL(cfmm::g_smooth_hist), 128 * sizeof(uint64_t)));
+    if (reset) { uint64_t z[128] = {}; HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(cfmm::g_smooth_hist), z, sizeof z)); }
+    return CFMM_OK;
+}
+int cfmm_debug_smooth_samples(cfmm_ctx *ctx, double *out768)
+{
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpyFromSymbol(out768, HIP_SYMBOL(cfmm::g_smooth_samples), 768 * sizeof(double)));
+    return CFMM_OK;
+}
+#endif
+
 int cfmm_debug_cholesky(cfmm_ctx *ctx, int n, const double *A, const double *b, double *x, int32_t *info)
 {
     if (!ctx || !A || !b || !x || n != ctx->n) return ctx ? fail(ctx, CFMM_E_ARG, "debug_cholesky: n must equal the context's token count") : CFMM_E_ARG;

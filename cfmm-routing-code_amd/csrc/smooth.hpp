@@ -75,6 +75,11 @@ __device__ __forceinline__ Fwd fwd2(double D, double Rin, double Rout, double g,
 }
 
 struct Branch { double D, L, L1, kappa, val; };
+#ifdef CFMM_SMOOTH_HIST
+__device__ unsigned long long g_smooth_hist[128];      // tuning builds: iterations per direction solve
+__device__ double g_smooth_samples[64 * 12];
+__device__ unsigned int g_smooth_nsamples;
+#endif
 
 // root of  a D^2 + b D + mu = 0  (a < 0, mu > 0) in D > 0, without cancellation
 __device__ __forceinline__ double barrier_root(double a, double b, double mu)
@@ -89,39 +94,98 @@ __device__ __forceinline__ double barrier_root(double a, double b, double mu)
 // linear, in particular deep inside the no-trade band where D ~ mu / |A|); a step is taken only if it
 // lands inside the bracket and at least halves the previous one, otherwise the bracket is bisected
 // (the stableswap A is flat, then falls off a knee: plain Newton cycles across it).
+// starting point without (or against) a warm start.  Trade side (A(0) > 0): the exact mu = 0 root where it is closed
+// form; for the stableswap curve an estimate of where the marginal price m = phi_x / phi_y has dropped to
+// rho = nu_in / (gamma nu_out): for y << x,  1 - m ~ alpha rho / (x y^2)  with  x ~ C - y  (three fixed-point sweeps) --
+// a few per cent off the root at the 80/20 imbalance such trades end at, from where the iteration converges in 5-6
+// steps (from D = 0 it first overshoots the knee and needs 12-16).  No-trade side: the root of the model at D = 0.
+template <int KIND>
+__device__ __forceinline__ double cold_start(double Rin, double Rout, double g, double r, double C, double ni, double no, double mu)
+{
+    double De = 0.0;
+    if (KIND == 0) De = (sqrt_nr(g * no * Rin * Rout * rcp_nr(ni)) - Rin) * rcp_nr(g);
+    if (KIND == 1) De = Rin * expm1(log(g * no * Rout * r / (ni * Rin)) / (r + 1.0)) / g;
+    if (De > 0.0) return De;
+    const Fwd f0 = fwd2<KIND>(0.0, Rin, Rout, g, r, C);
+    const double A0 = no * f0.L1 - ni;
+    if (KIND == 3 && A0 > 0.0) {
+        const double rho = ni * rcp_nr(g * no);
+        if (rho < 1.0) {
+            const double k = r * rho * rcp_nr(1.0 - rho);
+            double y = sqrt_nr(k * rcp_nr(C));
+            y = sqrt_nr(k * rcp_nr(C - y));
+            y = sqrt_nr(k * rcp_nr(C - y));
+            const double D0 = (C - y - Rin) * rcp_nr(g);
+            if (D0 > 0.0 && D0 < 1e300) return D0;
+        }
+    }
+    return barrier_root(fmin(no * f0.L2, -1e-300), A0, mu);
+}
+
 // `Dws` > 0: the root found by the previous evaluation of this direction, used as the starting point (prices and
-// barrier weight move little between consecutive evaluations of the outer iteration).
+// barrier weight move little between consecutive evaluations of the outer iteration); if the first step from it wants
+// to move by more than 8x either way the direction has switched regime (trade <-> no-trade) and the cold start is better.
 template <int KIND>
 __device__ __forceinline__ Branch smooth_branch(double Rin, double Rout, double g, double r, double C,
                                                 double ni, double no, double mu, double Dws)
 {
     Branch o;
-    double D;
-    if (Dws > 0.0 && Dws < 1e300) D = Dws;
-    else {
-        double De = 0.0;
-        if (KIND == 0) De = (sqrt_nr(g * no * Rin * Rout * rcp_nr(ni)) - Rin) * rcp_nr(g);
-        if (KIND == 1) De = Rin * expm1(log(g * no * Rout * r / (ni * Rin)) / (r + 1.0)) / g;
-        if (De > 0.0) D = De;
-        else {
-            const Fwd f0 = fwd2<KIND>(0.0, Rin, Rout, g, r, C);
-            D = barrier_root(fmin(no * f0.L2, -1e-300), no * f0.L1 - ni, mu);
-        }
+    bool warm = Dws > 0.0 && Dws < 1e300;
+    if (warm) {
+        // L'(0) needs no curve solve: in the no-trade regime (A(0) < 0) the root is at most mu / |A(0)|; a warm start
+        // far above that is left over from the trade regime
+        double L10;
+        if (KIND == 0) L10 = g * Rout * rcp_nr(Rin);
+        else if (KIND == 1) L10 = g * r * Rout * rcp_nr(Rin);
+        else { const double t = r * rcp_nr(Rin * Rout); L10 = g * fma(t, rcp_nr(Rin), 1.0) * rcp_nr(fma(t, rcp_nr(Rout), 1.0)); }
+        const double A0 = no * L10 - ni;
+        if (A0 < 0.0 && Dws * -A0 > 4.0 * mu) warm = false;
     }
+    double D = warm ? Dws : cold_start<KIND>(Rin, Rout, g, r, C, ni, no, mu);
     double lo = 0.0, hi = 1.7976931348623157e308, dprev = 1.7976931348623157e308;
+    double Flo = 0.0, Fhi = 0.0;                 // F at the bracket ends (0: not known yet)
+    int side = 0;                                // Illinois: which end the last false-position step kept
     for (int it = 0; it < 120; ++it) {
         const Fwd f = fwd2<KIND>(D, Rin, Rout, g, r, C);
         const double A = no * f.L1 - ni, A1 = fmin(no * f.L2, -1e-300);
         const double F = fma(mu, rcp_nr(D), A);
-        if (F > 0.0) lo = D; else hi = D;
+        if (F > 0.0) { lo = D; Flo = F; } else { hi = D; Fhi = F; }
         double Dn = barrier_root(A1, A - A1 * D, mu);
+        if (warm && (Dn > 8.0 * D || 8.0 * Dn < D)) {          // regime switch since the last evaluation: start over
+            warm = false;
+            D = cold_start<KIND>(Rin, Rout, g, r, C, ni, no, mu);
+            lo = 0.0; hi = 1.7976931348623157e308; Flo = 0.0; Fhi = 0.0;
+            continue;
+        }
+        warm = false;
         const double stepc = fabs(Dn - D);
         const bool conv = stepc <= 1e-13 * fmax(Dn, D);
         const bool ok = conv || (Dn > lo && Dn < hi && stepc < 0.5 * dprev);
-        if (!ok) Dn = hi < 1e308 ? 0.5 * (lo + hi) : 2.0 * D;
+        if (!ok) {
+            if (!(hi < 1e308)) Dn = 2.0 * D;
+            else if (Flo > 0.0 && Fhi < 0.0) {
+                // false position on the bracket (F is decreasing), Illinois-damped, kept off the very ends
+                const double wl = (side == 1) ? 0.5 * Flo : Flo, wh = (side == -1) ? 0.5 * Fhi : Fhi;
+                const double xf = (lo * (-wh) + hi * wl) * rcp_nr(wl - wh);
+                const double w = hi - lo;
+                Dn = fmin(fmax(xf, lo + 0.02 * w), hi - 0.02 * w);
+                side = (F > 0.0) ? 1 : -1;       // the end just updated is the one this step keeps
+            } else Dn = 0.5 * (lo + hi);
+        } else side = 0;
         dprev = fabs(Dn - D);
         D = Dn;
+#ifdef CFMM_SMOOTH_HIST
+        if (conv || dprev <= 1e-13 * D) {
+            atomicAdd(&g_smooth_hist[it < 127 ? it : 127], 1ULL);
+            if (it >= 12 && Dws > 0.0) {
+                const unsigned k = atomicAdd(&g_smooth_nsamples, 1u);
+                if (k < 64) { double *q = g_smooth_samples + 12 * k; q[0] = KIND; q[1] = Rin; q[2] = Rout; q[3] = g; q[4] = r; q[5] = ni; q[6] = no; q[7] = mu; q[8] = Dws; q[9] = D; q[10] = it; q[11] = C; }
+            }
+            break;
+        }
+#else
         if (conv || dprev <= 1e-13 * D) break;
+#endif
     }
     const Fwd f = fwd2<KIND>(D, Rin, Rout, g, r, C);
     o.D = D; o.L = f.L; o.L1 = f.L1;
