@@ -113,11 +113,13 @@ def test_smoothed_tenders_stay_inside_every_trading_set():
     p.close()
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(12))
 def test_second_order_small_instances_vs_primal(seed):
+    """random 14-pool instances over every pool family (seeds >= 6 include 3..5-asset Balancer pools) and the three
+    utilities, against SciPy SLSQP on the primal exactly as the scripts state it"""
     from oracle.primal_scipy import solve_primal
     util = ["liquidate", "swap", "arbitrage"][seed % 3]
-    inst = random_instance(400 + seed, n_tokens=6, n_pools=14, with_sum=True, with_curve=True, utility=util, two_asset_only=True)
+    inst = random_instance(400 + seed, n_tokens=6, n_pools=14, with_sum=True, with_curve=True, utility=util, two_asset_only=seed < 6)
     p = problem_of(inst)
     v = p.solve(tol=1e-8, method="newton")
     r = solve_primal(normalise_with_params(inst))
