@@ -653,8 +653,11 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         for (int j = 0; j < n; ++j) { if (mask[j]) d[j] = 0.0; dec -= G[j] * d[j]; dmax = std::max(dmax, std::fabs(d[j])); }
         if (!std::isfinite(dec) || !std::isfinite(dmax)) { status = CFMM_E_NUMERIC; break; }
         if (final_mu) {                        // centring at the final weight: give up (before moving, so that nu, psi and the
-            if (infeas < 0.5 * best_infeas) { best_infeas = infeas; stalled = 0; } else ++stalled;     // certificates stay those of
-            if (stalled >= 4) { status = 2; break; }                                                   // one point) once it stops helping
+            // certificates stay those of one point) once the Newton decrement is at rounding level and the feasibility of
+            // psi_mu has stopped improving all the same
+            if (infeas < 0.5 * best_infeas) { best_infeas = infeas; stalled = 0; }
+            else if (dec <= 1e-13 * std::max(1.0, std::fabs(gmu))) ++stalled;
+            if (stalled >= 4) { status = 2; break; }
         }
         // step length: cap on the log-price move, fraction to the boundary nu > c, Armijo back-tracking on the smoothed dual
         double t = std::min(1.0, o.max_step / std::max(dmax, 1e-300));
