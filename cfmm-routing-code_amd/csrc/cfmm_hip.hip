@@ -132,6 +132,7 @@ struct cfmm_ctx {
     // second-order method (allocated on first use)
     double *sm_out = nullptr, *sm_vec = nullptr, *H = nullptr, *Dinv = nullptr;
     double *sm_ws[CFMM_POOL_KINDS2] = {};   // warm starts of the smoothed per-direction solves
+    long long sm_ws_m[CFMM_POOL_KINDS2] = {};
     double *sm_slo = nullptr;               // low-order log-prices of the last second-order solve (smooth.hpp)
     bool slo_active = false;
     int *sm_mask = nullptr, *sm_info = nullptr;
@@ -434,8 +435,14 @@ int smooth_buffers(cfmm_ctx *ctx, bool hess)
         const size_t lds = (size_t)(2 * n + 32) * sizeof(double);
         if ((rc = set_lds_attr(ctx, smooth_kernel<false>, lds))) return rc;
         if ((rc = set_lds_attr(ctx, smooth_kernel<true>, lds))) return rc;
-        for (int k : {CFMM_POOL_CP2, CFMM_POOL_W2, CFMM_POOL_CURVE2})
-            if (ctx->pools->b2[k].m) { rc = dev_upload<double>(ctx, &ctx->sm_ws[k], nullptr, 2 * (size_t)ctx->pools->b2[k].m, nullptr); if (rc) return rc; }
+    }
+    for (int k : {CFMM_POOL_CP2, CFMM_POOL_W2, CFMM_POOL_CURVE2}) {           // warm starts: sized by the bucket as it is NOW (pools may be re-uploaded)
+        const long long m = ctx->pools->b2[k].m;
+        if (ctx->sm_ws_m[k] == m) continue;
+        if (ctx->sm_ws[k]) { (void)hipFree(ctx->sm_ws[k]); ctx->sm_ws[k] = nullptr; }
+        ctx->sm_ws_m[k] = 0;
+        if (m) { int rc = dev_upload<double>(ctx, &ctx->sm_ws[k], nullptr, 2 * (size_t)m, nullptr); if (rc) return rc; }
+        ctx->sm_ws_m[k] = m;
     }
     if (hess && !ctx->H) {
         const size_t ld = hess_ld(n), nr = hess_nr(n);
@@ -648,7 +655,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             continue;
         }
         ++steps;
-        reg = 0.0;
+        reg = reg > 0.0 ? 0.1 * reg : 0.0;      // a singular Hessian (tokens no pool connects) tends to stay singular: keep most of the shift
         double dec = 0.0, dmax = 0.0;
         for (int j = 0; j < n; ++j) { if (mask[j]) d[j] = 0.0; dec -= G[j] * d[j]; dmax = std::max(dmax, std::fabs(d[j])); }
         if (!std::isfinite(dec) || !std::isfinite(dmax)) { status = CFMM_E_NUMERIC; break; }

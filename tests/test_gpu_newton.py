@@ -315,3 +315,22 @@ dist.destroy_process_group()
     assert out["status"] == "optimal" and out["ranks"] == 1 and out["method"] == _lib.METHODS["newton"]
     assert out["gap"] <= 1e-6 and out["infeas"] <= 1e-6
     assert abs(out["v"] - out["w"]) <= 1e-6 * abs(out["w"])
+
+
+def test_second_order_after_pools_are_uploaded_again():
+    """the per-direction warm starts are sized by the bucket: re-uploading a larger bucket must not reuse the old ones"""
+    small = synthetic.make_network(40, m_cp2=200, m_curve2=2000, seed=0)
+    big = synthetic.make_network(40, m_cp2=2000, m_curve2=20000, seed=1)
+    big["prices"] = small["prices"]
+    n = small["n_tokens"]
+    h, t = _basket(small)
+    u = cfmm.Liquidate(h, t)
+    ctx = _lib.Context(n)
+    for net in (small, big, small):
+        for key, kind in (("cp2", 0), ("curve2", 3)):
+            b = net[key]
+            ctx.upload_pools2(kind, b["Ra"], b["Rb"], b["fee"], b["ia"], b["ib"], b.get("alpha"))
+        ctx.set_utility(u.c, u.h, u.ctype)
+        st = ctx.solve(cfmm.start_prices(net, u), method="newton")
+        assert st["status"] == 1 and st["gap"] <= 1e-6 and st["infeas"] <= 1e-6, (len(net["curve2"]["Ra"]), st)
+    ctx.close()
