@@ -552,11 +552,15 @@ class Problem:
         tolx = 10 * max(self._tol, 1e-12)
         if self.gap <= tolx and self.infeas <= tolx:
             self.status = "optimal"
-        elif self.status == "optimal":
-            # the device met its stopping rule but the certificates computed here do not hold: a token
-            # that must be traded away has no pool willing to take it (its price collapses to 0)
+        else:
+            # the certificates do not hold.  A token that must be traded away but has no pool willing to take it shows
+            # as a price collapsing to 0: report that as what it is; otherwise keep the device's verdict, or
+            # "inaccurate" if it believed it had converged
             collapsed = (u.h > 0) & (nu < 1e-12 * nu.max())
-            self.status = "infeasible" if collapsed.any() else "inaccurate"
+            if collapsed.any():
+                self.status = "infeasible"
+            elif self.status == "optimal":
+                self.status = "inaccurate"
         self.stats = dict(st)
         self.stats.update(total)
         self.stats["pool_subproblems"] = total["evals"] * self.m

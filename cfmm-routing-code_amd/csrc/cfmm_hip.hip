@@ -561,6 +561,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         nbar = (long long)cnt + ge;
     }
 
+    const std::vector<double> s_start = s;
     int evals = evals_before, steps = 0, status = 0;
     double arb_x = 0.0;
     auto exact = [&](const std::vector<double> &p) { ++evals; return cfmm_eval_dual(ctx, p.data(), &arb_x, psi_x.data(), nullptr); };
@@ -692,6 +693,11 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         if (trace) fprintf(stderr, "[newton]    dec %.3e |d| %.3e t %.3e (first %.3e) moved %d\n", dec, dmax, t, t_first, (int)moved);
         if (!moved) { status = 2; break; }
         s = s2; nu = nu2; slo = slo2; slo_on = slo2_on;
+        {                                       // a price that has collapsed by e^-60 since the start: a token that must be traded away
+            bool collapsed = false;             // but that no pool takes (the program is infeasible); no point in going on
+            for (int j = 0; j < n; ++j) collapsed = collapsed || (!mask[j] && s[j] < s_start[j] - 60.0);
+            if (collapsed) { status = 2; break; }
+        }
         if (final_mu) continue;                                        // the weight is small enough: finish centring at it
         if (dec < 10.0 * mu * (double)nbar && (t == t_first || dec < 1e-3 * mu * (double)nbar)) mu *= sigma;
     }

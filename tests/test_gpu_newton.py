@@ -334,3 +334,18 @@ def test_second_order_after_pools_are_uploaded_again():
         st = ctx.solve(cfmm.start_prices(net, u), method="newton")
         assert st["status"] == 1 and st["gap"] <= 1e-6 and st["infeas"] <= 1e-6, (len(net["curve2"]["Ra"]), st)
     ctx.close()
+
+
+def test_second_order_reports_an_unsellable_token_as_infeasible():
+    """a token that must be traded away (liquidation) but that no pool lists: its price collapses; the iteration stops
+    early instead of spending its whole budget, and the problem is reported infeasible (the reference's cvxpy would
+    set prob.status = 'infeasible')"""
+    net = synthetic.make_network(7, m_cp2=60, m_curve2=60, seed=5)
+    net["n_tokens"] = 8                                   # token 7 exists but no pool touches it
+    net["prices"] = np.append(net["prices"], 1.0); net["c"] = np.append(net["c"], 1.0)
+    h = np.zeros(8); h[7] = 3.0; h[2] = 1.0
+    p = cfmm.Problem.from_network(net, utility=cfmm.Liquidate(h, 0))
+    p.solve(method="newton")
+    assert p.status == "infeasible"
+    assert p.stats["newton_steps"] < 150
+    p.close()
