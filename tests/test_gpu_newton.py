@@ -349,3 +349,29 @@ def test_second_order_reports_an_unsellable_token_as_infeasible():
     assert p.status == "infeasible"
     assert p.stats["newton_steps"] < 150
     p.close()
+
+
+def test_c_abi_auto_method_choice_and_fallback():
+    """cfmm_solve with opts.method = CFMM_METHOD_AUTO (what a raw C-ABI caller gets): second order straight away from
+    4096 stableswap pools on, first order below that, and a first-order run that ends without its certificates is
+    handed on to the second-order method"""
+    net = synthetic.config("C5", scale=0.02)                 # 10 000 stableswap pools
+    h, t = _basket(net)
+    u = cfmm.Liquidate(h, t)
+    p = cfmm.Problem.from_network(net, utility=u)
+    ctx = p._ensure_ctx(); ctx.set_utility(u.c, u.h, u.ctype)
+    nu0 = cfmm.start_prices(net, u)
+    st = ctx.solve(nu0)                                       # default opts: method 0
+    assert st["method"] == _lib.METHODS["newton"] and st["status"] == 1
+    p.close()
+    small = synthetic.make_network(40, m_cp2=200, m_curve2=2000, seed=0)
+    h, t = _basket(small)
+    u = cfmm.Liquidate(h, t)
+    q = cfmm.Problem.from_network(small, utility=u)
+    ctx = q._ensure_ctx(); ctx.set_utility(u.c, u.h, u.ctype)
+    nu0 = cfmm.start_prices(small, u)
+    st = ctx.solve(nu0, max_evals=2000)
+    assert st["status"] == 1                                  # whichever method finished it
+    st = ctx.solve(nu0, max_evals=12)                         # first order cannot finish in 12 evaluations -> handed on
+    assert st["method"] == _lib.METHODS["newton"] and st["evals"] > 12
+    q.close()
