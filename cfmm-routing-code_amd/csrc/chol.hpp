@@ -28,74 +28,112 @@ namespace cfmm {
 
 constexpr int CH_NB = 32;
 
+// shared scratch of the 32 x 32 block routines below
+struct BlockLds {
+    double Lc[CH_NB][CH_NB + 1];         // Lc[j][r]: FINAL column j of the block, rows r >= j (unscaled while factoring)
+    double E0[2][CH_NB], E1[2][CH_NB];   // exchange: column j (final) and column j + 1 (still missing column j's update)
+    double X0[2][64], X1[2][64];         // the same for the panel solve
+    double piv[CH_NB];                   // 1 / L[j][j]
+};
+
+// In-place Cholesky of a 32 x 32 block by 256 threads.  Thread (r = tid % 32, g = tid / 32) holds the block's elements
+// (r, c = g + 8 q), q < 4, in a[] (entries above the diagonal must be 0).  TWO columns per barrier: with column j final
+// and column j + 1 published as it stands, every thread finishes column j + 1 for its own rows itself
+// (f = e1 - e0 l, l = D[j+1][j] / p_j) and applies the rank-two update; the dependent chain per pair is one LDS round
+// trip, two reciprocals and one barrier.  On return S.Lc[c][r] = L[r][c] (r >= c), S.piv[j] = 1 / L[j][j].
+__device__ __forceinline__ bool block_factor(double (&a)[CH_NB / 8], BlockLds &S)
+{
+    constexpr int NB = CH_NB, G = 256 / NB, Q = NB / G;
+    static_assert(NB % 2 == 0 && Q == CH_NB / 8, "columns are eliminated in pairs; 256 threads");
+    const int tid = threadIdx.x, r = tid % NB, g = tid / NB;
+    if (g == 0) { S.E0[0][r] = a[0]; S.Lc[0][r] = a[0]; }
+    if (g == 1 % G) S.E1[0][r] = a[1 / G];
+    __syncthreads();
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NB; j += 2) {
+        const int pb = (j >> 1) & 1;
+        const double p0 = S.E0[pb][j], d10 = S.E0[pb][j + 1];
+        const bool pos0 = p0 > 0.0 && p0 < 1.7976931348623157e308;
+        const double ip0 = rcp_nr(pos0 ? p0 : 1.0);
+        const double m = d10 * ip0;
+        const double p1 = fma(-d10, m, S.E1[pb][j + 1]);
+        const bool pos1 = p1 > 0.0 && p1 < 1.7976931348623157e308;
+        ok = ok && pos0 && pos1;
+        const double ip1 = rcp_nr(pos1 ? p1 : 1.0);
+        const double e0r = S.E0[pb][r];
+        const double fr = fma(-e0r, m, S.E1[pb][r]);           // final column j + 1, own row
+        const double s0 = e0r * ip0, s1 = fr * ip1;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int c = g + G * q;
+            if (c > j + 1 && c <= r) {
+                const double e0c = S.E0[pb][c];
+                const double fc = fma(-e0c, m, S.E1[pb][c]);
+                a[q] = fma(-s0, e0c, fma(-s1, fc, a[q]));
+            }
+        }
+        if (g == ((j + 1) % G)) { a[(j + 1) / G] = (r >= j + 1) ? fr : 0.0; S.Lc[j + 1][r] = a[(j + 1) / G]; }
+        if (j + 2 < NB) {
+            if (g == ((j + 2) % G)) { S.E0[pb ^ 1][r] = a[(j + 2) / G]; S.Lc[j + 2][r] = a[(j + 2) / G]; }
+            if (g == ((j + 3) % G)) S.E1[pb ^ 1][r] = a[(j + 3) / G];
+        }
+        __syncthreads();
+    }
+    if (tid < NB) { const double p = S.Lc[tid][tid]; S.piv[tid] = rsqrt_nr(p > 0.0 && p < 1.7976931348623157e308 ? p : 1.0); }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const int c = g + G * q; if (c < r) S.Lc[c][r] *= S.piv[c]; }      // L[r][c]
+    if (g == 0) S.Lc[r][r] *= S.piv[r];                                                              // sqrt(p)
+    __syncthreads();
+    return ok;
+}
+
+// X L' = B for 64 rows against the factor left in S by block_factor.  Thread (rr = tid % 64, h = tid / 64) holds
+// x[rr][c = h + 4 q], q < 8.  Two columns per barrier:  x_j = raw_j / L_jj,  x_{j+1} = (raw_{j+1} - x_j L[j+1][j]) / L_{j+1,j+1}.
+__device__ __forceinline__ void block_solve(double (&x)[CH_NB / 4], BlockLds &S)
+{
+    constexpr int NB = CH_NB, H = 4, QX = NB / H;
+    const int tid = threadIdx.x, rr = tid & 63, h = tid >> 6;
+    if (h == 0) S.X0[0][rr] = x[0];
+    if (h == 1) S.X1[0][rr] = x[0];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NB; j += 2) {
+        const int pb = (j >> 1) & 1;
+        const double xj = S.X0[pb][rr] * S.piv[j];
+        const double xj1 = fma(-xj, S.Lc[j][j + 1], S.X1[pb][rr]) * S.piv[j + 1];
+#pragma unroll
+        for (int q = 0; q < QX; ++q) { const int c = h + H * q; if (c > j + 1) x[q] = fma(-xj, S.Lc[j][c], fma(-xj1, S.Lc[j + 1][c], x[q])); }
+        if (h == (j % H)) x[j / H] = xj;
+        if (h == ((j + 1) % H)) x[(j + 1) / H] = xj1;
+        if (j + 2 < NB) {
+            if (h == ((j + 2) % H)) S.X0[pb ^ 1][rr] = x[(j + 2) / H];
+            if (h == ((j + 3) % H)) S.X1[pb ^ 1][rr] = x[(j + 3) / H];
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(256)
 chol_panel_kernel(double *__restrict__ A, int ld, int nrows, int k0, double *__restrict__ Dinv, int *__restrict__ info)
 {
-    constexpr int NB = CH_NB;
-    constexpr int G = 256 / NB, Q = NB / G;      // factor: thread (r, g) keeps the block's elements (r, c = g + G q), q < Q
-    constexpr int H = 4, QX = NB / H;            // solve: thread (rr, h) keeps x[rr][c = h + H q], q < QX, 64 rows per workgroup
-    static_assert(NB % 2 == 0, "columns are eliminated in pairs");
-    __shared__ double Lc[NB][NB + 1];            // Lc[j][r]: FINAL column j of the block, rows r >= j (unscaled while factoring)
-    __shared__ double E0[2][NB], E1[2][NB];      // exchange: column j (final) and column j + 1 (still missing column j's update)
-    __shared__ double X0[2][64], X1[2][64];      // the same for the panel solve
-    __shared__ double piv[NB];                   // 1 / L[j][j]
+    constexpr int NB = CH_NB, G = 256 / NB, Q = NB / G, H = 4, QX = NB / H;
+    __shared__ BlockLds S;
     const int tid = threadIdx.x;
-    // ---- factor, TWO columns per barrier: with column j final and column j + 1 published as it stands, every thread
-    //      finishes column j + 1 for its own rows itself (f = e1 - e0 l, l = D[j+1][j] / p_j) and applies the rank-two
-    //      update; the dependent chain per pair is one LDS round trip, two reciprocals and one barrier.
     {
         const int r = tid % NB, g = tid / NB;
         double a[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) { const int c = g + G * q; const double v = A[(size_t)(k0 + c) * ld + k0 + r]; a[q] = (c <= r) ? v : 0.0; }
-        if (g == 0) { E0[0][r] = a[0]; Lc[0][r] = a[0]; }
-        if (g == 1 % G) E1[0][r] = a[1 / G];
-        __syncthreads();
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < NB; j += 2) {
-            const int pb = (j >> 1) & 1;
-            const double p0 = E0[pb][j], d10 = E0[pb][j + 1];
-            const bool pos0 = p0 > 0.0 && p0 < 1.7976931348623157e308;
-            const double ip0 = rcp_nr(pos0 ? p0 : 1.0);
-            const double m = d10 * ip0;
-            const double p1 = fma(-d10, m, E1[pb][j + 1]);
-            const bool pos1 = p1 > 0.0 && p1 < 1.7976931348623157e308;
-            ok = ok && pos0 && pos1;
-            const double ip1 = rcp_nr(pos1 ? p1 : 1.0);
-            const double e0r = E0[pb][r];
-            const double fr = fma(-e0r, m, E1[pb][r]);           // final column j + 1, own row
-            const double s0 = e0r * ip0, s1 = fr * ip1;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int c = g + G * q;
-                if (c > j + 1 && c <= r) {
-                    const double e0c = E0[pb][c];
-                    const double fc = fma(-e0c, m, E1[pb][c]);
-                    a[q] = fma(-s0, e0c, fma(-s1, fc, a[q]));
-                }
-            }
-            if (g == ((j + 1) % G)) { a[(j + 1) / G] = (r >= j + 1) ? fr : 0.0; Lc[j + 1][r] = a[(j + 1) / G]; }
-            if (j + 2 < NB) {
-                if (g == ((j + 2) % G)) { E0[pb ^ 1][r] = a[(j + 2) / G]; Lc[j + 2][r] = a[(j + 2) / G]; }
-                if (g == ((j + 3) % G)) E1[pb ^ 1][r] = a[(j + 3) / G];
-            }
-            __syncthreads();
-        }
-        if (tid < NB) { const double p = Lc[tid][tid]; piv[tid] = rsqrt_nr(p > 0.0 && p < 1.7976931348623157e308 ? p : 1.0); }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < Q; ++q) { const int c = g + G * q; if (c < r) Lc[c][r] *= piv[c]; }      // L[r][c]
-        if (g == 0) Lc[r][r] *= piv[r];                                                              // sqrt(p)
-        __syncthreads();
+        const bool ok = block_factor(a, S);
         if (blockIdx.x == 0) {
             if (!ok && tid == 0) atomicMax(info, k0 + 1);
 #pragma unroll
-            for (int q = 0; q < Q; ++q) { const int c = g + G * q; A[(size_t)(k0 + c) * ld + k0 + r] = (c <= r) ? Lc[c][r] : 0.0; }
+            for (int q = 0; q < Q; ++q) { const int c = g + G * q; A[(size_t)(k0 + c) * ld + k0 + r] = (c <= r) ? S.Lc[c][r] : 0.0; }
         }
     }
-    // ---- solve X L' = B for 64 rows (workgroup 0: B = I, giving X = L^-T, i.e. the inverse transposed), again two
-    //      columns per barrier: x_j = raw_j / L_jj,  x_{j+1} = (raw_{j+1} - x_j L[j+1][j]) / L_{j+1,j+1}
+    // ---- solve X L' = B for 64 rows (workgroup 0: B = I, giving X = L^-T, i.e. the inverse transposed)
     const int rr = tid & 63, h = tid >> 6;
     const int row = k0 + NB + 64 * ((int)blockIdx.x - 1) + rr;
     const bool diag_wg = blockIdx.x == 0;
@@ -107,24 +145,7 @@ chol_panel_kernel(double *__restrict__ A, int ld, int nrows, int k0, double *__r
         if (diag_wg) x[q] = (c == rr) ? 1.0 : 0.0;
         else x[q] = A[(size_t)(k0 + c) * ld + (live ? row : k0)];
     }
-    if (h == 0) X0[0][rr] = x[0];
-    if (h == 1) X1[0][rr] = x[0];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NB; j += 2) {
-        const int pb = (j >> 1) & 1;
-        const double xj = X0[pb][rr] * piv[j];
-        const double xj1 = fma(-xj, Lc[j][j + 1], X1[pb][rr]) * piv[j + 1];
-#pragma unroll
-        for (int q = 0; q < QX; ++q) { const int c = h + H * q; if (c > j + 1) x[q] = fma(-xj, Lc[j][c], fma(-xj1, Lc[j + 1][c], x[q])); }
-        if (h == (j % H)) x[j / H] = xj;
-        if (h == ((j + 1) % H)) x[(j + 1) / H] = xj1;
-        if (j + 2 < NB) {
-            if (h == ((j + 2) % H)) X0[pb ^ 1][rr] = x[(j + 2) / H];
-            if (h == ((j + 3) % H)) X1[pb ^ 1][rr] = x[(j + 3) / H];
-        }
-        __syncthreads();
-    }
+    block_solve(x, S);
     if (live) {
 #pragma unroll
         for (int q = 0; q < QX; ++q) {
