@@ -1169,7 +1169,7 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     // first order ended without its certificates: hand the prices it reached to the second-order method
     const cfmm_stats first = *out;
     cfmm_opts o2 = o;
-    o2.max_evals = std::max(1, o.max_evals - first.evals);
+    o2.max_evals = std::max(o.max_evals, 500);      // the second-order method gets its own budget (it is also capped by max_newton)
     rc = solve_newton(ctx, o2, out, first.evals);
     out->wall_seconds += first.wall_seconds; out->device_seconds += first.device_seconds;
     return rc;
