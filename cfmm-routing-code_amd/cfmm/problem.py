@@ -380,6 +380,7 @@ class Problem:
             if "sum2" in self.net:
                 ctx.set_pool_flags(POOL_SUM2, None)
             self._dev_ties = False
+        nu0_given = nu0
         if nu0 is None:
             nu0 = self.nu if (warm_start and self.nu is not None) else start_prices(self.net, u)
         self._theta = {}
@@ -407,7 +408,11 @@ class Problem:
                     self._dev_ties = False
                 self._theta = {}
         if second_order:
-            st = self._run(ctx, nu0, total, tol=tol, method=_lib.METHODS["newton"], **kw)
+            # warm start after a second-order solve on this context: nu0 = NULL tells the library to continue from its
+            # own previous solution -- the prices AND (a multiple of) the final barrier weight, which is what turns the
+            # ~18 steps of a cold solve into 4-7 (the parametric sweep of two-asset.py:34-100)
+            cont = warm_start and nu0_given is None and self.nu is not None and (self.stats or {}).get("method") == _lib.METHODS["newton"]
+            st = self._run(ctx, None if cont else nu0, total, tol=tol, method=_lib.METHODS["newton"], **kw)
             nu, psi = ctx.get_solution()
         self._finish(st, nu, psi, total)
         return self.value

@@ -137,6 +137,7 @@ struct cfmm_ctx {
     bool slo_active = false;
     int *sm_mask = nullptr, *sm_info = nullptr;
     double mu_last = 0.0;              // barrier weight of the last solve (0: first-order, exact tenders)
+    double warm_mu = 0.0;              // barrier weight to continue from (cfmm_solve with nu0 == NULL after a second-order solve)
 };
 
 namespace {
@@ -590,6 +591,8 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     for (int j = 0; j < n; ++j) dual += (nu[j] - c[j]) * h[j];
     static const double mu0_scale = getenv("CFMM_NEWTON_MU0") ? atof(getenv("CFMM_NEWTON_MU0")) : 0.1;                      // tuning knob
     double mu = mu0_scale * std::max(std::fabs(dual), 1e-300) / (double)std::max<long long>(nbar, 1);
+    static const double warm_mult = getenv("CFMM_NEWTON_WARM") ? atof(getenv("CFMM_NEWTON_WARM")) : 1e3;                    // tuning knob
+    if (ctx->warm_mu > 0.0) mu = std::min(mu, warm_mult * ctx->warm_mu);
     const double sigma = (o.barrier_shrink > 0.0 && o.barrier_shrink < 1.0) ? o.barrier_shrink : 0.2;
     const int max_newton = o.max_newton > 0 ? o.max_newton : 200;
     double gap = 1.0, infeas = 1.0, primal = 0.0, reg = 0.0;
@@ -1156,6 +1159,9 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     if (o.method < CFMM_METHOD_AUTO || o.method > CFMM_METHOD_NEWTON) return fail(ctx, CFMM_E_ARG, "solve: method %d", o.method);
     if (!ctx->have_utility) return fail(ctx, CFMM_E_STATE, "solve: cfmm_set_utility has not been called");
     if (cfmm_pool_count(ctx) == 0) return fail(ctx, CFMM_E_STATE, "solve: no pools uploaded");
+    // nu0 == NULL continues from the previous solution: its prices and, for the second-order method, (a multiple of) its
+    // final barrier weight -- the warm start of a parametric sweep (two-asset.py:34-100)
+    ctx->warm_mu = nu0 ? 0.0 : ctx->mu_last;
     if (nu0) { int rc = cfmm_set_nu(ctx, nu0); if (rc) return rc; }
     if (!ctx->have_nu) return fail(ctx, CFMM_E_STATE, "solve: no start prices (pass nu0 or call cfmm_set_nu)");
     const char *why = "";

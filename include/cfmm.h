@@ -144,7 +144,8 @@ int cfmm_eval_smooth(cfmm_ctx *ctx, const double *nu, double mu, double *value, 
  * column-major, lower triangle read; n must equal the context's token count); *info != 0 flags a non-positive pivot */
 int cfmm_debug_cholesky(cfmm_ctx *ctx, int n, const double *A, const double *b, double *x, int32_t *info);
 
-/* prob.solve(): nu0 = start prices (NULL: use cfmm_set_nu / previous solution) */
+/* prob.solve(): nu0 = start prices.  NULL: continue from cfmm_set_nu / the previous solution -- after a second-order
+ * solve that includes (a multiple of) its final barrier weight: the warm start of a parametric sweep (two-asset.py:34-100) */
 int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts, cfmm_stats *out);
 
 /* read-back (arbitrage.py:84 prob.value is stats.primal_value; psi.value; deltas/lambdas.value) */

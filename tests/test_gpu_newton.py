@@ -375,3 +375,25 @@ def test_c_abi_auto_method_choice_and_fallback():
     st = ctx.solve(nu0, max_evals=12)                         # first order cannot finish in 12 evaluations -> handed on
     assert st["method"] == _lib.METHODS["newton"] and st["evals"] > 12
     q.close()
+
+
+def test_second_order_warm_start_over_a_basket_sweep():
+    """the parametric use of two-asset.py:34-100 at scale: one resident pool set, the basket scaled up and down; a
+    warm-started second-order solve (prices and barrier weight continued) needs a fraction of the cold solve's steps
+    and lands on the same optimum"""
+    net = synthetic.config("C5", scale=0.2)
+    h, t = _basket(net)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Liquidate(h, t))
+    p.solve(method="newton")
+    cold_steps = p.stats["newton_steps"]
+    assert p.status == "optimal"
+    for f in (1.05, 1.5, 0.5):
+        p.set_utility(cfmm.Liquidate(h * f, t))
+        vw = p.solve(method="newton", warm_start=True)
+        warm_steps = p.stats["newton_steps"]
+        assert p.status == "optimal" and p.gap <= 1e-6 and p.infeas <= 1e-6
+        vc = p.solve(method="newton")
+        assert p.status == "optimal"
+        assert abs(vw - vc) <= 2e-6 * abs(vc), (f, vw, vc)
+        assert warm_steps <= 0.6 * cold_steps, (f, warm_steps, cold_steps)
+    p.close()
