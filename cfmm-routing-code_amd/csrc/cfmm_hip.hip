@@ -534,7 +534,8 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
 
     std::vector<double> s(n), nu(n), d(n), G(n), Hd(n), rhs(n), s2(n), nu2(n), psi_x(n);
-    std::vector<int> mask(n);
+    std::vector<int> mask(n), pin(n);
+    std::vector<double> lob(n);                 // lower bound of the log-price: log c for a GE token with c > 0 (handled by projection)
     HIP_TRY(ctx, hipMemcpyAsync(nu.data(), ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     long long nbar = 0;
@@ -542,18 +543,19 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     nbar += 2 * ctx->pools->b2[CFMM_POOL_SUM2].m;
     for (int j = 0; j < n; ++j) {
         mask[j] = ct[j] == CFMM_FREE;
-        if (ct[j] == CFMM_GE) nbar += 1;
+        lob[j] = (ct[j] == CFMM_GE && c[j] > 0.0) ? std::log(c[j]) : -INFINITY;
+        if (ct[j] == CFMM_GE && !(c[j] > 0.0)) nbar += 1;
         double sj = std::log(nu[j]);
         if (ct[j] == CFMM_FREE) {
             if (!(c[j] > 0.0)) return fail(ctx, CFMM_E_ARG, "solve: token %d is unconstrained (CFMM_FREE) with c = 0: unbounded", j);
             sj = std::log(c[j]);
-        } else if (ct[j] == CFMM_GE && c[j] > 0.0) sj = std::max(sj, std::log(c[j]) + 1e-3);      // strictly inside nu > c
+        } else sj = std::max(sj, lob[j]);
         s[j] = sj; nu[j] = std::exp(sj);
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, mask.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     if (ctx->comm) {                        // the barrier terms of the pools of every rank (the utility's are replicated)
         long long ge = 0;
-        for (int j = 0; j < n; ++j) ge += ct[j] == CFMM_GE;
+        for (int j = 0; j < n; ++j) ge += ct[j] == CFMM_GE && !(c[j] > 0.0);
         double cnt = (double)(nbar - ge);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, &cnt, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         if (g_rccl.AllReduce(ctx->sm_vec, ctx->sm_vec, 1, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream) != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed");
@@ -572,12 +574,11 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         for (int j = 0; j < n; ++j) {
             g += (p[j] - c[j]) * h[j];
             double Gj = p[j] * (e.psi[j] + h[j]), hj = 0.0;
-            if (ct[j] == CFMM_GE) {
-                const double slack = p[j] - c[j];
-                g -= mu * std::log(slack);
-                Gj -= mu * p[j] / slack;
-                hj = mu * p[j] * c[j] / (slack * slack);
+            if (ct[j] == CFMM_GE && !(c[j] > 0.0)) {      // nu_j > 0: the barrier is -mu log nu_j, linear in the log-price
+                g -= mu * std::log(p[j]);
+                Gj -= mu;
             }
+            (void)hj;
             if (grad) (*grad)[j] = mask[j] ? 0.0 : Gj;
             if (hdiag) (*hdiag)[j] = std::max(Gj, 0.0) + hj;
         }
@@ -639,8 +640,14 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         if (std::fabs(gap) <= o.tol_gap && infeas <= o.tol_infeas) { status = 1; break; }
         if (steps >= max_newton || evals - evals_before >= o.max_evals) { status = 3; break; }
 
-        // Newton direction: (H + diag) d = -G on the unpinned tokens
-        for (int j = 0; j < n; ++j) { rhs[j] = -G[j]; Hd[j] += reg; }
+        // Newton direction: (H + diag) d = -G on the unpinned tokens.  Pinned: the CFMM_FREE tokens, and (projected
+        // Newton) every GE token sitting on its bound nu = c with the gradient pushing it further down
+        for (int j = 0; j < n; ++j) {
+            pin[j] = mask[j] || (s[j] + slo[j] <= lob[j] + 1e-13 * std::max(1.0, std::fabs(lob[j])) && G[j] > 0.0);
+            if (pin[j]) G[j] = 0.0;
+            rhs[j] = -G[j]; Hd[j] += reg;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, pin.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, Hd.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec + n, rhs.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, hess_nr(n), hess_ld(n), (const double *)ctx->sm_vec,
@@ -661,7 +668,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         ++steps;
         reg = reg > 0.0 ? 0.1 * reg : 0.0;      // a singular Hessian (tokens no pool connects) tends to stay singular: keep most of the shift
         double dec = 0.0, dmax = 0.0;
-        for (int j = 0; j < n; ++j) { if (mask[j]) d[j] = 0.0; dec -= G[j] * d[j]; dmax = std::max(dmax, std::fabs(d[j])); }
+        for (int j = 0; j < n; ++j) { if (pin[j]) d[j] = 0.0; dec -= G[j] * d[j]; dmax = std::max(dmax, std::fabs(d[j])); }
         if (!std::isfinite(dec) || !std::isfinite(dmax)) { status = CFMM_E_NUMERIC; break; }
         if (final_mu) {                        // centring at the final weight: give up (before moving, so that nu, psi and the
             // certificates stay those of one point) once the Newton decrement is at rounding level and the feasibility of
@@ -672,8 +679,6 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         }
         // step length: cap on the log-price move, fraction to the boundary nu > c, Armijo back-tracking on the smoothed dual
         double t = std::min(1.0, o.max_step / std::max(dmax, 1e-300));
-        for (int j = 0; j < n; ++j)
-            if (ct[j] == CFMM_GE && c[j] > 0.0 && d[j] < 0.0) t = std::min(t, 0.9 * (s[j] - std::log(c[j])) / -d[j]);
         const double t_first = t;
         bool moved = false;
         bool slo2_on = false;
@@ -682,15 +687,17 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             double lo_max = 0.0;
             for (int j = 0; j < n; ++j) lo_max = std::max(lo_max, std::fabs(slo[j] + t * d[j]));
             const bool small = final_mu && t * dmax < 1e-11 && lo_max < 1e-10;
+            double gd = 0.0;                    // G'(projected move): the Armijo slope of the projected step
             for (int j = 0; j < n; ++j) {
-                if (small) { s2[j] = s[j]; nu2[j] = nu[j]; slo2[j] = mask[j] ? 0.0 : slo[j] + t * d[j]; }
-                else { s2[j] = s[j] + slo[j] + t * d[j]; nu2[j] = mask[j] ? nu[j] : std::exp(s2[j]); slo2[j] = 0.0; }
+                if (small) { s2[j] = s[j]; nu2[j] = nu[j]; slo2[j] = mask[j] ? 0.0 : std::max(slo[j] + t * d[j], lob[j] - s[j]); }
+                else { s2[j] = std::max(s[j] + slo[j] + t * d[j], lob[j]); nu2[j] = mask[j] ? nu[j] : std::exp(s2[j]); slo2[j] = 0.0; }
+                gd += G[j] * ((s2[j] + slo2[j]) - (s[j] + slo[j]));
             }
             slo2_on = small;
             if ((rc = smooth_eval_host(ctx, nu2, mu, false, e2, true, slo2_on ? &slo2 : nullptr))) return rc;
             ++evals;
             const double g2 = assemble(nu2, e2, mu, nullptr, nullptr);
-            if (g2 <= gmu - o.armijo * t * dec || dec <= 1e-13 * std::fabs(gmu)) { moved = true; break; }
+            if (g2 <= gmu + o.armijo * gd || dec <= 1e-13 * std::fabs(gmu)) { moved = true; break; }
             t *= 0.5;
         }
         if (trace) fprintf(stderr, "[newton]    dec %.3e |d| %.3e t %.3e (first %.3e) moved %d\n", dec, dmax, t, t_first, (int)moved);
