@@ -1174,16 +1174,14 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     const char *why = "";
     const bool can_newton = newton_supported(ctx, &why);
     if (o.method == CFMM_METHOD_NEWTON || (o.method == CFMM_METHOD_AUTO && can_newton && near_linear_pools(ctx) && !o.pg_rule)) {
-        // Large problems from a cold, guessed start: a handful of first-order evaluations first.  They are cheap (an
-        // evaluation and an on-device update, no factorisation) and repair the grossly wrong prices of a heuristic start,
-        // which the second-order method would otherwise spend its first ~8 capped steps on (config 5: 18 -> 10 steps,
-        // 23 -> 14 ms).  Not when the utility prices every token itself (linear arbitrage: it costs steps there).
+        // Large problems from a cold start: a handful of first-order evaluations first.  They are cheap (an evaluation
+        // and an on-device update, no factorisation) and move the start prices most of the way, which the second-order
+        // method would otherwise spend its first ~8 capped steps on (config 5: liquidation 18 -> 10 steps, 23 -> 14.8 ms;
+        // linear arbitrage 17 -> 10 steps, 22 -> 15 ms).
         static const int prelude = getenv("CFMM_NEWTON_PRELUDE") ? atoi(getenv("CFMM_NEWTON_PRELUDE")) : 16;     // tuning knob
         int used = 0;
         double w0 = 0.0, d0 = 0.0;
-        bool priced = true;                     // every token priced by the utility (linear arbitrage): the start is not a guess
-        for (int jt = 0; jt < ctx->n; ++jt) priced = priced && ctx->hctype[jt] == CFMM_GE && ctx->hc[jt] > 0.0;
-        if (prelude > 0 && can_newton && !priced && ctx->warm_mu == 0.0 && cfmm_pool_count(ctx) >= 50000 && !o.pg_rule) {
+        if (prelude > 0 && can_newton && ctx->warm_mu == 0.0 && cfmm_pool_count(ctx) >= 50000 && !o.pg_rule) {
             cfmm_opts op = o;
             op.method = 0; op.max_newton = 0; op.barrier_shrink = 0.0; op.max_evals = prelude;
             int rc = solve_lbfgs(ctx, op, out);
