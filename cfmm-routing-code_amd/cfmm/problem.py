@@ -169,24 +169,33 @@ def start_prices(net, util):
         return c.copy()
     logp = np.where(known, np.log(np.where(known, c, 1.0)), 0.0)
     eu, ev, elr = [], [], []          # log p_u - log p_v = lr
+    # a rough guess is all this has to be (the solvers start by repairing it): on large networks every bucket is
+    # thinned to an evenly strided sample, ~64 price relations per token in all
+    total = sum(len(net[k]["Ra"]) for k in ("cp2", "w2", "sum2", "curve2") if k in net) + \
+        sum((kk - 1) * b["R"].shape[1] for kk, b in net.get("gn", {}).items())
+    stride = max(1, total // (64 * n))
     for key in ("cp2", "w2", "sum2", "curve2"):
         if key not in net:
             continue
         b = net[key]
+        sl = slice(0, None, stride)
+        Ra, Rb = b["Ra"][sl], b["Rb"][sl]
         if key == "cp2":
-            lr = np.log(b["Rb"] / b["Ra"])
+            lr = np.log(Rb / Ra)
         elif key == "w2":
-            lr = np.log(b["wa"] * b["Rb"] / ((1 - b["wa"]) * b["Ra"]))
+            wa = b["wa"][sl]
+            lr = np.log(wa * Rb / ((1 - wa) * Ra))
         elif key == "sum2":
-            lr = np.zeros(len(b["Ra"]))
+            lr = np.zeros(len(Ra))
         else:
-            x, y, al = b["Ra"], b["Rb"], b["alpha"]
-            lr = np.log((1 + al / (x * x * y)) / (1 + al / (x * y * y)))
-        eu.append(b["ia"]); ev.append(b["ib"]); elr.append(lr)
+            al = b["alpha"][sl]
+            lr = np.log((1 + al / (Ra * Ra * Rb)) / (1 + al / (Ra * Rb * Rb)))
+        eu.append(b["ia"][sl]); ev.append(b["ib"][sl]); elr.append(lr)
     for k, b in net.get("gn", {}).items():
+        sl = slice(0, None, stride)
         for j in range(1, k):
-            eu.append(b["idx"][j]); ev.append(b["idx"][0])
-            elr.append(np.log(b["w"][j] * b["R"][0] / (b["w"][0] * b["R"][j])))
+            eu.append(b["idx"][j][sl]); ev.append(b["idx"][0][sl])
+            elr.append(np.log(b["w"][j][sl] * b["R"][0][sl] / (b["w"][0][sl] * b["R"][j][sl])))
     if not eu:
         return np.where(known, c, 1.0)
     eu = np.concatenate(eu); ev = np.concatenate(ev); elr = np.concatenate(elr)
