@@ -594,7 +594,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     double mu = mu0_scale * std::max(std::fabs(dual), 1e-300) / (double)std::max<long long>(nbar, 1);
     static const double warm_mult = getenv("CFMM_NEWTON_WARM") ? atof(getenv("CFMM_NEWTON_WARM")) : 1e3;                    // tuning knob
     if (ctx->warm_mu > 0.0) mu = std::min(mu, warm_mult * ctx->warm_mu);
-    const double sigma = (o.barrier_shrink > 0.0 && o.barrier_shrink < 1.0) ? o.barrier_shrink : 0.2;
+    const double sigma = (o.barrier_shrink > 0.0 && o.barrier_shrink < 1.0) ? o.barrier_shrink : 0.1;
     const int max_newton = o.max_newton > 0 ? o.max_newton : 200;
     double gap = 1.0, infeas = 1.0, primal = 0.0, reg = 0.0;
     const bool trace = getenv("CFMM_NEWTON_TRACE") != nullptr;
@@ -748,7 +748,7 @@ void cfmm_default_opts(cfmm_opts *o)
     std::memset(o, 0, sizeof *o);
     o->tol_gap = 1e-6; o->tol_infeas = 1e-6; o->armijo = 1e-4; o->max_step = 2.0;
     o->max_evals = 2000; o->memory = 0; o->iters_per_graph = 4;
-    o->method = CFMM_METHOD_AUTO; o->max_newton = 200; o->barrier_shrink = 0.2;
+    o->method = CFMM_METHOD_AUTO; o->max_newton = 200; o->barrier_shrink = 0.1;
     if (const char *s = getenv("CFMM_ITERS_PER_GRAPH")) o->iters_per_graph = std::max(1, atoi(s));     // tuning knob
 }
 

@@ -77,7 +77,7 @@ typedef struct {
                                constant-sum pools are tied: psi then lacks their fill)           */
     int32_t method;         /* CFMM_METHOD_*  (0 = auto)                                                            */
     int32_t max_newton;     /* cap on second-order steps (200)                                                      */
-    double barrier_shrink;  /* factor applied to the barrier weight once a step lands near the central path (0.2)   */
+    double barrier_shrink;  /* factor applied to the barrier weight once a step lands near the central path (0.1)   */
 } cfmm_opts;
 
 typedef struct {

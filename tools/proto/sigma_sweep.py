@@ -12,7 +12,7 @@ for name, net, u in cases:
     p = cfmm.Problem.from_network(net, utility=u)
     ctx = p._ensure_ctx(); ctx.set_utility(u.c, u.h, u.ctype)
     nu0 = cfmm.start_prices(net, u)
-    for sg in ((0.2,) if len(sys.argv) > 1 else (0.05, 0.1, 0.2, 0.4)):
+    for sg in ((0.2,) if len(sys.argv) > 1 else (0.01, 0.03, 0.05, 0.1, 0.2)):
         st = ctx.solve(nu0, method="newton", barrier_shrink=sg)
         print("%-12s sigma %.2f: status %d steps %3d evals %3d gap %.1e infeas %.1e  %.1f ms" % (name, sg, st["status"], st["newton_steps"], st["evals"], st["gap"], st["infeas"], st["wall_seconds"] * 1e3))
     p.close()
