@@ -40,7 +40,10 @@ constexpr int MAX_MEMORY = 8;         // L-BFGS pairs kept (register-resident in
 // the fused evaluation kernel walks "wave-tiles": WT_LIGHT / WT_HEAVY consecutive pools of a two-asset bucket
 // (two / one per lane) or 64 / K consecutive pools of a K-asset bucket (one LEG per lane); buckets are laid out in
 // the tile space heaviest first, so the light tiles fill the tail of the launch
-constexpr int WT_LIGHT = 128;         // cp2, sum2: two pools per lane
+#ifndef WT_LIGHT_DEF
+#define WT_LIGHT_DEF 128
+#endif
+constexpr int WT_LIGHT = WT_LIGHT_DEF;  // cp2, sum2: two pools per lane
 constexpr int WT_HEAVY = 64;          // w2, curve2: one pool per lane
 __host__ __device__ constexpr int wave_tile_pools(int code)     // code: CFMM_POOL_* kind, or -k
 {
