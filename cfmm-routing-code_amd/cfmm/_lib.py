@@ -57,7 +57,7 @@ SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm
            "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_set_pool_flags", "cfmm_set_utility",
            "cfmm_set_ties", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_solve", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_comm_unique_id", "cfmm_comm_init",
-           "cfmm_time_eval_kernel", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
+           "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
 
 
 def lib():
@@ -92,6 +92,7 @@ def lib():
     L.cfmm_comm_unique_id.argtypes = [C.c_void_p]
     L.cfmm_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
     L.cfmm_time_eval_kernel.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.cfmm_time_collective.argtypes = [vp, C.c_int, dp, dp]
     L.cfmm_selftest.argtypes = [vp]
     L.cfmm_debug_timers.argtypes = [vp, C.POINTER(C.c_int64)]
     L.cfmm_pool_count.restype = C.c_int64; L.cfmm_pool_count.argtypes = [vp]
@@ -259,6 +260,12 @@ class Context:
         s = C.c_double()
         self._chk(self.L.cfmm_time_eval_kernel(self.h, kind, reps, C.byref(s)))
         return s.value
+
+    def time_collective(self, reps=50):
+        """(fold seconds, all-reduce seconds) per launch; collective when a communicator is set"""
+        f, a = C.c_double(), C.c_double()
+        self._chk(self.L.cfmm_time_collective(self.h, reps, C.byref(f), C.byref(a)))
+        return f.value, a.value
 
     def selftest(self):
         self._chk(self.L.cfmm_selftest(self.h))

@@ -9,7 +9,7 @@ only to agree on the 128-byte ncclUniqueId, for barriers and for the max-over-ra
 """
 import os
 
-from .problem import Problem, shard_network
+from .problem import Problem, HostComm, shard_network
 
 
 def env_world():
@@ -33,18 +33,26 @@ def broadcast_unique_id(dist, make_id, src=0):
     return uid
 
 
-def sharded_problem(net, utility, dist=None, device=None, shard=True):
+def sharded_problem(net, utility, dist=None, device=None, shard=True, context=None):
     """Problem over this rank's shard, with the library's RCCL communicator initialised.
 
     net: the FULL network (shard=True: it is sliced here) or this rank's own pools (shard=False,
-    e.g. bench.py's weak-scaling shards).  dist: an initialised torch.distributed (nccl) module."""
+    e.g. bench.py's weak-scaling shards).  dist: an initialised torch.distributed (nccl) module.
+    Host-side decisions of the solve (start prices, method, constant-sum ties) are then taken on global
+    quantities through problem.HostComm, so that every rank issues the same device collectives.
+    `context`: a ready device context to use instead of creating one on `device` (the CPU tests pass a stand-in
+    whose collective is gloo; the product never does)."""
     rank, local_rank, world = env_world()
     if dist is not None:
         rank, world = dist.get_rank(), dist.get_world_size()
     part = rank_network(net, rank, world) if (shard and world > 1) else net
     prob = Problem.from_network(part, utility=utility, device=local_rank if device is None else device)
+    if context is not None:
+        prob.ctx = context
     if dist is not None:                 # (a process group of one rank runs the same path)
-        from . import _lib
+        prob._host = HostComm(dist)
         prob._ensure_ctx()
-        prob.init_comm(world, rank, broadcast_unique_id(dist, _lib.comm_unique_id))
+        if context is None:
+            from . import _lib
+            prob.init_comm(world, rank, broadcast_unique_id(dist, _lib.comm_unique_id))
     return prob

@@ -254,6 +254,49 @@ class _Ties:
         return grp.astype(np.int32), self.off.copy(), len(uniq)
 
 
+# ------------------------------------------------------------------------------- pool-sharded agreement
+class HostComm:
+    """The host-side agreement a pool-sharded solve needs (cfmm.distributed): every decision that changes the
+    number or order of device collectives -- start prices, which method runs, which constant-sum pools are tied --
+    must be the SAME on every rank, so it is taken on global quantities exchanged here.  Tiny and off the hot path
+    (a few n-vectors per solve); wraps an initialised torch.distributed (nccl on the GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        import torch
+        self._torch = torch
+        self._dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+    def _t(self, a):
+        return self._torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy()).to(self._dev)
+
+    def broadcast(self, a, src=0):
+        t = self._t(a)
+        self.dist.broadcast(t, src=src)
+        return t.cpu().numpy()
+
+    def allreduce_sum(self, a):
+        t = self._t(a)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def allgather(self, obj):
+        box = [None] * self.world
+        self.dist.all_gather_object(box, obj)
+        return box
+
+    def assert_identical(self, a, what):
+        """every rank must hold bit-identical `a` (different prices on different ranks would make the all-reduced
+        psi a sum of shards evaluated at different points: silently wrong, or a hang)"""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        t = self._t(np.concatenate([a, -a]))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        mx = t.cpu().numpy()
+        if not (np.array_equal(mx[:len(a)], a) and np.array_equal(-mx[len(a):], a)):
+            raise CfmmError(f"pool-sharded solve: {what} differ between ranks")
+
+
 # ------------------------------------------------------------------------------- Problem
 AUTO_NEWTON_MIN_STABLE = 4096      # include/cfmm.h: CFMM_AUTO_NEWTON_MIN_STABLE
 
@@ -282,7 +325,8 @@ class Problem:
         self.gap = None; self.infeas = None; self.dual_value = None; self.stats = None
         self._theta = {}
         self._trade_cache = None
-        self._comm = None
+        self._comm = None              # (n_ranks, rank) once the library's RCCL communicator is up
+        self._host = None              # HostComm of a pool-sharded problem (cfmm.distributed.sharded_problem)
         self._dev_utility = None       # the Utility object whose data sits on the device
         self._dev_ties = False         # price ties / pool flags are set on the device
 
@@ -390,8 +434,25 @@ class Problem:
                 ctx.set_pool_flags(POOL_SUM2, None)
             self._dev_ties = False
         nu0_given = nu0
+        host = self._host
+        rank = host.rank if host else 0
+        # global pool counts: the branches below change the sequence of device collectives, so a pool-sharded solve
+        # takes them on what ALL ranks hold, never on its own shard
+        cnt = np.array([len(self.net["curve2"]["Ra"]) if "curve2" in self.net else 0,
+                        len(self.net["sum2"]["Ra"]) if "sum2" in self.net else 0], dtype=np.float64)
+        if host:
+            cnt = host.allreduce_sum(cnt)
+        n_stable, n_sum = int(cnt[0]), int(cnt[1])
         if nu0 is None:
-            nu0 = self.nu if (warm_start and self.nu is not None) else start_prices(self.net, u)
+            if warm_start and self.nu is not None:
+                nu0 = self.nu
+            elif host and not np.all(u.c > 0):
+                # start prices are a guess propagated through THIS rank's pools: rank 0's guess is everyone's
+                nu0 = host.broadcast(start_prices(self.net, u) if rank == 0 else np.zeros(self.n), src=0)
+            else:
+                nu0 = start_prices(self.net, u)
+        if host:
+            host.assert_identical(nu0, "the start prices")
         self._theta = {}
         self._trade_cache = None
         self._tol = tol
@@ -402,10 +463,10 @@ class Problem:
             raise ValueError(f"method {method!r}: expected one of {sorted(_lib.METHODS)}")
         # auto: many stableswap pools -> second order straight away (first order needs thousands of evaluations there);
         # otherwise first order (with the active-set loop over constant-sum kinks), second order if that fails
-        many_stable = "curve2" in self.net and len(self.net["curve2"]["Ra"]) >= AUTO_NEWTON_MIN_STABLE
+        many_stable = n_stable >= AUTO_NEWTON_MIN_STABLE
         second_order = method == "newton" or (method == "auto" and can_second and many_stable)
         if not second_order:
-            if "sum2" not in self.net:
+            if n_sum == 0:
                 st = self._run(ctx, nu0, total, tol=tol, method=_lib.METHODS["lbfgs"], **kw)
                 nu, psi = ctx.get_solution()
             else:
@@ -435,28 +496,40 @@ class Problem:
 
     def _kink_candidates(self, nu, kink_tol, banned, tied):
         """constant-sum pools whose price ratio sits on one of their two kinks
-        (log nu_a - log nu_b = +-log gamma): nearest kink, within kink_tol and well inside its half"""
-        b = self.net["sum2"]
-        r = np.log(nu[b["ia"]]) - np.log(nu[b["ib"]])
-        lg = np.log(b["fee"])
-        sgn = np.where(r < 0, 1, -1)                 # a->b kink at r = lg < 0, b->a kink at r = -lg > 0
-        dist = np.abs(r - sgn * lg)
-        near = (dist < kink_tol) & ((dist < 0.5 * np.abs(lg)) | (lg == 0.0))
+        (log nu_a - log nu_b = +-log gamma): nearest kink, within kink_tol and well inside its half.
+        Returns {(rank, i): record}: the pool's data travels with its key, so that every rank of a pool-sharded
+        solve can build the same ties and the same fill recovery from the union of all ranks' candidates."""
+        rank = self._host.rank if self._host else 0
         out = {}
-        for i in np.flatnonzero(near):               # (only the pools on a kink: the scan itself is vectorised)
-            i = int(i)
-            if i not in tied and (i, int(sgn[i])) not in banned:
-                out[i] = int(sgn[i])
-        return out
+        if "sum2" in self.net:
+            b = self.net["sum2"]
+            r = np.log(nu[b["ia"]]) - np.log(nu[b["ib"]])
+            lg = np.log(b["fee"])
+            sgn = np.where(r < 0, 1, -1)                 # a->b kink at r = lg < 0, b->a kink at r = -lg > 0
+            dist = np.abs(r - sgn * lg)
+            near = (dist < kink_tol) & ((dist < 0.5 * np.abs(lg)) | (lg == 0.0))
+            for i in np.flatnonzero(near):               # (only the pools on a kink: the scan itself is vectorised)
+                i = int(i)
+                key = (rank, i)
+                if key not in tied and (key, int(sgn[i])) not in banned:
+                    out[key] = dict(sgn=int(sgn[i]), ia=int(b["ia"][i]), ib=int(b["ib"][i]), fee=float(b["fee"][i]),
+                                    Ra=float(b["Ra"][i]), Rb=float(b["Rb"][i]))
+        if self._host:                                   # the union over ranks, identical everywhere
+            merged = {}
+            for part in self._host.allgather(out):
+                merged.update(part)
+            out = merged
+        return dict(sorted(out.items()))
 
     def _solve_kinks(self, ctx, nu, tol, kw, kink_tol, max_rounds, total):
         """A constant-sum pool whose optimum is a partial fill sits on a kink of the dual (all three
         shipped scripts do this).  Active-set loop: run the device solver in short legs; tie the two
         prices of every pool found on a kink (a linear equality in log-price) and skip it in the
         kernels; once the (now smooth) reduced dual has converged recover the fill fractions;
-        release ties whose fill leaves (0,1)."""
-        b = self.net["sum2"]
-        m2 = len(b["Ra"])
+        release ties whose fill leaves (0,1).  Pool-sharded: every decision below is a function of the
+        all-reduced prices / psi and of the all-gathered candidates, hence identical on every rank."""
+        rank = self._host.rank if self._host else 0
+        m2 = len(self.net["sum2"]["Ra"]) if "sum2" in self.net else 0
         tied, banned = {}, set()
         budget = min(kw["max_evals"], 100)
         st = None
@@ -466,35 +539,41 @@ class Problem:
                 break
             ties = _Ties(self.n)
             flags = np.zeros(m2, dtype=np.int32)
-            for i, sgn in list(tied.items()):
-                if ties.tie(int(b["ia"][i]), int(b["ib"][i]), sgn * np.log(b["fee"][i])):
-                    flags[i] = 1
+            for key, rec in list(tied.items()):
+                if ties.tie(rec["ia"], rec["ib"], rec["sgn"] * np.log(rec["fee"])):
+                    if key[0] == rank:
+                        flags[key[1]] = 1
                 else:
-                    del tied[i]; banned.add((i, sgn))
+                    del tied[key]; banned.add((key, rec["sgn"]))
             self._dev_ties = True
             if tied:
                 grp, off, ng = ties.groups()
-                ctx.set_ties(grp, off); ctx.set_pool_flags(POOL_SUM2, flags)
+                ctx.set_ties(grp, off)
+                if m2:
+                    ctx.set_pool_flags(POOL_SUM2, flags)
                 st = self._run(ctx, nu, total, tol=0.01 * tol, pg_rule=1, **dict(kw, max_evals=budget))
             else:
-                ctx.set_ties(None, None); ctx.set_pool_flags(POOL_SUM2, None)
+                ctx.set_ties(None, None)
+                if m2:
+                    ctx.set_pool_flags(POOL_SUM2, None)
                 st = self._run(ctx, nu, total, tol=tol, **dict(kw, max_evals=budget))
             nu, psi = ctx.get_solution()
             if st["status"] == 1:
                 if not tied:
                     return st, nu, psi
                 theta, ok = self._recover_fills(nu, psi, tied, tol)
-                bad = [i for i in tied if not (1e-9 < theta[i] < 1 - 1e-9)]
+                bad = [k for k in tied if not (1e-9 < theta[k] < 1 - 1e-9)]
                 if ok and not bad:
-                    self._theta = {i: (tied[i], theta[i]) for i in tied}
+                    self._theta = {k: (tied[k], theta[k]) for k in tied}
                     return st, nu, psi
                 if bad:                   # fully on / fully off after all: back to bang-bang
-                    for i in bad:
-                        banned.add((i, tied[i])); del tied[i]
+                    for k in bad:
+                        banned.add((k, tied[k]["sgn"])); del tied[k]
                     continue
             new = self._kink_candidates(nu, kink_tol, banned, tied)
             if new:
                 tied.update(new)
+                tied = dict(sorted(tied.items()))
                 banned = {bn for bn in banned if bn[0] in new}     # bans expire when the active set changes
             elif st["status"] == 3 and budget < kw["max_evals"]:
                 budget = min(kw["max_evals"], 2 * budget)           # no kink in sight: longer legs
@@ -504,14 +583,14 @@ class Problem:
                 break
         return st, nu, psi
 
-    def _fill_vector(self, i, sgn):
-        b = self.net["sum2"]
+    def _fill_vector(self, rec):
+        """net trade of the tied constant-sum pool `rec` at full fill in its kink's direction"""
         d = np.zeros(self.n)
-        a, bb, g = int(b["ia"][i]), int(b["ib"][i]), b["fee"][i]
-        if sgn > 0:    # tender a, drain b
-            d[a] = -b["Rb"][i] / g; d[bb] = b["Rb"][i]
-        else:          # tender b, drain a
-            d[bb] = -b["Ra"][i] / g; d[a] = b["Ra"][i]
+        a, bb, g = rec["ia"], rec["ib"], rec["fee"]
+        if rec["sgn"] > 0:    # tender a, drain b
+            d[a] = -rec["Rb"] / g; d[bb] = rec["Rb"]
+        else:                 # tender b, drain a
+            d[bb] = -rec["Ra"] / g; d[a] = rec["Ra"]
         return d
 
     def _recover_fills(self, nu, psi, tied, tol):
@@ -519,7 +598,7 @@ class Problem:
         (EQ tokens, GE tokens priced above their bound) and >= 0 on GE tokens at their bound."""
         u = self.utility
         keys = list(tied)
-        D = np.stack([self._fill_vector(i, tied[i]) for i in keys], axis=1)       # n x K
+        D = np.stack([self._fill_vector(tied[k]) for k in keys], axis=1)       # n x K
         r = psi + u.h
         at_bound = (u.ctype == GE) & (nu <= u.c * (1 + 1e-9))
         must = (u.ctype == EQ) | ((u.ctype == GE) & ~at_bound)
@@ -546,8 +625,8 @@ class Problem:
     def _finish(self, st, nu, psi, total):
         u = self.utility
         psi = psi.copy()
-        for i, (sgn, th) in self._theta.items():
-            psi += th * self._fill_vector(i, sgn)
+        for rec, th in self._theta.values():
+            psi += th * self._fill_vector(rec)
         r = psi + u.h
         self.value = float(u.c @ psi)
         if st.get("method") == _lib.METHODS["newton"]:
@@ -563,7 +642,9 @@ class Problem:
         self.infeas = float(viol.max() / max(np.abs(psi).max(), np.abs(u.h).max(), 1e-300))
         self.nu, self.psi = nu, psi
         self.status = _lib.STATUS.get(st["status"], f"error {st['status']}")
-        tolx = 10 * max(self._tol, 1e-12)
+        # "optimal" means what the caller asked for: both certificates at the requested tolerance (the recomputation
+        # above repeats the device's sums in another order: allow it rounding, not a looser bar)
+        tolx = max(self._tol, 1e-12) * (1 + 1e-6) + 1e-15
         if self.gap <= tolx and self.infeas <= tolx:
             self.status = "optimal"
         else:
@@ -590,12 +671,14 @@ class Problem:
                     tr[key] = ctx.get_trades2(kind, len(self.net[key]["Ra"]))
             for k, b in self.net.get("gn", {}).items():
                 tr[k] = ctx.get_tradesN(k, b["R"].shape[1])
-            if self._theta:
+            if self._theta and "sum2" in tr:
                 d, l = tr["sum2"]
-                for i, (sgn, th) in self._theta.items():
-                    full = self._fill_vector(i, sgn)
-                    a, bb = int(self.net["sum2"]["ia"][i]), int(self.net["sum2"]["ib"][i])
-                    y = th * np.array([full[a], full[bb]])
+                rank = self._host.rank if self._host else 0
+                for (r, i), (rec, th) in self._theta.items():
+                    if r != rank:                      # (another rank's pool: its tenders are read back there)
+                        continue
+                    full = self._fill_vector(rec)
+                    y = th * np.array([full[rec["ia"]], full[rec["ib"]]])
                     d[:, i] = np.maximum(-y, 0.0); l[:, i] = np.maximum(y, 0.0)
             self._trade_cache = tr
         return self._trade_cache

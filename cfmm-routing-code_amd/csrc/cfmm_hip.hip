@@ -16,7 +16,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cfmm.h"
@@ -70,13 +72,13 @@ struct DevBuf {
 // the pool columns in HBM; shared (reference-counted) between a context and its clones
 struct PoolStore {
     Bucket2 b2[CFMM_POOL_KINDS2] = {};
-    std::vector<void *> b2mem[CFMM_POOL_KINDS2];
+    void *b2mem[CFMM_POOL_KINDS2] = {};           // one arena (one hipMalloc) per bucket: every column lives in it
     BucketN bn[CFMM_MAX_POOL_SIZE + 1] = {};
-    std::vector<void *> bnmem[CFMM_MAX_POOL_SIZE + 1];
+    void *bnmem[CFMM_MAX_POOL_SIZE + 1] = {};
     ~PoolStore()
     {
-        for (auto &v : b2mem) for (void *q : v) (void)hipFree(q);
-        for (auto &v : bnmem) for (void *q : v) (void)hipFree(q);
+        for (void *q : b2mem) if (q) (void)hipFree(q);
+        for (void *q : bnmem) if (q) (void)hipFree(q);
     }
 };
 
@@ -92,6 +94,8 @@ struct cfmm_ctx {
     int *flags2 = nullptr;
     double *trade_buf = nullptr;       // grow-only scratch for cfmm_get_trades* (delta | lambda)
     size_t trade_cap = 0;
+    char *stage = nullptr;             // pinned staging ring of the upload hand-over: 2 slots of STAGE_BYTES
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
 
     // tokens / state (device)
     double *c = nullptr, *h = nullptr, *off = nullptr, *glo = nullptr, *ghi = nullptr;
@@ -128,6 +132,7 @@ struct cfmm_ctx {
     // RCCL
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
+    int64_t g_total = 0, g_stable = 0;     // pool counts over ALL ranks (refresh_global_counts)
 
     // second-order method (allocated on first use)
     double *sm_out = nullptr, *sm_vec = nullptr, *H = nullptr, *Dinv = nullptr;
@@ -184,10 +189,89 @@ int dev_upload(cfmm_ctx *ctx, T **dst, const T *src, size_t count, std::vector<v
     return CFMM_OK;
 }
 
-void free_all(std::vector<void *> &v)
+// ---- the upload hand-over (arbitrage.py:5-28: a drop-in call starts from host lists) ---------------------------
+// Every column of a bucket goes into ONE arena (one hipMalloc, 256-byte aligned pieces) through a pinned, double-
+// buffered staging ring: the host-side fill of chunk i (a few threads; the k-asset columns are transposed from the
+// ABI's slot-major to the device's pool-major layout on the way) overlaps the DMA of chunk i - 1.  Pageable
+// hipMemcpy of ~40 separately allocated columns ran at ~6 GB/s (round 1).
+constexpr size_t STAGE_BYTES = 8u << 20;
+struct Col {
+    size_t bytes = 0;
+    void **dst = nullptr;                                                  // receives the column's device address
+    std::function<void(char *out, size_t off, size_t len)> fill;          // writes bytes [off, off + len) of the column
+};
+Col plain_col(const void *src, size_t bytes, void **dst)
 {
-    for (void *p : v) (void)hipFree(p);
-    v.clear();
+    Col c; c.bytes = bytes; c.dst = dst;
+    c.fill = [src](char *out, size_t off, size_t len) { std::memcpy(out, (const char *)src + off, len); };
+    return c;
+}
+// column [k][m] (slot-major, the ABI) -> [m][k] (pool-major, the device): element e = i * k + j comes from j * m + i
+template <class T>
+Col transposed_col(const T *src, int k, int64_t m, void **dst)
+{
+    Col c; c.bytes = (size_t)k * m * sizeof(T); c.dst = dst;
+    c.fill = [src, k, m](char *out, size_t off, size_t len) {
+        T *o = (T *)out;
+        size_t e = off / sizeof(T);
+        const size_t cnt = len / sizeof(T);
+        int64_t i = (int64_t)(e / k); int j = (int)(e % k);
+        for (size_t q = 0; q < cnt; ++q) { o[q] = src[(size_t)j * m + i]; if (++j == k) { j = 0; ++i; } }
+    };
+    return c;
+}
+void parallel_fill(const Col &c, char *out, size_t off, size_t len)
+{
+    const int T = len >= (2u << 20) ? 4 : 1;
+    if (T == 1) { c.fill(out, off, len); return; }
+    std::vector<std::thread> th;
+    const size_t part = ((len / T) + 63) & ~(size_t)63;
+    for (int t = 0; t < T; ++t) {
+        const size_t b = (size_t)t * part, e = std::min(len, b + part);
+        if (b >= e) break;
+        th.emplace_back([&c, out, off, b, e]() { c.fill(out + b, off + b, e - b); });
+    }
+    for (auto &x : th) x.join();
+}
+int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out)
+{
+    size_t total = 0;
+    std::vector<size_t> offs;
+    for (auto &c : cols) { offs.push_back(total); total += (c.bytes + 255) & ~(size_t)255; }
+    char *base = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&base, total + 256));
+    auto bail = [&](hipError_t e, const char *what) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(base); return fail(ctx, CFMM_E_HIP, "upload: %s -> %s", what, hipGetErrorString(e)); };
+    if (!ctx->stage) {
+        hipError_t e = hipHostMalloc((void **)&ctx->stage, 2 * STAGE_BYTES, hipHostMallocDefault);
+        if (e != hipSuccess) { ctx->stage = nullptr; return bail(e, "hipHostMalloc(staging)"); }
+        for (auto &ev : ctx->stage_ev) { e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) return bail(e, "hipEventCreate"); }
+    }
+    int slot = 0;
+    bool used[2] = {false, false};
+    for (size_t q = 0; q < cols.size(); ++q) {
+        for (size_t off = 0; off < cols[q].bytes; off += STAGE_BYTES) {
+            const size_t len = std::min(STAGE_BYTES, cols[q].bytes - off);
+            char *st = ctx->stage + (size_t)slot * STAGE_BYTES;
+            if (used[slot]) { hipError_t e = hipEventSynchronize(ctx->stage_ev[slot]); if (e != hipSuccess) return bail(e, "hipEventSynchronize"); }
+            parallel_fill(cols[q], st, off, len);
+            hipError_t e = hipMemcpyAsync(base + offs[q] + off, st, len, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipEventRecord(ctx->stage_ev[slot], ctx->stream);
+            if (e != hipSuccess) return bail(e, "hipMemcpyAsync");
+            used[slot] = true; slot ^= 1;
+        }
+        *cols[q].dst = base + offs[q];
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return bail(e, "hipStreamSynchronize");
+    *arena_out = base;
+    return CFMM_OK;
+}
+
+// a successful (re-)upload invalidates everything that was derived from the previous pool set
+void pools_changed(cfmm_ctx *ctx)
+{
+    ctx->g_valid = false;
+    ctx->hsol_valid = false; ctx->mu_last = 0.0; ctx->warm_mu = 0.0; ctx->slo_active = false;
 }
 
 size_t eval_lds_bytes(int n, bool with_d) { return (size_t)eval_lds_doubles(n, with_d) * sizeof(double) + (size_t)(EVAL_THREADS / 64) * 64 * 16; }
@@ -346,7 +430,8 @@ int recompute_bounds(cfmm_ctx *ctx)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->glo, lo.data(), ng * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ghi, hi.data(), ng * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->g_valid = false;
+    // (the captured iteration holds device pointers and sizes only: new bound / utility VALUES do not invalidate it;
+    //  cfmm_set_ties, which changes the number of groups, does)
     return CFMM_OK;
 }
 
@@ -423,7 +508,24 @@ bool newton_supported(cfmm_ctx *ctx, const char **why)
 // many stableswap pools: the first-order iteration needs thousands of evaluations; a few of them, and constant-sum pools, are
 // left to the first-order path (the host's active-set loop over kinks is quicker while it copes) with the second-order
 // method as the fall-back
-bool near_linear_pools(cfmm_ctx *ctx) { return ctx->pools->b2[CFMM_POOL_CURVE2].m >= CFMM_AUTO_NEWTON_MIN_STABLE; }
+bool near_linear_pools(cfmm_ctx *ctx) { return ctx->g_stable >= CFMM_AUTO_NEWTON_MIN_STABLE; }
+
+// Pool-sharded contexts branch on GLOBAL pool counts (every rank must issue the same sequence of collectives: a
+// rank deciding on its own shard's size would take another method, or skip the prelude, and deadlock its peers)
+int refresh_global_counts(cfmm_ctx *ctx)
+{
+    ctx->g_total = cfmm_pool_count(ctx);
+    ctx->g_stable = ctx->pools->b2[CFMM_POOL_CURVE2].m;
+    if (!ctx->comm) return CFMM_OK;
+    double cnt[2] = {(double)ctx->g_total, (double)ctx->g_stable};
+    double *dv = ctx->psi_t;                         // scratch (overwritten by the first update of every solve)
+    HIP_TRY(ctx, hipMemcpyAsync(dv, cnt, sizeof cnt, hipMemcpyHostToDevice, ctx->stream));
+    if (g_rccl.AllReduce(dv, dv, 2, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream) != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce (pool counts) failed");
+    HIP_TRY(ctx, hipMemcpyAsync(cnt, dv, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->g_total = (int64_t)cnt[0]; ctx->g_stable = (int64_t)cnt[1];
+    return CFMM_OK;
+}
 
 int smooth_buffers(cfmm_ctx *ctx, bool hess)
 {
@@ -854,6 +956,8 @@ int cfmm_destroy(cfmm_ctx *ctx)
     ctx->pools.reset();
     if (ctx->flags2) (void)hipFree(ctx->flags2);
     if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
+    for (auto &e : ctx->stage_ev) if (e) (void)hipEventDestroy(e);
     for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
     void *ptrs[] = {ctx->c, ctx->h, ctx->off, ctx->glo, ctx->ghi, ctx->ctype, ctx->grp, ctx->nu, ctx->nu_acc, ctx->psi_acc,
                     ctx->psi_t, ctx->nu0, ctx->s, ctx->s_t, ctx->Gs, ctx->Gs_t, ctx->d, ctx->Ds, ctx->S, ctx->Y, ctx->rho,
@@ -898,24 +1002,27 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
     }
     if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_pools2: the pools are shared with a clone (cfmm_clone); destroy the clones first");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    free_all(ctx->pools->b2mem[kind]);
-    if (kind == CFMM_POOL_SUM2 && ctx->flags2) { (void)hipFree(ctx->flags2); ctx->flags2 = nullptr; }
+    // the new bucket is built first and swapped in only once every column has arrived: a failed upload leaves the
+    // previous pools (and everything derived from them) untouched
     Bucket2 b = {};
     b.m = m;
+    void *arena = nullptr;
     if (m > 0) {
-        auto &tr = ctx->pools->b2mem[kind];
-        int rc = 0;
-        rc |= dev_upload<double>(ctx, (double **)&b.Ra, Ra, m, &tr);
-        rc |= dev_upload<double>(ctx, (double **)&b.Rb, Rb, m, &tr);
-        rc |= dev_upload<double>(ctx, (double **)&b.fee, fee, m, &tr);
-        if (param) rc |= dev_upload<double>(ctx, (double **)&b.param, param, m, &tr);
-        rc |= dev_upload<int>(ctx, (int **)&b.ia, ia, m, &tr);
-        rc |= dev_upload<int>(ctx, (int **)&b.ib, ib, m, &tr);
-        if (rc) return CFMM_E_HIP;
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<Col> cols;
+        cols.push_back(plain_col(Ra, m * sizeof(double), (void **)&b.Ra));
+        cols.push_back(plain_col(Rb, m * sizeof(double), (void **)&b.Rb));
+        cols.push_back(plain_col(fee, m * sizeof(double), (void **)&b.fee));
+        if (param) cols.push_back(plain_col(param, m * sizeof(double), (void **)&b.param));
+        cols.push_back(plain_col(ia, m * sizeof(int32_t), (void **)&b.ia));
+        cols.push_back(plain_col(ib, m * sizeof(int32_t), (void **)&b.ib));
+        int rc = upload_arena(ctx, cols, &arena);
+        if (rc) return rc;
     }
+    if (ctx->pools->b2mem[kind]) (void)hipFree(ctx->pools->b2mem[kind]);
+    ctx->pools->b2mem[kind] = arena;
     ctx->pools->b2[kind] = b;
-    ctx->g_valid = false;
+    if (kind == CFMM_POOL_SUM2 && ctx->flags2) { (void)hipFree(ctx->flags2); ctx->flags2 = nullptr; }
+    pools_changed(ctx);
     return CFMM_OK;
 }
 
@@ -934,34 +1041,27 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
         if (!(fee[i] > 0.0 && fee[i] <= 1.0)) return fail(ctx, CFMM_E_ARG, "upload_poolsN: pool %lld has fee %g outside (0, 1]", (long long)i, fee[i]);
     if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_poolsN: the pools are shared with a clone (cfmm_clone); destroy the clones first");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    free_all(ctx->pools->bnmem[k]);
     BucketN b = {};
     b.m = m;
+    void *arena = nullptr;
     if (m > 0) {
-        auto &tr = ctx->pools->bnmem[k];
-        int rc = 0;
-        // the ABI hands columns slot-major [k][m]; the device layout is pool-major [m][k] (leg per lane)
-        std::vector<int32_t> tidx((size_t)k * m);
-        std::vector<double> tR((size_t)k * m), tw((size_t)k * m);
-        for (int j = 0; j < k; ++j)
-            for (int64_t i = 0; i < m; ++i) {
-                tidx[(size_t)i * k + j] = idx[(size_t)j * m + i];
-                tR[(size_t)i * k + j] = R[(size_t)j * m + i];
-                tw[(size_t)i * k + j] = w[(size_t)j * m + i];
-            }
-        rc |= dev_upload<int>(ctx, (int **)&b.idx, tidx.data(), (size_t)k * m, &tr);
-        rc |= dev_upload<double>(ctx, (double **)&b.R, tR.data(), (size_t)k * m, &tr);
-        rc |= dev_upload<double>(ctx, (double **)&b.w, tw.data(), (size_t)k * m, &tr);
-        if (!rc) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the staging vectors die at scope end
-        rc |= dev_upload<double>(ctx, (double **)&b.fee, fee, m, &tr);
+        // the ABI hands columns slot-major [k][m]; the device layout is pool-major [m][k] (leg per lane): transposed
+        // while staging.  log(fee) is computed once here (+8 B per pool instead of one log per wave-tile and evaluation)
         std::vector<double> lf(m);
         for (int64_t i = 0; i < m; ++i) lf[i] = std::log(fee[i]);
-        rc |= dev_upload<double>(ctx, (double **)&b.lfee, lf.data(), m, &tr);
-        if (rc) return CFMM_E_HIP;
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<Col> cols;
+        cols.push_back(transposed_col<int32_t>(idx, k, m, (void **)&b.idx));
+        cols.push_back(transposed_col<double>(R, k, m, (void **)&b.R));
+        cols.push_back(transposed_col<double>(w, k, m, (void **)&b.w));
+        cols.push_back(plain_col(fee, m * sizeof(double), (void **)&b.fee));
+        cols.push_back(plain_col(lf.data(), m * sizeof(double), (void **)&b.lfee));
+        int rc = upload_arena(ctx, cols, &arena);
+        if (rc) return rc;
     }
+    if (ctx->pools->bnmem[k]) (void)hipFree(ctx->pools->bnmem[k]);
+    ctx->pools->bnmem[k] = arena;
     ctx->pools->bn[k] = b;
-    ctx->g_valid = false;
+    pools_changed(ctx);
     return CFMM_OK;
 }
 
@@ -1016,6 +1116,7 @@ int cfmm_set_ties(cfmm_ctx *ctx, int n_groups, const int32_t *grp, const double 
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->grp, ctx->hgrp.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->off, ctx->hoff.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ctx->g_valid = false;                  // the number of groups is baked into the captured launches
     return recompute_bounds(ctx);
 }
 
@@ -1165,7 +1266,8 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
         return fail(ctx, CFMM_E_ARG, "solve: memory %d, iters_per_graph %d, max_evals %d", o.memory, o.iters_per_graph, o.max_evals);
     if (o.method < CFMM_METHOD_AUTO || o.method > CFMM_METHOD_NEWTON) return fail(ctx, CFMM_E_ARG, "solve: method %d", o.method);
     if (!ctx->have_utility) return fail(ctx, CFMM_E_STATE, "solve: cfmm_set_utility has not been called");
-    if (cfmm_pool_count(ctx) == 0) return fail(ctx, CFMM_E_STATE, "solve: no pools uploaded");
+    { int rc = refresh_global_counts(ctx); if (rc) return rc; }
+    if (ctx->g_total == 0) return fail(ctx, CFMM_E_STATE, "solve: no pools uploaded");      // (an empty SHARD is fine: it joins the collectives)
     // nu0 == NULL continues from the previous solution: its prices and, for the second-order method, (a multiple of) its
     // final barrier weight -- the warm start of a parametric sweep (two-asset.py:34-100)
     ctx->warm_mu = nu0 ? 0.0 : ctx->mu_last;
@@ -1181,7 +1283,7 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
         static const int prelude = getenv("CFMM_NEWTON_PRELUDE") ? atoi(getenv("CFMM_NEWTON_PRELUDE")) : 16;     // tuning knob
         int used = 0;
         double w0 = 0.0, d0 = 0.0;
-        if (prelude > 0 && can_newton && ctx->warm_mu == 0.0 && cfmm_pool_count(ctx) >= 50000 && !o.pg_rule) {
+        if (prelude > 0 && can_newton && ctx->warm_mu == 0.0 && ctx->g_total >= 50000 && !o.pg_rule) {
             cfmm_opts op = o;
             op.method = 0; op.max_newton = 0; op.barrier_shrink = 0.0; op.max_evals = prelude;
             int rc = solve_lbfgs(ctx, op, out);
@@ -1312,13 +1414,16 @@ int cfmm_get_tradesN(cfmm_ctx *ctx, int k, double *delta, double *lambda)
     { int rc = trade_scratch(ctx, cnt, &dd, &dl); if (rc) return rc; }
     const dim3 grid((unsigned)((b.m + 255) / 256)), blk(256);
     const double *nu = ctx->nu_acc;
+    // after a second-order solve that ended with low-order log-prices the k-asset pools were evaluated with them
+    // (gn_newton_kernel): the tenders handed out must be those of the same point, or they would not sum to psi
+    const double *slo = (ctx->mu_last > 0.0 && ctx->slo_active) ? ctx->sm_slo : nullptr;
     switch (k) {
-    case 3: hipLaunchKernelGGL(tradesn_kernel<3>, grid, blk, 0, ctx->stream, b, nu, dd, dl); break;
-    case 4: hipLaunchKernelGGL(tradesn_kernel<4>, grid, blk, 0, ctx->stream, b, nu, dd, dl); break;
-    case 5: hipLaunchKernelGGL(tradesn_kernel<5>, grid, blk, 0, ctx->stream, b, nu, dd, dl); break;
-    case 6: hipLaunchKernelGGL(tradesn_kernel<6>, grid, blk, 0, ctx->stream, b, nu, dd, dl); break;
-    case 7: hipLaunchKernelGGL(tradesn_kernel<7>, grid, blk, 0, ctx->stream, b, nu, dd, dl); break;
-    default: hipLaunchKernelGGL(tradesn_kernel<8>, grid, blk, 0, ctx->stream, b, nu, dd, dl); break;
+    case 3: hipLaunchKernelGGL(tradesn_kernel<3>, grid, blk, 0, ctx->stream, b, nu, slo, dd, dl); break;
+    case 4: hipLaunchKernelGGL(tradesn_kernel<4>, grid, blk, 0, ctx->stream, b, nu, slo, dd, dl); break;
+    case 5: hipLaunchKernelGGL(tradesn_kernel<5>, grid, blk, 0, ctx->stream, b, nu, slo, dd, dl); break;
+    case 6: hipLaunchKernelGGL(tradesn_kernel<6>, grid, blk, 0, ctx->stream, b, nu, slo, dd, dl); break;
+    case 7: hipLaunchKernelGGL(tradesn_kernel<7>, grid, blk, 0, ctx->stream, b, nu, slo, dd, dl); break;
+    default: hipLaunchKernelGGL(tradesn_kernel<8>, grid, blk, 0, ctx->stream, b, nu, slo, dd, dl); break;
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && delta) e = hipMemcpyAsync(delta, dd, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
@@ -1407,6 +1512,35 @@ int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_lau
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
     *sec_per_launch = ms * 1e-3 / reps;
+    return CFMM_OK;
+}
+
+int cfmm_time_collective(cfmm_ctx *ctx, int reps, double *fold_sec, double *allreduce_sec)
+{
+    if (!ctx || reps < 1) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n = ctx->n, len = acc_arb(n) + 1;
+    float ms = 0.f;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, n, ctx->nslices, 0, (const DevState *)nullptr);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+    if (fold_sec) *fold_sec = ms * 1e-3 / reps;
+    if (allreduce_sec) *allreduce_sec = 0.0;
+    if (ctx->comm && allreduce_sec) {              // (collective: every rank of the communicator must make this call)
+        for (int i = 0; i < 3; ++i)
+            if (g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream) != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed");
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+        for (int i = 0; i < reps; ++i)
+            if (g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream) != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed");
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+        *allreduce_sec = ms * 1e-3 / reps;
+    }
     return CFMM_OK;
 }
 

@@ -407,18 +407,38 @@ trades2_kernel(Bucket2 b, const double *__restrict__ nu, double *__restrict__ de
 
 template <int K>
 __global__ void __launch_bounds__(256)
-tradesn_kernel(BucketN b, const double *__restrict__ nu, double *__restrict__ delta, double *__restrict__ lambda)
+tradesn_kernel(BucketN b, const double *__restrict__ nu, const double *__restrict__ slo, double *__restrict__ delta, double *__restrict__ lambda)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.m) return;
     double R[K], w[K], p[K], y[K];
+    int tok[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {                      // device layout is pool-major (leg j of pool i at i*K + j)
         R[j] = b.R[i * K + j];
         w[j] = b.w[i * K + j];
-        p[j] = nu[b.idx[i * K + j]];
+        tok[j] = b.idx[i * K + j];
+        p[j] = nu[tok[j]];
     }
-    pool_geomean_n<K>(R, w, b.fee[i], [&](int j) { return p[j]; }, y);
+    const double g = b.fee[i];
+    pool_geomean_n<K>(R, w, g, [&](int j) { return p[j]; }, y);
+    if (slo) {
+        // low-order log-prices of a second-order solve (smooth.hpp: gn_newton_kernel): the legs that trade move by
+        // the pool's exact first-order response,  dy_j = -(w_j e^t / p_j)(dt - s_lo_j),  dt = sum_A w s_lo / sum_A w;
+        // w_j e^t / p_j is the traded leg's post-trade reserve (over the fee on the deposit side)
+        double wa = 0.0, dt = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) if (y[j] != 0.0) { wa += w[j]; dt += w[j] * slo[tok[j]]; }
+        if (wa > 0.0) {
+            dt /= wa;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (y[j] == 0.0) continue;
+                const double cx = y[j] > 0.0 ? (R[j] - y[j]) : (R[j] - g * y[j]) / g;  // c_j x_j = w_j e^t / p_j: x_j (withdrawn) or x_j / gamma (deposited)
+                y[j] -= cx * (dt - slo[tok[j]]);
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {                      // results slot-major, as the C-ABI hands them out
         delta[(size_t)j * b.m + i] = fmax(-y[j], 0.0);

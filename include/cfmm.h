@@ -168,6 +168,10 @@ int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128);
  * the k-asset bucket); returns the average seconds per launch in *sec_per_launch. */
 #define CFMM_TIME_ALL 100
 int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_launch);
+/* the two pool-sharded pieces of an outer iteration, timed the same way (bench.py's per-iteration split): `reps`
+ * back-to-back launches of the accumulator-slice fold, and `reps` back-to-back RCCL all-reduces of [psi | sum arb]
+ * (n + 1 doubles) -- the latter only on a context with a communicator, and then EVERY rank must make this call */
+int cfmm_time_collective(cfmm_ctx *ctx, int reps, double *fold_sec, double *allreduce_sec);
 /* checks the cross-lane primitives of the update kernels (DPP / v_permlane*_swap / ds_swizzle butterflies and the
  * 64-value reduce-scatter) against exact integer sums on this device; 0 = pass */
 int cfmm_selftest(cfmm_ctx *ctx);
@@ -176,6 +180,10 @@ int cfmm_selftest(cfmm_ctx *ctx);
  * per-wave tile log and per-block start/end clocks of the last evaluation; `out` holds
  * 64 + 8 * 4096 + 2048 int64 */
 int cfmm_debug_timers(cfmm_ctx *ctx, int64_t *out);
+#ifdef CFMM_SMOOTH_HIST        /* tuning builds only (tools/build_variants.sh): iteration histogram of the smoothed per-direction solves */
+int cfmm_debug_smooth_hist(cfmm_ctx *ctx, uint64_t *out128, int reset);
+int cfmm_debug_smooth_samples(cfmm_ctx *ctx, double *out768);
+#endif
 int64_t cfmm_pool_count(cfmm_ctx *ctx);
 void *cfmm_stream(cfmm_ctx *ctx);                 /* the hipStream_t the library launches on */
 

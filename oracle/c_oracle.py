@@ -54,6 +54,7 @@ def lib():
         L.oracle_start.restype = None; L.oracle_start.argtypes = [vp, dp, C.c_int]
         L.oracle_step.restype = C.c_int; L.oracle_step.argtypes = [vp, C.c_double, dp, dp, C.POINTER(Opts)]
         L.oracle_get.restype = None; L.oracle_get.argtypes = [vp, dp, dp, C.POINTER(Stats)]
+        L.oracle_get_psi.restype = None; L.oracle_get_psi.argtypes = [vp, dp]
         L.oracle_solve.restype = C.c_int
         L.oracle_solve.argtypes = [vp, dp, C.POINTER(Opts), C.POINTER(Stats), dp, dp]
         _lib = L
@@ -151,14 +152,14 @@ class Oracle:
         self.L.oracle_tradesN(self.h, b, _d(nu), _d(y))
         return y
 
-    def solve_sharded(self, nu0, allreduce, tol=1e-6, max_evals=2000, memory=0, armijo=1e-4, max_step=2.0):
+    def solve_sharded(self, nu0, allreduce, tol=1e-6, max_evals=2000, memory=0, armijo=1e-4, max_step=2.0, pg_rule=0):
         """the pool-sharded outer loop, exactly as the GPU library runs it: every rank evaluates ITS
         pools, `allreduce(vec)` sums [psi | sum arb | diag] over the ranks in place, and every rank
         takes the identical step.  `self` holds this rank's shard only."""
         nu0 = np.ascontiguousarray(nu0, dtype=np.float64)
         if memory == 0:
             memory = 8 if self.n <= 32 else 4
-        o = Opts(tol, tol, armijo, max_step, max_evals, memory, 0, 0)
+        o = Opts(tol, tol, armijo, max_step, max_evals, memory, pg_rule, 0)
         n = self.n
         self.L.oracle_start(self.h, _d(nu0), memory)
         nu = np.zeros(n); buf = np.zeros(2 * n + 1)
@@ -175,8 +176,8 @@ class Oracle:
             first = False
         nu_acc = np.zeros(n); psi_acc = np.zeros(n)
         self.L.oracle_get(self.h, None, _d(nu_acc), C.byref(st))
-        self.L.oracle_get(self.h, None, None, None)
-        return dict(nu=nu_acc, evals=st.evals, iters=st.iters, status=st.status, dual_value=st.dual_value,
+        self.L.oracle_get_psi(self.h, _d(psi_acc))
+        return dict(nu=nu_acc, psi=psi_acc, pg=st.pg, seconds=0.0, evals=st.evals, iters=st.iters, status=st.status, dual_value=st.dual_value,
                     primal_value=st.primal_value, gap=st.gap, infeas=st.infeas)
 
     def solve(self, nu0, tol=1e-6, max_evals=2000, memory=0, armijo=1e-4, max_step=2.0, pg_rule=0):

@@ -539,6 +539,9 @@ static double now_s(void)
 
 /* read-out for callers that drive oracle_start / oracle_eval / oracle_step themselves (the
  * pool-sharded loop of tests/test_distributed.py): trial prices, accepted prices, statistics */
+/* psi at the accepted point (after the all-reduce when the caller runs the pool-sharded loop) */
+void oracle_get_psi(oracle_t *o, double *psi) { memcpy(psi, o->psi, 8 * o->n); }
+
 void oracle_get(oracle_t *o, double *nu_trial, double *nu_acc, oracle_stats_t *st)
 {
     const int n = o->n;

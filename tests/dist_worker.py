@@ -1,24 +1,46 @@
 """worker of tests/test_distributed.py: one rank of a world_size-N gloo job on CPU.
 
-Runs the pool-sharded outer loop (this rank's shard evaluated by the C oracle, ONE all-reduce of
-[psi | sum arb | diag] per dual evaluation, identical step on every rank) -- the same structure
-libcfmm_hip.so runs with RCCL -- and writes what it found to argv[1]-<rank>.json."""
+Runs the PRODUCT's pool-sharded host path -- cfmm.distributed.sharded_problem -> cfmm.Problem.solve, with its
+global decisions (problem.HostComm), start-price broadcast and all-gathered constant-sum ties -- over a stand-in
+device context (tests/oracle_ctx.py: this rank's shard evaluated by the C oracle, ONE gloo all-reduce of
+[psi | sum arb | diag] per dual evaluation, identical step on every rank: the structure libcfmm_hip.so runs with
+RCCL).  Writes what it found to argv[1]-<rank>.json."""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "cfmm-routing-code_amd")):
+for p in (ROOT, os.path.join(ROOT, "cfmm-routing-code_amd"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import cfmm  # noqa: E402
 from cfmm import synthetic  # noqa: E402
-from oracle.c_oracle import Oracle  # noqa: E402
+from oracle import instances as I  # noqa: E402
+from oracle_ctx import ShardedOracleContext  # noqa: E402
+from helpers import utility_of  # noqa: E402
+
+
+def basket(net, kind):
+    """10-token basket against a random target (liquidation.py:57,77-80 / two-asset.py:66,86 at scale)"""
+    n = net["n_tokens"]
+    rng = np.random.default_rng(7)
+    h = np.zeros(n); idx = rng.choice(n, 10, replace=False)
+    h[idx] = np.exp(rng.normal(2, 0.5, 10)) / net["prices"][idx] * 10
+    t = int(rng.integers(0, n)); h[t] = 0.0
+    return cfmm.Liquidate(h, t) if kind == "liquidate" else cfmm.Swap(h, t)
+
+
+def run(net, util, tol, **kw):
+    ctx = ShardedOracleContext(net["n_tokens"], dist)
+    p = cfmm.distributed.sharded_problem(net, util, dist=dist, context=ctx)
+    v = p.solve(tol=tol, **kw)
+    return dict(value=v, status=p.status, gap=p.gap, infeas=p.infeas, evals=p.stats["evals"], allreduces=ctx.allreduces,
+                solves=ctx.solves, nu=p.nu.tolist(), psi=p.psi.tolist(), pools=cfmm.problem.network_pool_count(p.net),
+                nu0=[a.tolist() for a in ctx.start_prices[:1]], theta=sorted([list(k), th] for k, (_, th) in p._theta.items()))
 
 
 def main():
@@ -27,20 +49,27 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     assert cfmm.distributed.env_world()[0] == rank and cfmm.distributed.env_world()[2] == world
     uid = cfmm.distributed.broadcast_unique_id(dist, lambda: bytes(range(128)))      # stand-in for ncclGetUniqueId
+    res = dict(rank=rank, world=world, uid_ok=(uid == bytes(range(128))))
+    # (a gloo all-reduce costs ~0.1 s in the CI sandbox: each world size runs a subset, argv[2])
+    todo = sys.argv[2].split(",")
     net = synthetic.config("C3", scale=0.01, seed=3)
-    part = cfmm.distributed.rank_network(net, rank, world)
-    o = Oracle(net["n_tokens"]); o.add_network(part); o.set_utility(net["c"])
-    calls = [0]
-
-    def allreduce(buf):
-        t = torch.from_numpy(buf)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        calls[0] += 1
-
-    r = o.solve_sharded(net["c"], allreduce, tol=1e-7)
-    res = dict(rank=rank, world=world, uid_ok=(uid == bytes(range(128))), pools=cfmm.problem.network_pool_count(part),
-               evals=r["evals"], allreduces=calls[0], status=r["status"], primal=r["primal_value"], dual=r["dual_value"],
-               gap=r["gap"], infeas=r["infeas"], nu=r["nu"].tolist())
+    for key in ("arbitrage", "liquidate", "swap"):
+        if key in todo:
+            res[key] = run(net, cfmm.Arbitrage(net["c"]) if key == "arbitrage" else basket(net, key), 1e-6)
+    # the shipped scripts, pool-sharded: each holds a partially filled constant-sum pool (a kink of the dual), which
+    # only SOME rank owns -- the ties and the fill recovery must still be the same everywhere
+    for name, inst in (("arbitrage_py", I.arbitrage()), ("liquidation_py", I.liquidation()), ("two_asset_py", I.two_asset(I.two_asset_sweep()[10]))):
+        if name in todo:
+            pnet, _ = cfmm.pack(inst["n_tokens"], inst["local_indices"], inst["reserves"], inst["fees"], inst["kinds"], inst["weights"])
+            res[name] = run(pnet, utility_of(inst), 1e-9)
+    # ranks disagreeing on the start prices must be caught, not silently summed
+    bad = net["c"] * (1.0 + 1e-3 * rank)
+    try:
+        ctx = ShardedOracleContext(net["n_tokens"], dist)
+        cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, context=ctx).solve(nu0=bad, max_evals=2)
+        res["mismatch_caught"] = (world == 1)
+    except cfmm.CfmmError as e:
+        res["mismatch_caught"] = "differ between ranks" in str(e)
     with open(f"{out}-{rank}.json", "w") as f:
         json.dump(res, f)
     dist.barrier()

@@ -66,6 +66,9 @@ class OracleContext:
                     primal_value=r["primal_value"], gap=r["gap"], infeas=r["infeas"], wall_seconds=r["seconds"],
                     device_seconds=r["seconds"], pg=r["pg"], pool_subproblems=0)
 
+    def pool_count(self):
+        return sum(len(b["Ra"]) for b in self.b2.values()) + sum(b["R"].shape[1] for b in self.bn.values())
+
     def get_nu(self):
         return self._nu.copy()
 
@@ -91,3 +94,41 @@ class OracleContext:
 
     def close(self):
         pass
+
+
+class ShardedOracleContext(OracleContext):
+    """TEST-ONLY: one rank of a pool-sharded job on CPU.  This rank's shard is evaluated by the C oracle and
+    [psi | sum arb | diag] is all-reduced over torch.distributed (gloo) once per dual evaluation -- the structure
+    libcfmm_hip.so runs with RCCL -- so that the product's host-side sharded control flow (cfmm.problem /
+    cfmm.distributed: global decisions, start-price broadcast, all-gathered kink ties) runs under world_size > 1."""
+
+    def __init__(self, n_tokens, dist):
+        super().__init__(n_tokens)
+        self.dist = dist
+        self.allreduces = 0
+        self.solves = 0
+        self.start_prices = []
+
+    def _allreduce(self, buf):
+        import torch
+        t = torch.from_numpy(buf)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.allreduces += 1
+
+    def eval_dual(self, nu, want_diag=False):
+        r = self._build().eval(nu, True)
+        buf = np.concatenate([r[1], [r[0]], r[2]])
+        self._allreduce(buf)
+        n = self.n
+        return (buf[n], buf[:n].copy(), buf[n + 1:].copy()) if want_diag else (buf[n], buf[:n].copy())
+
+    def solve(self, nu0=None, tol=1e-6, max_evals=2000, memory=0, iters_per_graph=8, pg_rule=0, **kw):
+        o = self._build()
+        nu0 = nu0 if nu0 is not None else self._nu
+        self.start_prices.append(np.array(nu0, dtype=np.float64))
+        self.solves += 1
+        r = o.solve_sharded(nu0, self._allreduce, tol=tol, max_evals=max_evals, memory=memory, pg_rule=pg_rule)
+        self._nu, self._psi = r["nu"], r["psi"]
+        return dict(evals=r["evals"], iters=r["iters"], status=r["status"], n_ranks=self.dist.get_world_size(),
+                    dual_value=r["dual_value"], primal_value=r["primal_value"], gap=r["gap"], infeas=r["infeas"],
+                    wall_seconds=0.0, device_seconds=0.0, pg=r["pg"], pool_subproblems=0)

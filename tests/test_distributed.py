@@ -1,7 +1,8 @@
-"""CPU suite, part 3: the N > 1 path.  world_size-2 (and 3) gloo jobs run the pool-sharded outer loop
-with the C oracle standing in for the device and torch.distributed(gloo) for RCCL; the sharded run
-must reproduce the unsharded solve: one all-reduce per dual evaluation, identical prices on every
-rank, same optimum."""
+"""CPU suite, part 3: the N > 1 path.  world_size-2 (and 3) gloo jobs run the product's pool-sharded host path
+(cfmm.distributed.sharded_problem -> cfmm.Problem.solve: global decisions, start-price broadcast, all-gathered
+constant-sum ties) with the C oracle standing in for the device and torch.distributed(gloo) for RCCL; the sharded
+run must reproduce the unsharded solve: one all-reduce per dual evaluation, identical prices on every rank, same
+optimum -- for the linear, liquidation and swap utilities and for the shipped scripts with their kinks."""
 import json
 import os
 import socket
@@ -16,10 +17,15 @@ from cfmm import synthetic
 from oracle.c_oracle import Oracle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
 
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+SCENARIOS = {2: ["arbitrage", "liquidate", "liquidation_py", "two_asset_py"], 3: ["arbitrage", "swap", "arbitrage_py"]}
 
 
 def _run_world(world, tmp_path):
@@ -29,7 +35,7 @@ def _run_world(world, tmp_path):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1", PYTHONDONTWRITEBYTECODE="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), out], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), out, ",".join(SCENARIOS[world])], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         try:
@@ -42,24 +48,56 @@ def _run_world(world, tmp_path):
     return [json.load(open(f"{out}-{r}.json")) for r in range(world)]
 
 
+def _unsharded(net, util, tol):
+    from oracle_ctx import OracleContext
+    p = cfmm.Problem.from_network(net, utility=util)
+    p.ctx = OracleContext(net["n_tokens"])
+    v = p.solve(tol=tol)
+    return p, v
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_pool_sharded_solve_over_gloo_matches_unsharded(oracle_lib, tmp_path, world):
+    """the PRODUCT's sharded host path (cfmm.distributed.sharded_problem -> Problem.solve) under world_size 2 / 3"""
+    import dist_worker
+    from helpers import utility_of, golden
+    from oracle import instances as I
     res = _run_world(world, tmp_path)
     net = synthetic.config("C3", scale=0.01, seed=3)
-    o = Oracle(net["n_tokens"]); o.add_network(net); o.set_utility(net["c"])
-    ref = o.solve(net["c"], tol=1e-7)
-    assert ref["status"] == 1
-    assert sum(r["pools"] for r in res) == cfmm.problem.network_pool_count(net)
     for r in res:
-        assert r["uid_ok"] and r["world"] == world
-        assert r["status"] == 1 and r["gap"] <= 1e-7 and r["infeas"] <= 1e-7
-        assert r["allreduces"] == r["evals"]                      # ONE collective per dual evaluation
-        assert abs(r["primal"] - ref["primal_value"]) <= 1e-7 * abs(ref["primal_value"])
-        assert np.abs(np.asarray(r["nu"]) / ref["nu"] - 1).max() <= 1e-6
-    # every rank took the identical sequence of steps (no broadcast of nu is ever needed)
-    for r in res[1:]:
-        assert r["evals"] == res[0]["evals"]
-        assert np.array_equal(np.asarray(r["nu"]), np.asarray(res[0]["nu"]))
+        assert r["uid_ok"] and r["world"] == world and r["mismatch_caught"]
+    # 1. linear-utility arbitrage and the two basket utilities (start prices are a broadcast guess there)
+    for key, util in (("arbitrage", cfmm.Arbitrage(net["c"])), ("liquidate", dist_worker.basket(net, "liquidate")),
+                      ("swap", dist_worker.basket(net, "swap"))):
+        if key not in SCENARIOS[world]:
+            continue
+        ref, v = _unsharded(net, util, 1e-6)
+        assert ref.status == "optimal"
+        assert sum(r[key]["pools"] for r in res) == cfmm.problem.network_pool_count(net)
+        for r in res:
+            q = r[key]
+            assert q["status"] == "optimal" and q["gap"] <= 1e-6 and q["infeas"] <= 1e-6
+            assert q["allreduces"] == q["evals"]                      # ONE collective per dual evaluation
+            assert abs(q["value"] - v) <= 2e-6 * abs(v)
+        # every rank started from bit-identical prices and took the identical sequence of steps
+        for r in res[1:]:
+            assert r[key]["nu0"] == res[0][key]["nu0"]
+            assert r[key]["evals"] == res[0][key]["evals"]
+            assert r[key]["nu"] == res[0][key]["nu"] and r[key]["psi"] == res[0][key]["psi"]
+    # 2. the shipped scripts pool-sharded: a partially filled constant-sum pool held by one rank only
+    g = golden()
+    for key, gname in (("arbitrage_py", "arbitrage"), ("liquidation_py", "liquidation"), ("two_asset_py", "two_asset_10")):
+        if key not in SCENARIOS[world]:
+            continue
+        want = g[gname]["survey"]["value"]
+        for r in res:
+            q = r[key]
+            assert q["status"] == "optimal", (key, q)
+            assert abs(q["value"] - want) <= 1e-8 * max(1.0, abs(want))
+            assert len(q["theta"]) == 1 and 1e-6 < q["theta"][0][1] < 1 - 1e-6     # the kink was found and filled
+        for r in res[1:]:
+            assert r[key]["solves"] == res[0][key]["solves"] and r[key]["allreduces"] == res[0][key]["allreduces"]
+            assert r[key]["nu"] == res[0][key]["nu"] and r[key]["theta"] == res[0][key]["theta"]
 
 
 def test_virtual_shards_sum_to_the_unsharded_evaluation(oracle_lib):
