@@ -1,26 +1,37 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's metric on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C4] [--no-cpu]
 
 One *step* = one complete solve of the hot path (dual-decomposition routing, projected L-BFGS on
-log-prices, on device) from a cold start to the 1e-6 certificates on one batch of synthetic input:
-BASELINE config 3 (1e6 mixed Uniswap-v2 + Balancer pools / 1000 tokens, linear-utility
-arbitrage) PER GPU -- the configuration the metric is quoted on.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank holds its own 1e6-pool shard of an N x 1e6
-network over the same tokens (weak scaling) and the library all-reduces [psi | sum arb] over
-RCCL once per dual evaluation.  value = pool-subproblems solved by all ranks / wall time of the
-K timed solves (inputs resident in HBM; upload excluded).
+log-prices, on device) from a cold start to the 1e-6 certificates on one batch of synthetic input.
 
-Also reported on the same JSON line:
+  --config C3 (default; the configuration the metric is quoted on): BASELINE config 3 -- 1e6 mixed Uniswap-v2 +
+      Balancer pools / 1000 tokens, linear-utility arbitrage -- PER GPU.  With N > 1 every rank holds its own
+      1e6-pool shard of an N x 1e6 network over the same tokens: WEAK scaling.
+  --config C4: BASELINE config 4 exactly -- 1e7 constant-product pools / 2000 tokens -- split N ways (1.25e6 pools
+      per GPU at N = 8): STRONG scaling.  At N = 1 the whole 320 MB set streams from HBM on one GPU.
+
+With N > 1 there is one process per GPU and the library all-reduces [psi | sum arb] over RCCL once per dual
+evaluation.  `python bench.py --gpus N` launches those processes itself (torch.distributed.run on 127.0.0.1) when it
+is not already running under a launcher; `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+works as well.  value = pool-subproblems solved by all ranks / wall time of the K timed solves (barrier +
+synchronize on both sides, max over ranks; inputs resident in HBM, upload excluded).
+
+Also on the same JSON line:
   roofline     -- the dominant evaluation kernel timed live with HIP events on the library's stream:
-                  algorithmic bytes per launch / average launch duration vs the 8 TB/s HBM peak
-  cpu_baseline -- oracle/cfmm_oracle.c (the CPU restatement, OpenMP on all host cores) running the
+                  algorithmic bytes per launch / average launch duration vs the 8 TB/s HBM peak; next to it the
+                  rocprofv3 average and PMC traffic of the newest summary committed under profiles/
+  per_iteration_us -- evaluation launch / accumulator fold / RCCL all-reduce / nu update + launch boundaries
+  cpu_baseline -- oracle/cfmm_oracle.c (the CPU restatement, OpenMP on the host cores) running the
                   same solve on the same instance, timed in this run (rank 0, N = 1 only)
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import socket
 import sys
 import time
 
@@ -32,14 +43,41 @@ for p in (ROOT, os.path.join(ROOT, "cfmm-routing-code_amd")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
-# HBM bytes per eval_kernel launch on the C3 workload from the rocprofv3 PMC passes committed under
-# profiles/ (FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM, + WRITE_SIZE); None until measured
-TRAFFIC_BYTES = (2 * 22898 + 2008) * 1024      # profiles/r01c_rocprofv3_pmc_medians.csv, config C3
-TRAFFIC_NOTE = ("C3's 43.4 MB working set fits the 256 MiB Infinity Cache: back-to-back launches are cache-served; "
-                "profiles/ holds the PMC traffic and the HBM-streaming (>= 1e7 pools) variant")
+TRAFFIC_NOTE = {"C3": "C3's 43.4 MB working set fits the 256 MiB Infinity Cache: back-to-back launches are cache-served; "
+                      "profiles/ holds the PMC traffic and the HBM-streaming (>= 1e7 pools) variant",
+                "C4": "320 MB per launch at N = 1: streams from HBM (larger than the 256 MiB Infinity Cache)"}
 
 BYTES_PER_POOL = {"cp2": 32, "w2": 40, "sum2": 32, "curve2": 40}     # SURVEY 8(d); k-asset: 20 + 20 k (+ log fee)
 KIND_ID = {"cp2": 0, "w2": 1, "sum2": 2, "curve2": 3}
+METRIC = "pool-subproblems/sec to 1e-6 rel-gap; 1e6 pools / 1k tokens; 1/2/4/8 GPU"
+
+
+def profile_record(config):
+    """HBM bytes per eval_kernel launch (PMC, corrected as MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE
+    doubled on gfx950, + WRITE_SIZE) and the rocprofv3 kernel-trace average of the same launch, from the NEWEST
+    summary committed under profiles/ -- read at run time so that the bench line cannot go stale silently."""
+    out = dict(traffic=None, traffic_file=None, rocprof_avg_us=None, rocprof_file=None)
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_pmc_medians.csv")))
+    for f in reversed(pmc):
+        rows = {}
+        for r in csv.DictReader(open(f)):
+            if r["config"] == config and "eval" in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                rows.setdefault(r["kernel"], {})[r["counter"]] = float(r["median"])
+        rows = {k: v for k, v in rows.items() if len(v) == 2}
+        if rows:                                   # the evaluation kernel that moves the most bytes: the dominant one
+            v = max(rows.values(), key=lambda v: v["FETCH_SIZE"])
+            out["traffic"] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+            out["traffic_file"] = os.path.relpath(f, ROOT)
+            break
+    stats = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_rocprofv3_kernel_stats_{config}.csv")))
+    for f in reversed(stats):
+        cand = [r for r in csv.DictReader(open(f)) if "eval" in r.get("Name", "")]
+        if cand:
+            r = max(cand, key=lambda r: float(r["TotalDurationNs"]))
+            out["rocprof_avg_us"] = float(r["AverageNs"]) / 1e3
+            out["rocprof_file"] = os.path.relpath(f, ROOT)
+            break
+    return out
 
 
 def kernel_table(prob, reps):
@@ -49,16 +87,18 @@ def kernel_table(prob, reps):
     net = prob.net
     parts = []
     for key in ("cp2", "w2", "sum2", "curve2"):
-        if key in net:
+        if key in net and len(net[key]["Ra"]):
             m = len(net[key]["Ra"])
             parts.append((f"eval_kernel[{key} only]", KIND_ID[key], m, m * BYTES_PER_POOL[key]))
     for k, b in sorted(net.get("gn", {}).items()):
         m = b["R"].shape[1]
-        parts.append((f"eval_kernel[gn{k} only]", -k, m, m * (20 + 20 * k)))
+        if m:
+            parts.append((f"eval_kernel[gn{k} only]", -k, m, m * (20 + 20 * k)))
     rows = [dict(kernel="eval_kernel", pools=sum(p[2] for p in parts), bytes=sum(p[3] for p in parts),
                  seconds=prob.ctx.time_eval_kernel(_lib.TIME_ALL, reps))]
-    for name, code, m, nbytes in parts:
-        rows.append(dict(kernel=name, pools=m, bytes=nbytes, seconds=prob.ctx.time_eval_kernel(code, reps)))
+    if len(parts) > 1:
+        for name, code, m, nbytes in parts:
+            rows.append(dict(kernel=name, pools=m, bytes=nbytes, seconds=prob.ctx.time_eval_kernel(code, reps)))
     for r in rows:
         r["GBps"] = r["bytes"] / r["seconds"] / 1e9
         r["pools_per_s"] = r["pools"] / r["seconds"]
@@ -66,12 +106,24 @@ def kernel_table(prob, reps):
     return rows
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside any launcher: become the launcher.  One rank per GPU of this node,
+    rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C3")
+    ap.add_argument("--config", default=os.environ.get("BENCH_CONFIG", "C3"), choices=["C3", "C4"])
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--no-cpu", action="store_true")
@@ -82,12 +134,15 @@ def main():
                     help="run the pool-sharded code path (process group, RCCL communicator, all-reduce per evaluation) even with one rank")
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        self_launch(args)                        # (does not return)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    if launched and args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; using {world}", file=sys.stderr)
         args.gpus = world
 
     import cfmm
@@ -100,12 +155,22 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    net = synthetic.config(args.config, seed=0, scale=args.scale, pool_seed=(rank if world > 1 else None))
-    # weak scaling: every rank generates its OWN 1e6-pool shard (same tokens / prices / utility)
-    prob = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=local_rank, shard=False)
+    strong = args.config == "C4"
+    if strong:
+        # strong scaling: ONE fixed network (same seed on every rank), contiguous pool shards
+        net = synthetic.config("C4", seed=0, scale=args.scale)
+        total_pools = cfmm.problem.network_pool_count(net)
+        prob = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=local_rank, shard=True)
+    else:
+        # weak scaling: every rank generates its OWN 1e6-pool shard (same tokens / prices / utility)
+        net = synthetic.config("C3", seed=0, scale=args.scale, pool_seed=(rank if world > 1 else None))
+        prob = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=local_rank, shard=False)
+        total_pools = prob.m * world
     prob._ensure_ctx()
 
     def sync():
@@ -125,8 +190,10 @@ def main():
         prob.solve(tol=args.tol)
         evals += prob.stats["evals"]
         dev_s += prob.stats["device_seconds"]
-        if prob.status != "optimal":
-            raise SystemExit(f"rank {rank}: solve ended with status {prob.status} (gap {prob.gap:.2e}, infeas {prob.infeas:.2e})")
+        # the metric is "to 1e-6 rel-gap": both certificates at the requested tolerance, checked here and not only
+        # through the status string
+        if prob.status != "optimal" or not (prob.gap <= args.tol and prob.infeas <= args.tol):
+            raise SystemExit(f"rank {rank}: solve ended with status {prob.status} (gap {prob.gap:.2e}, infeas {prob.infeas:.2e}, tol {args.tol:g})")
     sync()
     dt = time.perf_counter() - t0
     if sharded:
@@ -134,33 +201,53 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    subproblems = evals * prob.m * world       # every rank runs the same number of evaluations
+    subproblems = evals * total_pools          # every rank runs the same number of evaluations over its own pools
     value = subproblems / dt
+
+    # per-iteration split (all ranks: the all-reduce timing is a collective)
+    fold_s, ar_s = prob.ctx.time_collective(args.kernel_reps) if sharded else (0.0, 0.0)
+    # the evaluation launch at prices ~1 % off the market (about 88 % of the pools trade, as in the first iterations
+    # of a solve and in tools/profile_eval.py, whose rocprofv3 trace is committed under profiles/)
+    prob.ctx.set_nu(net["c"] * np.exp(np.random.default_rng(0).normal(0, 0.01, net["n_tokens"])))
+    rows = kernel_table(prob, args.kernel_reps)
 
     out = None
     if rank == 0:
-        rows = kernel_table(prob, args.kernel_reps)
         dom = rows[0]
-        mix = ", ".join(f"{k}={len(net[k]['Ra'])}" for k in ("cp2", "w2", "curve2", "sum2") if k in net)
-        if "gn" in net:
-            mix += ", gn3-8=" + str(sum(b["R"].shape[1] for b in net["gn"].values()))
+        mix = ", ".join(f"{k}={len(prob.net[k]['Ra'])}" for k in ("cp2", "w2", "curve2", "sum2") if k in prob.net)
+        if "gn" in prob.net:
+            mix += ", gn3-8=" + str(sum(b["R"].shape[1] for b in prob.net["gn"].values()))
+        prof = profile_record(args.config)
+        us_iter = 1e6 * dev_s / max(evals, 1)
+        if strong:
+            workload = (f"C4: {total_pools} constant-product pools / {net['n_tokens']} tokens split over {world} GPU(s) "
+                        f"({prob.m} per GPU: {mix}), linear-utility arbitrage, cold-start solve to gap,infeas <= {args.tol:g}")
+        else:
+            workload = (f"C3: {prob.m} pools per GPU ({mix}) / {net['n_tokens']} tokens, "
+                        f"linear-utility arbitrage, cold-start solve to gap,infeas <= {args.tol:g}")
         out = {
-            "metric": "pool-subproblems/sec to 1e-6 rel-gap; 1e6 pools / 1k tokens; 1/2/4/8 GPU",
+            "metric": METRIC,
             "value": value, "unit": "pool-subproblems/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {prob.m} pools per GPU ({mix}) / {net['n_tokens']} tokens, "
-                                   f"linear-utility arbitrage, cold-start solve to gap,infeas <= {args.tol:g}",
-                       "pools_per_gpu": prob.m, "tokens": net["n_tokens"], "seed": 0,
-                       "parallelism": f"pool-sharding x{world}" if world > 1 else "single GPU"},
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "pools_per_gpu": prob.m, "pools_total": total_pools, "tokens": net["n_tokens"], "seed": 0,
+                       "parallelism": f"pool-sharding x{world}" if world > 1 else "single GPU",
+                       "rccl_ranks": prob.stats.get("n_ranks", 1)},
             "evals_per_solve": evals / args.steps,
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "us_per_eval": 1e6 * dt / max(evals, 1),
+            "per_iteration_us": {"total_device": us_iter, "eval_kernel": dom["us"], "fold": 1e6 * fold_s, "allreduce": 1e6 * ar_s,
+                                 "update_and_launch_boundaries": us_iter - dom["us"] - 1e6 * (fold_s + ar_s),
+                                 "note": "eval / fold / all-reduce timed as back-to-back launches with HIP events on the library's stream; "
+                                         "the remainder of the device time per iteration is the nu update and the dependent-launch boundaries"},
             "gap": prob.gap, "infeas": prob.infeas, "objective": prob.value,
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES,
+                         "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": prof["traffic"],
+                         "traffic_source": prof["traffic_file"],
                          "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": dom["seconds"] * 1e6,
-                         "note": TRAFFIC_NOTE,
+                         "rocprof_avg_launch_us": prof["rocprof_avg_us"], "rocprof_source": prof["rocprof_file"],
+                         "frac_rocprof": (dom["bytes"] / (prof["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if prof["rocprof_avg_us"] and world == 1 and args.scale == 1.0 else None,
+                         "note": TRAFFIC_NOTE[args.config],
                          "all_kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]},
         }
         if world == 1 and not args.no_cpu:
@@ -184,6 +271,8 @@ def main():
             t0 = time.perf_counter(); ce = 0; ns = 0
             while ns < args.cpu_solves or time.perf_counter() - t0 < args.cpu_seconds:     # >= 10 s: past any cgroup burst allowance
                 r = o.solve(net["c"], tol=args.tol); ce += r["evals"]; ns += 1
+                if time.perf_counter() - t0 > 3 * args.cpu_seconds:
+                    break
             cdt = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": ce * prob.m / cdt, "unit": "pool-subproblems/s", "cores": cores, "kind": "port",
                                    "sample": f"{ns} full solves of the same {prob.m}-pool instance to the same tolerance by "

@@ -2,7 +2,12 @@
 
     python -B oracle/make_golden.py
 
-Two independent sources per instance, both stored:
+Three independent sources per instance, all stored:
+  * "kkt":    the KKT system of the program polished by Newton's method in 50-digit arithmetic
+              (oracle/kkt_mp.py: geo-mean pools through the n-asset KKT form, active set verified on the
+              result) -- objective, psi, prices and EVERY pool's tenders to ~1e-30; this is what pins tenders
+              at 1e-9 in the tests.  It showed the survey's per-pool vectors to be good to ~5e-6 only
+              (arbitrage.py's constant-sum pool fills 0.3863495091 of its reserve, not 0.38634998);
   * "primal": the reference's primal model (arbitrage.py:51-78 etc.) solved by SciPy SLSQP
               (oracle/primal_scipy.py) -- the objective is good to ~1e-9, trades to ~1e-6;
   * "survey": the known answers of SURVEY.md Appendix B (derived in the survey session by SLSQP
@@ -19,6 +24,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import instances as I          # noqa: E402
 from oracle.primal_scipy import solve_primal   # noqa: E402
+from oracle import kkt_mp                       # noqa: E402
+
+# constant-sum pools that end on a kink ("PARTIAL fill"), with the direction of the kink
+# (+1: tender the pool's first token).  kkt_mp.polish verifies the guess (fill inside (0,1), complementary slackness).
+TIED = {"arbitrage": {4: -1}, "liquidation": {4: 1}, "two_asset_10": {4: -1}}
 
 SURVEY = {
     "arbitrage": dict(value=21.4998087639, psi=[0, 1.174978045, 0, 3.2500094379],
@@ -46,11 +56,13 @@ def main():
         cases.append((f"two_asset_{j}", I.two_asset(sweep[j])))
     for name, inst in cases:
         r = solve_primal(I.normalise(inst))
+        k = kkt_mp.polish(I.normalise(inst), SURVEY[name]["nu"], TIED.get(name, {}))
         out[name] = dict(
+            kkt=k,
             primal=dict(value=r["value"], psi=r["psi"].tolist(), y=[v.tolist() for v in r["y"]]),
             survey=SURVEY[name],
             t=inst["utility"].get("h", [0])[0] if inst["name"] == "two_asset" else None)
-        print(name, r["value"], SURVEY[name]["value"])
+        print(name, k["value_str"], r["value"], SURVEY[name]["value"])
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "shipped_instances.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -52,6 +52,45 @@ def test_eval_dual_matches_oracle(oracle_lib, cfg, scale):
     p.close()
 
 
+@pytest.mark.parametrize("cfg", ["C3", "C4shard", "C4", "C5"])
+def test_full_size_eval_dual_matches_oracle(oracle_lib, cfg):
+    """BASELINE configs 3, 4 (one GPU's shard AND the whole 1e7-pool set) and 5 at FULL size: one dual evaluation,
+    GPU vs the C oracle on the same seeded input -- sum arb, every entry of psi, the diagonal metric"""
+    net = synthetic.config(cfg, seed=0)
+    n = net["n_tokens"]
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    o = _oracle_for(oracle_lib, net, threads=16)
+    rng = np.random.default_rng(12)
+    for sig in (0.01, 0.2):
+        nu = net["c"] * np.exp(rng.normal(0, sig, n))
+        f1, psi1, d1 = p.eval_dual(nu, want_diag=True)
+        f0, psi0, d0 = o.eval(nu, want_diag=True)
+        assert abs(f1 - f0) <= 1e-11 * max(abs(f0), 1.0)
+        # psi_j is a sum of ~2 m / n terms of either sign: the yardstick is the gross flow, not the cancelling net
+        assert np.abs(psi1 - psi0).max() <= 1e-10 * max(np.abs(psi0).max(), 1.0)
+        assert np.abs(d1 - d0).max() <= 1e-11 * np.abs(d0).max()
+    p.close()
+
+
+@pytest.mark.parametrize("cfg", ["C3", "C4shard", "C4"])
+def test_full_size_solve_matches_oracle_solver(oracle_lib, cfg):
+    """... and the converged solve (the configuration bench.py times, and both forms of config 4): objective, dual
+    value and prices against the C oracle running the same iteration to the same 1e-6 certificates"""
+    net = synthetic.config(cfg, seed=0)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    o = _oracle_for(oracle_lib, net, threads=16)
+    v = p.solve(tol=1e-6)
+    r = o.solve(net["c"], tol=1e-6)
+    assert p.status == "optimal" and p.gap <= 1e-6 and p.infeas <= 1e-6 and r["status"] == 1
+    assert abs(v - r["primal_value"]) <= 2e-6 * abs(v)              # both within 1e-6 of the optimum
+    assert abs(p.dual_value - r["dual_value"]) <= 2e-6 * abs(v)
+    assert p.stats["evals"] <= 2 * r["evals"] + 16
+    f0, psi0 = o.eval(p.nu)                                       # the oracle's evaluation AT the GPU's prices
+    assert np.abs(p.psi - psi0).max() <= 1e-9 * max(np.abs(psi0).max(), 1.0)
+    assert abs(net["c"] @ psi0 - v) <= 1e-9 * abs(v)
+    p.close()
+
+
 def test_trades_match_oracle_pool_by_pool(oracle_lib):
     net = synthetic.config("C3", scale=0.02, seed=4)
     cv = synthetic.config("C5", scale=0.01, seed=4)
@@ -141,11 +180,14 @@ def test_shipped_instances_through_hip(name, inst):
     assert p.status == "optimal"
     assert abs(v - g["survey"]["value"]) <= 1e-6 * max(1, abs(v))          # the north-star tolerance
     assert abs(v - g["survey"]["value"]) <= 1e-8 * max(1, abs(v))          # ... and what we actually reach
-    assert np.abs(p.psi - np.asarray(g["primal"]["psi"])).max() <= 2e-5
-    ys = g["survey"].get("y") or g["primal"]["y"]
-    for d, l, y in zip(p.deltas, p.lambdas, ys):
+    assert abs(v - g["kkt"]["value"]) <= 1e-9 * max(1, abs(v))             # (against the 50-digit KKT solution)
+    assert p.gap <= 1e-10 and p.infeas <= 1e-10
+    # psi and EVERY pool's tenders against the 50-digit KKT solution: 1e-6 absolute is the bar
+    assert np.abs(p.psi - np.asarray(g["kkt"]["psi"])).max() <= 5e-8
+    for d, l, y in zip(p.deltas, p.lambdas, g["kkt"]["y"]):
         assert np.all(d >= 0) and np.all(l >= 0) and np.all(d * l == 0)
-        assert np.abs((l - d) - np.asarray(y)).max() <= 2e-5
+        assert np.abs((l - d) - np.asarray(y)).max() <= 1e-6
+        assert np.abs((l - d) - np.asarray(y)).max() <= 5e-8
     p.close()
 
 
@@ -160,7 +202,7 @@ def test_two_asset_sweep_warm_started():
     vals = np.array(vals)
     g = golden()
     for j in (0, 1, 10, 25, 49):
-        assert abs(vals[j] - g[f"two_asset_{j}"]["survey"]["value"]) <= 1e-7
+        assert abs(vals[j] - g[f"two_asset_{j}"]["kkt"]["value"]) <= 1e-7
     assert np.all(np.diff(vals) > 0)
     p.close()
 
@@ -237,8 +279,14 @@ def test_integration_md_ctypes_stub_runs():
     ns = {}
     exec(stub[0].replace("<repo>", root), ns)
     st = ns["st"]
-    assert st.status == 1 and st.gap <= 1e-6 and st.infeas <= 1e-6 and st.primal_value > 1.0
-    assert np.all(ns["psi"] >= -1e-6 * np.abs(ns["psi"]).max())
+    # the full five-pool instance of arbitrage.py through the raw ABI: prob.value of arbitrage.py:84
+    assert st.status == 1 and st.gap <= 1e-9 and st.infeas <= 1e-9
+    assert abs(st.primal_value - 21.4998087635) <= 1e-7 and abs(st.primal_value - golden()["arbitrage"]["kkt"]["value"]) <= 1e-7
+    assert np.all(ns["psi"] >= -1e-8 * np.abs(ns["psi"]).max())
+    assert np.abs(ns["psi"] - np.asarray(golden()["arbitrage"]["kkt"]["psi"])).max() <= 1e-6
+    # ... and the partially filled constant-sum pool's net tender (38.6 % of its reserve, arbitrage.py:12,20,28)
+    y = ns["lam"] - ns["dlt"]
+    assert np.abs(y[:, 0] - np.asarray(golden()["arbitrage"]["kkt"]["y"][4])).max() <= 1e-6
 
 
 def test_full_size_c4_single_gpu_streams_from_hbm():
