@@ -156,7 +156,7 @@ def main():
         import torch
         import torch.distributed as dist
         if torch.cuda.device_count() < world:
-            raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
+            raise SystemExit(f"bench.py: rank {rank} of {world}: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
