@@ -23,6 +23,7 @@
 
 #include "../../include/cfmm.h"
 #include "kernels.hpp"
+#include "iterate.hpp"
 #include "smooth.hpp"
 #include "chol.hpp"
 
@@ -122,6 +123,13 @@ struct cfmm_ctx {
     // host copies needed to derive bounds
     std::vector<double> hc, hh, hoff;
     std::vector<int> hctype, hgrp;
+
+    // fused iteration (iterate.hpp): three rotating sets of accumulators / solver state, a history ring of M + 1 slots
+    bool fused = true;                 // CFMM_FUSED=0: the two-launch iteration of round 1 (A/B)
+    double *acc3 = nullptr, *xs3 = nullptr, *S5 = nullptr, *Y5 = nullptr, *rho5 = nullptr;
+    DevState *st3 = nullptr;
+    DevState *hst3 = nullptr;          // pinned [2][3]
+    int iter_blocks_per_cu = 1;
 
     // graph cache
     hipGraphExec_t gexec = nullptr;
@@ -354,6 +362,8 @@ int set_all_lds_attrs(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, update_reg_kernel<256, 8, 4>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_gram_kernel<512, 2>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, start_kernel, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<1>, e0))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<2>, e0))) return rc;
     return CFMM_OK;
 }
 
@@ -371,6 +381,70 @@ UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
     a.tol_gap = o.tol_gap; a.tol_infeas = o.tol_infeas; a.armijo = o.armijo; a.max_step = o.max_step;
     a.max_evals = o.max_evals; a.pg_rule = o.pg_rule; a.ts = ctx->ts;
     return a;
+}
+
+// ---- the fused iteration (iterate.hpp) ---------------------------------------------------------------------------
+// applies when the update fits the evaluation launch: no price ties, <= 2048 tokens, memory <= 4
+bool fused_applies(cfmm_ctx *ctx, const cfmm_opts &o)
+{
+    return ctx->fused && ctx->ng == ctx->n && ctx->n <= 2 * EVAL_THREADS && o.memory <= GRAM_MM;
+}
+
+size_t acc_set_doubles(cfmm_ctx *ctx) { return (size_t)ctx->nslices * acc_stride(ctx->n); }
+
+IterArgs make_iter_args(cfmm_ctx *ctx, const cfmm_opts &o)
+{
+    IterArgs a = {};
+    a.ev = make_eval_args(ctx, false);
+    a.ev.nu = nullptr; a.ev.acc = nullptr;
+    a.n = ctx->n; a.M = o.memory; a.nread = ctx->comm ? 1 : ctx->nslices; a.phase = 0;
+    a.xvs = iter_xvs(ctx->n); a.max_evals = o.max_evals; a.pg_rule = o.pg_rule;
+    a.acc3 = ctx->acc3; a.acc_set = (long long)acc_set_doubles(ctx);
+    a.xs = ctx->xs3; a.xs_set = (long long)XS_VECS * a.xvs;
+    a.st3 = ctx->st3;
+    a.S = ctx->S5; a.Y = ctx->Y5; a.rho = ctx->rho5;
+    a.c = ctx->c; a.h = ctx->h; a.glo = ctx->glo; a.ghi = ctx->ghi; a.ctype = ctx->ctype;
+    a.Ds = ctx->Ds;
+    a.nu = ctx->nu; a.nu_acc = ctx->nu_acc; a.psi_acc = ctx->psi_acc;
+    a.tol_gap = o.tol_gap; a.tol_infeas = o.tol_infeas; a.armijo = o.armijo; a.max_step = o.max_step;
+    return a;
+}
+
+// outer iteration t >= 1 as ONE launch (+ the stableswap bucket's own evaluation launch, + fold / all-reduce when
+// pool-sharded): update from the accumulators of launch t - 1, evaluation at the new prices into set t % 3
+int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
+{
+    IterArgs a = base;
+    a.phase = t % 3;
+    const int n = ctx->n, E = (n <= EVAL_THREADS && ITER_E_SMALL == 1) ? 1 : 2;
+    int grid, threads;
+    {
+        const int slots = ctx->cus * ctx->iter_blocks_per_cu * ctx->eval_grid_mult;
+        int wpb = (a.ev.ntiles + slots - 1) / slots;
+        wpb = wpb < 1 ? 1 : (wpb > EVAL_THREADS / 64 ? EVAL_THREADS / 64 : wpb);
+        const int need = (n + 64 * E - 1) / (64 * E);          // waves the update needs: E variables per thread
+        if (wpb < need) wpb = need;
+        threads = 64 * wpb;
+        grid = (a.ev.ntiles + wpb - 1) / wpb;
+        if (grid > slots) grid = slots;
+        if (grid < 1) grid = 1;                                 // (a shard without pools still takes the step)
+    }
+    const size_t lds = eval_lds_bytes(n, false);
+    if (E == 1) hipLaunchKernelGGL(iter_kernel<1>, dim3(grid), dim3(threads), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(iter_kernel<2>, dim3(grid), dim3(threads), lds, ctx->stream, a);
+    double *acc_p = ctx->acc3 + (size_t)a.phase * acc_set_doubles(ctx);
+    if (ctx->pools->b2[CFMM_POOL_CURVE2].m > 0) {              // the stableswap bucket has its own instantiation: it reads the
+        EvalArgs es = make_eval_args(ctx, true);              // prices (and the stop flag) workgroup 0 has just stored
+        es.nu = ctx->nu; es.acc = acc_p;
+        launch_eval<false, true>(ctx, es);
+    }
+    if (ctx->comm) {
+        const int len = acc_arb(n) + 1;
+        hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, acc_p, n, ctx->nslices, 0, (const DevState *)nullptr);
+        int rc = g_rccl.AllReduce(acc_p, acc_p, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
+        if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    }
+    return CFMM_OK;
 }
 
 // the nu update: register-resident kernel up to 2048 tokens (2 per thread), the generic one beyond
@@ -448,6 +522,10 @@ int build_graph(cfmm_ctx *ctx, const cfmm_opts &o)
     hipGraph_t graph = nullptr;
     HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     int rc = CFMM_OK;
+    if (fused_applies(ctx, o)) {
+        const IterArgs ia = make_iter_args(ctx, o);            // (iters_per_graph is a multiple of 3 here: the phases are baked in)
+        for (int it = 0; it < o.iters_per_graph && rc == CFMM_OK; ++it) rc = enqueue_fused_iteration(ctx, ia, it + 1);
+    } else
     for (int it = 0; it < o.iters_per_graph && rc == CFMM_OK; ++it) rc = enqueue_iteration<false>(ctx, ua);
     hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
     if (rc != CFMM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -885,13 +963,14 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
         return bail(CFMM_E_LIMIT);
     }
     TRY_C(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    if (const char *s = getenv("CFMM_SLICES")) ctx->nslices = std::max(1, atoi(s));
+    if (const char *s = getenv("CFMM_SLICES")) ctx->nslices = std::min(64, std::max(1, atoi(s)));
     if (const char *s = getenv("CFMM_EVAL_GRID_MULT")) ctx->eval_grid_mult = std::max(1, atoi(s));
     if (const char *s = getenv("CFMM_UPDATE_GENERIC")) ctx->upd_generic = atoi(s) != 0;
     if (const char *s = getenv("CFMM_UPDATE_VARIANT")) ctx->upd_variant = atoi(s);
     if (const char *s = getenv("CFMM_UPD_GRID")) ctx->upd_grid = std::max(1, atoi(s));
     if (const char *s = getenv("CFMM_MULTI_GRAPH")) ctx->multi_graph = atoi(s) != 0;
     if (const char *s = getenv("CFMM_NO_GRAPH")) ctx->no_graph = atoi(s) != 0;
+    if (const char *s = getenv("CFMM_FUSED")) ctx->fused = atoi(s) != 0;
     const int n = n_tokens;
     int rc = 0;
     rc |= dev_upload<double>(ctx, &ctx->c, nullptr, n + 4, nullptr);
@@ -909,9 +988,16 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     rc |= dev_upload<double>(ctx, &ctx->rho, nullptr, MAX_MEMORY, nullptr);
     rc |= dev_upload<double>(ctx, &ctx->acc, nullptr, (size_t)ctx->nslices * acc_stride(n) + 4, nullptr);
     rc |= dev_upload<DevState>(ctx, &ctx->st, nullptr, 1, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->acc3, nullptr, 3 * (size_t)ctx->nslices * acc_stride(n) + 4, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->xs3, nullptr, 3 * (size_t)XS_VECS * iter_xvs(n) + 4, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->S5, nullptr, (size_t)ITER_RING * hist_stride(n) + 4, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->Y5, nullptr, (size_t)ITER_RING * hist_stride(n) + 4, nullptr);
+    rc |= dev_upload<double>(ctx, &ctx->rho5, nullptr, ITER_RING + 3, nullptr);
+    rc |= dev_upload<DevState>(ctx, &ctx->st3, nullptr, 3, nullptr);
     rc |= dev_upload<long long>(ctx, &ctx->ts, nullptr, 64 + 8 * 4096 + 2048, nullptr);
     if (rc) return bail(CFMM_E_HIP);
     TRY_C(hipHostMalloc((void **)&ctx->hst, 2 * sizeof(DevState), hipHostMallocDefault));
+    TRY_C(hipHostMalloc((void **)&ctx->hst3, 6 * sizeof(DevState), hipHostMallocDefault));
     TRY_C(hipHostMalloc((void **)&ctx->hsol, 2 * (size_t)n * sizeof(double), hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) TRY_C(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
     TRY_C(hipEventCreate(&ctx->ev_t0));
@@ -921,6 +1007,10 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
         int nb = 0;
         TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eval_kernel<false, false>, EVAL_THREADS, eval_lds_bytes(n, false)));
         ctx->eval_blocks_per_cu = nb < 1 ? 1 : nb;
+        nb = 0;
+        if (n <= 1024) TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iter_kernel<1>, EVAL_THREADS, eval_lds_bytes(n, false)));
+        else TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iter_kernel<2>, EVAL_THREADS, eval_lds_bytes(n, false)));
+        ctx->iter_blocks_per_cu = nb < 1 ? 1 : nb;
     }
     if (ctx->nslices > 64) ctx->nslices = 64;
     // default utility state: identity groups
@@ -961,9 +1051,10 @@ int cfmm_destroy(cfmm_ctx *ctx)
     for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
     void *ptrs[] = {ctx->c, ctx->h, ctx->off, ctx->glo, ctx->ghi, ctx->ctype, ctx->grp, ctx->nu, ctx->nu_acc, ctx->psi_acc,
                     ctx->psi_t, ctx->nu0, ctx->s, ctx->s_t, ctx->Gs, ctx->Gs_t, ctx->d, ctx->Ds, ctx->S, ctx->Y, ctx->rho,
-                    ctx->acc, ctx->st, ctx->ts};
+                    ctx->acc, ctx->st, ctx->ts, ctx->acc3, ctx->xs3, ctx->S5, ctx->Y5, ctx->rho5, ctx->st3};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->hst) (void)hipHostFree(ctx->hst);
+    if (ctx->hst3) (void)hipHostFree(ctx->hst3);
     if (ctx->hsol) (void)hipHostFree(ctx->hsol);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
@@ -1308,45 +1399,85 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     return rc;
 }
 
-static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out)
+static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
 {
     const int n = ctx->n;
     ctx->mu_last = 0.0;
+    cfmm_opts o = o_in;
+    // One launch per iteration (iterate.hpp) whenever the update fits the evaluation launch; otherwise the
+    // two-launch iteration (evaluation kernel, single-workgroup update kernel).
+    const bool fused = fused_applies(ctx, o);
+    if (fused) o.iters_per_graph = (o.iters_per_graph + 2) / 3 * 3;       // the rotation phase t % 3 is baked into captured launches
     // Single GPU: `iters_per_graph` iterations are replayed from one captured hipGraph.  Pool-sharded
     // (RCCL all-reduce inside every iteration): the same iterations are enqueued eagerly, the way RCCL
     // is conventionally driven (CFMM_MULTI_GRAPH=1 opts into capturing them too).
     const bool use_graph = (!ctx->comm || ctx->multi_graph) && !ctx->no_graph;
     if (use_graph && (!ctx->g_valid || !same_opts(o, ctx->g_opts))) { int rc = build_graph(ctx, o); if (rc) return rc; }
-    const UpdArgs ua = make_upd_args(ctx, o);
+    UpdArgs ua = make_upd_args(ctx, o);
+    const IterArgs ia = make_iter_args(ctx, o);
+    const size_t aset = acc_set_doubles(ctx);
 
     // ---- timed region: the outer loop (upload and trade read-back excluded) ----------------
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu0, ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(start_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu0);
-    { int rc = enqueue_iteration<true>(ctx, ua); if (rc) return rc; }      // first evaluation also builds the metric
+    if (fused) {
+        // launch 0: the start point and the first evaluation (with the diagonal metric) into state / accumulator set 0
+        HIP_TRY(ctx, hipMemsetAsync(ctx->acc3, 0, 3 * aset * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->st3, 0, 3 * sizeof(DevState), ctx->stream));
+        double *x0 = ctx->xs3;
+        ua.s = x0; ua.s_t = x0 + ia.xvs; ua.Gs = x0 + 2 * ia.xvs; ua.d = x0 + 3 * ia.xvs; ua.nu = x0 + 4 * ia.xvs; ua.st = ctx->st3;
+        hipLaunchKernelGGL(start_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu0);
+        for (int stable = 0; stable < 2; ++stable) {
+            EvalArgs e0 = make_eval_args(ctx, stable != 0);
+            e0.nu = ua.nu; e0.acc = ctx->acc3;
+            if (stable) launch_eval<true, true>(ctx, e0); else launch_eval<true, false>(ctx, e0);
+        }
+        if (ctx->comm) {
+            const int len = acc_stride(n);
+            hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc3, n, ctx->nslices, 1, (const DevState *)nullptr);
+            int rc = g_rccl.AllReduce(ctx->acc3, ctx->acc3, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
+            if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+        }
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
+        hipLaunchKernelGGL(start_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu0);
+        { int rc = enqueue_iteration<true>(ctx, ua); if (rc) return rc; }      // first evaluation also builds the metric
+    }
     HIP_TRY(ctx, hipGetLastError());
     const int max_chunks = (o.max_evals + o.iters_per_graph - 1) / o.iters_per_graph + 1;
-    int status = 0;
+    // the state lives in ONE DevState (two-launch iteration) or in three rotating ones, of which the newest counts
+    auto newest = [&](const DevState *h) -> const DevState & {
+        int b = 0;
+        if (fused) for (int q = 1; q < 3; ++q) if (h[q].evals > h[b].evals) b = q;      // (every update counts one evaluation)
+        return h[b];
+    };
+    const int nst = fused ? 3 : 1;
+    DevState *hring = fused ? ctx->hst3 : ctx->hst;
+    const DevState *dst = fused ? ctx->st3 : ctx->st;
+    int status = 0, t = 1;
     for (int cidx = 0; cidx < max_chunks; ++cidx) {
         if (use_graph) {
             HIP_TRY(ctx, hipGraphLaunch(ctx->gexec, ctx->stream));
         } else {
-            for (int it = 0; it < o.iters_per_graph; ++it) { int rc = enqueue_iteration<false>(ctx, ua); if (rc) return rc; }
+            for (int it = 0; it < o.iters_per_graph; ++it) {
+                int rc = fused ? enqueue_fused_iteration(ctx, ia, t + it) : enqueue_iteration<false>(ctx, ua);
+                if (rc) return rc;
+            }
             HIP_TRY(ctx, hipGetLastError());
         }
-        HIP_TRY(ctx, hipMemcpyAsync(&ctx->hst[cidx & 1], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
+        t += o.iters_per_graph;
+        HIP_TRY(ctx, hipMemcpyAsync(hring + (cidx & 1) * nst, dst, nst * sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev[cidx & 1], ctx->stream));
         if (cidx >= 1) {                       // poll one chunk behind: the device never idles
             HIP_TRY(ctx, hipEventSynchronize(ctx->ev[(cidx - 1) & 1]));
-            status = ctx->hst[(cidx - 1) & 1].status;
+            status = newest(hring + ((cidx - 1) & 1) * nst).status;
             if (status != 0) break;
         }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(&ctx->hst[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(hring, dst, nst * sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->hsol, ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->hsol + n, ctx->psi_acc, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1355,7 +1486,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out)
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
 
-    const DevState &st = ctx->hst[0];
+    const DevState st = newest(hring);
     std::memset(out, 0, sizeof *out);
     out->evals = st.evals; out->iters = st.iters; out->status = st.status ? st.status : 3;
     out->n_ranks = ctx->n_ranks;
@@ -1473,6 +1604,7 @@ int cfmm_selftest(cfmm_ctx *ctx)
     HIP_TRY(ctx, hipMalloc((void **)&d, sizeof(int)));
     HIP_TRY(ctx, hipMemsetAsync(d, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
+    hipLaunchKernelGGL(selftest_gram_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
     hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);

@@ -1,0 +1,496 @@
+// iter_kernel: ONE launch per outer iteration -- the nu update folded into the evaluation launch (gfx950, wave64, fp64).
+//
+// Round 1 ran an outer iteration as two dependent launches: eval_kernel (256 workgroups) -> update_gram_kernel (ONE
+// workgroup: 255 CUs idle for 8.6 us) -> next eval_kernel, i.e. two launch boundaries (~2 us each) and a serial section
+// per iteration: 28.5 us of device time for a 15-16 us evaluation.  Here EVERY workgroup of the evaluation launch
+// performs the (cheap, latency-bound) update itself in its prologue -- redundantly and bit-identically: same code, same
+// inputs, same reduction order -- from the accumulators the previous launch flushed, writes the new prices straight into
+// its LDS copy and goes on to its tiles.  Workgroup 0 alone stores the new solver state.
+//                                                                        reference: arbitrage.py:82 (prob.solve())
+// No grid barrier, no flags: what one launch writes is only read by the NEXT launch.  That needs rotation:
+//   * accumulators, three sets: launch t reads A[(t-1) % 3] (complete: flushed by launch t-1), flushes into A[t % 3],
+//     and one of its workgroups zeroes A[(t+1) % 3] (last read by launch t-1, next flushed into by launch t+1);
+//   * solver state (s, s_t, Gs, d, trial prices, DevState), three sets: read X[(t-1) % 3], write X[t % 3];
+//   * the L-BFGS history is a ring of M + 1 slots for a window of M pairs, so the slot a launch writes is never one
+//     another workgroup of the same launch still reads.
+// The phase t % 3 is a kernel argument; captured graphs hold a multiple of three launches.
+// Pool-sharded: launch t -> fold A[t % 3] -> ncclAllReduce(slice 0) -> launch t+1 reads that one slice.
+//
+// The update itself is the Gram form of kernels.hpp (update_gram_kernel; mirrors oracle/cfmm_oracle.c:oracle_step):
+// all 44 scalars the accept test, the stopping rule and the two-loop recursion need come out of ONE batched
+// reduce-scatter.  To fit the evaluation kernel's register budget (128 VGPRs at 16 waves per CU; the stand-alone
+// Gram kernel uses 223) the 64 per-lane products are never alive together: values i and i + 32 are produced as a pair
+// and immediately exchanged across the wave halves (v_permlane32_swap), which leaves 32 running values.
+#pragma once
+#include <utility>
+#include "kernels.hpp"
+
+namespace cfmm {
+
+#ifndef ITER_E_SMALL_DEF
+#define ITER_E_SMALL_DEF 1
+#endif
+constexpr int ITER_E_SMALL = ITER_E_SMALL_DEF;  // variables per thread of the in-launch update up to EVAL_THREADS tokens (2 beyond)
+constexpr int ITER_RING = GRAM_MM + 1;      // physical history slots (window GRAM_MM)
+constexpr int XS_VECS = 5;                  // s | s_t | Gs | d | trial prices, per state set
+__host__ __device__ inline int iter_xvs(int n) { return (n + 3) & ~1; }      // vector stride of a state set: >= n + 2 (the stop flag rides at [n]), even
+
+struct IterArgs {
+    EvalArgs ev;                    // tile space of the evaluation (ev.nu / ev.acc are not used here)
+    int n, M, nread, phase;         // nread: accumulator slices to read (nslices, or 1 behind an all-reduce)
+    int xvs, max_evals, pg_rule, pad;
+    double *acc3; long long acc_set;        // 3 sets of nslices * acc_stride(n) doubles
+    double *xs; long long xs_set;           // 3 sets of XS_VECS * xvs doubles
+    DevState *st3;                          // 3 sets
+    double *S, *Y, *rho;                    // rings of ITER_RING slots (row stride hist_stride(n))
+    const double *c, *h, *glo, *ghi;
+    const int *ctype;
+    double *Ds;
+    double *nu, *nu_acc, *psi_acc;          // written by workgroup 0: trial prices (+ stop flag at [n]), accepted point
+    double tol_gap, tol_infeas, armijo, max_step;
+};
+
+template <int E> __device__ __forceinline__ void ldE(const double *p, int first, double (&v)[E]);
+template <> __device__ __forceinline__ void ldE<1>(const double *p, int first, double (&v)[1]) { v[0] = p[first]; }
+template <> __device__ __forceinline__ void ldE<2>(const double *p, int first, double (&v)[2])
+{
+    const double2 t = *reinterpret_cast<const double2 *>(p + first);
+    v[0] = t.x; v[1] = t.y;
+}
+template <int E> __device__ __forceinline__ void ldEi(const int *p, int first, int (&v)[E]);
+template <> __device__ __forceinline__ void ldEi<1>(const int *p, int first, int (&v)[1]) { v[0] = p[first]; }
+template <> __device__ __forceinline__ void ldEi<2>(const int *p, int first, int (&v)[2])
+{
+    const int2 t = *reinterpret_cast<const int2 *>(p + first);
+    v[0] = t.x; v[1] = t.y;
+}
+// store E adjacent doubles starting at `first`, never touching index >= len (first is a multiple of E)
+template <int E> __device__ __forceinline__ void stE(double *p, int first, int len, const double (&v)[E])
+{
+    if (E == 2 && first + 1 < len) { *reinterpret_cast<double2 *>(p + first) = make_double2(v[0], v[E - 1]); return; }
+    if (first < len) p[first] = v[0];
+}
+
+// what one thread contributes to the 44 batched scalars (update_gram_kernel's layout):
+//   0 f_lin 1 gapv 2 Gs.ds 3 Gs_t.ds 4 s.y 5 s.s 6 y.y 7 pg 8 |q0|^2 | 9..13 u_k = s_k.q0 | 14..18 v_k = y_k.H0 q0
+//   19..28 SY[k][j] = s_k.y_j (k > j) | 29..43 YHY[k][j] = y_k.H0 y_j (k >= j)          pairs newest first, 0 = the new one
+template <int E>
+struct GramIn {
+    double g1[9];
+    double S[GRAM_P][E], Y[GRAM_P][E], q0[E], H0[E], hq[E];
+};
+__host__ __device__ constexpr int sy_row(int c) { int k = 1; while (k * (k + 1) / 2 <= c) ++k; return k; }            // c = k(k-1)/2 + j, j < k
+__host__ __device__ constexpr int yhy_row(int c) { int k = 0; while ((k + 1) * (k + 2) / 2 <= c) ++k; return k; }     // c = k(k+1)/2 + j, j <= k
+template <int I, int E>
+__device__ __forceinline__ double gram_val(const GramIn<E> &in)
+{
+    double r = 0.0;
+    if constexpr (I < 9) r = in.g1[I];
+    else if constexpr (I < 14) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) r = fma(in.S[I - 9][e], in.q0[e], r);
+    } else if constexpr (I < 19) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) r = fma(in.Y[I - 14][e], in.hq[e], r);
+    } else if constexpr (I < 29) {
+        constexpr int c = I - 19, k = sy_row(c), j = c - k * (k - 1) / 2;
+        static_assert(j >= 0 && j < k && k < GRAM_P, "SY index");
+#pragma unroll
+        for (int e = 0; e < E; ++e) r = fma(in.S[k][e], in.Y[j][e], r);
+    } else if constexpr (I < 44) {
+        constexpr int c = I - 29, k = yhy_row(c), j = c - k * (k + 1) / 2;
+        static_assert(j >= 0 && j <= k && k < GRAM_P, "YHY index");
+#pragma unroll
+        for (int e = 0; e < E; ++e) r = fma(in.H0[e] * in.Y[k][e], in.Y[j][e], r);
+    }
+    return r;
+}
+
+// The batched wave reduction, in two register-lean batches (the evaluation kernel leaves ~128 VGPRs per wave):
+//   batch A, quantities 0..31: values i and i + 16 are produced as a pair and exchanged across row pairs at once
+//     (v_permlane16_swap: even rows keep i, odd rows i + 16), so only 16 running values exist; four halving steps
+//     inside the rows of 16 lanes (DPP row_ror:8, ds_swizzle xor 4, quad_perm) and one xor-32 butterfly leave the wave
+//     total of quantity l in lane l (l < 32);
+//   batch B, quantities 32..47: pairs (j, j + 8) exchanged inside the rows (8 running values), three halving steps,
+//     two butterflies (xor 16, xor 32): lane l ends with the total of quantity 32 + (l & 15).
+// 32 + 17 exchange-adds; the 64-value form of kernels.hpp needs 63 and 128 VGPRs of running values.
+template <int I, int E>
+__device__ __forceinline__ double gram_pair16(const GramIn<E> &in)
+{
+    const double a = gram_val<I, E>(in), b = gram_val<I + 16, E>(in);
+    const int l0 = __double2loint(a), h0 = __double2hiint(a);
+    const int l1 = __double2loint(b), h1 = __double2hiint(b);
+    const auto lo = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(h0, h1, false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+template <int E, int... I>
+__device__ __forceinline__ void gram_pairs16(const GramIn<E> &in, double (&v)[16], std::integer_sequence<int, I...>)
+{
+    ((v[I] = gram_pair16<I, E>(in)), ...);
+}
+template <int J, int E>
+__device__ __forceinline__ double gram_pair8(const GramIn<E> &in, bool b8)
+{
+    const double a = gram_val<32 + J, E>(in), b = gram_val<32 + J + 8, E>(in);
+    const double keep = b8 ? b : a, send = b8 ? a : b;
+    return keep + dppd_ror8(send);
+}
+template <int E, int... J>
+__device__ __forceinline__ void gram_pairs8(const GramIn<E> &in, double (&v)[8], bool b8, std::integer_sequence<int, J...>)
+{
+    ((v[J] = gram_pair8<J, E>(in, b8)), ...);
+}
+// halving steps 4, 2, 1 inside a row of 16 lanes on v[0..3]: lane l ends with the row total of quantity (l & 7) [+ 8 for b8 lanes]
+__device__ __forceinline__ double row_halve4(double (&v)[8], int lane)
+{
+    const bool b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double keep = b4 ? v[i + 4] : v[i], send = b4 ? v[i] : v[i + 4];
+        v[i] = keep + swz_xor4(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double keep = b2 ? v[i + 2] : v[i], send = b2 ? v[i] : v[i + 2];
+        v[i] = keep + dpp_f64<0x4E>(send);
+    }
+    const double keep = b1 ? v[1] : v[0], send = b1 ? v[0] : v[1];
+    return keep + dpp_f64<0xB1>(send);
+}
+// returns {total of quantity lane (lanes < 32), total of quantity 32 + (lane & 15)}
+template <int E>
+__device__ __forceinline__ void gram_reduce48(const GramIn<E> &in, int lane, double &qa, double &qb)
+{
+    const bool b8 = lane & 8;
+    double x, y;
+    {
+        double v[16];
+        gram_pairs16<E>(in, v, std::make_integer_sequence<int, 16>{});
+        double w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double keep = b8 ? v[i + 8] : v[i], send = b8 ? v[i] : v[i + 8];
+            w[i] = keep + dppd_ror8(send);
+        }
+        const double r = row_halve4(w, lane);
+        swap32_f64(r, x, y);
+        qa = x + y;
+    }
+    {
+        double w[8];
+        gram_pairs8<E>(in, w, b8, std::make_integer_sequence<int, 8>{});
+        double r = row_halve4(w, lane);
+        swap16_f64(r, x, y); r = x + y;
+        swap32_f64(r, x, y);
+        qb = x + y;
+    }
+}
+
+// self-test of gram_reduce48 (cfmm_selftest): small-integer inputs make every product and sum exact, the reference
+// is one plain butterfly per quantity (wave_allsum, itself checked by selftest_kernel); comparison is bitwise
+template <int... I>
+__device__ __forceinline__ int gram_selfcheck(const GramIn<1> &in, int lane, double qa, double qb, std::integer_sequence<int, I...>)
+{
+    int bad = 0;
+    (([&] {
+        const double want = wave_allsum(gram_val<I, 1>(in));
+        if (I < 32 && lane == I && qa != want) ++bad;
+        if (I >= 32 && (lane & 15) == I - 32 && qb != want) ++bad;
+    }()), ...);
+    return bad;
+}
+__global__ void __launch_bounds__(64)
+selftest_gram_kernel(int *out)
+{
+    const int lane = threadIdx.x;
+    GramIn<1> in;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) in.g1[i] = (double)(((lane + 2) * (i + 3)) % 17) - 8.0;
+#pragma unroll
+    for (int k = 0; k < GRAM_P; ++k) {
+        in.S[k][0] = (double)(((lane + 5) * (k + 2)) % 11) - 5.0;
+        in.Y[k][0] = (double)(((lane + 1) * (k + 7)) % 13) - 6.0;
+    }
+    in.q0[0] = (double)((lane * 7) % 9) - 4.0;
+    in.H0[0] = (double)((lane % 3) + 1);
+    in.hq[0] = in.H0[0] * in.q0[0];
+    double qa, qb;
+    gram_reduce48<1>(in, lane, qa, qb);
+    atomicAdd(out, gram_selfcheck(in, lane, qa, qb, std::make_integer_sequence<int, 48>{}));
+}
+
+template <int E>
+__global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
+iter_kernel(IterArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int MM = GRAM_MM, P = GRAM_P, RS = ITER_RING;
+    const int n = a.n, M = a.M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    // LDS carve of eval_kernel<false, .>; the update borrows the waves' exchange strips (16 KB, free until the tile loop)
+    double *psi_s = lds;
+    double *nu_s = lds + n;                              // [n + 1]
+    double *fpart = nu_s + n + 2;                        // [16]
+    int *next_tile = reinterpret_cast<int *>(fpart + 16);
+    double *strips = lds + eval_lds_doubles(n, false);
+    double *xw = strips;                                 // [16][64] per-wave sums
+    double *xt = xw + 16 * 64;                           // [64] totals
+    double *xm = xt + 64;                                // [16][2] maxima
+    BlockRed red(xm + 32);                               // [2][12][16]
+
+    PHASE_STAMP(a.ev.ts, 16);
+    const int p = a.phase, pr = (p + 2) % 3, pz = (p + 1) % 3;
+    DevState st = a.st3[pr];
+    if (st.status != 0) {                                // the solve has ended: every workgroup of every later launch leaves here;
+        if (blockIdx.x == 0 && tid == 0) a.st3[p] = st;  // the final state is handed on, or the launch after next would read a set
+        return;                                          // from before the end (status 0) and resume from stale state
+    }
+    PHASE_STAMP(a.ev.ts, 17);
+    const int hs = hist_stride(n), stride = acc_stride(n), xvs = a.xvs;
+    const double *Xr = a.xs + (size_t)pr * a.xs_set;
+    double *Xw = a.xs + (size_t)p * a.xs_set;
+    const double *Ar = a.acc3 + (size_t)pr * a.acc_set;
+    const bool wr = blockIdx.x == 0;                     // the one workgroup that stores the new state
+    const int nS = wr ? n : 0;
+    const int r0 = tid * E;
+    const int ld0 = (r0 < n) ? r0 : 0;                   // threads past the end load element 0 and are masked out
+    bool tin[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) tin[e] = r0 + e < n;
+
+    // ---- loads, all issued up front.  Waves that own no variable (n < 64 E waves) skip the update's vector work
+    //      altogether (wave-uniform branch) and only meet the others at the barriers --------------------------
+    const bool wave_active = wave * 64 * E < n;
+    double s[E], s_t[E], Gs[E], d[E], nuj[E], Ds[E], glo[E], ghi[E], hj[E], cj[E];
+    int ct[E];
+    double psi[E], dg[E], Gs_t[E];
+    bool act[E];
+    double mx[2] = {0.0, 0.0};
+    GramIn<E> in;
+    double rho[P];
+    double qa = 0.0, qb = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        s[e] = s_t[e] = Gs[e] = d[e] = nuj[e] = Ds[e] = glo[e] = ghi[e] = hj[e] = cj[e] = psi[e] = dg[e] = Gs_t[e] = 0.0;
+        ct[e] = 0; act[e] = true; in.q0[e] = in.H0[e] = in.hq[e] = 0.0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) { in.S[k][e] = 0.0; in.Y[k][e] = 0.0; }
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) rho[k] = 0.0;
+    // the set the NEXT launch flushes into was last read one launch ago: one workgroup clears it now
+    if (blockIdx.x == gridDim.x - 1) {
+        double *Z = a.acc3 + (size_t)pz * a.acc_set;
+        const int len = a.ev.nslices * stride;
+        for (int j = tid; j < len; j += blockDim.x) Z[j] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < MM; ++k) {                       // (every wave runs the scalar recursion: every wave needs the rho's)
+        const bool have = k < st.hist;
+        rho[k + 1] = have ? a.rho[(st.head - 1 - k + 2 * RS) % RS] : 0.0;
+    }
+    if (wave_active) {
+    ldE<E>(Xr, ld0, s); ldE<E>(Xr + xvs, ld0, s_t); ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 3 * xvs, ld0, d); ldE<E>(Xr + 4 * xvs, ld0, nuj);
+    ldE<E>(a.Ds, ld0, Ds); ldE<E>(a.glo, ld0, glo); ldE<E>(a.ghi, ld0, ghi); ldE<E>(a.h, ld0, hj); ldE<E>(a.c, ld0, cj); ldEi<E>(a.ctype, ld0, ct);
+    for (int sl = 0; sl < a.nread; ++sl) {
+        double t1[E];
+        ldE<E>(Ar + (size_t)sl * stride, ld0, t1);
+#pragma unroll
+        for (int e = 0; e < E; ++e) psi[e] += t1[e];
+    }
+    if (st.first) {                                      // first update of a solve: the diagonal metric rides along
+        for (int sl = 0; sl < a.nread; ++sl) {
+            double t2[E];
+            ldE<E>(Ar + (size_t)sl * stride + acc_diag(n), ld0, t2);
+#pragma unroll
+            for (int e = 0; e < E; ++e) dg[e] += t2[e];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MM; ++k) {                       // stored pairs, newest first, at in.S[k + 1]
+        const bool have = k < st.hist;
+        const int slot = have ? (st.head - 1 - k + 2 * RS) % RS : 0;
+        if (have) { ldE<E>(a.S + (size_t)slot * hs, ld0, in.S[k + 1]); ldE<E>(a.Y + (size_t)slot * hs, ld0, in.Y[k + 1]); }
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (!tin[e]) { in.S[k + 1][e] = 0.0; in.Y[k + 1][e] = 0.0; }
+    }
+    double fpools = 0.0;
+    if (tid < a.nread) fpools = Ar[(size_t)tid * stride + acc_arb(n)];
+
+    // ---- the trial point's gradient, and the batch ---------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 9; ++i) in.g1[i] = 0.0;
+    in.g1[0] = fpools;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (tin[e]) {
+            const double rj = psi[e] + hj[e];
+            Gs_t[e] = nuj[e] * rj;
+            if (st.first) Ds[e] = dg[e];
+            in.g1[0] += (nuj[e] - cj[e]) * hj[e];
+            in.g1[1] += (nuj[e] - cj[e]) * rj;
+            mx[0] = fmax(mx[0], ct[e] == 0 ? fmax(-rj, 0.0) : (ct[e] == 1 ? fabs(rj) : 0.0));
+            mx[1] = fmax(mx[1], fmax(fabs(psi[e]), fabs(hj[e])));
+            const double sv = s_t[e] - s[e], yv = Gs_t[e] - Gs[e];
+            if (!st.first) {
+                in.S[0][e] = sv; in.Y[0][e] = yv;
+                in.g1[2] += Gs[e] * sv; in.g1[3] += Gs_t[e] * sv;
+                in.g1[4] += sv * yv; in.g1[5] += sv * sv; in.g1[6] += yv * yv;
+            }
+            const double G = Gs_t[e], sr = s_t[e];
+            double v = G;
+            if (glo[e] == ghi[e]) v = 0.0;
+            else if (sr <= glo[e] + 1e-14) v = fmin(G, 0.0);
+            else if (sr >= ghi[e] - 1e-14) v = fmax(G, 0.0);
+            in.g1[7] += fabs(v);
+            act[e] = is_active(sr, glo[e], ghi[e], G);
+            in.q0[e] = act[e] ? 0.0 : G;
+            in.g1[8] += in.q0[e] * in.q0[e];
+            const double H = Ds[e] + fmax(G, 0.0);
+            in.H0[e] = H > 0.0 ? rcp_nr(H) : 0.0;
+            in.hq[e] = in.H0[e] * in.q0[e];
+        }
+    }
+    PHASE_STAMP(a.ev.ts, 18);
+    gram_reduce48<E>(in, lane, qa, qb);
+    }
+    PHASE_STAMP(a.ev.ts, 19);
+    mx[0] = wave_allmax(mx[0]); mx[1] = wave_allmax(mx[1]);
+    if (lane < 32) xw[wave * 64 + lane] = qa;
+    else if (lane < 48) xw[wave * 64 + lane] = qb;       // (lane - 32 = lane & 15 there)
+    if (lane == 0) { xm[wave * 2] = mx[0]; xm[wave * 2 + 1] = mx[1]; }
+    __syncthreads();
+    if (wave == 0 && lane < 48) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += xw[w * 64 + lane];
+        xt[lane] = t;
+    }
+    __syncthreads();
+    // (the 44 totals stay in LDS and are read where they are used: as registers they would cost 88 VGPRs)
+    const double *T = xt;
+    PHASE_STAMP(a.ev.ts, 20);
+    double viol = 0.0, scale = 0.0;
+    for (int w = 0; w < nw; ++w) { viol = fmax(viol, xm[w * 2]); scale = fmax(scale, xm[w * 2 + 1]); }
+    const double f_t = T[0], gapv = T[1];
+    st.evals += 1;
+
+    // ---- accept test --------------------------------------------------------------------------------------------
+    bool accept = st.first != 0;
+    if (!st.first)
+        accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * T[2]) ||
+                                  (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && T[3] <= 0.8 * fabs(T[2])));
+    if (!accept) {
+        st.t_step *= 0.5;
+        st.nrej += 1;
+        if (st.t_step < 1e-9) st.status = 2;
+    } else {
+        // ---- curvature pair, move the accepted point ---------------------------------------------------------
+        bool pair_ok = false;
+        const int old_hist0 = st.hist;
+        if (!st.first) {
+            if (T[4] > 1e-12 * sqrt(T[5]) * sqrt(T[6])) {
+                pair_ok = true;
+                if (r0 < n) { stE<E>(a.S + (size_t)st.head * hs, r0, nS, in.S[0]); stE<E>(a.Y + (size_t)st.head * hs, r0, nS, in.Y[0]); }
+                if (wr && tid == 0) a.rho[st.head] = 1.0 / T[4];
+                st.head = (st.head + 1) % RS;
+                if (st.hist < M) st.hist += 1;
+            }
+            st.iters += 1;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (tin[e]) { s[e] = s_t[e]; Gs[e] = Gs_t[e]; }
+        if (r0 < n) { stE<E>(a.psi_acc, r0, nS, psi); stE<E>(a.nu_acc, r0, nS, nuj); if (st.first) stE<E>(a.Ds, r0, nS, Ds); }
+        st.f = f_t;
+        st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
+        st.infeas = viol / fmax(scale, 1e-300);
+        st.primal = f_t - gapv;                   // c'psi = g - (nu - c)'(psi + h)
+        st.pg = T[7] / fmax(1.0, fabs(f_t));
+        const double gp_sq = T[8];
+        const bool was_first = st.first != 0;
+        st.first = 0;
+        const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
+        if (conv) {
+            st.status = 1;
+        } else {
+            // ---- the two-loop recursion on scalars -----------------------------------------------------------
+            // which pairs are in the window: the new one if it passed, then the newest stored ones
+            const int keep_old = was_first ? 0 : (pair_ok ? (old_hist0 < M ? old_hist0 : M - 1) : old_hist0);
+            rho[0] = pair_ok ? 1.0 / T[4] : 0.0;
+#pragma unroll
+            for (int k = 1; k < P; ++k) if (k - 1 >= keep_old) rho[k] = 0.0;
+            double al[P], ga[P];
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                double t = T[9 + k];
+#pragma unroll
+                for (int j = 0; j < k; ++j) t -= al[j] * T[19 + k * (k - 1) / 2 + j];
+                al[k] = rho[k] * t;
+            }
+#pragma unroll
+            for (int k = P - 1; k >= 0; --k) {
+                double t = T[14 + k];
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    const int hi = j > k ? j : k, lo = j > k ? k : j;
+                    t -= al[j] * T[29 + hi * (hi + 1) / 2 + lo];
+                }
+#pragma unroll
+                for (int j = k + 1; j < P; ++j) t += ga[j] * T[19 + j * (j - 1) / 2 + k];
+                ga[k] = al[k] - rho[k] * t;
+            }
+            PHASE_STAMP(a.ev.ts, 21);
+            double F[2] = {0.0, 0.0};              // d.G | max |d|
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                double qm = in.q0[e], rs = 0.0;
+#pragma unroll
+                for (int k = 0; k < P; ++k) { qm -= al[k] * in.Y[k][e]; rs += ga[k] * in.S[k][e]; }
+                d[e] = (tin[e] && !act[e]) ? -(in.H0[e] * qm + rs) : 0.0;
+                F[0] += d[e] * Gs[e]; F[1] = fmax(F[1], fabs(d[e]));
+            }
+            red.run<1, 1>(F);
+            if (!(F[0] < 0.0) && gp_sq > 0.0) {       // not a descent direction: restart from the metric
+                st.hist = 0;
+                double m1[1] = {0.0};
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    d[e] = (!tin[e] || act[e]) ? 0.0 : -Gs[e] * in.H0[e];
+                    m1[0] = fmax(m1[0], fabs(d[e]));
+                }
+                red.run<0, 1>(m1);
+                F[1] = m1[0];
+            }
+            st.t_step = (F[1] > a.max_step) ? a.max_step / F[1] : 1.0;
+        }
+    }
+
+    PHASE_STAMP(a.ev.ts, 22);
+    // ---- next trial point: into this workgroup's LDS copy of the prices; workgroup 0 also stores the state ------------
+    double v[E], nn[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        v[e] = fmin(fmax(s[e] + st.t_step * d[e], glo[e]), ghi[e]);
+        nn[e] = (st.status == 0 && tin[e]) ? exp(v[e]) : nuj[e];
+    }
+    if (st.status == 0 && st.evals >= a.max_evals) st.status = 3;
+    if (wr) {
+        if (r0 < n) {
+            stE<E>(Xw, r0, n, s); stE<E>(Xw + xvs, r0, n, v); stE<E>(Xw + 2 * xvs, r0, n, Gs); stE<E>(Xw + 3 * xvs, r0, n, d);
+            stE<E>(Xw + 4 * xvs, r0, n, nn); stE<E>(a.nu, r0, n, nn);
+        }
+        if (tid == 0) { a.st3[p] = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; }
+    }
+    if (st.status != 0) return;                          // ended (converged / stalled / out of budget): nothing to evaluate
+    __syncthreads();                                     // (the scratch in the exchange strips is free from here on)
+#pragma unroll
+    for (int e = 0; e < E; ++e) if (tin[e]) nu_s[r0 + e] = nn[e];
+    for (int j = tid; j < n; j += blockDim.x) psi_s[j] = 0.0;
+    if (tid == 0) *next_tile = 0;
+    __syncthreads();
+    PHASE_STAMP(a.ev.ts, 23);
+    double2 *xs = reinterpret_cast<double2 *>(strips) + 64 * wave;
+    eval_tiles_and_flush<false, false>(a.ev, a.acc3 + (size_t)p * a.acc_set, nu_s, psi_s, nullptr, fpart, next_tile, xs);
+}
+
+}  // namespace cfmm

@@ -279,31 +279,13 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
 // ------------------------------------------------------------------------------------------
 // STABLE = false: every bucket but the stableswap one; STABLE = true: the stableswap bucket alone (its Newton loops need
 // ~20 more VGPRs than anything else: kept out of the main instantiation, it lets that one run at 6 waves per SIMD)
+// the tile loop and the flush, shared by eval_kernel (below) and iter_kernel (iterate.hpp).  On entry nu_s holds the
+// prices, psi_s (diag_s) are zero, *next_tile is 0 and a barrier has been passed; `acc` is the accumulator set to flush into.
 template <bool WITH_D, bool STABLE>
-__global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
-eval_kernel(EvalArgs a)
+__device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *acc, const double *nu_s, double *psi_s, double *diag_s,
+                                                     double *fpart, int *next_tile, double2 *xs)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    PHASE_STAMP(a.ts, 0);
-#ifdef CFMM_PHASE_TIMERS
-    if (a.ts && threadIdx.x == 0 && blockIdx.x < 1024) a.ts[64 + 8 * 4096 + 2 * blockIdx.x] = wall_clock64();    // block start
-#endif
     const int n = a.n;
-    double *psi_s = lds, *diag_s = lds + n;
-    double *nu_s = lds + (WITH_D ? 2 : 1) * n;          // [n + 1]
-    double *fpart = nu_s + n + 2;                       // [16]
-    int *next_tile = reinterpret_cast<int *>(fpart + 16);   // the workgroup's tile ticket counter
-    if (threadIdx.x == 0) *next_tile = 0;
-    double2 *xs = reinterpret_cast<double2 *>(lds + eval_lds_doubles(n, WITH_D)) + 64 * (threadIdx.x >> 6);   // wave-private [64]
-    // prices and the stop flag arrive in ONE round trip (the flag rides behind the prices)
-    for (int j = threadIdx.x; j <= n; j += blockDim.x) {
-        nu_s[j] = a.nu[j];
-        if (j < n) { psi_s[j] = 0.0; if (WITH_D) diag_s[j] = 0.0; }
-    }
-    __syncthreads();
-    if (nu_s[n] != 0.0) return;
-    PHASE_STAMP(a.ts, 1);
-
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double fsum = 0.0;
@@ -364,7 +346,7 @@ eval_kernel(EvalArgs a)
     __syncthreads();
     PHASE_STAMP(a.ts, 3);
 
-    double *base = a.acc + (size_t)(blockIdx.x % a.nslices) * acc_stride(n);
+    double *base = acc + (size_t)(blockIdx.x % a.nslices) * acc_stride(n);
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const double v = psi_s[j];
         if (v != 0.0) unsafeAtomicAdd(&base[j], v);
@@ -379,6 +361,33 @@ eval_kernel(EvalArgs a)
         if (f != 0.0) unsafeAtomicAdd(&base[acc_arb(n)], f);
     }
     PHASE_STAMP(a.ts, 4);
+}
+
+template <bool WITH_D, bool STABLE>
+__global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
+eval_kernel(EvalArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    PHASE_STAMP(a.ts, 0);
+#ifdef CFMM_PHASE_TIMERS
+    if (a.ts && threadIdx.x == 0 && blockIdx.x < 1024) a.ts[64 + 8 * 4096 + 2 * blockIdx.x] = wall_clock64();    // block start
+#endif
+    const int n = a.n;
+    double *psi_s = lds, *diag_s = lds + n;
+    double *nu_s = lds + (WITH_D ? 2 : 1) * n;          // [n + 1]
+    double *fpart = nu_s + n + 2;                       // [16]
+    int *next_tile = reinterpret_cast<int *>(fpart + 16);   // the workgroup's tile ticket counter
+    if (threadIdx.x == 0) *next_tile = 0;
+    double2 *xs = reinterpret_cast<double2 *>(lds + eval_lds_doubles(n, WITH_D)) + 64 * (threadIdx.x >> 6);   // wave-private [64]
+    // prices and the stop flag arrive in ONE round trip (the flag rides behind the prices)
+    for (int j = threadIdx.x; j <= n; j += blockDim.x) {
+        nu_s[j] = a.nu[j];
+        if (j < n) { psi_s[j] = 0.0; if (WITH_D) diag_s[j] = 0.0; }
+    }
+    __syncthreads();
+    if (nu_s[n] != 0.0) return;
+    PHASE_STAMP(a.ts, 1);
+    eval_tiles_and_flush<WITH_D, STABLE>(a, a.acc, nu_s, psi_s, diag_s, fpart, next_tile, xs);
 #ifdef CFMM_PHASE_TIMERS
     __syncthreads();
     if (a.ts && threadIdx.x == 0 && blockIdx.x < 1024) a.ts[64 + 8 * 4096 + 2 * blockIdx.x + 1] = wall_clock64();    // block end

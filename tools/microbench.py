@@ -88,6 +88,10 @@ if ts.any():
     out["eval_phases(cyc,us)"] = dict(prologue=d(ts, 0, 1), tiles=d(ts, 1, 2), reduce=d(ts, 2, 3), flush=d(ts, 3, 4))
     out["upd_phases(cyc,us)"] = dict(st=d(tu, 8, 9), loads=d(tu, 9, 10), A=d(tu, 10, 11), B=d(tu, 11, 12), C=d(tu, 12, 13),
                                      D=d(tu, 13, 14), E=d(tu, 14, 15), total=d(tu, 8, 15))
-    if tu[19].any():
+    if tu[16].any():
+        out["iter_phases(cyc,us)"] = dict(st=d(tu, 16, 17), loads_grad=d(tu, 17, 18), gram_reduce=d(tu, 18, 19), lds_exchange=d(tu, 19, 20),
+                                          recursion=d(tu, 20, 21), direction_F=d(tu, 21, 22), trial=d(tu, 22, 23), tiles=d(tu, 23, 2),
+                                          reduce=d(tu, 2, 3), flush=d(tu, 3, 4), total=d(tu, 16, 4))
+    if tu[19].any() and not tu[16].any():
         out["upd_A_detail(cyc,us)"] = dict(grad=d(tu, 10, 19), partials=d(tu, 19, 20), reduce_scatter=d(tu, 20, 21), lds_exchange=d(tu, 21, 22), tail=d(tu, 22, 11))
 print(json.dumps(out), flush=True)
