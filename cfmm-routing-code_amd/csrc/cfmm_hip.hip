@@ -111,7 +111,7 @@ struct cfmm_ctx {
     double *hsol = nullptr;           // pinned [2][n]: nu | psi of the last solve (saves cfmm_get_solution a synchronisation)
     bool hsol_valid = false;
     hipEvent_t ev[2] = {nullptr, nullptr}, ev_t0 = nullptr, ev_t1 = nullptr;
-    int nslices = 4;
+    int nslices = 2;                   // accumulator slices the workgroups flush into (blockIdx % nslices): flat from 2 upward for the flush, and every slice is one more vector the in-launch update of EVERY workgroup reads (27.4 vs 28.4 us per iteration at 2 vs 4, C3)
     int eval_grid_mult = 1;
     int eval_blocks_per_cu = 1;        // resident EVAL_THREADS-workgroups per CU (occupancy query at create)
     int upd_grid = 1;
@@ -126,10 +126,14 @@ struct cfmm_ctx {
 
     // fused iteration (iterate.hpp): three rotating sets of accumulators / solver state, a history ring of M + 1 slots
     bool fused = true;                 // CFMM_FUSED=0: the two-launch iteration of round 1 (A/B)
+    bool plain = false;                // utility has h == 0 and only CFMM_GE tokens (IterArgs::plain)
     double *acc3 = nullptr, *xs3 = nullptr, *S5 = nullptr, *Y5 = nullptr, *rho5 = nullptr;
     DevState *st3 = nullptr;
     DevState *hst3 = nullptr;          // pinned [2][3]
     int iter_blocks_per_cu = 1;
+    volatile unsigned long long *hstat_h = nullptr;     // pinned, device-mapped progress word (iterate.hpp: IterArgs::hstat)
+    unsigned long long *hstat_d = nullptr;
+    int run_ahead = 3;                 // CFMM_RUN_AHEAD: launches the host keeps enqueued beyond the last one the device reported
 
     // graph cache
     hipGraphExec_t gexec = nullptr;
@@ -283,6 +287,7 @@ void pools_changed(cfmm_ctx *ctx)
 }
 
 size_t eval_lds_bytes(int n, bool with_d) { return (size_t)eval_lds_doubles(n, with_d) * sizeof(double) + (size_t)(EVAL_THREADS / 64) * 64 * 16; }
+size_t iter_lds_bytes(int n) { return eval_lds_bytes(n, false) + (size_t)iter_extra_lds_doubles() * sizeof(double); }
 size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 16 * 64 + 64 + 32 + 2 * 12 * 16 + 8) * sizeof(double); }
 
 // processing order of the fused evaluation kernel (heaviest first): bucket code = -k for the
@@ -362,8 +367,8 @@ int set_all_lds_attrs(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, update_reg_kernel<256, 8, 4>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_gram_kernel<512, 2>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, start_kernel, upd_lds_bytes(ctx->n)))) return rc;
-    if ((rc = set_lds_attr(ctx, iter_kernel<1>, e0))) return rc;
-    if ((rc = set_lds_attr(ctx, iter_kernel<2>, e0))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<1>, iter_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<2>, iter_lds_bytes(ctx->n)))) return rc;
     return CFMM_OK;
 }
 
@@ -399,6 +404,7 @@ IterArgs make_iter_args(cfmm_ctx *ctx, const cfmm_opts &o)
     a.ev.nu = nullptr; a.ev.acc = nullptr;
     a.n = ctx->n; a.M = o.memory; a.nread = ctx->comm ? 1 : ctx->nslices; a.phase = 0;
     a.xvs = iter_xvs(ctx->n); a.max_evals = o.max_evals; a.pg_rule = o.pg_rule;
+    a.plain = ctx->plain ? 1 : 0;
     a.acc3 = ctx->acc3; a.acc_set = (long long)acc_set_doubles(ctx);
     a.xs = ctx->xs3; a.xs_set = (long long)XS_VECS * a.xvs;
     a.st3 = ctx->st3;
@@ -407,6 +413,7 @@ IterArgs make_iter_args(cfmm_ctx *ctx, const cfmm_opts &o)
     a.Ds = ctx->Ds;
     a.nu = ctx->nu; a.nu_acc = ctx->nu_acc; a.psi_acc = ctx->psi_acc;
     a.tol_gap = o.tol_gap; a.tol_infeas = o.tol_infeas; a.armijo = o.armijo; a.max_step = o.max_step;
+    a.hstat = ctx->hstat_d;
     return a;
 }
 
@@ -429,7 +436,7 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
         if (grid > slots) grid = slots;
         if (grid < 1) grid = 1;                                 // (a shard without pools still takes the step)
     }
-    const size_t lds = eval_lds_bytes(n, false);
+    const size_t lds = iter_lds_bytes(n);
     if (E == 1) hipLaunchKernelGGL(iter_kernel<1>, dim3(grid), dim3(threads), lds, ctx->stream, a);
     else hipLaunchKernelGGL(iter_kernel<2>, dim3(grid), dim3(threads), lds, ctx->stream, a);
     double *acc_p = ctx->acc3 + (size_t)a.phase * acc_set_doubles(ctx);
@@ -971,6 +978,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if (const char *s = getenv("CFMM_MULTI_GRAPH")) ctx->multi_graph = atoi(s) != 0;
     if (const char *s = getenv("CFMM_NO_GRAPH")) ctx->no_graph = atoi(s) != 0;
     if (const char *s = getenv("CFMM_FUSED")) ctx->fused = atoi(s) != 0;
+    if (const char *s = getenv("CFMM_RUN_AHEAD")) ctx->run_ahead = std::max(1, atoi(s));
     const int n = n_tokens;
     int rc = 0;
     rc |= dev_upload<double>(ctx, &ctx->c, nullptr, n + 4, nullptr);
@@ -998,6 +1006,9 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if (rc) return bail(CFMM_E_HIP);
     TRY_C(hipHostMalloc((void **)&ctx->hst, 2 * sizeof(DevState), hipHostMallocDefault));
     TRY_C(hipHostMalloc((void **)&ctx->hst3, 6 * sizeof(DevState), hipHostMallocDefault));
+    TRY_C(hipHostMalloc((void **)&ctx->hstat_h, 64, hipHostMallocMapped));
+    TRY_C(hipHostGetDevicePointer((void **)&ctx->hstat_d, (void *)ctx->hstat_h, 0));
+    *ctx->hstat_h = 0;
     TRY_C(hipHostMalloc((void **)&ctx->hsol, 2 * (size_t)n * sizeof(double), hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) TRY_C(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
     TRY_C(hipEventCreate(&ctx->ev_t0));
@@ -1008,8 +1019,8 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
         TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eval_kernel<false, false>, EVAL_THREADS, eval_lds_bytes(n, false)));
         ctx->eval_blocks_per_cu = nb < 1 ? 1 : nb;
         nb = 0;
-        if (n <= 1024) TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iter_kernel<1>, EVAL_THREADS, eval_lds_bytes(n, false)));
-        else TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iter_kernel<2>, EVAL_THREADS, eval_lds_bytes(n, false)));
+        if (n <= 1024) TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iter_kernel<1>, EVAL_THREADS, iter_lds_bytes(n)));
+        else TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iter_kernel<2>, EVAL_THREADS, iter_lds_bytes(n)));
         ctx->iter_blocks_per_cu = nb < 1 ? 1 : nb;
     }
     if (ctx->nslices > 64) ctx->nslices = 64;
@@ -1055,6 +1066,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->hst) (void)hipHostFree(ctx->hst);
     if (ctx->hst3) (void)hipHostFree(ctx->hst3);
+    if (ctx->hstat_h) (void)hipHostFree((void *)ctx->hstat_h);
     if (ctx->hsol) (void)hipHostFree(ctx->hsol);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
@@ -1188,6 +1200,10 @@ int cfmm_set_utility(cfmm_ctx *ctx, const double *c, const double *h, const int3
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h, ctx->hh.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ctype, ctx->hctype.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     ctx->have_utility = true;
+    bool plain = true;                      // h == 0 and psi >= 0 on every token: the update kernel then skips three vectors
+    for (int j = 0; j < n; ++j) if (ctx->hh[j] != 0.0 || ctx->hctype[j] != CFMM_GE) { plain = false; break; }
+    if (plain != ctx->plain) ctx->g_valid = false;      // (baked into captured launches)
+    ctx->plain = plain;
     return recompute_bounds(ctx);
 }
 
@@ -1411,7 +1427,9 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     // Single GPU: `iters_per_graph` iterations are replayed from one captured hipGraph.  Pool-sharded
     // (RCCL all-reduce inside every iteration): the same iterations are enqueued eagerly, the way RCCL
     // is conventionally driven (CFMM_MULTI_GRAPH=1 opts into capturing them too).
-    const bool use_graph = (!ctx->comm || ctx->multi_graph) && !ctx->no_graph;
+    static const bool graph_forced = getenv("CFMM_FUSED_GRAPH") && atoi(getenv("CFMM_FUSED_GRAPH")) != 0;     // (A/B: replay the fused launches from a graph)
+    const bool use_graph_opt = fused && !ctx->comm && graph_forced;
+    const bool use_graph = (!ctx->comm || ctx->multi_graph) && !ctx->no_graph && (!fused || ctx->comm || graph_forced);
     if (use_graph && (!ctx->g_valid || !same_opts(o, ctx->g_opts))) { int rc = build_graph(ctx, o); if (rc) return rc; }
     UpdArgs ua = make_upd_args(ctx, o);
     const IterArgs ia = make_iter_args(ctx, o);
@@ -1422,6 +1440,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu0, ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    *ctx->hstat_h = 0;                                     // (the stream is idle: nothing can still write the progress word)
     if (fused) {
         // launch 0: the start point and the first evaluation (with the diagonal metric) into state / accumulator set 0
         HIP_TRY(ctx, hipMemsetAsync(ctx->acc3, 0, 3 * aset * sizeof(double), ctx->stream));
@@ -1457,6 +1476,33 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     DevState *hring = fused ? ctx->hst3 : ctx->hst;
     const DevState *dst = fused ? ctx->st3 : ctx->st;
     int status = 0, t = 1;
+    if (fused && !ctx->comm && !use_graph_opt) {
+        // Single GPU, one launch per iteration: launches are enqueued eagerly, a few ahead of the device, whose workgroup 0
+        // reports {evals, status} into a pinned host word as it goes (zero-copy: the host polls memory, no API call, no
+        // copy engine).  No graph-replay gaps (~19 us per replay), and only `run_ahead` idle launches behind the end.
+        const auto spin0 = std::chrono::steady_clock::now();
+        long spins = 0;
+        for (;;) {
+            const unsigned long long w = *ctx->hstat_h;
+            const int done = (int)(w & 0xffffffffu);
+            status = (int)(w >> 32);
+            if (status != 0) break;
+            if (t > o.max_evals + 1) {                     // every evaluation the budget allows is enqueued: the device ends it (status 3)
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                break;
+            }
+            if (t - done <= ctx->run_ahead) {
+                int rc = enqueue_fused_iteration(ctx, ia, t); if (rc) return rc;
+                ++t; spins = 0;
+                continue;
+            }
+            if ((++spins & 0xfffff) == 0) {                // (a dead device must not hang the host for ever)
+                if (hipGetLastError() != hipSuccess || std::chrono::duration<double>(std::chrono::steady_clock::now() - spin0).count() > 120.0)
+                    return fail(ctx, CFMM_E_HIP, "solve: the device stopped reporting progress (launch %d, %d done)", t, done);
+            }
+        }
+        HIP_TRY(ctx, hipGetLastError());
+    } else
     for (int cidx = 0; cidx < max_chunks; ++cidx) {
         if (use_graph) {
             HIP_TRY(ctx, hipGraphLaunch(ctx->gexec, ctx->stream));

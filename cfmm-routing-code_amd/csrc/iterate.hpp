@@ -28,7 +28,7 @@
 namespace cfmm {
 
 #ifndef ITER_E_SMALL_DEF
-#define ITER_E_SMALL_DEF 1
+#define ITER_E_SMALL_DEF 2
 #endif
 constexpr int ITER_E_SMALL = ITER_E_SMALL_DEF;  // variables per thread of the in-launch update up to EVAL_THREADS tokens (2 beyond)
 constexpr int ITER_RING = GRAM_MM + 1;      // physical history slots (window GRAM_MM)
@@ -38,7 +38,9 @@ __host__ __device__ inline int iter_xvs(int n) { return (n + 3) & ~1; }      // 
 struct IterArgs {
     EvalArgs ev;                    // tile space of the evaluation (ev.nu / ev.acc are not used here)
     int n, M, nread, phase;         // nread: accumulator slices to read (nslices, or 1 behind an all-reduce)
-    int xvs, max_evals, pg_rule, pad;
+    int xvs, max_evals, pg_rule;
+    int plain;                      // 1: h == 0, every token CFMM_GE, no upper bounds (the linear-utility arbitrage of arbitrage.py:57,77):
+                                    //    three of the update's vectors need not be read
     double *acc3; long long acc_set;        // 3 sets of nslices * acc_stride(n) doubles
     double *xs; long long xs_set;           // 3 sets of XS_VECS * xvs doubles
     DevState *st3;                          // 3 sets
@@ -48,6 +50,7 @@ struct IterArgs {
     double *Ds;
     double *nu, *nu_acc, *psi_acc;          // written by workgroup 0: trial prices (+ stop flag at [n]), accepted point
     double tol_gap, tol_infeas, armijo, max_step;
+    unsigned long long *hstat;              // pinned HOST word (zero-copy): evals | status << 32, for the host's run-ahead control
 };
 
 template <int E> __device__ __forceinline__ void ldE(const double *p, int first, double (&v)[E]);
@@ -220,6 +223,16 @@ selftest_gram_kernel(int *out)
     atomicAdd(out, gram_selfcheck(in, lane, qa, qb, std::make_integer_sequence<int, 48>{}));
 }
 
+// a wave-uniform value held in SGPRs instead of one VGPR pair per lane (the update is register-bound)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// extra LDS of iter_kernel behind eval_kernel's carve: wave-private copies of the 48 batch totals
+__host__ __device__ inline int iter_extra_lds_doubles() { return 16 * 48; }
+
 template <int E>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 iter_kernel(IterArgs a)
@@ -227,17 +240,19 @@ iter_kernel(IterArgs a)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int MM = GRAM_MM, P = GRAM_P, RS = ITER_RING;
     const int n = a.n, M = a.M;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     // LDS carve of eval_kernel<false, .>; the update borrows the waves' exchange strips (16 KB, free until the tile loop)
+    // and the psi tile (a stash for the trial gradient)
     double *psi_s = lds;
     double *nu_s = lds + n;                              // [n + 1]
     double *fpart = nu_s + n + 2;                        // [16]
     int *next_tile = reinterpret_cast<int *>(fpart + 16);
     double *strips = lds + eval_lds_doubles(n, false);
     double *xw = strips;                                 // [16][64] per-wave sums
-    double *xt = xw + 16 * 64;                           // [64] totals
-    double *xm = xt + 64;                                // [16][2] maxima
+    double *xm = xw + 16 * 64;                           // [16][2] maxima
     BlockRed red(xm + 32);                               // [2][12][16]
+    double *xt = strips + 16 * 128 + wave * 48;          // this wave's own copy of the 48 totals (behind the strips)
+    double *gst_s = psi_s;                               // [n] trial gradient, stashed between the two halves of the update
 
     PHASE_STAMP(a.ev.ts, 16);
     const int p = a.phase, pr = (p + 2) % 3, pz = (p + 1) % 3;
@@ -246,6 +261,8 @@ iter_kernel(IterArgs a)
         if (blockIdx.x == 0 && tid == 0) a.st3[p] = st;  // the final state is handed on, or the launch after next would read a set
         return;                                          // from before the end (status 0) and resume from stale state
     }
+    st.evals = uni(st.evals); st.iters = uni(st.iters); st.first = uni(st.first); st.hist = uni(st.hist); st.head = uni(st.head);
+    st.nrej = uni(st.nrej); st.f = uni(st.f); st.t_step = uni(st.t_step);
     PHASE_STAMP(a.ev.ts, 17);
     const int hs = hist_stride(n), stride = acc_stride(n), xvs = a.xvs;
     const double *Xr = a.xs + (size_t)pr * a.xs_set;
@@ -258,115 +275,123 @@ iter_kernel(IterArgs a)
     bool tin[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) tin[e] = r0 + e < n;
-
-    // ---- loads, all issued up front.  Waves that own no variable (n < 64 E waves) skip the update's vector work
-    //      altogether (wave-uniform branch) and only meet the others at the barriers --------------------------
+    // Waves that own no variable skip the update's vector work altogether (wave-uniform branch) and only meet the
+    // others at the barriers: every scalar section below is executed by every wave of a SIMD in turn, so the fewer
+    // waves carry variables the shorter it gets (E = 2: 8 waves at 1000 tokens)
     const bool wave_active = wave * 64 * E < n;
-    double s[E], s_t[E], Gs[E], d[E], nuj[E], Ds[E], glo[E], ghi[E], hj[E], cj[E];
-    int ct[E];
-    double psi[E], dg[E], Gs_t[E];
-    bool act[E];
-    double mx[2] = {0.0, 0.0};
-    GramIn<E> in;
-    double rho[P];
-    double qa = 0.0, qb = 0.0;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        s[e] = s_t[e] = Gs[e] = d[e] = nuj[e] = Ds[e] = glo[e] = ghi[e] = hj[e] = cj[e] = psi[e] = dg[e] = Gs_t[e] = 0.0;
-        ct[e] = 0; act[e] = true; in.q0[e] = in.H0[e] = in.hq[e] = 0.0;
-#pragma unroll
-        for (int k = 0; k < P; ++k) { in.S[k][e] = 0.0; in.Y[k][e] = 0.0; }
-    }
-#pragma unroll
-    for (int k = 0; k < P; ++k) rho[k] = 0.0;
+
     // the set the NEXT launch flushes into was last read one launch ago: one workgroup clears it now
     if (blockIdx.x == gridDim.x - 1) {
         double *Z = a.acc3 + (size_t)pz * a.acc_set;
         const int len = a.ev.nslices * stride;
         for (int j = tid; j < len; j += blockDim.x) Z[j] = 0.0;
     }
+    double rho[P];
+    rho[0] = 0.0;
 #pragma unroll
     for (int k = 0; k < MM; ++k) {                       // (every wave runs the scalar recursion: every wave needs the rho's)
         const bool have = k < st.hist;
-        rho[k + 1] = have ? a.rho[(st.head - 1 - k + 2 * RS) % RS] : 0.0;
+        rho[k + 1] = have ? uni(a.rho[(st.head - 1 - k + 2 * RS) % RS]) : 0.0;
     }
-    if (wave_active) {
-    ldE<E>(Xr, ld0, s); ldE<E>(Xr + xvs, ld0, s_t); ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 3 * xvs, ld0, d); ldE<E>(Xr + 4 * xvs, ld0, nuj);
-    ldE<E>(a.Ds, ld0, Ds); ldE<E>(a.glo, ld0, glo); ldE<E>(a.ghi, ld0, ghi); ldE<E>(a.h, ld0, hj); ldE<E>(a.c, ld0, cj); ldEi<E>(a.ctype, ld0, ct);
-    for (int sl = 0; sl < a.nread; ++sl) {
-        double t1[E];
-        ldE<E>(Ar + (size_t)sl * stride, ld0, t1);
-#pragma unroll
-        for (int e = 0; e < E; ++e) psi[e] += t1[e];
-    }
-    if (st.first) {                                      // first update of a solve: the diagonal metric rides along
-        for (int sl = 0; sl < a.nread; ++sl) {
-            double t2[E];
-            ldE<E>(Ar + (size_t)sl * stride + acc_diag(n), ld0, t2);
-#pragma unroll
-            for (int e = 0; e < E; ++e) dg[e] += t2[e];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < MM; ++k) {                       // stored pairs, newest first, at in.S[k + 1]
-        const bool have = k < st.hist;
-        const int slot = have ? (st.head - 1 - k + 2 * RS) % RS : 0;
-        if (have) { ldE<E>(a.S + (size_t)slot * hs, ld0, in.S[k + 1]); ldE<E>(a.Y + (size_t)slot * hs, ld0, in.Y[k + 1]); }
-#pragma unroll
-        for (int e = 0; e < E; ++e) if (!tin[e]) { in.S[k + 1][e] = 0.0; in.Y[k + 1][e] = 0.0; }
-    }
-    double fpools = 0.0;
-    if (tid < a.nread) fpools = Ar[(size_t)tid * stride + acc_arb(n)];
 
-    // ---- the trial point's gradient, and the batch ---------------------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < 9; ++i) in.g1[i] = 0.0;
-    in.g1[0] = fpools;
+    // ================= first half: everything that feeds the batched reduction.  Its inputs (state, bounds,
+    // accumulators: ~20 registers per variable) die here; the second half reloads the few it needs ================
+    GramIn<E> in;
+    bool act[E];
+    double mx[2] = {0.0, 0.0};
+    double qa = 0.0, qb = 0.0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        if (tin[e]) {
-            const double rj = psi[e] + hj[e];
-            Gs_t[e] = nuj[e] * rj;
-            if (st.first) Ds[e] = dg[e];
-            in.g1[0] += (nuj[e] - cj[e]) * hj[e];
-            in.g1[1] += (nuj[e] - cj[e]) * rj;
-            mx[0] = fmax(mx[0], ct[e] == 0 ? fmax(-rj, 0.0) : (ct[e] == 1 ? fabs(rj) : 0.0));
-            mx[1] = fmax(mx[1], fmax(fabs(psi[e]), fabs(hj[e])));
-            const double sv = s_t[e] - s[e], yv = Gs_t[e] - Gs[e];
-            if (!st.first) {
-                in.S[0][e] = sv; in.Y[0][e] = yv;
-                in.g1[2] += Gs[e] * sv; in.g1[3] += Gs_t[e] * sv;
-                in.g1[4] += sv * yv; in.g1[5] += sv * sv; in.g1[6] += yv * yv;
-            }
-            const double G = Gs_t[e], sr = s_t[e];
-            double v = G;
-            if (glo[e] == ghi[e]) v = 0.0;
-            else if (sr <= glo[e] + 1e-14) v = fmin(G, 0.0);
-            else if (sr >= ghi[e] - 1e-14) v = fmax(G, 0.0);
-            in.g1[7] += fabs(v);
-            act[e] = is_active(sr, glo[e], ghi[e], G);
-            in.q0[e] = act[e] ? 0.0 : G;
-            in.g1[8] += in.q0[e] * in.q0[e];
-            const double H = Ds[e] + fmax(G, 0.0);
-            in.H0[e] = H > 0.0 ? rcp_nr(H) : 0.0;
-            in.hq[e] = in.H0[e] * in.q0[e];
+        act[e] = true; in.q0[e] = in.H0[e] = in.hq[e] = 0.0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) { in.S[k][e] = 0.0; in.Y[k][e] = 0.0; }
+    }
+    if (wave_active) {
+        double s[E], s_t[E], Gs[E], nuj[E], Ds[E], glo[E], ghi[E], hj[E], cj[E], psi[E], dg[E];
+        int ct[E];
+        ldE<E>(Xr, ld0, s); ldE<E>(Xr + xvs, ld0, s_t); ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 4 * xvs, ld0, nuj);
+        ldE<E>(a.Ds, ld0, Ds); ldE<E>(a.glo, ld0, glo); ldE<E>(a.c, ld0, cj);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { psi[e] = 0.0; dg[e] = 0.0; ghi[e] = __builtin_inf(); hj[e] = 0.0; ct[e] = 0; }
+        if (!a.plain) { ldE<E>(a.ghi, ld0, ghi); ldE<E>(a.h, ld0, hj); ldEi<E>(a.ctype, ld0, ct); }
+        for (int sl = 0; sl < a.nread; ++sl) {
+            double t1[E];
+            ldE<E>(Ar + (size_t)sl * stride, ld0, t1);
+#pragma unroll
+            for (int e = 0; e < E; ++e) psi[e] += t1[e];
         }
+        if (st.first) {                                  // first update of a solve: the diagonal metric rides along
+            for (int sl = 0; sl < a.nread; ++sl) {
+                double t2[E];
+                ldE<E>(Ar + (size_t)sl * stride + acc_diag(n), ld0, t2);
+#pragma unroll
+                for (int e = 0; e < E; ++e) dg[e] += t2[e];
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) Ds[e] = dg[e];
+            if (r0 < n) stE<E>(a.Ds, r0, nS, Ds);        // (the first trial point is always accepted)
+        }
+#pragma unroll
+        for (int k = 0; k < MM; ++k) {                   // stored pairs, newest first, at in.S[k + 1]
+            const bool have = k < st.hist;
+            const int slot = have ? (st.head - 1 - k + 2 * RS) % RS : 0;
+            if (have) { ldE<E>(a.S + (size_t)slot * hs, ld0, in.S[k + 1]); ldE<E>(a.Y + (size_t)slot * hs, ld0, in.Y[k + 1]); }
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (!tin[e]) { in.S[k + 1][e] = 0.0; in.Y[k + 1][e] = 0.0; }
+        }
+        double fpools = 0.0;
+        if (tid < a.nread) fpools = Ar[(size_t)tid * stride + acc_arb(n)];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) in.g1[i] = 0.0;
+        in.g1[0] = fpools;
+        double Gs_t[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            Gs_t[e] = 0.0;
+            if (tin[e]) {
+                const double rj = psi[e] + hj[e];
+                Gs_t[e] = nuj[e] * rj;
+                in.g1[0] += (nuj[e] - cj[e]) * hj[e];
+                in.g1[1] += (nuj[e] - cj[e]) * rj;
+                mx[0] = fmax(mx[0], ct[e] == 0 ? fmax(-rj, 0.0) : (ct[e] == 1 ? fabs(rj) : 0.0));
+                mx[1] = fmax(mx[1], fmax(fabs(psi[e]), fabs(hj[e])));
+                const double sv = s_t[e] - s[e], yv = Gs_t[e] - Gs[e];
+                if (!st.first) {
+                    in.S[0][e] = sv; in.Y[0][e] = yv;
+                    in.g1[2] += Gs[e] * sv; in.g1[3] += Gs_t[e] * sv;
+                    in.g1[4] += sv * yv; in.g1[5] += sv * sv; in.g1[6] += yv * yv;
+                }
+                const double G = Gs_t[e], sr = s_t[e];
+                double v = G;
+                if (glo[e] == ghi[e]) v = 0.0;
+                else if (sr <= glo[e] + 1e-14) v = fmin(G, 0.0);
+                else if (sr >= ghi[e] - 1e-14) v = fmax(G, 0.0);
+                in.g1[7] += fabs(v);
+                act[e] = is_active(sr, glo[e], ghi[e], G);
+                in.q0[e] = act[e] ? 0.0 : G;
+                in.g1[8] += in.q0[e] * in.q0[e];
+                const double H = Ds[e] + fmax(G, 0.0);
+                in.H0[e] = H > 0.0 ? rcp_nr(H) : 0.0;
+                in.hq[e] = in.H0[e] * in.q0[e];
+                gst_s[r0 + e] = Gs_t[e];
+            }
+        }
+        PHASE_STAMP(a.ev.ts, 18);
+        gram_reduce48<E>(in, lane, qa, qb);
+        PHASE_STAMP(a.ev.ts, 19);
+        mx[0] = wave_allmax(mx[0]); mx[1] = wave_allmax(mx[1]);
     }
-    PHASE_STAMP(a.ev.ts, 18);
-    gram_reduce48<E>(in, lane, qa, qb);
-    }
-    PHASE_STAMP(a.ev.ts, 19);
-    mx[0] = wave_allmax(mx[0]); mx[1] = wave_allmax(mx[1]);
     if (lane < 32) xw[wave * 64 + lane] = qa;
     else if (lane < 48) xw[wave * 64 + lane] = qb;       // (lane - 32 = lane & 15 there)
     if (lane == 0) { xm[wave * 2] = mx[0]; xm[wave * 2 + 1] = mx[1]; }
     __syncthreads();
-    if (wave == 0 && lane < 48) {
+    // every wave sums the per-wave rows itself, into its own copy: no second barrier, no broadcast
+    if (lane < 48) {
         double t = 0.0;
         for (int w = 0; w < nw; ++w) t += xw[w * 64 + lane];
         xt[lane] = t;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();                     // (LDS operations of one wave complete in order)
     // (the 44 totals stay in LDS and are read where they are used: as registers they would cost 88 VGPRs)
     const double *T = xt;
     PHASE_STAMP(a.ev.ts, 20);
@@ -380,6 +405,39 @@ iter_kernel(IterArgs a)
     if (!st.first)
         accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * T[2]) ||
                                   (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && T[3] <= 0.8 * fabs(T[2])));
+    // second half's inputs, requested NOW so that their latency (L1 / L2 hits) hides behind the scalar recursion: the
+    // accepted point (s moves to the trial point, or stays), its gradient (the stashed trial gradient, or the old one),
+    // the old direction in case this trial point is rejected, the bounds
+    double s[E], Gs[E], d[E], glo[E], ghi[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { s[e] = Gs[e] = d[e] = glo[e] = 0.0; ghi[e] = __builtin_inf(); }
+    if (wave_active) {
+        ldE<E>(Xr + (accept ? xvs : 0), ld0, s);
+        ldE<E>(a.glo, ld0, glo);
+        if (!a.plain) ldE<E>(a.ghi, ld0, ghi);
+        if (accept) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) Gs[e] = tin[e] ? gst_s[r0 + e] : 0.0;
+        } else { ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 3 * xvs, ld0, d); }
+        if (wr && accept && r0 < n) {                    // the accepted prices and their net trade, for the read-back
+            double psi[E], nuj[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) psi[e] = 0.0;
+            for (int sl = 0; sl < a.nread; ++sl) {
+                double t1[E];
+                ldE<E>(Ar + (size_t)sl * stride, ld0, t1);
+#pragma unroll
+                for (int e = 0; e < E; ++e) psi[e] += t1[e];
+            }
+            ldE<E>(Xr + 4 * xvs, ld0, nuj);
+            stE<E>(a.psi_acc, r0, n, psi); stE<E>(a.nu_acc, r0, n, nuj);
+        }
+    }
+    bool new_dir = false;
+    double al[P], ga[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) { al[k] = 0.0; ga[k] = 0.0; }
+    double gp_sq = 0.0;
     if (!accept) {
         st.t_step *= 0.5;
         st.nrej += 1;
@@ -391,22 +449,19 @@ iter_kernel(IterArgs a)
         if (!st.first) {
             if (T[4] > 1e-12 * sqrt(T[5]) * sqrt(T[6])) {
                 pair_ok = true;
-                if (r0 < n) { stE<E>(a.S + (size_t)st.head * hs, r0, nS, in.S[0]); stE<E>(a.Y + (size_t)st.head * hs, r0, nS, in.Y[0]); }
+                if (wave_active && r0 < n) { stE<E>(a.S + (size_t)st.head * hs, r0, nS, in.S[0]); stE<E>(a.Y + (size_t)st.head * hs, r0, nS, in.Y[0]); }
                 if (wr && tid == 0) a.rho[st.head] = 1.0 / T[4];
                 st.head = (st.head + 1) % RS;
                 if (st.hist < M) st.hist += 1;
             }
             st.iters += 1;
         }
-#pragma unroll
-        for (int e = 0; e < E; ++e) if (tin[e]) { s[e] = s_t[e]; Gs[e] = Gs_t[e]; }
-        if (r0 < n) { stE<E>(a.psi_acc, r0, nS, psi); stE<E>(a.nu_acc, r0, nS, nuj); if (st.first) stE<E>(a.Ds, r0, nS, Ds); }
         st.f = f_t;
         st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
         st.infeas = viol / fmax(scale, 1e-300);
         st.primal = f_t - gapv;                   // c'psi = g - (nu - c)'(psi + h)
         st.pg = T[7] / fmax(1.0, fabs(f_t));
-        const double gp_sq = T[8];
+        gp_sq = T[8];
         const bool was_first = st.first != 0;
         st.first = 0;
         const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
@@ -415,17 +470,18 @@ iter_kernel(IterArgs a)
         } else {
             // ---- the two-loop recursion on scalars -----------------------------------------------------------
             // which pairs are in the window: the new one if it passed, then the newest stored ones
+            new_dir = true;
+            if (wave_active) {                           // (waves without variables need no direction: they wait at the next barrier)
             const int keep_old = was_first ? 0 : (pair_ok ? (old_hist0 < M ? old_hist0 : M - 1) : old_hist0);
             rho[0] = pair_ok ? 1.0 / T[4] : 0.0;
 #pragma unroll
             for (int k = 1; k < P; ++k) if (k - 1 >= keep_old) rho[k] = 0.0;
-            double al[P], ga[P];
 #pragma unroll
             for (int k = 0; k < P; ++k) {
                 double t = T[9 + k];
 #pragma unroll
                 for (int j = 0; j < k; ++j) t -= al[j] * T[19 + k * (k - 1) / 2 + j];
-                al[k] = rho[k] * t;
+                al[k] = uni(rho[k] * t);           // (wave-uniform: lives in SGPRs)
             }
 #pragma unroll
             for (int k = P - 1; k >= 0; --k) {
@@ -437,52 +493,62 @@ iter_kernel(IterArgs a)
                 }
 #pragma unroll
                 for (int j = k + 1; j < P; ++j) t += ga[j] * T[19 + j * (j - 1) / 2 + k];
-                ga[k] = al[k] - rho[k] * t;
+                ga[k] = uni(al[k] - rho[k] * t);
             }
-            PHASE_STAMP(a.ev.ts, 21);
-            double F[2] = {0.0, 0.0};              // d.G | max |d|
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                double qm = in.q0[e], rs = 0.0;
-#pragma unroll
-                for (int k = 0; k < P; ++k) { qm -= al[k] * in.Y[k][e]; rs += ga[k] * in.S[k][e]; }
-                d[e] = (tin[e] && !act[e]) ? -(in.H0[e] * qm + rs) : 0.0;
-                F[0] += d[e] * Gs[e]; F[1] = fmax(F[1], fabs(d[e]));
             }
-            red.run<1, 1>(F);
-            if (!(F[0] < 0.0) && gp_sq > 0.0) {       // not a descent direction: restart from the metric
-                st.hist = 0;
-                double m1[1] = {0.0};
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    d[e] = (!tin[e] || act[e]) ? 0.0 : -Gs[e] * in.H0[e];
-                    m1[0] = fmax(m1[0], fabs(d[e]));
-                }
-                red.run<0, 1>(m1);
-                F[1] = m1[0];
-            }
-            st.t_step = (F[1] > a.max_step) ? a.max_step / F[1] : 1.0;
         }
     }
+    PHASE_STAMP(a.ev.ts, 21);
 
+    // ================= second half: the direction, the next trial point =================================================
+    if (new_dir) {
+        double F[2] = {0.0, 0.0};              // d.G | max |d|
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            double qm = in.q0[e], rs = 0.0;
+#pragma unroll
+            for (int k = 0; k < P; ++k) { qm -= al[k] * in.Y[k][e]; rs += ga[k] * in.S[k][e]; }
+            d[e] = (tin[e] && !act[e]) ? -(in.H0[e] * qm + rs) : 0.0;
+            F[0] += d[e] * Gs[e]; F[1] = fmax(F[1], fabs(d[e]));
+        }
+        red.run<1, 1>(F);
+        if (!(F[0] < 0.0) && gp_sq > 0.0) {       // not a descent direction: restart from the metric
+            st.hist = 0;
+            double m1[1] = {0.0};
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                d[e] = (!tin[e] || act[e]) ? 0.0 : -Gs[e] * in.H0[e];
+                m1[0] = fmax(m1[0], fabs(d[e]));
+            }
+            red.run<0, 1>(m1);
+            F[1] = m1[0];
+        }
+        st.t_step = (F[1] > a.max_step) ? a.max_step / F[1] : 1.0;
+    }
     PHASE_STAMP(a.ev.ts, 22);
+
     // ---- next trial point: into this workgroup's LDS copy of the prices; workgroup 0 also stores the state ------------
     double v[E], nn[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         v[e] = fmin(fmax(s[e] + st.t_step * d[e], glo[e]), ghi[e]);
-        nn[e] = (st.status == 0 && tin[e]) ? exp(v[e]) : nuj[e];
+        nn[e] = (st.status == 0 && tin[e]) ? exp(v[e]) : 0.0;
     }
     if (st.status == 0 && st.evals >= a.max_evals) st.status = 3;
     if (wr) {
-        if (r0 < n) {
+        if (wave_active && r0 < n) {
             stE<E>(Xw, r0, n, s); stE<E>(Xw + xvs, r0, n, v); stE<E>(Xw + 2 * xvs, r0, n, Gs); stE<E>(Xw + 3 * xvs, r0, n, d);
             stE<E>(Xw + 4 * xvs, r0, n, nn); stE<E>(a.nu, r0, n, nn);
         }
-        if (tid == 0) { a.st3[p] = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; }
+        if (tid == 0) {
+            a.st3[p] = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0;
+            // progress word for the host (system-scope store into pinned host memory: no copy, no API call on the host side)
+            if (a.hstat) __hip_atomic_store(a.hstat, (unsigned long long)(unsigned)st.evals | ((unsigned long long)(unsigned)st.status << 32),
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (st.status != 0) return;                          // ended (converged / stalled / out of budget): nothing to evaluate
-    __syncthreads();                                     // (the scratch in the exchange strips is free from here on)
+    __syncthreads();                                     // (the scratch in the exchange strips and the psi tile is free from here on)
 #pragma unroll
     for (int e = 0; e < E; ++e) if (tin[e]) nu_s[r0 + e] = nn[e];
     for (int j = tid; j < n; j += blockDim.x) psi_s[j] = 0.0;
