@@ -6,6 +6,7 @@ Drop-in for the `cp.Problem(obj, cons).solve()` call of angeris/cfmm-routing-cod
 from .problem import Problem, Utility, Arbitrage, Liquidate, Swap, HostComm, pack, shard_network, start_prices
 from ._lib import CfmmError, GE, EQ, FREE
 from . import distributed
+from . import cvx
 
 __all__ = ["Problem", "Utility", "Arbitrage", "Liquidate", "Swap", "pack", "shard_network",
-           "start_prices", "HostComm", "CfmmError", "GE", "EQ", "FREE", "distributed"]
+           "start_prices", "HostComm", "CfmmError", "GE", "EQ", "FREE", "distributed", "cvx"]

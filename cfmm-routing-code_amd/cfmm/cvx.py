@@ -1,0 +1,419 @@
+"""cfmm.cvx -- the slice of cvxpy's modelling surface the reference scripts use, mapped onto cfmm.Problem.
+
+    import cfmm.cvx as cp          # instead of:  import cvxpy as cp
+
+With that one line changed, /root/reference/arbitrage.py, liquidation.py and two-asset.py run as written (SURVEY 8(f)
+rank 4): `cp.Variable(n, nonneg=True)`, numpy-on-the-left affine arithmetic (`A_i @ (L - D)`, `R + gamma * D - L`,
+`market_value @ psi`, `psi[4]`, `psi + current_assets`), `cp.sum`, `cp.geo_mean(x, p=...)`, `>=` / `==`,
+`cp.Maximize`, `cp.Problem(obj, cons).solve()`, and `.value` on variables, expressions, the objective and the problem
+(arbitrage.py:51-84, liquidation.py:51-87, two-asset.py:60-100).
+
+This is NOT a general convex modelling layer.  `Problem.solve()` pattern-matches the constraint list into the routing
+problem's vocabulary and refuses anything else with `NotImplementedError`:
+
+  * `geo_mean(R + gamma*D - L, p=w) >= geo_mean(R[, p=w])`      -> a (weighted) geometric-mean pool   arbitrage.py:65,68-70
+  * `sum(R + gamma*D - L) >= sum(R)` with `R + gamma*D - L >= 0` -> a constant-sum pool               arbitrage.py:73-74
+  * rows of  psi + h (>= | ==) 0  with  psi = sum_i A_i (L_i - D_i)  and a linear objective in psi     -> the utility
+    (arbitrage.py:57,77; liquidation.py:57,77-80; two-asset.py:66,86)
+
+and hands the result to cfmm.Problem, i.e. to libcfmm_hip.so on the MI355X -- there is no CPU path here either.
+"""
+import builtins
+
+import numpy as np
+
+from .problem import Problem as _RoutingProblem, Utility as _Utility
+from ._lib import GE as _GE, EQ as _EQ, FREE as _FREE
+
+# tests only: a callable n_tokens -> device context standing in for cfmm._lib.Context (the product leaves it None)
+CONTEXT_FACTORY = None
+
+OPTIMAL, INACCURATE, INFEASIBLE = "optimal", "optimal_inaccurate", "infeasible"
+
+
+def _const(x):
+    a = np.asarray(x, dtype=np.float64)
+    return a.reshape(1) if a.ndim == 0 else a
+
+
+class Expression:
+    """affine vector expression  const + sum_v coef[v] @ v   (1-D; a scalar is length 1 with .scalar set)"""
+    __array_ufunc__ = None          # numpy on the left defers to our reflected operators
+    __array_priority__ = 1000
+
+    def __init__(self, coefs, const, scalar=False):
+        self.coefs = coefs           # {Variable: (m, v.size) array}
+        self.const = np.asarray(const, dtype=np.float64)
+        self.scalar = scalar
+
+    # -- shape -----------------------------------------------------------------------------------------
+    @property
+    def size(self):
+        return len(self.const)
+
+    @property
+    def shape(self):
+        return () if self.scalar else (self.size,)
+
+    def __len__(self):
+        return self.size
+
+    # -- arithmetic ------------------------------------------------------------------------------------
+    @staticmethod
+    def _lift(x, m):
+        if isinstance(x, Expression):
+            return x
+        c = _const(x)
+        if c.ndim != 1:
+            raise NotImplementedError("cfmm.cvx: only vectors and scalars")
+        return Expression({}, np.broadcast_to(c, (m,)).copy() if len(c) == 1 and m != 1 else c, scalar=(np.ndim(x) == 0))
+
+    def _binary(self, other, sign):
+        o = self._lift(other, self.size)
+        a, b = self, o
+        m = max(a.size, b.size)
+        if a.size != b.size:            # scalar broadcast
+            if a.size == 1:
+                a = Expression({v: np.repeat(c, m, axis=0) for v, c in a.coefs.items()}, np.repeat(a.const, m))
+            elif b.size == 1:
+                b = Expression({v: np.repeat(c, m, axis=0) for v, c in b.coefs.items()}, np.repeat(b.const, m))
+            else:
+                raise ValueError(f"cfmm.cvx: shapes {a.size} and {b.size} do not match")
+        coefs = {v: c.copy() for v, c in a.coefs.items()}
+        for v, c in b.coefs.items():
+            coefs[v] = coefs[v] + sign * c if v in coefs else sign * c
+        return Expression(coefs, a.const + sign * b.const, scalar=a.scalar and b.scalar)
+
+    def __add__(self, other): return self._binary(other, 1.0)
+    __radd__ = __add__
+    def __sub__(self, other): return self._binary(other, -1.0)
+    def __rsub__(self, other): return (-self)._binary(other, 1.0)
+    def __neg__(self): return Expression({v: -c for v, c in self.coefs.items()}, -self.const, self.scalar)
+
+    def __mul__(self, k):
+        if isinstance(k, Expression):
+            raise NotImplementedError("cfmm.cvx: products of expressions are not affine")
+        k = np.asarray(k, dtype=np.float64)
+        if k.ndim == 0:
+            return Expression({v: float(k) * c for v, c in self.coefs.items()}, float(k) * self.const, self.scalar)
+        if k.shape != (self.size,):
+            raise ValueError("cfmm.cvx: elementwise factor of the wrong length")
+        return Expression({v: k[:, None] * c for v, c in self.coefs.items()}, k * self.const)
+    __rmul__ = __mul__
+
+    def __truediv__(self, k): return self * (1.0 / float(k))
+
+    def __rmatmul__(self, M):
+        M = np.asarray(M, dtype=np.float64)
+        if M.ndim == 1:
+            if len(M) != self.size:
+                raise ValueError("cfmm.cvx: inner dimensions do not match")
+            return Expression({v: (M @ c)[None, :] for v, c in self.coefs.items()}, np.array([M @ self.const]), scalar=True)
+        if M.ndim != 2 or M.shape[1] != self.size:
+            raise ValueError("cfmm.cvx: inner dimensions do not match")
+        return Expression({v: M @ c for v, c in self.coefs.items()}, M @ self.const)
+
+    def __matmul__(self, M):
+        M = np.asarray(M, dtype=np.float64)
+        if M.ndim != 1:
+            raise NotImplementedError("cfmm.cvx: expression @ matrix")
+        return self.__rmatmul__(M)
+
+    def __getitem__(self, k):
+        if isinstance(k, (int, np.integer)):
+            k = int(k) % self.size
+            return Expression({v: c[k:k + 1] for v, c in self.coefs.items()}, self.const[k:k + 1], scalar=True)
+        return Expression({v: c[k] for v, c in self.coefs.items()}, self.const[k])
+
+    # -- comparisons -> constraints ---------------------------------------------------------------------
+    def __ge__(self, other): return Constraint(self - other, ">=")
+    def __le__(self, other): return Constraint(self._lift(other, self.size) - self, ">=")
+    def __eq__(self, other): return Constraint(self - other, "==")     # noqa: PLW1641 (expressions are not hashed)
+    __hash__ = None
+
+    # -- evaluation -------------------------------------------------------------------------------------
+    @property
+    def value(self):
+        out = self.const.copy()
+        for v, c in self.coefs.items():
+            if v._value is None:
+                return None
+            out = out + c @ v._value
+        return float(out[0]) if self.scalar else out
+
+
+class Variable(Expression):
+    """cp.Variable(n, nonneg=True)   (arbitrage.py:51-52: the tenders Delta_i, Lambda_i)"""
+    _count = 0
+
+    def __init__(self, shape=1, nonneg=False, name=None):
+        n = int(shape if not isinstance(shape, tuple) else shape[0])
+        self.n = n
+        self.nonneg = bool(nonneg)
+        self._value = None
+        Variable._count += 1
+        self.name = name or f"var{Variable._count}"
+        Expression.__init__(self, {self: np.eye(n)}, np.zeros(n))
+
+    __hash__ = object.__hash__
+
+    def __eq__(self, other):            # identity for dict keys; `var == x` constraints go through Expression
+        if isinstance(other, Variable):
+            return self is other
+        return Expression.__eq__(self, other)
+
+    @property
+    def value(self):
+        return None if self._value is None else self._value.copy()
+
+
+class Constraint:
+    def __init__(self, expr, op):
+        self.expr, self.op = expr, op
+
+
+class _GeoMean:
+    """cp.geo_mean(x, p=w) of an affine x: only ever compared with a constant (arbitrage.py:65,68-70)"""
+
+    def __init__(self, expr, w):
+        self.expr, self.w = expr, w
+
+    def __ge__(self, rhs):
+        if isinstance(rhs, _GeoMean):
+            raise NotImplementedError("cfmm.cvx: geo_mean(x) >= geo_mean(y) needs a constant y")
+        return _GeoConstraint(self.expr, self.w, float(rhs))
+
+
+class _GeoConstraint:
+    def __init__(self, expr, w, rhs):
+        self.expr, self.w, self.rhs = expr, w, rhs
+
+
+def geo_mean(x, p=None):
+    """cp.geo_mean(x, p): prod_k x_k^(p_k / sum p); a plain number for a constant x (the right-hand sides)"""
+    if isinstance(x, Expression):
+        n = x.size
+        w = np.ones(n) if p is None else np.asarray(p, dtype=np.float64)
+        if w.shape != (n,) or not np.all(w > 0):
+            raise ValueError("cfmm.cvx: geo_mean weights must be positive, one per entry")
+        return _GeoMean(x, w / w.sum())
+    a = np.asarray(x, dtype=np.float64)
+    w = np.ones(len(a)) if p is None else np.asarray(p, dtype=np.float64)
+    return float(np.exp((w / w.sum()) @ np.log(a)))
+
+
+def sum(x, axis=None):        # noqa: A001 (mirrors cp.sum)
+    """cp.sum: a list of expressions adds elementwise (arbitrage.py:54); an expression or array sums its entries"""
+    if isinstance(x, (list, tuple)):
+        return builtins.sum(x[1:], x[0])
+    if isinstance(x, Expression):
+        return np.ones(x.size) @ x
+    return float(np.sum(x))
+
+
+class Maximize:
+    def __init__(self, expr):
+        if not isinstance(expr, Expression) or expr.size != 1:
+            raise ValueError("cfmm.cvx: the objective must be a scalar affine expression")
+        self.expr = expr
+        self.sign = 1.0
+
+    @property
+    def value(self):
+        return self.expr.value
+
+
+class Minimize(Maximize):
+    def __init__(self, expr):
+        Maximize.__init__(self, -expr if isinstance(expr, Expression) else expr)
+        self.sign = -1.0
+
+    @property
+    def value(self):
+        v = self.expr.value
+        return None if v is None else -v
+
+
+def _is_scaled_identity(c, tol=1e-12):
+    """c == g * I ?  -> g or None"""
+    if c.shape[0] != c.shape[1]:
+        return None
+    g = c[0, 0]
+    return float(g) if np.abs(c - g * np.eye(c.shape[0])).max() <= tol * max(1.0, abs(g)) else None
+
+
+def _pool_of(expr):
+    """expr == R + gamma * Delta - Lambda  ->  (Delta, Lambda, R, gamma)   (arbitrage.py:60)"""
+    if len(expr.coefs) != 2:
+        return None
+    (va, ca), (vb, cb) = expr.coefs.items()
+    ga, gb = _is_scaled_identity(ca), _is_scaled_identity(cb)
+    if ga is None or gb is None:
+        return None
+    if abs(gb + 1.0) <= 1e-12 and 0.0 < ga <= 1.0 + 1e-12:
+        D, L, g = va, vb, ga
+    elif abs(ga + 1.0) <= 1e-12 and 0.0 < gb <= 1.0 + 1e-12:
+        D, L, g = vb, va, gb
+    else:
+        return None
+    if not (isinstance(D, Variable) and isinstance(L, Variable) and D.nonneg and L.nonneg and np.all(expr.const > 0)):
+        return None
+    return D, L, expr.const.copy(), min(g, 1.0)
+
+
+class Problem:
+    """cp.Problem(obj, cons); .solve() -> prob.value (arbitrage.py:81-84)"""
+
+    def __init__(self, objective, constraints=()):
+        self.objective = objective
+        self.constraints = list(constraints)
+        self.value = None
+        self.status = None
+        self.routing = None          # the cfmm.Problem the model was mapped onto (prices: .routing.nu)
+
+    # -- the pattern match --------------------------------------------------------------------------------
+    def _match(self):
+        pools = {}                   # Delta variable -> dict
+        rest = []
+        vec_nonneg = []
+        for con in self.constraints:
+            if isinstance(con, _GeoConstraint):
+                pl = _pool_of(con.expr)
+                if pl is None:
+                    raise NotImplementedError("cfmm.cvx: geo_mean(...) must be taken of R + gamma*Delta - Lambda (arbitrage.py:60,65)")
+                D, L, R, g = pl
+                want = float(np.exp(con.w @ np.log(R)))
+                if abs(con.rhs - want) > 1e-9 * want:
+                    raise NotImplementedError("cfmm.cvx: the right-hand side must be the pool's trading function at its current "
+                                              f"reserves ({want:.12g}), got {con.rhs:.12g}")
+                if D in pools:
+                    raise NotImplementedError("cfmm.cvx: two trading functions for one pool")
+                pools[D] = dict(D=D, L=L, R=R, fee=g, kind="geomean", w=con.w)
+            elif isinstance(con, Constraint):
+                pl = _pool_of(con.expr) if (con.op == ">=" and con.expr.size > 1) else None
+                if pl is not None:
+                    vec_nonneg.append(pl)          # new_reserves >= 0: the partner of a constant-sum constraint
+                else:
+                    rest.append(con)
+            else:
+                raise NotImplementedError(f"cfmm.cvx: unsupported constraint {type(con).__name__}")
+        # constant sum: sum(R + gamma*D - L) >= sum(R), recognised through its >= 0 partner (arbitrage.py:73-74)
+        for D, L, R, g in vec_nonneg:
+            hit = None
+            for con in rest:
+                e = con.expr
+                if con.op == ">=" and e.size == 1 and set(e.coefs) == {D, L} and abs(e.const[0]) <= 1e-12 * R.sum() \
+                        and np.allclose(e.coefs[D], g) and np.allclose(e.coefs[L], -1.0):
+                    hit = con
+                    break
+            if hit is None:
+                raise NotImplementedError("cfmm.cvx: `R + gamma*D - L >= 0` without its `sum(...) >= sum(R)` constraint")
+            rest.remove(hit)
+            if D in pools:
+                raise NotImplementedError("cfmm.cvx: two trading functions for one pool")
+            if len(R) != 2:
+                raise NotImplementedError("cfmm.cvx: constant-sum pools are two-asset (as in the reference)")
+            pools[D] = dict(D=D, L=L, R=R, fee=g, kind="sum", w=None)
+        pools = list(pools.values())
+        if not pools:
+            raise NotImplementedError("cfmm.cvx: no pool constraints found")
+        Lam = {p["L"]: i for i, p in enumerate(pools)}
+        Del = {p["D"]: i for i, p in enumerate(pools)}
+        width = builtins.sum(len(p["R"]) for p in pools)
+        offs = np.cumsum([0] + [len(p["R"]) for p in pools])
+
+        def row_matrix(expr):
+            """rows of expr as coefficients on the stacked net-trade slots (Lambda_i - Delta_i): the coefficient on Lambda_i,
+            which the one on Delta_i must negate (arbitrage.py:54: only A_i (Lambda_i - Delta_i) leaves a pool)"""
+            M = np.zeros((expr.size, width))
+            for v, c in expr.coefs.items():
+                if v in Lam:
+                    i, other = Lam[v], pools[Lam[v]]["D"]
+                    M[:, offs[i]:offs[i + 1]] = c
+                elif v in Del:
+                    i, other = Del[v], pools[Del[v]]["L"]
+                else:
+                    raise NotImplementedError("cfmm.cvx: a variable that is no pool's tender")
+                co = expr.coefs.get(other)
+                if co is None or np.abs(co + c).max() > 1e-12:
+                    raise NotImplementedError("cfmm.cvx: only the net trade Lambda - Delta may appear outside the pool constraints")
+            return M
+
+        # token rows: every row of the remaining constraints must select entries of psi (0/1 on the slots)
+        rows, hs, kinds = [], [], []
+        for con in rest:
+            M = row_matrix(con.expr)
+            for r in range(con.expr.size):
+                rows.append(M[r]); hs.append(con.expr.const[r]); kinds.append(_GE if con.op == ">=" else _EQ)
+        objM = row_matrix(self.objective.expr)[0]
+        tokens = []                  # list of (selector row, h, ctype)
+        for r, h, k in zip(rows, hs, kinds):
+            if not np.all((np.abs(r) < 1e-12) | (np.abs(r - 1.0) < 1e-12)):
+                raise NotImplementedError("cfmm.cvx: constraints on psi must be on its entries")
+            if any(np.abs(r - t[0]).max() < 1e-12 for t in tokens):
+                raise NotImplementedError("cfmm.cvx: two constraints on one entry of psi")
+            tokens.append((np.round(r), float(h), k))
+        # the objective: a combination of token rows, plus -- at most -- selector rows of tokens no constraint mentions
+        left = objM.copy()
+        c = np.zeros(len(tokens))
+        if tokens:
+            T = np.stack([t[0] for t in tokens], axis=1)
+            c, *_ = np.linalg.lstsq(T, objM, rcond=None)
+            c[np.abs(c) < 1e-14] = 0.0
+            left = objM - T @ c
+        c = list(c)
+        if np.abs(left).max() > 1e-10:
+            # what is left must itself be selector rows times one value each: split by slot ownership
+            covered = np.zeros(width, dtype=bool)
+            for t in tokens:
+                covered |= t[0] > 0.5
+            free_slots = np.flatnonzero(~covered & (np.abs(left) > 1e-12))
+            vals = np.unique(np.round(left[free_slots], 12))
+            for val in vals:
+                sel = np.zeros(width); sel[free_slots[np.abs(left[free_slots] - val) < 1e-12]] = 1.0
+                tokens.append((sel, 0.0, _FREE)); c.append(float(val))
+            left = objM - np.stack([t[0] for t in tokens], axis=1) @ np.asarray(c)
+            if np.abs(left).max() > 1e-10:
+                raise NotImplementedError("cfmm.cvx: the objective must be linear in psi")
+        c = np.asarray(c) * 1.0
+        if np.any(c < -1e-14):
+            raise NotImplementedError("cfmm.cvx: negative objective weights on psi")
+        # slots no token row covers: a pool asset that appears in neither objective nor constraints is unpriced
+        cover = np.zeros(width)
+        for t in tokens:
+            cover += t[0]
+        if np.any(cover < 0.5):
+            raise NotImplementedError("cfmm.cvx: a pool asset that no entry of psi mentions (unbounded or irrelevant)")
+        if np.any(cover > 1.5):
+            raise NotImplementedError("cfmm.cvx: a pool slot mapped to two tokens")
+        local = []
+        for i, p in enumerate(pools):
+            idx = []
+            for s in range(offs[i], offs[i + 1]):
+                idx.append(int(np.flatnonzero([t[0][s] > 0.5 for t in tokens])[0]))
+            local.append(idx)
+        n = len(tokens)
+        util = _Utility(np.maximum(c, 0.0), np.array([t[1] for t in tokens]), np.array([t[2] for t in tokens], dtype=np.int32))
+        return pools, local, n, util
+
+    def solve(self, solver=None, verbose=False, **kw):
+        """maps the model onto cfmm.Problem and solves it on the device; returns prob.value like cvxpy"""
+        pools, local, n, util = self._match()
+        tol = float(kw.pop("tol", 1e-9))
+        p = _RoutingProblem(n, local, [pl["R"] for pl in pools], [pl["fee"] for pl in pools],
+                            ["geomean" if pl["kind"] == "geomean" else "sum" for pl in pools],
+                            [pl["w"] for pl in pools], utility=util)
+        if CONTEXT_FACTORY is not None:
+            p.ctx = CONTEXT_FACTORY(n)
+        p.solve(tol=tol, **kw)
+        self.routing = p
+        deltas, lambdas = p.deltas, p.lambdas
+        for pl, d, l in zip(pools, deltas, lambdas):
+            pl["D"]._value = np.asarray(d, dtype=np.float64)
+            pl["L"]._value = np.asarray(l, dtype=np.float64)
+        self.status = {"optimal": OPTIMAL, "inaccurate": INACCURATE, "infeasible": INFEASIBLE}.get(p.status, p.status)
+        self.value = self.objective.value
+        if verbose:
+            print(f"cfmm.cvx: {len(pools)} pools / {n} tokens, status {p.status}, gap {p.gap:.2e}, infeas {p.infeas:.2e}, "
+                  f"{p.stats['evals']} dual evaluations")
+        return self.value

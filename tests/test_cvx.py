@@ -1,0 +1,129 @@
+"""the cvxpy-compatible shim (cfmm.cvx).  CPU part: the shim's algebra and pattern match, and the three
+shipped programs through it with the C oracle standing in for the device; when /root/reference is present (this container,
+not the GPU box) the REAL scripts are executed with nothing changed but what `import cvxpy` resolves to."""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+import cfmm
+import cfmm.cvx as cp
+from oracle import instances as I
+from helpers import golden, shipped_cases
+from oracle_ctx import OracleContext
+import cvx_models
+
+REF = "/root/reference"
+
+
+@pytest.fixture
+def oracle_device(oracle_lib):
+    cp.CONTEXT_FACTORY = lambda n: OracleContext(n)
+    yield
+    cp.CONTEXT_FACTORY = None
+
+
+def _check(name, prob, goal, net, tender, receive, tol_y):
+    k = golden()[name]["kkt"]
+    assert prob.status == cp.OPTIMAL
+    assert abs(prob.value - k["value"]) <= 1e-8 * max(1.0, abs(k["value"]))
+    assert abs(goal.value - prob.value) <= 1e-12 * max(1.0, abs(prob.value))
+    assert np.abs(net.value - np.asarray(k["psi"])).max() <= tol_y
+    for d, l, y in zip(tender, receive, k["y"]):
+        assert np.all(d.value >= 0) and np.all(l.value >= 0)
+        assert np.abs((l.value - d.value) - np.asarray(y)).max() <= tol_y
+
+
+@pytest.mark.parametrize("name,inst", shipped_cases())
+def test_shipped_programs_through_the_shim(oracle_device, name, inst):
+    prob, goal, net, tender, receive = cvx_models.build(cp, inst)
+    v = prob.solve(tol=1e-10)
+    assert v == prob.value
+    _check(name, prob, goal, net, tender, receive, 2e-8)
+
+
+def _run_reference_script(fname):
+    """exec the reference's own script text with `cvxpy` resolving to the shim (and the plotting modules, which need a
+    LaTeX installation, to inert stand-ins): nothing else is changed"""
+    src = open(os.path.join(REF, fname)).read()
+    fake_plt = types.ModuleType("matplotlib.pyplot")
+    for fn in ("plot", "legend", "xlabel", "ylabel", "ylim", "savefig", "figure", "close"):
+        setattr(fake_plt, fn, lambda *a, **k: None)
+    fake_mpl = types.ModuleType("matplotlib"); fake_mpl.pyplot = fake_plt
+    fake_latexify = types.ModuleType("latexify"); fake_latexify.latexify = lambda *a, **k: None
+    saved = {k: sys.modules.get(k) for k in ("cvxpy", "matplotlib", "matplotlib.pyplot", "latexify")}
+    sys.modules.update({"cvxpy": cp, "matplotlib": fake_mpl, "matplotlib.pyplot": fake_plt, "latexify": fake_latexify})
+    out = io.StringIO()
+    ns = {"__name__": "__main__"}
+    try:
+        with contextlib.redirect_stdout(out):
+            exec(compile(src, fname, "exec"), ns)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return ns, out.getvalue()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout does not travel to the GPU box")
+def test_the_reference_scripts_run_unmodified(oracle_device):
+    g = golden()
+    ns, out = _run_reference_script("arbitrage.py")
+    assert abs(ns["prob"].value - g["arbitrage"]["kkt"]["value"]) <= 1e-7
+    assert out.strip().startswith("Total output value: 21.49980")
+    ns, out = _run_reference_script("liquidation.py")
+    assert abs(ns["psi"].value[4] - g["liquidation"]["kkt"]["value"]) <= 1e-7
+    assert out.strip().startswith("Total liquidated value: 15.88301")
+    ns, out = _run_reference_script("two-asset.py")           # the 50-point sweep, 50 solves
+    u = ns["u_t"]
+    for j in (0, 1, 10, 25, 49):
+        assert abs(u[j] - g[f"two_asset_{j}"]["kkt"]["value"]) <= 1e-7
+        for k in range(5):
+            assert np.abs(ns["all_values"][k][:, j] - np.asarray(g[f"two_asset_{j}"]["kkt"]["y"][k])).max() <= 1e-6
+    assert np.all(np.diff(u) > 0) and out.count("Total liquidated value:") == 50
+
+
+def test_affine_algebra_matches_numpy():
+    rng = np.random.default_rng(0)
+    x, y = cp.Variable(3, nonneg=True), cp.Variable(2, nonneg=True)
+    A, B, c = rng.normal(size=(4, 3)), rng.normal(size=(4, 2)), rng.normal(size=4)
+    e = A @ x - 2.0 * (B @ y) + c
+    f = (c @ e) + e[1] - cp.sum(e) / 2
+    x._value, y._value = rng.random(3), rng.random(2)
+    ev = A @ x._value - 2.0 * (B @ y._value) + c
+    assert np.allclose(e.value, ev) and np.isclose(f.value, c @ ev + ev[1] - ev.sum() / 2)
+    assert np.allclose((c + e).value, c + ev) and np.allclose((c - e).value, c - ev) and np.allclose((e * 3).value, 3 * ev)
+    assert cp.geo_mean(np.array([4.0, 4.0, 4.0, 4.0]), p=np.array([4, 3, 2, 1])) == pytest.approx(4.0)
+    assert cp.sum(np.array([1.0, 2.0])) == 3.0
+
+
+def test_models_outside_the_routing_class_are_refused(oracle_device):
+    inst = I.arbitrage()
+    prob, goal, net, tender, receive = cvx_models.build(cp, inst)
+    bad = cp.Problem(goal, prob.constraints + [2.0 * net[0] >= 1.0])            # not an entry of psi
+    with pytest.raises(NotImplementedError):
+        bad.solve()
+    x = cp.Variable(2, nonneg=True)
+    with pytest.raises(NotImplementedError):
+        cp.Problem(cp.Maximize(cp.sum(x)), [x <= 1]).solve()                    # no pools at all
+    # a geo-mean right-hand side that is not the pool's current invariant
+    d, l = cp.Variable(2, nonneg=True), cp.Variable(2, nonneg=True)
+    R = np.array([1.0, 2.0])
+    with pytest.raises(NotImplementedError, match="current"):
+        cp.Problem(cp.Maximize((l - d)[0]), [cp.geo_mean(R + 0.99 * d - l) >= 5.0, (l - d)[1] + 1 >= 0]).solve()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,inst", shipped_cases())
+def test_shipped_programs_through_the_shim_on_the_gpu(name, inst):
+    cp.CONTEXT_FACTORY = None
+    prob, goal, net, tender, receive = cvx_models.build(cp, inst)
+    prob.solve(tol=1e-10)
+    _check(name, prob, goal, net, tender, receive, 5e-8)
+    prob.routing.close()
