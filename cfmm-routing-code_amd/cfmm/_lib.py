@@ -55,7 +55,7 @@ _lib = None
 
 SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm_backend", "cfmm_default_opts",
            "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_set_pool_flags", "cfmm_set_utility",
-           "cfmm_set_ties", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_solve", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
+           "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_solve", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_comm_unique_id", "cfmm_comm_init",
            "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
 
@@ -81,6 +81,8 @@ def lib():
     L.cfmm_set_pool_flags.argtypes = [vp, C.c_int, ip]
     L.cfmm_set_utility.argtypes = [vp, dp, dp, ip]
     L.cfmm_set_ties.argtypes = [vp, C.c_int, ip, dp]
+    L.cfmm_set_deterministic.argtypes = [vp, C.c_int]
+    L.cfmm_debug_eval_limbs.argtypes = [vp, dp, C.c_double, C.c_double, C.POINTER(C.c_uint64)]
     L.cfmm_eval_dual.argtypes = [vp, dp, dp, dp, dp]
     L.cfmm_eval_smooth.argtypes = [vp, dp, C.c_double, dp, dp, dp, dp]
     L.cfmm_debug_cholesky.argtypes = [vp, C.c_int, dp, dp, dp, ip]
@@ -181,6 +183,17 @@ class Context:
         else:
             grp, off = i32(grp), f64(off)
             self._chk(self.L.cfmm_set_ties(self.h, int(grp.max()) + 1, _i(grp), _d(off)))
+
+    def set_deterministic(self, on=True):
+        """bitwise-reproducible psi (integer accumulation): see include/cfmm.h"""
+        self._chk(self.L.cfmm_set_deterministic(self.h, 1 if on else 0))
+
+    def debug_eval_limbs(self, nu, ref_reserve, ref_fee):
+        """raw fixed-point limbs [3][n] of psi (uint64) from one reproducible-mode evaluation (test hook)"""
+        nu = f64(nu)
+        limbs = np.zeros((3, self.n), dtype=np.uint64)
+        self._chk(self.L.cfmm_debug_eval_limbs(self.h, _d(nu), float(ref_reserve), float(ref_fee), limbs.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return limbs
 
     def eval_dual(self, nu, want_diag=False):
         nu = f64(nu)

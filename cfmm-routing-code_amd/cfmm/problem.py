@@ -310,7 +310,7 @@ class Problem:
     """
 
     def __init__(self, n_tokens, local_indices=None, reserves=None, fees=None, kinds=None, weights=None,
-                 params=None, utility=None, device=0, network=None):
+                 params=None, utility=None, device=0, network=None, deterministic=False):
         self.n = int(n_tokens)
         if network is not None:
             self.net, self.where = network, None
@@ -319,6 +319,7 @@ class Problem:
         self.m = network_pool_count(self.net)
         self.utility = utility
         self.device = device
+        self.deterministic = bool(deterministic)      # bitwise-reproducible psi (include/cfmm.h: cfmm_set_deterministic)
         self.ctx = None
         self._uploaded = False
         self.value = None; self.status = None; self.psi = None; self.nu = None
@@ -331,15 +332,16 @@ class Problem:
         self._dev_ties = False         # price ties / pool flags are set on the device
 
     @classmethod
-    def from_network(cls, net, utility=None, device=0):
-        return cls(net["n_tokens"], utility=utility, device=device, network=net)
+    def from_network(cls, net, utility=None, device=0, deterministic=False):
+        return cls(net["n_tokens"], utility=utility, device=device, network=net, deterministic=deterministic)
 
     def clone(self, utility=None):
         """A Problem over the SAME pools -- they stay where they are in HBM, nothing is uploaded again --
         with its own utility, prices and solver state (cfmm_clone).  Clones may be solved concurrently from
         different host threads: `solve_many`."""
         ctx = self._ensure_ctx()
-        q = Problem(self.n, utility=utility if utility is not None else self.utility, device=self.device, network=self.net)
+        q = Problem(self.n, utility=utility if utility is not None else self.utility, device=self.device, network=self.net,
+                    deterministic=self.deterministic)        # (cfmm_clone hands the mode on to the new context)
         q.where = self.where
         q.ctx = ctx.clone()
         q._uploaded = True
@@ -390,6 +392,8 @@ class Problem:
     def _ensure_ctx(self):
         if self.ctx is None:
             self.ctx = _lib.Context(self.n, self.device)      # raises without HIP lib / gfx950
+            if self.deterministic:
+                self.ctx.set_deterministic(True)
         if not self._uploaded:
             for key, kind in KIND2.items():
                 if key in self.net:

@@ -62,7 +62,7 @@ struct Rccl {
     }
 };
 Rccl g_rccl;
-constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0;
+constexpr int NCCL_FLOAT64 = 8, NCCL_INT64 = 4, NCCL_SUM = 0, NCCL_MAX = 2;
 
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
@@ -76,6 +76,8 @@ struct PoolStore {
     void *b2mem[CFMM_POOL_KINDS2] = {};           // one arena (one hipMalloc) per bucket: every column lives in it
     BucketN bn[CFMM_MAX_POOL_SIZE + 1] = {};
     void *bnmem[CFMM_MAX_POOL_SIZE + 1] = {};
+    double mxr2[CFMM_POOL_KINDS2] = {}, mnf2[CFMM_POOL_KINDS2] = {1.0, 1.0, 1.0, 1.0};       // largest reserve / smallest fee per bucket
+    double mxrn[CFMM_MAX_POOL_SIZE + 1] = {}, mnfn[CFMM_MAX_POOL_SIZE + 1] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
     ~PoolStore()
     {
         for (void *q : b2mem) if (q) (void)hipFree(q);
@@ -127,6 +129,13 @@ struct cfmm_ctx {
     // fused iteration (iterate.hpp): three rotating sets of accumulators / solver state, a history ring of M + 1 slots
     bool fused = true;                 // CFMM_FUSED=0: the two-launch iteration of round 1 (A/B)
     bool plain = false;                // utility has h == 0 and only CFMM_GE tokens (IterArgs::plain)
+    // reproducible mode (kernels.hpp: Scatter<true>): psi accumulated as exact fixed-point integers
+    bool det = false;
+    unsigned long long *acc_l = nullptr;   // [2][3][n] limbs of psi | diag
+    double max_reserve = 0.0, min_fee = 1.0;   // over the pools of THIS context (for the fixed-point exponent)
+    double g_max_reserve = 0.0;        // ... and over all ranks
+    double nu_max = 1.0;               // largest price last handed in (scales the diagonal metric's limbs)
+    double det_ref_reserve = 0.0, det_ref_fee = 0.0;   // (test hook) exponent reference instead of this context's own maxima
     double *acc3 = nullptr, *xs3 = nullptr, *S5 = nullptr, *Y5 = nullptr, *rho5 = nullptr;
     DevState *st3 = nullptr;
     DevState *hst3 = nullptr;          // pinned [2][3]
@@ -279,20 +288,44 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out)
     return CFMM_OK;
 }
 
+// largest reserve / smallest fee over this context's pools (the fixed-point exponent of the reproducible mode)
+void local_extrema(cfmm_ctx *ctx)
+{
+    ctx->max_reserve = 0.0; ctx->min_fee = 1.0;
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) if (ctx->pools->b2[k].m) { ctx->max_reserve = std::max(ctx->max_reserve, ctx->pools->mxr2[k]); ctx->min_fee = std::min(ctx->min_fee, ctx->pools->mnf2[k]); }
+    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) if (ctx->pools->bn[k].m) { ctx->max_reserve = std::max(ctx->max_reserve, ctx->pools->mxrn[k]); ctx->min_fee = std::min(ctx->min_fee, ctx->pools->mnfn[k]); }
+    ctx->g_max_reserve = ctx->max_reserve;
+}
+
 // a successful (re-)upload invalidates everything that was derived from the previous pool set
 void pools_changed(cfmm_ctx *ctx)
 {
+    local_extrema(ctx);
     ctx->g_valid = false;
     ctx->hsol_valid = false; ctx->mu_last = 0.0; ctx->warm_mu = 0.0; ctx->slo_active = false;
 }
 
-size_t eval_lds_bytes(int n, bool with_d) { return (size_t)eval_lds_doubles(n, with_d) * sizeof(double) + (size_t)(EVAL_THREADS / 64) * 64 * 16; }
-size_t iter_lds_bytes(int n) { return eval_lds_bytes(n, false) + (size_t)iter_extra_lds_doubles() * sizeof(double); }
+size_t eval_lds_bytes(int n, bool with_d, bool det = false) { return (size_t)eval_lds_doubles(n, with_d, det) * sizeof(double) + (size_t)(EVAL_THREADS / 64) * 64 * 16; }
+size_t iter_lds_bytes(int n, bool det = false) { return eval_lds_bytes(n, false, det) + (size_t)iter_extra_lds_doubles() * sizeof(double); }
 size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 16 * 64 + 64 + 32 + 2 * 12 * 16 + 8) * sizeof(double); }
 
 // processing order of the fused evaluation kernel (heaviest first): bucket code = -k for the
 // k-asset geo-mean buckets, CFMM_POOL_* for the two-asset ones
 const int kOrder[N_BUCKETS] = {-8, -7, -6, -5, -4, -3, CFMM_POOL_CURVE2, CFMM_POOL_W2, CFMM_POOL_CP2, CFMM_POOL_SUM2};
+
+// reproducible mode: contributions to psi are bounded by (largest reserve) / (smallest fee); they are scaled by 2^F with
+// F such that their 96-bit fixed-point image keeps 10 bits of head-room (kernels.hpp: Scatter<true>).  The diagonal
+// metric's terms are (price x reserve)-sized.  Every rank derives the same exponents from the global maxima.
+void det_scales(cfmm_ctx *ctx, double &sc, double &scd)
+{
+    const double mr = std::max(ctx->det_ref_reserve > 0.0 ? ctx->det_ref_reserve : (ctx->comm ? ctx->g_max_reserve : ctx->max_reserve), 1e-300);
+    const double mf = ctx->det_ref_fee > 0.0 ? ctx->det_ref_fee : ctx->min_fee;
+    int e = 0;
+    (void)std::frexp(mr / std::max(mf, 1e-3), &e);                  // value < 2^e
+    sc = std::ldexp(1.0, 84 - e);
+    (void)std::frexp(mr * std::max(ctx->nu_max, 1e-300), &e);
+    scd = std::ldexp(1.0, 84 - e);
+}
 
 // `only` = a bucket code to evaluate that bucket alone (measurement hook), or 0x7fffffff for all;
 // `stable` selects the tile space of eval_kernel<.., STABLE>: the stableswap bucket alone, or everything else
@@ -313,6 +346,8 @@ EvalArgs make_eval_args(cfmm_ctx *ctx, bool stable, int only = 0x7fffffff)
     a.ntiles = (int)tiles;
     a.n = ctx->n; a.nslices = ctx->nslices;
     a.nu = ctx->nu; a.acc = ctx->acc; a.ts = ctx->ts;
+    a.acc_l = ctx->acc_l;
+    det_scales(ctx, a.det_scale, a.det_scale_d);
     return a;
 }
 
@@ -335,7 +370,23 @@ void launch_eval(cfmm_ctx *ctx, const EvalArgs &a)
     if (a.ntiles == 0) return;
     int grid, threads;
     eval_geometry(ctx, a.ntiles, grid, threads);
-    hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), ctx->stream, a);
+    if (ctx->det) hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE, true>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D, true), ctx->stream, a);
+    else hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), ctx->stream, a);
+}
+
+// reproducible mode, after the evaluation launches: [integer all-reduce of the limbs] -> det_fold_kernel writes psi,
+// sum arb = nu'psi (and the diagonal metric) into accumulator slice 0 at `out` and clears the limbs
+int det_finish(cfmm_ctx *ctx, double *out, const double *nu, bool with_d)
+{
+    const int n = ctx->n;
+    if (ctx->comm) {
+        int rc = g_rccl.AllReduce(ctx->acc_l, ctx->acc_l, (size_t)(with_d ? 6 : 3) * n, NCCL_INT64, NCCL_SUM, ctx->comm, ctx->stream);
+        if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce (limbs) -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    }
+    double sc, scd;
+    det_scales(ctx, sc, scd);
+    hipLaunchKernelGGL(det_fold_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->acc_l, nu, out, n, 1.0 / sc, 1.0 / scd, with_d ? 1 : 0);
+    return CFMM_OK;
 }
 
 // one dual evaluation of every bucket: one launch, plus one for the stableswap bucket when there is one
@@ -369,13 +420,21 @@ int set_all_lds_attrs(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, start_kernel, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, iter_kernel<1>, iter_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, iter_kernel<2>, iter_lds_bytes(ctx->n)))) return rc;
+    if (eval_lds_bytes(ctx->n, true, true) <= 160 * 1024) {        // reproducible mode: tiles of 3 n integer limbs
+        if ((rc = set_lds_attr(ctx, eval_kernel<false, false, true>, eval_lds_bytes(ctx->n, false, true)))) return rc;
+        if ((rc = set_lds_attr(ctx, eval_kernel<true, false, true>, eval_lds_bytes(ctx->n, true, true)))) return rc;
+        if ((rc = set_lds_attr(ctx, eval_kernel<false, true, true>, eval_lds_bytes(ctx->n, false, true)))) return rc;
+        if ((rc = set_lds_attr(ctx, eval_kernel<true, true, true>, eval_lds_bytes(ctx->n, true, true)))) return rc;
+        if ((rc = set_lds_attr(ctx, iter_kernel<1, true>, iter_lds_bytes(ctx->n, true)))) return rc;
+        if ((rc = set_lds_attr(ctx, iter_kernel<2, true>, iter_lds_bytes(ctx->n, true)))) return rc;
+    }
     return CFMM_OK;
 }
 
 UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
 {
     UpdArgs a;
-    a.n = ctx->n; a.ng = ctx->ng; a.M = o.memory; a.nslices = ctx->comm ? 1 : ctx->nslices;
+    a.n = ctx->n; a.ng = ctx->ng; a.M = o.memory; a.nslices = (ctx->comm || ctx->det) ? 1 : ctx->nslices;
     a.acc = ctx->acc;
     a.c = ctx->c; a.h = ctx->h; a.off = ctx->off; a.glo = ctx->glo; a.ghi = ctx->ghi;
     a.ctype = ctx->ctype; a.grp = ctx->grp;
@@ -402,7 +461,7 @@ IterArgs make_iter_args(cfmm_ctx *ctx, const cfmm_opts &o)
     IterArgs a = {};
     a.ev = make_eval_args(ctx, false);
     a.ev.nu = nullptr; a.ev.acc = nullptr;
-    a.n = ctx->n; a.M = o.memory; a.nread = ctx->comm ? 1 : ctx->nslices; a.phase = 0;
+    a.n = ctx->n; a.M = o.memory; a.nread = (ctx->comm || ctx->det) ? 1 : ctx->nslices; a.phase = 0;
     a.xvs = iter_xvs(ctx->n); a.max_evals = o.max_evals; a.pg_rule = o.pg_rule;
     a.plain = ctx->plain ? 1 : 0;
     a.acc3 = ctx->acc3; a.acc_set = (long long)acc_set_doubles(ctx);
@@ -436,8 +495,11 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
         if (grid > slots) grid = slots;
         if (grid < 1) grid = 1;                                 // (a shard without pools still takes the step)
     }
-    const size_t lds = iter_lds_bytes(n);
-    if (E == 1) hipLaunchKernelGGL(iter_kernel<1>, dim3(grid), dim3(threads), lds, ctx->stream, a);
+    const size_t lds = iter_lds_bytes(n, ctx->det);
+    if (ctx->det) {
+        if (E == 1) hipLaunchKernelGGL((iter_kernel<1, true>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((iter_kernel<2, true>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+    } else if (E == 1) hipLaunchKernelGGL(iter_kernel<1>, dim3(grid), dim3(threads), lds, ctx->stream, a);
     else hipLaunchKernelGGL(iter_kernel<2>, dim3(grid), dim3(threads), lds, ctx->stream, a);
     double *acc_p = ctx->acc3 + (size_t)a.phase * acc_set_doubles(ctx);
     if (ctx->pools->b2[CFMM_POOL_CURVE2].m > 0) {              // the stableswap bucket has its own instantiation: it reads the
@@ -445,6 +507,7 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
         es.nu = ctx->nu; es.acc = acc_p;
         launch_eval<false, true>(ctx, es);
     }
+    if (ctx->det) return det_finish(ctx, acc_p, ctx->nu, false);     // (the prices workgroup 0 has just stored)
     if (ctx->comm) {
         const int len = acc_arb(n) + 1;
         hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, acc_p, n, ctx->nslices, 0, (const DevState *)nullptr);
@@ -481,7 +544,8 @@ template <bool WITH_D>
 int enqueue_iteration(cfmm_ctx *ctx, const UpdArgs &ua)
 {
     launch_all_evals<WITH_D>(ctx);
-    if (ctx->comm) {                            // pool-sharded (a communicator of one rank runs the same path)
+    if (ctx->det) { int rc = det_finish(ctx, ctx->acc, ctx->nu, WITH_D); if (rc) return rc; }
+    else if (ctx->comm) {                       // pool-sharded (a communicator of one rank runs the same path)
         const int len = WITH_D ? acc_stride(ctx->n) : acc_arb(ctx->n) + 1;
         hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, ctx->n,
                            ctx->nslices, WITH_D ? 1 : 0, (const DevState *)nullptr);
@@ -601,7 +665,17 @@ int refresh_global_counts(cfmm_ctx *ctx)
 {
     ctx->g_total = cfmm_pool_count(ctx);
     ctx->g_stable = ctx->pools->b2[CFMM_POOL_CURVE2].m;
+    local_extrema(ctx);
     if (!ctx->comm) return CFMM_OK;
+    if (ctx->det) {                                  // the fixed-point exponent must be the same on every rank: global maxima
+        double mx[2] = {ctx->max_reserve, 1.0 / ctx->min_fee};
+        double *dm = ctx->psi_t + 2;
+        HIP_TRY(ctx, hipMemcpyAsync(dm, mx, sizeof mx, hipMemcpyHostToDevice, ctx->stream));
+        if (g_rccl.AllReduce(dm, dm, 2, NCCL_FLOAT64, NCCL_MAX, ctx->comm, ctx->stream) != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce (maxima) failed");
+        HIP_TRY(ctx, hipMemcpyAsync(mx, dm, sizeof mx, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->g_max_reserve = mx[0]; ctx->min_fee = 1.0 / mx[1];
+    }
     double cnt[2] = {(double)ctx->g_total, (double)ctx->g_stable};
     double *dv = ctx->psi_t;                         // scratch (overwritten by the first update of every solve)
     HIP_TRY(ctx, hipMemcpyAsync(dv, cnt, sizeof cnt, hipMemcpyHostToDevice, ctx->stream));
@@ -979,6 +1053,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if (const char *s = getenv("CFMM_NO_GRAPH")) ctx->no_graph = atoi(s) != 0;
     if (const char *s = getenv("CFMM_FUSED")) ctx->fused = atoi(s) != 0;
     if (const char *s = getenv("CFMM_RUN_AHEAD")) ctx->run_ahead = std::max(1, atoi(s));
+    if (const char *s = getenv("CFMM_DETERMINISTIC")) ctx->det = atoi(s) != 0;
     const int n = n_tokens;
     int rc = 0;
     rc |= dev_upload<double>(ctx, &ctx->c, nullptr, n + 4, nullptr);
@@ -1002,6 +1077,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     rc |= dev_upload<double>(ctx, &ctx->Y5, nullptr, (size_t)ITER_RING * hist_stride(n) + 4, nullptr);
     rc |= dev_upload<double>(ctx, &ctx->rho5, nullptr, ITER_RING + 3, nullptr);
     rc |= dev_upload<DevState>(ctx, &ctx->st3, nullptr, 3, nullptr);
+    rc |= dev_upload<unsigned long long>(ctx, &ctx->acc_l, nullptr, 6 * (size_t)n + 4, nullptr);
     rc |= dev_upload<long long>(ctx, &ctx->ts, nullptr, 64 + 8 * 4096 + 2048, nullptr);
     if (rc) return bail(CFMM_E_HIP);
     TRY_C(hipHostMalloc((void **)&ctx->hst, 2 * sizeof(DevState), hipHostMallocDefault));
@@ -1013,6 +1089,10 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     for (int i = 0; i < 2; ++i) TRY_C(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
     TRY_C(hipEventCreate(&ctx->ev_t0));
     TRY_C(hipEventCreate(&ctx->ev_t1));
+    if (ctx->det && eval_lds_bytes(n, true, true) > 160 * 1024) {
+        fail(ctx, CFMM_E_LIMIT, "cfmm_create: CFMM_DETERMINISTIC=1 with %d tokens exceeds the LDS tile of the reproducible mode", n);
+        return bail(CFMM_E_LIMIT);
+    }
     if ((rc = set_all_lds_attrs(ctx))) return bail(rc);
     {
         int nb = 0;
@@ -1042,6 +1122,8 @@ int cfmm_clone(cfmm_ctx *src, cfmm_ctx **out)
     int rc = cfmm_create(src->device, src->n, &c);
     if (rc) { src->err = g_create_error; return rc; }
     c->pools = src->pools;                 // the pool columns are shared: no copy, no second upload
+    c->det = src->det;
+    local_extrema(c);
     c->nslices = src->nslices <= c->nslices ? src->nslices : c->nslices;
     *out = c;
     return CFMM_OK;
@@ -1062,7 +1144,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
     void *ptrs[] = {ctx->c, ctx->h, ctx->off, ctx->glo, ctx->ghi, ctx->ctype, ctx->grp, ctx->nu, ctx->nu_acc, ctx->psi_acc,
                     ctx->psi_t, ctx->nu0, ctx->s, ctx->s_t, ctx->Gs, ctx->Gs_t, ctx->d, ctx->Ds, ctx->S, ctx->Y, ctx->rho,
-                    ctx->acc, ctx->st, ctx->ts, ctx->acc3, ctx->xs3, ctx->S5, ctx->Y5, ctx->rho5, ctx->st3};
+                    ctx->acc, ctx->st, ctx->ts, ctx->acc3, ctx->xs3, ctx->S5, ctx->Y5, ctx->rho5, ctx->st3, ctx->acc_l};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->hst) (void)hipHostFree(ctx->hst);
     if (ctx->hst3) (void)hipHostFree(ctx->hst3);
@@ -1096,6 +1178,8 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
     for (int64_t i = 0; i < m; ++i)
         if (ia[i] < 0 || ia[i] >= ctx->n || ib[i] < 0 || ib[i] >= ctx->n || ia[i] == ib[i])
             return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has token ids (%d, %d) outside [0,%d) or equal", (long long)i, ia[i], ib[i], ctx->n);
+    double mxr = 0.0, mnf = 1.0;
+    for (int64_t i = 0; i < m; ++i) { mxr = std::max(mxr, std::max(Ra[i], Rb[i])); mnf = std::min(mnf, fee[i]); }
     for (int64_t i = 0; i < m; ++i) {
         if (!(Ra[i] > 0.0) || !(Rb[i] > 0.0) || !std::isfinite(Ra[i]) || !std::isfinite(Rb[i]))
             return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has a reserve that is not positive and finite", (long long)i);
@@ -1124,6 +1208,7 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
     if (ctx->pools->b2mem[kind]) (void)hipFree(ctx->pools->b2mem[kind]);
     ctx->pools->b2mem[kind] = arena;
     ctx->pools->b2[kind] = b;
+    ctx->pools->mxr2[kind] = mxr; ctx->pools->mnf2[kind] = mnf;
     if (kind == CFMM_POOL_SUM2 && ctx->flags2) { (void)hipFree(ctx->flags2); ctx->flags2 = nullptr; }
     pools_changed(ctx);
     return CFMM_OK;
@@ -1142,6 +1227,9 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
             return fail(ctx, CFMM_E_ARG, "upload_poolsN: leg %lld has reserve %g / weight %g (need R > 0, 0 < w < 1)", (long long)i, R[i], w[i]);
     for (int64_t i = 0; i < m; ++i)
         if (!(fee[i] > 0.0 && fee[i] <= 1.0)) return fail(ctx, CFMM_E_ARG, "upload_poolsN: pool %lld has fee %g outside (0, 1]", (long long)i, fee[i]);
+    double mxr = 0.0, mnf = 1.0;
+    for (int64_t i = 0; i < (int64_t)k * m; ++i) mxr = std::max(mxr, R[i]);
+    for (int64_t i = 0; i < m; ++i) mnf = std::min(mnf, fee[i]);
     if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_poolsN: the pools are shared with a clone (cfmm_clone); destroy the clones first");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     BucketN b = {};
@@ -1164,6 +1252,7 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
     if (ctx->pools->bnmem[k]) (void)hipFree(ctx->pools->bnmem[k]);
     ctx->pools->bnmem[k] = arena;
     ctx->pools->bn[k] = b;
+    ctx->pools->mxrn[k] = mxr; ctx->pools->mnfn[k] = mnf;
     pools_changed(ctx);
     return CFMM_OK;
 }
@@ -1232,6 +1321,7 @@ int cfmm_set_nu(cfmm_ctx *ctx, const double *nu)
     if (!ctx || !nu) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int j = 0; j < ctx->n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "set_nu: nu[%d] = %g is not a positive finite price", j, nu[j]);
+    { double mx = 0.0; for (int j = 0; j < ctx->n; ++j) mx = std::max(mx, nu[j]); ctx->nu_max = mx; }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu_acc, nu, ctx->n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the caller's (pageable) buffer may go away after we return
     ctx->have_nu = true; ctx->hsol_valid = false; ctx->mu_last = 0.0; ctx->slo_active = false;
@@ -1280,11 +1370,15 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, nu, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->nu + n, 0, sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
+    { double mx = 0.0; for (int j = 0; j < n; ++j) mx = std::max(mx, nu[j]); ctx->nu_max = mx; }
+    if (ctx->det && ctx->comm) { int rc = refresh_global_counts(ctx); if (rc) return rc; }      // (the fixed-point exponent is a global quantity)
+    if (ctx->det) HIP_TRY(ctx, hipMemsetAsync(ctx->acc_l, 0, 6 * (size_t)n * sizeof(unsigned long long), ctx->stream));
     if (diag) launch_all_evals<true>(ctx); else launch_all_evals<false>(ctx);
     const int len = acc_stride(n);
-    hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, n, ctx->nslices, 1, (const DevState *)nullptr);
+    if (ctx->det) { int rc = det_finish(ctx, ctx->acc, ctx->nu, diag != nullptr); if (rc) return rc; }
+    else hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, n, ctx->nslices, 1, (const DevState *)nullptr);
     HIP_TRY(ctx, hipGetLastError());
-    if (ctx->comm) {                            // pool-sharded (a communicator of one rank runs the same path)
+    if (ctx->comm && !ctx->det) {               // pool-sharded (a communicator of one rank runs the same path)
         int rc = g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
         if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed (%d)", rc);
     }
@@ -1441,6 +1535,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu0, ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     *ctx->hstat_h = 0;                                     // (the stream is idle: nothing can still write the progress word)
+    if (ctx->det) HIP_TRY(ctx, hipMemsetAsync(ctx->acc_l, 0, 6 * (size_t)n * sizeof(unsigned long long), ctx->stream));
     if (fused) {
         // launch 0: the start point and the first evaluation (with the diagonal metric) into state / accumulator set 0
         HIP_TRY(ctx, hipMemsetAsync(ctx->acc3, 0, 3 * aset * sizeof(double), ctx->stream));
@@ -1453,7 +1548,8 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
             e0.nu = ua.nu; e0.acc = ctx->acc3;
             if (stable) launch_eval<true, true>(ctx, e0); else launch_eval<true, false>(ctx, e0);
         }
-        if (ctx->comm) {
+        if (ctx->det) { int rc = det_finish(ctx, ctx->acc3, ua.nu, true); if (rc) return rc; }
+        else if (ctx->comm) {
             const int len = acc_stride(n);
             hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc3, n, ctx->nslices, 1, (const DevState *)nullptr);
             int rc = g_rccl.AllReduce(ctx->acc3, ctx->acc3, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
@@ -1528,6 +1624,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->hsol + n, ctx->psi_acc, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->hsol_valid = true;
+    { double mx = 0.0; for (int j = 0; j < n; ++j) mx = std::max(mx, ctx->hsol[j]); if (mx > 0.0 && std::isfinite(mx)) ctx->nu_max = mx; }
     const auto t1 = std::chrono::steady_clock::now();
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
@@ -1642,6 +1739,38 @@ int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128)
     return CFMM_OK;
 }
 
+int cfmm_set_deterministic(cfmm_ctx *ctx, int on)
+{
+    if (!ctx) return CFMM_E_ARG;
+    if (on && eval_lds_bytes(ctx->n, true, true) > 160 * 1024)
+        return fail(ctx, CFMM_E_LIMIT, "set_deterministic: %d tokens exceed the LDS tile of the reproducible mode (7 n doubles)", ctx->n);
+    if ((on != 0) != ctx->det) ctx->g_valid = false;
+    ctx->det = on != 0;
+    return CFMM_OK;
+}
+
+int cfmm_debug_eval_limbs(cfmm_ctx *ctx, const double *nu, double ref_reserve, double ref_fee, uint64_t *limbs)
+{
+    if (!ctx || !nu || !limbs) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n = ctx->n;
+    if (eval_lds_bytes(n, true, true) > 160 * 1024) return fail(ctx, CFMM_E_LIMIT, "debug_eval_limbs: too many tokens for the reproducible mode");
+    for (int j = 0; j < n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "debug_eval_limbs: nu[%d] is not a positive finite price", j);
+    { int rc = refresh_global_counts(ctx); if (rc) return rc; }
+    const bool was = ctx->det;
+    ctx->det = true; ctx->det_ref_reserve = ref_reserve; ctx->det_ref_fee = ref_fee;
+    hipError_t e = hipMemcpyAsync(ctx->nu, nu, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->nu + n, 0, sizeof(double), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->acc_l, 0, 6 * (size_t)n * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) { launch_all_evals<false>(ctx); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(limbs, ctx->acc_l, 3 * (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->acc_l, 0, 6 * (size_t)n * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    ctx->det = was; ctx->det_ref_reserve = 0.0; ctx->det_ref_fee = 0.0;
+    if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "debug_eval_limbs -> %s", hipGetErrorString(e));
+    return CFMM_OK;
+}
+
 int cfmm_selftest(cfmm_ctx *ctx)
 {
     if (!ctx) return CFMM_E_ARG;
@@ -1685,6 +1814,7 @@ int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_lau
     for (int i = 0; i < reps; ++i) launch();
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(ctx->n) * sizeof(double), ctx->stream));
+    if (ctx->det) HIP_TRY(ctx, hipMemsetAsync(ctx->acc_l, 0, 6 * (size_t)ctx->n * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
     float ms = 0.f;

@@ -233,7 +233,7 @@ __device__ __forceinline__ double uni(double v)
 // extra LDS of iter_kernel behind eval_kernel's carve: wave-private copies of the 48 batch totals
 __host__ __device__ inline int iter_extra_lds_doubles() { return 16 * 48; }
 
-template <int E>
+template <int E, bool DET = false>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 iter_kernel(IterArgs a)
 {
@@ -243,11 +243,12 @@ iter_kernel(IterArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = uni((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     // LDS carve of eval_kernel<false, .>; the update borrows the waves' exchange strips (16 KB, free until the tile loop)
     // and the psi tile (a stash for the trial gradient)
+    const int tile = eval_tile_doubles(n, DET);          // (reproducible mode: the psi tile holds 3 n integer limbs)
     double *psi_s = lds;
-    double *nu_s = lds + n;                              // [n + 1]
+    double *nu_s = lds + tile;                           // [n + 1]
     double *fpart = nu_s + n + 2;                        // [16]
     int *next_tile = reinterpret_cast<int *>(fpart + 16);
-    double *strips = lds + eval_lds_doubles(n, false);
+    double *strips = lds + eval_lds_doubles(n, false, DET);
     double *xw = strips;                                 // [16][64] per-wave sums
     double *xm = xw + 16 * 64;                           // [16][2] maxima
     BlockRed red(xm + 32);                               // [2][12][16]
@@ -551,12 +552,12 @@ iter_kernel(IterArgs a)
     __syncthreads();                                     // (the scratch in the exchange strips and the psi tile is free from here on)
 #pragma unroll
     for (int e = 0; e < E; ++e) if (tin[e]) nu_s[r0 + e] = nn[e];
-    for (int j = tid; j < n; j += blockDim.x) psi_s[j] = 0.0;
+    for (int j = tid; j < tile; j += blockDim.x) psi_s[j] = 0.0;
     if (tid == 0) *next_tile = 0;
     __syncthreads();
     PHASE_STAMP(a.ev.ts, 23);
     double2 *xs = reinterpret_cast<double2 *>(strips) + 64 * wave;
-    eval_tiles_and_flush<false, false>(a.ev, a.acc3 + (size_t)p * a.acc_set, nu_s, psi_s, nullptr, fpart, next_tile, xs);
+    eval_tiles_and_flush<false, false, DET>(a.ev, a.acc3 + (size_t)p * a.acc_set, nu_s, psi_s, nullptr, fpart, next_tile, xs);
 }
 
 }  // namespace cfmm

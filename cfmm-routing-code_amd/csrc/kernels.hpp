@@ -78,10 +78,16 @@ struct EvalArgs {
     const double *nu;                 // [n + 1]: prices, then the stop flag (non-zero = solve has ended)
     double *acc;
     long long *ts;                    // phase timers (tuning builds only)
+    unsigned long long *acc_l;        // reproducible mode: [2][3][n] fixed-point limbs of psi | diag (see Scatter<true>)
+    double det_scale, det_scale_d;    // reproducible mode: powers of two that scale psi / diag contributions to integers
 };
 
 // LDS carve of eval_kernel (doubles), 16-byte aligned pieces; then 64 double2 per wave
-__host__ __device__ inline int eval_lds_doubles(int n, bool with_d) { return (((with_d ? 3 : 2) * n + 2 + 16 + 2) + 1) & ~1; }
+__host__ __device__ inline int eval_tile_doubles(int n, bool det) { return (det ? 3 : 1) * n; }     // one scatter tile (psi or diag)
+__host__ __device__ inline int eval_lds_doubles(int n, bool with_d, bool det = false)
+{
+    return (((with_d ? 2 : 1) * eval_tile_doubles(n, det) + n + 2 + 16 + 2) + 1) & ~1;
+}
 
 // accumulator slice layout (np = n rounded up to even, so that every piece is 16-byte aligned):
 //   [0,n) psi | [np] sum arb | [np+8, np+8+n) diag
@@ -143,13 +149,45 @@ __device__ __forceinline__ double wave_sum(double v) { return wave_allsum(v); }
 __device__ __forceinline__ double wave_max(double v) { return wave_allmax(v); }
 
 // ------------------------------------------------------------------------------------------
+// Where a pool's A_i (Lambda_i - Delta_i) lands in the workgroup's LDS tile of psi (arbitrage.py:54).
+//   Scatter<false>: ds_add_f64 -- fast, but fp64 addition is not associative: the sum depends on the order in which lanes,
+//     waves and workgroups arrive, so psi differs in its last bits from run to run (and with it the path of the solve).
+//   Scatter<true> (reproducible mode, cfmm_set_deterministic): every contribution is converted EXACTLY to a 96-bit
+//     fixed-point integer  y * 2^F = a2 2^64 + a1 2^32 + a0  and its three limbs are added to three 64-bit integer
+//     accumulators (ds_add_u64; 32 bits of carry head-room each: no carry propagation while adding).  Integer addition is
+//     associative and commutative, so the result is bit-identical whatever the order -- lanes, waves, ticket scheduling,
+//     workgroups, accumulator flushes, pool shards on other GPUs (the limbs are all-reduced as integers) -- and the one
+//     conversion back to fp64 happens in a fixed order (det_fold_kernel).  F is chosen per problem from the largest reserve.
+// ------------------------------------------------------------------------------------------
+template <bool DET> struct Scatter;
+template <> struct Scatter<false> {
+    double *t; int n; double sc;
+    __device__ __forceinline__ void add(int tok, double y) const { unsafeAtomicAdd(&t[tok], y); }
+};
+template <> struct Scatter<true> {
+    double *t; int n; double sc;                       // t: [3][n] unsigned 64-bit limbs, limb-major
+    __device__ __forceinline__ void add(int tok, double y) const
+    {
+        unsigned long long *L = reinterpret_cast<unsigned long long *>(t);
+        const double yf = y * sc;                                  // exact (power of two)
+        const double a2 = floor(yf * 0x1p-64);
+        const double r = fma(-a2, 0x1p64, yf);                     // exact, in [0, 2^64)
+        const double a1 = floor(r * 0x1p-32);
+        const double a0 = floor(fma(-a1, 0x1p32, r));              // in [0, 2^32); the fraction below 2^-F is dropped
+        atomicAdd(&L[tok], (unsigned long long)(unsigned)__double2uint_rz(a0));
+        atomicAdd(&L[n + tok], (unsigned long long)(unsigned)__double2uint_rz(a1));
+        atomicAdd(&L[2 * n + tok], (unsigned long long)(long long)__double2int_rz(a2));
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // one wave-tile of a two-asset bucket: lane l solves pools i0 + l + 64 u, u < U.  All 5U column
 // loads are issued before the first use (each 512 B coalesced per wave).
 // 32 B (CP2, SUM2) or 40 B (W2, CURVE2) of HBM per pool, read once.
 // ------------------------------------------------------------------------------------------
-template <int KIND, bool WITH_D>
+template <int KIND, bool WITH_D, bool DET>
 __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, const double *nu_s,
-                                      double *psi_s, double *diag_s, double &fsum)
+                                      const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double &fsum)
 {
     constexpr int U = wave_tile_pools(KIND) / 64;
     asm volatile("" : "+v"(lane));              // (opaque: keeps per-kind lane arithmetic from being hoisted out of the tile loop)
@@ -171,21 +209,21 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
         const double pa = nu_s[ia[u]], pb = nu_s[ib[u]];
         Y2 y;
         if (KIND == 0) y = pool_cp2(Ra[u], Rb[u], g[u], pa, pb);
-        else if (KIND == 1) y = pool_w2(Ra[u], Rb[u], g[u], prm[u], pa, pb);
+        else if (KIND == 1) y = pool_w2<DET>(Ra[u], Rb[u], g[u], prm[u], pa, pb);
         else if (KIND == 2) { y = pool_sum2(Ra[u], Rb[u], g[u], pa, pb); if (fl[u]) { y.ya = 0.0; y.yb = 0.0; } }
         else y = pool_curve2(Ra[u], Rb[u], g[u], prm[u], pa, pb);
         if (live[u] && (y.ya != 0.0 || y.yb != 0.0)) {
-            unsafeAtomicAdd(&psi_s[ia[u]], y.ya);
-            unsafeAtomicAdd(&psi_s[ib[u]], y.yb);
-            fsum += pa * y.ya + pb * y.yb;
+            psi_s.add(ia[u], y.ya);
+            psi_s.add(ib[u], y.yb);
+            if (!DET) fsum += pa * y.ya + pb * y.yb;
         }
         if (WITH_D && live[u] && KIND != 2) {
             double da = 0.0, db = 0.0;
             if (KIND == 0) { da = 0.5 * pa * Ra[u]; db = 0.5 * pb * Rb[u]; }
             else if (KIND == 1) { da = (1.0 - prm[u]) * pa * Ra[u]; db = prm[u] * pb * Rb[u]; }
             else curve_diag(Ra[u], Rb[u], prm[u], pa, pb, da, db);
-            unsafeAtomicAdd(&diag_s[ia[u]], da);
-            unsafeAtomicAdd(&diag_s[ib[u]], db);
+            diag_s.add(ia[u], da);
+            diag_s.add(ib[u], db);
         }
     }
 }
@@ -208,9 +246,9 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
 template <int K>
 __host__ __device__ constexpr int pools_per_wave() { return 64 / K; }
 
-template <int K, bool WITH_D>
+template <int K, bool WITH_D, bool DET>
 __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, const double *nu_s,
-                                      double *psi_s, double *diag_s, double2 *xs, double &fsum)
+                                      const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double2 *xs, double &fsum)
 {
     constexpr int P = pools_per_wave<K>();
     // (opaque copy: otherwise the lane / K, lane % K and strip addresses of all six instantiations are hoisted out of
@@ -256,13 +294,13 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
     double y = 0.0;
     if (den > 0.0 && (wd || dp)) {
         const double t = num * rcp_nr(den);
-        const double rx = -R * expm1_wave(wd ? t - t1 : t - t2);    // R - x,  x = R e^{f(t - a_j)}
+        const double rx = -R * expm1_wave<DET>(wd ? t - t1 : t - t2);    // R - x,  x = R e^{f(t - a_j)}
         y = wd ? rx : rx * rcp_nr(fee);
     }
     SCHED_FENCE();
     if (live) {
-        if (y != 0.0) { unsafeAtomicAdd(&psi_s[tok], y); fsum += p * y; }
-        if (WITH_D) unsafeAtomicAdd(&diag_s[tok], (1.0 - w) * p * R);
+        if (y != 0.0) { psi_s.add(tok, y); if (!DET) fsum += p * y; }
+        if (WITH_D) diag_s.add(tok, (1.0 - w) * p * R);
     }
 }
 
@@ -281,11 +319,12 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
 // ~20 more VGPRs than anything else: kept out of the main instantiation, it lets that one run at 6 waves per SIMD)
 // the tile loop and the flush, shared by eval_kernel (below) and iter_kernel (iterate.hpp).  On entry nu_s holds the
 // prices, psi_s (diag_s) are zero, *next_tile is 0 and a barrier has been passed; `acc` is the accumulator set to flush into.
-template <bool WITH_D, bool STABLE>
-__device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *acc, const double *nu_s, double *psi_s, double *diag_s,
+template <bool WITH_D, bool STABLE, bool DET = false>
+__device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *acc, const double *nu_s, double *psi_t, double *diag_t,
                                                      double *fpart, int *next_tile, double2 *xs)
 {
     const int n = a.n;
+    const Scatter<DET> psi_s{psi_t, n, a.det_scale}, diag_s{diag_t, n, a.det_scale_d};
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double fsum = 0.0;
@@ -314,16 +353,16 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
         t_out += tc0 - t_prev;
 #endif
         switch (bk) {
-        case 0: if constexpr (!STABLE) { tilen<8, WITH_D>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
-        case 1: if constexpr (!STABLE) { tilen<7, WITH_D>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
-        case 2: if constexpr (!STABLE) { tilen<6, WITH_D>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
-        case 3: if constexpr (!STABLE) { tilen<5, WITH_D>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
-        case 4: if constexpr (!STABLE) { tilen<4, WITH_D>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
-        case 5: if constexpr (!STABLE) { tilen<3, WITH_D>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
-        case 6: if constexpr (STABLE) { tile2<3, WITH_D>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum); } break;
-        case 7: if constexpr (!STABLE) { tile2<1, WITH_D>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum); } break;
-        case 8: if constexpr (!STABLE) { tile2<0, WITH_D>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum); } break;
-        default: if constexpr (!STABLE) { tile2<2, WITH_D>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum); } break;
+        case 0: if constexpr (!STABLE) { tilen<8, WITH_D, DET>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
+        case 1: if constexpr (!STABLE) { tilen<7, WITH_D, DET>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
+        case 2: if constexpr (!STABLE) { tilen<6, WITH_D, DET>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
+        case 3: if constexpr (!STABLE) { tilen<5, WITH_D, DET>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
+        case 4: if constexpr (!STABLE) { tilen<4, WITH_D, DET>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
+        case 5: if constexpr (!STABLE) { tilen<3, WITH_D, DET>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
+        case 6: if constexpr (STABLE) { tile2<3, WITH_D, DET>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum); } break;
+        case 7: if constexpr (!STABLE) { tile2<1, WITH_D, DET>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum); } break;
+        case 8: if constexpr (!STABLE) { tile2<0, WITH_D, DET>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum); } break;
+        default: if constexpr (!STABLE) { tile2<2, WITH_D, DET>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum); } break;
         }
 #ifdef CFMM_PHASE_TIMERS
         if (a.ts && lane == 0) {                       // per-wave tile log: ts[64 + 8 gw + i] = bucket << 48 | cycles
@@ -346,12 +385,23 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
     __syncthreads();
     PHASE_STAMP(a.ts, 3);
 
+    if constexpr (DET) {
+        // integer limbs: ONE global accumulator (no slices: the order of these atomics cannot change the sum)
+        const unsigned long long *pl = reinterpret_cast<const unsigned long long *>(psi_t), *dl = reinterpret_cast<const unsigned long long *>(diag_t);
+        for (int j = threadIdx.x; j < 3 * n; j += blockDim.x) {
+            const unsigned long long v = pl[j];
+            if (v) atomicAdd(&a.acc_l[j], v);
+            if (WITH_D) { const unsigned long long dv = dl[j]; if (dv) atomicAdd(&a.acc_l[3 * n + j], dv); }
+        }
+        PHASE_STAMP(a.ts, 4);
+        return;
+    }
     double *base = acc + (size_t)(blockIdx.x % a.nslices) * acc_stride(n);
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
-        const double v = psi_s[j];
+        const double v = psi_t[j];
         if (v != 0.0) unsafeAtomicAdd(&base[j], v);
         if (WITH_D) {
-            const double dv = diag_s[j];
+            const double dv = diag_t[j];
             if (dv != 0.0) unsafeAtomicAdd(&base[acc_diag(n) + j], dv);
         }
     }
@@ -363,7 +413,7 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
     PHASE_STAMP(a.ts, 4);
 }
 
-template <bool WITH_D, bool STABLE>
+template <bool WITH_D, bool STABLE, bool DET = false>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 eval_kernel(EvalArgs a)
 {
@@ -372,22 +422,20 @@ eval_kernel(EvalArgs a)
 #ifdef CFMM_PHASE_TIMERS
     if (a.ts && threadIdx.x == 0 && blockIdx.x < 1024) a.ts[64 + 8 * 4096 + 2 * blockIdx.x] = wall_clock64();    // block start
 #endif
-    const int n = a.n;
-    double *psi_s = lds, *diag_s = lds + n;
-    double *nu_s = lds + (WITH_D ? 2 : 1) * n;          // [n + 1]
+    const int n = a.n, tile = eval_tile_doubles(n, DET);
+    double *psi_s = lds, *diag_s = lds + tile;
+    double *nu_s = lds + (WITH_D ? 2 : 1) * tile;       // [n + 1]
     double *fpart = nu_s + n + 2;                       // [16]
     int *next_tile = reinterpret_cast<int *>(fpart + 16);   // the workgroup's tile ticket counter
     if (threadIdx.x == 0) *next_tile = 0;
-    double2 *xs = reinterpret_cast<double2 *>(lds + eval_lds_doubles(n, WITH_D)) + 64 * (threadIdx.x >> 6);   // wave-private [64]
+    double2 *xs = reinterpret_cast<double2 *>(lds + eval_lds_doubles(n, WITH_D, DET)) + 64 * (threadIdx.x >> 6);   // wave-private [64]
     // prices and the stop flag arrive in ONE round trip (the flag rides behind the prices)
-    for (int j = threadIdx.x; j <= n; j += blockDim.x) {
-        nu_s[j] = a.nu[j];
-        if (j < n) { psi_s[j] = 0.0; if (WITH_D) diag_s[j] = 0.0; }
-    }
+    for (int j = threadIdx.x; j <= n; j += blockDim.x) nu_s[j] = a.nu[j];
+    for (int j = threadIdx.x; j < (WITH_D ? 2 : 1) * tile; j += blockDim.x) lds[j] = 0.0;      // (+0.0 is the all-zero bit pattern: limbs too)
     __syncthreads();
     if (nu_s[n] != 0.0) return;
     PHASE_STAMP(a.ts, 1);
-    eval_tiles_and_flush<WITH_D, STABLE>(a, a.acc, nu_s, psi_s, diag_s, fpart, next_tile, xs);
+    eval_tiles_and_flush<WITH_D, STABLE, DET>(a, a.acc, nu_s, psi_s, diag_s, fpart, next_tile, xs);
 #ifdef CFMM_PHASE_TIMERS
     __syncthreads();
     if (a.ts && threadIdx.x == 0 && blockIdx.x < 1024) a.ts[64 + 8 * 4096 + 2 * blockIdx.x + 1] = wall_clock64();    // block end
@@ -470,6 +518,44 @@ __global__ void fold_kernel(double *__restrict__ acc, int n, int nslices, int wi
         acc[(size_t)s * acc_stride(n) + j] = 0.0;
     }
     acc[j] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// reproducible mode: the integer limbs (after the integer all-reduce when pool-sharded) -> fp64 accumulator slice 0, in
+// a FIXED order: psi_j and diag_j from their three limbs, sum_i arb_i = nu'psi by a fixed reduction tree (the pools' own
+// running sums of arb_i would depend on the tile schedule).  Clears the limbs for the next evaluation.  One workgroup.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double limbs_to_double(unsigned long long l0, unsigned long long l1, unsigned long long l2, double inv_scale)
+{
+    // value = l2 2^64 + l1 2^32 + l0 with every limb a wrapped SIGNED 64-bit sum: exact in 128-bit integer arithmetic
+    const __int128 t = ((__int128)(long long)l2 << 64) + ((__int128)(long long)l1 << 32) + (__int128)(long long)l0;
+    const long long hi = (long long)(t >> 64);
+    const unsigned long long lo = (unsigned long long)t;
+    return ((double)hi * 0x1p64 + (double)lo) * inv_scale;     // two roundings, always the same two
+}
+__global__ void __launch_bounds__(1024)
+det_fold_kernel(unsigned long long *__restrict__ L, const double *__restrict__ nu, double *__restrict__ out, int n, double inv_scale,
+                double inv_scale_d, int with_d)
+{
+    __shared__ double part[1024];
+    double f = 0.0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const double psi = limbs_to_double(L[j], L[n + j], L[2 * n + j], inv_scale);
+        L[j] = 0; L[n + j] = 0; L[2 * n + j] = 0;
+        out[j] = psi;
+        f = fma(nu[j], psi, f);
+        if (with_d) {
+            out[acc_diag(n) + j] = limbs_to_double(L[3 * n + j], L[4 * n + j], L[5 * n + j], inv_scale_d);
+            L[3 * n + j] = 0; L[4 * n + j] = 0; L[5 * n + j] = 0;
+        }
+    }
+    part[threadIdx.x] = f;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {                 // fixed tree
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[acc_arb(n)] = part[0];
 }
 
 // ------------------------------------------------------------------------------------------

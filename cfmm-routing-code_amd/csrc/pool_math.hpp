@@ -38,9 +38,12 @@ __device__ __forceinline__ double rsqrt_nr(double x)
 // log1p and expm1 for the small arguments that dominate here (a pool a few per cent off the market):
 // short series, taken only when EVERY active lane of the wave is in range (wave-uniform branch, no
 // divergence); otherwise the library routines.  Relative error < 2e-16 inside the ranges below.
+// PURE = true (reproducible mode): the choice is made per lane, so that a pool's result is a function of the pool alone and
+// not of which other pools share its wave (a different sharding of the pools must reproduce every contribution bit for bit)
+template <bool PURE = false>
 __device__ __forceinline__ double log1p_wave(double d)        // log(1 + d)
 {
-    if (__all(fabs(d) < 0.125)) {
+    if (PURE ? (fabs(d) < 0.125) : (bool)__all(fabs(d) < 0.125)) {
         const double s = d * rcp_nr(2.0 + d), z = s * s;           // log(1+d) = 2 atanh(d / (2 + d))
         double p = 1.0 / 13.0;
         p = fma(p, z, 1.0 / 11.0); p = fma(p, z, 1.0 / 9.0); p = fma(p, z, 1.0 / 7.0);
@@ -49,9 +52,10 @@ __device__ __forceinline__ double log1p_wave(double d)        // log(1 + d)
     }
     return log1p(d);
 }
+template <bool PURE = false>
 __device__ __forceinline__ double expm1_wave(double x)
 {
-    if (__all(fabs(x) < 0.0625)) {                                   // Taylor to x^11 / 11!
+    if (PURE ? (fabs(x) < 0.0625) : (bool)__all(fabs(x) < 0.0625)) {  // Taylor to x^11 / 11!
         double p = 1.0 / 39916800.0;
         p = fma(p, x, 1.0 / 3628800.0); p = fma(p, x, 1.0 / 362880.0); p = fma(p, x, 1.0 / 40320.0);
         p = fma(p, x, 1.0 / 5040.0); p = fma(p, x, 1.0 / 720.0); p = fma(p, x, 1.0 / 120.0);
@@ -89,6 +93,7 @@ __device__ __forceinline__ Y2 pool_cp2(double Ra, double Rb, double g, double pa
 //     rho = gamma v_out / v_in > 1,   and with L = log rho:
 //     x / R_in = rho^{w_out}:  y_in = -R_in expm1(w_out L) / gamma,   y_out = -R_out expm1(-w_in L).
 // One log and two expm1, all on the well-conditioned quantity L (no x - R_in cancellation).
+template <bool PURE = false>
 __device__ __forceinline__ Y2 pool_w2(double Ra, double Rb, double g, double wa, double pa, double pb)
 {
     const double wb = 1.0 - wa;
@@ -101,11 +106,11 @@ __device__ __forceinline__ Y2 pool_w2(double Ra, double Rb, double g, double wa,
         const double Rin = ab ? Ra : Rb, Rout = ab ? Rb : Ra;
         const double win = ab ? wa : wb, wout = ab ? wb : wa;
         // (scheduling fences: interleaving the three library routines costs ~30 VGPRs and the kernel sits on a register cliff)
-        const double L = log1p_wave(fma(g, vout, -vin) * rcp_nr(vin));      // log rho; rho - 1 formed without cancellation
+        const double L = log1p_wave<PURE>(fma(g, vout, -vin) * rcp_nr(vin));      // log rho; rho - 1 formed without cancellation
         SCHED_FENCE();
-        const double yin = -Rin * expm1_wave(wout * L) * rcp_nr(g);
+        const double yin = -Rin * expm1_wave<PURE>(wout * L) * rcp_nr(g);
         SCHED_FENCE();
-        const double yout = -Rout * expm1_wave(-win * L);
+        const double yout = -Rout * expm1_wave<PURE>(-win * L);
         SCHED_FENCE();
         y.ya = ab ? yin : yout;
         y.yb = ab ? yout : yin;

@@ -144,6 +144,20 @@ int cfmm_eval_smooth(cfmm_ctx *ctx, const double *nu, double mu, double *value, 
  * column-major, lower triangle read; n must equal the context's token count); *info != 0 flags a non-positive pivot */
 int cfmm_debug_cholesky(cfmm_ctx *ctx, int n, const double *A, const double *b, double *x, int32_t *info);
 
+/* Reproducible mode.  By default psi is scatter-added with fp64 atomics, whose order -- lanes, waves, workgroups -- varies
+ * from run to run: psi, and with it the path of a solve, is reproducible to rounding only.  With `on` != 0 every pool's
+ * contribution is converted exactly to a 96-bit fixed-point integer and accumulated with integer atomics (associative:
+ * any order gives the same bits), all-reduced as integers when pool-sharded, and converted back in a fixed order:
+ * psi, the iterates and the evaluation count are then BITWISE identical from run to run and for any number of pool
+ * shards / GPUs.  Costs about 2x in the evaluation kernel (three LDS atomics per leg instead of one) plus one small launch
+ * per evaluation.  First-order path and cfmm_eval_dual; needs <= ~2600 tokens; fees >= 1e-3.  Also: CFMM_DETERMINISTIC=1. */
+int cfmm_set_deterministic(cfmm_ctx *ctx, int on);
+/* test hook of the reproducible mode: one dual evaluation returning the RAW integer limbs of psi ([3][n], limb-major, value =
+ * (limb2 2^64 + limb1 2^32 + limb0) / 2^F, every limb a wrapped signed 64-bit sum) with the fixed-point exponent F derived from
+ * (ref_reserve, ref_fee) instead of this context's own largest reserve / smallest fee -- so that the limbs of the S shards
+ * of a network, added as integers on the host, can be compared bit for bit with the unsharded network's. */
+int cfmm_debug_eval_limbs(cfmm_ctx *ctx, const double *nu, double ref_reserve, double ref_fee, uint64_t *limbs);
+
 /* prob.solve(): nu0 = start prices.  NULL: continue from cfmm_set_nu / the previous solution -- after a second-order
  * solve that includes (a multiple of) its final barrier weight: the warm start of a parametric sweep (two-asset.py:34-100) */
 int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts, cfmm_stats *out);

@@ -408,27 +408,31 @@ dist.destroy_process_group()
     assert out["df"] <= 1e-12 and out["dpsi"] <= 1e-10
 
 
-def test_clones_share_pools_and_solve_many_matches_sequential():
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_clones_share_pools_and_solve_many_matches_sequential(deterministic):
     """cfmm_clone: several solves in flight over ONE resident pool set give the same answers as one after
-    the other; re-uploading pools while clones exist is refused"""
+    the other; re-uploading pools while clones exist is refused.  In reproducible mode "the same" is bitwise."""
     net = synthetic.config("C3", scale=0.1, seed=3)
     n = net["n_tokens"]
     rng = np.random.default_rng(11)
     utils = [cfmm.Arbitrage(net["c"] * np.exp(rng.normal(0, 0.01, n))) for _ in range(6)]
     h = np.zeros(n); idx = rng.choice(n, 5, replace=False); h[idx] = 50.0 / net["prices"][idx]
     utils.append(cfmm.Swap(h, int(rng.integers(0, n))))
-    p = cfmm.Problem.from_network(net, utility=utils[0])
+    p = cfmm.Problem.from_network(net, utility=utils[0], deterministic=deterministic)
     seq = []
     for u in utils:
         p.set_utility(u); p.solve(tol=1e-7)
-        seq.append((p.value, p.status, p.psi.copy()))
+        seq.append((p.value, p.status, p.psi.copy(), p.stats["evals"]))
     for conc in (1, 3):
         res = p.solve_many(utils, concurrency=conc, tol=1e-7)
-        for (v, st, psi), r in zip(seq, res):
+        for (v, st, psi, ev), r in zip(seq, res):
             assert r["status"] == st == "optimal"
-            # (fp64 atomics are order-nondeterministic: two runs agree to the solver tolerance, not bitwise)
-            assert abs(r["value"] - v) <= 5e-7 * abs(v)
-            assert np.abs(r["psi"] - psi).max() <= 1e-4 * np.abs(psi).max()
+            if deterministic:
+                assert r["value"] == v and r["stats"]["evals"] == ev and np.array_equal(r["psi"], psi)
+            else:
+                # (fp64 atomics are order-nondeterministic: two runs agree to the solver tolerance, not bitwise)
+                assert abs(r["value"] - v) <= 5e-7 * abs(v)
+                assert np.abs(r["psi"] - psi).max() <= 1e-4 * np.abs(psi).max()
     q = p.clone()
     with pytest.raises(cfmm.CfmmError, match="shared with a clone"):
         p.ctx.upload_pools2(_lib.POOL_CP2, [1.0], [1.0], [0.99], [0], [1])
@@ -450,3 +454,69 @@ def test_every_update_kernel_instantiation_agrees_with_the_oracle(oracle_lib, n_
     assert abs(v - r["primal_value"]) <= 2e-7 * abs(v)
     assert abs(p.stats["evals"] - r["evals"]) <= max(6, r["evals"] // 3)     # same algorithm, fp-noise apart
     p.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reproducible mode (cfmm_set_deterministic): psi accumulated as exact fixed-point integers
+# ---------------------------------------------------------------------------------------------------------------
+def _limbs_value(limbs, scale):
+    """(limb2 2^64 + limb1 2^32 + limb0) / scale, exactly (Python integers), as the nearest double"""
+    l = limbs.astype(np.uint64).view(np.int64)
+    return np.array([(int(l[2, j]) * 2 ** 64 + int(l[1, j]) * 2 ** 32 + int(l[0, j])) / scale for j in range(l.shape[1])])
+
+
+@pytest.mark.parametrize("zipf", [None, 1.1])
+def test_reproducible_mode_is_bitwise_run_to_run_and_shard_invariant(oracle_lib, zipf):
+    """integer accumulation: psi does not depend on the order in which lanes, waves, workgroups or pool shards arrive --
+    10 evaluations and 5 solves give identical bits; the limbs of S = 2, 3, 8 pool shards, added as integers, are the
+    unsharded network's limbs bit for bit (what the integer RCCL all-reduce computes); and the values agree with the oracle"""
+    net = synthetic.make_network(600, m_cp2=150_000, m_w2=40_000, m_gn=20_000, seed=21, zipf_s=zipf)
+    n = net["n_tokens"]
+    nu = net["c"] * np.exp(np.random.default_rng(5).normal(0, 0.03, n))
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]), deterministic=True)
+    f0, psi0, d0 = p.eval_dual(nu, want_diag=True)
+    for _ in range(9):
+        f, psi, d = p.eval_dual(nu, want_diag=True)
+        assert f == f0 and np.array_equal(psi, psi0) and np.array_equal(d, d0)
+    o = _oracle_for(oracle_lib, net)
+    fo, psio, do = o.eval(nu, want_diag=True)
+    assert abs(f0 - fo) <= 1e-11 * abs(fo) and np.abs(psi0 - psio).max() <= 1e-10 * np.abs(psio).max()
+    assert np.abs(d0 - do).max() <= 1e-11 * np.abs(do).max()
+    # solves: identical iterates, identical evaluation counts
+    runs = []
+    for _ in range(5):
+        v = p.solve(tol=1e-7)
+        runs.append((v, p.stats["evals"], p.nu.copy(), p.psi.copy()))
+        assert p.status == "optimal"
+    for v, ev, nu_, psi_ in runs[1:]:
+        assert v == runs[0][0] and ev == runs[0][1] and np.array_equal(nu_, runs[0][2]) and np.array_equal(psi_, runs[0][3])
+    r = o.solve(net["c"], tol=1e-7)
+    assert abs(runs[0][0] - r["primal_value"]) <= 2e-7 * abs(r["primal_value"])
+    # shard invariance of the integer representation
+    mr = max(b[k].max() for b in (net["cp2"], net["w2"]) for k in ("Ra", "Rb"))
+    mr = max(mr, max(b["R"].max() for b in net["gn"].values()))
+    mf = min(min(net[k]["fee"].min() for k in ("cp2", "w2")), min(b["fee"].min() for b in net["gn"].values()))
+    whole = p._ensure_ctx().debug_eval_limbs(nu, mr, mf)
+    import math
+    scale = 2.0 ** (84 - math.frexp(mr / mf)[1])
+    assert np.array_equal(_limbs_value(whole, scale), psi0)              # the device's conversion == exact integer arithmetic, rounded once
+    p.close()
+    for S in (2, 3, 8):
+        tot = np.zeros_like(whole)
+        for rk in range(S):
+            q = cfmm.Problem.from_network(cfmm.distributed.rank_network(net, rk, S), utility=cfmm.Arbitrage(net["c"]))
+            tot = tot + q._ensure_ctx().debug_eval_limbs(nu, mr, mf)      # uint64 addition wraps: exactly the integer all-reduce
+            q.close()
+        assert np.array_equal(tot, whole), S
+
+
+def test_default_mode_is_reproducible_to_rounding_only():
+    """(the fp64-atomic default, for contrast: repeated evaluations differ in their last bits -- if this ever stops
+    being true the reproducible mode has lost its reason to exist)"""
+    net = synthetic.config("C3", scale=0.2, seed=2)
+    nu = net["c"] * np.exp(np.random.default_rng(5).normal(0, 0.03, net["n_tokens"]))
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    outs = [p.eval_dual(nu)[1] for _ in range(6)]
+    p.close()
+    gross = np.abs(outs[0]).max()
+    assert all(np.abs(x - outs[0]).max() <= 1e-11 * gross for x in outs)
