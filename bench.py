@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--cpu-solves", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--kernel-reps", type=int, default=50)
+    ap.add_argument("--allreduce", default=os.environ.get("CFMM_ALLREDUCE", "rccl"), choices=["rccl", "oneshot"],
+                    help="the per-evaluation all-reduce: RCCL (default) or the one-shot xGMI exchange (csrc/oneshot.hpp)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the pool-sharded code path (process group, RCCL communicator, all-reduce per evaluation) even with one rank")
     args = ap.parse_args()
@@ -165,11 +167,11 @@ def main():
         # strong scaling: ONE fixed network (same seed on every rank), contiguous pool shards
         net = synthetic.config("C4", seed=0, scale=args.scale)
         total_pools = cfmm.problem.network_pool_count(net)
-        prob = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=local_rank, shard=True)
+        prob = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=local_rank, shard=True, allreduce=args.allreduce)
     else:
         # weak scaling: every rank generates its OWN 1e6-pool shard (same tokens / prices / utility)
         net = synthetic.config("C3", seed=0, scale=args.scale, pool_seed=(rank if world > 1 else None))
-        prob = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=local_rank, shard=False)
+        prob = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=local_rank, shard=False, allreduce=args.allreduce)
         total_pools = prob.m * world
     prob._ensure_ctx()
 
@@ -232,7 +234,7 @@ def main():
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "pools_per_gpu": prob.m, "pools_total": total_pools, "tokens": net["n_tokens"], "seed": 0,
                        "parallelism": f"pool-sharding x{world}" if world > 1 else "single GPU",
-                       "rccl_ranks": prob.stats.get("n_ranks", 1)},
+                       "rccl_ranks": prob.stats.get("n_ranks", 1), "allreduce": args.allreduce if sharded else None},
             "evals_per_solve": evals / args.steps,
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "us_per_eval": 1e6 * dt / max(evals, 1),

@@ -44,7 +44,7 @@ class Stats(C.Structure):
 
 def build(force=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("cfmm_hip.hip", "kernels.hpp", "iterate.hpp", "pool_math.hpp", "smooth.hpp", "chol.hpp")]
+    srcs = [os.path.join(_CSRC, f) for f in ("cfmm_hip.hip", "kernels.hpp", "iterate.hpp", "oneshot.hpp", "pool_math.hpp", "smooth.hpp", "chol.hpp")]
     srcs.append(os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "cfmm.h"))
     if force or not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _CSRC, "-s"])
@@ -57,6 +57,7 @@ SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm
            "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_set_pool_flags", "cfmm_set_utility",
            "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_solve", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_comm_unique_id", "cfmm_comm_init",
+           "cfmm_oneshot_export", "cfmm_oneshot_import", "cfmm_oneshot_attach", "cfmm_oneshot_mailbox",
            "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
 
 
@@ -93,6 +94,10 @@ def lib():
     L.cfmm_get_tradesN.argtypes = [vp, C.c_int, dp, dp]
     L.cfmm_comm_unique_id.argtypes = [C.c_void_p]
     L.cfmm_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
+    L.cfmm_oneshot_export.argtypes = [vp, C.c_void_p]
+    L.cfmm_oneshot_import.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
+    L.cfmm_oneshot_attach.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.cfmm_oneshot_mailbox.restype = vp; L.cfmm_oneshot_mailbox.argtypes = [vp]
     L.cfmm_time_eval_kernel.argtypes = [vp, C.c_int, C.c_int, dp]
     L.cfmm_time_collective.argtypes = [vp, C.c_int, dp, dp]
     L.cfmm_selftest.argtypes = [vp]
@@ -268,6 +273,24 @@ class Context:
     def comm_init(self, n_ranks, rank, uid):
         buf = C.create_string_buffer(bytes(uid), 128)
         self._chk(self.L.cfmm_comm_init(self.h, n_ranks, rank, buf))
+
+    def oneshot_export(self):
+        """this rank's mailbox of the one-shot xGMI all-reduce as a 64-byte IPC handle (csrc/oneshot.hpp)"""
+        buf = C.create_string_buffer(64)
+        self._chk(self.L.cfmm_oneshot_export(self.h, buf))
+        return bytes(buf.raw)
+
+    def oneshot_import(self, n_ranks, rank, handles):
+        buf = C.create_string_buffer(b"".join(bytes(h) for h in handles), 64 * n_ranks)
+        self._chk(self.L.cfmm_oneshot_import(self.h, n_ranks, rank, buf))
+
+    def oneshot_mailbox(self):
+        return self.L.cfmm_oneshot_mailbox(self.h)
+
+    def oneshot_attach(self, n_ranks, rank, mailboxes):
+        """same-process ranks (tests): raw device pointers of every rank's mailbox"""
+        arr = (C.c_void_p * n_ranks)(*[C.c_void_p(m) for m in mailboxes])
+        self._chk(self.L.cfmm_oneshot_attach(self.h, n_ranks, rank, arr))
 
     def time_eval_kernel(self, kind, reps=20):
         s = C.c_double()

@@ -33,7 +33,18 @@ def broadcast_unique_id(dist, make_id, src=0):
     return uid
 
 
-def sharded_problem(net, utility, dist=None, device=None, shard=True, context=None):
+def attach_oneshot(prob, dist):
+    """switch this rank's collectives to the one-shot xGMI exchange (csrc/oneshot.hpp): every rank exports its mailbox as
+    an IPC handle, the handles travel over torch.distributed, every rank maps its peers' mailboxes.  RCCL stays
+    initialised underneath (it carries what does not fit a mailbox, e.g. the second-order method's Hessian)."""
+    ctx = prob._ensure_ctx()
+    mine = ctx.oneshot_export()
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, mine)
+    ctx.oneshot_import(dist.get_world_size(), dist.get_rank(), box)
+
+
+def sharded_problem(net, utility, dist=None, device=None, shard=True, context=None, allreduce=None):
     """Problem over this rank's shard, with the library's RCCL communicator initialised.
 
     net: the FULL network (shard=True: it is sliced here) or this rank's own pools (shard=False,
@@ -41,7 +52,8 @@ def sharded_problem(net, utility, dist=None, device=None, shard=True, context=No
     Host-side decisions of the solve (start prices, method, constant-sum ties) are then taken on global
     quantities through problem.HostComm, so that every rank issues the same device collectives.
     `context`: a ready device context to use instead of creating one on `device` (the CPU tests pass a stand-in
-    whose collective is gloo; the product never does)."""
+    whose collective is gloo; the product never does).  `allreduce`: "rccl" (default) or "oneshot" (also selected by
+    CFMM_ALLREDUCE=oneshot): the per-evaluation all-reduce as ONE xGMI hop through peer-mapped mailboxes."""
     rank, local_rank, world = env_world()
     if dist is not None:
         rank, world = dist.get_rank(), dist.get_world_size()
@@ -55,4 +67,9 @@ def sharded_problem(net, utility, dist=None, device=None, shard=True, context=No
         if context is None:
             from . import _lib
             prob.init_comm(world, rank, broadcast_unique_id(dist, _lib.comm_unique_id))
+            how = (allreduce or os.environ.get("CFMM_ALLREDUCE", "rccl")).lower()
+            if how not in ("rccl", "oneshot"):
+                raise ValueError(f"allreduce={how!r}: expected 'rccl' or 'oneshot'")
+            if how == "oneshot":
+                attach_oneshot(prob, dist)
     return prob

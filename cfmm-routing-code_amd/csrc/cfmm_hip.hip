@@ -24,6 +24,7 @@
 #include "../../include/cfmm.h"
 #include "kernels.hpp"
 #include "iterate.hpp"
+#include "oneshot.hpp"
 #include "smooth.hpp"
 #include "chol.hpp"
 
@@ -155,6 +156,14 @@ struct cfmm_ctx {
     int n_ranks = 1, rank = 0;
     int64_t g_total = 0, g_stable = 0;     // pool counts over ALL ranks (refresh_global_counts)
 
+    // one-shot xGMI all-reduce (oneshot.hpp): this rank's mailbox and the peers' (IPC-mapped, or same-process pointers in tests)
+    unsigned long long *os_mail = nullptr;
+    size_t os_cap = 0;
+    unsigned long long *os_peers[ONESHOT_MAX_RANKS] = {};
+    std::vector<void *> os_opened;     // hipIpcOpenMemHandle mappings to close
+    bool os_ready = false;             // attached: the collectives below go through it
+    unsigned long long os_epoch = 0;
+
     // second-order method (allocated on first use)
     double *sm_out = nullptr, *sm_vec = nullptr, *H = nullptr, *Dinv = nullptr;
     double *sm_ws[CFMM_POOL_KINDS2] = {};   // warm starts of the smoothed per-direction solves
@@ -197,6 +206,28 @@ int fail(cfmm_ctx *ctx, int code, const char *fmt, ...)
         hipError_t e_ = (call);                                                                   \
         if (e_ != hipSuccess) return fail(ctx, CFMM_E_HIP, "%s -> %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// pool-sharded: a communicator (RCCL) and / or an attached one-shot exchange
+inline bool sharded(const cfmm_ctx *ctx) { return ctx->comm != nullptr || ctx->os_ready; }
+
+// the collective of the pool-sharded iteration, enqueued on ctx->stream: the one-shot exchange when it is attached and the
+// message fits its mailbox (sum of doubles / of 64-bit integers, max of doubles), RCCL otherwise
+int all_reduce(cfmm_ctx *ctx, void *buf, size_t count, int dtype, int op)
+{
+    if (ctx->os_ready && count <= ctx->os_cap) {
+        OneShotArgs a = {};
+        for (int r = 0; r < ctx->n_ranks; ++r) a.mail[r] = ctx->os_peers[r];
+        a.buf = (unsigned long long *)buf; a.epoch = ++ctx->os_epoch;
+        a.n_ranks = ctx->n_ranks; a.rank = ctx->rank; a.count = (int)count; a.cap = ctx->os_cap;
+        a.op = dtype == NCCL_INT64 ? ONESHOT_SUM_I64 : (op == NCCL_MAX ? ONESHOT_MAX_F64 : ONESHOT_SUM_F64);
+        hipLaunchKernelGGL(oneshot_allreduce_kernel, dim3(1), dim3(ONESHOT_THREADS), 0, ctx->stream, a);
+        return CFMM_OK;
+    }
+    if (!ctx->comm) return fail(ctx, CFMM_E_UNSUPPORTED, "all-reduce of %zu elements: beyond the one-shot mailbox and no RCCL communicator", count);
+    const int rc = g_rccl.AllReduce(buf, buf, count, dtype, op, ctx->comm, ctx->stream);
+    if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    return CFMM_OK;
+}
 
 template <class T>
 int dev_upload(cfmm_ctx *ctx, T **dst, const T *src, size_t count, std::vector<void *> *track)
@@ -318,7 +349,7 @@ const int kOrder[N_BUCKETS] = {-8, -7, -6, -5, -4, -3, CFMM_POOL_CURVE2, CFMM_PO
 // metric's terms are (price x reserve)-sized.  Every rank derives the same exponents from the global maxima.
 void det_scales(cfmm_ctx *ctx, double &sc, double &scd)
 {
-    const double mr = std::max(ctx->det_ref_reserve > 0.0 ? ctx->det_ref_reserve : (ctx->comm ? ctx->g_max_reserve : ctx->max_reserve), 1e-300);
+    const double mr = std::max(ctx->det_ref_reserve > 0.0 ? ctx->det_ref_reserve : (sharded(ctx) ? ctx->g_max_reserve : ctx->max_reserve), 1e-300);
     const double mf = ctx->det_ref_fee > 0.0 ? ctx->det_ref_fee : ctx->min_fee;
     int e = 0;
     (void)std::frexp(mr / std::max(mf, 1e-3), &e);                  // value < 2^e
@@ -379,10 +410,7 @@ void launch_eval(cfmm_ctx *ctx, const EvalArgs &a)
 int det_finish(cfmm_ctx *ctx, double *out, const double *nu, bool with_d)
 {
     const int n = ctx->n;
-    if (ctx->comm) {
-        int rc = g_rccl.AllReduce(ctx->acc_l, ctx->acc_l, (size_t)(with_d ? 6 : 3) * n, NCCL_INT64, NCCL_SUM, ctx->comm, ctx->stream);
-        if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce (limbs) -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
-    }
+    if (sharded(ctx)) { int rc = all_reduce(ctx, ctx->acc_l, (size_t)(with_d ? 6 : 3) * n, NCCL_INT64, NCCL_SUM); if (rc) return rc; }
     double sc, scd;
     det_scales(ctx, sc, scd);
     hipLaunchKernelGGL(det_fold_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->acc_l, nu, out, n, 1.0 / sc, 1.0 / scd, with_d ? 1 : 0);
@@ -434,7 +462,7 @@ int set_all_lds_attrs(cfmm_ctx *ctx)
 UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
 {
     UpdArgs a;
-    a.n = ctx->n; a.ng = ctx->ng; a.M = o.memory; a.nslices = (ctx->comm || ctx->det) ? 1 : ctx->nslices;
+    a.n = ctx->n; a.ng = ctx->ng; a.M = o.memory; a.nslices = (sharded(ctx) || ctx->det) ? 1 : ctx->nslices;
     a.acc = ctx->acc;
     a.c = ctx->c; a.h = ctx->h; a.off = ctx->off; a.glo = ctx->glo; a.ghi = ctx->ghi;
     a.ctype = ctx->ctype; a.grp = ctx->grp;
@@ -461,7 +489,7 @@ IterArgs make_iter_args(cfmm_ctx *ctx, const cfmm_opts &o)
     IterArgs a = {};
     a.ev = make_eval_args(ctx, false);
     a.ev.nu = nullptr; a.ev.acc = nullptr;
-    a.n = ctx->n; a.M = o.memory; a.nread = (ctx->comm || ctx->det) ? 1 : ctx->nslices; a.phase = 0;
+    a.n = ctx->n; a.M = o.memory; a.nread = (sharded(ctx) || ctx->det) ? 1 : ctx->nslices; a.phase = 0;
     a.xvs = iter_xvs(ctx->n); a.max_evals = o.max_evals; a.pg_rule = o.pg_rule;
     a.plain = ctx->plain ? 1 : 0;
     a.acc3 = ctx->acc3; a.acc_set = (long long)acc_set_doubles(ctx);
@@ -508,11 +536,10 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
         launch_eval<false, true>(ctx, es);
     }
     if (ctx->det) return det_finish(ctx, acc_p, ctx->nu, false);     // (the prices workgroup 0 has just stored)
-    if (ctx->comm) {
+    if (sharded(ctx)) {
         const int len = acc_arb(n) + 1;
         hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, acc_p, n, ctx->nslices, 0, (const DevState *)nullptr);
-        int rc = g_rccl.AllReduce(acc_p, acc_p, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
-        if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+        return all_reduce(ctx, acc_p, (size_t)len, NCCL_FLOAT64, NCCL_SUM);
     }
     return CFMM_OK;
 }
@@ -545,12 +572,11 @@ int enqueue_iteration(cfmm_ctx *ctx, const UpdArgs &ua)
 {
     launch_all_evals<WITH_D>(ctx);
     if (ctx->det) { int rc = det_finish(ctx, ctx->acc, ctx->nu, WITH_D); if (rc) return rc; }
-    else if (ctx->comm) {                       // pool-sharded (a communicator of one rank runs the same path)
+    else if (sharded(ctx)) {                    // pool-sharded (a communicator of one rank runs the same path)
         const int len = WITH_D ? acc_stride(ctx->n) : acc_arb(ctx->n) + 1;
         hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, ctx->n,
                            ctx->nslices, WITH_D ? 1 : 0, (const DevState *)nullptr);
-        int rc = g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
-        if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+        int rc = all_reduce(ctx, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc;
     }
     launch_update(ctx, ua);
     return CFMM_OK;
@@ -666,12 +692,12 @@ int refresh_global_counts(cfmm_ctx *ctx)
     ctx->g_total = cfmm_pool_count(ctx);
     ctx->g_stable = ctx->pools->b2[CFMM_POOL_CURVE2].m;
     local_extrema(ctx);
-    if (!ctx->comm) return CFMM_OK;
+    if (!sharded(ctx)) return CFMM_OK;
     if (ctx->det) {                                  // the fixed-point exponent must be the same on every rank: global maxima
         double mx[2] = {ctx->max_reserve, 1.0 / ctx->min_fee};
         double *dm = ctx->psi_t + 2;
         HIP_TRY(ctx, hipMemcpyAsync(dm, mx, sizeof mx, hipMemcpyHostToDevice, ctx->stream));
-        if (g_rccl.AllReduce(dm, dm, 2, NCCL_FLOAT64, NCCL_MAX, ctx->comm, ctx->stream) != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce (maxima) failed");
+        { int rc = all_reduce(ctx, dm, 2, NCCL_FLOAT64, NCCL_MAX); if (rc) return rc; }
         HIP_TRY(ctx, hipMemcpyAsync(mx, dm, sizeof mx, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->g_max_reserve = mx[0]; ctx->min_fee = 1.0 / mx[1];
@@ -679,7 +705,7 @@ int refresh_global_counts(cfmm_ctx *ctx)
     double cnt[2] = {(double)ctx->g_total, (double)ctx->g_stable};
     double *dv = ctx->psi_t;                         // scratch (overwritten by the first update of every solve)
     HIP_TRY(ctx, hipMemcpyAsync(dv, cnt, sizeof cnt, hipMemcpyHostToDevice, ctx->stream));
-    if (g_rccl.AllReduce(dv, dv, 2, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream) != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce (pool counts) failed");
+    { int rc = all_reduce(ctx, dv, 2, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc; }
     HIP_TRY(ctx, hipMemcpyAsync(cnt, dv, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->g_total = (int64_t)cnt[0]; ctx->g_stable = (int64_t)cnt[1];
@@ -755,10 +781,10 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm, bool with_slo)
 #undef GN_LAUNCH
     }
     HIP_TRY(ctx, hipGetLastError());
-    if (ctx->comm) {                        // pool-sharded: every rank needs the whole [psi | value | trade] and the whole Hessian
-        int rc = g_rccl.AllReduce(ctx->sm_out, ctx->sm_out, (size_t)(n + 2), NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
-        if (rc == 0 && hess) rc = g_rccl.AllReduce(ctx->H, ctx->H, (size_t)hess_ld(n) * hess_nr(n), NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
-        if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed (%d)", rc);
+    if (sharded(ctx)) {                     // pool-sharded: every rank needs the whole [psi | value | trade] and the whole Hessian
+        int rc = all_reduce(ctx, ctx->sm_out, (size_t)(n + 2), NCCL_FLOAT64, NCCL_SUM);
+        if (rc == 0 && hess) rc = all_reduce(ctx, ctx->H, (size_t)hess_ld(n) * hess_nr(n), NCCL_FLOAT64, NCCL_SUM);      // (8.6 MB at 1000 tokens: RCCL)
+        if (rc != 0) return rc;
     }
     return CFMM_OK;
 }
@@ -814,12 +840,12 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         s[j] = sj; nu[j] = std::exp(sj);
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, mask.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    if (ctx->comm) {                        // the barrier terms of the pools of every rank (the utility's are replicated)
+    if (sharded(ctx)) {                     // the barrier terms of the pools of every rank (the utility's are replicated)
         long long ge = 0;
         for (int j = 0; j < n; ++j) ge += ct[j] == CFMM_GE && !(c[j] > 0.0);
         double cnt = (double)(nbar - ge);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, &cnt, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        if (g_rccl.AllReduce(ctx->sm_vec, ctx->sm_vec, 1, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream) != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed");
+        { int rc = all_reduce(ctx, ctx->sm_vec, 1, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc; }
         HIP_TRY(ctx, hipMemcpyAsync(&cnt, ctx->sm_vec, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         nbar = (long long)cnt + ge;
@@ -1136,6 +1162,8 @@ int cfmm_destroy(cfmm_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     drop_graph(ctx);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    for (void *q : ctx->os_opened) (void)hipIpcCloseMemHandle(q);
+    if (ctx->os_mail) (void)hipFree(ctx->os_mail);
     ctx->pools.reset();
     if (ctx->flags2) (void)hipFree(ctx->flags2);
     if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
@@ -1371,16 +1399,15 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
     HIP_TRY(ctx, hipMemsetAsync(ctx->nu + n, 0, sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
     { double mx = 0.0; for (int j = 0; j < n; ++j) mx = std::max(mx, nu[j]); ctx->nu_max = mx; }
-    if (ctx->det && ctx->comm) { int rc = refresh_global_counts(ctx); if (rc) return rc; }      // (the fixed-point exponent is a global quantity)
+    if (ctx->det && sharded(ctx)) { int rc = refresh_global_counts(ctx); if (rc) return rc; }      // (the fixed-point exponent is a global quantity)
     if (ctx->det) HIP_TRY(ctx, hipMemsetAsync(ctx->acc_l, 0, 6 * (size_t)n * sizeof(unsigned long long), ctx->stream));
     if (diag) launch_all_evals<true>(ctx); else launch_all_evals<false>(ctx);
     const int len = acc_stride(n);
     if (ctx->det) { int rc = det_finish(ctx, ctx->acc, ctx->nu, diag != nullptr); if (rc) return rc; }
     else hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, n, ctx->nslices, 1, (const DevState *)nullptr);
     HIP_TRY(ctx, hipGetLastError());
-    if (ctx->comm && !ctx->det) {               // pool-sharded (a communicator of one rank runs the same path)
-        int rc = g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
-        if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed (%d)", rc);
+    if (sharded(ctx) && !ctx->det) {            // pool-sharded (a communicator of one rank runs the same path)
+        int rc = all_reduce(ctx, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc;
     }
     std::vector<double> host(len);
     HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->acc, len * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1522,8 +1549,9 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     // (RCCL all-reduce inside every iteration): the same iterations are enqueued eagerly, the way RCCL
     // is conventionally driven (CFMM_MULTI_GRAPH=1 opts into capturing them too).
     static const bool graph_forced = getenv("CFMM_FUSED_GRAPH") && atoi(getenv("CFMM_FUSED_GRAPH")) != 0;     // (A/B: replay the fused launches from a graph)
-    const bool use_graph_opt = fused && !ctx->comm && graph_forced;
-    const bool use_graph = (!ctx->comm || ctx->multi_graph) && !ctx->no_graph && (!fused || ctx->comm || graph_forced);
+    const bool shard = sharded(ctx);
+    const bool use_graph_opt = fused && !shard && graph_forced;
+    const bool use_graph = (!shard || (ctx->multi_graph && !ctx->os_ready)) && !ctx->no_graph && (!fused || shard || graph_forced);
     if (use_graph && (!ctx->g_valid || !same_opts(o, ctx->g_opts))) { int rc = build_graph(ctx, o); if (rc) return rc; }
     UpdArgs ua = make_upd_args(ctx, o);
     const IterArgs ia = make_iter_args(ctx, o);
@@ -1549,11 +1577,10 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
             if (stable) launch_eval<true, true>(ctx, e0); else launch_eval<true, false>(ctx, e0);
         }
         if (ctx->det) { int rc = det_finish(ctx, ctx->acc3, ua.nu, true); if (rc) return rc; }
-        else if (ctx->comm) {
+        else if (shard) {
             const int len = acc_stride(n);
             hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc3, n, ctx->nslices, 1, (const DevState *)nullptr);
-            int rc = g_rccl.AllReduce(ctx->acc3, ctx->acc3, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
-            if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+            int rc = all_reduce(ctx, ctx->acc3, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc;
         }
     } else {
         HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
@@ -1572,7 +1599,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     DevState *hring = fused ? ctx->hst3 : ctx->hst;
     const DevState *dst = fused ? ctx->st3 : ctx->st;
     int status = 0, t = 1;
-    if (fused && !ctx->comm && !use_graph_opt) {
+    if (fused && !shard && !use_graph_opt) {
         // Single GPU, one launch per iteration: launches are enqueued eagerly, a few ahead of the device, whose workgroup 0
         // reports {evals, status} into a pinned host word as it goes (zero-copy: the host polls memory, no API call, no
         // copy engine).  No graph-replay gaps (~19 us per replay), and only `run_ahead` idle launches behind the end.
@@ -1771,6 +1798,68 @@ int cfmm_debug_eval_limbs(cfmm_ctx *ctx, const double *nu, double ref_reserve, d
     return CFMM_OK;
 }
 
+static int oneshot_alloc(cfmm_ctx *ctx)
+{
+    if (ctx->os_mail) return CFMM_OK;
+    ctx->os_cap = (size_t)std::max(acc_stride(ctx->n), 6 * ctx->n) + 8;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->os_mail, oneshot_bytes(ctx->os_cap)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->os_mail, 0, oneshot_bytes(ctx->os_cap), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CFMM_OK;
+}
+
+void *cfmm_oneshot_mailbox(cfmm_ctx *ctx)
+{
+    if (!ctx || hipSetDevice(ctx->device) != hipSuccess || oneshot_alloc(ctx) != CFMM_OK) return nullptr;
+    return ctx->os_mail;
+}
+
+int cfmm_oneshot_export(cfmm_ctx *ctx, void *handle64)
+{
+    if (!ctx || !handle64) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc = oneshot_alloc(ctx); if (rc) return rc; }
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    HIP_TRY(ctx, hipIpcGetMemHandle(&h, ctx->os_mail));
+    std::memcpy(handle64, &h, sizeof h);
+    return CFMM_OK;
+}
+
+int cfmm_oneshot_attach(cfmm_ctx *ctx, int n_ranks, int rank, void *const *mailboxes)
+{
+    if (!ctx || !mailboxes || n_ranks < 1 || n_ranks > ONESHOT_MAX_RANKS || rank < 0 || rank >= n_ranks)
+        return ctx ? fail(ctx, CFMM_E_ARG, "oneshot_attach: %d ranks (at most %d), rank %d", n_ranks, ONESHOT_MAX_RANKS, rank) : CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc = oneshot_alloc(ctx); if (rc) return rc; }
+    if (ctx->comm && ctx->n_ranks != n_ranks) return fail(ctx, CFMM_E_STATE, "oneshot_attach: the RCCL communicator has %d ranks", ctx->n_ranks);
+    for (int r = 0; r < n_ranks; ++r) {
+        ctx->os_peers[r] = r == rank ? ctx->os_mail : (unsigned long long *)mailboxes[r];
+        if (!ctx->os_peers[r]) return fail(ctx, CFMM_E_ARG, "oneshot_attach: mailbox of rank %d is NULL", r);
+    }
+    ctx->n_ranks = n_ranks; ctx->rank = rank;
+    ctx->os_epoch = 0; ctx->os_ready = true; ctx->g_valid = false;
+    return CFMM_OK;
+}
+
+int cfmm_oneshot_import(cfmm_ctx *ctx, int n_ranks, int rank, const void *handles)
+{
+    if (!ctx || !handles || n_ranks < 1 || n_ranks > ONESHOT_MAX_RANKS || rank < 0 || rank >= n_ranks) return ctx ? fail(ctx, CFMM_E_ARG, "oneshot_import: bad arguments") : CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *ptrs[ONESHOT_MAX_RANKS] = {};
+    for (int r = 0; r < n_ranks; ++r) {
+        if (r == rank) continue;
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, (const char *)handles + 64 * (size_t)r, sizeof h);
+        void *p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "oneshot_import: hipIpcOpenMemHandle(rank %d) -> %s", r, hipGetErrorString(e));
+        ctx->os_opened.push_back(p);
+        ptrs[r] = p;
+    }
+    return cfmm_oneshot_attach(ctx, n_ranks, rank, ptrs);
+}
+
 int cfmm_selftest(cfmm_ctx *ctx)
 {
     if (!ctx) return CFMM_E_ARG;
@@ -1838,12 +1927,10 @@ int cfmm_time_collective(cfmm_ctx *ctx, int reps, double *fold_sec, double *allr
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
     if (fold_sec) *fold_sec = ms * 1e-3 / reps;
     if (allreduce_sec) *allreduce_sec = 0.0;
-    if (ctx->comm && allreduce_sec) {              // (collective: every rank of the communicator must make this call)
-        for (int i = 0; i < 3; ++i)
-            if (g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream) != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed");
+    if (sharded(ctx) && allreduce_sec) {           // (collective: every rank of the communicator must make this call)
+        for (int i = 0; i < 3; ++i) { int rc = all_reduce(ctx, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc; }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
-        for (int i = 0; i < reps; ++i)
-            if (g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream) != 0) return fail(ctx, CFMM_E_RCCL, "ncclAllReduce failed");
+        for (int i = 0; i < reps; ++i) { int rc = all_reduce(ctx, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc; }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));

@@ -1,0 +1,91 @@
+// One-shot all-reduce over the xGMI mesh for the 8-50 KB messages of the outer iteration.
+//
+// The pool-sharded iteration exchanges ONE small vector per dual evaluation: [psi | sum arb] (n + 1 doubles, 8-16 KB),
+// or the 3 n integer limbs of the reproducible mode.  At that size a ring all-reduce is pure latency (2 (R - 1)
+// dependent hops); MI355X's xGMI links are point to point and every GPU of a node reaches every other directly, so the
+// whole exchange can be ONE hop: every rank stores its vector straight into a mailbox in each peer's HBM, raises a
+// flag there, waits for the R flags in its own mailbox and sums the R vectors itself -- in RANK ORDER, so that every
+// rank computes the same bits (no broadcast needed, and fp64 results do not depend on a ring's reduction order).
+//
+//   mailbox of a rank (device memory, exported to the peers with hipIpcGetMemHandle, one process per GPU):
+//       flag[2][ONESHOT_MAX_RANKS]            epoch of the last vector rank r delivered into parity slot p
+//       slot[2][ONESHOT_MAX_RANKS][cap]       the vectors, 8-byte elements
+//   Two parity slots: a rank can run at most one all-reduce ahead of a peer (it needs the peer's vector of epoch e + 1
+//   to finish e + 1, and the peer sends that only after it has finished reading epoch e), so epoch e + 1 never lands on
+//   data of epoch e still being read.
+// All mailbox traffic uses system-scope relaxed atomics (write-through / cache-bypassing 8-byte accesses) with a
+// system-scope fence between payload and flag: nothing of it may linger in an L2 that the other GPU cannot see.
+// One workgroup per rank: the kernels of all ranks must be running at the same time for the exchange to complete, and one
+// workgroup per GPU always is.  The spin is bounded; on expiry the result is poisoned with NaN (the solve then ends with
+// CFMM_E_NUMERIC instead of hanging).
+//
+// RCCL stays the default and the checker (CFMM_ALLREDUCE=oneshot, or cfmm_oneshot_import, selects this path).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cfmm {
+
+constexpr int ONESHOT_MAX_RANKS = 16;
+constexpr int ONESHOT_THREADS = 1024;
+enum { ONESHOT_SUM_F64 = 0, ONESHOT_SUM_I64 = 1, ONESHOT_MAX_F64 = 2 };
+
+__host__ __device__ inline size_t oneshot_flag_words() { return 2 * ONESHOT_MAX_RANKS; }
+__host__ __device__ inline size_t oneshot_bytes(size_t cap) { return (oneshot_flag_words() + 2 * (size_t)ONESHOT_MAX_RANKS * cap) * 8; }
+
+struct OneShotArgs {
+    unsigned long long *mail[ONESHOT_MAX_RANKS];    // every rank's mailbox (mail[rank] is the local one)
+    unsigned long long *buf;                        // the vector, reduced in place
+    unsigned long long epoch;                       // 1, 2, 3, ... : the same on every rank for the same call
+    int n_ranks, rank, count, op;
+    size_t cap;
+};
+
+__device__ __forceinline__ void sys_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned long long sys_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+__global__ void __launch_bounds__(ONESHOT_THREADS)
+oneshot_allreduce_kernel(OneShotArgs a)
+{
+    const int tid = threadIdx.x, R = a.n_ranks;
+    const int par = (int)(a.epoch & 1);
+    const size_t slot_off = oneshot_flag_words() + ((size_t)par * ONESHOT_MAX_RANKS + a.rank) * a.cap;
+    // 1. my vector into everybody's mailbox (my own included)
+    for (int j = tid; j < a.count; j += blockDim.x) {
+        const unsigned long long v = a.buf[j];
+        for (int r = 0; r < R; ++r) sys_store(a.mail[r] + slot_off + j, v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: the payload is out before any flag
+    __syncthreads();
+    if (tid < R) sys_store(a.mail[tid] + par * ONESHOT_MAX_RANKS + a.rank, a.epoch);
+    // 2. wait for the R vectors of this epoch in MY mailbox
+    __shared__ int ok;
+    if (tid == 0) ok = 1;
+    __syncthreads();
+    if (tid < R) {
+        const unsigned long long *f = a.mail[a.rank] + par * ONESHOT_MAX_RANKS + tid;
+        long spins = 0;
+        while (sys_load(f) != a.epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1L << 26)) { ok = 0; break; }   // (~ seconds: a peer has died)
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    // 3. reduce in rank order: the same bits on every rank
+    const unsigned long long *mine = a.mail[a.rank] + oneshot_flag_words() + (size_t)par * ONESHOT_MAX_RANKS * a.cap;
+    for (int j = tid; j < a.count; j += blockDim.x) {
+        unsigned long long acc = sys_load(mine + j);
+        for (int r = 1; r < R; ++r) {
+            const unsigned long long v = sys_load(mine + (size_t)r * a.cap + j);
+            if (a.op == ONESHOT_SUM_I64) acc += v;
+            else {
+                const double x = __longlong_as_double((long long)acc), y = __longlong_as_double((long long)v);
+                acc = (unsigned long long)__double_as_longlong(a.op == ONESHOT_SUM_F64 ? x + y : fmax(x, y));
+            }
+        }
+        if (!ok) acc = 0x7ff8000000000000ull;               // NaN: the exchange timed out
+        a.buf[j] = acc;
+    }
+}
+
+}  // namespace cfmm

@@ -176,6 +176,18 @@ int cfmm_get_tradesN(cfmm_ctx *ctx, int k, double *delta, double *lambda);
 int cfmm_comm_unique_id(void *uid128);
 int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128);
 
+/* One-shot all-reduce over the xGMI mesh for the iteration's 8-50 KB messages (csrc/oneshot.hpp): every rank stores its
+ * vector straight into a mailbox in each peer's HBM, one hop instead of a ring's 2 (R - 1); reduced in rank order, so every
+ * rank holds the same bits.  RCCL (cfmm_comm_init) stays the default and carries whatever does not fit a mailbox.
+ *   cfmm_oneshot_export: allocates this rank's mailbox, returns its 64-byte hipIpcMemHandle_t;
+ *   cfmm_oneshot_import: all ranks' handles ([n_ranks][64], own entry ignored) -> the collectives above use the mailboxes;
+ *   cfmm_oneshot_attach / cfmm_oneshot_mailbox: the same with raw device pointers, for ranks living in ONE process
+ *     (several contexts on one GPU: how the exchange is tested where a second GPU is not available). */
+int cfmm_oneshot_export(cfmm_ctx *ctx, void *handle64);
+int cfmm_oneshot_import(cfmm_ctx *ctx, int n_ranks, int rank, const void *handles);
+int cfmm_oneshot_attach(cfmm_ctx *ctx, int n_ranks, int rank, void *const *mailboxes);
+void *cfmm_oneshot_mailbox(cfmm_ctx *ctx);
+
 /* measurement hooks (bench.py): time `reps` back-to-back launches of the fused evaluation kernel
  * with HIP events on the library's stream, over every bucket (kind = CFMM_TIME_ALL: exactly the
  * launch one dual evaluation makes) or restricted to one bucket (kind = CFMM_POOL_*, or -k for

@@ -1,0 +1,56 @@
+"""worker of tests/test_gpu.py::test_one_shot_all_reduce_against_rccl_on_real_peers: one rank per GPU (torch.distributed.run).
+Each rank holds one pool shard; the same evaluations and the same solve run once over RCCL and once over the one-shot
+xGMI mailboxes (csrc/oneshot.hpp).  Rank 0 writes the comparison to argv[1]."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "cfmm-routing-code_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import cfmm  # noqa: E402
+from cfmm import synthetic  # noqa: E402
+
+
+def main():
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    net = synthetic.config("C3", scale=0.2, seed=4)
+    n = net["n_tokens"]
+    nu = net["c"] * np.exp(np.random.default_rng(3).normal(0, 0.02, n))
+    res = {}
+    for how in ("rccl", "oneshot"):
+        for det in (False, True):
+            p = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=local, allreduce=how)
+            if det:
+                p.ctx.set_deterministic(True)
+            f, psi = p.eval_dual(nu)
+            v = p.solve(tol=1e-7)
+            # every rank must hold the same bits: compare with rank 0's
+            ref = [None]
+            if rank == 0:
+                ref[0] = (f, psi.tolist(), p.nu.tolist(), p.stats["evals"])
+            dist.broadcast_object_list(ref, src=0)
+            same = (f == ref[0][0]) and psi.tolist() == ref[0][1] and p.nu.tolist() == ref[0][2] and p.stats["evals"] == ref[0][3]
+            flags = [None] * world
+            dist.all_gather_object(flags, bool(same))
+            res[f"{how}{'_det' if det else ''}"] = dict(f=f, psi=psi.tolist(), value=v, evals=p.stats["evals"], status=p.status,
+                                                        nu=p.nu.tolist(), all_ranks_same_bits=all(flags))
+            p.close()
+    if rank == 0:
+        with open(sys.argv[1], "w") as fh:
+            json.dump(dict(world=world, res=res), fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -520,3 +520,131 @@ def test_default_mode_is_reproducible_to_rounding_only():
     p.close()
     gross = np.abs(outs[0]).max()
     assert all(np.abs(x - outs[0]).max() <= 1e-11 * gross for x in outs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one-shot all-reduce (csrc/oneshot.hpp) and the pool-sharded C path with MORE than one rank, on one GPU: the ranks
+# are contexts of ONE process on the same device, their mailboxes attached by raw pointer (cfmm_oneshot_attach)
+# ---------------------------------------------------------------------------------------------------------------
+class _ThreadComm:
+    """test double of cfmm.problem.HostComm for ranks that are threads of one process"""
+    import threading as _th
+
+    def __init__(self, world):
+        self.world = world
+        self.bar = self._th.Barrier(world)
+        self.box = [None] * world
+
+    def view(self, rank):
+        parent = self
+
+        class V:
+            world = parent.world
+
+            def __init__(s):
+                s.rank = rank
+
+            def _exchange(s, obj):
+                parent.box[rank] = obj
+                parent.bar.wait()
+                out = list(parent.box)
+                parent.bar.wait()
+                return out
+
+            def broadcast(s, a, src=0):
+                return np.array(s._exchange(np.array(a, dtype=np.float64))[src])
+
+            def allreduce_sum(s, a):
+                return np.sum(s._exchange(np.array(a, dtype=np.float64)), axis=0)
+
+            def allgather(s, obj):
+                return s._exchange(obj)
+
+            def assert_identical(s, a, what):
+                parts = s._exchange(np.array(a, dtype=np.float64))
+                if not all(np.array_equal(x, parts[0]) for x in parts):
+                    raise cfmm.CfmmError(f"pool-sharded solve: {what} differ between ranks")
+        return V()
+
+
+@pytest.mark.parametrize("world,deterministic", [(2, False), (3, False), (2, True)])
+def test_pool_sharded_c_path_with_the_one_shot_all_reduce(oracle_lib, world, deterministic):
+    """`world` ranks = `world` contexts on this GPU, each holding one contiguous pool shard, exchanging [psi | sum arb]
+    (or the integer limbs) through the one-shot mailboxes: the whole fold -> all-reduce -> in-launch update control
+    flow of an N-GPU job runs here with N > 1.  Every rank must see the same bits, and the unsharded optimum."""
+    import threading
+    net = synthetic.config("C3", scale=0.05, seed=6)
+    n = net["n_tokens"]
+    nu = net["c"] * np.exp(np.random.default_rng(1).normal(0, 0.02, n))
+    whole = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]), deterministic=deterministic)
+    f_ref, psi_ref = whole.eval_dual(nu)
+    v_ref = whole.solve(tol=1e-7)
+    comm = _ThreadComm(world)
+    ranks = []
+    for r in range(world):
+        q = cfmm.Problem.from_network(cfmm.distributed.rank_network(net, r, world), utility=cfmm.Arbitrage(net["c"]), deterministic=deterministic)
+        q._ensure_ctx()
+        ranks.append(q)
+    boxes = [q.ctx.oneshot_mailbox() for q in ranks]
+    for r, q in enumerate(ranks):
+        q.ctx.oneshot_attach(world, r, boxes)
+        q._host = comm.view(r)
+    out = [None] * world
+    err = []
+
+    def run(r):
+        try:
+            q = ranks[r]
+            f, psi = q.eval_dual(nu)
+            v = q.solve(tol=1e-7)
+            out[r] = dict(f=f, psi=psi, v=v, status=q.status, evals=q.stats["evals"], nu=q.nu.copy(), psi_sol=q.psi.copy(), ranks=q.stats["n_ranks"])
+        except Exception as e:       # surfaced below
+            err.append(e); comm.bar.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not err, err
+    assert all(o is not None for o in out)
+    for o in out:
+        assert o["status"] == "optimal" and o["ranks"] == world
+        assert abs(o["f"] - f_ref) <= 1e-11 * abs(f_ref) and np.abs(o["psi"] - psi_ref).max() <= 1e-10 * np.abs(psi_ref).max()
+        assert abs(o["v"] - v_ref) <= 2e-7 * abs(v_ref)
+        # rank-order reduction: every rank holds the SAME bits
+        assert o["f"] == out[0]["f"] and np.array_equal(o["psi"], out[0]["psi"])
+        assert o["evals"] == out[0]["evals"] and np.array_equal(o["nu"], out[0]["nu"]) and np.array_equal(o["psi_sol"], out[0]["psi_sol"])
+    if deterministic:                      # integer limbs: the sharded run IS the unsharded run, bit for bit
+        assert out[0]["f"] == f_ref and np.array_equal(out[0]["psi"], psi_ref)
+        assert out[0]["v"] == v_ref and out[0]["evals"] == whole.stats["evals"] and np.array_equal(out[0]["nu"], whole.nu)
+    for q in ranks:
+        q.close()
+    whole.close()
+
+
+def test_one_shot_all_reduce_against_rccl_on_real_peers(tmp_path):
+    """needs >= 2 GPUs (skipped on the one-GPU box): one process per GPU, the same sharded evaluation and solve over RCCL
+    and over the one-shot mailboxes mapped through hipIpc.  Every rank holds the same bits either way; the two
+    transports agree to rounding (their summation orders differ), and bit for bit in reproducible mode, where the sum
+    is an integer sum."""
+    import subprocess, sys, json, socket
+    import torch
+    ngpu = torch.cuda.device_count()
+    if ngpu < 2:
+        pytest.skip(f"{ngpu} GPU visible: the one-shot exchange over real peers needs two")
+    world = min(ngpu, 8)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "oneshot.json")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(here, "dist_gpu_worker.py"), out], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    res = json.load(open(out))["res"]
+    for k, v in res.items():
+        assert v["status"] == "optimal" and v["all_ranks_same_bits"], k
+    a, b = res["rccl"], res["oneshot"]
+    assert abs(a["f"] - b["f"]) <= 1e-12 * abs(a["f"]) and np.abs(np.array(a["psi"]) - np.array(b["psi"])).max() <= 1e-11 * np.abs(a["psi"]).max()
+    assert abs(a["value"] - b["value"]) <= 2e-7 * abs(a["value"])
+    a, b = res["rccl_det"], res["oneshot_det"]
+    assert a["f"] == b["f"] and a["psi"] == b["psi"] and a["nu"] == b["nu"] and a["evals"] == b["evals"]
