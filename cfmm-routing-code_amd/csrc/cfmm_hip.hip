@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <functional>
 #include <string>
 #include <thread>
@@ -98,8 +99,6 @@ struct cfmm_ctx {
     int *flags2 = nullptr;
     double *trade_buf = nullptr;       // grow-only scratch for cfmm_get_trades* (delta | lambda)
     size_t trade_cap = 0;
-    char *stage = nullptr;             // pinned staging ring of the upload hand-over: 2 slots of STAGE_BYTES
-    hipEvent_t stage_ev[2] = {nullptr, nullptr};
 
     // tokens / state (device)
     double *c = nullptr, *h = nullptr, *off = nullptr, *glo = nullptr, *ghi = nullptr;
@@ -247,14 +246,39 @@ int dev_upload(cfmm_ctx *ctx, T **dst, const T *src, size_t count, std::vector<v
 // ABI's slot-major to the device's pool-major layout on the way) overlaps the DMA of chunk i - 1.  Pageable
 // hipMemcpy of ~40 separately allocated columns ran at ~6 GB/s (round 1).
 constexpr size_t STAGE_BYTES = 8u << 20;
+// the ring is process-wide and allocated once (pinning 16 MB takes milliseconds: per context it cost more than it saved);
+// uploads of different contexts take turns on it
+struct StageRing {
+    std::mutex mu;
+    char *buf = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+StageRing g_stage;
 struct Col {
     size_t bytes = 0;
     void **dst = nullptr;                                                  // receives the column's device address
     std::function<void(char *out, size_t off, size_t len)> fill;          // writes bytes [off, off + len) of the column
+    const void *direct = nullptr;                                          // the caller's buffer when the column is copied as it is
 };
+// host-side helper: f(begin, end) over [0, m) on a few threads (validation scans and staging fills run at memory speed)
+template <class F>
+void parallel_range(int64_t m, F f)
+{
+    const int T = m >= (1 << 17) ? 8 : 1;
+    if (T == 1) { f((int64_t)0, m); return; }
+    std::vector<std::thread> th;
+    const int64_t part = (m + T - 1) / T;
+    for (int t = 0; t < T; ++t) {
+        const int64_t b = t * part, e = std::min<int64_t>(m, b + part);
+        if (b >= e) break;
+        th.emplace_back([=]() { f(b, e); });
+    }
+    for (auto &x : th) x.join();
+}
+
 Col plain_col(const void *src, size_t bytes, void **dst)
 {
-    Col c; c.bytes = bytes; c.dst = dst;
+    Col c; c.bytes = bytes; c.dst = dst; c.direct = src;
     c.fill = [src](char *out, size_t off, size_t len) { std::memcpy(out, (const char *)src + off, len); };
     return c;
 }
@@ -274,7 +298,7 @@ Col transposed_col(const T *src, int k, int64_t m, void **dst)
 }
 void parallel_fill(const Col &c, char *out, size_t off, size_t len)
 {
-    const int T = len >= (2u << 20) ? 4 : 1;
+    const int T = len >= (2u << 20) ? 8 : 1;
     if (T == 1) { c.fill(out, off, len); return; }
     std::vector<std::thread> th;
     const size_t part = ((len / T) + 63) & ~(size_t)63;
@@ -293,21 +317,44 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out)
     char *base = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&base, total + 256));
     auto bail = [&](hipError_t e, const char *what) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(base); return fail(ctx, CFMM_E_HIP, "upload: %s -> %s", what, hipGetErrorString(e)); };
-    if (!ctx->stage) {
-        hipError_t e = hipHostMalloc((void **)&ctx->stage, 2 * STAGE_BYTES, hipHostMallocDefault);
-        if (e != hipSuccess) { ctx->stage = nullptr; return bail(e, "hipHostMalloc(staging)"); }
-        for (auto &ev : ctx->stage_ev) { e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) return bail(e, "hipEventCreate"); }
+    // (A/B) CFMM_UPLOAD=register: page-lock the caller's buffers in place and let the copy engine read them directly
+    static const bool by_register = getenv("CFMM_UPLOAD") && std::string(getenv("CFMM_UPLOAD")) == "register";
+    if (by_register) {
+        std::vector<void *> pinned;
+        hipError_t e = hipSuccess;
+        for (size_t q = 0; q < cols.size() && e == hipSuccess; ++q) {
+            if (cols[q].direct && cols[q].bytes >= (1u << 20)) {
+                e = hipHostRegister(const_cast<void *>(cols[q].direct), cols[q].bytes, hipHostRegisterDefault);
+                if (e == hipSuccess) { pinned.push_back(const_cast<void *>(cols[q].direct)); e = hipMemcpyAsync(base + offs[q], cols[q].direct, cols[q].bytes, hipMemcpyHostToDevice, ctx->stream); }
+            } else {
+                std::vector<char> tmp(cols[q].bytes);
+                cols[q].fill(tmp.data(), 0, cols[q].bytes);
+                e = hipMemcpy(base + offs[q], tmp.data(), cols[q].bytes, hipMemcpyHostToDevice);
+            }
+            *cols[q].dst = base + offs[q];
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        for (void *h : pinned) (void)hipHostUnregister(h);
+        if (e != hipSuccess) return bail(e, "hipHostRegister / copy");
+        *arena_out = base;
+        return CFMM_OK;
+    }
+    std::lock_guard<std::mutex> lock(g_stage.mu);
+    if (!g_stage.buf) {
+        hipError_t e = hipHostMalloc((void **)&g_stage.buf, 2 * STAGE_BYTES, hipHostMallocDefault);
+        if (e != hipSuccess) { g_stage.buf = nullptr; return bail(e, "hipHostMalloc(staging)"); }
+        for (auto &ev : g_stage.ev) { e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) return bail(e, "hipEventCreate"); }
     }
     int slot = 0;
     bool used[2] = {false, false};
     for (size_t q = 0; q < cols.size(); ++q) {
         for (size_t off = 0; off < cols[q].bytes; off += STAGE_BYTES) {
             const size_t len = std::min(STAGE_BYTES, cols[q].bytes - off);
-            char *st = ctx->stage + (size_t)slot * STAGE_BYTES;
-            if (used[slot]) { hipError_t e = hipEventSynchronize(ctx->stage_ev[slot]); if (e != hipSuccess) return bail(e, "hipEventSynchronize"); }
+            char *st = g_stage.buf + (size_t)slot * STAGE_BYTES;
+            if (used[slot]) { hipError_t e = hipEventSynchronize(g_stage.ev[slot]); if (e != hipSuccess) return bail(e, "hipEventSynchronize"); }
             parallel_fill(cols[q], st, off, len);
             hipError_t e = hipMemcpyAsync(base + offs[q] + off, st, len, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipEventRecord(ctx->stage_ev[slot], ctx->stream);
+            if (e == hipSuccess) e = hipEventRecord(g_stage.ev[slot], ctx->stream);
             if (e != hipSuccess) return bail(e, "hipMemcpyAsync");
             used[slot] = true; slot ^= 1;
         }
@@ -446,15 +493,21 @@ int set_all_lds_attrs(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, update_reg_kernel<256, 8, 4>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_gram_kernel<512, 2>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, start_kernel, upd_lds_bytes(ctx->n)))) return rc;
-    if ((rc = set_lds_attr(ctx, iter_kernel<1>, iter_lds_bytes(ctx->n)))) return rc;
-    if ((rc = set_lds_attr(ctx, iter_kernel<2>, iter_lds_bytes(ctx->n)))) return rc;
+    const size_t il = iter_lds_bytes(ctx->n);
+    if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, false>, il))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, true>, il))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<2, false, false>, il))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<2, false, true>, il))) return rc;
     if (eval_lds_bytes(ctx->n, true, true) <= 160 * 1024) {        // reproducible mode: tiles of 3 n integer limbs
         if ((rc = set_lds_attr(ctx, eval_kernel<false, false, true>, eval_lds_bytes(ctx->n, false, true)))) return rc;
         if ((rc = set_lds_attr(ctx, eval_kernel<true, false, true>, eval_lds_bytes(ctx->n, true, true)))) return rc;
         if ((rc = set_lds_attr(ctx, eval_kernel<false, true, true>, eval_lds_bytes(ctx->n, false, true)))) return rc;
         if ((rc = set_lds_attr(ctx, eval_kernel<true, true, true>, eval_lds_bytes(ctx->n, true, true)))) return rc;
-        if ((rc = set_lds_attr(ctx, iter_kernel<1, true>, iter_lds_bytes(ctx->n, true)))) return rc;
-        if ((rc = set_lds_attr(ctx, iter_kernel<2, true>, iter_lds_bytes(ctx->n, true)))) return rc;
+        const size_t ild = iter_lds_bytes(ctx->n, true);
+        if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, true, false>, ild))) return rc;
+        if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, true, true>, ild))) return rc;
+        if ((rc = set_lds_attr(ctx, iter_kernel<2, true, false>, ild))) return rc;
+        if ((rc = set_lds_attr(ctx, iter_kernel<2, true, true>, ild))) return rc;
     }
     return CFMM_OK;
 }
@@ -524,11 +577,12 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
         if (grid < 1) grid = 1;                                 // (a shard without pools still takes the step)
     }
     const size_t lds = iter_lds_bytes(n, ctx->det);
-    if (ctx->det) {
-        if (E == 1) hipLaunchKernelGGL((iter_kernel<1, true>), dim3(grid), dim3(threads), lds, ctx->stream, a);
-        else hipLaunchKernelGGL((iter_kernel<2, true>), dim3(grid), dim3(threads), lds, ctx->stream, a);
-    } else if (E == 1) hipLaunchKernelGGL(iter_kernel<1>, dim3(grid), dim3(threads), lds, ctx->stream, a);
-    else hipLaunchKernelGGL(iter_kernel<2>, dim3(grid), dim3(threads), lds, ctx->stream, a);
+    const dim3 g(grid), b(threads);
+#define ITER_LAUNCH(EE) do { \
+        if (ctx->det) { if (a.plain) hipLaunchKernelGGL((iter_kernel<EE, true, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<EE, true, false>), g, b, lds, ctx->stream, a); } \
+        else { if (a.plain) hipLaunchKernelGGL((iter_kernel<EE, false, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<EE, false, false>), g, b, lds, ctx->stream, a); } } while (0)
+    if (E == 1) ITER_LAUNCH(ITER_E_SMALL); else ITER_LAUNCH(2);
+#undef ITER_LAUNCH
     double *acc_p = ctx->acc3 + (size_t)a.phase * acc_set_doubles(ctx);
     if (ctx->pools->b2[CFMM_POOL_CURVE2].m > 0) {              // the stableswap bucket has its own instantiation: it reads the
         EvalArgs es = make_eval_args(ctx, true);              // prices (and the stop flag) workgroup 0 has just stored
@@ -1125,8 +1179,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
         TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eval_kernel<false, false>, EVAL_THREADS, eval_lds_bytes(n, false)));
         ctx->eval_blocks_per_cu = nb < 1 ? 1 : nb;
         nb = 0;
-        if (n <= 1024) TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iter_kernel<1>, EVAL_THREADS, iter_lds_bytes(n)));
-        else TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iter_kernel<2>, EVAL_THREADS, iter_lds_bytes(n)));
+        TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iter_kernel<2, false, false>, EVAL_THREADS, iter_lds_bytes(n)));
         ctx->iter_blocks_per_cu = nb < 1 ? 1 : nb;
     }
     if (ctx->nslices > 64) ctx->nslices = 64;
@@ -1167,8 +1220,6 @@ int cfmm_destroy(cfmm_ctx *ctx)
     ctx->pools.reset();
     if (ctx->flags2) (void)hipFree(ctx->flags2);
     if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
-    if (ctx->stage) (void)hipHostFree(ctx->stage);
-    for (auto &e : ctx->stage_ev) if (e) (void)hipEventDestroy(e);
     for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
     void *ptrs[] = {ctx->c, ctx->h, ctx->off, ctx->glo, ctx->ghi, ctx->ctype, ctx->grp, ctx->nu, ctx->nu_acc, ctx->psi_acc,
                     ctx->psi_t, ctx->nu0, ctx->s, ctx->s_t, ctx->Gs, ctx->Gs_t, ctx->d, ctx->Ds, ctx->S, ctx->Y, ctx->rho,
@@ -1203,17 +1254,32 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
     if (m > 0 && (!Ra || !Rb || !fee || !ia || !ib)) return fail(ctx, CFMM_E_ARG, "upload_pools2: NULL column");
     if (m > 0 && (kind == CFMM_POOL_W2 || kind == CFMM_POOL_CURVE2) && !param) return fail(ctx, CFMM_E_ARG, "upload_pools2: kind %d needs param", kind);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    for (int64_t i = 0; i < m; ++i)
-        if (ia[i] < 0 || ia[i] >= ctx->n || ib[i] < 0 || ib[i] >= ctx->n || ia[i] == ib[i])
-            return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has token ids (%d, %d) outside [0,%d) or equal", (long long)i, ia[i], ib[i], ctx->n);
+    // one pass over the columns, on a few threads: ids, reserves, fee, parameter; and the extrema the reproducible mode needs
     double mxr = 0.0, mnf = 1.0;
-    for (int64_t i = 0; i < m; ++i) { mxr = std::max(mxr, std::max(Ra[i], Rb[i])); mnf = std::min(mnf, fee[i]); }
-    for (int64_t i = 0; i < m; ++i) {
-        if (!(Ra[i] > 0.0) || !(Rb[i] > 0.0) || !std::isfinite(Ra[i]) || !std::isfinite(Rb[i]))
-            return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has a reserve that is not positive and finite", (long long)i);
-        if (!(fee[i] > 0.0 && fee[i] <= 1.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has fee %g outside (0, 1]", (long long)i, fee[i]);
-        if (kind == CFMM_POOL_W2 && !(param[i] > 0.0 && param[i] < 1.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has weight %g outside (0, 1)", (long long)i, param[i]);
-        if (kind == CFMM_POOL_CURVE2 && !(param[i] > 0.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has alpha %g <= 0", (long long)i, param[i]);
+    {
+        std::mutex mu;
+        int64_t bad = -1; int what = 0;
+        const int ntok = ctx->n;
+        parallel_range(m, [&](int64_t b, int64_t e) {
+            double lmx = 0.0, lmn = 1.0; int64_t lbad = -1; int lwhat = 0;
+            for (int64_t i = b; i < e && lbad < 0; ++i) {
+                if (ia[i] < 0 || ia[i] >= ntok || ib[i] < 0 || ib[i] >= ntok || ia[i] == ib[i]) { lbad = i; lwhat = 1; }
+                else if (!(Ra[i] > 0.0) || !(Rb[i] > 0.0) || !std::isfinite(Ra[i]) || !std::isfinite(Rb[i])) { lbad = i; lwhat = 2; }
+                else if (!(fee[i] > 0.0 && fee[i] <= 1.0)) { lbad = i; lwhat = 3; }
+                else if (kind == CFMM_POOL_W2 && !(param[i] > 0.0 && param[i] < 1.0)) { lbad = i; lwhat = 4; }
+                else if (kind == CFMM_POOL_CURVE2 && !(param[i] > 0.0)) { lbad = i; lwhat = 5; }
+                else { lmx = std::max(lmx, std::max(Ra[i], Rb[i])); lmn = std::min(lmn, fee[i]); }
+            }
+            std::lock_guard<std::mutex> g(mu);
+            mxr = std::max(mxr, lmx); mnf = std::min(mnf, lmn);
+            if (lbad >= 0 && (bad < 0 || lbad < bad)) { bad = lbad; what = lwhat; }
+        });
+        const long long i = (long long)bad;
+        if (what == 1) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has token ids (%d, %d) outside [0,%d) or equal", i, ia[bad], ib[bad], ctx->n);
+        if (what == 2) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has a reserve that is not positive and finite", i);
+        if (what == 3) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has fee %g outside (0, 1]", i, fee[bad]);
+        if (what == 4) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has weight %g outside (0, 1)", i, param[bad]);
+        if (what == 5) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has alpha %g <= 0", i, param[bad]);
     }
     if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_pools2: the pools are shared with a clone (cfmm_clone); destroy the clones first");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -233,7 +233,9 @@ __device__ __forceinline__ double uni(double v)
 // extra LDS of iter_kernel behind eval_kernel's carve: wave-private copies of the 48 batch totals
 __host__ __device__ inline int iter_extra_lds_doubles() { return 16 * 48; }
 
-template <int E, bool DET = false>
+// PLAIN: the utility has h == 0, every token CFMM_GE and no upper bounds (linear-utility arbitrage, arbitrage.py:57,77):
+// three of the update's vectors are never read and their registers do not exist (the other instantiation spills a few)
+template <int E, bool DET = false, bool PLAIN = false>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 iter_kernel(IterArgs a)
 {
@@ -314,7 +316,7 @@ iter_kernel(IterArgs a)
         ldE<E>(a.Ds, ld0, Ds); ldE<E>(a.glo, ld0, glo); ldE<E>(a.c, ld0, cj);
 #pragma unroll
         for (int e = 0; e < E; ++e) { psi[e] = 0.0; dg[e] = 0.0; ghi[e] = __builtin_inf(); hj[e] = 0.0; ct[e] = 0; }
-        if (!a.plain) { ldE<E>(a.ghi, ld0, ghi); ldE<E>(a.h, ld0, hj); ldEi<E>(a.ctype, ld0, ct); }
+        if (!PLAIN) { ldE<E>(a.ghi, ld0, ghi); ldE<E>(a.h, ld0, hj); ldEi<E>(a.ctype, ld0, ct); }
         for (int sl = 0; sl < a.nread; ++sl) {
             double t1[E];
             ldE<E>(Ar + (size_t)sl * stride, ld0, t1);
@@ -350,12 +352,12 @@ iter_kernel(IterArgs a)
         for (int e = 0; e < E; ++e) {
             Gs_t[e] = 0.0;
             if (tin[e]) {
-                const double rj = psi[e] + hj[e];
+                const double rj = PLAIN ? psi[e] : psi[e] + hj[e];
                 Gs_t[e] = nuj[e] * rj;
-                in.g1[0] += (nuj[e] - cj[e]) * hj[e];
+                if (!PLAIN) in.g1[0] += (nuj[e] - cj[e]) * hj[e];
                 in.g1[1] += (nuj[e] - cj[e]) * rj;
-                mx[0] = fmax(mx[0], ct[e] == 0 ? fmax(-rj, 0.0) : (ct[e] == 1 ? fabs(rj) : 0.0));
-                mx[1] = fmax(mx[1], fmax(fabs(psi[e]), fabs(hj[e])));
+                mx[0] = fmax(mx[0], (PLAIN || ct[e] == 0) ? fmax(-rj, 0.0) : (ct[e] == 1 ? fabs(rj) : 0.0));
+                mx[1] = fmax(mx[1], PLAIN ? fabs(psi[e]) : fmax(fabs(psi[e]), fabs(hj[e])));
                 const double sv = s_t[e] - s[e], yv = Gs_t[e] - Gs[e];
                 if (!st.first) {
                     in.S[0][e] = sv; in.Y[0][e] = yv;
@@ -364,11 +366,11 @@ iter_kernel(IterArgs a)
                 }
                 const double G = Gs_t[e], sr = s_t[e];
                 double v = G;
-                if (glo[e] == ghi[e]) v = 0.0;
+                if (!PLAIN && glo[e] == ghi[e]) v = 0.0;
                 else if (sr <= glo[e] + 1e-14) v = fmin(G, 0.0);
-                else if (sr >= ghi[e] - 1e-14) v = fmax(G, 0.0);
+                else if (!PLAIN && sr >= ghi[e] - 1e-14) v = fmax(G, 0.0);
                 in.g1[7] += fabs(v);
-                act[e] = is_active(sr, glo[e], ghi[e], G);
+                act[e] = PLAIN ? (sr <= glo[e] + 1e-14 && G > 0.0) : is_active(sr, glo[e], ghi[e], G);
                 in.q0[e] = act[e] ? 0.0 : G;
                 in.g1[8] += in.q0[e] * in.q0[e];
                 const double H = Ds[e] + fmax(G, 0.0);
@@ -406,34 +408,6 @@ iter_kernel(IterArgs a)
     if (!st.first)
         accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * T[2]) ||
                                   (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && T[3] <= 0.8 * fabs(T[2])));
-    // second half's inputs, requested NOW so that their latency (L1 / L2 hits) hides behind the scalar recursion: the
-    // accepted point (s moves to the trial point, or stays), its gradient (the stashed trial gradient, or the old one),
-    // the old direction in case this trial point is rejected, the bounds
-    double s[E], Gs[E], d[E], glo[E], ghi[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) { s[e] = Gs[e] = d[e] = glo[e] = 0.0; ghi[e] = __builtin_inf(); }
-    if (wave_active) {
-        ldE<E>(Xr + (accept ? xvs : 0), ld0, s);
-        ldE<E>(a.glo, ld0, glo);
-        if (!a.plain) ldE<E>(a.ghi, ld0, ghi);
-        if (accept) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) Gs[e] = tin[e] ? gst_s[r0 + e] : 0.0;
-        } else { ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 3 * xvs, ld0, d); }
-        if (wr && accept && r0 < n) {                    // the accepted prices and their net trade, for the read-back
-            double psi[E], nuj[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) psi[e] = 0.0;
-            for (int sl = 0; sl < a.nread; ++sl) {
-                double t1[E];
-                ldE<E>(Ar + (size_t)sl * stride, ld0, t1);
-#pragma unroll
-                for (int e = 0; e < E; ++e) psi[e] += t1[e];
-            }
-            ldE<E>(Xr + 4 * xvs, ld0, nuj);
-            stE<E>(a.psi_acc, r0, n, psi); stE<E>(a.nu_acc, r0, n, nuj);
-        }
-    }
     bool new_dir = false;
     double al[P], ga[P];
 #pragma unroll
@@ -502,6 +476,35 @@ iter_kernel(IterArgs a)
     PHASE_STAMP(a.ev.ts, 21);
 
     // ================= second half: the direction, the next trial point =================================================
+    // second half's inputs, reloaded (L1 / L2 hits; requesting them before the recursion to hide their latency only made the
+    // allocator spill across it): the accepted point (s moves to the trial point, or stays), its gradient (the stashed
+    // trial gradient, or the old one), the old direction in case this trial point is rejected, the bounds
+    double s[E], Gs[E], d[E], glo[E], ghi[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { s[e] = Gs[e] = d[e] = glo[e] = 0.0; ghi[e] = __builtin_inf(); }
+    if (wave_active) {
+        ldE<E>(Xr + (accept ? xvs : 0), ld0, s);
+        ldE<E>(a.glo, ld0, glo);
+        if (!PLAIN) ldE<E>(a.ghi, ld0, ghi);
+        if (accept) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) Gs[e] = tin[e] ? gst_s[r0 + e] : 0.0;
+        } else { ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 3 * xvs, ld0, d); }
+        if (wr && accept && r0 < n) {                    // the accepted prices and their net trade, for the read-back
+            double psi[E], nuj[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) psi[e] = 0.0;
+            for (int sl = 0; sl < a.nread; ++sl) {
+                double t1[E];
+                ldE<E>(Ar + (size_t)sl * stride, ld0, t1);
+#pragma unroll
+                for (int e = 0; e < E; ++e) psi[e] += t1[e];
+            }
+            ldE<E>(Xr + 4 * xvs, ld0, nuj);
+            stE<E>(a.psi_acc, r0, n, psi); stE<E>(a.nu_acc, r0, n, nuj);
+        }
+    }
+
     if (new_dir) {
         double F[2] = {0.0, 0.0};              // d.G | max |d|
 #pragma unroll
@@ -532,7 +535,8 @@ iter_kernel(IterArgs a)
     double v[E], nn[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        v[e] = fmin(fmax(s[e] + st.t_step * d[e], glo[e]), ghi[e]);
+        v[e] = fmax(s[e] + st.t_step * d[e], glo[e]);
+        if (!PLAIN) v[e] = fmin(v[e], ghi[e]);
         nn[e] = (st.status == 0 && tin[e]) ? exp(v[e]) : 0.0;
     }
     if (st.status == 0 && st.evals >= a.max_evals) st.status = 3;

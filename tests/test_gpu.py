@@ -373,7 +373,8 @@ def test_eager_iteration_path_matches_graph_path(tmp_path):
     assert abs(out["0"]["v"] - out["1"]["v"]) <= 1e-9 * abs(out["0"]["v"])
 
 
-def test_pool_sharded_path_with_a_one_rank_communicator():
+@pytest.mark.parametrize("allreduce", ["rccl", "oneshot"])
+def test_pool_sharded_path_with_a_one_rank_communicator(allreduce):
     """the whole N > 1 code path on ONE GPU: torch.distributed(nccl) rendezvous, communicator id broadcast,
     cfmm_comm_init (RCCL resolved at run time, warm-up all-reduce), eager iterations with fold + ncclAllReduce
     + update -- a communicator of one rank runs exactly what every rank of an 8-GPU job runs"""
@@ -388,7 +389,7 @@ from cfmm import synthetic
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 net = synthetic.config("C3", scale=0.05, seed=0)
-p = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=0)
+p = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=0, allreduce=%r)
 v = p.solve(tol=1e-6)
 f, psi = p.eval_dual(p.nu)
 q = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
@@ -397,7 +398,7 @@ f2, psi2 = q.eval_dual(p.nu)
 print(json.dumps(dict(v=v, w=w, status=p.status, evals=p.stats["evals"], evals1=q.stats["evals"], ranks=p.stats["n_ranks"],
                       df=abs(f - f2) / abs(f2), dpsi=float(abs(psi - psi2).max() / abs(psi2).max()))))
 dist.destroy_process_group()
-''' % (root, os.path.join(root, "cfmm-routing-code_amd"))
+''' % (root, os.path.join(root, "cfmm-routing-code_amd"), allreduce)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
