@@ -111,6 +111,7 @@ struct cfmm_ctx {
     long long *ts = nullptr;           // phase timers (tuning builds)
     DevState *hst = nullptr;          // pinned, 2 slots
     double *hsol = nullptr;           // pinned [2][n]: nu | psi of the last solve (saves cfmm_get_solution a synchronisation)
+    double *hnu0 = nullptr;           // pinned [n]: staging of cfmm_set_nu
     bool hsol_valid = false;
     hipEvent_t ev[2] = {nullptr, nullptr}, ev_t0 = nullptr, ev_t1 = nullptr;
     int nslices = 2;                   // accumulator slices the workgroups flush into (blockIdx % nslices): flat from 2 upward for the flush, and every slice is one more vector the in-launch update of EVERY workgroup reads (27.4 vs 28.4 us per iteration at 2 vs 4, C3)
@@ -1166,6 +1167,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     TRY_C(hipHostGetDevicePointer((void **)&ctx->hstat_d, (void *)ctx->hstat_h, 0));
     *ctx->hstat_h = 0;
     TRY_C(hipHostMalloc((void **)&ctx->hsol, 2 * (size_t)n * sizeof(double), hipHostMallocDefault));
+    TRY_C(hipHostMalloc((void **)&ctx->hnu0, (size_t)n * sizeof(double), hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) TRY_C(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
     TRY_C(hipEventCreate(&ctx->ev_t0));
     TRY_C(hipEventCreate(&ctx->ev_t1));
@@ -1229,6 +1231,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     if (ctx->hst3) (void)hipHostFree(ctx->hst3);
     if (ctx->hstat_h) (void)hipHostFree((void *)ctx->hstat_h);
     if (ctx->hsol) (void)hipHostFree(ctx->hsol);
+    if (ctx->hnu0) (void)hipHostFree(ctx->hnu0);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
@@ -1416,8 +1419,11 @@ int cfmm_set_nu(cfmm_ctx *ctx, const double *nu)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int j = 0; j < ctx->n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "set_nu: nu[%d] = %g is not a positive finite price", j, nu[j]);
     { double mx = 0.0; for (int j = 0; j < ctx->n; ++j) mx = std::max(mx, nu[j]); ctx->nu_max = mx; }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu_acc, nu, ctx->n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the caller's (pageable) buffer may go away after we return
+    // through the context's own pinned vector: the caller's (pageable) buffer may go away after we return, and copying it
+    // here spares a stream synchronisation per solve (the previous copy out of hnu0 has completed: every solve ends synchronised)
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(ctx->hnu0, nu, ctx->n * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu_acc, ctx->hnu0, ctx->n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     ctx->have_nu = true; ctx->hsol_valid = false; ctx->mu_last = 0.0; ctx->slo_active = false;
     return CFMM_OK;
 }
@@ -1627,16 +1633,16 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu0, ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     *ctx->hstat_h = 0;                                     // (the stream is idle: nothing can still write the progress word)
     if (ctx->det) HIP_TRY(ctx, hipMemsetAsync(ctx->acc_l, 0, 6 * (size_t)n * sizeof(unsigned long long), ctx->stream));
     if (fused) {
         // launch 0: the start point and the first evaluation (with the diagonal metric) into state / accumulator set 0
-        HIP_TRY(ctx, hipMemsetAsync(ctx->acc3, 0, 3 * aset * sizeof(double), ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->st3, 0, 3 * sizeof(DevState), ctx->stream));
+        // (the start kernel also clears the three accumulator sets and the two spare state records, and reads the start
+        //  prices where they are: three fill / copy operations less on the stream per solve)
         double *x0 = ctx->xs3;
         ua.s = x0; ua.s_t = x0 + ia.xvs; ua.Gs = x0 + 2 * ia.xvs; ua.d = x0 + 3 * ia.xvs; ua.nu = x0 + 4 * ia.xvs; ua.st = ctx->st3;
-        hipLaunchKernelGGL(start_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu0);
+        hipLaunchKernelGGL(start_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
+                           ctx->acc3, (long long)(3 * aset), ctx->st3 + 1, 2);
         for (int stable = 0; stable < 2; ++stable) {
             EvalArgs e0 = make_eval_args(ctx, stable != 0);
             e0.nu = ua.nu; e0.acc = ctx->acc3;
@@ -1649,8 +1655,8 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
             int rc = all_reduce(ctx, ctx->acc3, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc;
         }
     } else {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
-        hipLaunchKernelGGL(start_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu0);
+        hipLaunchKernelGGL(start_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
+                           ctx->acc, (long long)((size_t)ctx->nslices * acc_stride(n)), (DevState *)nullptr, 0);
         { int rc = enqueue_iteration<true>(ctx, ua); if (rc) return rc; }      // first evaluation also builds the metric
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -254,7 +254,6 @@ iter_kernel(IterArgs a)
     double *xw = strips;                                 // [16][64] per-wave sums
     double *xm = xw + 16 * 64;                           // [16][2] maxima
     BlockRed red(xm + 32);                               // [2][12][16]
-    double *xt = strips + 16 * 128 + wave * 48;          // this wave's own copy of the 48 totals (behind the strips)
     double *gst_s = psi_s;                               // [n] trial gradient, stashed between the two halves of the update
 
     PHASE_STAMP(a.ev.ts, 16);
@@ -388,26 +387,23 @@ iter_kernel(IterArgs a)
     else if (lane < 48) xw[wave * 64 + lane] = qb;       // (lane - 32 = lane & 15 there)
     if (lane == 0) { xm[wave * 2] = mx[0]; xm[wave * 2 + 1] = mx[1]; }
     __syncthreads();
-    // every wave sums the per-wave rows itself, into its own copy: no second barrier, no broadcast
-    if (lane < 48) {
-        double t = 0.0;
-        for (int w = 0; w < nw; ++w) t += xw[w * 64 + lane];
-        xt[lane] = t;
-    }
-    __builtin_amdgcn_wave_barrier();                     // (LDS operations of one wave complete in order)
-    // (the 44 totals stay in LDS and are read where they are used: as registers they would cost 88 VGPRs)
-    const double *T = xt;
+    // every wave sums the per-wave rows itself: lane l ends with total l, and the scalar sections below fetch a total
+    // with two v_readlane (into SGPRs: no second barrier, no LDS broadcast round trips on the dependent chain)
+    double tl = 0.0;
+    if (lane < 48) for (int w = 0; w < nw; ++w) tl += xw[w * 64 + lane];
+    const int tl_lo = __double2loint(tl), tl_hi = __double2hiint(tl);
+    auto T = [&](int i) { return __hiloint2double(__builtin_amdgcn_readlane(tl_hi, i), __builtin_amdgcn_readlane(tl_lo, i)); };
     PHASE_STAMP(a.ev.ts, 20);
     double viol = 0.0, scale = 0.0;
     for (int w = 0; w < nw; ++w) { viol = fmax(viol, xm[w * 2]); scale = fmax(scale, xm[w * 2 + 1]); }
-    const double f_t = T[0], gapv = T[1];
+    const double f_t = T(0), gapv = T(1);
     st.evals += 1;
 
     // ---- accept test --------------------------------------------------------------------------------------------
     bool accept = st.first != 0;
     if (!st.first)
-        accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * T[2]) ||
-                                  (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && T[3] <= 0.8 * fabs(T[2])));
+        accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * T(2)) ||
+                                  (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && T(3) <= 0.8 * fabs(T(2))));
     bool new_dir = false;
     double al[P], ga[P];
 #pragma unroll
@@ -422,10 +418,10 @@ iter_kernel(IterArgs a)
         bool pair_ok = false;
         const int old_hist0 = st.hist;
         if (!st.first) {
-            if (T[4] > 1e-12 * sqrt(T[5]) * sqrt(T[6])) {
+            if (T(4) > 1e-12 * sqrt(T(5)) * sqrt(T(6))) {
                 pair_ok = true;
                 if (wave_active && r0 < n) { stE<E>(a.S + (size_t)st.head * hs, r0, nS, in.S[0]); stE<E>(a.Y + (size_t)st.head * hs, r0, nS, in.Y[0]); }
-                if (wr && tid == 0) a.rho[st.head] = 1.0 / T[4];
+                if (wr && tid == 0) a.rho[st.head] = 1.0 / T(4);
                 st.head = (st.head + 1) % RS;
                 if (st.hist < M) st.hist += 1;
             }
@@ -435,8 +431,8 @@ iter_kernel(IterArgs a)
         st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
         st.infeas = viol / fmax(scale, 1e-300);
         st.primal = f_t - gapv;                   // c'psi = g - (nu - c)'(psi + h)
-        st.pg = T[7] / fmax(1.0, fabs(f_t));
-        gp_sq = T[8];
+        st.pg = T(7) / fmax(1.0, fabs(f_t));
+        gp_sq = T(8);
         const bool was_first = st.first != 0;
         st.first = 0;
         const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
@@ -448,26 +444,26 @@ iter_kernel(IterArgs a)
             new_dir = true;
             if (wave_active) {                           // (waves without variables need no direction: they wait at the next barrier)
             const int keep_old = was_first ? 0 : (pair_ok ? (old_hist0 < M ? old_hist0 : M - 1) : old_hist0);
-            rho[0] = pair_ok ? 1.0 / T[4] : 0.0;
+            rho[0] = pair_ok ? 1.0 / T(4) : 0.0;
 #pragma unroll
             for (int k = 1; k < P; ++k) if (k - 1 >= keep_old) rho[k] = 0.0;
 #pragma unroll
             for (int k = 0; k < P; ++k) {
-                double t = T[9 + k];
+                double t = T(9 + k);
 #pragma unroll
-                for (int j = 0; j < k; ++j) t -= al[j] * T[19 + k * (k - 1) / 2 + j];
+                for (int j = 0; j < k; ++j) t -= al[j] * T(19 + k * (k - 1) / 2 + j);
                 al[k] = uni(rho[k] * t);           // (wave-uniform: lives in SGPRs)
             }
 #pragma unroll
             for (int k = P - 1; k >= 0; --k) {
-                double t = T[14 + k];
+                double t = T(14 + k);
 #pragma unroll
                 for (int j = 0; j < P; ++j) {
                     const int hi = j > k ? j : k, lo = j > k ? k : j;
-                    t -= al[j] * T[29 + hi * (hi + 1) / 2 + lo];
+                    t -= al[j] * T(29 + hi * (hi + 1) / 2 + lo);
                 }
 #pragma unroll
-                for (int j = k + 1; j < P; ++j) t += ga[j] * T[19 + j * (j - 1) / 2 + k];
+                for (int j = k + 1; j < P; ++j) t += ga[j] * T(19 + j * (j - 1) / 2 + k);
                 ga[k] = uni(al[k] - rho[k] * t);
             }
             }

@@ -1593,8 +1593,13 @@ selftest_kernel(int *out)
 
 // start of a solve: group variable = mean over members of (log nu0_j - off_j), clamped
 __global__ void __launch_bounds__(UPD_THREADS)
-start_kernel(UpdArgs a, const double *__restrict__ nu0)
+start_kernel(UpdArgs a, const double *nu0, double *zero, long long nzero, DevState *st_clear, int n_clear)
 {
+    // (nu0 may be a.nu_acc itself: every element is read before the first one is written.  `zero` / `st_clear`: the
+    //  accumulator sets and the spare solver-state records of the one-launch iteration, cleared here instead of by
+    //  separate fill operations on the stream)
+    for (long long j = threadIdx.x; j < nzero; j += blockDim.x) zero[j] = 0.0;
+    if ((int)threadIdx.x < n_clear) { DevState z = {}; st_clear[threadIdx.x] = z; }
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *sum = lds, *cnt = lds + a.ng;
     const int tid = threadIdx.x, nt = blockDim.x;

@@ -14,7 +14,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
 
-shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{tag}_bench.json"))
+for name in ("bench.json", "bench_C4.json", "bench_dist1.json", "upload.json", "kernel_durations.json"):
+    if os.path.exists(os.path.join(SRC, name)):
+        shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{tag}_{name}"))
 for d in sorted(glob.glob(os.path.join(SRC, "trace_*"))):
     name = os.path.basename(d)[len("trace_"):]
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
