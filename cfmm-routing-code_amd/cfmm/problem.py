@@ -628,11 +628,16 @@ class Problem:
 
     def _finish(self, st, nu, psi, total):
         u = self.utility
-        psi = psi.copy()
-        for rec, th in self._theta.values():
-            psi += th * self._fill_vector(rec)
-        r = psi + u.h
+        if self._theta:
+            psi = psi.copy()
+            for rec, th in self._theta.values():
+                psi += th * self._fill_vector(rec)
+        plain = getattr(u, "_plain", None)
+        if plain is None:                    # h == 0 and psi >= 0 everywhere (arbitrage.py:57,77): a shorter certificate check
+            plain = u._plain = bool(not u.h.any() and not u.ctype.any())
+        r = psi if plain else psi + u.h
         self.value = float(u.c @ psi)
+        cs = float((nu - u.c) @ r)                            # complementary slackness (nu - c)'(psi + h)
         if st.get("method") == _lib.METHODS["newton"]:
             # psi is the barrier-smoothed primal point (strictly inside every pool's trading set); the dual value
             # and the gap against it were computed on the device from an exact evaluation at nu
@@ -640,10 +645,15 @@ class Problem:
             self.gap = abs(float(st["gap"]))
         else:
             # sum_i arb_i = nu'psi_pools; tied pools trade value-neutrally at their kink prices
-            self.dual_value = float((nu - u.c) @ u.h + nu @ psi)
-            self.gap = abs(float((nu - u.c) @ r)) / max(1.0, abs(self.dual_value))
-        viol = np.where(u.ctype == GE, np.maximum(-r, 0.0), np.where(u.ctype == EQ, np.abs(r), 0.0))
-        self.infeas = float(viol.max() / max(np.abs(psi).max(), np.abs(u.h).max(), 1e-300))
+            self.dual_value = float(nu @ psi) if plain else float((nu - u.c) @ u.h + nu @ psi)
+            self.gap = abs(cs) / max(1.0, abs(self.dual_value))
+        if plain:
+            viol = max(-float(r.min()), 0.0)
+            scale = max(float(psi.max()), -float(psi.min()), 1e-300)
+        else:
+            viol = float(np.where(u.ctype == GE, np.maximum(-r, 0.0), np.where(u.ctype == EQ, np.abs(r), 0.0)).max())
+            scale = max(float(np.abs(psi).max()), float(np.abs(u.h).max()), 1e-300)
+        self.infeas = viol / scale
         self.nu, self.psi = nu, psi
         self.status = _lib.STATUS.get(st["status"], f"error {st['status']}")
         # "optimal" means what the caller asked for: both certificates at the requested tolerance (the recomputation

@@ -533,7 +533,7 @@ UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
 // applies when the update fits the evaluation launch: no price ties, <= 2048 tokens, memory <= 4
 bool fused_applies(cfmm_ctx *ctx, const cfmm_opts &o)
 {
-    return ctx->fused && ctx->ng == ctx->n && ctx->n <= 2 * EVAL_THREADS && o.memory <= GRAM_MM;
+    return ctx->fused && ctx->ng == ctx->n && ctx->n <= 2 * EVAL_THREADS && o.memory <= ITER_MM;
 }
 
 size_t acc_set_doubles(cfmm_ctx *ctx) { return (size_t)ctx->nslices * acc_stride(ctx->n); }
@@ -1561,7 +1561,7 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     cfmm_opts o;
     if (opts_in) o = *opts_in; else cfmm_default_opts(&o);
-    if (o.memory == 0) o.memory = ctx->n <= 32 ? 8 : 4;      // auto: tiny problems afford (nearly) full quasi-Newton memory
+    if (o.memory == 0) o.memory = ctx->n <= 32 ? 8 : 3;      // auto: tiny problems afford (nearly) full quasi-Newton memory; else 3 (iterate.hpp: ITER_MM)
     if (o.memory < 1 || o.memory > MAX_MEMORY || o.iters_per_graph < 1 || o.iters_per_graph > 256 || o.max_evals < 1)
         return fail(ctx, CFMM_E_ARG, "solve: memory %d, iters_per_graph %d, max_evals %d", o.memory, o.iters_per_graph, o.max_evals);
     if (o.method < CFMM_METHOD_AUTO || o.method > CFMM_METHOD_NEWTON) return fail(ctx, CFMM_E_ARG, "solve: method %d", o.method);

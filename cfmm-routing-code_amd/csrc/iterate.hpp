@@ -16,11 +16,13 @@
 // The phase t % 3 is a kernel argument; captured graphs hold a multiple of three launches.
 // Pool-sharded: launch t -> fold A[t % 3] -> ncclAllReduce(slice 0) -> launch t+1 reads that one slice.
 //
-// The update itself is the Gram form of kernels.hpp (update_gram_kernel; mirrors oracle/cfmm_oracle.c:oracle_step):
-// all 44 scalars the accept test, the stopping rule and the two-loop recursion need come out of ONE batched
-// reduce-scatter.  To fit the evaluation kernel's register budget (128 VGPRs at 16 waves per CU; the stand-alone
-// Gram kernel uses 223) the 64 per-lane products are never alive together: values i and i + 32 are produced as a pair
-// and immediately exchanged across the wave halves (v_permlane32_swap), which leaves 32 running values.
+// The update itself is the Gram form of kernels.hpp (update_gram_kernel; mirrors oracle/cfmm_oracle.c:oracle_step) with a
+// history of 3 pairs: all 32 scalars the accept test, the stopping rule and the two-loop recursion need come out of ONE
+// batched reduce-scatter.  To fit the evaluation kernel's register budget (128 VGPRs at 16 waves per CU; the
+// stand-alone Gram kernel uses 223) the per-lane products are never alive together: values i and i + 16 are produced
+// as a pair and immediately exchanged across row pairs (v_permlane16_swap), which leaves 16 running values; every thread
+// owns E = 2 variables, the update runs in two halves that reload what they need instead of holding it, and its uniform
+// scalars live in SGPRs (v_readfirstlane / v_readlane).
 #pragma once
 #include <utility>
 #include "kernels.hpp"
@@ -31,7 +33,16 @@ namespace cfmm {
 #define ITER_E_SMALL_DEF 2
 #endif
 constexpr int ITER_E_SMALL = ITER_E_SMALL_DEF;  // variables per thread of the in-launch update up to EVAL_THREADS tokens (2 beyond)
-constexpr int ITER_RING = GRAM_MM + 1;      // physical history slots (window GRAM_MM)
+// history of the in-launch update: 3 pairs.  On the BASELINE configs memory 3 needs no more evaluations than 4 (mean over
+// 12 instances 32.0 against 34.4; 2: 39.3, 5: 34.5, 6: 34.7) and makes the batch exactly 32 scalars -- one register-lean
+// reduce-scatter, two vectors less to load in every workgroup
+constexpr int ITER_MM = 3;                  // history pairs kept by the in-launch update
+constexpr int ITER_P = ITER_MM + 1;         // + the new pair
+constexpr int ITER_RING = ITER_MM + 1;      // physical history slots (window ITER_MM)
+// layout of the batched scalars (8 + 2 P + P (P - 1) / 2 + P (P + 1) / 2 = 32 for P = 4)
+constexpr int GI_U = 8, GI_V = GI_U + ITER_P, GI_SY = GI_V + ITER_P, GI_YHY = GI_SY + ITER_P * (ITER_P - 1) / 2,
+              GI_END = GI_YHY + ITER_P * (ITER_P + 1) / 2;
+static_assert(GI_END <= 32, "the batch must fit one 32-value reduce-scatter");
 constexpr int XS_VECS = 5;                  // s | s_t | Gs | d | trial prices, per state set
 __host__ __device__ inline int iter_xvs(int n) { return (n + 3) & ~1; }      // vector stride of a state set: >= n + 2 (the stop flag rides at [n]), even
 
@@ -74,13 +85,13 @@ template <int E> __device__ __forceinline__ void stE(double *p, int first, int l
     if (first < len) p[first] = v[0];
 }
 
-// what one thread contributes to the 44 batched scalars (update_gram_kernel's layout):
-//   0 f_lin 1 gapv 2 Gs.ds 3 Gs_t.ds 4 s.y 5 s.s 6 y.y 7 pg 8 |q0|^2 | 9..13 u_k = s_k.q0 | 14..18 v_k = y_k.H0 q0
-//   19..28 SY[k][j] = s_k.y_j (k > j) | 29..43 YHY[k][j] = y_k.H0 y_j (k >= j)          pairs newest first, 0 = the new one
+// what one thread contributes to the batched scalars:
+//   0 f_lin 1 gapv 2 Gs.ds 3 Gs_t.ds 4 s.y 5 s.s 6 y.y 7 pg | GI_U.. u_k = s_k.q0 | GI_V.. v_k = y_k.H0 q0
+//   GI_SY.. SY[k][j] = s_k.y_j (k > j) | GI_YHY.. YHY[k][j] = y_k.H0 y_j (k >= j)          pairs newest first, 0 = the new one
 template <int E>
 struct GramIn {
-    double g1[9];
-    double S[GRAM_P][E], Y[GRAM_P][E], q0[E], H0[E], hq[E];
+    double g1[8];
+    double S[ITER_P][E], Y[ITER_P][E], q0[E], H0[E], hq[E];
 };
 __host__ __device__ constexpr int sy_row(int c) { int k = 1; while (k * (k + 1) / 2 <= c) ++k; return k; }            // c = k(k-1)/2 + j, j < k
 __host__ __device__ constexpr int yhy_row(int c) { int k = 0; while ((k + 1) * (k + 2) / 2 <= c) ++k; return k; }     // c = k(k+1)/2 + j, j <= k
@@ -88,35 +99,32 @@ template <int I, int E>
 __device__ __forceinline__ double gram_val(const GramIn<E> &in)
 {
     double r = 0.0;
-    if constexpr (I < 9) r = in.g1[I];
-    else if constexpr (I < 14) {
+    if constexpr (I < GI_U) r = in.g1[I];
+    else if constexpr (I < GI_V) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) r = fma(in.S[I - 9][e], in.q0[e], r);
-    } else if constexpr (I < 19) {
+        for (int e = 0; e < E; ++e) r = fma(in.S[I - GI_U][e], in.q0[e], r);
+    } else if constexpr (I < GI_SY) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) r = fma(in.Y[I - 14][e], in.hq[e], r);
-    } else if constexpr (I < 29) {
-        constexpr int c = I - 19, k = sy_row(c), j = c - k * (k - 1) / 2;
-        static_assert(j >= 0 && j < k && k < GRAM_P, "SY index");
+        for (int e = 0; e < E; ++e) r = fma(in.Y[I - GI_V][e], in.hq[e], r);
+    } else if constexpr (I < GI_YHY) {
+        constexpr int c = I - GI_SY, k = sy_row(c), j = c - k * (k - 1) / 2;
+        static_assert(j >= 0 && j < k && k < ITER_P, "SY index");
 #pragma unroll
         for (int e = 0; e < E; ++e) r = fma(in.S[k][e], in.Y[j][e], r);
-    } else if constexpr (I < 44) {
-        constexpr int c = I - 29, k = yhy_row(c), j = c - k * (k + 1) / 2;
-        static_assert(j >= 0 && j <= k && k < GRAM_P, "YHY index");
+    } else if constexpr (I < GI_END) {
+        constexpr int c = I - GI_YHY, k = yhy_row(c), j = c - k * (k + 1) / 2;
+        static_assert(j >= 0 && j <= k && k < ITER_P, "YHY index");
 #pragma unroll
         for (int e = 0; e < E; ++e) r = fma(in.H0[e] * in.Y[k][e], in.Y[j][e], r);
     }
     return r;
 }
 
-// The batched wave reduction, in two register-lean batches (the evaluation kernel leaves ~128 VGPRs per wave):
-//   batch A, quantities 0..31: values i and i + 16 are produced as a pair and exchanged across row pairs at once
-//     (v_permlane16_swap: even rows keep i, odd rows i + 16), so only 16 running values exist; four halving steps
-//     inside the rows of 16 lanes (DPP row_ror:8, ds_swizzle xor 4, quad_perm) and one xor-32 butterfly leave the wave
-//     total of quantity l in lane l (l < 32);
-//   batch B, quantities 32..47: pairs (j, j + 8) exchanged inside the rows (8 running values), three halving steps,
-//     two butterflies (xor 16, xor 32): lane l ends with the total of quantity 32 + (l & 15).
-// 32 + 17 exchange-adds; the 64-value form of kernels.hpp needs 63 and 128 VGPRs of running values.
+// The batched wave reduction, register-lean (the evaluation kernel leaves ~128 VGPRs per wave): values i and i + 16 are
+// produced as a pair and exchanged across row pairs at once (v_permlane16_swap: even rows keep i, odd rows i + 16), so
+// only 16 running values exist; four halving steps inside the rows of 16 lanes (DPP row_ror:8, ds_swizzle xor 4,
+// quad_perm) and one xor-32 butterfly leave the wave total of quantity l in lane l (l < 32).  32 exchange-adds; the
+// 64-value form of kernels.hpp needs 63 and 128 VGPRs of running values.
 template <int I, int E>
 __device__ __forceinline__ double gram_pair16(const GramIn<E> &in)
 {
@@ -132,19 +140,7 @@ __device__ __forceinline__ void gram_pairs16(const GramIn<E> &in, double (&v)[16
 {
     ((v[I] = gram_pair16<I, E>(in)), ...);
 }
-template <int J, int E>
-__device__ __forceinline__ double gram_pair8(const GramIn<E> &in, bool b8)
-{
-    const double a = gram_val<32 + J, E>(in), b = gram_val<32 + J + 8, E>(in);
-    const double keep = b8 ? b : a, send = b8 ? a : b;
-    return keep + dppd_ror8(send);
-}
-template <int E, int... J>
-__device__ __forceinline__ void gram_pairs8(const GramIn<E> &in, double (&v)[8], bool b8, std::integer_sequence<int, J...>)
-{
-    ((v[J] = gram_pair8<J, E>(in, b8)), ...);
-}
-// halving steps 4, 2, 1 inside a row of 16 lanes on v[0..3]: lane l ends with the row total of quantity (l & 7) [+ 8 for b8 lanes]
+// halving steps 4, 2, 1 inside a row of 16 lanes on v[0..7]: lane l ends with the row total of quantity (l & 7) [+ 8 for b8 lanes]
 __device__ __forceinline__ double row_halve4(double (&v)[8], int lane)
 {
     const bool b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
@@ -161,45 +157,34 @@ __device__ __forceinline__ double row_halve4(double (&v)[8], int lane)
     const double keep = b1 ? v[1] : v[0], send = b1 ? v[0] : v[1];
     return keep + dpp_f64<0xB1>(send);
 }
-// returns {total of quantity lane (lanes < 32), total of quantity 32 + (lane & 15)}
+// returns in lane l < 32 the wave total of quantity l (lanes 32..63 hold a copy)
 template <int E>
-__device__ __forceinline__ void gram_reduce48(const GramIn<E> &in, int lane, double &qa, double &qb)
+__device__ __forceinline__ double gram_reduce32(const GramIn<E> &in, int lane)
 {
     const bool b8 = lane & 8;
-    double x, y;
-    {
-        double v[16];
-        gram_pairs16<E>(in, v, std::make_integer_sequence<int, 16>{});
-        double w[8];
+    double v[16];
+    gram_pairs16<E>(in, v, std::make_integer_sequence<int, 16>{});
+    double w[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const double keep = b8 ? v[i + 8] : v[i], send = b8 ? v[i] : v[i + 8];
-            w[i] = keep + dppd_ror8(send);
-        }
-        const double r = row_halve4(w, lane);
-        swap32_f64(r, x, y);
-        qa = x + y;
+    for (int i = 0; i < 8; ++i) {
+        const double keep = b8 ? v[i + 8] : v[i], send = b8 ? v[i] : v[i + 8];
+        w[i] = keep + dppd_ror8(send);
     }
-    {
-        double w[8];
-        gram_pairs8<E>(in, w, b8, std::make_integer_sequence<int, 8>{});
-        double r = row_halve4(w, lane);
-        swap16_f64(r, x, y); r = x + y;
-        swap32_f64(r, x, y);
-        qb = x + y;
-    }
+    const double r = row_halve4(w, lane);
+    double x, y;
+    swap32_f64(r, x, y);
+    return x + y;
 }
 
-// self-test of gram_reduce48 (cfmm_selftest): small-integer inputs make every product and sum exact, the reference
+// self-test of gram_reduce32 (cfmm_selftest): small-integer inputs make every product and sum exact, the reference
 // is one plain butterfly per quantity (wave_allsum, itself checked by selftest_kernel); comparison is bitwise
 template <int... I>
-__device__ __forceinline__ int gram_selfcheck(const GramIn<1> &in, int lane, double qa, double qb, std::integer_sequence<int, I...>)
+__device__ __forceinline__ int gram_selfcheck(const GramIn<1> &in, int lane, double q, std::integer_sequence<int, I...>)
 {
     int bad = 0;
     (([&] {
         const double want = wave_allsum(gram_val<I, 1>(in));
-        if (I < 32 && lane == I && qa != want) ++bad;
-        if (I >= 32 && (lane & 15) == I - 32 && qb != want) ++bad;
+        if ((lane & 31) == I && q != want) ++bad;
     }()), ...);
     return bad;
 }
@@ -209,18 +194,17 @@ selftest_gram_kernel(int *out)
     const int lane = threadIdx.x;
     GramIn<1> in;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) in.g1[i] = (double)(((lane + 2) * (i + 3)) % 17) - 8.0;
+    for (int i = 0; i < 8; ++i) in.g1[i] = (double)(((lane + 2) * (i + 3)) % 17) - 8.0;
 #pragma unroll
-    for (int k = 0; k < GRAM_P; ++k) {
+    for (int k = 0; k < ITER_P; ++k) {
         in.S[k][0] = (double)(((lane + 5) * (k + 2)) % 11) - 5.0;
         in.Y[k][0] = (double)(((lane + 1) * (k + 7)) % 13) - 6.0;
     }
     in.q0[0] = (double)((lane * 7) % 9) - 4.0;
     in.H0[0] = (double)((lane % 3) + 1);
     in.hq[0] = in.H0[0] * in.q0[0];
-    double qa, qb;
-    gram_reduce48<1>(in, lane, qa, qb);
-    atomicAdd(out, gram_selfcheck(in, lane, qa, qb, std::make_integer_sequence<int, 48>{}));
+    const double q = gram_reduce32<1>(in, lane);
+    atomicAdd(out, gram_selfcheck(in, lane, q, std::make_integer_sequence<int, 32>{}));
 }
 
 // a wave-uniform value held in SGPRs instead of one VGPR pair per lane (the update is register-bound)
@@ -231,7 +215,7 @@ __device__ __forceinline__ double uni(double v)
 }
 
 // extra LDS of iter_kernel behind eval_kernel's carve: wave-private copies of the 48 batch totals
-__host__ __device__ inline int iter_extra_lds_doubles() { return 16 * 48; }
+__host__ __device__ inline int iter_extra_lds_doubles() { return 0; }
 
 // PLAIN: the utility has h == 0, every token CFMM_GE and no upper bounds (linear-utility arbitrage, arbitrage.py:57,77):
 // three of the update's vectors are never read and their registers do not exist (the other instantiation spills a few)
@@ -240,7 +224,7 @@ __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 iter_kernel(IterArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int MM = GRAM_MM, P = GRAM_P, RS = ITER_RING;
+    constexpr int MM = ITER_MM, P = ITER_P, RS = ITER_RING;
     const int n = a.n, M = a.M;
     const int tid = threadIdx.x, lane = tid & 63, wave = uni((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     // LDS carve of eval_kernel<false, .>; the update borrows the waves' exchange strips (16 KB, free until the tile loop)
@@ -251,8 +235,8 @@ iter_kernel(IterArgs a)
     double *fpart = nu_s + n + 2;                        // [16]
     int *next_tile = reinterpret_cast<int *>(fpart + 16);
     double *strips = lds + eval_lds_doubles(n, false, DET);
-    double *xw = strips;                                 // [16][64] per-wave sums
-    double *xm = xw + 16 * 64;                           // [16][2] maxima
+    double *xw = strips;                                 // [16][32] per-wave sums
+    double *xm = xw + 16 * 32;                           // [16][2] maxima
     BlockRed red(xm + 32);                               // [2][12][16]
     double *gst_s = psi_s;                               // [n] trial gradient, stashed between the two halves of the update
 
@@ -301,7 +285,7 @@ iter_kernel(IterArgs a)
     GramIn<E> in;
     bool act[E];
     double mx[2] = {0.0, 0.0};
-    double qa = 0.0, qb = 0.0;
+    double qa = 0.0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         act[e] = true; in.q0[e] = in.H0[e] = in.hq[e] = 0.0;
@@ -344,7 +328,7 @@ iter_kernel(IterArgs a)
         double fpools = 0.0;
         if (tid < a.nread) fpools = Ar[(size_t)tid * stride + acc_arb(n)];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) in.g1[i] = 0.0;
+        for (int i = 0; i < 8; ++i) in.g1[i] = 0.0;
         in.g1[0] = fpools;
         double Gs_t[E];
 #pragma unroll
@@ -371,7 +355,6 @@ iter_kernel(IterArgs a)
                 in.g1[7] += fabs(v);
                 act[e] = PLAIN ? (sr <= glo[e] + 1e-14 && G > 0.0) : is_active(sr, glo[e], ghi[e], G);
                 in.q0[e] = act[e] ? 0.0 : G;
-                in.g1[8] += in.q0[e] * in.q0[e];
                 const double H = Ds[e] + fmax(G, 0.0);
                 in.H0[e] = H > 0.0 ? rcp_nr(H) : 0.0;
                 in.hq[e] = in.H0[e] * in.q0[e];
@@ -379,18 +362,17 @@ iter_kernel(IterArgs a)
             }
         }
         PHASE_STAMP(a.ev.ts, 18);
-        gram_reduce48<E>(in, lane, qa, qb);
+        qa = gram_reduce32<E>(in, lane);
         PHASE_STAMP(a.ev.ts, 19);
         mx[0] = wave_allmax(mx[0]); mx[1] = wave_allmax(mx[1]);
     }
-    if (lane < 32) xw[wave * 64 + lane] = qa;
-    else if (lane < 48) xw[wave * 64 + lane] = qb;       // (lane - 32 = lane & 15 there)
+    if (lane < 32) xw[wave * 32 + lane] = qa;
     if (lane == 0) { xm[wave * 2] = mx[0]; xm[wave * 2 + 1] = mx[1]; }
     __syncthreads();
     // every wave sums the per-wave rows itself: lane l ends with total l, and the scalar sections below fetch a total
     // with two v_readlane (into SGPRs: no second barrier, no LDS broadcast round trips on the dependent chain)
     double tl = 0.0;
-    if (lane < 48) for (int w = 0; w < nw; ++w) tl += xw[w * 64 + lane];
+    if (lane < 32) for (int w = 0; w < nw; ++w) tl += xw[w * 32 + lane];
     const int tl_lo = __double2loint(tl), tl_hi = __double2hiint(tl);
     auto T = [&](int i) { return __hiloint2double(__builtin_amdgcn_readlane(tl_hi, i), __builtin_amdgcn_readlane(tl_lo, i)); };
     PHASE_STAMP(a.ev.ts, 20);
@@ -432,7 +414,7 @@ iter_kernel(IterArgs a)
         st.infeas = viol / fmax(scale, 1e-300);
         st.primal = f_t - gapv;                   // c'psi = g - (nu - c)'(psi + h)
         st.pg = T(7) / fmax(1.0, fabs(f_t));
-        gp_sq = T(8);
+        gp_sq = T(7);                              // (sum |projected gradient|: positive iff some free variable has a gradient)
         const bool was_first = st.first != 0;
         st.first = 0;
         const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
@@ -449,21 +431,21 @@ iter_kernel(IterArgs a)
             for (int k = 1; k < P; ++k) if (k - 1 >= keep_old) rho[k] = 0.0;
 #pragma unroll
             for (int k = 0; k < P; ++k) {
-                double t = T(9 + k);
+                double t = T(GI_U + k);
 #pragma unroll
-                for (int j = 0; j < k; ++j) t -= al[j] * T(19 + k * (k - 1) / 2 + j);
+                for (int j = 0; j < k; ++j) t -= al[j] * T(GI_SY + k * (k - 1) / 2 + j);
                 al[k] = uni(rho[k] * t);           // (wave-uniform: lives in SGPRs)
             }
 #pragma unroll
             for (int k = P - 1; k >= 0; --k) {
-                double t = T(14 + k);
+                double t = T(GI_V + k);
 #pragma unroll
                 for (int j = 0; j < P; ++j) {
                     const int hi = j > k ? j : k, lo = j > k ? k : j;
-                    t -= al[j] * T(29 + hi * (hi + 1) / 2 + lo);
+                    t -= al[j] * T(GI_YHY + hi * (hi + 1) / 2 + lo);
                 }
 #pragma unroll
-                for (int j = k + 1; j < P; ++j) t += ga[j] * T(19 + j * (j - 1) / 2 + k);
+                for (int j = k + 1; j < P; ++j) t += ga[j] * T(GI_SY + j * (j - 1) / 2 + k);
                 ga[k] = uni(al[k] - rho[k] * t);
             }
             }

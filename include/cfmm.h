@@ -71,7 +71,7 @@ typedef struct {
     double armijo;          /* sufficient-decrease constant (1e-4)                                 */
     double max_step;        /* cap on one step in log-price (2.0)                                  */
     int32_t max_evals;      /* cap on dual evaluations (2000); a hand-over to the second-order method starts a fresh count */
-    int32_t memory;         /* L-BFGS pairs kept, 1..8; 0 = auto (8 up to 32 tokens, else 4: fewer evaluations AND a cheaper update)                                        */
+    int32_t memory;         /* L-BFGS pairs kept, 1..8; 0 = auto (8 up to 32 tokens, else 3: no more evaluations than 4..6 on average and the cheapest update)                                        */
     int32_t iters_per_graph;/* outer iterations captured per hipGraph replay (4)                   */
     int32_t pg_rule;        /* 1: stop on the projected-gradient value <= tol_gap instead (used when
                                constant-sum pools are tied: psi then lacks their fill)           */
