@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="skip the batched-solve figure")
     ap.add_argument("--cpu-solves", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--kernel-reps", type=int, default=50)
@@ -260,6 +261,31 @@ def main():
                          "note": TRAFFIC_NOTE[args.config],
                          "all_kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]},
         }
+        if world == 1 and not strong and not args.no_batch:
+            # B price vectors per pool read (cfmm_solve_batch; the parametric-sweep use of two-asset.py:34-100): B solves
+            # of the same pools under B utilities in lock-step.  Not `value` (the metric is quoted on ONE solve of this
+            # config): an extra figure in the same unit.
+            B = prob.ctx.batch_capacity()
+            rng = np.random.default_rng(1)
+            us = [cfmm.Arbitrage(net["c"] * np.exp(rng.normal(0, 0.01, net["n_tokens"]))) for _ in range(B)]
+            prob.solve_many(us, tol=args.tol, batch=B)
+            t0 = time.perf_counter(); bev = 0; bit = 0; bdev = 0.0
+            for _ in range(args.steps):
+                res = prob.solve_many(us, tol=args.tol, batch=B)
+                if any(r["status"] != "optimal" for r in res):
+                    raise SystemExit("batched solve: " + ", ".join(r["status"] for r in res))
+                bev += sum(r["stats"]["evals"] for r in res); bit += max(r["stats"]["evals"] for r in res)
+                bdev += res[0]["stats"]["device_seconds"]
+            bdt = time.perf_counter() - t0
+            out["batched"] = {"solves_per_batch": B, "value": bev * prob.m / bdt, "unit": "pool-subproblems/s",
+                              "ms_per_batch": 1e3 * bdt / args.steps, "ms_per_solve": 1e3 * bdt / args.steps / B,
+                              "device_us_per_lockstep_iteration": 1e6 * bdev / max(bit, 1),
+                              "device_us_per_solve_iteration": 1e6 * bdev / max(bev, 1),
+                              "note": f"{B} cold solves of the same pools under {B} market-value vectors (1 % apart) in lock-step: every "
+                                      "outer iteration reads every pool column once and solves each pool at all price vectors "
+                                      "(eval_batch_kernel + one update workgroup per solve); wall time includes the host-side start "
+                                      "prices and certificate checks of every solve"}
+            prob.set_utility(cfmm.Arbitrage(net["c"]))
         if world == 1 and not args.no_cpu:
             from oracle.c_oracle import Oracle
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

@@ -55,7 +55,7 @@ _lib = None
 
 SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm_backend", "cfmm_default_opts",
            "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_set_pool_flags", "cfmm_set_utility",
-           "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_solve", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
+           "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_comm_unique_id", "cfmm_comm_init",
            "cfmm_oneshot_export", "cfmm_oneshot_import", "cfmm_oneshot_attach", "cfmm_oneshot_mailbox",
            "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
@@ -88,6 +88,8 @@ def lib():
     L.cfmm_eval_smooth.argtypes = [vp, dp, C.c_double, dp, dp, dp, dp]
     L.cfmm_debug_cholesky.argtypes = [vp, C.c_int, dp, dp, dp, ip]
     L.cfmm_solve.argtypes = [vp, dp, C.POINTER(Opts), C.POINTER(Stats)]
+    L.cfmm_solve_batch.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(dp), C.POINTER(Opts), C.POINTER(Stats)]
+    L.cfmm_batch_capacity.argtypes = [C.c_int]
     L.cfmm_get_nu.argtypes = [vp, dp]; L.cfmm_set_nu.argtypes = [vp, dp]; L.cfmm_get_psi.argtypes = [vp, dp]
     L.cfmm_get_solution.argtypes = [vp, dp, dp]
     L.cfmm_get_trades2.argtypes = [vp, C.c_int, dp, dp]
@@ -229,11 +231,12 @@ class Context:
         self.L.cfmm_default_opts(C.byref(o))
         return o
 
-    def solve(self, nu0=None, **kw):
+    def _opts(self, kw):
         d = getattr(self, "_opts0", None)
         if d is None:                       # the defaults are fetched once per context (a ctypes call each is 5 % of a 0.7 ms solve)
             d = self._opts0 = bytes(self.default_opts())
         o = Opts.from_buffer_copy(d)
+        kw = dict(kw)
         if "tol" in kw:
             o.tol_gap = o.tol_infeas = kw.pop("tol")
         if isinstance(kw.get("method"), str):
@@ -242,6 +245,27 @@ class Context:
             if not hasattr(o, k):
                 raise TypeError(f"unknown solver option {k!r}")
             setattr(o, k, v)
+        return o
+
+    def batch_capacity(self):
+        """solves that cfmm_solve_batch takes per call at this token count"""
+        return int(self.L.cfmm_batch_capacity(self.n))
+
+    def solve_batch(self, clones, nu0s=None, **kw):
+        """this context and `clones` (its clone()s), each with its own utility set, solved in lock-step: every pool
+        column is read once per outer iteration for all of them (cfmm_solve_batch).  Returns one stats dict per solve."""
+        ctxs = [self] + list(clones)
+        nb = len(ctxs)
+        o = self._opts(kw)
+        hs = (C.c_void_p * nb)(*[c.h for c in ctxs])
+        keep = [None if nu0s is None or nu0s[b] is None else f64(nu0s[b]) for b in range(nb)]
+        ptrs = (C.POINTER(C.c_double) * nb)(*[_d(a) if a is not None else C.POINTER(C.c_double)() for a in keep])
+        st = (Stats * nb)()
+        self._chk(self.L.cfmm_solve_batch(hs, nb, ptrs, C.byref(o), st))
+        return [st[b].asdict() for b in range(nb)]
+
+    def solve(self, nu0=None, **kw):
+        o = self._opts(kw)
         st = Stats()
         nu0 = f64(nu0)
         self._chk(self.L.cfmm_solve(self.h, _d(nu0), C.byref(o), C.byref(st)))

@@ -347,14 +347,28 @@ class Problem:
         q._uploaded = True
         return q
 
-    def solve_many(self, utilities, concurrency=2, nu0s=None, warm_start=False, **kw):
-        """Solve the same pools under many utilities (the two-asset.py:34-100 sweep; independent baskets).
-        `concurrency` clones work through the list from as many host threads; while one solve is inside its
-        single-workgroup nu update, the evaluation kernels of another fill the GPU.  Returns one dict per
-        utility, in order: value, status, psi, nu, gap, infeas, stats.  With warm_start each worker starts
-        a solve from the prices of its previous one."""
-        import threading
+    def solve_many(self, utilities, concurrency=2, nu0s=None, warm_start=False, batch=None, **kw):
+        """Solve the same pools under many utilities (the two-asset.py:34-100 sweep; independent baskets).  Returns one
+        dict per utility, in order: value, status, psi, nu, gap, infeas, stats.
+
+        Batched (the default wherever it applies: first-order method, no constant-sum / stableswap pools, one GPU):
+        `batch` solves at a time (default: as many as the LDS tile takes, 8 up to ~1100 tokens) run in lock-step through
+        cfmm_solve_batch -- every outer iteration reads every pool column once for all of them.  With warm_start the
+        solves of one group start from the prices the same slot reached in the previous group.
+        Otherwise (`batch=0`, or a network the batched path does not take): `concurrency` clones work through the list
+        from as many host threads."""
         utilities = list(utilities)
+        ctx = self._ensure_ctx()
+        can_batch = (hasattr(ctx, "solve_batch") and "sum2" not in self.net and "curve2" not in self.net and self._host is None
+                     and not self.deterministic and kw.get("method", "auto") in ("auto", "lbfgs"))
+        if batch is None:
+            batch = ctx.batch_capacity() if can_batch else 0
+        if batch and not can_batch:
+            raise ValueError("solve_many(batch=...): the batched path takes first-order solves of networks without constant-sum / "
+                             "stableswap pools on one GPU")
+        if batch:
+            return self._solve_batched(utilities, int(batch), nu0s, warm_start, **kw)
+        import threading
         workers = [self] + [self.clone() for _ in range(max(1, int(concurrency)) - 1)]
         results = [None] * len(utilities)
         errors = []
@@ -372,8 +386,7 @@ class Problem:
                     p.set_utility(utilities[i])
                     p.solve(nu0=None if nu0s is None else nu0s[i], warm_start=warm_start and not first, **kw)
                     first = False
-                    results[i] = dict(value=p.value, status=p.status, psi=p.psi, nu=p.nu, gap=p.gap, infeas=p.infeas,
-                                      dual_value=p.dual_value, stats=p.stats)
+                    results[i] = p._result()
             except Exception as e:       # surfaced in the caller's thread
                 errors.append(e)
 
@@ -386,6 +399,46 @@ class Problem:
             p.close()
         if errors:
             raise errors[0]
+        return results
+
+    def _result(self):
+        return dict(value=self.value, status=self.status, psi=self.psi, nu=self.nu, gap=self.gap, infeas=self.infeas,
+                    dual_value=self.dual_value, stats=self.stats)
+
+    def _solve_batched(self, utilities, batch, nu0s, warm_start, tol=1e-6, max_evals=2000, memory=0, method="auto", **kw):
+        if kw:
+            raise TypeError(f"solve_many: unknown option(s) {sorted(kw)}")
+        ctx = self._ensure_ctx()
+        batch = max(1, min(batch, ctx.batch_capacity(), len(utilities) or 1))
+        workers = getattr(self, "_batch_workers", None) or [self]
+        while len(workers) < batch:
+            workers.append(self.clone())
+        self._batch_workers = workers          # (kept: the next sweep over these pools reuses the clones' state buffers)
+        results = []
+        for g0 in range(0, len(utilities), batch):
+            group = utilities[g0:g0 + batch]
+            ws = workers[:len(group)]
+            starts = []
+            for k, (p, u) in enumerate(zip(ws, group)):
+                p.utility = u
+                p.ctx.set_utility(u.c, u.h, u.ctype)
+                p._dev_utility = u
+                p._theta = {}; p._trade_cache = None; p._tol = tol
+                given = None if nu0s is None else nu0s[g0 + k]
+                if given is not None:
+                    starts.append(given)
+                elif warm_start and p.nu is not None:
+                    starts.append(p.nu)
+                else:
+                    starts.append(start_prices(self.net, u))
+            sts = ws[0].ctx.solve_batch([p.ctx for p in ws[1:]], starts, tol=tol, max_evals=max_evals, memory=memory,
+                                        method=_lib.METHODS["lbfgs"])
+            for p, st in zip(ws, sts):
+                nu, psi = p.ctx.get_solution()
+                total = dict(evals=st["evals"], iters=st["iters"], wall_seconds=st["wall_seconds"], device_seconds=st["device_seconds"],
+                             rounds=1, batch=len(group))
+                p._finish(st, nu, psi, total)
+                results.append(p._result())
         return results
 
     # -- device plumbing ---------------------------------------------------------------------
@@ -716,6 +769,9 @@ class Problem:
         return self._per_pool(1)
 
     def close(self):
+        for p in (getattr(self, "_batch_workers", None) or [])[1:]:
+            p.close()
+        self._batch_workers = None
         if self.ctx is not None:
             self.ctx.close(); self.ctx = None; self._uploaded = False
             self._dev_utility = None; self._dev_ties = False

@@ -144,6 +144,8 @@ struct cfmm_ctx {
     volatile unsigned long long *hstat_h = nullptr;     // pinned, device-mapped progress word (iterate.hpp: IterArgs::hstat)
     unsigned long long *hstat_d = nullptr;
     int run_ahead = 3;                 // CFMM_RUN_AHEAD: launches the host keeps enqueued beyond the last one the device reported
+    // batched solves (cfmm_solve_batch): the per-solve update arguments, on the lead context
+    UpdArgs *upd_batch_d = nullptr, *upd_batch_h = nullptr;
 
     // graph cache
     hipGraphExec_t gexec = nullptr;
@@ -444,13 +446,14 @@ void eval_geometry(cfmm_ctx *ctx, int ntiles, int &grid, int &threads)
 }
 
 template <bool WITH_D, bool STABLE>
-void launch_eval(cfmm_ctx *ctx, const EvalArgs &a)
+void launch_eval(cfmm_ctx *ctx, const EvalArgs &a, hipStream_t stream = nullptr)
 {
     if (a.ntiles == 0) return;
+    if (!stream) stream = ctx->stream;
     int grid, threads;
     eval_geometry(ctx, a.ntiles, grid, threads);
-    if (ctx->det) hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE, true>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D, true), ctx->stream, a);
-    else hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), ctx->stream, a);
+    if (ctx->det) hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE, true>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D, true), stream, a);
+    else hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), stream, a);
 }
 
 // reproducible mode, after the evaluation launches: [integer all-reduce of the limbs] -> det_fold_kernel writes psi,
@@ -488,12 +491,18 @@ int set_all_lds_attrs(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, eval_kernel<true, false>, e1))) return rc;
     if ((rc = set_lds_attr(ctx, eval_kernel<false, true>, e0))) return rc;
     if ((rc = set_lds_attr(ctx, eval_kernel<true, true>, e1))) return rc;
-    if ((rc = set_lds_attr(ctx, update_kernel, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, update_kernel<false>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 8, 2>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 4, 4>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_reg_kernel<256, 8, 4>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_gram_kernel<512, 2>, upd_lds_bytes(ctx->n)))) return rc;
-    if ((rc = set_lds_attr(ctx, start_kernel, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, start_kernel<false>, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, update_kernel<true>, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 8, 2, true>, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 4, 4, true>, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, update_gram_kernel<512, 2, true>, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, start_kernel<true>, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, eval_batch_kernel, batch_lds_bytes(ctx->n, batch_capacity(ctx->n))))) return rc;
     const size_t il = iter_lds_bytes(ctx->n);
     if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, false>, il))) return rc;
     if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, true>, il))) return rc;
@@ -526,6 +535,7 @@ UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
     a.st = ctx->st;
     a.tol_gap = o.tol_gap; a.tol_infeas = o.tol_infeas; a.armijo = o.armijo; a.max_step = o.max_step;
     a.max_evals = o.max_evals; a.pg_rule = o.pg_rule; a.ts = ctx->ts;
+    a.batch = nullptr; a.hstat = nullptr;
     return a;
 }
 
@@ -618,7 +628,7 @@ void launch_update(cfmm_ctx *ctx, const UpdArgs &ua)
     else if (v == 2 && n <= 1024)                   // (A/B) 4 per thread, <= 4 waves
         hipLaunchKernelGGL((update_reg_kernel<256, 8, 4>), dim3(1), dim3(thr(4)), lds, ctx->stream, ua);
     else
-        hipLaunchKernelGGL(update_kernel, dim3(1), dim3(UPD_THREADS), lds, ctx->stream, ua);
+        hipLaunchKernelGGL(update_kernel<false>, dim3(1), dim3(UPD_THREADS), lds, ctx->stream, ua);
 }
 
 // evaluation -> [fold + all-reduce] -> update : one outer iteration, enqueued on ctx->stream
@@ -1232,6 +1242,8 @@ int cfmm_destroy(cfmm_ctx *ctx)
     if (ctx->hstat_h) (void)hipHostFree((void *)ctx->hstat_h);
     if (ctx->hsol) (void)hipHostFree(ctx->hsol);
     if (ctx->hnu0) (void)hipHostFree(ctx->hnu0);
+    if (ctx->upd_batch_d) (void)hipFree(ctx->upd_batch_d);
+    if (ctx->upd_batch_h) (void)hipHostFree(ctx->upd_batch_h);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
@@ -1641,7 +1653,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
         //  prices where they are: three fill / copy operations less on the stream per solve)
         double *x0 = ctx->xs3;
         ua.s = x0; ua.s_t = x0 + ia.xvs; ua.Gs = x0 + 2 * ia.xvs; ua.d = x0 + 3 * ia.xvs; ua.nu = x0 + 4 * ia.xvs; ua.st = ctx->st3;
-        hipLaunchKernelGGL(start_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
+        hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
                            ctx->acc3, (long long)(3 * aset), ctx->st3 + 1, 2);
         for (int stable = 0; stable < 2; ++stable) {
             EvalArgs e0 = make_eval_args(ctx, stable != 0);
@@ -1655,7 +1667,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
             int rc = all_reduce(ctx, ctx->acc3, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc;
         }
     } else {
-        hipLaunchKernelGGL(start_kernel, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
+        hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
                            ctx->acc, (long long)((size_t)ctx->nslices * acc_stride(n)), (DevState *)nullptr, 0);
         { int rc = enqueue_iteration<true>(ctx, ua); if (rc) return rc; }      // first evaluation also builds the metric
     }
@@ -1741,6 +1753,144 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     if (!std::isfinite(st.f)) { out->status = CFMM_E_NUMERIC; return fail(ctx, CFMM_E_NUMERIC, "solve: dual value is not finite"); }
     return CFMM_OK;
 }
+
+// B first-order solves over ONE resident pool set in lock-step ("B price vectors per pool read"; the
+// reference use is the sweep of two-asset.py:34-100).  ctxs[0] is the lead context, the others its clones (cfmm_clone):
+// each holds its own utility, prices and solver state.  Per outer iteration TWO launches serve all B solves:
+//   eval_batch_kernel    every pool column read once, every pool solved at the B price vectors
+//   update_*_kernel<BATCH>   B workgroups, one projected L-BFGS step each
+// A solve that has ended drops out of both (its stop flag / status), the loop ends when all have.  The first evaluation
+// of every solve also builds the diagonal metric and runs through eval_kernel, one launch per solve.
+int cfmm_solve_batch(cfmm_ctx *const *ctxs, int nb, const double *const *nu0, const cfmm_opts *opts_in, cfmm_stats *out)
+{
+    if (!ctxs || nb < 1 || !ctxs[0] || !out) return CFMM_E_ARG;
+    cfmm_ctx *c0 = ctxs[0];
+    HIP_TRY(c0, hipSetDevice(c0->device));
+    const int n = c0->n;
+    if (nb > batch_capacity(n)) return fail(c0, CFMM_E_LIMIT, "solve_batch: %d solves, at most %d fit the LDS tile at %d tokens", nb, batch_capacity(n), n);
+    cfmm_opts o;
+    if (opts_in) o = *opts_in; else cfmm_default_opts(&o);
+    if (o.memory == 0) o.memory = n <= 32 ? 8 : 3;
+    if (o.memory < 1 || o.memory > MAX_MEMORY || o.max_evals < 1) return fail(c0, CFMM_E_ARG, "solve_batch: memory %d, max_evals %d", o.memory, o.max_evals);
+    if (o.method == CFMM_METHOD_NEWTON) return fail(c0, CFMM_E_UNSUPPORTED, "solve_batch: first-order method only");
+    for (int b = 0; b < nb; ++b) {
+        cfmm_ctx *c = ctxs[b];
+        if (!c) return fail(c0, CFMM_E_ARG, "solve_batch: context %d is NULL", b);
+        for (int q = 0; q < b; ++q) if (ctxs[q] == c) return fail(c0, CFMM_E_ARG, "solve_batch: context %d appears twice", b);
+        if (c->pools.get() != c0->pools.get() || c->n != n || c->device != c0->device || c->nslices != c0->nslices)
+            return fail(c0, CFMM_E_ARG, "solve_batch: context %d does not share the lead context's pools (cfmm_clone)", b);
+        if (c->ng != n || c->flags2) return fail(c0, CFMM_E_UNSUPPORTED, "solve_batch: context %d has price ties set", b);
+        if (sharded(c) || c->det) return fail(c0, CFMM_E_UNSUPPORTED, "solve_batch: pool-sharded / reproducible contexts are solved one at a time");
+        if (!c->have_utility) return fail(c0, CFMM_E_STATE, "solve_batch: context %d has no utility", b);
+        if (nu0 && nu0[b]) { int rc = cfmm_set_nu(c, nu0[b]); if (rc) { c0->err = c->err; return rc; } }
+        if (!c->have_nu) return fail(c0, CFMM_E_STATE, "solve_batch: context %d has no start prices", b);
+        c->warm_mu = 0.0; c->mu_last = 0.0;
+        HIP_TRY(c0, hipStreamSynchronize(c->stream));
+    }
+    if (cfmm_pool_count(c0) == 0) return fail(c0, CFMM_E_STATE, "solve_batch: no pools uploaded");
+    if (c0->pools->b2[CFMM_POOL_CURVE2].m > 0) return fail(c0, CFMM_E_UNSUPPORTED, "solve_batch: stableswap pools take the second-order path, one solve at a time");
+    if (!c0->upd_batch_d) {
+        HIP_TRY(c0, hipMalloc((void **)&c0->upd_batch_d, BATCH_MAX * sizeof(UpdArgs)));
+        HIP_TRY(c0, hipHostMalloc((void **)&c0->upd_batch_h, BATCH_MAX * sizeof(UpdArgs), hipHostMallocDefault));
+    }
+    hipStream_t stream = c0->stream;
+    BatchArgs bt = {};
+    bt.nb = nb;
+    for (int b = 0; b < nb; ++b) {
+        UpdArgs ua = make_upd_args(ctxs[b], o);
+        ua.hstat = c0->hstat_d + b;
+        c0->upd_batch_h[b] = ua;
+        c0->hstat_h[b] = 0;
+        bt.nu[b] = ctxs[b]->nu; bt.acc[b] = ctxs[b]->acc;
+    }
+    UpdArgs lead = c0->upd_batch_h[0];
+    lead.batch = c0->upd_batch_d;
+    const EvalArgs ea = make_eval_args(c0, false);
+    int egrid, ethreads;
+    eval_geometry(c0, ea.ntiles, egrid, ethreads);
+    const size_t elds = batch_lds_bytes(n, nb), ulds = upd_lds_bytes(n);
+    auto launch_update_batch = [&]() {
+        const int M = o.memory;
+        auto thr = [n](int E) { return 64 * ((n + 64 * E - 1) / (64 * E)); };
+        if (c0->upd_generic || n > 2048 || (n > 1024 && M > 4))
+            hipLaunchKernelGGL(update_kernel<true>, dim3(nb), dim3(UPD_THREADS), ulds, stream, lead);
+        else if (n <= 1024 && M <= GRAM_MM)
+            hipLaunchKernelGGL((update_gram_kernel<512, 2, true>), dim3(nb), dim3(thr(2)), ulds, stream, lead);
+        else if (n <= 1024)
+            hipLaunchKernelGGL((update_reg_kernel<512, 8, 2, true>), dim3(nb), dim3(thr(2)), ulds, stream, lead);
+        else
+            hipLaunchKernelGGL((update_reg_kernel<512, 4, 4, true>), dim3(nb), dim3(thr(4)), ulds, stream, lead);
+    };
+
+    // ---- timed region ------------------------------------------------------------------------------
+    HIP_TRY(c0, hipStreamSynchronize(stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(c0, hipEventRecord(c0->ev_t0, stream));
+    HIP_TRY(c0, hipMemcpyAsync(c0->upd_batch_d, c0->upd_batch_h, nb * sizeof(UpdArgs), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(start_kernel<true>, dim3(nb), dim3(UPD_THREADS), ulds, stream, lead, (const double *)nullptr, (double *)nullptr,
+                       (long long)((size_t)c0->nslices * acc_stride(n)), (DevState *)nullptr, 0);
+    for (int b = 0; b < nb; ++b) launch_eval<true, false>(ctxs[b], make_eval_args(ctxs[b], false), stream);     // first evaluation: with the metric
+    launch_update_batch();
+    HIP_TRY(c0, hipGetLastError());
+    int t = 1;
+    {
+        const auto spin0 = std::chrono::steady_clock::now();
+        long spins = 0;
+        for (;;) {
+            int done = 0, running = 0;
+            for (int b = 0; b < nb; ++b) {
+                const unsigned long long w = c0->hstat_h[b];
+                done = std::max(done, (int)(w & 0xffffffffu));
+                if ((w >> 32) == 0) ++running;
+            }
+            if (!running) break;
+            if (t > o.max_evals + 1) { HIP_TRY(c0, hipStreamSynchronize(stream)); break; }      // the device ends every solve at its budget (status 3)
+            if (t - done <= c0->run_ahead) {
+                hipLaunchKernelGGL(eval_batch_kernel, dim3(egrid), dim3(ethreads), elds, stream, ea, bt);
+                launch_update_batch();
+                ++t; spins = 0;
+                continue;
+            }
+            if ((++spins & 0xfffff) == 0) {
+                if (hipGetLastError() != hipSuccess || std::chrono::duration<double>(std::chrono::steady_clock::now() - spin0).count() > 120.0)
+                    return fail(c0, CFMM_E_HIP, "solve_batch: the device stopped reporting progress (launch %d, %d done)", t, done);
+            }
+        }
+        HIP_TRY(c0, hipGetLastError());
+    }
+    HIP_TRY(c0, hipEventRecord(c0->ev_t1, stream));
+    for (int b = 0; b < nb; ++b) {
+        cfmm_ctx *c = ctxs[b];
+        HIP_TRY(c0, hipMemcpyAsync(c->hst, c->st, sizeof(DevState), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(c0, hipMemcpyAsync(c->hsol, c->nu_acc, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(c0, hipMemcpyAsync(c->hsol + n, c->psi_acc, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(c0, hipStreamSynchronize(stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    float ms = 0.f;
+    HIP_TRY(c0, hipEventElapsedTime(&ms, c0->ev_t0, c0->ev_t1));
+    int rc_all = CFMM_OK;
+    for (int b = 0; b < nb; ++b) {
+        cfmm_ctx *c = ctxs[b];
+        c->hsol_valid = true;
+        { double mx = 0.0; for (int j = 0; j < n; ++j) mx = std::max(mx, c->hsol[j]); if (mx > 0.0 && std::isfinite(mx)) c->nu_max = mx; }
+        const DevState st = c->hst[0];
+        cfmm_stats *s = out + b;
+        std::memset(s, 0, sizeof *s);
+        s->evals = st.evals; s->iters = st.iters; s->status = st.status ? st.status : 3;
+        s->n_ranks = 1;
+        s->dual_value = st.f; s->primal_value = st.primal; s->gap = st.gap; s->infeas = st.infeas;
+        s->wall_seconds = std::chrono::duration<double>(t1 - t0).count();      // (of the whole batch)
+        s->device_seconds = ms * 1e-3;
+        s->pg = st.pg;
+        s->pool_subproblems = (int64_t)st.evals * cfmm_pool_count(c0);
+        s->method = CFMM_METHOD_LBFGS;
+        if (!std::isfinite(st.f)) { s->status = CFMM_E_NUMERIC; rc_all = fail(c0, CFMM_E_NUMERIC, "solve_batch: dual value of solve %d is not finite", b); }
+    }
+    return rc_all;
+}
+
+int cfmm_batch_capacity(int n_tokens) { return n_tokens < 1 ? 0 : batch_capacity(n_tokens); }
 
 int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda)
 {

@@ -181,14 +181,24 @@ template <> struct Scatter<true> {
 };
 
 // ------------------------------------------------------------------------------------------
+// Batched evaluation (eval_batch_kernel: B price vectors per pool read -- the parametric sweep of two-asset.py:34-100,
+// independent baskets over one pool set): the B price vectors sit `nu_stride` doubles apart in LDS, their psi tiles
+// `tile_stride` apart; `alive` has one bit per vector whose solve is still running (wave-uniform).  A tile loads its
+// pool columns ONCE and solves the pools at every live price vector.
+// ------------------------------------------------------------------------------------------
+constexpr int BATCH_MAX = 8;
+struct BatchCtl { unsigned alive; int nu_stride, tile_stride; };
+
+// ------------------------------------------------------------------------------------------
 // one wave-tile of a two-asset bucket: lane l solves pools i0 + l + 64 u, u < U.  All 5U column
 // loads are issued before the first use (each 512 B coalesced per wave).
 // 32 B (CP2, SUM2) or 40 B (W2, CURVE2) of HBM per pool, read once.
 // ------------------------------------------------------------------------------------------
-template <int KIND, bool WITH_D, bool DET>
+template <int KIND, bool WITH_D, bool DET, bool BATCH = false>
 __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, const double *nu_s,
-                                      const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double &fsum)
+                                      const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double &fsum, const BatchCtl &bc)
 {
+    static_assert(!(BATCH && WITH_D), "the batched evaluation does not build the metric");
     constexpr int U = wave_tile_pools(KIND) / 64;
     asm volatile("" : "+v"(lane));              // (opaque: keeps per-kind lane arithmetic from being hoisted out of the tile loop)
     double Ra[U], Rb[U], g[U], prm[U];
@@ -204,26 +214,32 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
         prm[u] = (KIND == 1 || KIND == 3) ? b.param[i] : 0.0;
         fl[u] = (KIND == 2 && b.flags) ? b.flags[i] : 0;
     }
+#pragma unroll 1
+    for (unsigned mask = BATCH ? bc.alive : 1u; mask; mask &= mask - 1) {
+        const int bb = BATCH ? __builtin_ctz(mask) : 0;
+        const double *nub = BATCH ? nu_s + bb * bc.nu_stride : nu_s;
+        const Scatter<DET> ps{BATCH ? psi_s.t + bb * bc.tile_stride : psi_s.t, psi_s.n, psi_s.sc};
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const double pa = nu_s[ia[u]], pb = nu_s[ib[u]];
-        Y2 y;
-        if (KIND == 0) y = pool_cp2(Ra[u], Rb[u], g[u], pa, pb);
-        else if (KIND == 1) y = pool_w2<DET>(Ra[u], Rb[u], g[u], prm[u], pa, pb);
-        else if (KIND == 2) { y = pool_sum2(Ra[u], Rb[u], g[u], pa, pb); if (fl[u]) { y.ya = 0.0; y.yb = 0.0; } }
-        else y = pool_curve2(Ra[u], Rb[u], g[u], prm[u], pa, pb);
-        if (live[u] && (y.ya != 0.0 || y.yb != 0.0)) {
-            psi_s.add(ia[u], y.ya);
-            psi_s.add(ib[u], y.yb);
-            if (!DET) fsum += pa * y.ya + pb * y.yb;
-        }
-        if (WITH_D && live[u] && KIND != 2) {
-            double da = 0.0, db = 0.0;
-            if (KIND == 0) { da = 0.5 * pa * Ra[u]; db = 0.5 * pb * Rb[u]; }
-            else if (KIND == 1) { da = (1.0 - prm[u]) * pa * Ra[u]; db = prm[u] * pb * Rb[u]; }
-            else curve_diag(Ra[u], Rb[u], prm[u], pa, pb, da, db);
-            diag_s.add(ia[u], da);
-            diag_s.add(ib[u], db);
+        for (int u = 0; u < U; ++u) {
+            const double pa = nub[ia[u]], pb = nub[ib[u]];
+            Y2 y;
+            if (KIND == 0) y = pool_cp2(Ra[u], Rb[u], g[u], pa, pb);
+            else if (KIND == 1) y = pool_w2<DET>(Ra[u], Rb[u], g[u], prm[u], pa, pb);
+            else if (KIND == 2) { y = pool_sum2(Ra[u], Rb[u], g[u], pa, pb); if (fl[u]) { y.ya = 0.0; y.yb = 0.0; } }
+            else y = pool_curve2(Ra[u], Rb[u], g[u], prm[u], pa, pb);
+            if (live[u] && (y.ya != 0.0 || y.yb != 0.0)) {
+                ps.add(ia[u], y.ya);
+                ps.add(ib[u], y.yb);
+                if (!DET && !BATCH) fsum += pa * y.ya + pb * y.yb;
+            }
+            if (WITH_D && live[u] && KIND != 2) {
+                double da = 0.0, db = 0.0;
+                if (KIND == 0) { da = 0.5 * pa * Ra[u]; db = 0.5 * pb * Rb[u]; }
+                else if (KIND == 1) { da = (1.0 - prm[u]) * pa * Ra[u]; db = prm[u] * pb * Rb[u]; }
+                else curve_diag(Ra[u], Rb[u], prm[u], pa, pb, da, db);
+                diag_s.add(ia[u], da);
+                diag_s.add(ib[u], db);
+            }
         }
     }
 }
@@ -246,10 +262,11 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
 template <int K>
 __host__ __device__ constexpr int pools_per_wave() { return 64 / K; }
 
-template <int K, bool WITH_D, bool DET>
+template <int K, bool WITH_D, bool DET, bool BATCH = false>
 __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, const double *nu_s,
-                                      const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double2 *xs, double &fsum)
+                                      const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double2 *xs, double &fsum, const BatchCtl &bc)
 {
+    static_assert(!(BATCH && WITH_D), "the batched evaluation does not build the metric");
     constexpr int P = pools_per_wave<K>();
     // (opaque copy: otherwise the lane / K, lane % K and strip addresses of all six instantiations are hoisted out of
     //  the tile loop and stay live across it -- ~20 VGPRs on a kernel that sits on a register cliff)
@@ -262,45 +279,50 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
     const double R = b.R[leg], w = b.w[leg];
     const double fee = b.fee[live ? pool : 0];
     const double lg = b.lfee[live ? pool : 0];
-    const double p = nu_s[tok];
-    SCHED_FENCE();
-    const double a = log(R * p * rcp_nr(w));
-    SCHED_FENCE();
     const int gb = (g < P ? g : 0) * K;
-    xs[lane] = make_double2(a, w);                     // ds_write_b128; same-wave LDS ops stay in order
-    __builtin_amdgcn_wave_barrier();
-    const double t1 = a, t2 = a - lg;
-    double f1 = 0.0, f2 = 0.0;
+#pragma unroll 1
+    for (unsigned mask = BATCH ? bc.alive : 1u; mask; mask &= mask - 1) {
+        const int bb = BATCH ? __builtin_ctz(mask) : 0;
+        const Scatter<DET> ps{BATCH ? psi_s.t + bb * bc.tile_stride : psi_s.t, psi_s.n, psi_s.sc};
+        const double p = (BATCH ? nu_s + bb * bc.nu_stride : nu_s)[tok];
+        SCHED_FENCE();
+        const double a = log(R * p * rcp_nr(w));
+        SCHED_FENCE();
+        xs[lane] = make_double2(a, w);                     // ds_write_b128; same-wave LDS ops stay in order
+        __builtin_amdgcn_wave_barrier();
+        const double t1 = a, t2 = a - lg;
+        double f1 = 0.0, f2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const double2 v = xs[gb + k];
-        const double u1 = t1 - v.x, u2 = t2 - v.x;
-        f1 += v.y * (fmin(u1, 0.0) + fmax(u1 + lg, 0.0));
-        f2 += v.y * (fmin(u2, 0.0) + fmax(u2 + lg, 0.0));
-    }
-    SCHED_FENCE();
-    const bool wd = f1 > 0.0;                           // withdrawn at the root: t* < a_j
-    const bool dp = f2 < 0.0;                           // deposited at the root: t* > a_j - lg
-    const double den_j = (wd || dp) ? w : 0.0;
-    const double num_j = wd ? w * t1 : (dp ? w * t2 : 0.0);
-    __builtin_amdgcn_wave_barrier();
-    xs[lane] = make_double2(num_j, den_j);
-    __builtin_amdgcn_wave_barrier();
-    double num = 0.0, den = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double2 v = xs[gb + k];
+            const double u1 = t1 - v.x, u2 = t2 - v.x;
+            f1 += v.y * (fmin(u1, 0.0) + fmax(u1 + lg, 0.0));
+            f2 += v.y * (fmin(u2, 0.0) + fmax(u2 + lg, 0.0));
+        }
+        SCHED_FENCE();
+        const bool wd = f1 > 0.0;                           // withdrawn at the root: t* < a_j
+        const bool dp = f2 < 0.0;                           // deposited at the root: t* > a_j - lg
+        const double den_j = (wd || dp) ? w : 0.0;
+        const double num_j = wd ? w * t1 : (dp ? w * t2 : 0.0);
+        __builtin_amdgcn_wave_barrier();
+        xs[lane] = make_double2(num_j, den_j);
+        __builtin_amdgcn_wave_barrier();
+        double num = 0.0, den = 0.0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) { const double2 v = xs[gb + k]; num += v.x; den += v.y; }
-    __builtin_amdgcn_wave_barrier();
-    SCHED_FENCE();
-    double y = 0.0;
-    if (den > 0.0 && (wd || dp)) {
-        const double t = num * rcp_nr(den);
-        const double rx = -R * expm1_wave<DET>(wd ? t - t1 : t - t2);    // R - x,  x = R e^{f(t - a_j)}
-        y = wd ? rx : rx * rcp_nr(fee);
-    }
-    SCHED_FENCE();
-    if (live) {
-        if (y != 0.0) { psi_s.add(tok, y); if (!DET) fsum += p * y; }
-        if (WITH_D) diag_s.add(tok, (1.0 - w) * p * R);
+        for (int k = 0; k < K; ++k) { const double2 v = xs[gb + k]; num += v.x; den += v.y; }
+        __builtin_amdgcn_wave_barrier();
+        SCHED_FENCE();
+        double y = 0.0;
+        if (den > 0.0 && (wd || dp)) {
+            const double t = num * rcp_nr(den);
+            const double rx = -R * expm1_wave<DET>(wd ? t - t1 : t - t2);    // R - x,  x = R e^{f(t - a_j)}
+            y = wd ? rx : rx * rcp_nr(fee);
+        }
+        SCHED_FENCE();
+        if (live) {
+            if (y != 0.0) { ps.add(tok, y); if (!DET && !BATCH) fsum += p * y; }
+            if (WITH_D) diag_s.add(tok, (1.0 - w) * p * R);
+        }
     }
 }
 
@@ -319,9 +341,12 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
 // ~20 more VGPRs than anything else: kept out of the main instantiation, it lets that one run at 6 waves per SIMD)
 // the tile loop and the flush, shared by eval_kernel (below) and iter_kernel (iterate.hpp).  On entry nu_s holds the
 // prices, psi_s (diag_s) are zero, *next_tile is 0 and a barrier has been passed; `acc` is the accumulator set to flush into.
-template <bool WITH_D, bool STABLE, bool DET = false>
+// BATCH: `bc` describes the B price vectors / psi tiles in LDS, `acc_b[b]` is where vector b's tile is flushed; sum arb
+// is formed at the flush as nu' psi per vector (sum_i arb_i = sum_i nu' y_i) instead of being carried per lane.
+template <bool WITH_D, bool STABLE, bool DET = false, bool BATCH = false>
 __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *acc, const double *nu_s, double *psi_t, double *diag_t,
-                                                     double *fpart, int *next_tile, double2 *xs)
+                                                     double *fpart, int *next_tile, double2 *xs, const BatchCtl &bc = BatchCtl{1u, 0, 0},
+                                                     double *const *acc_b = nullptr)
 {
     const int n = a.n;
     const Scatter<DET> psi_s{psi_t, n, a.det_scale}, diag_s{diag_t, n, a.det_scale_d};
@@ -353,16 +378,16 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
         t_out += tc0 - t_prev;
 #endif
         switch (bk) {
-        case 0: if constexpr (!STABLE) { tilen<8, WITH_D, DET>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
-        case 1: if constexpr (!STABLE) { tilen<7, WITH_D, DET>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
-        case 2: if constexpr (!STABLE) { tilen<6, WITH_D, DET>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
-        case 3: if constexpr (!STABLE) { tilen<5, WITH_D, DET>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
-        case 4: if constexpr (!STABLE) { tilen<4, WITH_D, DET>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
-        case 5: if constexpr (!STABLE) { tilen<3, WITH_D, DET>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum); } break;
-        case 6: if constexpr (STABLE) { tile2<3, WITH_D, DET>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum); } break;
-        case 7: if constexpr (!STABLE) { tile2<1, WITH_D, DET>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum); } break;
-        case 8: if constexpr (!STABLE) { tile2<0, WITH_D, DET>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum); } break;
-        default: if constexpr (!STABLE) { tile2<2, WITH_D, DET>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum); } break;
+        case 0: if constexpr (!STABLE) { tilen<8, WITH_D, DET, BATCH>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 1: if constexpr (!STABLE) { tilen<7, WITH_D, DET, BATCH>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 2: if constexpr (!STABLE) { tilen<6, WITH_D, DET, BATCH>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 3: if constexpr (!STABLE) { tilen<5, WITH_D, DET, BATCH>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 4: if constexpr (!STABLE) { tilen<4, WITH_D, DET, BATCH>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 5: if constexpr (!STABLE) { tilen<3, WITH_D, DET, BATCH>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 6: if constexpr (STABLE) { tile2<3, WITH_D, DET, BATCH>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 7: if constexpr (!STABLE) { tile2<1, WITH_D, DET, BATCH>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 8: if constexpr (!STABLE) { tile2<0, WITH_D, DET, BATCH>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        default: if constexpr (!STABLE) { tile2<2, WITH_D, DET, BATCH>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
         }
 #ifdef CFMM_PHASE_TIMERS
         if (a.ts && lane == 0) {                       // per-wave tile log: ts[64 + 8 gw + i] = bucket << 48 | cycles
@@ -380,6 +405,30 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
     }
 #endif
     PHASE_STAMP(a.ts, 2);
+    if constexpr (BATCH) {
+        // every live vector's tile into its own accumulator; fpart: [BATCH_MAX][16] wave partials of nu' psi
+        __syncthreads();
+        const int nwv = blockDim.x >> 6;
+        for (unsigned mask = bc.alive; mask; mask &= mask - 1) {
+            const int bb = __builtin_ctz(mask);
+            double *base = acc_b[bb] + (size_t)(blockIdx.x % a.nslices) * acc_stride(n);
+            const double *pt = psi_t + bb * bc.tile_stride, *nub = nu_s + bb * bc.nu_stride;
+            double f = 0.0;
+            for (int j = threadIdx.x; j < n; j += blockDim.x) {
+                const double v = pt[j];
+                if (v != 0.0) { unsafeAtomicAdd(&base[j], v); f += nub[j] * v; }
+            }
+            f = wave_sum(f);
+            if (lane == 0) fpart[bb * 16 + wib] = f;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < BATCH_MAX && ((bc.alive >> threadIdx.x) & 1u)) {
+            double f = 0.0;
+            for (int w = 0; w < nwv; ++w) f += fpart[threadIdx.x * 16 + w];
+            if (f != 0.0) unsafeAtomicAdd(&acc_b[threadIdx.x][(size_t)(blockIdx.x % a.nslices) * acc_stride(n) + acc_arb(n)], f);
+        }
+        return;
+    }
     fsum = wave_sum(fsum);
     if (lane == 0) fpart[wib] = fsum;
     __syncthreads();
@@ -440,6 +489,54 @@ eval_kernel(EvalArgs a)
     __syncthreads();
     if (a.ts && threadIdx.x == 0 && blockIdx.x < 1024) a.ts[64 + 8 * 4096 + 2 * blockIdx.x + 1] = wall_clock64();    // block end
 #endif
+}
+
+// ------------------------------------------------------------------------------------------
+// The dual evaluation at B price vectors in ONE pass over the pools ("B price vectors per pool read").
+// The B solves share the pool set (cfmm_clone) and differ in utility, prices and solver state: vector b's prices come
+// from nu[b] (its own stop flag behind them), its psi tile is flushed into acc[b].  Per tile the pool columns are loaded
+// once; arithmetic, LDS gathers and scatters are per vector.  LDS: psi[B][n] | nu[B][n + 2] | fpart[B_MAX][16] | ticket
+// | strips: 144 KB at B = 8 and 1000 tokens.  No metric (WITH_D) and no stableswap bucket here: the first evaluation
+// of every solve (which builds the metric) runs through eval_kernel.
+// ------------------------------------------------------------------------------------------
+struct BatchArgs {
+    const double *nu[BATCH_MAX];
+    double *acc[BATCH_MAX];
+    int nb, pad;
+};
+__host__ __device__ inline int batch_nu_stride(int n) { return (n + 3) & ~1; }
+__host__ __device__ inline int batch_lds_doubles(int n, int nb) { return nb * n + nb * batch_nu_stride(n) + BATCH_MAX * 16 + 2; }
+__host__ __device__ inline size_t batch_lds_bytes(int n, int nb) { return (size_t)(batch_lds_doubles(n, nb) + 2 * 64 * (EVAL_THREADS / 64)) * sizeof(double); }
+__host__ __device__ inline int batch_capacity(int n)          // price vectors per launch that fit 160 KB of LDS
+{
+    int nb = BATCH_MAX;
+    while (nb > 1 && batch_lds_bytes(n, nb) > 160 * 1024) --nb;
+    return nb;
+}
+
+__global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
+eval_batch_kernel(EvalArgs a, BatchArgs bt)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = a.n, nb = bt.nb, nus = batch_nu_stride(n);
+    double *psi_s = lds;                                // [nb][n]
+    double *nu_s = lds + nb * n;                        // [nb][nus]: prices, then the stop flag
+    double *fpart = nu_s + nb * nus;                    // [BATCH_MAX][16]
+    int *next_tile = reinterpret_cast<int *>(fpart + BATCH_MAX * 16);
+    if (threadIdx.x == 0) *next_tile = 0;
+    double2 *xs = reinterpret_cast<double2 *>(lds + batch_lds_doubles(n, nb)) + 64 * (threadIdx.x >> 6);
+    for (int b = 0; b < nb; ++b) {
+        const double *src = bt.nu[b];
+        for (int j = threadIdx.x; j <= n; j += blockDim.x) nu_s[b * nus + j] = src[j];
+    }
+    for (int j = threadIdx.x; j < nb * n; j += blockDim.x) psi_s[j] = 0.0;
+    __syncthreads();
+    unsigned alive = 0;
+    for (int b = 0; b < nb; ++b) alive |= (nu_s[b * nus + n] == 0.0 ? 1u : 0u) << b;
+    alive = __builtin_amdgcn_readfirstlane(alive);
+    if (!alive) return;
+    const BatchCtl bc{alive, nus, n};
+    eval_tiles_and_flush<false, false, false, true>(a, nullptr, nu_s, psi_s, nullptr, fpart, next_tile, xs, bc, bt.acc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -573,7 +670,20 @@ struct UpdArgs {
     double tol_gap, tol_infeas, armijo, max_step;
     int max_evals, pg_rule;
     long long *ts;                    // phase timers (tuning builds only)
+    // batched solves (cfmm_solve_batch): the update kernels are launched with one workgroup per solve, workgroup b taking
+    // its arguments from batch[b] (device memory); hstat: pinned host word {status << 32 | evals} the host polls
+    const UpdArgs *batch;
+    unsigned long long *hstat;
 };
+template <bool BATCH>
+__device__ __forceinline__ const UpdArgs &upd_args(const UpdArgs &a0)
+{
+    if constexpr (BATCH) return a0.batch[blockIdx.x]; else return a0;
+}
+__device__ __forceinline__ void report_progress(const UpdArgs &a, const DevState &st)
+{
+    if (a.hstat) __hip_atomic_store(a.hstat, ((unsigned long long)(unsigned)st.status << 32) | (unsigned)st.evals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // block-wide reduction of NV sums and NM maxima at once; result broadcast to every thread
 template <int NV, int NM>
@@ -597,9 +707,11 @@ __device__ __forceinline__ bool is_active(double s, double lo, double hi, double
     return (s <= lo + 1e-14 && G > 0.0) || (s >= hi - 1e-14 && G < 0.0) || (lo == hi);
 }
 
+template <bool BATCH = false>
 __global__ void __launch_bounds__(UPD_THREADS)
-update_kernel(UpdArgs a)
+update_kernel(UpdArgs a0)
 {
+    const UpdArgs &a = upd_args<BATCH>(a0);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *q = lds;                         // [ng]
     double *q2 = lds + a.ng;                 // [ng]
@@ -789,7 +901,7 @@ update_kernel(UpdArgs a)
         for (int j = tid; j < n; j += nt) a.nu[j] = exp(a.s_t[a.grp[j]] + a.off[j]);
         if (st.evals >= a.max_evals) st.status = 3;
     }
-    if (tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; }
+    if (tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; report_progress(a, st); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -877,16 +989,17 @@ __device__ __forceinline__ void stv(double *p, int first, int len, const double 
     }
 }
 
-template <int MAXT, int MM, int E>          // <= MAXT threads (register budget), <= MM history pairs, E variables per thread
+template <int MAXT, int MM, int E, bool BATCH = false>          // <= MAXT threads (register budget), <= MM history pairs, E variables per thread
 __global__ void __launch_bounds__(MAXT)
-update_reg_kernel(UpdArgs a)
+update_reg_kernel(UpdArgs a0)
 {
+    const UpdArgs &a = upd_args<BATCH>(a0);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     const int n = a.n, ng = a.ng, M = a.M;
     const int hs = hist_stride(n);
     // (tuning probe) the kernel may be launched with several identical workgroups: only workgroup 0 stores
-    const bool wr = blockIdx.x == 0;
+    const bool wr = BATCH || blockIdx.x == 0;
     const int nS = wr ? n : 0, ngS = wr ? ng : 0;
     double *q = lds;                         // [ng]
     double *q2 = lds + ng;                   // [ng]
@@ -1165,7 +1278,7 @@ update_reg_kernel(UpdArgs a)
         if (r0 < n) stv<E>(a.nu, r0, nS, nn);
         if (st.evals >= a.max_evals) st.status = 3;
     }
-    if (wr && tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; }
+    if (wr && tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; report_progress(a, st); }
     PHASE_STAMP(a.ts, 15);
 }
 
@@ -1240,10 +1353,11 @@ __device__ __forceinline__ double wave_reduce_scatter64(double (&v)[64], int lan
 constexpr int GRAM_MM = 4;                  // history pairs kept by the Gram form
 constexpr int GRAM_P = GRAM_MM + 1;         // + the new pair
 
-template <int MAXT, int E>
+template <int MAXT, int E, bool BATCH = false>
 __global__ void __launch_bounds__(MAXT)
-update_gram_kernel(UpdArgs a)
+update_gram_kernel(UpdArgs a0)
 {
+    const UpdArgs &a = upd_args<BATCH>(a0);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int MM = GRAM_MM, P = GRAM_P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -1257,7 +1371,7 @@ update_gram_kernel(UpdArgs a)
     BlockRed red(xm + 32);                   // [2][12][16] for the small closing reduction
     const int stride = acc_stride(n);
     const bool ties = (ng != n);
-    const bool wr = blockIdx.x == 0;
+    const bool wr = BATCH || blockIdx.x == 0;
     const int nS = wr ? n : 0, ngS = wr ? ng : 0;
     const int r0 = tid * E;
     const int pr = (r0 < n) ? r0 : 0;
@@ -1562,7 +1676,7 @@ update_gram_kernel(UpdArgs a)
         if (r0 < n) stv<E>(a.nu, r0, nS, nn);
         if (st.evals >= a.max_evals) st.status = 3;
     }
-    if (wr && tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; }
+    if (wr && tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; report_progress(a, st); }
     PHASE_STAMP(a.ts, 15);
 }
 
@@ -1592,9 +1706,14 @@ selftest_kernel(int *out)
 }
 
 // start of a solve: group variable = mean over members of (log nu0_j - off_j), clamped
+template <bool BATCH = false>
 __global__ void __launch_bounds__(UPD_THREADS)
-start_kernel(UpdArgs a, const double *nu0, double *zero, long long nzero, DevState *st_clear, int n_clear)
+start_kernel(UpdArgs a0, const double *nu0_, double *zero, long long nzero, DevState *st_clear, int n_clear)
 {
+    // (batched: workgroup b starts solve b from ITS previous / given prices a.nu_acc, and clears its own accumulator)
+    const UpdArgs &a = upd_args<BATCH>(a0);
+    const double *nu0 = BATCH ? a.nu_acc : nu0_;
+    if (BATCH) { zero = a.acc; }
     // (nu0 may be a.nu_acc itself: every element is read before the first one is written.  `zero` / `st_clear`: the
     //  accumulator sets and the spare solver-state records of the one-launch iteration, cleared here instead of by
     //  separate fill operations on the stream)
@@ -1626,6 +1745,7 @@ start_kernel(UpdArgs a, const double *nu0, double *zero, long long nzero, DevSta
         st.f = 0.0; st.t_step = 1.0; st.gap = 0.0; st.infeas = 0.0; st.primal = 0.0; st.pg = 0.0;
         *a.st = st;
         a.nu[n] = 0.0;
+        report_progress(a, st);
     }
 }
 

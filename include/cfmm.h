@@ -162,6 +162,17 @@ int cfmm_debug_eval_limbs(cfmm_ctx *ctx, const double *nu, double ref_reserve, d
  * solve that includes (a multiple of) its final barrier weight: the warm start of a parametric sweep (two-asset.py:34-100) */
 int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts, cfmm_stats *out);
 
+/* `nb` prob.solve() calls over the SAME pools in lock-step: the loop body of the parametric sweep, two-asset.py:34-100
+ * (the pools, reserves and fees of lines 7-32 stay, only the utility of line 66 / 86 changes with t), or independent
+ * baskets over one pool set.  ctxs[0] is the context the pools were uploaded to, ctxs[1..] its cfmm_clone()s, each with
+ * its own cfmm_set_utility; nu0[b] (or nu0 itself) may be NULL = continue from that context's prices.  Every outer
+ * iteration reads every pool column ONCE and solves each pool at all nb price vectors (first-order method; no price
+ * ties, no stableswap pools, not pool-sharded); out[b] are the statistics of solve b (wall / device seconds: of the
+ * whole batch).  nb <= cfmm_batch_capacity(n_tokens) (8 up to ~1100 tokens; bounded by the LDS tile beyond).
+ * Afterwards every context is read back as after cfmm_solve (cfmm_get_solution, cfmm_get_trades*). */
+int cfmm_solve_batch(cfmm_ctx *const *ctxs, int nb, const double *const *nu0, const cfmm_opts *opts, cfmm_stats *out);
+int cfmm_batch_capacity(int n_tokens);
+
 /* read-back (arbitrage.py:84 prob.value is stats.primal_value; psi.value; deltas/lambdas.value) */
 int cfmm_get_nu(cfmm_ctx *ctx, double *nu);
 int cfmm_set_nu(cfmm_ctx *ctx, const double *nu);

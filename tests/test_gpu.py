@@ -305,7 +305,9 @@ def test_full_size_c4_single_gpu_streams_from_hbm():
     assert np.abs(psi - p.psi).max() <= 1e-9 * np.abs(psi).max()
     xa = b["Ra"] + b["fee"] * d[0] - l[0]; xb = b["Rb"] + b["fee"] * d[1] - l[1]
     assert np.abs(0.5 * np.log(xa / b["Ra"]) + 0.5 * np.log(xb / b["Rb"])).max() <= 1e-12
-    assert 0 <= p.dual_value - v <= 2e-6 * abs(v)
+    # weak duality: the dual value bounds the objective of every FEASIBLE psi from above; this psi satisfies psi >= 0 only to
+    # the 1e-6 certificate, so it may overshoot the bound by that much
+    assert -1e-6 * abs(v) <= p.dual_value - v <= 2e-6 * abs(v)
     p.close()
 
 
@@ -425,7 +427,7 @@ def test_clones_share_pools_and_solve_many_matches_sequential(deterministic):
         p.set_utility(u); p.solve(tol=1e-7)
         seq.append((p.value, p.status, p.psi.copy(), p.stats["evals"]))
     for conc in (1, 3):
-        res = p.solve_many(utils, concurrency=conc, tol=1e-7)
+        res = p.solve_many(utils, concurrency=conc, tol=1e-7, batch=0)         # (host threads over clones; the batched path is tested below)
         for (v, st, psi, ev), r in zip(seq, res):
             assert r["status"] == st == "optimal"
             if deterministic:
@@ -440,6 +442,131 @@ def test_clones_share_pools_and_solve_many_matches_sequential(deterministic):
     q.close()
     p.ctx.upload_pools2(_lib.POOL_SUM2, [1.0], [1.0], [0.99], [0], [1])      # fine again once the clone is gone
     p.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# batched solves (cfmm_solve_batch): B price vectors per pool read
+# ---------------------------------------------------------------------------------------------------------------
+def _mixed_utilities(net, rng, count):
+    """arbitrage under perturbed market values, liquidations and swaps of random baskets (arbitrage.py:57,77,
+    liquidation.py:57,77-80, two-asset.py:66,86): solves that need different numbers of iterations"""
+    n = net["n_tokens"]
+    out = []
+    for k in range(count):
+        if k % 3 == 0:
+            out.append(cfmm.Arbitrage(net["c"] * np.exp(rng.normal(0, 0.003 * (1 + k), n))))
+        else:
+            h = np.zeros(n); idx = rng.choice(n, 4 + k, replace=False)
+            h[idx] = np.exp(rng.normal(2, 0.5, idx.size)) / net["prices"][idx] * 10
+            t = int(rng.integers(0, n)); h[t] = 0.0
+            out.append(cfmm.Liquidate(h, t) if k % 3 == 1 else cfmm.Swap(h, t))
+    return out
+
+
+@pytest.mark.parametrize("n_tokens,memory,count", [(1000, 0, 8), (300, 8, 5), (1500, 0, 4), (3000, 0, 2)])
+def test_batched_solves_match_the_oracle_and_single_solves(oracle_lib, n_tokens, memory, count):
+    """B solves in lock-step over one pool set -- one pool read per iteration for all of them -- reach the optimum of the
+    oracle's solver and of the single-solve path, each with its own certificates, whatever iteration each one ends at;
+    every instantiation of the batched update (Gram form, register form 2 / 4 per thread, generic) is covered"""
+    net = synthetic.make_network(n_tokens, m_cp2=60_000, m_w2=20_000, m_gn=10_000, seed=21)
+    rng = np.random.default_rng(5)
+    utils = _mixed_utilities(net, rng, count)
+    p = cfmm.Problem.from_network(net, utility=utils[0])
+    assert p._ensure_ctx().batch_capacity() >= min(count, 2)
+    res = p.solve_many(utils, tol=1e-7, memory=memory)
+    assert len(res) == count
+    evs = [r["stats"]["evals"] for r in res]
+    assert len(set(evs)) > 1 or count <= 2                                 # (the solves do end at different iterations)
+    q = cfmm.Problem.from_network(net, utility=utils[0])
+    for u, r in zip(utils, res):
+        assert r["status"] == "optimal" and r["gap"] <= 1e-7 and r["infeas"] <= 1e-7
+        assert r["stats"]["batch"] == min(count, p.ctx.batch_capacity())
+        o = oracle_lib.Oracle(n_tokens, threads=4); o.add_network(net); o.set_utility(u.c, u.h, u.ctype)
+        ro = o.solve(cfmm.start_prices(net, u), tol=1e-7, memory=memory)
+        assert ro["status"] == 1
+        assert abs(r["value"] - ro["primal_value"]) <= 2e-6 * max(abs(r["value"]), 1.0)
+        q.set_utility(u)
+        v1 = q.solve(tol=1e-7, memory=memory)
+        assert q.status == "optimal" and abs(r["value"] - v1) <= 1e-6 * max(abs(v1), 1.0)
+        assert np.abs(r["psi"] - q.psi).max() <= 1e-4 * np.abs(q.psi).max()
+    q.close(); p.close()
+
+
+def test_batched_parametric_sweep_matches_the_primal_model():
+    """the sweep of two-asset.py:34-100 as the batched path runs it -- 24 values of t over the four geometric-mean pools
+    of two-asset.py:7-32 (its constant-sum pool needs the host-side kink handling, which solves one at a time), in groups
+    of 8, each group warm-started from the previous one -- against the primal model (two-asset.py:51-88) solved by SciPy,
+    objective 1e-7 and per-pool tenders 1e-6 (two-asset.py:94-98)"""
+    from oracle.primal_scipy import solve_primal
+    base = I.two_asset(0.0)
+    keep = [i for i, k in enumerate(base["kinds"]) if k != "sum"]
+    def inst(t):
+        d = dict(I.two_asset(t))
+        for key in ("local_indices", "reserves", "fees", "kinds", "weights"):
+            d[key] = [d[key][i] for i in keep]
+        return d
+    ts = np.linspace(0.5, 50, 24)
+    p = problem_of(inst(0.0))
+    res = p.solve_many([cfmm.Swap([t, 0, 0], 2) for t in ts], tol=1e-9, warm_start=True)
+    assert all(r["status"] == "optimal" and r["stats"]["batch"] == 8 for r in res)
+    vals = np.array([r["value"] for r in res])
+    assert np.all(np.diff(vals) > 0)
+    for j in (0, 7, 8, 15, 23):
+        r = solve_primal(I.normalise(inst(ts[j])))
+        assert abs(vals[j] - r["value"]) <= 1e-7
+    w = p._batch_workers[23 % 8]                     # the clone that solved the last point still holds its tenders
+    for d, l, y in zip(w.deltas, w.lambdas, r["y"]):
+        assert np.abs((np.asarray(l) - np.asarray(d)) - np.asarray(y)).max() <= 1e-6
+    p.close()
+
+
+def test_batched_solve_full_size_c3_properties(oracle_lib):
+    """BASELINE config 3 at full size, 8 utilities at once: certificates of every solve, and one of them against the
+    oracle's solver"""
+    net = synthetic.config("C3", seed=0)
+    rng = np.random.default_rng(3)
+    n = net["n_tokens"]
+    utils = [cfmm.Arbitrage(net["c"] * np.exp(rng.normal(0, 0.01, n))) for _ in range(8)]
+    p = cfmm.Problem.from_network(net, utility=utils[0])
+    res = p.solve_many(utils, tol=1e-6)
+    for r in res:
+        assert r["status"] == "optimal" and r["gap"] <= 1e-6 and r["infeas"] <= 1e-6
+        assert r["psi"].min() >= -1e-6 * np.abs(r["psi"]).max()
+    o = _oracle_for(oracle_lib, net, threads=8); o.set_utility(utils[3].c)
+    ro = o.solve(utils[3].c, tol=1e-6)
+    assert ro["status"] == 1 and abs(res[3]["value"] - ro["primal_value"]) <= 2e-6 * abs(ro["primal_value"])
+    p.close()
+
+
+def test_batched_solve_error_behaviour():
+    net = synthetic.make_network(50, m_cp2=500, m_w2=100, m_gn=60, seed=2)
+    u = cfmm.Arbitrage(net["c"])
+    a = cfmm.Problem.from_network(net, utility=u); b = cfmm.Problem.from_network(net, utility=u)
+    ca, cb = a._ensure_ctx(), b._ensure_ctx()
+    for c in (ca, cb):
+        c.set_utility(u.c, u.h, u.ctype)
+    with pytest.raises(cfmm.CfmmError, match="does not share"):
+        ca.solve_batch([cb], [net["c"], net["c"]])
+    k = ca.clone()
+    with pytest.raises(cfmm.CfmmError, match="no utility"):
+        ca.solve_batch([k], [net["c"], net["c"]])
+    k.set_utility(u.c, u.h, u.ctype)
+    with pytest.raises(cfmm.CfmmError, match="appears twice"):
+        ca.solve_batch([k, k], [net["c"]] * 3)
+    with pytest.raises(cfmm.CfmmError, match="no start prices"):
+        ca.solve_batch([k], None)
+    sts = ca.solve_batch([k], [net["c"], None and net["c"] or net["c"]], tol=1e-8)
+    assert [s["status"] for s in sts] == [1, 1] and abs(sts[0]["primal_value"] - sts[1]["primal_value"]) <= 1e-9 * abs(sts[0]["primal_value"])
+    clones = [ca.clone() for _ in range(ca.batch_capacity())]
+    for c in clones:
+        c.set_utility(u.c, u.h, u.ctype)
+    with pytest.raises(cfmm.CfmmError, match="at most"):
+        ca.solve_batch(clones, [net["c"]] * (len(clones) + 1))
+    for c in clones + [k]:
+        c.close()
+    with pytest.raises(ValueError, match="batched path"):
+        cfmm.Problem.from_network(synthetic.config("C5", scale=0.01, seed=0), utility=u).solve_many([u], batch=4)
+    a.close(); b.close()
 
 
 @pytest.mark.parametrize("n_tokens,memory", [(700, 8), (1500, 0), (2000, 8), (3000, 0)])
@@ -580,6 +707,8 @@ def test_pool_sharded_c_path_with_the_one_shot_all_reduce(oracle_lib, world, det
     whole = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]), deterministic=deterministic)
     f_ref, psi_ref = whole.eval_dual(nu)
     v_ref = whole.solve(tol=1e-7)
+    evals_ref = whole.stats["evals"]; nu_ref = whole.nu.copy()
+    whole.close()          # (its stream's hardware queue goes back to the pool: see conftest.py on GPU_MAX_HW_QUEUES)
     comm = _ThreadComm(world)
     ranks = []
     for r in range(world):
@@ -617,10 +746,9 @@ def test_pool_sharded_c_path_with_the_one_shot_all_reduce(oracle_lib, world, det
         assert o["evals"] == out[0]["evals"] and np.array_equal(o["nu"], out[0]["nu"]) and np.array_equal(o["psi_sol"], out[0]["psi_sol"])
     if deterministic:                      # integer limbs: the sharded run IS the unsharded run, bit for bit
         assert out[0]["f"] == f_ref and np.array_equal(out[0]["psi"], psi_ref)
-        assert out[0]["v"] == v_ref and out[0]["evals"] == whole.stats["evals"] and np.array_equal(out[0]["nu"], whole.nu)
+        assert out[0]["v"] == v_ref and out[0]["evals"] == evals_ref and np.array_equal(out[0]["nu"], nu_ref)
     for q in ranks:
         q.close()
-    whole.close()
 
 
 def test_one_shot_all_reduce_against_rccl_on_real_peers(tmp_path):
