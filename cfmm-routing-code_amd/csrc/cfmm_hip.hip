@@ -10,7 +10,9 @@
 #include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +20,7 @@
 #include <memory>
 #include <mutex>
 #include <functional>
+#include <limits>
 #include <string>
 #include <thread>
 #include <vector>
@@ -109,6 +112,7 @@ struct cfmm_ctx {
     double *acc = nullptr;
     DevState *st = nullptr;
     long long *ts = nullptr;           // phase timers (tuning builds)
+    char *dev_arena = nullptr, *host_arena = nullptr;   // every per-context device / pinned host buffer below is a piece of these
     DevState *hst = nullptr;          // pinned, 2 slots
     double *hsol = nullptr;           // pinned [2][n]: nu | psi of the last solve (saves cfmm_get_solution a synchronisation)
     double *hnu0 = nullptr;           // pinned [n]: staging of cfmm_set_nu
@@ -245,80 +249,217 @@ int dev_upload(cfmm_ctx *ctx, T **dst, const T *src, size_t count, std::vector<v
 
 // ---- the upload hand-over (arbitrage.py:5-28: a drop-in call starts from host lists) ---------------------------
 // Every column of a bucket goes into ONE arena (one hipMalloc, 256-byte aligned pieces) through a pinned, double-
-// buffered staging ring: the host-side fill of chunk i (a few threads; the k-asset columns are transposed from the
-// ABI's slot-major to the device's pool-major layout on the way) overlaps the DMA of chunk i - 1.  Pageable
-// hipMemcpy of ~40 separately allocated columns ran at ~6 GB/s (round 1).
-constexpr size_t STAGE_BYTES = 8u << 20;
+// buffered staging ring: the host-side fill of chunk i overlaps the DMA of chunk i - 1.  The fill is the ONLY pass over
+// the caller's data: it copies (the k-asset columns are transposed from the ABI's slot-major to the device's pool-major
+// layout on the way), validates what it has just copied while it is still in cache, and collects the extrema the
+// reproducible mode needs.  It runs on a persistent pool of host threads (spawning threads per chunk cost ~0.1 ms each).
+// Round 1: pageable hipMemcpy of ~40 separately allocated columns, ~6 GB/s; round 2a: separate validation pass + staged
+// copies, 7 GB/s.
+constexpr size_t STAGE_BYTES = 4u << 20;
+constexpr int STAGE_SLOTS = 4;
 // the ring is process-wide and allocated once (pinning 16 MB takes milliseconds: per context it cost more than it saved);
 // uploads of different contexts take turns on it
 struct StageRing {
     std::mutex mu;
     char *buf = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev[STAGE_SLOTS] = {};
 };
 StageRing g_stage;
+std::mutex g_stream_mu;
+std::vector<hipStream_t> g_free_streams[64];
+
+// persistent host workers: run(n, f) executes f(0) .. f(n - 1) on the pool and the calling thread and returns when all are
+// done.  Workers spin briefly after a job (uploads arrive in bursts: a futex wake costs 20-50 us) before they sleep.
+class HostPool {
+public:
+    static HostPool &get() { static HostPool *p = new HostPool(); return *p; }      // (leaked on purpose: detached threads outlive static destructors)
+    int threads() const { return nthreads_ + 1; }
+    void run(int n, const std::function<void(int)> &f)
+    {
+        if (n <= 0) return;
+        if (n == 1 || nthreads_ == 0) { for (int i = 0; i < n; ++i) f(i); return; }
+        std::unique_lock<std::mutex> own(run_mu_);          // one run at a time
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            job_ = &f; njobs_ = n; next_.store(0, std::memory_order_relaxed); left_.store(n, std::memory_order_relaxed);
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        work();
+        while (left_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        { std::lock_guard<std::mutex> g(mu_); job_ = nullptr; }               // no worker enters from here on ...
+        while (active_.load(std::memory_order_acquire) > 0) std::this_thread::yield();      // ... and none is left inside: the next run may rewrite the job
+    }
+private:
+    HostPool()
+    {
+        int want = 8;
+        if (const char *s = getenv("CFMM_UPLOAD_THREADS")) want = std::max(1, atoi(s));
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && want > hw) want = hw;
+        nthreads_ = want - 1;
+        for (int t = 0; t < nthreads_; ++t) std::thread([this]() { loop(); }).detach();
+    }
+    void work()
+    {
+        for (;;) {
+            const int i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= njobs_) return;
+            (*job_)(i);
+            left_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    void loop()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            // spin for a while (~100 us), then sleep on the condition variable
+            bool got = false;
+            for (int spin = 0; spin < 20000 && !got; ++spin) {
+                if (gen_.load(std::memory_order_acquire) != seen) got = true;
+                else __builtin_ia32_pause();
+            }
+            if (!got) {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&]() { return gen_.load(std::memory_order_acquire) != seen; });
+            }
+            seen = gen_.load(std::memory_order_acquire);
+            { std::lock_guard<std::mutex> g(mu_); if (!job_) continue; active_.fetch_add(1, std::memory_order_relaxed); }    // (else: a run that has already finished)
+            work();
+            active_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_;
+    const std::function<void(int)> *job_ = nullptr;
+    int njobs_ = 0, nthreads_ = 0;
+    std::atomic<int> next_{0}, left_{0}, active_{0};
+    std::atomic<unsigned long long> gen_{0};
+};
+
+// what the fills find out on the way (one per upload call)
+struct UploadScan {
+    std::atomic<bool> bad{false};
+    std::mutex mu;
+    double mxr = 0.0, mnf = 1.0;
+    void fold(double mx, double mn) { std::lock_guard<std::mutex> g(mu); mxr = std::max(mxr, mx); mnf = std::min(mnf, mn); }
+};
 struct Col {
     size_t bytes = 0;
     void **dst = nullptr;                                                  // receives the column's device address
     std::function<void(char *out, size_t off, size_t len)> fill;          // writes bytes [off, off + len) of the column
     const void *direct = nullptr;                                          // the caller's buffer when the column is copied as it is
 };
-// host-side helper: f(begin, end) over [0, m) on a few threads (validation scans and staging fills run at memory speed)
+// f(begin, end) over [0, m) on the pool
 template <class F>
 void parallel_range(int64_t m, F f)
 {
-    const int T = m >= (1 << 17) ? 8 : 1;
+    const int T = m >= (1 << 15) ? HostPool::get().threads() : 1;
     if (T == 1) { f((int64_t)0, m); return; }
-    std::vector<std::thread> th;
     const int64_t part = (m + T - 1) / T;
-    for (int t = 0; t < T; ++t) {
-        const int64_t b = t * part, e = std::min<int64_t>(m, b + part);
-        if (b >= e) break;
-        th.emplace_back([=]() { f(b, e); });
-    }
-    for (auto &x : th) x.join();
+    HostPool::get().run(T, [&](int t) { const int64_t b = t * part, e = std::min<int64_t>(m, b + part); if (b < e) f(b, e); });
 }
 
+// copy + check: `pred(x)` must hold for every element (NaN fails every comparison); tracks max / min of the block
+template <class T, class P>
+inline bool copy_scan(T *out, const T *src, size_t cnt, P pred, T &mx, T &mn)
+{
+    std::memcpy(out, src, cnt * sizeof(T));
+    bool ok0 = true, ok1 = true, ok2 = true, ok3 = true;
+    T a0 = mx, a1 = mx, a2 = mx, a3 = mx, b0 = mn, b1 = mn, b2 = mn, b3 = mn;
+    size_t i = 0;
+    for (; i + 4 <= cnt; i += 4) {                       // (on the copy: it is in cache)
+        const T x0 = out[i], x1 = out[i + 1], x2 = out[i + 2], x3 = out[i + 3];
+        ok0 &= pred(x0); ok1 &= pred(x1); ok2 &= pred(x2); ok3 &= pred(x3);
+        a0 = x0 > a0 ? x0 : a0; a1 = x1 > a1 ? x1 : a1; a2 = x2 > a2 ? x2 : a2; a3 = x3 > a3 ? x3 : a3;
+        b0 = x0 < b0 ? x0 : b0; b1 = x1 < b1 ? x1 : b1; b2 = x2 < b2 ? x2 : b2; b3 = x3 < b3 ? x3 : b3;
+    }
+    for (; i < cnt; ++i) { const T x = out[i]; ok0 &= pred(x); a0 = x > a0 ? x : a0; b0 = x < b0 ? x : b0; }
+    mx = std::max(std::max(a0, a1), std::max(a2, a3)); mn = std::min(std::min(b0, b1), std::min(b2, b3));
+    return ok0 && ok1 && ok2 && ok3;
+}
+// a column copied as it is, checked on the way; ROLE: 0 reserve (max), 1 fee (min), 2 other
+template <class T, class P>
+Col checked_col(const T *src, size_t count, void **dst, UploadScan *scan, int role, P pred)
+{
+    Col c; c.bytes = count * sizeof(T); c.dst = dst; c.direct = src;
+    c.fill = [src, scan, role, pred](char *out, size_t off, size_t len) {
+        T mx = T(0), mn = T(1);
+        if (role == 2) { mx = std::numeric_limits<T>::lowest(); mn = std::numeric_limits<T>::max(); }
+        if (!copy_scan<T>((T *)out, src + off / sizeof(T), len / sizeof(T), pred, mx, mn)) scan->bad.store(true, std::memory_order_relaxed);
+        if (role == 0) scan->fold((double)mx, 1.0);
+        if (role == 1) scan->fold(0.0, (double)mn);
+    };
+    return c;
+}
 Col plain_col(const void *src, size_t bytes, void **dst)
 {
     Col c; c.bytes = bytes; c.dst = dst; c.direct = src;
     c.fill = [src](char *out, size_t off, size_t len) { std::memcpy(out, (const char *)src + off, len); };
     return c;
 }
-// column [k][m] (slot-major, the ABI) -> [m][k] (pool-major, the device): element e = i * k + j comes from j * m + i
-template <class T>
-Col transposed_col(const T *src, int k, int64_t m, void **dst)
+// column [k][m] (slot-major, the ABI) -> [m][k] (pool-major, the device): element e = i * k + j comes from j * m + i.
+// K is a compile-time constant in the body (whole pools: the k gathers per pool unroll); ragged ends go element-wise.
+template <class T, int K, class P>
+inline void transpose_fill(T *o, const T *src, int64_t m, size_t e, size_t cnt, P pred, bool &ok, T &mx)
+{
+    size_t q = 0;
+    int64_t i = (int64_t)(e / K); int j = (int)(e % K);
+    for (; q < cnt && j != 0; ++q) { const T x = src[(size_t)j * m + i]; o[q] = x; ok &= pred(x); mx = x > mx ? x : mx; if (++j == K) { j = 0; ++i; } }
+    bool okv = true; T mxv = mx;
+    for (; q + K <= cnt; q += K, ++i) {
+#pragma unroll
+        for (int jj = 0; jj < K; ++jj) { const T x = src[(size_t)jj * m + i]; o[q + jj] = x; okv &= pred(x); mxv = x > mxv ? x : mxv; }
+    }
+    ok &= okv; mx = mxv;
+    for (j = 0; q < cnt; ++q, ++j) { const T x = src[(size_t)j * m + i]; o[q] = x; ok &= pred(x); mx = x > mx ? x : mx; }
+}
+template <class T, class P>
+Col transposed_col(const T *src, int k, int64_t m, void **dst, UploadScan *scan, bool track_max, P pred)
 {
     Col c; c.bytes = (size_t)k * m * sizeof(T); c.dst = dst;
-    c.fill = [src, k, m](char *out, size_t off, size_t len) {
+    c.fill = [src, k, m, scan, track_max, pred](char *out, size_t off, size_t len) {
         T *o = (T *)out;
-        size_t e = off / sizeof(T);
-        const size_t cnt = len / sizeof(T);
-        int64_t i = (int64_t)(e / k); int j = (int)(e % k);
-        for (size_t q = 0; q < cnt; ++q) { o[q] = src[(size_t)j * m + i]; if (++j == k) { j = 0; ++i; } }
+        const size_t e = off / sizeof(T), cnt = len / sizeof(T);
+        bool ok = true; T mx = T(0);
+        switch (k) {
+        case 3: transpose_fill<T, 3>(o, src, m, e, cnt, pred, ok, mx); break;
+        case 4: transpose_fill<T, 4>(o, src, m, e, cnt, pred, ok, mx); break;
+        case 5: transpose_fill<T, 5>(o, src, m, e, cnt, pred, ok, mx); break;
+        case 6: transpose_fill<T, 6>(o, src, m, e, cnt, pred, ok, mx); break;
+        case 7: transpose_fill<T, 7>(o, src, m, e, cnt, pred, ok, mx); break;
+        default: transpose_fill<T, 8>(o, src, m, e, cnt, pred, ok, mx); break;
+        }
+        if (!ok) scan->bad.store(true, std::memory_order_relaxed);
+        if (track_max) scan->fold((double)mx, 1.0);
     };
     return c;
 }
 void parallel_fill(const Col &c, char *out, size_t off, size_t len)
 {
-    const int T = len >= (2u << 20) ? 8 : 1;
-    if (T == 1) { c.fill(out, off, len); return; }
-    std::vector<std::thread> th;
+    const size_t grain = 64u << 10;
+    int T = (int)std::min<size_t>((len + grain - 1) / grain, (size_t)HostPool::get().threads());
+    if (T <= 1) { c.fill(out, off, len); return; }
     const size_t part = ((len / T) + 63) & ~(size_t)63;
-    for (int t = 0; t < T; ++t) {
-        const size_t b = (size_t)t * part, e = std::min(len, b + part);
-        if (b >= e) break;
-        th.emplace_back([&c, out, off, b, e]() { c.fill(out + b, off + b, e - b); });
-    }
-    for (auto &x : th) x.join();
+    HostPool::get().run(T, [&](int t) {
+        const size_t b = (size_t)t * part, e = (t == T - 1) ? len : std::min(len, b + part);
+        if (b < e) c.fill(out + b, off + b, e - b);
+    });
 }
-int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out)
+// returns CFMM_E_ARG (no message set) when a fill flagged bad data: the caller describes what is wrong
+int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const UploadScan *scan = nullptr)
 {
     size_t total = 0;
     std::vector<size_t> offs;
     for (auto &c : cols) { offs.push_back(total); total += (c.bytes + 255) & ~(size_t)255; }
     char *base = nullptr;
+    static const bool trace = getenv("CFMM_UPLOAD_TRACE") != nullptr;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto tA = now();
     HIP_TRY(ctx, hipMalloc((void **)&base, total + 256));
+    const auto tB = now();
+    double t_fill = 0.0, t_wait = 0.0, t_enq = 0.0;
     auto bail = [&](hipError_t e, const char *what) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(base); return fail(ctx, CFMM_E_HIP, "upload: %s -> %s", what, hipGetErrorString(e)); };
     // (A/B) CFMM_UPLOAD=register: page-lock the caller's buffers in place and let the copy engine read them directly
     static const bool by_register = getenv("CFMM_UPLOAD") && std::string(getenv("CFMM_UPLOAD")) == "register";
@@ -326,12 +467,12 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out)
         std::vector<void *> pinned;
         hipError_t e = hipSuccess;
         for (size_t q = 0; q < cols.size() && e == hipSuccess; ++q) {
+            std::vector<char> tmp(cols[q].bytes);
+            cols[q].fill(tmp.data(), 0, cols[q].bytes);          // (the checks ride on the fill: run it either way)
             if (cols[q].direct && cols[q].bytes >= (1u << 20)) {
                 e = hipHostRegister(const_cast<void *>(cols[q].direct), cols[q].bytes, hipHostRegisterDefault);
                 if (e == hipSuccess) { pinned.push_back(const_cast<void *>(cols[q].direct)); e = hipMemcpyAsync(base + offs[q], cols[q].direct, cols[q].bytes, hipMemcpyHostToDevice, ctx->stream); }
             } else {
-                std::vector<char> tmp(cols[q].bytes);
-                cols[q].fill(tmp.data(), 0, cols[q].bytes);
                 e = hipMemcpy(base + offs[q], tmp.data(), cols[q].bytes, hipMemcpyHostToDevice);
             }
             *cols[q].dst = base + offs[q];
@@ -339,32 +480,42 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out)
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         for (void *h : pinned) (void)hipHostUnregister(h);
         if (e != hipSuccess) return bail(e, "hipHostRegister / copy");
+        if (scan && scan->bad.load()) { (void)hipFree(base); return CFMM_E_ARG; }
         *arena_out = base;
         return CFMM_OK;
     }
     std::lock_guard<std::mutex> lock(g_stage.mu);
     if (!g_stage.buf) {
-        hipError_t e = hipHostMalloc((void **)&g_stage.buf, 2 * STAGE_BYTES, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc((void **)&g_stage.buf, STAGE_SLOTS * STAGE_BYTES, hipHostMallocDefault);
         if (e != hipSuccess) { g_stage.buf = nullptr; return bail(e, "hipHostMalloc(staging)"); }
         for (auto &ev : g_stage.ev) { e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) return bail(e, "hipEventCreate"); }
     }
     int slot = 0;
-    bool used[2] = {false, false};
+    bool used[STAGE_SLOTS] = {};
+    // small columns share a staging chunk: pieces = (column, offset, length) packed into <= STAGE_BYTES
     for (size_t q = 0; q < cols.size(); ++q) {
         for (size_t off = 0; off < cols[q].bytes; off += STAGE_BYTES) {
             const size_t len = std::min(STAGE_BYTES, cols[q].bytes - off);
             char *st = g_stage.buf + (size_t)slot * STAGE_BYTES;
+            const auto t0 = now();
             if (used[slot]) { hipError_t e = hipEventSynchronize(g_stage.ev[slot]); if (e != hipSuccess) return bail(e, "hipEventSynchronize"); }
+            const auto t1 = now();
             parallel_fill(cols[q], st, off, len);
+            const auto t2 = now();
+            if (scan && scan->bad.load(std::memory_order_relaxed)) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(base); return CFMM_E_ARG; }
             hipError_t e = hipMemcpyAsync(base + offs[q] + off, st, len, hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess) e = hipEventRecord(g_stage.ev[slot], ctx->stream);
             if (e != hipSuccess) return bail(e, "hipMemcpyAsync");
-            used[slot] = true; slot ^= 1;
+            t_wait += ms(t0, t1); t_fill += ms(t1, t2); t_enq += ms(t2, now());
+            used[slot] = true; slot = (slot + 1) % STAGE_SLOTS;
         }
         *cols[q].dst = base + offs[q];
     }
+    const auto tC = now();
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return bail(e, "hipStreamSynchronize");
+    if (trace) fprintf(stderr, "[cfmm upload] %.2f MB: hipMalloc %.3f ms, fill %.3f, wait-for-slot %.3f, enqueue %.3f, final sync %.3f, total %.3f\n",
+                       total / 1e6, ms(tA, tB), t_fill, t_wait, t_enq, ms(tC, now()), ms(tA, now()));
     *arena_out = base;
     return CFMM_OK;
 }
@@ -483,7 +634,21 @@ int set_lds_attr(cfmm_ctx *ctx, F f, size_t bytes)
     return CFMM_OK;
 }
 
+int set_all_lds_attrs_uncached(cfmm_ctx *ctx);
+// the limits are per function and device and only ever need to grow: a context with no more tokens than an earlier one
+// on the same device finds them set (40 hipFuncSetAttribute calls per cfmm_create / cfmm_clone otherwise)
 int set_all_lds_attrs(cfmm_ctx *ctx)
+{
+    static std::mutex mu;
+    static int done_n[64] = {};
+    std::lock_guard<std::mutex> g(mu);
+    const int d = ctx->device & 63;
+    if (ctx->n <= done_n[d]) return CFMM_OK;
+    int rc = set_all_lds_attrs_uncached(ctx);
+    if (rc == CFMM_OK) done_n[d] = ctx->n;
+    return rc;
+}
+int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
 {
     const size_t e0 = eval_lds_bytes(ctx->n, false), e1 = eval_lds_bytes(ctx->n, true);
     int rc;
@@ -1121,9 +1286,13 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     ctx->device = device; ctx->n = n_tokens; ctx->ng = n_tokens;
     auto bail = [&](int rc) { g_create_error = ctx->err; cfmm_destroy(ctx); return rc; };
 #define TRY_C(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(ctx, CFMM_E_HIP, "%s -> %s", #call, hipGetErrorString(e_)); return bail(CFMM_E_HIP); } } while (0)
+    static const bool trace_c = getenv("CFMM_UPLOAD_TRACE") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (trace_c) fprintf(stderr, "[cfmm create] %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count()); };
     TRY_C(hipSetDevice(device));
     hipDeviceProp_t prop;
     TRY_C(hipGetDeviceProperties(&prop, device));
+    lap("device properties");
     ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->backend = std::string("hip:") + prop.gcnArchName;
     if (ctx->backend.find("gfx950") == std::string::npos) {
@@ -1134,7 +1303,16 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
         fail(ctx, CFMM_E_LIMIT, "cfmm_create: %d tokens exceed the LDS-staged limit (%d)", n_tokens, (int)((160 * 1024 / 8 - 16) / 3));
         return bail(CFMM_E_LIMIT);
     }
-    TRY_C(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    {   // creating a stream (a hardware queue) takes ~2 ms: streams of destroyed contexts are kept and handed out again
+        // (CFMM_STREAM_POOL=0: always a fresh stream -- the tests that run several "ranks" as contexts of one process need
+        //  streams on distinct hardware queues, which creation order gives and reuse does not)
+        const char *sp = getenv("CFMM_STREAM_POOL");
+        std::lock_guard<std::mutex> g(g_stream_mu);
+        auto &fl = g_free_streams[device & 63];
+        if (!(sp && atoi(sp) == 0) && !fl.empty()) { ctx->stream = fl.back(); fl.pop_back(); }
+    }
+    if (!ctx->stream) TRY_C(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    lap("stream");
     if (const char *s = getenv("CFMM_SLICES")) ctx->nslices = std::min(64, std::max(1, atoi(s)));
     if (const char *s = getenv("CFMM_EVAL_GRID_MULT")) ctx->eval_grid_mult = std::max(1, atoi(s));
     if (const char *s = getenv("CFMM_UPDATE_GENERIC")) ctx->upd_generic = atoi(s) != 0;
@@ -1147,37 +1325,46 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if (const char *s = getenv("CFMM_DETERMINISTIC")) ctx->det = atoi(s) != 0;
     const int n = n_tokens;
     int rc = 0;
-    rc |= dev_upload<double>(ctx, &ctx->c, nullptr, n + 4, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->h, nullptr, n + 4, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->off, nullptr, n + 4, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->glo, nullptr, n + 4, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->ghi, nullptr, n + 4, nullptr);
-    rc |= dev_upload<int>(ctx, &ctx->ctype, nullptr, n + 4, nullptr);
-    rc |= dev_upload<int>(ctx, &ctx->grp, nullptr, n + 4, nullptr);
-    double **vecs[] = {&ctx->nu, &ctx->nu_acc, &ctx->psi_acc, &ctx->psi_t, &ctx->nu0, &ctx->s, &ctx->s_t,
-                       &ctx->Gs, &ctx->Gs_t, &ctx->d, &ctx->Ds};
-    for (auto v : vecs) rc |= dev_upload<double>(ctx, v, nullptr, n + 4, nullptr);     // nu[n] = stop flag; +1: pair loads
-    rc |= dev_upload<double>(ctx, &ctx->S, nullptr, (size_t)MAX_MEMORY * hist_stride(n) + 4, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->Y, nullptr, (size_t)MAX_MEMORY * hist_stride(n) + 4, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->rho, nullptr, MAX_MEMORY, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->acc, nullptr, (size_t)ctx->nslices * acc_stride(n) + 4, nullptr);
-    rc |= dev_upload<DevState>(ctx, &ctx->st, nullptr, 1, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->acc3, nullptr, 3 * (size_t)ctx->nslices * acc_stride(n) + 4, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->xs3, nullptr, 3 * (size_t)XS_VECS * iter_xvs(n) + 4, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->S5, nullptr, (size_t)ITER_RING * hist_stride(n) + 4, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->Y5, nullptr, (size_t)ITER_RING * hist_stride(n) + 4, nullptr);
-    rc |= dev_upload<double>(ctx, &ctx->rho5, nullptr, ITER_RING + 3, nullptr);
-    rc |= dev_upload<DevState>(ctx, &ctx->st3, nullptr, 3, nullptr);
-    rc |= dev_upload<unsigned long long>(ctx, &ctx->acc_l, nullptr, 6 * (size_t)n + 4, nullptr);
-    rc |= dev_upload<long long>(ctx, &ctx->ts, nullptr, 64 + 8 * 4096 + 2048, nullptr);
-    if (rc) return bail(CFMM_E_HIP);
-    TRY_C(hipHostMalloc((void **)&ctx->hst, 2 * sizeof(DevState), hipHostMallocDefault));
-    TRY_C(hipHostMalloc((void **)&ctx->hst3, 6 * sizeof(DevState), hipHostMallocDefault));
+    // every per-context device buffer is carved from ONE allocation, cleared by one fill (31 hipMalloc + fill pairs cost
+    // ~1 ms per context: a clone per batched solve, a context per one-shot problem); likewise the pinned host buffers
+    {
+        struct Piece { void **dst; size_t bytes; };
+        std::vector<Piece> pieces;
+        auto want = [&](auto **pp, size_t count) { pieces.push_back({(void **)pp, count * sizeof(**pp)}); };
+        want(&ctx->c, n + 4); want(&ctx->h, n + 4); want(&ctx->off, n + 4); want(&ctx->glo, n + 4); want(&ctx->ghi, n + 4);
+        want(&ctx->ctype, n + 4); want(&ctx->grp, n + 4);
+        double **vecs[] = {&ctx->nu, &ctx->nu_acc, &ctx->psi_acc, &ctx->psi_t, &ctx->nu0, &ctx->s, &ctx->s_t,
+                           &ctx->Gs, &ctx->Gs_t, &ctx->d, &ctx->Ds};
+        for (auto v : vecs) want(v, n + 4);                  // nu[n] = stop flag; +1: pair loads
+        want(&ctx->S, (size_t)MAX_MEMORY * hist_stride(n) + 4); want(&ctx->Y, (size_t)MAX_MEMORY * hist_stride(n) + 4);
+        want(&ctx->rho, MAX_MEMORY);
+        want(&ctx->acc, (size_t)ctx->nslices * acc_stride(n) + 4);
+        want(&ctx->st, 1);
+        want(&ctx->acc3, 3 * (size_t)ctx->nslices * acc_stride(n) + 4);
+        want(&ctx->xs3, 3 * (size_t)XS_VECS * iter_xvs(n) + 4);
+        want(&ctx->S5, (size_t)ITER_RING * hist_stride(n) + 4); want(&ctx->Y5, (size_t)ITER_RING * hist_stride(n) + 4);
+        want(&ctx->rho5, ITER_RING + 3);
+        want(&ctx->st3, 3);
+        want(&ctx->acc_l, 6 * (size_t)n + 4);
+        want(&ctx->ts, 64 + 8 * 4096 + 2048);
+        size_t total = 0;
+        for (auto &pc : pieces) total += (pc.bytes + 16 + 255) & ~(size_t)255;
+        TRY_C(hipMalloc((void **)&ctx->dev_arena, total));
+        TRY_C(hipMemsetAsync(ctx->dev_arena, 0, total, ctx->stream));
+        size_t off = 0;
+        for (auto &pc : pieces) { *pc.dst = ctx->dev_arena + off; off += (pc.bytes + 16 + 255) & ~(size_t)255; }
+        const size_t hb[4] = {2 * sizeof(DevState), 6 * sizeof(DevState), 2 * (size_t)n * sizeof(double), (size_t)n * sizeof(double)};
+        size_t ho[5] = {0, 0, 0, 0, 0};
+        for (int q = 0; q < 4; ++q) ho[q + 1] = ho[q] + ((hb[q] + 255) & ~(size_t)255);
+        TRY_C(hipHostMalloc((void **)&ctx->host_arena, ho[4], hipHostMallocDefault));
+        ctx->hst = (DevState *)(ctx->host_arena + ho[0]); ctx->hst3 = (DevState *)(ctx->host_arena + ho[1]);
+        ctx->hsol = (double *)(ctx->host_arena + ho[2]); ctx->hnu0 = (double *)(ctx->host_arena + ho[3]);
+    }
+    lap("device + pinned arenas");
     TRY_C(hipHostMalloc((void **)&ctx->hstat_h, 64, hipHostMallocMapped));
     TRY_C(hipHostGetDevicePointer((void **)&ctx->hstat_d, (void *)ctx->hstat_h, 0));
     *ctx->hstat_h = 0;
-    TRY_C(hipHostMalloc((void **)&ctx->hsol, 2 * (size_t)n * sizeof(double), hipHostMallocDefault));
-    TRY_C(hipHostMalloc((void **)&ctx->hnu0, (size_t)n * sizeof(double), hipHostMallocDefault));
+    lap("mapped progress word");
     for (int i = 0; i < 2; ++i) TRY_C(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
     TRY_C(hipEventCreate(&ctx->ev_t0));
     TRY_C(hipEventCreate(&ctx->ev_t1));
@@ -1185,7 +1372,9 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
         fail(ctx, CFMM_E_LIMIT, "cfmm_create: CFMM_DETERMINISTIC=1 with %d tokens exceeds the LDS tile of the reproducible mode", n);
         return bail(CFMM_E_LIMIT);
     }
+    lap("events");
     if ((rc = set_all_lds_attrs(ctx))) return bail(rc);
+    lap("LDS attributes");
     {
         int nb = 0;
         TRY_C(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, eval_kernel<false, false>, EVAL_THREADS, eval_lds_bytes(n, false)));
@@ -1199,8 +1388,10 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     ctx->hc.assign(n, 0.0); ctx->hh.assign(n, 0.0); ctx->hoff.assign(n, 0.0);
     ctx->hctype.assign(n, CFMM_GE); ctx->hgrp.resize(n);
     for (int j = 0; j < n; ++j) ctx->hgrp[j] = j;
+    lap("occupancy queries");
     TRY_C(hipMemcpyAsync(ctx->grp, ctx->hgrp.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     TRY_C(hipStreamSynchronize(ctx->stream));
+    lap("group ids + sync");
 #undef TRY_C
     *out = ctx;
     return CFMM_OK;
@@ -1233,21 +1424,19 @@ int cfmm_destroy(cfmm_ctx *ctx)
     if (ctx->flags2) (void)hipFree(ctx->flags2);
     if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
     for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
-    void *ptrs[] = {ctx->c, ctx->h, ctx->off, ctx->glo, ctx->ghi, ctx->ctype, ctx->grp, ctx->nu, ctx->nu_acc, ctx->psi_acc,
-                    ctx->psi_t, ctx->nu0, ctx->s, ctx->s_t, ctx->Gs, ctx->Gs_t, ctx->d, ctx->Ds, ctx->S, ctx->Y, ctx->rho,
-                    ctx->acc, ctx->st, ctx->ts, ctx->acc3, ctx->xs3, ctx->S5, ctx->Y5, ctx->rho5, ctx->st3, ctx->acc_l};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (ctx->hst) (void)hipHostFree(ctx->hst);
-    if (ctx->hst3) (void)hipHostFree(ctx->hst3);
+    if (ctx->dev_arena) (void)hipFree(ctx->dev_arena);
+    if (ctx->host_arena) (void)hipHostFree(ctx->host_arena);
     if (ctx->hstat_h) (void)hipHostFree((void *)ctx->hstat_h);
-    if (ctx->hsol) (void)hipHostFree(ctx->hsol);
-    if (ctx->hnu0) (void)hipHostFree(ctx->hnu0);
     if (ctx->upd_batch_d) (void)hipFree(ctx->upd_batch_d);
     if (ctx->upd_batch_h) (void)hipHostFree(ctx->upd_batch_h);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream) {
+        std::lock_guard<std::mutex> g(g_stream_mu);
+        auto &fl = g_free_streams[ctx->device & 63];
+        if (fl.size() < 16) fl.push_back(ctx->stream); else (void)hipStreamDestroy(ctx->stream);      // (idle: synchronised above)
+    }
     delete ctx;
     return CFMM_OK;
 }
@@ -1269,51 +1458,57 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
     if (m > 0 && (!Ra || !Rb || !fee || !ia || !ib)) return fail(ctx, CFMM_E_ARG, "upload_pools2: NULL column");
     if (m > 0 && (kind == CFMM_POOL_W2 || kind == CFMM_POOL_CURVE2) && !param) return fail(ctx, CFMM_E_ARG, "upload_pools2: kind %d needs param", kind);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // one pass over the columns, on a few threads: ids, reserves, fee, parameter; and the extrema the reproducible mode needs
-    double mxr = 0.0, mnf = 1.0;
-    {
-        std::mutex mu;
-        int64_t bad = -1; int what = 0;
-        const int ntok = ctx->n;
-        parallel_range(m, [&](int64_t b, int64_t e) {
-            double lmx = 0.0, lmn = 1.0; int64_t lbad = -1; int lwhat = 0;
-            for (int64_t i = b; i < e && lbad < 0; ++i) {
-                if (ia[i] < 0 || ia[i] >= ntok || ib[i] < 0 || ib[i] >= ntok || ia[i] == ib[i]) { lbad = i; lwhat = 1; }
-                else if (!(Ra[i] > 0.0) || !(Rb[i] > 0.0) || !std::isfinite(Ra[i]) || !std::isfinite(Rb[i])) { lbad = i; lwhat = 2; }
-                else if (!(fee[i] > 0.0 && fee[i] <= 1.0)) { lbad = i; lwhat = 3; }
-                else if (kind == CFMM_POOL_W2 && !(param[i] > 0.0 && param[i] < 1.0)) { lbad = i; lwhat = 4; }
-                else if (kind == CFMM_POOL_CURVE2 && !(param[i] > 0.0)) { lbad = i; lwhat = 5; }
-                else { lmx = std::max(lmx, std::max(Ra[i], Rb[i])); lmn = std::min(lmn, fee[i]); }
-            }
-            std::lock_guard<std::mutex> g(mu);
-            mxr = std::max(mxr, lmx); mnf = std::min(mnf, lmn);
-            if (lbad >= 0 && (bad < 0 || lbad < bad)) { bad = lbad; what = lwhat; }
-        });
-        const long long i = (long long)bad;
-        if (what == 1) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has token ids (%d, %d) outside [0,%d) or equal", i, ia[bad], ib[bad], ctx->n);
-        if (what == 2) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has a reserve that is not positive and finite", i);
-        if (what == 3) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has fee %g outside (0, 1]", i, fee[bad]);
-        if (what == 4) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has weight %g outside (0, 1)", i, param[bad]);
-        if (what == 5) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has alpha %g <= 0", i, param[bad]);
-    }
     if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_pools2: the pools are shared with a clone (cfmm_clone); destroy the clones first");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // the new bucket is built first and swapped in only once every column has arrived: a failed upload leaves the
-    // previous pools (and everything derived from them) untouched
+    // the new bucket is built first and swapped in only once every column has arrived and passed its checks: a failed
+    // upload leaves the previous pools (and everything derived from them) untouched.  The checks (ids, reserves, fee,
+    // parameter) and the extrema the reproducible mode needs ride on the staging copy: one pass over the caller's data.
     Bucket2 b = {};
     b.m = m;
     void *arena = nullptr;
+    UploadScan scan;
     if (m > 0) {
+        const int ntok = ctx->n;
         std::vector<Col> cols;
-        cols.push_back(plain_col(Ra, m * sizeof(double), (void **)&b.Ra));
-        cols.push_back(plain_col(Rb, m * sizeof(double), (void **)&b.Rb));
-        cols.push_back(plain_col(fee, m * sizeof(double), (void **)&b.fee));
-        if (param) cols.push_back(plain_col(param, m * sizeof(double), (void **)&b.param));
-        cols.push_back(plain_col(ia, m * sizeof(int32_t), (void **)&b.ia));
-        cols.push_back(plain_col(ib, m * sizeof(int32_t), (void **)&b.ib));
-        int rc = upload_arena(ctx, cols, &arena);
+        auto reserve_ok = [](double x) { return x > 0.0 && x <= std::numeric_limits<double>::max(); };
+        cols.push_back(checked_col<double>(Ra, m, (void **)&b.Ra, &scan, 0, reserve_ok));
+        cols.push_back(checked_col<double>(Rb, m, (void **)&b.Rb, &scan, 0, reserve_ok));
+        cols.push_back(checked_col<double>(fee, m, (void **)&b.fee, &scan, 1, [](double x) { return x > 0.0 && x <= 1.0; }));
+        if (param) {
+            if (kind == CFMM_POOL_W2) cols.push_back(checked_col<double>(param, m, (void **)&b.param, &scan, 2, [](double x) { return x > 0.0 && x < 1.0; }));
+            else if (kind == CFMM_POOL_CURVE2) cols.push_back(checked_col<double>(param, m, (void **)&b.param, &scan, 2, [](double x) { return x > 0.0; }));
+            else cols.push_back(plain_col(param, m * sizeof(double), (void **)&b.param));
+        }
+        cols.push_back(checked_col<int32_t>(ia, m, (void **)&b.ia, &scan, 2, [ntok](int32_t v) { return (uint32_t)v < (uint32_t)ntok; }));
+        {   // ib: its own range, and ia != ib
+            Col c; c.bytes = m * sizeof(int32_t); c.dst = (void **)&b.ib; c.direct = ib;
+            UploadScan *sp = &scan;
+            c.fill = [ia, ib, ntok, sp](char *out, size_t off, size_t len) {
+                const size_t i0 = off / sizeof(int32_t), cnt = len / sizeof(int32_t);
+                std::memcpy(out, ib + i0, len);
+                const int32_t *o = (const int32_t *)out, *a = ia + i0;
+                bool ok = true;
+                for (size_t i = 0; i < cnt; ++i) ok &= ((uint32_t)o[i] < (uint32_t)ntok) & (o[i] != a[i]);
+                if (!ok) sp->bad.store(true, std::memory_order_relaxed);
+            };
+            cols.push_back(c);
+        }
+        int rc = upload_arena(ctx, cols, &arena, &scan);
+        if (rc == CFMM_E_ARG && scan.bad.load()) {
+            // something failed its check: find the first offender for the message (the slow path)
+            for (int64_t i = 0; i < m; ++i) {
+                const long long q = (long long)i;
+                if (ia[i] < 0 || ia[i] >= ntok || ib[i] < 0 || ib[i] >= ntok || ia[i] == ib[i]) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has token ids (%d, %d) outside [0,%d) or equal", q, ia[i], ib[i], ctx->n);
+                if (!(Ra[i] > 0.0) || !(Rb[i] > 0.0) || !std::isfinite(Ra[i]) || !std::isfinite(Rb[i])) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has a reserve that is not positive and finite", q);
+                if (!(fee[i] > 0.0 && fee[i] <= 1.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has fee %g outside (0, 1]", q, fee[i]);
+                if (kind == CFMM_POOL_W2 && !(param[i] > 0.0 && param[i] < 1.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has weight %g outside (0, 1)", q, param[i]);
+                if (kind == CFMM_POOL_CURVE2 && !(param[i] > 0.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has alpha %g <= 0", q, param[i]);
+            }
+            return fail(ctx, CFMM_E_ARG, "upload_pools2: a column failed its checks");
+        }
         if (rc) return rc;
     }
+    const double mxr = scan.mxr, mnf = scan.mnf;
     if (ctx->pools->b2mem[kind]) (void)hipFree(ctx->pools->b2mem[kind]);
     ctx->pools->b2mem[kind] = arena;
     ctx->pools->b2[kind] = b;
@@ -1329,35 +1524,44 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
     if (k < 3 || k > CFMM_MAX_POOL_SIZE || m < 0) return fail(ctx, CFMM_E_LIMIT, "upload_poolsN: pool size %d outside 3..%d", k, CFMM_MAX_POOL_SIZE);
     if (m > 0 && (!idx || !R || !w || !fee)) return fail(ctx, CFMM_E_ARG, "upload_poolsN: NULL column");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    for (int64_t i = 0; i < (int64_t)k * m; ++i)
-        if (idx[i] < 0 || idx[i] >= ctx->n) return fail(ctx, CFMM_E_ARG, "upload_poolsN: token id %d outside [0,%d)", idx[i], ctx->n);
-    for (int64_t i = 0; i < (int64_t)k * m; ++i)
-        if (!(R[i] > 0.0) || !std::isfinite(R[i]) || !(w[i] > 0.0 && w[i] < 1.0))
-            return fail(ctx, CFMM_E_ARG, "upload_poolsN: leg %lld has reserve %g / weight %g (need R > 0, 0 < w < 1)", (long long)i, R[i], w[i]);
-    for (int64_t i = 0; i < m; ++i)
-        if (!(fee[i] > 0.0 && fee[i] <= 1.0)) return fail(ctx, CFMM_E_ARG, "upload_poolsN: pool %lld has fee %g outside (0, 1]", (long long)i, fee[i]);
-    double mxr = 0.0, mnf = 1.0;
-    for (int64_t i = 0; i < (int64_t)k * m; ++i) mxr = std::max(mxr, R[i]);
-    for (int64_t i = 0; i < m; ++i) mnf = std::min(mnf, fee[i]);
     if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_poolsN: the pools are shared with a clone (cfmm_clone); destroy the clones first");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     BucketN b = {};
     b.m = m;
     void *arena = nullptr;
+    UploadScan scan;
     if (m > 0) {
         // the ABI hands columns slot-major [k][m]; the device layout is pool-major [m][k] (leg per lane): transposed
-        // while staging.  log(fee) is computed once here (+8 B per pool instead of one log per wave-tile and evaluation)
-        std::vector<double> lf(m);
-        for (int64_t i = 0; i < m; ++i) lf[i] = std::log(fee[i]);
+        // while staging, checked on the way.  log(fee) is computed once here (+8 B per pool instead of one log per
+        // wave-tile and evaluation)
+        const int ntok = ctx->n;
         std::vector<Col> cols;
-        cols.push_back(transposed_col<int32_t>(idx, k, m, (void **)&b.idx));
-        cols.push_back(transposed_col<double>(R, k, m, (void **)&b.R));
-        cols.push_back(transposed_col<double>(w, k, m, (void **)&b.w));
-        cols.push_back(plain_col(fee, m * sizeof(double), (void **)&b.fee));
-        cols.push_back(plain_col(lf.data(), m * sizeof(double), (void **)&b.lfee));
-        int rc = upload_arena(ctx, cols, &arena);
+        cols.push_back(transposed_col<int32_t>(idx, k, m, (void **)&b.idx, &scan, false, [ntok](int32_t v) { return (uint32_t)v < (uint32_t)ntok; }));
+        cols.push_back(transposed_col<double>(R, k, m, (void **)&b.R, &scan, true, [](double x) { return x > 0.0 && x <= std::numeric_limits<double>::max(); }));
+        cols.push_back(transposed_col<double>(w, k, m, (void **)&b.w, &scan, false, [](double x) { return x > 0.0 && x < 1.0; }));
+        cols.push_back(checked_col<double>(fee, m, (void **)&b.fee, &scan, 1, [](double x) { return x > 0.0 && x <= 1.0; }));
+        {
+            Col c; c.bytes = m * sizeof(double); c.dst = (void **)&b.lfee;
+            c.fill = [fee](char *out, size_t off, size_t len) {
+                double *o = (double *)out; const double *f = fee + off / sizeof(double);
+                for (size_t i = 0; i < len / sizeof(double); ++i) o[i] = std::log(f[i]);
+            };
+            cols.push_back(c);
+        }
+        int rc = upload_arena(ctx, cols, &arena, &scan);
+        if (rc == CFMM_E_ARG && scan.bad.load()) {
+            for (int64_t i = 0; i < (int64_t)k * m; ++i)
+                if (idx[i] < 0 || idx[i] >= ctx->n) return fail(ctx, CFMM_E_ARG, "upload_poolsN: token id %d outside [0,%d)", idx[i], ctx->n);
+            for (int64_t i = 0; i < (int64_t)k * m; ++i)
+                if (!(R[i] > 0.0) || !std::isfinite(R[i]) || !(w[i] > 0.0 && w[i] < 1.0))
+                    return fail(ctx, CFMM_E_ARG, "upload_poolsN: leg %lld has reserve %g / weight %g (need R > 0, 0 < w < 1)", (long long)i, R[i], w[i]);
+            for (int64_t i = 0; i < m; ++i)
+                if (!(fee[i] > 0.0 && fee[i] <= 1.0)) return fail(ctx, CFMM_E_ARG, "upload_poolsN: pool %lld has fee %g outside (0, 1]", (long long)i, fee[i]);
+            return fail(ctx, CFMM_E_ARG, "upload_poolsN: a column failed its checks");
+        }
         if (rc) return rc;
     }
+    const double mxr = scan.mxr, mnf = scan.mnf;
     if (ctx->pools->bnmem[k]) (void)hipFree(ctx->pools->bnmem[k]);
     ctx->pools->bnmem[k] = arena;
     ctx->pools->bn[k] = b;

@@ -545,6 +545,8 @@ def test_batched_solve_error_behaviour():
     ca, cb = a._ensure_ctx(), b._ensure_ctx()
     for c in (ca, cb):
         c.set_utility(u.c, u.h, u.ctype)
+    with pytest.raises(cfmm.CfmmError, match="no start prices"):
+        ca.solve_batch([], None)
     with pytest.raises(cfmm.CfmmError, match="does not share"):
         ca.solve_batch([cb], [net["c"], net["c"]])
     k = ca.clone()
@@ -553,9 +555,7 @@ def test_batched_solve_error_behaviour():
     k.set_utility(u.c, u.h, u.ctype)
     with pytest.raises(cfmm.CfmmError, match="appears twice"):
         ca.solve_batch([k, k], [net["c"]] * 3)
-    with pytest.raises(cfmm.CfmmError, match="no start prices"):
-        ca.solve_batch([k], None)
-    sts = ca.solve_batch([k], [net["c"], None and net["c"] or net["c"]], tol=1e-8)
+    sts = ca.solve_batch([k], [net["c"], None], tol=1e-8)         # (None: continue from the prices the context holds)
     assert [s["status"] for s in sts] == [1, 1] and abs(sts[0]["primal_value"] - sts[1]["primal_value"]) <= 1e-9 * abs(sts[0]["primal_value"])
     clones = [ca.clone() for _ in range(ca.batch_capacity())]
     for c in clones:
@@ -696,7 +696,7 @@ class _ThreadComm:
 
 
 @pytest.mark.parametrize("world,deterministic", [(2, False), (3, False), (2, True)])
-def test_pool_sharded_c_path_with_the_one_shot_all_reduce(oracle_lib, world, deterministic):
+def test_pool_sharded_c_path_with_the_one_shot_all_reduce(oracle_lib, world, deterministic, monkeypatch):
     """`world` ranks = `world` contexts on this GPU, each holding one contiguous pool shard, exchanging [psi | sum arb]
     (or the integer limbs) through the one-shot mailboxes: the whole fold -> all-reduce -> in-launch update control
     flow of an N-GPU job runs here with N > 1.  Every rank must see the same bits, and the unsharded optimum."""
@@ -711,6 +711,7 @@ def test_pool_sharded_c_path_with_the_one_shot_all_reduce(oracle_lib, world, det
     whole.close()          # (its stream's hardware queue goes back to the pool: see conftest.py on GPU_MAX_HW_QUEUES)
     comm = _ThreadComm(world)
     ranks = []
+    monkeypatch.setenv("CFMM_STREAM_POOL", "0")      # fresh streams, created back to back: distinct hardware queues (conftest.py)
     for r in range(world):
         q = cfmm.Problem.from_network(cfmm.distributed.rank_network(net, r, world), utility=cfmm.Arbitrage(net["c"]), deterministic=deterministic)
         q._ensure_ctx()

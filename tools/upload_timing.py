@@ -42,15 +42,17 @@ for _ in range(args.reps):
         ctx.upload_poolsN(b["idx"], b["R"], b["w"], b["fee"])
     per["gn"] = time.perf_counter() - t0
     t.append(time.perf_counter())
-    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"])); p.ctx = ctx; p._uploaded = True
-    p.solve(tol=1e-6); t.append(time.perf_counter())
-    p.solve(tol=1e-6); t.append(time.perf_counter())
+    # the first solve through the C-ABI as INTEGRATION.md's stub drives it (utility, solve, read the prices and psi back)
+    u = cfmm.Arbitrage(net["c"])
+    ctx.set_utility(u.c, u.h, u.ctype); st = ctx.solve(net["c"], tol=1e-6); ctx.get_solution(); t.append(time.perf_counter())
+    p = cfmm.Problem.from_network(net, utility=u); p.ctx = ctx; p._uploaded = True
+    p.solve(tol=1e-6); t.append(time.perf_counter())           # the same through cfmm.Problem (host-side certificates, bookkeeping)
     p.bucket_trades("cp2"); t.append(time.perf_counter())
-    rows.append(dict(create=t[1] - t[0], upload=t[2] - t[1], first=t[3] - t[2], later=t[4] - t[3], readback=t[5] - t[4], evals=p.stats["evals"], **{"up_" + k: v for k, v in per.items()}))
+    rows.append(dict(create=t[1] - t[0], upload=t[2] - t[1], first=t[3] - t[2], later=t[4] - t[3], readback=t[5] - t[4], evals=st["evals"], **{"up_" + k: v for k, v in per.items()}))
     p.close()
 med = lambda k: sorted(r[k] for r in rows)[len(rows) // 2]
 out = dict(config=args.config, pools=cfmm.problem.network_pool_count(net), column_bytes=nbytes, create_ms=1e3 * med("create"), upload_ms=1e3 * med("upload"),
-           upload_GBps=nbytes / med("upload") / 1e9, first_solve_ms=1e3 * med("first"), later_solve_ms=1e3 * med("later"),
+           upload_GBps=nbytes / med("upload") / 1e9, first_solve_ms=1e3 * med("first"), problem_solve_ms=1e3 * med("later"),
            readback_cp2_ms=1e3 * med("readback"), evals=rows[0]["evals"],
            per_bucket_ms={k[3:]: round(1e3 * med(k), 3) for k in rows[0] if k.startswith("up_")},
            pcie_inclusive_subproblems_per_s=cfmm.problem.network_pool_count(net) * rows[0]["evals"] / (med("create") + med("upload") + med("first")))
