@@ -576,7 +576,7 @@ void pools_changed(cfmm_ctx *ctx)
 }
 
 size_t eval_lds_bytes(int n, bool with_d, bool det = false) { return (size_t)eval_lds_doubles(n, with_d, det) * sizeof(double) + (size_t)(EVAL_THREADS / 64) * 64 * 16; }
-size_t iter_lds_bytes(int n, bool det = false) { return eval_lds_bytes(n, false, det) + (size_t)iter_extra_lds_doubles() * sizeof(double); }
+size_t iter_lds_bytes(int n, bool det = false) { return eval_lds_bytes(n, false, det) + (size_t)iter_extra_lds_doubles(n) * sizeof(double); }
 size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 16 * 64 + 64 + 32 + 2 * 12 * 16 + 8) * sizeof(double); }
 
 // processing order of the fused evaluation kernel (heaviest first): bucket code = -k for the

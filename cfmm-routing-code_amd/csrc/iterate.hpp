@@ -214,8 +214,8 @@ __device__ __forceinline__ double uni(double v)
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
-// extra LDS of iter_kernel behind eval_kernel's carve: wave-private copies of the 48 batch totals
-__host__ __device__ inline int iter_extra_lds_doubles() { return 0; }
+// extra LDS of iter_kernel behind eval_kernel's carve: the bounds, stashed between the two halves of the update
+__host__ __device__ inline int iter_extra_lds_doubles(int n) { return 2 * iter_xvs(n); }
 
 // PLAIN: the utility has h == 0, every token CFMM_GE and no upper bounds (linear-utility arbitrage, arbitrage.py:57,77):
 // three of the update's vectors are never read and their registers do not exist (the other instantiation spills a few)
@@ -239,17 +239,12 @@ iter_kernel(IterArgs a)
     double *xm = xw + 16 * 32;                           // [16][2] maxima
     BlockRed red(xm + 32);                               // [2][12][16]
     double *gst_s = psi_s;                               // [n] trial gradient, stashed between the two halves of the update
+    double *sts_s = nu_s;                                // [n] trial point, likewise (the prices are written at the very end)
+    double *glo_s = strips + 2 * 64 * (EVAL_THREADS / 64);   // [xvs] lower bounds | [xvs] upper bounds
+    double *ghi_s = glo_s + a.xvs;
 
     PHASE_STAMP(a.ev.ts, 16);
     const int p = a.phase, pr = (p + 2) % 3, pz = (p + 1) % 3;
-    DevState st = a.st3[pr];
-    if (st.status != 0) {                                // the solve has ended: every workgroup of every later launch leaves here;
-        if (blockIdx.x == 0 && tid == 0) a.st3[p] = st;  // the final state is handed on, or the launch after next would read a set
-        return;                                          // from before the end (status 0) and resume from stale state
-    }
-    st.evals = uni(st.evals); st.iters = uni(st.iters); st.first = uni(st.first); st.hist = uni(st.hist); st.head = uni(st.head);
-    st.nrej = uni(st.nrej); st.f = uni(st.f); st.t_step = uni(st.t_step);
-    PHASE_STAMP(a.ev.ts, 17);
     const int hs = hist_stride(n), stride = acc_stride(n), xvs = a.xvs;
     const double *Xr = a.xs + (size_t)pr * a.xs_set;
     double *Xw = a.xs + (size_t)p * a.xs_set;
@@ -265,6 +260,31 @@ iter_kernel(IterArgs a)
     // others at the barriers: every scalar section below is executed by every wave of a SIMD in turn, so the fewer
     // waves carry variables the shorter it gets (E = 2: 8 waves at 1000 tokens)
     const bool wave_active = wave * 64 * E < n;
+    // the loads whose addresses the rotation phase alone determines go out BEFORE the solver state is waited for (one
+    // dependent memory round trip less on the chain: state -> history slots -> products)
+    double s[E], s_t[E], Gs[E], nuj[E], Ds[E], glo[E], ghi[E], hj[E], cj[E], psi[E];
+    int ct[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { s[e] = s_t[e] = Gs[e] = nuj[e] = Ds[e] = glo[e] = cj[e] = 0.0; psi[e] = 0.0; ghi[e] = __builtin_inf(); hj[e] = 0.0; ct[e] = 0; }
+    if (wave_active) {
+        ldE<E>(Xr, ld0, s); ldE<E>(Xr + xvs, ld0, s_t); ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 4 * xvs, ld0, nuj);
+        ldE<E>(a.Ds, ld0, Ds); ldE<E>(a.glo, ld0, glo); ldE<E>(a.c, ld0, cj);
+        if (!PLAIN) { ldE<E>(a.ghi, ld0, ghi); ldE<E>(a.h, ld0, hj); ldEi<E>(a.ctype, ld0, ct); }
+        for (int sl = 0; sl < a.nread; ++sl) {
+            double t1[E];
+            ldE<E>(Ar + (size_t)sl * stride, ld0, t1);
+#pragma unroll
+            for (int e = 0; e < E; ++e) psi[e] += t1[e];
+        }
+    }
+    DevState st = a.st3[pr];
+    if (st.status != 0) {                                // the solve has ended: every workgroup of every later launch leaves here;
+        if (blockIdx.x == 0 && tid == 0) a.st3[p] = st;  // the final state is handed on, or the launch after next would read a set
+        return;                                          // from before the end (status 0) and resume from stale state
+    }
+    st.evals = uni(st.evals); st.iters = uni(st.iters); st.first = uni(st.first); st.hist = uni(st.hist); st.head = uni(st.head);
+    st.nrej = uni(st.nrej); st.f = uni(st.f); st.t_step = uni(st.t_step);
+    PHASE_STAMP(a.ev.ts, 17);
 
     // the set the NEXT launch flushes into was last read one launch ago: one workgroup clears it now
     if (blockIdx.x == gridDim.x - 1) {
@@ -293,19 +313,9 @@ iter_kernel(IterArgs a)
         for (int k = 0; k < P; ++k) { in.S[k][e] = 0.0; in.Y[k][e] = 0.0; }
     }
     if (wave_active) {
-        double s[E], s_t[E], Gs[E], nuj[E], Ds[E], glo[E], ghi[E], hj[E], cj[E], psi[E], dg[E];
-        int ct[E];
-        ldE<E>(Xr, ld0, s); ldE<E>(Xr + xvs, ld0, s_t); ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 4 * xvs, ld0, nuj);
-        ldE<E>(a.Ds, ld0, Ds); ldE<E>(a.glo, ld0, glo); ldE<E>(a.c, ld0, cj);
+        double dg[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) { psi[e] = 0.0; dg[e] = 0.0; ghi[e] = __builtin_inf(); hj[e] = 0.0; ct[e] = 0; }
-        if (!PLAIN) { ldE<E>(a.ghi, ld0, ghi); ldE<E>(a.h, ld0, hj); ldEi<E>(a.ctype, ld0, ct); }
-        for (int sl = 0; sl < a.nread; ++sl) {
-            double t1[E];
-            ldE<E>(Ar + (size_t)sl * stride, ld0, t1);
-#pragma unroll
-            for (int e = 0; e < E; ++e) psi[e] += t1[e];
-        }
+        for (int e = 0; e < E; ++e) dg[e] = 0.0;
         if (st.first) {                                  // first update of a solve: the diagonal metric rides along
             for (int sl = 0; sl < a.nread; ++sl) {
                 double t2[E];
@@ -359,6 +369,8 @@ iter_kernel(IterArgs a)
                 in.H0[e] = H > 0.0 ? rcp_nr(H) : 0.0;
                 in.hq[e] = in.H0[e] * in.q0[e];
                 gst_s[r0 + e] = Gs_t[e];
+                sts_s[r0 + e] = s_t[e]; glo_s[r0 + e] = glo[e];
+                if (!PLAIN) ghi_s[r0 + e] = ghi[e];
             }
         }
         PHASE_STAMP(a.ev.ts, 18);
@@ -400,20 +412,22 @@ iter_kernel(IterArgs a)
         bool pair_ok = false;
         const int old_hist0 = st.hist;
         if (!st.first) {
-            if (T(4) > 1e-12 * sqrt(T(5)) * sqrt(T(6))) {
+            const double sy = T(4);
+            if (sy > 0.0 && sy * sy > 1e-24 * T(5) * T(6)) {          // (s'y > 1e-12 |s| |y|, without the square roots)
                 pair_ok = true;
                 if (wave_active && r0 < n) { stE<E>(a.S + (size_t)st.head * hs, r0, nS, in.S[0]); stE<E>(a.Y + (size_t)st.head * hs, r0, nS, in.Y[0]); }
-                if (wr && tid == 0) a.rho[st.head] = 1.0 / T(4);
+                if (wr && tid == 0) a.rho[st.head] = rcp_nr(sy);
                 st.head = (st.head + 1) % RS;
                 if (st.hist < M) st.hist += 1;
             }
             st.iters += 1;
         }
         st.f = f_t;
-        st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
-        st.infeas = viol / fmax(scale, 1e-300);
+        const double rf = rcp_nr(fmax(1.0, fabs(f_t)));      // (v_rcp_f64 + two Newton steps: ~1 ulp, a fifth of the IEEE division's chain)
+        st.gap = fabs(gapv) * rf;
+        st.infeas = viol * rcp_nr(fmax(scale, 1e-300));
         st.primal = f_t - gapv;                   // c'psi = g - (nu - c)'(psi + h)
-        st.pg = T(7) / fmax(1.0, fabs(f_t));
+        st.pg = T(7) * rf;
         gp_sq = T(7);                              // (sum |projected gradient|: positive iff some free variable has a gradient)
         const bool was_first = st.first != 0;
         st.first = 0;
@@ -426,7 +440,7 @@ iter_kernel(IterArgs a)
             new_dir = true;
             if (wave_active) {                           // (waves without variables need no direction: they wait at the next barrier)
             const int keep_old = was_first ? 0 : (pair_ok ? (old_hist0 < M ? old_hist0 : M - 1) : old_hist0);
-            rho[0] = pair_ok ? 1.0 / T(4) : 0.0;
+            rho[0] = pair_ok ? rcp_nr(T(4)) : 0.0;
 #pragma unroll
             for (int k = 1; k < P; ++k) if (k - 1 >= keep_old) rho[k] = 0.0;
 #pragma unroll
@@ -454,20 +468,20 @@ iter_kernel(IterArgs a)
     PHASE_STAMP(a.ev.ts, 21);
 
     // ================= second half: the direction, the next trial point =================================================
-    // second half's inputs, reloaded (L1 / L2 hits; requesting them before the recursion to hide their latency only made the
-    // allocator spill across it): the accepted point (s moves to the trial point, or stays), its gradient (the stashed
-    // trial gradient, or the old one), the old direction in case this trial point is rejected, the bounds
-    double s[E], Gs[E], d[E], glo[E], ghi[E];
+    // second half's inputs come back from the LDS stash (keeping them in registers across the reduction spills; global
+    // reloads cost an L2 round trip on the chain): the accepted point (s moves to the trial point, or stays), its
+    // gradient (the stashed trial gradient, or the old one), the bounds; a rejected trial point reloads the old point,
+    // gradient and direction from the state set
+    double d[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) { s[e] = Gs[e] = d[e] = glo[e] = 0.0; ghi[e] = __builtin_inf(); }
     if (wave_active) {
-        ldE<E>(Xr + (accept ? xvs : 0), ld0, s);
-        ldE<E>(a.glo, ld0, glo);
-        if (!PLAIN) ldE<E>(a.ghi, ld0, ghi);
-        if (accept) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) Gs[e] = tin[e] ? gst_s[r0 + e] : 0.0;
-        } else { ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 3 * xvs, ld0, d); }
+        for (int e = 0; e < E; ++e) if (tin[e]) { glo[e] = glo_s[r0 + e]; if (!PLAIN) ghi[e] = ghi_s[r0 + e]; }
+        if (accept) {                                    // the trial point and its gradient: from the LDS stash
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (tin[e]) { s[e] = sts_s[r0 + e]; Gs[e] = gst_s[r0 + e]; }
+        } else { ldE<E>(Xr, ld0, s); ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 3 * xvs, ld0, d); }
         if (wr && accept && r0 < n) {                    // the accepted prices and their net trade, for the read-back
             double psi[E], nuj[E];
 #pragma unroll
@@ -505,7 +519,7 @@ iter_kernel(IterArgs a)
             red.run<0, 1>(m1);
             F[1] = m1[0];
         }
-        st.t_step = (F[1] > a.max_step) ? a.max_step / F[1] : 1.0;
+        st.t_step = (F[1] > a.max_step) ? a.max_step * rcp_nr(F[1]) : 1.0;
     }
     PHASE_STAMP(a.ev.ts, 22);
 
