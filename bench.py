@@ -53,29 +53,41 @@ METRIC = "pool-subproblems/sec to 1e-6 rel-gap; 1e6 pools / 1k tokens; 1/2/4/8 G
 
 
 def profile_record(config):
-    """HBM bytes per eval_kernel launch (PMC, corrected as MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE
-    doubled on gfx950, + WRITE_SIZE) and the rocprofv3 kernel-trace average of the same launch, from the NEWEST
-    summary committed under profiles/ -- read at run time so that the bench line cannot go stale silently."""
-    out = dict(traffic=None, traffic_file=None, rocprof_avg_us=None, rocprof_file=None)
+    """HBM bytes per launch (PMC, corrected as MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE doubled on gfx950,
+    + WRITE_SIZE) and the rocprofv3 kernel-trace average of the same launch, from the NEWEST summaries committed under
+    profiles/ -- read at run time so that the bench line cannot go stale silently.  Two records: "iter" = iter_kernel
+    (the one launch per outer iteration; averages over its FULL launches, the idle run-ahead launches behind the end of a
+    solve excluded) from tools/profile_iter.py's trace, "eval" = eval_kernel alone from tools/profile_eval.py's."""
+    import json
+    out = {k: dict(traffic=None, traffic_file=None, rocprof_avg_us=None, rocprof_file=None) for k in ("iter", "eval")}
     pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_pmc_medians.csv")))
-    for f in reversed(pmc):
-        rows = {}
-        for r in csv.DictReader(open(f)):
-            if r["config"] == config and ("eval" in r["kernel"] or "iter_kernel" in r["kernel"]) and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
-                rows.setdefault(r["kernel"], {})[r["counter"]] = float(r["median"])
-        rows = {k: v for k, v in rows.items() if len(v) == 2}
-        if rows:                                   # the evaluation kernel that moves the most bytes: the dominant one
-            v = max(rows.values(), key=lambda v: v["FETCH_SIZE"])
-            out["traffic"] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
-            out["traffic_file"] = os.path.relpath(f, ROOT)
+    for which, cfg, name in (("iter", config + "iter", "iter_kernel"), ("eval", config, "eval_kernel")):
+        for f in reversed(pmc):
+            rows = {}
+            for r in csv.DictReader(open(f)):
+                if r["config"] == cfg and name in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    rows.setdefault(r["kernel"], {})[r["counter"]] = float(r["median"])
+            rows = {k: v for k, v in rows.items() if len(v) == 2}
+            if rows:                                   # the instantiation that moves the most bytes: the dominant one
+                v = max(rows.values(), key=lambda v: v["FETCH_SIZE"])
+                out[which]["traffic"] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+                out[which]["traffic_file"] = os.path.relpath(f, ROOT)
+                break
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_durations.json")))):
+        d = json.load(open(f)).get(config + "iter", {})
+        cand = [v for k, v in d.items() if "iter_kernel" in k]
+        if cand:
+            v = max(cand, key=lambda v: v["full_launches"])
+            out["iter"]["rocprof_avg_us"] = v["full_mean_us"]
+            out["iter"]["rocprof_file"] = os.path.relpath(f, ROOT)
             break
     stats = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_rocprofv3_kernel_stats_{config}.csv")))
     for f in reversed(stats):
-        cand = [r for r in csv.DictReader(open(f)) if "eval" in r.get("Name", "") or "iter_kernel" in r.get("Name", "")]
+        cand = [r for r in csv.DictReader(open(f)) if "eval_kernel" in r.get("Name", "")]
         if cand:
             r = max(cand, key=lambda r: float(r["TotalDurationNs"]))
-            out["rocprof_avg_us"] = float(r["AverageNs"]) / 1e3
-            out["rocprof_file"] = os.path.relpath(f, ROOT)
+            out["eval"]["rocprof_avg_us"] = float(r["AverageNs"]) / 1e3
+            out["eval"]["rocprof_file"] = os.path.relpath(f, ROOT)
             break
     return out
 
@@ -221,6 +233,7 @@ def main():
         if "gn" in prob.net:
             mix += ", gn3-8=" + str(sum(b["R"].shape[1] for b in prob.net["gn"].values()))
         prof = profile_record(args.config)
+        pk = "iter" if prob.stats.get("method") == 1 and prof["iter"]["rocprof_avg_us"] else "eval"
         us_iter = 1e6 * dev_s / max(evals, 1)
         if strong:
             workload = (f"C4: {total_pools} constant-product pools / {net['n_tokens']} tokens split over {world} GPU(s) "
@@ -252,12 +265,13 @@ def main():
             # launched without the update (eval_kernel, what cfmm_eval_dual runs), timed as back-to-back launches.
             "roofline": {"bound": "hbm", "kernel": "iter_kernel (nu update + evaluation, one launch per iteration)" if prob.stats.get("method") == 1 else dom["kernel"],
                          "achieved": dom["bytes"] / (us_iter * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dom["bytes"] / (us_iter * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": prof["traffic"],
-                         "traffic_source": prof["traffic_file"],
+                         "unit": "GB/s", "frac": dom["bytes"] / (us_iter * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": prof[pk]["traffic"],
+                         "traffic_source": prof[pk]["traffic_file"],
                          "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": us_iter,
-                         "rocprof_avg_launch_us": prof["rocprof_avg_us"], "rocprof_source": prof["rocprof_file"],
+                         "rocprof_avg_launch_us": prof[pk]["rocprof_avg_us"], "rocprof_source": prof[pk]["rocprof_file"],
                          "evaluation_only": {"kernel": "eval_kernel", "avg_launch_us": dom["seconds"] * 1e6, "achieved": dom["GBps"],
-                                             "frac": dom["GBps"] / HBM_PEAK_GBS},
+                                             "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": prof["eval"]["traffic"],
+                                             "rocprof_avg_launch_us": prof["eval"]["rocprof_avg_us"], "rocprof_source": prof["eval"]["rocprof_file"]},
                          "note": TRAFFIC_NOTE[args.config],
                          "all_kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]},
         }
