@@ -551,9 +551,10 @@ class Problem:
         total["wall_seconds"] += st["wall_seconds"]; total["device_seconds"] += st["device_seconds"]
         return st
 
-    def _kink_candidates(self, nu, kink_tol, banned, tied):
+    def _kink_candidates(self, nu, kink_tol, banned, tied, loose=False):
         """constant-sum pools whose price ratio sits on one of their two kinks
-        (log nu_a - log nu_b = +-log gamma): nearest kink, within kink_tol and well inside its half.
+        (log nu_a - log nu_b = +-log gamma): nearest kink, within kink_tol and well inside its half
+        (`loose`: anywhere within kink_tol of it -- a guess for a leg that would not converge; see _solve_kinks).
         Returns {(rank, i): record}: the pool's data travels with its key, so that every rank of a pool-sharded
         solve can build the same ties and the same fill recovery from the union of all ranks' candidates."""
         rank = self._host.rank if self._host else 0
@@ -564,13 +565,13 @@ class Problem:
             lg = np.log(b["fee"])
             sgn = np.where(r < 0, 1, -1)                 # a->b kink at r = lg < 0, b->a kink at r = -lg > 0
             dist = np.abs(r - sgn * lg)
-            near = (dist < kink_tol) & ((dist < 0.5 * np.abs(lg)) | (lg == 0.0))
+            near = (dist < kink_tol) & ((dist < 0.5 * np.abs(lg)) | (lg == 0.0) | loose)
             for i in np.flatnonzero(near):               # (only the pools on a kink: the scan itself is vectorised)
                 i = int(i)
                 key = (rank, i)
                 if key not in tied and (key, int(sgn[i])) not in banned:
                     out[key] = dict(sgn=int(sgn[i]), ia=int(b["ia"][i]), ib=int(b["ib"][i]), fee=float(b["fee"][i]),
-                                    Ra=float(b["Ra"][i]), Rb=float(b["Rb"][i]))
+                                    Ra=float(b["Ra"][i]), Rb=float(b["Rb"][i]), loose=bool(loose))
         if self._host:                                   # the union over ranks, identical everywhere
             merged = {}
             for part in self._host.allgather(out):
@@ -588,7 +589,9 @@ class Problem:
         rank = self._host.rank if self._host else 0
         m2 = len(self.net["sum2"]["Ra"]) if "sum2" in self.net else 0
         tied, banned = {}, set()
-        budget = min(kw["max_evals"], 100)
+        # legs: short on small networks (a solve stuck on a kink gains nothing from more evaluations: the reference's own
+        # instances spent 300 of their 315 evaluations that way), longer where an evaluation covers many pools
+        budget = min(kw["max_evals"], 40 if self.m <= 1000 else 100)
         st = None
         psi = None
         for _ in range(8 * max_rounds):
@@ -625,9 +628,21 @@ class Problem:
                     return st, nu, psi
                 if bad:                   # fully on / fully off after all: back to bang-bang
                     for k in bad:
-                        banned.add((k, tied[k]["sgn"])); del tied[k]
+                        rec = tied.pop(k)
+                        banned.add((k, rec["sgn"]))
+                        # a guessed kink that carries no trade: the pool's fee band is narrower than the leg could
+                        # resolve and the optimum sits on its OTHER kink (arbitrage.py / liquidation.py: fee 0.999)
+                        if rec.get("loose") and theta[k] <= 1e-9 and (k, -rec["sgn"]) not in banned:
+                            tied[k] = dict(rec, sgn=-rec["sgn"], loose=False)
+                    tied = dict(sorted(tied.items()))
                     continue
             new = self._kink_candidates(nu, kink_tol, banned, tied)
+            # nothing within the tolerance although the leg did not converge: look further out before spending another leg
+            # (a wrongly tied pool shows as a fill outside (0,1) and is released again)
+            wide = kink_tol
+            while not new and st["status"] != 1 and wide < 0.05:
+                wide *= 10
+                new = self._kink_candidates(nu, wide, banned, tied, loose=True)
             if new:
                 tied.update(new)
                 tied = dict(sorted(tied.items()))
@@ -665,12 +680,17 @@ class Problem:
         rhs = -r[rows] * nu[rows]
         if A.shape[0] == 0:
             th = np.full(len(keys), 0.5)
+        elif len(keys) == 1:              # one tied pool (every shipped script): the bounded least squares in closed form
+            a1 = A[:, 0]
+            th = np.array([min(1.0, max(0.0, float(a1 @ rhs) / max(float(a1 @ a1), 1e-300)))])
         else:
-            try:
-                from scipy.optimize import lsq_linear
-                th = lsq_linear(A, rhs, bounds=(0.0, 1.0), tol=1e-14).x
-            except Exception:
-                th = np.clip(np.linalg.lstsq(A, rhs, rcond=None)[0], 0.0, 1.0)
+            th = np.linalg.lstsq(A, rhs, rcond=None)[0]
+            if th.min() < 0.0 or th.max() > 1.0:          # a bound is active: the bounded problem proper
+                try:
+                    from scipy.optimize import lsq_linear
+                    th = lsq_linear(A, rhs, bounds=(0.0, 1.0), tol=1e-14).x
+                except Exception:
+                    th = np.clip(th, 0.0, 1.0)
         tot = r + D @ th
         scale = max(1.0, float(np.abs(nu * (np.abs(psi) + np.abs(u.h))).sum()))
         res_eq = np.abs(nu[must] * tot[must]).sum() / scale if must.any() else 0.0

@@ -28,6 +28,7 @@
 #include "../../include/cfmm.h"
 #include "kernels.hpp"
 #include "iterate.hpp"
+#include "tiny.hpp"
 #include "oneshot.hpp"
 #include "smooth.hpp"
 #include "chol.hpp"
@@ -133,6 +134,7 @@ struct cfmm_ctx {
 
     // fused iteration (iterate.hpp): three rotating sets of accumulators / solver state, a history ring of M + 1 slots
     bool fused = true;                 // CFMM_FUSED=0: the two-launch iteration of round 1 (A/B)
+    bool tiny_path = true;             // CFMM_TINY=0: tiny networks through the grid-wide path too (A/B)
     bool plain = false;                // utility has h == 0 and only CFMM_GE tokens (IterArgs::plain)
     // reproducible mode (kernels.hpp: Scatter<true>): psi accumulated as exact fixed-point integers
     bool det = false;
@@ -706,6 +708,7 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, update_gram_kernel<512, 2, true>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, start_kernel<true>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, eval_batch_kernel, batch_lds_bytes(ctx->n, batch_capacity(ctx->n))))) return rc;
+    if (ctx->n <= TINY_N && (rc = set_lds_attr(ctx, solve_tiny_kernel, (size_t)tiny_lds_doubles(ctx->n) * sizeof(double)))) return rc;
     const size_t il = iter_lds_bytes(ctx->n);
     if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, false>, il))) return rc;
     if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, true>, il))) return rc;
@@ -740,6 +743,13 @@ UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
     a.max_evals = o.max_evals; a.pg_rule = o.pg_rule; a.ts = ctx->ts;
     a.batch = nullptr; a.hstat = nullptr;
     return a;
+}
+
+// ---- tiny networks (the reference's own instances): the whole solve in one launch of one workgroup (tiny.hpp) -----
+bool tiny_applies(cfmm_ctx *ctx, const EvalArgs &ea, const cfmm_opts &o)
+{
+    return ctx->tiny_path && !sharded(ctx) && !ctx->det && ctx->pools->b2[CFMM_POOL_CURVE2].m == 0 && ea.ntiles >= 1 &&
+           ea.ntiles <= TINY_MAX_TILES && ctx->n <= TINY_N && o.memory <= MAX_MEMORY;
 }
 
 // ---- the fused iteration (iterate.hpp) ---------------------------------------------------------------------------
@@ -1359,6 +1369,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if (const char *s = getenv("CFMM_MULTI_GRAPH")) ctx->multi_graph = atoi(s) != 0;
     if (const char *s = getenv("CFMM_NO_GRAPH")) ctx->no_graph = atoi(s) != 0;
     if (const char *s = getenv("CFMM_FUSED")) ctx->fused = atoi(s) != 0;
+    if (const char *s = getenv("CFMM_TINY")) ctx->tiny_path = atoi(s) != 0;
     if (const char *s = getenv("CFMM_RUN_AHEAD")) ctx->run_ahead = std::max(1, atoi(s));
     if (const char *s = getenv("CFMM_DETERMINISTIC")) ctx->det = atoi(s) != 0;
     const int n = n_tokens;
@@ -1869,7 +1880,9 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     cfmm_opts o = o_in;
     // One launch per iteration (iterate.hpp) whenever the update fits the evaluation launch; otherwise the
     // two-launch iteration (evaluation kernel, single-workgroup update kernel).
-    const bool fused = fused_applies(ctx, o);
+    const EvalArgs ea_small = make_eval_args(ctx, false);
+    const bool small = tiny_applies(ctx, ea_small, o);
+    const bool fused = !small && fused_applies(ctx, o);
     if (fused) o.iters_per_graph = (o.iters_per_graph + 2) / 3 * 3;       // the rotation phase t % 3 is baked into captured launches
     // Single GPU: `iters_per_graph` iterations are replayed from one captured hipGraph.  Pool-sharded
     // (RCCL all-reduce inside every iteration): the same iterations are enqueued eagerly, the way RCCL
@@ -1877,7 +1890,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     static const bool graph_forced = getenv("CFMM_FUSED_GRAPH") && atoi(getenv("CFMM_FUSED_GRAPH")) != 0;     // (A/B: replay the fused launches from a graph)
     const bool shard = sharded(ctx);
     const bool use_graph_opt = fused && !shard && graph_forced;
-    const bool use_graph = (!shard || (ctx->multi_graph && !ctx->os_ready)) && !ctx->no_graph && (!fused || shard || graph_forced);
+    const bool use_graph = !small && (!shard || (ctx->multi_graph && !ctx->os_ready)) && !ctx->no_graph && (!fused || shard || graph_forced);
     if (use_graph && (!ctx->g_valid || !same_opts(o, ctx->g_opts))) { int rc = build_graph(ctx, o); if (rc) return rc; }
     UpdArgs ua = make_upd_args(ctx, o);
     const IterArgs ia = make_iter_args(ctx, o);
@@ -1908,6 +1921,13 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
             hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc3, n, ctx->nslices, 1, (const DevState *)nullptr);
             int rc = all_reduce(ctx, ctx->acc3, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc;
         }
+    } else if (small) {
+        // one workgroup, one launch: every evaluation and update of the solve, nothing of it in global memory (tiny.hpp);
+        // the device ends it: converged, stalled, or out of budget
+        hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
+                           ctx->acc, (long long)((size_t)ctx->nslices * acc_stride(n)), (DevState *)nullptr, 0);
+        const int threads = 64 * std::min(TINY_THREADS / 64, std::max(1, ea_small.ntiles));
+        hipLaunchKernelGGL(solve_tiny_kernel, dim3(1), dim3(threads), (size_t)tiny_lds_doubles(n) * sizeof(double), ctx->stream, ea_small, ua, o.max_evals + 1);
     } else {
         hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
                            ctx->acc, (long long)((size_t)ctx->nslices * acc_stride(n)), (DevState *)nullptr, 0);
@@ -1925,7 +1945,9 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     DevState *hring = fused ? ctx->hst3 : ctx->hst;
     const DevState *dst = fused ? ctx->st3 : ctx->st;
     int status = 0, t = 1;
-    if (fused && !shard && !use_graph_opt) {
+    if (small) {
+        // (nothing to enqueue: the read-back below waits for the one launch)
+    } else if (fused && !shard && !use_graph_opt) {
         // Single GPU, one launch per iteration: launches are enqueued eagerly, a few ahead of the device, whose workgroup 0
         // reports {evals, status} into a pinned host word as it goes (zero-copy: the host polls memory, no API call, no
         // copy engine).  No graph-replay gaps (~19 us per replay), and only `run_ahead` idle launches behind the end.

@@ -343,7 +343,9 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
 // prices, psi_s (diag_s) are zero, *next_tile is 0 and a barrier has been passed; `acc` is the accumulator set to flush into.
 // BATCH: `bc` describes the B price vectors / psi tiles in LDS, `acc_b[b]` is where vector b's tile is flushed; sum arb
 // is formed at the flush as nu' psi per vector (sum_i arb_i = sum_i nu' y_i) instead of being carried per lane.
-template <bool WITH_D, bool STABLE, bool DET = false, bool BATCH = false>
+// FLUSH = false: the tiles stay in LDS (psi_t, diag_t, fpart[wave] = per-wave partial of sum arb) for a consumer in the same
+// workgroup (tiny.hpp)
+template <bool WITH_D, bool STABLE, bool DET = false, bool BATCH = false, bool FLUSH = true>
 __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *acc, const double *nu_s, double *psi_t, double *diag_t,
                                                      double *fpart, int *next_tile, double2 *xs, const BatchCtl &bc = BatchCtl{1u, 0, 0},
                                                      double *const *acc_b = nullptr)
@@ -433,6 +435,7 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
     if (lane == 0) fpart[wib] = fsum;
     __syncthreads();
     PHASE_STAMP(a.ts, 3);
+    if constexpr (!FLUSH) return;
 
     if constexpr (DET) {
         // integer limbs: ONE global accumulator (no slices: the order of these atomics cannot change the sum)
@@ -707,17 +710,15 @@ __device__ __forceinline__ bool is_active(double s, double lo, double hi, double
     return (s <= lo + 1e-14 && G > 0.0) || (s >= hi - 1e-14 && G < 0.0) || (lo == hi);
 }
 
-template <bool BATCH = false>
-__global__ void __launch_bounds__(UPD_THREADS)
-update_kernel(UpdArgs a0)
+// the body of the generic update: any token count, price ties, any memory.  `lds`: upd_lds_bytes(ng) of scratch.
+// Returns the solve's status after the step (the same in every thread).
+__device__ __forceinline__ int update_generic_body(const UpdArgs &a, double *lds)
 {
-    const UpdArgs &a = upd_args<BATCH>(a0);
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     double *q = lds;                         // [ng]
     double *q2 = lds + a.ng;                 // [ng]
     double *scratch = lds + 2 * a.ng;        // [16*8]
     DevState st = *a.st;
-    if (st.status != 0) return;
+    if (st.status != 0) return st.status;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int n = a.n, ng = a.ng, M = a.M;
     const int stride = acc_stride(n);
@@ -902,6 +903,15 @@ update_kernel(UpdArgs a0)
         if (st.evals >= a.max_evals) st.status = 3;
     }
     if (tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; report_progress(a, st); }
+    return st.status;
+}
+
+template <bool BATCH = false>
+__global__ void __launch_bounds__(UPD_THREADS)
+update_kernel(UpdArgs a0)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    (void)update_generic_body(upd_args<BATCH>(a0), lds);
 }
 
 // ------------------------------------------------------------------------------------------

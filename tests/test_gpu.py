@@ -207,6 +207,27 @@ def test_two_asset_sweep_warm_started():
     p.close()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_tiny_one_launch_solve_matches_the_grid_path(seed, monkeypatch):
+    """networks of the reference's own size (<= 64 tokens, <= 64 wave-tiles) are solved by ONE workgroup in ONE launch
+    (tiny.hpp: tiles stay in LDS, the update is one wave); CFMM_TINY=0 sends the same instance through the grid-wide
+    kernels: same optimum, same certificates, comparable evaluation counts -- price ties (a constant-sum pool on its
+    kink) included"""
+    inst = random_instance(seed, n_tokens=5 + seed, n_pools=8 + 3 * seed, with_sum=True, utility=("arbitrage", "liquidate", "swap", "arbitrage")[seed])
+    res = {}
+    for tiny in ("1", "0"):
+        monkeypatch.setenv("CFMM_TINY", tiny)
+        p = problem_of(inst)
+        v = p.solve(tol=1e-9)
+        res[tiny] = (v, p.status, p.psi.copy(), p.stats["evals"], p.gap, p.infeas)
+        p.close()
+    (v1, s1, psi1, e1, g1, i1), (v0, s0, psi0, e0, g0, i0) = res["1"], res["0"]
+    assert s1 == s0 == "optimal" and max(g1, g0, i1, i0) <= 1e-9
+    assert abs(v1 - v0) <= 1e-8 * max(1.0, abs(v0))
+    assert np.abs(psi1 - psi0).max() <= 1e-6 * max(1.0, np.abs(psi0).max())
+    assert e1 <= 2 * e0 + 20 and e0 <= 2 * e1 + 20
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_small_instances_vs_primal(seed):
     from oracle.primal_scipy import solve_primal
