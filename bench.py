@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--cpu-solves", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--kernel-reps", type=int, default=50)
-    ap.add_argument("--allreduce", default=os.environ.get("CFMM_ALLREDUCE", "rccl"), choices=["rccl", "oneshot"],
+    ap.add_argument("--allreduce", default=os.environ.get("CFMM_ALLREDUCE", "auto"), choices=["auto", "rccl", "oneshot"],
                     help="the per-evaluation all-reduce: RCCL (default) or the one-shot xGMI exchange (csrc/oneshot.hpp)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the pool-sharded code path (process group, RCCL communicator, all-reduce per evaluation) even with one rank")
@@ -248,7 +248,9 @@ def main():
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "pools_per_gpu": prob.m, "pools_total": total_pools, "tokens": net["n_tokens"], "seed": 0,
                        "parallelism": f"pool-sharding x{world}" if world > 1 else "single GPU",
-                       "rccl_ranks": prob.stats.get("n_ranks", 1), "allreduce": args.allreduce if sharded else None},
+                       "rccl_ranks": prob.stats.get("n_ranks", 1),
+                       "allreduce": getattr(prob, "allreduce", args.allreduce) if sharded else None,
+                       "allreduce_note": getattr(prob, "allreduce_note", "") if sharded else None},
             "evals_per_solve": evals / args.steps,
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "us_per_eval": 1e6 * dt / max(evals, 1),

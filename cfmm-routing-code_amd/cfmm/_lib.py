@@ -57,7 +57,7 @@ SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm
            "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_set_pool_flags", "cfmm_set_utility",
            "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_comm_unique_id", "cfmm_comm_init",
-           "cfmm_oneshot_export", "cfmm_oneshot_import", "cfmm_oneshot_attach", "cfmm_oneshot_mailbox",
+           "cfmm_oneshot_export", "cfmm_oneshot_import", "cfmm_oneshot_attach", "cfmm_oneshot_mailbox", "cfmm_oneshot_enable",
            "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
 
 
@@ -100,6 +100,7 @@ def lib():
     L.cfmm_oneshot_import.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
     L.cfmm_oneshot_attach.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.cfmm_oneshot_mailbox.restype = vp; L.cfmm_oneshot_mailbox.argtypes = [vp]
+    L.cfmm_oneshot_enable.argtypes = [vp, C.c_int]
     L.cfmm_time_eval_kernel.argtypes = [vp, C.c_int, C.c_int, dp]
     L.cfmm_time_collective.argtypes = [vp, C.c_int, dp, dp]
     L.cfmm_selftest.argtypes = [vp]
@@ -310,6 +311,9 @@ class Context:
     def oneshot_import(self, n_ranks, rank, handles):
         buf = C.create_string_buffer(b"".join(bytes(h) for h in handles), 64 * n_ranks)
         self._chk(self.L.cfmm_oneshot_import(self.h, n_ranks, rank, buf))
+
+    def oneshot_enable(self, on):
+        self._chk(self.L.cfmm_oneshot_enable(self.h, 1 if on else 0))
 
     def oneshot_mailbox(self):
         return self.L.cfmm_oneshot_mailbox(self.h)

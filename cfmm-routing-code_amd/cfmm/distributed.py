@@ -44,6 +44,55 @@ def attach_oneshot(prob, dist):
     ctx.oneshot_import(dist.get_world_size(), dist.get_rank(), box)
 
 
+def attach_oneshot_checked(prob, dist, evaluations=4, solve_evals=18):
+    """allreduce="auto": set the one-shot exchange up and TRUST it only after it has reproduced RCCL on the real peers --
+    the same sharded dual evaluations (several in a row: both parity slots, epochs running ahead) and the same short
+    solve, compared on every rank; any rank's failure (IPC mapping refused, a timed-out exchange, a differing sum) sends
+    ALL ranks back to RCCL.  Returns ("oneshot" | "rccl", reason)."""
+    import numpy as np
+    from ._lib import CfmmError, METHODS
+    host = prob._host
+    ctx = prob._ensure_ctx()
+    why = ""
+    try:
+        attach_oneshot(prob, dist)               # (leaves the one-shot path enabled)
+        ctx.oneshot_enable(False)
+    except CfmmError as e:
+        why = f"rank {host.rank}: {e}"
+    failed = host.allreduce_sum(np.array([1.0 if why else 0.0]))[0]
+    if failed:
+        return "rccl", why or "a peer could not map the mailboxes"
+    u = prob.utility
+    base = np.where(u.c > 0, u.c, 1.0)
+    pts = [base * np.exp(0.01 * np.sin(1.0 + k + np.arange(prob.n))) for k in range(evaluations)]
+
+    def run():
+        out = [prob.eval_dual(nu) for nu in pts]
+        st = ctx.solve(pts[0], tol=1e-6, max_evals=solve_evals, method=METHODS["lbfgs"])
+        nu, psi = ctx.get_solution()
+        return out, (st["evals"], st["dual_value"], nu, psi)
+
+    ref, ref_solve = run()                       # RCCL
+    ok = True
+    try:
+        ctx.oneshot_enable(True)
+        got, got_solve = run()
+        for (f0, p0), (f1, p1) in zip(ref, got):
+            ok &= bool(np.isfinite(f1) and abs(f1 - f0) <= 1e-10 * max(1.0, abs(f0)) and
+                       np.all(np.isfinite(p1)) and np.abs(p1 - p0).max() <= 1e-10 * max(1.0, np.abs(p0).max()))
+        ok &= bool(got_solve[0] == ref_solve[0] and abs(got_solve[1] - ref_solve[1]) <= 1e-8 * max(1.0, abs(ref_solve[1])) and
+                   np.abs(got_solve[2] - ref_solve[2]).max() <= 1e-6 * np.abs(ref_solve[2]).max())
+        if not ok:
+            why = f"rank {host.rank}: the one-shot exchange did not reproduce RCCL"
+    except CfmmError as e:
+        ok, why = False, f"rank {host.rank}: {e}"
+    failed = host.allreduce_sum(np.array([0.0 if ok else 1.0]))[0]
+    if failed:
+        ctx.oneshot_enable(False)
+        return "rccl", why or "a peer's check failed"
+    return "oneshot", f"reproduced RCCL on {evaluations} evaluations and a {solve_evals}-evaluation solve"
+
+
 def sharded_problem(net, utility, dist=None, device=None, shard=True, context=None, allreduce=None):
     """Problem over this rank's shard, with the library's RCCL communicator initialised.
 
@@ -52,8 +101,10 @@ def sharded_problem(net, utility, dist=None, device=None, shard=True, context=No
     Host-side decisions of the solve (start prices, method, constant-sum ties) are then taken on global
     quantities through problem.HostComm, so that every rank issues the same device collectives.
     `context`: a ready device context to use instead of creating one on `device` (the CPU tests pass a stand-in
-    whose collective is gloo; the product never does).  `allreduce`: "rccl" (default) or "oneshot" (also selected by
-    CFMM_ALLREDUCE=oneshot): the per-evaluation all-reduce as ONE xGMI hop through peer-mapped mailboxes."""
+    whose collective is gloo; the product never does).  `allreduce`: "rccl" (default), "oneshot" (also selected by
+    CFMM_ALLREDUCE=oneshot): the per-evaluation all-reduce as ONE xGMI hop through peer-mapped mailboxes, or "auto": the
+    one-shot exchange if -- and only if -- it reproduces RCCL on these peers at start-up (attach_oneshot_checked); what
+    was chosen, and why, is left in prob.allreduce / prob.allreduce_note."""
     rank, local_rank, world = env_world()
     if dist is not None:
         rank, world = dist.get_rank(), dist.get_world_size()
@@ -68,8 +119,13 @@ def sharded_problem(net, utility, dist=None, device=None, shard=True, context=No
             from . import _lib
             prob.init_comm(world, rank, broadcast_unique_id(dist, _lib.comm_unique_id))
             how = (allreduce or os.environ.get("CFMM_ALLREDUCE", "rccl")).lower()
-            if how not in ("rccl", "oneshot"):
-                raise ValueError(f"allreduce={how!r}: expected 'rccl' or 'oneshot'")
+            if how not in ("rccl", "oneshot", "auto"):
+                raise ValueError(f"allreduce={how!r}: expected 'rccl', 'oneshot' or 'auto'")
+            prob.allreduce, prob.allreduce_note = how, ""
             if how == "oneshot":
                 attach_oneshot(prob, dist)
+            elif how == "auto" and world > 1:
+                prob.allreduce, prob.allreduce_note = attach_oneshot_checked(prob, dist)
+            elif how == "auto":
+                prob.allreduce = "rccl"
     return prob

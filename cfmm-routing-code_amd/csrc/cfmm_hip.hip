@@ -2346,6 +2346,18 @@ int cfmm_oneshot_import(cfmm_ctx *ctx, int n_ranks, int rank, const void *handle
     return cfmm_oneshot_attach(ctx, n_ranks, rank, ptrs);
 }
 
+int cfmm_oneshot_enable(cfmm_ctx *ctx, int on)
+{
+    if (!ctx) return CFMM_E_ARG;
+    if (on && !ctx->os_peers[ctx->rank]) return fail(ctx, CFMM_E_STATE, "oneshot_enable: no mailboxes attached (cfmm_oneshot_import / _attach first)");
+    if (!on && !ctx->comm && ctx->os_ready) return fail(ctx, CFMM_E_STATE, "oneshot_enable(0): no RCCL communicator to fall back on");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((on != 0) != ctx->os_ready) drop_graph(ctx);
+    ctx->os_ready = on != 0;
+    return CFMM_OK;
+}
+
 int cfmm_selftest(cfmm_ctx *ctx)
 {
     if (!ctx) return CFMM_E_ARG;

@@ -197,6 +197,10 @@ int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128);
 int cfmm_oneshot_export(cfmm_ctx *ctx, void *handle64);
 int cfmm_oneshot_import(cfmm_ctx *ctx, int n_ranks, int rank, const void *handles);
 int cfmm_oneshot_attach(cfmm_ctx *ctx, int n_ranks, int rank, void *const *mailboxes);
+/* with mailboxes attached AND an RCCL communicator: route the collectives through the one-shot exchange (1) or back through
+ * RCCL (0).  Must be called with the same value on every rank (the one-shot epochs advance only while it is on).  Used by
+ * cfmm.distributed's start-up check, which compares the two paths on the real peers before trusting the one-shot one. */
+int cfmm_oneshot_enable(cfmm_ctx *ctx, int on);
 void *cfmm_oneshot_mailbox(cfmm_ctx *ctx);
 
 /* measurement hooks (bench.py): time `reps` back-to-back launches of the fused evaluation kernel

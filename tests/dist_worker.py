@@ -43,6 +43,33 @@ def run(net, util, tol, **kw):
                 nu0=[a.tolist() for a in ctx.start_prices[:1]], theta=sorted([list(k), th] for k, (_, th) in p._theta.items()))
 
 
+class OneShotStub(ShardedOracleContext):
+    """the one-shot exchange as cfmm.distributed.attach_oneshot_checked sees it: export / import / enable, and a collective
+    that -- while enabled -- reproduces the reference one ("good"), returns a slightly different sum on rank 1 ("corrupt"),
+    or cannot be set up on rank 1 at all ("refuse")"""
+
+    def __init__(self, n_tokens, dist, mode):
+        super().__init__(n_tokens, dist)
+        self.mode, self.enabled, self.imported = mode, False, False
+
+    def oneshot_export(self):
+        return bytes(64)
+
+    def oneshot_import(self, n_ranks, rank, handles):
+        if self.mode == "refuse" and rank == 1:
+            raise cfmm.CfmmError("hipIpcOpenMemHandle(rank 0) -> invalid argument (stub)")
+        assert len(handles) == n_ranks and all(len(h) == 64 for h in handles)
+        self.imported, self.enabled = True, True
+
+    def oneshot_enable(self, on):
+        self.enabled = bool(on)
+
+    def _allreduce(self, buf):
+        super()._allreduce(buf)
+        if self.enabled and self.mode == "corrupt" and self.dist.get_rank() == 1:
+            buf[0] *= 1.0 + 1e-6
+
+
 def main():
     out = sys.argv[1]
     dist.init_process_group("gloo")
@@ -62,6 +89,14 @@ def main():
         if name in todo:
             pnet, _ = cfmm.pack(inst["n_tokens"], inst["local_indices"], inst["reserves"], inst["fees"], inst["kinds"], inst["weights"])
             res[name] = run(pnet, utility_of(inst), 1e-9)
+    # allreduce="auto": the one-shot exchange is used only if it reproduces the reference collective on EVERY rank
+    if "auto_allreduce" in todo:
+        res["auto_allreduce"] = {}
+        for mode in ("good", "corrupt", "refuse"):
+            ctx = OneShotStub(net["n_tokens"], dist, mode)
+            p = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, context=ctx)
+            how, note = cfmm.distributed.attach_oneshot_checked(p, dist, evaluations=2, solve_evals=4)
+            res["auto_allreduce"][mode] = dict(how=how, note=note, enabled=ctx.enabled)
     # ranks disagreeing on the start prices must be caught, not silently summed
     bad = net["c"] * (1.0 + 1e-3 * rank)
     try:

@@ -28,14 +28,14 @@ def _free_port():
 SCENARIOS = {2: ["arbitrage", "liquidate", "liquidation_py", "two_asset_py"], 3: ["arbitrage", "swap", "arbitrage_py"]}
 
 
-def _run_world(world, tmp_path):
+def _run_world(world, tmp_path, scenarios=None):
     port = _free_port()
     out = str(tmp_path / "res")
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1", PYTHONDONTWRITEBYTECODE="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), out, ",".join(SCENARIOS[world])], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), out, ",".join(scenarios or SCENARIOS[world])], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         try:
@@ -98,6 +98,20 @@ def test_pool_sharded_solve_over_gloo_matches_unsharded(oracle_lib, tmp_path, wo
         for r in res[1:]:
             assert r[key]["solves"] == res[0][key]["solves"] and r[key]["allreduces"] == res[0][key]["allreduces"]
             assert r[key]["nu"] == res[0][key]["nu"] and r[key]["theta"] == res[0][key]["theta"]
+
+
+def test_auto_allreduce_trusts_the_one_shot_exchange_only_after_it_reproduced_the_reference(oracle_lib, tmp_path):
+    """cfmm.distributed.attach_oneshot_checked (allreduce="auto", what bench.py --gpus N uses): all ranks switch to the
+    one-shot exchange iff it reproduced the reference collective on every rank; a rank whose sums differ, or that could not
+    map its peers' mailboxes, sends EVERY rank back to the reference path"""
+    res = _run_world(2, tmp_path, ["auto_allreduce"])
+    for r in res:
+        a = r["auto_allreduce"]
+        assert a["good"]["how"] == "oneshot" and a["good"]["enabled"] is True
+        assert a["corrupt"]["how"] == "rccl" and a["corrupt"]["enabled"] is False
+        assert a["refuse"]["how"] == "rccl" and a["refuse"]["enabled"] is False
+    assert any("did not reproduce" in r["auto_allreduce"]["corrupt"]["note"] for r in res)
+    assert any("hipIpcOpenMemHandle" in r["auto_allreduce"]["refuse"]["note"] for r in res)
 
 
 def test_virtual_shards_sum_to_the_unsharded_evaluation(oracle_lib):

@@ -791,7 +791,9 @@ def test_one_shot_all_reduce_against_rccl_on_real_peers(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(here, "dist_gpu_worker.py"), out], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    res = json.load(open(out))["res"]
+    doc = json.load(open(out))
+    res = doc["res"]
+    assert doc["auto"]["how"] == "oneshot" and doc["auto"]["status"] == "optimal", doc["auto"]      # the start-up check passed on real peers
     for k, v in res.items():
         assert v["status"] == "optimal" and v["all_ranks_same_bits"], k
     a, b = res["rccl"], res["oneshot"]

@@ -14,7 +14,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
 
-for name in ("bench.json", "bench_C4.json", "bench_dist1.json", "upload.json", "kernel_durations.json"):
+for name in ("bench.json", "bench_C4.json", "bench_dist1.json", "upload.json", "kernel_durations.json", "small.json", "batch_C3.jsonl", "batch_C4shard.jsonl"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{tag}_{name}"))
 for d in sorted(glob.glob(os.path.join(SRC, "trace_*"))):
