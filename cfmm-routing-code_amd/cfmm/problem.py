@@ -483,6 +483,10 @@ class Problem:
         u = self.utility
         # device-side utility / tie state is re-sent only when it changed (each call is a synchronisation)
         if self._dev_utility is not u:
+            if self._host:
+                # the utility is replicated: every rank must hold the same one (checked when it is sent to the device, once
+                # per utility object -- the host-side collectives of a solve are off its steady-state path)
+                self._host.assert_identical(np.concatenate([u.c, u.h, u.ctype.astype(np.float64)]), "the utilities")
             ctx.set_utility(u.c, u.h, u.ctype)
             self._dev_utility = u
         if self._dev_ties:
@@ -495,10 +499,13 @@ class Problem:
         rank = host.rank if host else 0
         # global pool counts: the branches below change the sequence of device collectives, so a pool-sharded solve
         # takes them on what ALL ranks hold, never on its own shard
-        cnt = np.array([len(self.net["curve2"]["Ra"]) if "curve2" in self.net else 0,
-                        len(self.net["sum2"]["Ra"]) if "sum2" in self.net else 0], dtype=np.float64)
-        if host:
-            cnt = host.allreduce_sum(cnt)
+        cnt = getattr(self, "_global_counts", None)
+        if cnt is None:                               # (the pools of a Problem never change: one collective per Problem, not per solve)
+            cnt = np.array([len(self.net["curve2"]["Ra"]) if "curve2" in self.net else 0,
+                            len(self.net["sum2"]["Ra"]) if "sum2" in self.net else 0], dtype=np.float64)
+            if host:
+                cnt = host.allreduce_sum(cnt)
+            self._global_counts = cnt
         n_stable, n_sum = int(cnt[0]), int(cnt[1])
         if nu0 is None:
             if warm_start and self.nu is not None:
@@ -508,7 +515,9 @@ class Problem:
                 nu0 = host.broadcast(start_prices(self.net, u) if rank == 0 else np.zeros(self.n), src=0)
             else:
                 nu0 = start_prices(self.net, u)
-        if host:
+        # start prices: derived from the (verified) utility, broadcast from rank 0, or the previous solution of an identical
+        # solve -- identical on every rank by construction; prices the CALLER supplies are verified every time
+        if host and nu0_given is not None:
             host.assert_identical(nu0, "the start prices")
         self._theta = {}
         self._trade_cache = None

@@ -163,6 +163,7 @@ struct cfmm_ctx {
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
     int64_t g_total = 0, g_stable = 0;     // pool counts over ALL ranks (refresh_global_counts)
+    bool g_counts_valid = false;
 
     // one-shot xGMI all-reduce (oneshot.hpp): this rank's mailbox and the peers' (IPC-mapped, or same-process pointers in tests)
     unsigned long long *os_mail = nullptr;
@@ -170,7 +171,6 @@ struct cfmm_ctx {
     unsigned long long *os_peers[ONESHOT_MAX_RANKS] = {};
     std::vector<void *> os_opened;     // hipIpcOpenMemHandle mappings to close
     bool os_ready = false;             // attached: the collectives below go through it
-    unsigned long long os_epoch = 0;
 
     // second-order method (allocated on first use)
     double *sm_out = nullptr, *sm_vec = nullptr, *H = nullptr, *Dinv = nullptr;
@@ -220,12 +220,20 @@ inline bool sharded(const cfmm_ctx *ctx) { return ctx->comm != nullptr || ctx->o
 
 // the collective of the pool-sharded iteration, enqueued on ctx->stream: the one-shot exchange when it is attached and the
 // message fits its mailbox (sum of doubles / of 64-bit integers, max of doubles), RCCL otherwise
-int all_reduce(cfmm_ctx *ctx, void *buf, size_t count, int dtype, int op)
+// `fold_slices` > 1: buf is the first of that many accumulator slices (acc_stride(n) apart) to be summed first -- by the
+// one-shot kernel itself, or by a fold launch in front of RCCL
+int all_reduce(cfmm_ctx *ctx, void *buf, size_t count, int dtype, int op, const DevState *stop = nullptr, int fold_slices = 1)
 {
+    if (fold_slices > 1 && !(ctx->os_ready && count <= ctx->os_cap))
+        hipLaunchKernelGGL(fold_kernel, dim3(((int)count + 255) / 256), dim3(256), 0, ctx->stream, (double *)buf, ctx->n, fold_slices,
+                           count > (size_t)acc_arb(ctx->n) + 1 ? 1 : 0, stop);
     if (ctx->os_ready && count <= ctx->os_cap) {
         OneShotArgs a = {};
         for (int r = 0; r < ctx->n_ranks; ++r) a.mail[r] = ctx->os_peers[r];
-        a.buf = (unsigned long long *)buf; a.epoch = ++ctx->os_epoch;
+        a.buf = (unsigned long long *)buf;
+        a.epoch_word = ctx->os_mail + oneshot_bytes(ctx->os_cap) / 8;
+        a.stop = stop ? &stop->status : nullptr;
+        a.nslices = fold_slices; a.stride = acc_stride(ctx->n);
         a.n_ranks = ctx->n_ranks; a.rank = ctx->rank; a.count = (int)count; a.cap = ctx->os_cap;
         a.op = dtype == NCCL_INT64 ? ONESHOT_SUM_I64 : (op == NCCL_MAX ? ONESHOT_MAX_F64 : ONESHOT_SUM_F64);
         hipLaunchKernelGGL(oneshot_allreduce_kernel, dim3(1), dim3(ONESHOT_THREADS), 0, ctx->stream, a);
@@ -573,7 +581,7 @@ void local_extrema(cfmm_ctx *ctx)
 void pools_changed(cfmm_ctx *ctx)
 {
     local_extrema(ctx);
-    ctx->g_valid = false;
+    ctx->g_valid = false; ctx->g_counts_valid = false;
     ctx->hsol_valid = false; ctx->mu_last = 0.0; ctx->warm_mu = 0.0; ctx->slo_active = false;
 }
 
@@ -781,6 +789,13 @@ IterArgs make_iter_args(cfmm_ctx *ctx, const cfmm_opts &o)
     return a;
 }
 
+// pool-sharded through the one-shot exchange (not the reproducible mode, whose fold is a different kernel): the iteration's
+// collectives can be skipped on the device, so the host may run ahead of it as on a single GPU
+bool oneshot_runahead(cfmm_ctx *ctx)
+{
+    return ctx->os_ready && !ctx->det && (size_t)acc_stride(ctx->n) <= ctx->os_cap && ctx->pools->b2[CFMM_POOL_CURVE2].m == 0;
+}
+
 // outer iteration t >= 1 as ONE launch (+ the stableswap bucket's own evaluation launch, + fold / all-reduce when
 // pool-sharded): update from the accumulators of launch t - 1, evaluation at the new prices into set t % 3
 int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
@@ -815,9 +830,12 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
     }
     if (ctx->det) return det_finish(ctx, acc_p, ctx->nu, false);     // (the prices workgroup 0 has just stored)
     if (sharded(ctx)) {
+        // a launch enqueued behind the end of the solve has evaluated nothing: with the one-shot exchange its fold and
+        // its exchange return at once too (oneshot.hpp: every rank skips the same ones), which is what allows the
+        // host-side run-ahead below; RCCL's collective cannot be made conditional and keeps the chunked scheme
+        const DevState *stop = oneshot_runahead(ctx) ? ctx->st3 + a.phase : nullptr;
         const int len = acc_arb(n) + 1;
-        hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, acc_p, n, ctx->nslices, 0, (const DevState *)nullptr);
-        return all_reduce(ctx, acc_p, (size_t)len, NCCL_FLOAT64, NCCL_SUM);
+        return all_reduce(ctx, acc_p, (size_t)len, NCCL_FLOAT64, NCCL_SUM, stop, ctx->nslices);
     }
     return CFMM_OK;
 }
@@ -967,6 +985,9 @@ bool near_linear_pools(cfmm_ctx *ctx) { return ctx->g_stable >= CFMM_AUTO_NEWTON
 // rank deciding on its own shard's size would take another method, or skip the prelude, and deadlock its peers)
 int refresh_global_counts(cfmm_ctx *ctx)
 {
+    // (pool-sharded: the global figures cost a collective and a synchronisation; they change only with the pools, the
+    //  communicator, the exchange or the reproducible mode -- calls every rank makes alike -- and are kept until then)
+    if (sharded(ctx) && ctx->g_counts_valid) return CFMM_OK;
     ctx->g_total = cfmm_pool_count(ctx);
     ctx->g_stable = ctx->pools->b2[CFMM_POOL_CURVE2].m;
     local_extrema(ctx);
@@ -987,6 +1008,7 @@ int refresh_global_counts(cfmm_ctx *ctx)
     HIP_TRY(ctx, hipMemcpyAsync(cnt, dv, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->g_total = (int64_t)cnt[0]; ctx->g_stable = (int64_t)cnt[1];
+    ctx->g_counts_valid = true;
     return CFMM_OK;
 }
 
@@ -1947,8 +1969,8 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     int status = 0, t = 1;
     if (small) {
         // (nothing to enqueue: the read-back below waits for the one launch)
-    } else if (fused && !shard && !use_graph_opt) {
-        // Single GPU, one launch per iteration: launches are enqueued eagerly, a few ahead of the device, whose workgroup 0
+    } else if (fused && (!shard || oneshot_runahead(ctx)) && !use_graph_opt) {
+        // Single GPU (or pool-sharded through the one-shot exchange), one launch per iteration: launches are enqueued eagerly, a few ahead of the device, whose workgroup 0
         // reports {evals, status} into a pinned host word as it goes (zero-copy: the host polls memory, no API call, no
         // copy engine).  No graph-replay gaps (~19 us per replay), and only `run_ahead` idle launches behind the end.
         const auto spin0 = std::chrono::steady_clock::now();
@@ -2243,7 +2265,7 @@ int cfmm_comm_init(cfmm_ctx *ctx, int n_ranks, int rank, const void *uid128)
     int rc = g_rccl.CommInitRank(&ctx->comm, n_ranks, id, rank);
     if (rc != 0) return fail(ctx, CFMM_E_RCCL, "ncclCommInitRank -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
     ctx->n_ranks = n_ranks; ctx->rank = rank;
-    ctx->g_valid = false;
+    ctx->g_valid = false; ctx->g_counts_valid = false;
     // one all-reduce outside any timed or captured region: RCCL sets up its channels / buffers on first use.
     // (the accumulators are all zero here, and stay zero)
     rc = g_rccl.AllReduce(ctx->acc, ctx->acc, (size_t)acc_stride(ctx->n), NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
@@ -2257,7 +2279,7 @@ int cfmm_set_deterministic(cfmm_ctx *ctx, int on)
     if (!ctx) return CFMM_E_ARG;
     if (on && eval_lds_bytes(ctx->n, true, true) > 160 * 1024)
         return fail(ctx, CFMM_E_LIMIT, "set_deterministic: %d tokens exceed the LDS tile of the reproducible mode (7 n doubles)", ctx->n);
-    if ((on != 0) != ctx->det) ctx->g_valid = false;
+    if ((on != 0) != ctx->det) { ctx->g_valid = false; ctx->g_counts_valid = false; }
     ctx->det = on != 0;
     return CFMM_OK;
 }
@@ -2288,8 +2310,8 @@ static int oneshot_alloc(cfmm_ctx *ctx)
 {
     if (ctx->os_mail) return CFMM_OK;
     ctx->os_cap = (size_t)std::max(acc_stride(ctx->n), 6 * ctx->n) + 8;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->os_mail, oneshot_bytes(ctx->os_cap)));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->os_mail, 0, oneshot_bytes(ctx->os_cap), ctx->stream));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->os_mail, oneshot_alloc_bytes(ctx->os_cap)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->os_mail, 0, oneshot_alloc_bytes(ctx->os_cap), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CFMM_OK;
 }
@@ -2324,7 +2346,9 @@ int cfmm_oneshot_attach(cfmm_ctx *ctx, int n_ranks, int rank, void *const *mailb
         if (!ctx->os_peers[r]) return fail(ctx, CFMM_E_ARG, "oneshot_attach: mailbox of rank %d is NULL", r);
     }
     ctx->n_ranks = n_ranks; ctx->rank = rank;
-    ctx->os_epoch = 0; ctx->os_ready = true; ctx->g_valid = false;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->os_mail, 0, oneshot_alloc_bytes(ctx->os_cap), ctx->stream));      // flags and the epoch counter start from zero
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->os_ready = true; ctx->g_valid = false; ctx->g_counts_valid = false;
     return CFMM_OK;
 }
 
@@ -2354,7 +2378,7 @@ int cfmm_oneshot_enable(cfmm_ctx *ctx, int on)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if ((on != 0) != ctx->os_ready) drop_graph(ctx);
-    ctx->os_ready = on != 0;
+    ctx->os_ready = on != 0; ctx->g_counts_valid = false;
     return CFMM_OK;
 }
 
@@ -2417,18 +2441,24 @@ int cfmm_time_collective(cfmm_ctx *ctx, int reps, double *fold_sec, double *allr
     const int n = ctx->n, len = acc_arb(n) + 1;
     float ms = 0.f;
     HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
-    for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, n, ctx->nslices, 0, (const DevState *)nullptr);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
-    if (fold_sec) *fold_sec = ms * 1e-3 / reps;
+    // the fold is a launch of its own in front of RCCL; the one-shot exchange folds the slices itself
+    const bool folded_inside = ctx->os_ready && (size_t)len <= ctx->os_cap && !ctx->det;
+    if (fold_sec) *fold_sec = 0.0;
+    if (!folded_inside) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+        for (int i = 0; i < reps; ++i)
+            hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, n, ctx->nslices, 0, (const DevState *)nullptr);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+        if (fold_sec) *fold_sec = ms * 1e-3 / reps;
+    }
     if (allreduce_sec) *allreduce_sec = 0.0;
     if (sharded(ctx) && allreduce_sec) {           // (collective: every rank of the communicator must make this call)
-        for (int i = 0; i < 3; ++i) { int rc = all_reduce(ctx, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc; }
+        const int fs = folded_inside ? ctx->nslices : 1;
+        for (int i = 0; i < 3; ++i) { int rc = all_reduce(ctx, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, nullptr, fs); if (rc) return rc; }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
-        for (int i = 0; i < reps; ++i) { int rc = all_reduce(ctx, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc; }
+        for (int i = 0; i < reps; ++i) { int rc = all_reduce(ctx, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, nullptr, fs); if (rc) return rc; }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));

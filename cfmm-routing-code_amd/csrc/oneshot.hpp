@@ -31,14 +31,23 @@ enum { ONESHOT_SUM_F64 = 0, ONESHOT_SUM_I64 = 1, ONESHOT_MAX_F64 = 2 };
 
 __host__ __device__ inline size_t oneshot_flag_words() { return 2 * ONESHOT_MAX_RANKS; }
 __host__ __device__ inline size_t oneshot_bytes(size_t cap) { return (oneshot_flag_words() + 2 * (size_t)ONESHOT_MAX_RANKS * cap) * 8; }
+// (+ one private word behind the mailbox: the rank's epoch counter)
+__host__ __device__ inline size_t oneshot_alloc_bytes(size_t cap) { return oneshot_bytes(cap) + 64; }
 
 struct OneShotArgs {
     unsigned long long *mail[ONESHOT_MAX_RANKS];    // every rank's mailbox (mail[rank] is the local one)
     unsigned long long *buf;                        // the vector, reduced in place
-    unsigned long long epoch;                       // 1, 2, 3, ... : the same on every rank for the same call
+    unsigned long long *epoch_word;                 // this rank's count of exchanges done so far (device memory, private)
+    const int *stop;                                // optional: a solve's status word; non-zero = the solve has ended, NO exchange
     int n_ranks, rank, count, op;
     size_t cap;
+    int nslices;                                    // > 1 (sums of doubles only): buf holds `nslices` accumulator slices `stride`
+    long long stride;                               //   elements apart; they are folded into slice 0 on the way out (no fold launch)
 };
+// The epoch is counted on the DEVICE, by the exchanges that actually happen: with `stop` set, launches enqueued behind the
+// end of a solve return at once (every rank holds the same status at the same launch index, so they all skip the same
+// exchanges), which lets every rank keep its own number of launches in flight beyond the end -- the host-side run-ahead
+// of the single-GPU path -- without the ranks' epochs drifting apart.
 
 __device__ __forceinline__ void sys_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ unsigned long long sys_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -46,17 +55,24 @@ __device__ __forceinline__ unsigned long long sys_load(const unsigned long long 
 __global__ void __launch_bounds__(ONESHOT_THREADS)
 oneshot_allreduce_kernel(OneShotArgs a)
 {
+    if (a.stop && *a.stop != 0) return;
     const int tid = threadIdx.x, R = a.n_ranks;
-    const int par = (int)(a.epoch & 1);
+    const unsigned long long epoch = *a.epoch_word + 1;     // (read by every thread before thread 0 writes it back, behind two barriers)
+    const int par = (int)(epoch & 1);
     const size_t slot_off = oneshot_flag_words() + ((size_t)par * ONESHOT_MAX_RANKS + a.rank) * a.cap;
     // 1. my vector into everybody's mailbox (my own included)
     for (int j = tid; j < a.count; j += blockDim.x) {
-        const unsigned long long v = a.buf[j];
+        unsigned long long v = a.buf[j];
+        if (a.nslices > 1) {                                // this rank's slices, folded in a fixed order
+            double x = __longlong_as_double((long long)v);
+            for (int sl = 1; sl < a.nslices; ++sl) { x += __longlong_as_double((long long)a.buf[(size_t)sl * a.stride + j]); a.buf[(size_t)sl * a.stride + j] = 0ull; }
+            v = (unsigned long long)__double_as_longlong(x);
+        }
         for (int r = 0; r < R; ++r) sys_store(a.mail[r] + slot_off + j, v);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: the payload is out before any flag
     __syncthreads();
-    if (tid < R) sys_store(a.mail[tid] + par * ONESHOT_MAX_RANKS + a.rank, a.epoch);
+    if (tid < R) sys_store(a.mail[tid] + par * ONESHOT_MAX_RANKS + a.rank, epoch);
     // 2. wait for the R vectors of this epoch in MY mailbox
     __shared__ int ok;
     if (tid == 0) ok = 1;
@@ -64,7 +80,7 @@ oneshot_allreduce_kernel(OneShotArgs a)
     if (tid < R) {
         const unsigned long long *f = a.mail[a.rank] + par * ONESHOT_MAX_RANKS + tid;
         long spins = 0;
-        while (sys_load(f) != a.epoch) {
+        while (sys_load(f) != epoch) {
             __builtin_amdgcn_s_sleep(2);
             if (++spins > (1L << 26)) { ok = 0; break; }   // (~ seconds: a peer has died)
         }
@@ -86,6 +102,7 @@ oneshot_allreduce_kernel(OneShotArgs a)
         if (!ok) acc = 0x7ff8000000000000ull;               // NaN: the exchange timed out
         a.buf[j] = acc;
     }
+    if (tid == 0) *a.epoch_word = epoch;
 }
 
 }  // namespace cfmm

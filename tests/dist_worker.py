@@ -105,6 +105,13 @@ def main():
         res["mismatch_caught"] = (world == 1)
     except cfmm.CfmmError as e:
         res["mismatch_caught"] = "differ between ranks" in str(e)
+    # ... and so must ranks holding different utilities
+    try:
+        ctx = ShardedOracleContext(net["n_tokens"], dist)
+        cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"] * (1.0 + 1e-6 * rank)), dist=dist, context=ctx).solve(max_evals=2)
+        res["utility_mismatch_caught"] = (world == 1)
+    except cfmm.CfmmError as e:
+        res["utility_mismatch_caught"] = "utilities differ between ranks" in str(e)
     with open(f"{out}-{rank}.json", "w") as f:
         json.dump(res, f)
     dist.barrier()

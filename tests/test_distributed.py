@@ -65,7 +65,7 @@ def test_pool_sharded_solve_over_gloo_matches_unsharded(oracle_lib, tmp_path, wo
     res = _run_world(world, tmp_path)
     net = synthetic.config("C3", scale=0.01, seed=3)
     for r in res:
-        assert r["uid_ok"] and r["world"] == world and r["mismatch_caught"]
+        assert r["uid_ok"] and r["world"] == world and r["mismatch_caught"] and r["utility_mismatch_caught"]
     # 1. linear-utility arbitrage and the two basket utilities (start prices are a broadcast guess there)
     for key, util in (("arbitrage", cfmm.Arbitrage(net["c"])), ("liquidate", dist_worker.basket(net, "liquidate")),
                       ("swap", dist_worker.basket(net, "swap"))):
