@@ -1906,6 +1906,10 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     const bool small = tiny_applies(ctx, ea_small, o);
     const bool fused = !small && fused_applies(ctx, o);
     if (fused) o.iters_per_graph = (o.iters_per_graph + 2) / 3 * 3;       // the rotation phase t % 3 is baked into captured launches
+    // pool-sharded through RCCL: the chunked scheme polls one chunk behind, so a solve leaves up to two chunks of iterations
+    // -- each with a live collective and RCCL's ~35 us of host time per call -- behind its end: short chunks
+    // (a one-rank communicator's collective is free: there the polls cost more than the idle iterations, 0.79 vs 0.75 ms)
+    if (sharded(ctx) && ctx->n_ranks > 1 && !oneshot_runahead(ctx) && !ctx->multi_graph) o.iters_per_graph = 3;
     // Single GPU: `iters_per_graph` iterations are replayed from one captured hipGraph.  Pool-sharded
     // (RCCL all-reduce inside every iteration): the same iterations are enqueued eagerly, the way RCCL
     // is conventionally driven (CFMM_MULTI_GRAPH=1 opts into capturing them too).
