@@ -502,7 +502,6 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const 
     }
     int slot = 0;
     bool used[STAGE_SLOTS] = {};
-    // small columns share a staging chunk: pieces = (column, offset, length) packed into <= STAGE_BYTES
     for (size_t q = 0; q < cols.size(); ++q) {
         for (size_t off = 0; off < cols[q].bytes; off += STAGE_BYTES) {
             const size_t len = std::min(STAGE_BYTES, cols[q].bytes - off);
@@ -1902,9 +1901,9 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     cfmm_opts o = o_in;
     // One launch per iteration (iterate.hpp) whenever the update fits the evaluation launch; otherwise the
     // two-launch iteration (evaluation kernel, single-workgroup update kernel).
-    const EvalArgs ea_small = make_eval_args(ctx, false);
-    const bool small = tiny_applies(ctx, ea_small, o);
-    const bool fused = !small && fused_applies(ctx, o);
+    const EvalArgs ea_tiny = make_eval_args(ctx, false);
+    const bool tiny = tiny_applies(ctx, ea_tiny, o);
+    const bool fused = !tiny && fused_applies(ctx, o);
     if (fused) o.iters_per_graph = (o.iters_per_graph + 2) / 3 * 3;       // the rotation phase t % 3 is baked into captured launches
     // pool-sharded through RCCL: the chunked scheme polls one chunk behind, so a solve leaves up to two chunks of iterations
     // -- each with a live collective and RCCL's ~35 us of host time per call -- behind its end: short chunks
@@ -1916,7 +1915,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     static const bool graph_forced = getenv("CFMM_FUSED_GRAPH") && atoi(getenv("CFMM_FUSED_GRAPH")) != 0;     // (A/B: replay the fused launches from a graph)
     const bool shard = sharded(ctx);
     const bool use_graph_opt = fused && !shard && graph_forced;
-    const bool use_graph = !small && (!shard || (ctx->multi_graph && !ctx->os_ready)) && !ctx->no_graph && (!fused || shard || graph_forced);
+    const bool use_graph = !tiny && (!shard || (ctx->multi_graph && !ctx->os_ready)) && !ctx->no_graph && (!fused || shard || graph_forced);
     if (use_graph && (!ctx->g_valid || !same_opts(o, ctx->g_opts))) { int rc = build_graph(ctx, o); if (rc) return rc; }
     UpdArgs ua = make_upd_args(ctx, o);
     const IterArgs ia = make_iter_args(ctx, o);
@@ -1947,13 +1946,13 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
             hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc3, n, ctx->nslices, 1, (const DevState *)nullptr);
             int rc = all_reduce(ctx, ctx->acc3, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc;
         }
-    } else if (small) {
+    } else if (tiny) {
         // one workgroup, one launch: every evaluation and update of the solve, nothing of it in global memory (tiny.hpp);
         // the device ends it: converged, stalled, or out of budget
         hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
                            ctx->acc, (long long)((size_t)ctx->nslices * acc_stride(n)), (DevState *)nullptr, 0);
-        const int threads = 64 * std::min(TINY_THREADS / 64, std::max(1, ea_small.ntiles));
-        hipLaunchKernelGGL(solve_tiny_kernel, dim3(1), dim3(threads), (size_t)tiny_lds_doubles(n) * sizeof(double), ctx->stream, ea_small, ua, o.max_evals + 1);
+        const int threads = 64 * std::min(TINY_THREADS / 64, std::max(1, ea_tiny.ntiles));
+        hipLaunchKernelGGL(solve_tiny_kernel, dim3(1), dim3(threads), (size_t)tiny_lds_doubles(n) * sizeof(double), ctx->stream, ea_tiny, ua, o.max_evals + 1);
     } else {
         hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
                            ctx->acc, (long long)((size_t)ctx->nslices * acc_stride(n)), (DevState *)nullptr, 0);
@@ -1971,7 +1970,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     DevState *hring = fused ? ctx->hst3 : ctx->hst;
     const DevState *dst = fused ? ctx->st3 : ctx->st;
     int status = 0, t = 1;
-    if (small) {
+    if (tiny) {
         // (nothing to enqueue: the read-back below waits for the one launch)
     } else if (fused && (!shard || oneshot_runahead(ctx)) && !use_graph_opt) {
         // Single GPU (or pool-sharded through the one-shot exchange), one launch per iteration: launches are enqueued eagerly, a few ahead of the device, whose workgroup 0
