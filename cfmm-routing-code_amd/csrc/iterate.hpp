@@ -214,8 +214,9 @@ __device__ __forceinline__ double uni(double v)
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
-// extra LDS of iter_kernel behind eval_kernel's carve: the bounds, stashed between the two halves of the update
-__host__ __device__ inline int iter_extra_lds_doubles(int n) { return 2 * iter_xvs(n); }
+// extra LDS of iter_kernel behind eval_kernel's carve: the bounds (every workgroup) and the trial point's prices and net
+// trade (workgroup 0, which stores them when the point is accepted), stashed between the two halves of the update
+__host__ __device__ inline int iter_extra_lds_doubles(int n) { return 4 * iter_xvs(n); }
 
 // PLAIN: the utility has h == 0, every token CFMM_GE and no upper bounds (linear-utility arbitrage, arbitrage.py:57,77):
 // three of the update's vectors are never read and their registers do not exist (the other instantiation spills a few)
@@ -242,6 +243,7 @@ iter_kernel(IterArgs a)
     double *sts_s = nu_s;                                // [n] trial point, likewise (the prices are written at the very end)
     double *glo_s = strips + 2 * 64 * (EVAL_THREADS / 64);   // [xvs] lower bounds | [xvs] upper bounds
     double *ghi_s = glo_s + a.xvs;
+    double *psi_k = ghi_s + a.xvs, *nu_k = psi_k + a.xvs;    // workgroup 0 only
 
     PHASE_STAMP(a.ev.ts, 16);
     const int p = a.phase, pr = (p + 2) % 3, pz = (p + 1) % 3;
@@ -371,6 +373,7 @@ iter_kernel(IterArgs a)
                 gst_s[r0 + e] = Gs_t[e];
                 sts_s[r0 + e] = s_t[e]; glo_s[r0 + e] = glo[e];
                 if (!PLAIN) ghi_s[r0 + e] = ghi[e];
+                if (wr) { psi_k[r0 + e] = psi[e]; nu_k[r0 + e] = nuj[e]; }
             }
         }
         PHASE_STAMP(a.ev.ts, 18);
@@ -483,17 +486,10 @@ iter_kernel(IterArgs a)
             for (int e = 0; e < E; ++e) if (tin[e]) { s[e] = sts_s[r0 + e]; Gs[e] = gst_s[r0 + e]; }
         } else { ldE<E>(Xr, ld0, s); ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 3 * xvs, ld0, d); }
         if (wr && accept && r0 < n) {                    // the accepted prices and their net trade, for the read-back
-            double psi[E], nuj[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) psi[e] = 0.0;
-            for (int sl = 0; sl < a.nread; ++sl) {
-                double t1[E];
-                ldE<E>(Ar + (size_t)sl * stride, ld0, t1);
-#pragma unroll
-                for (int e = 0; e < E; ++e) psi[e] += t1[e];
-            }
-            ldE<E>(Xr + 4 * xvs, ld0, nuj);
-            stE<E>(a.psi_acc, r0, n, psi); stE<E>(a.nu_acc, r0, n, nuj);
+            double pk[E], nk[E];                         // (from the stash: a reload through L2 sat on workgroup 0's chain, and
+#pragma unroll                                           //  the kernel ends with its slowest workgroup)
+            for (int e = 0; e < E; ++e) { pk[e] = tin[e] ? psi_k[r0 + e] : 0.0; nk[e] = tin[e] ? nu_k[r0 + e] : 0.0; }
+            stE<E>(a.psi_acc, r0, n, pk); stE<E>(a.nu_acc, r0, n, nk);
         }
     }
 
