@@ -302,6 +302,33 @@ def main():
                                       "(eval_batch_kernel + one update workgroup per solve); wall time includes the host-side start "
                                       "prices and certificate checks of every solve"}
             prob.set_utility(cfmm.Arbitrage(net["c"]))
+        if world == 1 and not strong:
+            # the same solve with the host-buffer hand-over inside the clock (never `value`): a fresh context, the pool columns
+            # uploaded from pageable NumPy buffers, utility, one cold solve, prices and psi read back -- through the raw
+            # C-ABI calls INTEGRATION.md's stub makes
+            from cfmm.problem import KIND2
+            u = cfmm.Arbitrage(net["c"])
+            rows = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                c2 = _lib.Context(net["n_tokens"], 0)
+                for key, kind in KIND2.items():
+                    if key in net:
+                        b = net[key]
+                        c2.upload_pools2(kind, b["Ra"], b["Rb"], b["fee"], b["ia"], b["ib"], b.get("wa") if key == "w2" else b.get("alpha"))
+                for k, b in net.get("gn", {}).items():
+                    c2.upload_poolsN(b["idx"], b["R"], b["w"], b["fee"])
+                t1 = time.perf_counter()
+                c2.set_utility(u.c, u.h, u.ctype); st2 = c2.solve(net["c"], tol=args.tol); c2.get_solution()
+                t2 = time.perf_counter()
+                rows.append((t2 - t0, t1 - t0, st2["evals"]))
+                c2.close()
+            rows.sort()
+            tot, up, ev2 = rows[len(rows) // 2]
+            out["pcie_inclusive"] = {"value": ev2 * prob.m / tot, "unit": "pool-subproblems/s", "ms_total": 1e3 * tot, "ms_create_and_upload": 1e3 * up,
+                                     "upload_GBps": dom["bytes"] / up / 1e9, "evals": ev2,
+                                     "note": "median of 5: cfmm_create + cfmm_upload_* of the pool columns from pageable host buffers + "
+                                             "cfmm_set_utility + one cold cfmm_solve + cfmm_get_solution"}
         if world == 1 and not args.no_cpu:
             from oracle.c_oracle import Oracle
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
