@@ -801,3 +801,29 @@ def test_one_shot_all_reduce_against_rccl_on_real_peers(tmp_path):
     assert abs(a["value"] - b["value"]) <= 2e-7 * abs(a["value"])
     a, b = res["rccl_det"], res["oneshot_det"]
     assert a["f"] == b["f"] and a["psi"] == b["psi"] and a["nu"] == b["nu"] and a["evals"] == b["evals"]
+
+
+def test_bench_line_keeps_the_contract(tmp_path):
+    """`python bench.py` (N = 1, a short run): ONE JSON line with the contract's keys, BASELINE's metric and unit, the
+    roofline and CPU-baseline objects, and the extra figures (batched, PCIe-inclusive) beside -- not instead of -- `value`"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "1", "--cpu-solves", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["unit"] == "pool-subproblems/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 1e10 and abs(d["ms_per_step"] * 1e-3 * d["value"] - d["evals_per_solve"] * d["config"]["pools_total"]) <= 1e-6 * d["evals_per_solve"] * d["config"]["pools_total"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["traffic"] is None or rf["traffic"] > 4e7
+    assert rf["rocprof_avg_launch_us"] is None or abs(rf["rocprof_avg_launch_us"] - rf["avg_launch_us"]) <= 0.15 * rf["avg_launch_us"]     # live vs committed trace
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "pool-subproblems/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert d["batched"]["solves_per_batch"] >= 2 and d["batched"]["value"] > d["value"]
+    assert d["pcie_inclusive"]["value"] < d["value"]
