@@ -39,26 +39,66 @@ __device__ __forceinline__ double curve_y_stable(double x, double ix, double C, 
     return b >= 0.0 ? 0.5 * (b + sq) : 0.5 * q * rcp_nr(sq - b);
 }
 
-// KIND 0 constant product | 1 weighted (r = w_in / w_out) | 3 stableswap (r = alpha, C = level)
-template <int KIND>
-__device__ __forceinline__ Fwd fwd2(double D, double Rin, double Rout, double g, double r, double C)
-{
-    Fwd o;
-    const double x = fma(g, D, Rin);
-    const double ix = rcp_nr(x);
-    if (KIND == 0) {
+// ---- the trading-function table of the second-order path ---------------------------------------
+// A two-asset trading function enters the smoothed evaluation, its Hessian and the interior tenders ONLY through the five
+// members below: a new function is one more Phi2<KIND> (plus its bucket in the upload layer and its closed form -- or a
+// generic root search on the same L' -- in pool_math.hpp for the exact first-order evaluation).
+//   fwd(D, Rin, Rout, g, r, C)   L(D), L'(D), L''(D) of the forward exchange function L(D) = R_out - Y(R_in + g D) on the
+//                                pool's level set (arbitrage.py:60,63-74), formed without cancellation
+//   marginal0(Rin, Rout, g, r)   L'(0), without a curve solve
+//   ratio(prm, a_to_b)           the direction's parameter r from the pool's stored parameter
+//   level(Ra, Rb, prm)           a per-pool constant C handed to fwd (0 where the function needs none)
+//   start(...)                   a starting tender on the trade side: the exact mu = 0 root where it is closed form, an
+//                                estimate otherwise, <= 0 for "none" (the barrier model at D = 0 is used then)
+template <int KIND> struct Phi2;
+
+template <> struct Phi2<0> {                       // constant product (arbitrage.py:68-70)
+    static __device__ __forceinline__ Fwd fwd(double D, double Rin, double Rout, double g, double, double)
+    {
+        Fwd o;
+        const double ix = rcp_nr(fma(g, D, Rin));
         const double gy = g * Rout * ix;                   // L = gamma D R_out / x  (no cancellation)
         o.L = D * gy;
         o.L1 = gy * Rin * ix;                              // gamma k / x^2
         o.L2 = -2.0 * g * o.L1 * ix;
-    } else if (KIND == 1) {
+        return o;
+    }
+    static __device__ __forceinline__ double marginal0(double Rin, double Rout, double g, double) { return g * Rout * rcp_nr(Rin); }
+    static __device__ __forceinline__ double ratio(double, bool) { return 0.0; }
+    static __device__ __forceinline__ double level(double, double, double) { return 0.0; }
+    static __device__ __forceinline__ double start(double Rin, double Rout, double g, double, double, double ni, double no)
+    {
+        return (sqrt_nr(g * no * Rin * Rout * rcp_nr(ni)) - Rin) * rcp_nr(g);
+    }
+};
+
+template <> struct Phi2<1> {                       // weighted geometric mean, r = w_in / w_out (arbitrage.py:65 with two tokens)
+    static __device__ __forceinline__ Fwd fwd(double D, double Rin, double Rout, double g, double r, double)
+    {
+        Fwd o;
+        const double ix = rcp_nr(fma(g, D, Rin));
         const double lq = -r * log1p(g * D * rcp_nr(Rin)); // log (R_in / x)^r
         const double q = exp(lq);
         o.L = -Rout * expm1(lq);
         o.L1 = g * Rout * r * q * ix;
         o.L2 = -g * (r + 1.0) * o.L1 * ix;
-    } else {
-        const double al = r;
+        return o;
+    }
+    static __device__ __forceinline__ double marginal0(double Rin, double Rout, double g, double r) { return g * r * Rout * rcp_nr(Rin); }
+    static __device__ __forceinline__ double ratio(double wa, bool a_to_b) { return a_to_b ? wa / (1.0 - wa) : (1.0 - wa) / wa; }
+    static __device__ __forceinline__ double level(double, double, double) { return 0.0; }
+    static __device__ __forceinline__ double start(double Rin, double Rout, double g, double r, double, double ni, double no)
+    {
+        return Rin * expm1(log(g * no * Rout * r / (ni * Rin)) / (r + 1.0)) / g;
+    }
+};
+
+template <> struct Phi2<3> {                       // stableswap  x + y - alpha / (x y),  r = alpha, C = the pool's level
+    static __device__ __forceinline__ Fwd fwd(double D, double Rin, double Rout, double g, double al, double C)
+    {
+        Fwd o;
+        const double x = fma(g, D, Rin);
+        const double ix = rcp_nr(x);
         const double y = curve_y_stable(x, ix, C, al);
         const double iy = rcp_nr(y);
         const double t = al * ix * iy;                     // alpha / (x y)
@@ -70,9 +110,35 @@ __device__ __forceinline__ Fwd fwd2(double D, double Rin, double Rout, double g,
         o.L = Rout - y;
         o.L1 = -g * y1;
         o.L2 = -g * g * y2;
+        return o;
     }
-    return o;
-}
+    static __device__ __forceinline__ double marginal0(double Rin, double Rout, double g, double al)
+    {
+        const double t = al * rcp_nr(Rin * Rout);
+        return g * fma(t, rcp_nr(Rin), 1.0) * rcp_nr(fma(t, rcp_nr(Rout), 1.0));
+    }
+    static __device__ __forceinline__ double ratio(double al, bool) { return al; }
+    static __device__ __forceinline__ double level(double Ra, double Rb, double al) { return Ra + Rb - al / (Ra * Rb); }
+    // where the marginal price m = phi_x / phi_y has dropped to rho = nu_in / (gamma nu_out): for y << x,
+    // 1 - m ~ alpha rho / (x y^2) with x ~ C - y (three fixed-point sweeps) -- a few per cent off the root at the 80/20
+    // imbalance such trades end at, from where the iteration converges in 5-6 steps (from D = 0 it first overshoots the
+    // knee and needs 12-16)
+    static __device__ __forceinline__ double start(double Rin, double Rout, double g, double al, double C, double ni, double no)
+    {
+        if (!(no * marginal0(Rin, Rout, g, al) - ni > 0.0)) return 0.0;       // no-trade side
+        const double rho = ni * rcp_nr(g * no);
+        if (!(rho < 1.0)) return 0.0;
+        const double k = al * rho * rcp_nr(1.0 - rho);
+        double y = sqrt_nr(k * rcp_nr(C));
+        y = sqrt_nr(k * rcp_nr(C - y));
+        y = sqrt_nr(k * rcp_nr(C - y));
+        const double D0 = (C - y - Rin) * rcp_nr(g);
+        return (D0 > 0.0 && D0 < 1e300) ? D0 : 0.0;
+    }
+};
+
+template <int KIND>
+__device__ __forceinline__ Fwd fwd2(double D, double Rin, double Rout, double g, double r, double C) { return Phi2<KIND>::fwd(D, Rin, Rout, g, r, C); }
 
 struct Branch { double D, L, L1, kappa, val; };
 #ifdef CFMM_SMOOTH_HIST
@@ -102,24 +168,10 @@ __device__ __forceinline__ double barrier_root(double a, double b, double mu)
 template <int KIND>
 __device__ __forceinline__ double cold_start(double Rin, double Rout, double g, double r, double C, double ni, double no, double mu)
 {
-    double De = 0.0;
-    if (KIND == 0) De = (sqrt_nr(g * no * Rin * Rout * rcp_nr(ni)) - Rin) * rcp_nr(g);
-    if (KIND == 1) De = Rin * expm1(log(g * no * Rout * r / (ni * Rin)) / (r + 1.0)) / g;
-    if (De > 0.0) return De;
-    const Fwd f0 = fwd2<KIND>(0.0, Rin, Rout, g, r, C);
-    const double A0 = no * f0.L1 - ni;
-    if (KIND == 3 && A0 > 0.0) {
-        const double rho = ni * rcp_nr(g * no);
-        if (rho < 1.0) {
-            const double k = r * rho * rcp_nr(1.0 - rho);
-            double y = sqrt_nr(k * rcp_nr(C));
-            y = sqrt_nr(k * rcp_nr(C - y));
-            y = sqrt_nr(k * rcp_nr(C - y));
-            const double D0 = (C - y - Rin) * rcp_nr(g);
-            if (D0 > 0.0 && D0 < 1e300) return D0;
-        }
-    }
-    return barrier_root(fmin(no * f0.L2, -1e-300), A0, mu);
+    const double De = Phi2<KIND>::start(Rin, Rout, g, r, C, ni, no);
+    if (De > 0.0 && De < 1e300) return De;
+    const Fwd f0 = Phi2<KIND>::fwd(0.0, Rin, Rout, g, r, C);
+    return barrier_root(fmin(no * f0.L2, -1e-300), no * f0.L1 - ni, mu);
 }
 
 // `Dws` > 0: the root found by the previous evaluation of this direction, used as the starting point (prices and
@@ -134,11 +186,7 @@ __device__ __forceinline__ Branch smooth_branch(double Rin, double Rout, double 
     if (warm) {
         // L'(0) needs no curve solve: in the no-trade regime (A(0) < 0) the root is at most mu / |A(0)|; a warm start
         // far above that is left over from the trade regime
-        double L10;
-        if (KIND == 0) L10 = g * Rout * rcp_nr(Rin);
-        else if (KIND == 1) L10 = g * r * Rout * rcp_nr(Rin);
-        else { const double t = r * rcp_nr(Rin * Rout); L10 = g * fma(t, rcp_nr(Rin), 1.0) * rcp_nr(fma(t, rcp_nr(Rout), 1.0)); }
-        const double A0 = no * L10 - ni;
+        const double A0 = no * Phi2<KIND>::marginal0(Rin, Rout, g, r) - ni;
         if (A0 < 0.0 && Dws * -A0 > 4.0 * mu) warm = false;
     }
     double D = warm ? Dws : cold_start<KIND>(Rin, Rout, g, r, C, ni, no, mu);
@@ -233,10 +281,10 @@ __device__ __forceinline__ void smooth_pool(const Bucket2 &b, long long i, doubl
         ab = smooth_branch_sum(Rb, g, pa, pb, mu);
         ba = smooth_branch_sum(Ra, g, pb, pa, mu);
     } else {
-        const double prm = KIND == 0 ? 0.0 : b.param[i];
-        const double C = KIND == 3 ? Ra + Rb - prm / (Ra * Rb) : 0.0;
-        const double rab = KIND == 1 ? prm / (1.0 - prm) : prm, rba = KIND == 1 ? (1.0 - prm) / prm : prm;
         constexpr int K = KIND == 2 ? 0 : KIND;
+        const double prm = KIND == 0 ? 0.0 : b.param[i];
+        const double C = Phi2<K>::level(Ra, Rb, prm);
+        const double rab = Phi2<K>::ratio(prm, true), rba = Phi2<K>::ratio(prm, false);
         ab = smooth_branch<K>(Ra, Rb, g, rab, C, pa, pb, mu, ws ? ws[i] : 0.0);          // tender a, receive b
         ba = smooth_branch<K>(Rb, Ra, g, rba, C, pb, pa, mu, ws ? ws[b.m + i] : 0.0);    // tender b, receive a
         if (ws) { ws[i] = ab.D; ws[b.m + i] = ba.D; }
