@@ -114,6 +114,8 @@ struct cfmm_ctx {
     DevState *st = nullptr;
     long long *ts = nullptr;           // phase timers (tuning builds)
     char *dev_arena = nullptr, *host_arena = nullptr;   // every per-context device / pinned host buffer below is a piece of these
+    char *util_h = nullptr;            // pinned mirror of the device span c | h | glo | ghi | ctype
+    size_t util_span = 0;
     DevState *hst = nullptr;          // pinned, 2 slots
     double *hsol = nullptr;           // pinned [2][n]: nu | psi of the last solve (saves cfmm_get_solution a synchronisation)
     double *hnu0 = nullptr;           // pinned [n]: staging of cfmm_set_nu
@@ -877,10 +879,12 @@ int enqueue_iteration(cfmm_ctx *ctx, const UpdArgs &ua)
     return CFMM_OK;
 }
 
-int recompute_bounds(cfmm_ctx *ctx)
+// bounds of the group variables from (c, ctype, ties), written into the pinned mirror of the utility span
+int bounds_into_mirror(cfmm_ctx *ctx)
 {
     const int n = ctx->n, ng = ctx->ng;
-    std::vector<double> lo(ng, -INFINITY), hi(ng, INFINITY);
+    double *lo = (double *)(ctx->util_h + ((char *)ctx->glo - (char *)ctx->c)), *hi = (double *)(ctx->util_h + ((char *)ctx->ghi - (char *)ctx->c));
+    for (int r = 0; r < ng; ++r) { lo[r] = -INFINITY; hi[r] = INFINITY; }
     for (int j = 0; j < n; ++j) {
         const int r = ctx->hgrp[j];
         double l = -INFINITY, u = INFINITY;
@@ -893,8 +897,16 @@ int recompute_bounds(cfmm_ctx *ctx)
         if (l > lo[r]) lo[r] = l;
         if (u < hi[r]) hi[r] = u;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->glo, lo.data(), ng * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ghi, hi.data(), ng * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return CFMM_OK;
+}
+
+int recompute_bounds(cfmm_ctx *ctx)
+{
+    const int ng = ctx->ng;
+    { int rc = bounds_into_mirror(ctx); if (rc) return rc; }
+    const size_t olo = (size_t)((char *)ctx->glo - (char *)ctx->c), ohi = (size_t)((char *)ctx->ghi - (char *)ctx->c);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->glo, ctx->util_h + olo, ng * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ghi, ctx->util_h + ohi, ng * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // (the captured iteration holds device pointers and sizes only: new bound / utility VALUES do not invalidate it;
     //  cfmm_set_ties, which changes the number of groups, does)
@@ -1401,8 +1413,9 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
         struct Piece { void **dst; size_t bytes; };
         std::vector<Piece> pieces;
         auto want = [&](auto **pp, size_t count) { pieces.push_back({(void **)pp, count * sizeof(**pp)}); };
-        want(&ctx->c, n + 4); want(&ctx->h, n + 4); want(&ctx->off, n + 4); want(&ctx->glo, n + 4); want(&ctx->ghi, n + 4);
-        want(&ctx->ctype, n + 4); want(&ctx->grp, n + 4);
+        // (c | h | glo | ghi | ctype are contiguous: cfmm_set_utility sends them as ONE copy from a pinned mirror)
+        want(&ctx->c, n + 4); want(&ctx->h, n + 4); want(&ctx->glo, n + 4); want(&ctx->ghi, n + 4); want(&ctx->ctype, n + 4);
+        want(&ctx->off, n + 4); want(&ctx->grp, n + 4);
         double **vecs[] = {&ctx->nu, &ctx->nu_acc, &ctx->psi_acc, &ctx->psi_t, &ctx->nu0, &ctx->s, &ctx->s_t,
                            &ctx->Gs, &ctx->Gs_t, &ctx->d, &ctx->Ds};
         for (auto v : vecs) want(v, n + 4);                  // nu[n] = stop flag; +1: pair loads
@@ -1423,12 +1436,15 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
         TRY_C(hipMemsetAsync(ctx->dev_arena, 0, total, ctx->stream));
         size_t off = 0;
         for (auto &pc : pieces) { *pc.dst = ctx->dev_arena + off; off += (pc.bytes + 16 + 255) & ~(size_t)255; }
-        const size_t hb[4] = {2 * sizeof(DevState), 6 * sizeof(DevState), 2 * (size_t)n * sizeof(double), (size_t)n * sizeof(double)};
-        size_t ho[5] = {0, 0, 0, 0, 0};
-        for (int q = 0; q < 4; ++q) ho[q + 1] = ho[q] + ((hb[q] + 255) & ~(size_t)255);
-        TRY_C(hipHostMalloc((void **)&ctx->host_arena, ho[4], hipHostMallocDefault));
+        ctx->util_span = (size_t)((char *)ctx->off - (char *)ctx->c);
+        const size_t hb[5] = {2 * sizeof(DevState), 6 * sizeof(DevState), 2 * (size_t)n * sizeof(double), (size_t)n * sizeof(double), ctx->util_span};
+        size_t ho[6] = {0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < 5; ++q) ho[q + 1] = ho[q] + ((hb[q] + 255) & ~(size_t)255);
+        TRY_C(hipHostMalloc((void **)&ctx->host_arena, ho[5], hipHostMallocDefault));
         ctx->hst = (DevState *)(ctx->host_arena + ho[0]); ctx->hst3 = (DevState *)(ctx->host_arena + ho[1]);
         ctx->hsol = (double *)(ctx->host_arena + ho[2]); ctx->hnu0 = (double *)(ctx->host_arena + ho[3]);
+        ctx->util_h = ctx->host_arena + ho[4];
+        std::memset(ctx->util_h, 0, ctx->util_span);
     }
     lap("device + pinned arenas");
     TRY_C(hipHostMalloc((void **)&ctx->hstat_h, 64, hipHostMallocMapped));
@@ -1668,15 +1684,21 @@ int cfmm_set_utility(cfmm_ctx *ctx, const double *c, const double *h, const int3
     ctx->hc.assign(c, c + n);
     if (h) ctx->hh.assign(h, h + n); else ctx->hh.assign(n, 0.0);
     if (ctype) ctx->hctype.assign(ctype, ctype + n); else ctx->hctype.assign(n, CFMM_GE);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->c, ctx->hc.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h, ctx->hh.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ctype, ctx->hctype.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     ctx->have_utility = true;
     bool plain = true;                      // h == 0 and psi >= 0 on every token: the update kernel then skips three vectors
     for (int j = 0; j < n; ++j) if (ctx->hh[j] != 0.0 || ctx->hctype[j] != CFMM_GE) { plain = false; break; }
     if (plain != ctx->plain) ctx->g_valid = false;      // (baked into captured launches)
     ctx->plain = plain;
-    return recompute_bounds(ctx);
+    // c | h | bounds | ctype: filled into the pinned mirror of their (contiguous) device span, ONE copy (five staged
+    // pageable copies cost ~40 us per call: 8 % of a batched sweep)
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                    // (the mirror may still be in flight)
+    std::memcpy(ctx->util_h, ctx->hc.data(), n * sizeof(double));
+    std::memcpy(ctx->util_h + ((char *)ctx->h - (char *)ctx->c), ctx->hh.data(), n * sizeof(double));
+    std::memcpy(ctx->util_h + ((char *)ctx->ctype - (char *)ctx->c), ctx->hctype.data(), n * sizeof(int));
+    { int rc = bounds_into_mirror(ctx); if (rc) return rc; }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->c, ctx->util_h, ctx->util_span, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CFMM_OK;
 }
 
 int cfmm_set_ties(cfmm_ctx *ctx, int n_groups, const int32_t *grp, const double *off)
