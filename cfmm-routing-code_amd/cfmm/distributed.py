@@ -93,7 +93,7 @@ def attach_oneshot_checked(prob, dist, evaluations=4, solve_evals=18):
     return "oneshot", f"reproduced RCCL on {evaluations} evaluations and a {solve_evals}-evaluation solve"
 
 
-def sharded_problem(net, utility, dist=None, device=None, shard=True, context=None, allreduce=None):
+def sharded_problem(net, utility, dist=None, device=None, shard=True, context=None, allreduce=None, rccl=True):
     """Problem over this rank's shard, with the library's RCCL communicator initialised.
 
     net: the FULL network (shard=True: it is sliced here) or this rank's own pools (shard=False,
@@ -104,7 +104,9 @@ def sharded_problem(net, utility, dist=None, device=None, shard=True, context=No
     whose collective is gloo; the product never does).  `allreduce`: "rccl" (default), "oneshot" (also selected by
     CFMM_ALLREDUCE=oneshot): the per-evaluation all-reduce as ONE xGMI hop through peer-mapped mailboxes, or "auto": the
     one-shot exchange if -- and only if -- it reproduces RCCL on these peers at start-up (attach_oneshot_checked); what
-    was chosen, and why, is left in prob.allreduce / prob.allreduce_note."""
+    was chosen, and why, is left in prob.allreduce / prob.allreduce_note.  `rccl=False` (with allreduce="oneshot"): no
+    RCCL communicator at all -- the ranks may then share ONE GPU (RCCL refuses that), which is how the IPC path of the
+    one-shot exchange is tested between real processes on a one-GPU box."""
     rank, local_rank, world = env_world()
     if dist is not None:
         rank, world = dist.get_rank(), dist.get_world_size()
@@ -117,8 +119,11 @@ def sharded_problem(net, utility, dist=None, device=None, shard=True, context=No
         prob._ensure_ctx()
         if context is None:
             from . import _lib
-            prob.init_comm(world, rank, broadcast_unique_id(dist, _lib.comm_unique_id))
             how = (allreduce or os.environ.get("CFMM_ALLREDUCE", "rccl")).lower()
+            if rccl:
+                prob.init_comm(world, rank, broadcast_unique_id(dist, _lib.comm_unique_id))
+            elif how != "oneshot":
+                raise ValueError("rccl=False needs allreduce='oneshot'")
             if how not in ("rccl", "oneshot", "auto"):
                 raise ValueError(f"allreduce={how!r}: expected 'rccl', 'oneshot' or 'auto'")
             prob.allreduce, prob.allreduce_note = how, ""

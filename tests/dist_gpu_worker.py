@@ -18,7 +18,45 @@ import cfmm  # noqa: E402
 from cfmm import synthetic  # noqa: E402
 
 
+def same_gpu():
+    """argv[2] == "same_gpu": the ranks are PROCESSES sharing GPU 0 (gloo for the host side, no RCCL -- it refuses two
+    ranks on one device): the real IPC path of the one-shot exchange (hipIpcGetMemHandle / OpenMemHandle, mailboxes
+    written by another process, system-scope visibility) without a second GPU"""
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    net = synthetic.config("C3", scale=0.1, seed=4)
+    n = net["n_tokens"]
+    nus = [net["c"] * np.exp(np.random.default_rng(3 + k).normal(0, 0.02, n)) for k in range(3)]
+    res = {}
+    for det in (False, True):
+        p = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=0, allreduce="oneshot", rccl=False)
+        if det:
+            p.ctx.set_deterministic(True)
+        ev = [p.eval_dual(nu) for nu in nus]
+        v = p.solve(tol=1e-6, method="lbfgs")          # (first order only: the second-order fall-back all-reduces a Hessian, which needs RCCL)
+        mine = dict(f=[e[0] for e in ev], psi=[e[1].tolist() for e in ev], value=v, evals=p.stats["evals"], status=p.status,
+                    nu=p.nu.tolist(), ranks=p.stats["n_ranks"])
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        ref = None
+        if rank == 0:                                   # the unsharded problem, same GPU, after the ranks are done
+            q = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]), deterministic=det)
+            ev0 = [q.eval_dual(nu) for nu in nus]
+            ref = dict(f=[e[0] for e in ev0], psi=[e[1].tolist() for e in ev0], value=q.solve(tol=1e-6, method="lbfgs"), evals=q.stats["evals"], nu=q.nu.tolist())
+            q.close()
+        res["det" if det else "fp64"] = dict(ranks=box, unsharded=ref)
+        p.close()
+        dist.barrier()
+    if rank == 0:
+        with open(sys.argv[1], "w") as fh:
+            json.dump(dict(world=world, res=res), fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[2] == "same_gpu":
+        return same_gpu()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local))

@@ -773,6 +773,37 @@ def test_pool_sharded_c_path_with_the_one_shot_all_reduce(oracle_lib, world, det
         q.close()
 
 
+def test_one_shot_exchange_between_processes_sharing_one_gpu(tmp_path, world=2):
+    """the one-shot exchange between REAL processes: two ranks on GPU 0, mailboxes exported / mapped through hipIpc,
+    written by the other process's kernels, the host running ahead of the device.  Everything of the multi-GPU path
+    except the xGMI hop itself: every rank holds the same bits, they match the unsharded problem to rounding and -- in
+    reproducible mode -- bit for bit, the evaluation count included.  (Two processes run side by side on one GPU; with
+    three the scheduler time-slices them and the exchange kernels, which WAIT for each other, run into their spin
+    bound -- an artefact of sharing a device that one process per GPU does not have.)"""
+    import subprocess, sys, json, socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "same_gpu.json")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(here, "dist_gpu_worker.py"), out, "same_gpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    doc = json.load(open(out))
+    assert doc["world"] == world
+    for mode in ("fp64", "det"):
+        ranks, ref = doc["res"][mode]["ranks"], doc["res"][mode]["unsharded"]
+        for q in ranks:
+            assert q["status"] == "optimal" and q["ranks"] == world
+            assert q["f"] == ranks[0]["f"] and q["psi"] == ranks[0]["psi"] and q["nu"] == ranks[0]["nu"] and q["evals"] == ranks[0]["evals"]
+        q = ranks[0]
+        if mode == "det":
+            assert q["f"] == ref["f"] and q["psi"] == ref["psi"] and q["value"] == ref["value"] and q["nu"] == ref["nu"] and q["evals"] == ref["evals"]
+        else:
+            for f1, f0, p1, p0 in zip(q["f"], ref["f"], q["psi"], ref["psi"]):
+                assert abs(f1 - f0) <= 1e-11 * abs(f0) and np.abs(np.array(p1) - np.array(p0)).max() <= 1e-10 * np.abs(p0).max()
+            assert abs(q["value"] - ref["value"]) <= 2e-6 * abs(ref["value"])
+
+
 def test_one_shot_all_reduce_against_rccl_on_real_peers(tmp_path):
     """needs >= 2 GPUs (skipped on the one-GPU box): one process per GPU, the same sharded evaluation and solve over RCCL
     and over the one-shot mailboxes mapped through hipIpc.  Every rank holds the same bits either way; the two
