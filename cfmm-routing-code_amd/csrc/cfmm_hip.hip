@@ -2416,11 +2416,12 @@ int cfmm_selftest(cfmm_ctx *ctx)
     HIP_TRY(ctx, hipMemsetAsync(d, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
     hipLaunchKernelGGL(selftest_gram_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
+    hipLaunchKernelGGL(selftest_log_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
     hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "selftest -> %s", hipGetErrorString(e));
-    if (h != 0) return fail(ctx, CFMM_E_NUMERIC, "selftest: %d lane results of the cross-lane reductions are wrong on this device / ROCm", h);
+    if (h != 0) return fail(ctx, CFMM_E_NUMERIC, "selftest: %d results of the cross-lane reductions / the fast logarithm are wrong on this device / ROCm", h);
     return CFMM_OK;
 }
 

@@ -286,7 +286,7 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
         const Scatter<DET> ps{BATCH ? psi_s.t + bb * bc.tile_stride : psi_s.t, psi_s.n, psi_s.sc};
         const double p = (BATCH ? nu_s + bb * bc.nu_stride : nu_s)[tok];
         SCHED_FENCE();
-        const double a = log(R * p * rcp_nr(w));
+        const double a = log_pos(R * p * rcp_nr(w));
         SCHED_FENCE();
         xs[lane] = make_double2(a, w);                     // ds_write_b128; same-wave LDS ops stay in order
         __builtin_amdgcn_wave_barrier();
@@ -1713,6 +1713,25 @@ selftest_kernel(int *out)
     for (int l = 0; l < 64; ++l) want += (double)(((l + 3) * (lane + 5)) % 23) - 7.0;      // total of quantity `lane`
     if (wave_reduce_scatter64(V, lane) != want) ++bad;
     atomicAdd(out, bad);
+}
+
+// self-test of log_pos (pool_math.hpp) against the library logarithm: 64 x 256 arguments from 1e-300 to 1e300, dense around 1
+// (where log changes sign and the argument reduction switches octave); counts results more than 2 ulp apart
+__global__ void __launch_bounds__(64)
+selftest_log_kernel(int *out)
+{
+    int bad = 0;
+    for (int k = 0; k < 256; ++k) {
+        const int i = k * 64 + threadIdx.x;                          // 0 .. 16383
+        double x;
+        if (i < 8192) x = exp((i - 4096) * (690.0 / 4096.0));         // e^-690 .. e^690
+        else x = 1.0 + (i - 12288) * (1.0 / 8192.0) * ((i & 1) ? 1.0 : 1e-6);   // around 1, coarse and fine
+        if (!(x > 0.0)) continue;
+        const double a = log_pos(x), b = log(x);
+        const double ulp = fmax(fabs(b), 1e-300) * 2.220446049250313e-16;
+        if (!(fabs(a - b) <= 2.0 * ulp + 1e-320)) ++bad;
+    }
+    if (bad) atomicAdd(out, bad);
 }
 
 // start of a solve: group variable = mean over members of (log nu0_j - off_j), clamped

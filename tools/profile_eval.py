@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C3")
 ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--reps", type=int, default=50)
+ap.add_argument("--only", type=int, default=None, help="one bucket alone: 0 cp2, 1 w2, 2 sum2, 3 curve2, -k the k-asset bucket")
 args = ap.parse_args()
 
 import numpy as np  # noqa: E402
@@ -32,7 +33,7 @@ prob = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
 ctx = prob._ensure_ctx()
 # prices a few percent off the market values: ~88 % of the pools trade, as at the first iterations of a solve
 ctx.set_nu(net["c"] * np.exp(np.random.default_rng(0).normal(0, 0.01, net["n_tokens"])))
-sec = ctx.time_eval_kernel(_lib.TIME_ALL, args.reps)
+sec = ctx.time_eval_kernel(_lib.TIME_ALL if args.only is None else args.only, args.reps)
 nbytes = sum(len(net[k]["Ra"]) * bench.BYTES_PER_POOL[k] for k in ("cp2", "w2", "sum2", "curve2") if k in net)
 nbytes += sum(b["R"].shape[1] * (20 + 20 * k) for k, b in net.get("gn", {}).items())
 print(json.dumps(dict(config=args.config, pools=prob.m, tokens=net["n_tokens"], reps=args.reps, launch_us=sec * 1e6,
