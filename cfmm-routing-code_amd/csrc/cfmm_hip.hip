@@ -1541,6 +1541,7 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
 {
     if (!ctx) return CFMM_E_ARG;
     if (kind < 0 || kind >= CFMM_POOL_KINDS2 || m < 0) return fail(ctx, CFMM_E_ARG, "upload_pools2: kind %d, m %lld", kind, (long long)m);
+    if (m >= (1ll << 29)) return fail(ctx, CFMM_E_LIMIT, "upload_pools2: %lld pools in one bucket (the kernels address a column with 32-bit byte offsets: < 2^29)", (long long)m);
     if (m > 0 && (!Ra || !Rb || !fee || !ia || !ib)) return fail(ctx, CFMM_E_ARG, "upload_pools2: NULL column");
     if (m > 0 && (kind == CFMM_POOL_W2 || kind == CFMM_POOL_CURVE2) && !param) return fail(ctx, CFMM_E_ARG, "upload_pools2: kind %d needs param", kind);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1608,6 +1609,7 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
 {
     if (!ctx) return CFMM_E_ARG;
     if (k < 3 || k > CFMM_MAX_POOL_SIZE || m < 0) return fail(ctx, CFMM_E_LIMIT, "upload_poolsN: pool size %d outside 3..%d", k, CFMM_MAX_POOL_SIZE);
+    if ((long long)k * m >= (1ll << 29)) return fail(ctx, CFMM_E_LIMIT, "upload_poolsN: %lld legs in one bucket (the kernels address a column with 32-bit byte offsets: < 2^29)", (long long)k * m);
     if (m > 0 && (!idx || !R || !w || !fee)) return fail(ctx, CFMM_E_ARG, "upload_poolsN: NULL column");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_poolsN: the pools are shared with a clone (cfmm_clone); destroy the clones first");

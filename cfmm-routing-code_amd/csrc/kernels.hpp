@@ -159,6 +159,13 @@ __device__ __forceinline__ double wave_max(double v) { return wave_allmax(v); }
 //     workgroups, accumulator flushes, pool shards on other GPUs (the limbs are all-reduced as integers) -- and the one
 //     conversion back to fp64 happens in a fixed order (det_fold_kernel).  F is chosen per problem from the largest reserve.
 // ------------------------------------------------------------------------------------------
+// element `i` of a column whose base is wave-uniform: byte offset formed in 32 bits (columns stay below 4 GB)
+template <class T>
+__device__ __forceinline__ T ld_off(const T *base, unsigned i)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(i * (unsigned)sizeof(T)));
+}
+
 template <bool DET> struct Scatter;
 template <> struct Scatter<false> {
     double *t; int n; double sc;
@@ -206,13 +213,15 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
     bool live[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        long long i = i0 + u * 64 + lane;
-        live[u] = i < b.m;
-        i = live[u] ? i : b.m - 1;
-        Ra[u] = b.Ra[i]; Rb[u] = b.Rb[i]; g[u] = b.fee[i];
-        ia[u] = b.ia[i]; ib[u] = b.ib[i];
-        prm[u] = (KIND == 1 || KIND == 3) ? b.param[i] : 0.0;
-        fl[u] = (KIND == 2 && b.flags) ? b.flags[i] : 0;
+        // (32-bit element offsets against the uniform column bases -- a bucket holds < 2^29 pools -- instead of seven 64-bit
+        //  address computations per lane)
+        unsigned i = (unsigned)i0 + u * 64 + lane;
+        live[u] = i < (unsigned long long)b.m;
+        i = live[u] ? i : (unsigned)b.m - 1u;
+        Ra[u] = ld_off(b.Ra, i); Rb[u] = ld_off(b.Rb, i); g[u] = ld_off(b.fee, i);
+        ia[u] = ld_off(b.ia, i); ib[u] = ld_off(b.ib, i);
+        prm[u] = (KIND == 1 || KIND == 3) ? ld_off(b.param, i) : 0.0;
+        fl[u] = (KIND == 2 && b.flags) ? ld_off(b.flags, i) : 0;
     }
 #pragma unroll 1
     for (unsigned mask = BATCH ? bc.alive : 1u; mask; mask &= mask - 1) {
@@ -222,6 +231,15 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const double pa = nub[ia[u]], pb = nub[ib[u]];
+            if constexpr (KIND == 0 && !WITH_D) {          // constant product, directed form (pool_math.hpp)
+                const Y2dir y = pool_cp2_dir(Ra[u], Rb[u], g[u], pa, pb);
+                if (live[u] && y.active) {
+                    ps.add(y.ab ? ia[u] : ib[u], y.yin);
+                    ps.add(y.ab ? ib[u] : ia[u], y.yout);
+                    if (!DET && !BATCH) fsum += y.arb;
+                }
+                continue;
+            }
             Y2 y;
             if (KIND == 0) y = pool_cp2(Ra[u], Rb[u], g[u], pa, pb);
             else if (KIND == 1) y = pool_w2<DET>(Ra[u], Rb[u], g[u], prm[u], pa, pb);
@@ -272,13 +290,15 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
     //  the tile loop and stay live across it -- ~20 VGPRs on a kernel that sits on a register cliff)
     asm volatile("" : "+v"(lane));
     const int g = lane / K, j = lane - g * K;
-    const long long pool = tb * P + g;
-    const bool live = (g < P) && (pool < b.m);
-    const long long leg = live ? pool * K + j : 0;
-    const int tok = b.idx[leg];
-    const double R = b.R[leg], w = b.w[leg];
-    const double fee = b.fee[live ? pool : 0];
-    const double lg = b.lfee[live ? pool : 0];
+    // (32-bit element offsets against the uniform column bases: a bucket holds < 2^28 legs, and the loads then take the
+    //  scalar-base + 32-bit-offset form instead of five 64-bit address computations per lane)
+    const unsigned pool = (unsigned)tb * P + g;
+    const bool live = (g < P) && (pool < (unsigned long long)b.m);
+    const unsigned leg = live ? pool * K + j : 0u, pl = live ? pool : 0u;
+    const int tok = ld_off(b.idx, leg);
+    const double R = ld_off(b.R, leg), w = ld_off(b.w, leg);
+    const double fee = ld_off(b.fee, pl);
+    const double lg = ld_off(b.lfee, pl);
     const int gb = (g < P ? g : 0) * K;
 #pragma unroll 1
     for (unsigned mask = BATCH ? bc.alive : 1u; mask; mask &= mask - 1) {
@@ -291,6 +311,9 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
         xs[lane] = make_double2(a, w);                     // ds_write_b128; same-wave LDS ops stay in order
         __builtin_amdgcn_wave_barrier();
         const double t1 = a, t2 = a - lg;
+        // (NOT rewritten as min(u,0) + max(u,L) - L etc., two operations fewer per term: inside a pool's no-trade band F is
+        //  EXACTLY zero in this form -- a sum of exact zeros -- and the strict sign tests below rely on it; the rewritten sums
+        //  come out as +-1e-19 there and flag legs of pools that must not trade)
         double f1 = 0.0, f2 = 0.0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {

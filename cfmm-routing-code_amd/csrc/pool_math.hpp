@@ -111,6 +111,29 @@ __device__ __forceinline__ Y2 pool_cp2(double Ra, double Rb, double g, double pa
     return y;
 }
 
+// The same solution in directed form, for the evaluation tiles: which way the pool trades, y of the tendered and of the
+// received token, and the pool's arbitrage profit  nu_in y_in + nu_out y_out = v_out (1 - 1/sqrt(rho)) - v_in (sqrt(rho) - 1) / gamma
+// straight from the values (the tile scatters y_in / y_out to the tokens it picks with `ab`: ten selects fewer per pool
+// than building (y_a, y_b) and their price-weighted sum).
+struct Y2dir { double yin, yout, arb; bool ab, active; };
+__device__ __forceinline__ Y2dir pool_cp2_dir(double Ra, double Rb, double g, double pa, double pb)
+{
+    const double va = pa * Ra, vb = pb * Rb;
+    Y2dir o;
+    o.ab = g * vb > va;
+    o.active = o.ab || (g * va > vb);
+    const double vin = o.ab ? va : vb, vout = o.ab ? vb : va;
+    const double Rin = o.ab ? Ra : Rb, Rout = o.ab ? Rb : Ra;
+    const double rho = g * vout * rcp_nr(vin);
+    const double r = rsqrt_nr(rho);
+    const double X = fma(rho, r, -1.0), ig = rcp_nr(g);         // sqrt(rho) - 1,  1 / gamma
+    const double om = 1.0 - r;
+    o.yin = -Rin * X * ig;                                      // (the same operations in the same order as pool_cp2: the
+    o.yout = Rout * om;                                         //  reproducible mode compares the two forms bit for bit)
+    o.arb = fma(vout, om, -vin * X * ig);
+    return o;
+}
+
 // Weighted geometric mean x^wa y^(1-wa) (2-asset Balancer: arbitrage.py:65 with two tokens).
 // With weighted values va = w_b p_a R_a, vb = w_a p_b R_b the pool tenders `in` iff
 //     rho = gamma v_out / v_in > 1,   and with L = log rho:
