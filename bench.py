@@ -277,7 +277,7 @@ def main():
                          "note": TRAFFIC_NOTE[args.config],
                          "all_kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]},
         }
-        if world == 1 and not strong and not args.no_batch:
+        if not sharded and not strong and not args.no_batch:
             # B price vectors per pool read (cfmm_solve_batch; the parametric-sweep use of two-asset.py:34-100): B solves
             # of the same pools under B utilities in lock-step.  Not `value` (the metric is quoted on ONE solve of this
             # config): an extra figure in the same unit.
@@ -302,7 +302,7 @@ def main():
                                       "(eval_batch_kernel + one update workgroup per solve); wall time includes the host-side start "
                                       "prices and certificate checks of every solve"}
             prob.set_utility(cfmm.Arbitrage(net["c"]))
-        if world == 1 and not strong:
+        if not sharded and not strong:
             # the same solve with the host-buffer hand-over inside the clock (never `value`): a fresh context, the pool columns
             # uploaded from pageable NumPy buffers, utility, one cold solve, prices and psi read back -- through the raw
             # C-ABI calls INTEGRATION.md's stub makes
@@ -329,7 +329,7 @@ def main():
                                      "upload_GBps": dom["bytes"] / up / 1e9, "evals": ev2,
                                      "note": "median of 5: cfmm_create + cfmm_upload_* of the pool columns from pageable host buffers + "
                                              "cfmm_set_utility + one cold cfmm_solve + cfmm_get_solution"}
-        if world == 1 and not args.no_cpu:
+        if not sharded and not args.no_cpu:
             from oracle.c_oracle import Oracle
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             # calibrate the thread count on single dual evaluations (a cgroup quota can make "all logical

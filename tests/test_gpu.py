@@ -858,3 +858,10 @@ def test_bench_line_keeps_the_contract(tmp_path):
     assert cb["kind"] == "port" and cb["unit"] == "pool-subproblems/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert d["batched"]["solves_per_batch"] >= 2 and d["batched"]["value"] > d["value"]
     assert d["pcie_inclusive"]["value"] < d["value"]
+    # the pool-sharded code path with a one-rank process group (what the driver's --gpus N > 1 runs per rank)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--force-dist", "--no-cpu"],
+                       capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    d1 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d1["n_gpus"] == 1 and d1["config"]["rccl_ranks"] == 1 and d1["config"]["allreduce"] == "rccl" and d1["value"] > 1e10
+    assert abs(d1["objective"] - d["objective"]) <= 2e-6 * abs(d["objective"])
