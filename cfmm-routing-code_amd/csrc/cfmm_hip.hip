@@ -275,6 +275,8 @@ struct StageRing {
     std::mutex mu;
     char *buf = nullptr;
     hipEvent_t ev[STAGE_SLOTS] = {};
+    bool used[STAGE_SLOTS] = {};       // the slot's last copy may still be in flight (its event tells): kept ACROSS calls
+    int next = 0;
 };
 StageRing g_stage;
 std::mutex g_stream_mu;
@@ -502,31 +504,43 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const 
         if (e != hipSuccess) { g_stage.buf = nullptr; return bail(e, "hipHostMalloc(staging)"); }
         for (auto &ev : g_stage.ev) { e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) return bail(e, "hipEventCreate"); }
     }
-    int slot = 0;
-    bool used[STAGE_SLOTS] = {};
-    for (size_t q = 0; q < cols.size(); ++q) {
-        for (size_t off = 0; off < cols[q].bytes; off += STAGE_BYTES) {
-            const size_t len = std::min(STAGE_BYTES, cols[q].bytes - off);
-            char *st = g_stage.buf + (size_t)slot * STAGE_BYTES;
-            const auto t0 = now();
-            if (used[slot]) { hipError_t e = hipEventSynchronize(g_stage.ev[slot]); if (e != hipSuccess) return bail(e, "hipEventSynchronize"); }
-            const auto t1 = now();
-            parallel_fill(cols[q], st, off, len);
-            const auto t2 = now();
-            if (scan && scan->bad.load(std::memory_order_relaxed)) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(base); return CFMM_E_ARG; }
-            hipError_t e = hipMemcpyAsync(base + offs[q] + off, st, len, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipEventRecord(g_stage.ev[slot], ctx->stream);
-            if (e != hipSuccess) return bail(e, "hipMemcpyAsync");
-            t_wait += ms(t0, t1); t_fill += ms(t1, t2); t_enq += ms(t2, now());
-            used[slot] = true; slot = (slot + 1) % STAGE_SLOTS;
+    // The arena's byte range goes out in chunks of STAGE_BYTES; a chunk may span several columns (a small bucket is ONE
+    // chunk, one fork-join of the workers and one copy instead of one of each per column: the six K-asset buckets of C3 cost
+    // 0.17 ms per call that way, mostly fixed).  Work items: (column, byte range) pieces of >= 64 KB.
+    struct Job { size_t q, col_off, len, st_off; };
+    int slot = g_stage.next;
+    bool *used = g_stage.used;
+    std::vector<Job> jobs;
+    for (size_t c0 = 0; c0 < total; c0 += STAGE_BYTES) {
+        const size_t clen = std::min(STAGE_BYTES, total - c0);
+        char *st = g_stage.buf + (size_t)slot * STAGE_BYTES;
+        jobs.clear();
+        for (size_t q = 0; q < cols.size(); ++q) {
+            const size_t lo = std::max(offs[q], c0), hi = std::min(offs[q] + cols[q].bytes, c0 + clen);
+            if (lo >= hi) continue;
+            const size_t grain = 64u << 10;
+            for (size_t b = lo; b < hi; b += grain) jobs.push_back({q, b - offs[q], std::min(grain, hi - b), b - c0});
         }
-        *cols[q].dst = base + offs[q];
+        const auto t0 = now();
+        if (used[slot]) { hipError_t e = hipEventSynchronize(g_stage.ev[slot]); if (e != hipSuccess) return bail(e, "hipEventSynchronize"); }
+        const auto t1 = now();
+        HostPool::get().run((int)jobs.size(), [&](int j) { const Job &w = jobs[j]; cols[w.q].fill(st + w.st_off, w.col_off, w.len); });
+        const auto t2 = now();
+        if (scan && scan->bad.load(std::memory_order_relaxed)) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(base); return CFMM_E_ARG; }
+        hipError_t e = hipMemcpyAsync(base + c0, st, clen, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(g_stage.ev[slot], ctx->stream);
+        if (e != hipSuccess) return bail(e, "hipMemcpyAsync");
+        t_wait += ms(t0, t1); t_fill += ms(t1, t2); t_enq += ms(t2, now());
+        used[slot] = true; slot = (slot + 1) % STAGE_SLOTS;
     }
-    const auto tC = now();
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) return bail(e, "hipStreamSynchronize");
-    if (trace) fprintf(stderr, "[cfmm upload] %.2f MB: hipMalloc %.3f ms, fill %.3f, wait-for-slot %.3f, enqueue %.3f, final sync %.3f, total %.3f\n",
-                       total / 1e6, ms(tA, tB), t_fill, t_wait, t_enq, ms(tC, now()), ms(tA, now()));
+    for (size_t q = 0; q < cols.size(); ++q) *cols[q].dst = base + offs[q];
+    g_stage.next = slot;
+    // No synchronisation here: the caller's buffers have been consumed (they are in the staging ring), the copies are
+    // ordered on ctx->stream in front of everything that will read the pools, and the ring slots guard their own reuse
+    // -- so the fill of the NEXT bucket overlaps the tail of this one's DMA (0.04-0.13 ms per call at C3).  A failed copy
+    // surfaces at the next synchronisation (cfmm_clone and cfmm_destroy synchronise).
+    if (trace) fprintf(stderr, "[cfmm upload] %.2f MB: hipMalloc %.3f ms, fill %.3f, wait-for-slot %.3f, enqueue %.3f, total %.3f\n",
+                       total / 1e6, ms(tA, tB), t_fill, t_wait, t_enq, ms(tA, now()));
     *arena_out = base;
     return CFMM_OK;
 }
@@ -545,6 +559,8 @@ int download_staged(cfmm_ctx *ctx, void *host_dst, const void *dev_src, size_t b
         HIP_TRY(ctx, hipHostMalloc((void **)&g_stage.buf, STAGE_SLOTS * STAGE_BYTES, hipHostMallocDefault));
         for (auto &ev : g_stage.ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
+    // (uploads may have left copies in flight out of the ring)
+    for (int q = 0; q < STAGE_SLOTS; ++q) if (g_stage.used[q]) { HIP_TRY(ctx, hipEventSynchronize(g_stage.ev[q])); g_stage.used[q] = false; }
     const size_t nchunks = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
     auto enqueue = [&](size_t c) -> hipError_t {
         const size_t off = c * STAGE_BYTES, len = std::min(STAGE_BYTES, bytes - off);
@@ -1486,6 +1502,8 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
 int cfmm_clone(cfmm_ctx *src, cfmm_ctx **out)
 {
     if (!src || !out) return CFMM_E_ARG;
+    HIP_TRY(src, hipSetDevice(src->device));
+    HIP_TRY(src, hipStreamSynchronize(src->stream));         // (the pools the clone will read may still be arriving)
     cfmm_ctx *c = nullptr;
     int rc = cfmm_create(src->device, src->n, &c);
     if (rc) { src->err = g_create_error; return rc; }
@@ -1546,7 +1564,7 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
     if (m > 0 && (kind == CFMM_POOL_W2 || kind == CFMM_POOL_CURVE2) && !param) return fail(ctx, CFMM_E_ARG, "upload_pools2: kind %d needs param", kind);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_pools2: the pools are shared with a clone (cfmm_clone); destroy the clones first");
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pools->b2mem[kind]) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // (replacing a bucket kernels may still be reading)
     // the new bucket is built first and swapped in only once every column has arrived and passed its checks: a failed
     // upload leaves the previous pools (and everything derived from them) untouched.  The checks (ids, reserves, fee,
     // parameter) and the extrema the reproducible mode needs ride on the staging copy: one pass over the caller's data.
@@ -1613,7 +1631,7 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
     if (m > 0 && (!idx || !R || !w || !fee)) return fail(ctx, CFMM_E_ARG, "upload_poolsN: NULL column");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_poolsN: the pools are shared with a clone (cfmm_clone); destroy the clones first");
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pools->bnmem[k]) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // (replacing a bucket kernels may still be reading)
     BucketN b = {};
     b.m = m;
     void *arena = nullptr;
