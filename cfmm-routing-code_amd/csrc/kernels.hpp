@@ -86,7 +86,7 @@ struct EvalArgs {
 __host__ __device__ inline int eval_tile_doubles(int n, bool det) { return (det ? 3 : 1) * n; }     // one scatter tile (psi or diag)
 __host__ __device__ inline int eval_lds_doubles(int n, bool with_d, bool det = false)
 {
-    return (((with_d ? 2 : 1) * eval_tile_doubles(n, det) + n + 2 + 16 + 2) + 1) & ~1;
+    return (((with_d ? 2 : 1) * eval_tile_doubles(n, det) + n + 2 + 16 + 2 + N_BUCKETS) + 1) & ~1;     // (+ ticket + the tile-range table: 2 x N_BUCKETS ints)
 }
 
 // accumulator slice layout (np = n rounded up to even, so that every piece is 16-byte aligned):
@@ -382,22 +382,43 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
     int nlog = 0;
     long long t_prev = clock64(), t_out = 0;         // time spent between tiles (ticket, bucket search, dispatch)
 #endif
-    // Workgroup b owns the tiles {b + gridDim * i}: every workgroup sees the same mix of buckets, heaviest
-    // first.  Its waves draw i from an LDS ticket counter (ds_add_rtn, ~100 cycles against >= 1 us per
-    // tile), so they all finish within one tile of each other however uneven the tile costs are.
-    const int ntiles = a.ntiles, tstride = gridDim.x;
+    // Workgroup b owns a CONTIGUOUS range of every bucket's wave-tiles, [b n_q / G, (b + 1) n_q / G) of bucket q's n_q:
+    // every workgroup sees the same mix of buckets, heaviest first, and -- the point -- with the pools of a bucket ordered by
+    // token blocks at upload (reorder.hpp) the pools of ONE workgroup touch few tokens: its psi tile is sparse, the flush
+    // sends a few hundred atomics instead of n, the LDS gathers / scatters stay in a small window (C4 shard: evaluation
+    // 16.1 -> 10.5 us).  Its waves draw the index i into the concatenation of its ranges from an LDS ticket counter
+    // (ds_add_rtn, ~100 cycles against >= 1 us per tile), so they all finish within one tile of each other however
+    // uneven the tile costs are.  Range table (LDS, behind the ticket): tab[q] = tiles of buckets <= q in this workgroup,
+    // tab[N_BUCKETS + q] = first tile of its range inside bucket q.
+    int *tab = next_tile + 2;
+    if (threadIdx.x < N_BUCKETS) {
+        const int q = threadIdx.x;
+        const int nq = a.tile_end[q] - (q ? a.tile_end[q - 1] : 0);
+        const double G = (double)gridDim.x;           // (products < 2^47: exact in fp64, and the floors below cannot be off by one)
+        const int s = (int)(((double)blockIdx.x * nq) / G), e = (int)(((double)(blockIdx.x + 1) * nq) / G);
+        tab[N_BUCKETS + q] = s;
+        tab[q] = e - s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int c = 0; for (int q = 0; q < N_BUCKETS; ++q) { c += tab[q]; tab[q] = c; } }
+    __syncthreads();
+    const int nlocal = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS - 1]);
+    int bk = 0, cstart = 0;
+    int cend = __builtin_amdgcn_readfirstlane(tab[0]), sfirst = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS]);
     int ticket = 0;
     if (lane == 0) ticket = atomicAdd(next_tile, 1);
     for (;;) {
-        const int t = blockIdx.x + tstride * __builtin_amdgcn_readfirstlane(ticket);
-        if (t >= ntiles) break;
+        const int i = __builtin_amdgcn_readfirstlane(ticket);
+        if (i >= nlocal) break;
         // the NEXT ticket is drawn before this tile's work, so its LDS round trip (behind the
         // previous tile's scatter atomics) overlaps the tile instead of separating two tiles
         if (lane == 0) ticket = atomicAdd(next_tile, 1);
-        int bk = 0;
-#pragma unroll
-        for (int q = 0; q < N_BUCKETS - 1; ++q) bk += (t >= a.tile_end[q]) ? 1 : 0;
-        const int tb = t - (bk ? a.tile_end[bk - 1] : 0);
+        while (i >= cend) {                              // (a wave's tickets only grow: the bucket pointer only moves forward)
+            ++bk; cstart = cend;
+            cend = __builtin_amdgcn_readfirstlane(tab[bk]);
+            sfirst = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS + bk]);
+        }
+        const int tb = sfirst + (i - cstart);
 #ifdef CFMM_PHASE_TIMERS
         const long long tc0 = clock64();
         t_out += tc0 - t_prev;
@@ -531,7 +552,7 @@ struct BatchArgs {
     int nb, pad;
 };
 __host__ __device__ inline int batch_nu_stride(int n) { return (n + 3) & ~1; }
-__host__ __device__ inline int batch_lds_doubles(int n, int nb) { return nb * n + nb * batch_nu_stride(n) + BATCH_MAX * 16 + 2; }
+__host__ __device__ inline int batch_lds_doubles(int n, int nb) { return nb * n + nb * batch_nu_stride(n) + BATCH_MAX * 16 + 2 + N_BUCKETS; }
 __host__ __device__ inline size_t batch_lds_bytes(int n, int nb) { return (size_t)(batch_lds_doubles(n, nb) + 2 * 64 * (EVAL_THREADS / 64)) * sizeof(double); }
 __host__ __device__ inline int batch_capacity(int n)          // price vectors per launch that fit 160 KB of LDS
 {
