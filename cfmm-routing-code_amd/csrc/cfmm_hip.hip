@@ -29,6 +29,7 @@
 #include "kernels.hpp"
 #include "iterate.hpp"
 #include "tiny.hpp"
+#include "reorder.hpp"
 #include "oneshot.hpp"
 #include "smooth.hpp"
 #include "chol.hpp"
@@ -84,8 +85,13 @@ struct PoolStore {
     void *bnmem[CFMM_MAX_POOL_SIZE + 1] = {};
     double mxr2[CFMM_POOL_KINDS2] = {}, mnf2[CFMM_POOL_KINDS2] = {1.0, 1.0, 1.0, 1.0};       // largest reserve / smallest fee per bucket
     double mxrn[CFMM_MAX_POOL_SIZE + 1] = {}, mnfn[CFMM_MAX_POOL_SIZE + 1] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+    // token-block ordering still to be done (reorder.hpp): the arena's column bytes, 0 = nothing pending.  Done lazily, in
+    // front of the first kernel that reads the pools, so that the uploads' copies are not queued behind sort kernels
+    size_t ro2[CFMM_POOL_KINDS2] = {}, ron[CFMM_MAX_POOL_SIZE + 1] = {};
+    std::vector<void *> landed;                    // landing arenas whose permuted copies have been enqueued: freed by release_landed
     ~PoolStore()
     {
+        for (void *q : landed) (void)hipFree(q);
         for (void *q : b2mem) if (q) (void)hipFree(q);
         for (void *q : bnmem) if (q) (void)hipFree(q);
     }
@@ -461,7 +467,7 @@ void parallel_fill(const Col &c, char *out, size_t off, size_t len)
     });
 }
 // returns CFMM_E_ARG (no message set) when a fill flagged bad data: the caller describes what is wrong
-int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const UploadScan *scan = nullptr)
+int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const UploadScan *scan = nullptr, int64_t reorder_m = 0, size_t *total_out = nullptr)
 {
     size_t total = 0;
     std::vector<size_t> offs;
@@ -471,7 +477,9 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const 
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto tA = now();
+    (void)reorder_m;
     HIP_TRY(ctx, hipMalloc((void **)&base, total + 256));
+    if (total_out) *total_out = total;
     const auto tB = now();
     double t_fill = 0.0, t_wait = 0.0, t_enq = 0.0;
     auto bail = [&](hipError_t e, const char *what) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(base); return fail(ctx, CFMM_E_HIP, "upload: %s -> %s", what, hipGetErrorString(e)); };
@@ -1357,6 +1365,9 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
 
 extern "C" {
 
+static void pools_ready(cfmm_ctx *ctx);     // (the pending token-block orderings: reorder.hpp)
+static void release_landed(cfmm_ctx *ctx);
+
 void cfmm_default_opts(cfmm_opts *o)
 {
     std::memset(o, 0, sizeof *o);
@@ -1503,6 +1514,7 @@ int cfmm_clone(cfmm_ctx *src, cfmm_ctx **out)
 {
     if (!src || !out) return CFMM_E_ARG;
     HIP_TRY(src, hipSetDevice(src->device));
+    pools_ready(src);
     HIP_TRY(src, hipStreamSynchronize(src->stream));         // (the pools the clone will read may still be arriving)
     cfmm_ctx *c = nullptr;
     int rc = cfmm_create(src->device, src->n, &c);
@@ -1554,6 +1566,104 @@ int64_t cfmm_pool_count(cfmm_ctx *ctx)
     return m;
 }
 
+// ---- token-block ordering of a freshly uploaded bucket (reorder.hpp) -------------------------------------------------
+// Done lazily, in front of the first kernel that reads the pools (pools_ready): the upload's copies are not queued behind
+// sort kernels, and its arena is not twice the size (a 2x allocation slowed the H2D copies: 1.31 -> 2.2 ms for C3).  The
+// columns are permuted into a NEW arena (+ the permutation, + the sort's 256 counters); the landing arena is freed.
+static bool reorder_applies(cfmm_ctx *ctx, int kind_or_k, int64_t m)
+{
+    static const bool off = getenv("CFMM_REORDER") && atoi(getenv("CFMM_REORDER")) == 0;      // (A/B)
+    return !off && m >= (kind_or_k >= 3 ? RO_MIN_POOLS_N : RO_MIN_POOLS) && ctx->n >= 2 * RO_NB && kind_or_k != CFMM_POOL_SUM2;    // (tied constant-sum pools are flagged by the caller's index)
+}
+static char *reorder_arena(cfmm_ctx *ctx, size_t total, int64_t m, int **perm, unsigned **hist)
+{
+    char *na = nullptr;
+    const size_t pbytes = ((size_t)m * 4 + 255) & ~(size_t)255;
+    if (hipMalloc((void **)&na, total + 256 + pbytes + 4096) != hipSuccess) return nullptr;
+    *perm = (int *)(na + total + 256);
+    *hist = (unsigned *)(na + total + 256 + pbytes);
+    (void)hipMemsetAsync(*hist, 0, RO_KEYS * sizeof(unsigned), ctx->stream);
+    return na;
+}
+static bool reorder_bucket2(cfmm_ctx *ctx, Bucket2 &b, void **arena, size_t total)
+{
+    int *perm; unsigned *hist;
+    char *old = (char *)*arena, *na = reorder_arena(ctx, total, b.m, &perm, &hist);
+    if (!na) return false;                             // (no memory for the second copy: the pools stay in the caller's order)
+    auto sh = [&](const void *p) { return p ? (void *)(na + ((const char *)p - old)) : nullptr; };
+    Cols2 d{(double *)sh(b.Ra), (double *)sh(b.Rb), (double *)sh(b.fee), (double *)sh(b.param), (int *)sh(b.ia), (int *)sh(b.ib)};
+    const int bsz = (ctx->n + RO_NB - 1) / RO_NB;
+    const int per = RO_THREADS * RO_PER, grid = (int)((b.m + per - 1) / per);
+    hipLaunchKernelGGL(ro_hist_kernel<2>, dim3(std::min(grid, 2048)), dim3(RO_THREADS), 0, ctx->stream, b.ia, b.ib, (long long)b.m, bsz, hist);
+    hipLaunchKernelGGL(ro_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, hist);
+    hipLaunchKernelGGL(ro_scatter2_kernel, dim3(grid), dim3(RO_THREADS), 0, ctx->stream, b, d, perm, bsz, hist);
+    b.Ra = d.Ra; b.Rb = d.Rb; b.fee = d.fee; b.param = d.param; b.ia = d.ia; b.ib = d.ib; b.perm = perm;
+    *arena = na;
+    return true;
+}
+static bool reorder_bucketN(cfmm_ctx *ctx, int k, BucketN &b, void **arena, size_t total)
+{
+    int *perm; unsigned *hist;
+    char *old = (char *)*arena, *na = reorder_arena(ctx, total, b.m, &perm, &hist);
+    if (!na) return false;
+    auto sh = [&](const void *p) { return (void *)(na + ((const char *)p - old)); };
+    ColsN d{(int *)sh(b.idx), (double *)sh(b.R), (double *)sh(b.w), (double *)sh(b.fee), (double *)sh(b.lfee)};
+    const int bsz = (ctx->n + RO_NB - 1) / RO_NB;
+    const int per = RO_THREADS * RO_PER, grid = (int)((b.m + per - 1) / per);
+    const dim3 gh(std::min(grid, 2048)), gs(grid), blk(RO_THREADS);
+    switch (k) {
+#define RO_CASE(KK) case KK: hipLaunchKernelGGL(ro_hist_kernel<KK>, gh, blk, 0, ctx->stream, b.idx, (const int *)nullptr, (long long)b.m, bsz, hist); \
+                             hipLaunchKernelGGL(ro_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, hist); \
+                             hipLaunchKernelGGL(ro_scatterN_kernel<KK>, gs, blk, 0, ctx->stream, b, d, perm, bsz, hist); break;
+    RO_CASE(3) RO_CASE(4) RO_CASE(5) RO_CASE(6) RO_CASE(7) default: RO_CASE(8)
+#undef RO_CASE
+    }
+    b.idx = d.idx; b.R = d.R; b.w = d.w; b.fee = d.fee; b.lfee = d.lfee; b.perm = perm;
+    *arena = na;
+    return true;
+}
+
+// in front of everything that reads the pools on the device: the pending token-block orderings, on this context's stream
+static void pools_ready(cfmm_ctx *ctx)
+{
+    PoolStore &ps = *ctx->pools;
+    {   // Is there anything to gain?  A K-asset pool localises two of its K legs; the other K - 2 land anywhere, and once a
+        // workgroup's share of those stray legs is of the order of the token count its psi tile is dense whatever the order of
+        // the two-asset pools (C3: 1e5 K-asset pools, ~1400 stray legs per workgroup over 1000 tokens: the ordering bought
+        // nothing there and cost 0.4 ms on the first solve).  Then the buckets stay in the caller's order.
+        bool pending = false;
+        for (size_t v : ps.ro2) pending |= v != 0;
+        for (size_t v : ps.ron) pending |= v != 0;
+        if (!pending) return;
+        double stray = 0.0;
+        for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) stray += (double)ps.bn[k].m * (k - 2);
+        if (stray / (double)ctx->cus >= 0.5 * ctx->n) {
+            for (size_t &v : ps.ro2) v = 0;
+            for (size_t &v : ps.ron) v = 0;
+            return;
+        }
+    }
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) if (ps.ro2[k]) {
+        void *old = ps.b2mem[k];
+        if (reorder_bucket2(ctx, ps.b2[k], &ps.b2mem[k], ps.ro2[k])) ps.landed.push_back(old);
+        ps.ro2[k] = 0;
+    }
+    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) if (ps.ron[k]) {
+        void *old = ps.bnmem[k];
+        if (reorder_bucketN(ctx, k, ps.bn[k], &ps.bnmem[k], ps.ron[k])) ps.landed.push_back(old);
+        ps.ron[k] = 0;
+    }
+}
+// at the END of an entry point that has synchronised its stream (the permuted copies are complete): the landing arenas
+// go.  hipFree synchronises the whole device -- at the start of a call that could wait on a kernel of another in-process
+// "rank" that is itself waiting for this rank's next exchange; behind this call's own synchronisation nothing waits for us
+static void release_landed(cfmm_ctx *ctx)
+{
+    PoolStore &ps = *ctx->pools;
+    for (void *q : ps.landed) (void)hipFree(q);
+    ps.landed.clear();
+}
+
 int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, const double *Rb, const double *fee,
                        const double *param, const int32_t *ia, const int32_t *ib)
 {
@@ -1572,6 +1682,7 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
     b.m = m;
     void *arena = nullptr;
     UploadScan scan;
+    size_t ro_total = 0;
     if (m > 0) {
         const int ntok = ctx->n;
         std::vector<Col> cols;
@@ -1598,7 +1709,9 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
             };
             cols.push_back(c);
         }
-        int rc = upload_arena(ctx, cols, &arena, &scan);
+        size_t total = 0;
+        const bool ro = reorder_applies(ctx, kind, m);
+        int rc = upload_arena(ctx, cols, &arena, &scan, ro ? m : 0, &total);
         if (rc == CFMM_E_ARG && scan.bad.load()) {
             // something failed its check: find the first offender for the message (the slow path)
             for (int64_t i = 0; i < m; ++i) {
@@ -1612,11 +1725,13 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
             return fail(ctx, CFMM_E_ARG, "upload_pools2: a column failed its checks");
         }
         if (rc) return rc;
+        if (ro) ro_total = total;
     }
     const double mxr = scan.mxr, mnf = scan.mnf;
     if (ctx->pools->b2mem[kind]) (void)hipFree(ctx->pools->b2mem[kind]);
     ctx->pools->b2mem[kind] = arena;
     ctx->pools->b2[kind] = b;
+    ctx->pools->ro2[kind] = ro_total;
     ctx->pools->mxr2[kind] = mxr; ctx->pools->mnf2[kind] = mnf;
     if (kind == CFMM_POOL_SUM2 && ctx->flags2) { (void)hipFree(ctx->flags2); ctx->flags2 = nullptr; }
     pools_changed(ctx);
@@ -1636,6 +1751,7 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
     b.m = m;
     void *arena = nullptr;
     UploadScan scan;
+    size_t ro_total = 0;
     if (m > 0) {
         // the ABI hands columns slot-major [k][m]; the device layout is pool-major [m][k] (leg per lane): transposed
         // while staging, checked on the way.  log(fee) is computed once here (+8 B per pool instead of one log per
@@ -1654,7 +1770,9 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
             };
             cols.push_back(c);
         }
-        int rc = upload_arena(ctx, cols, &arena, &scan);
+        size_t total = 0;
+        const bool ro = reorder_applies(ctx, k, m);
+        int rc = upload_arena(ctx, cols, &arena, &scan, ro ? m : 0, &total);
         if (rc == CFMM_E_ARG && scan.bad.load()) {
             for (int64_t i = 0; i < (int64_t)k * m; ++i)
                 if (idx[i] < 0 || idx[i] >= ctx->n) return fail(ctx, CFMM_E_ARG, "upload_poolsN: token id %d outside [0,%d)", idx[i], ctx->n);
@@ -1666,11 +1784,13 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
             return fail(ctx, CFMM_E_ARG, "upload_poolsN: a column failed its checks");
         }
         if (rc) return rc;
+        if (ro) ro_total = total;
     }
     const double mxr = scan.mxr, mnf = scan.mnf;
     if (ctx->pools->bnmem[k]) (void)hipFree(ctx->pools->bnmem[k]);
     ctx->pools->bnmem[k] = arena;
     ctx->pools->bn[k] = b;
+    ctx->pools->ron[k] = ro_total;
     ctx->pools->mxrn[k] = mxr; ctx->pools->mnfn[k] = mnf;
     pools_changed(ctx);
     return CFMM_OK;
@@ -1793,6 +1913,7 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
 {
     if (!ctx || !nu) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pools_ready(ctx);
     const int n = ctx->n;
     for (int j = 0; j < n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "eval_dual: nu[%d] = %g is not a positive finite price", j, nu[j]);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, nu, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -1816,6 +1937,7 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
     if (psi) std::memcpy(psi, host.data(), n * sizeof(double));
     if (arb_sum) *arb_sum = host[acc_arb(n)];
     if (diag) std::memcpy(diag, host.data() + acc_diag(n), n * sizeof(double));
+    release_landed(ctx);
     return CFMM_OK;
 }
 
@@ -1863,6 +1985,7 @@ int cfmm_eval_smooth(cfmm_ctx *ctx, const double *nu, double mu, double *value, 
 {
     if (!ctx || !nu || !(mu > 0.0)) return ctx ? fail(ctx, CFMM_E_ARG, "eval_smooth: nu is NULL or mu <= 0") : CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pools_ready(ctx);
     const char *why = "";
     if (!newton_supported(ctx, &why)) return fail(ctx, CFMM_E_UNSUPPORTED, "eval_smooth: %s", why);
     const int n = ctx->n;
@@ -1887,6 +2010,8 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
 {
     if (!ctx || !out) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pools_ready(ctx);
+    struct AtExit { cfmm_ctx *c; ~AtExit() { release_landed(c); } } at_exit{ctx};      // (every path out of a solve ends behind a synchronisation)
     cfmm_opts o;
     if (opts_in) o = *opts_in; else cfmm_default_opts(&o);
     if (o.memory == 0) o.memory = ctx->n <= 32 ? 8 : 3;      // auto: tiny problems afford (nearly) full quasi-Newton memory; else 3 (iterate.hpp: ITER_MM)
@@ -2097,6 +2222,7 @@ int cfmm_solve_batch(cfmm_ctx *const *ctxs, int nb, const double *const *nu0, co
     if (!ctxs || nb < 1 || !ctxs[0] || !out) return CFMM_E_ARG;
     cfmm_ctx *c0 = ctxs[0];
     HIP_TRY(c0, hipSetDevice(c0->device));
+    pools_ready(c0);
     const int n = c0->n;
     if (nb > batch_capacity(n)) return fail(c0, CFMM_E_LIMIT, "solve_batch: %d solves, at most %d fit the LDS tile at %d tokens", nb, batch_capacity(n), n);
     cfmm_opts o;
@@ -2227,6 +2353,7 @@ int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda)
 {
     if (!ctx || kind < 0 || kind >= CFMM_POOL_KINDS2) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pools_ready(ctx);
     Bucket2 b = ctx->pools->b2[kind];
     if (kind == CFMM_POOL_SUM2) b.flags = ctx->flags2;
     if (b.m == 0) return CFMM_OK;
@@ -2261,6 +2388,7 @@ int cfmm_get_tradesN(cfmm_ctx *ctx, int k, double *delta, double *lambda)
 {
     if (!ctx || k < 3 || k > CFMM_MAX_POOL_SIZE) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pools_ready(ctx);
     const BucketN &b = ctx->pools->bn[k];
     if (b.m == 0) return CFMM_OK;
     const size_t cnt = (size_t)k * b.m;
@@ -2333,6 +2461,7 @@ int cfmm_debug_eval_limbs(cfmm_ctx *ctx, const double *nu, double ref_reserve, d
 {
     if (!ctx || !nu || !limbs) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pools_ready(ctx);
     const int n = ctx->n;
     if (eval_lds_bytes(n, true, true) > 160 * 1024) return fail(ctx, CFMM_E_LIMIT, "debug_eval_limbs: too many tokens for the reproducible mode");
     for (int j = 0; j < n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "debug_eval_limbs: nu[%d] is not a positive finite price", j);
@@ -2459,6 +2588,7 @@ int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_lau
 {
     if (!ctx || reps < 1 || !sec_per_launch) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pools_ready(ctx);
     if (!ctx->have_nu) return fail(ctx, CFMM_E_STATE, "time_eval_kernel: no prices set");
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, ctx->nu_acc, ctx->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->nu + ctx->n, 0, sizeof(double), ctx->stream));

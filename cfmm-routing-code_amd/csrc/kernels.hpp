@@ -61,6 +61,7 @@ struct Bucket2 {
     long long m;
     const double *Ra, *Rb, *fee, *param;
     const int *ia, *ib, *flags;
+    const int *perm;                  // position -> the caller's pool index (reorder.hpp); null = the caller's order
 };
 
 struct BucketN {
@@ -68,6 +69,7 @@ struct BucketN {
     const int *idx;
     const double *R, *w, *fee;
     const double *lfee;               // log(fee), computed once at upload (+8 B/pool instead of one log per wave-tile)
+    const int *perm;                  // position -> the caller's pool index (reorder.hpp); null = the caller's order
 };
 
 struct EvalArgs {
@@ -602,8 +604,9 @@ trades2_kernel(Bucket2 b, const double *__restrict__ nu, double *__restrict__ de
     else if (KIND == 1) y = pool_w2(Ra, Rb, g, b.param[i], pa, pb);
     else if (KIND == 2) { y = pool_sum2(Ra, Rb, g, pa, pb); if (b.flags && b.flags[i]) { y.ya = 0.0; y.yb = 0.0; } }
     else y = pool_curve2(Ra, Rb, g, b.param[i], pa, pb);
-    delta[i] = fmax(-y.ya, 0.0);  delta[b.m + i] = fmax(-y.yb, 0.0);
-    lambda[i] = fmax(y.ya, 0.0);  lambda[b.m + i] = fmax(y.yb, 0.0);
+    const long long o = b.perm ? b.perm[i] : i;          // (the tenders go out in the caller's pool order)
+    delta[o] = fmax(-y.ya, 0.0);  delta[b.m + o] = fmax(-y.yb, 0.0);
+    lambda[o] = fmax(y.ya, 0.0);  lambda[b.m + o] = fmax(y.yb, 0.0);
 }
 
 template <int K>
@@ -640,10 +643,11 @@ tradesn_kernel(BucketN b, const double *__restrict__ nu, const double *__restric
             }
         }
     }
+    const long long o = b.perm ? b.perm[i] : i;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {                      // results slot-major, as the C-ABI hands them out
-        delta[(size_t)j * b.m + i] = fmax(-y[j], 0.0);
-        lambda[(size_t)j * b.m + i] = fmax(y[j], 0.0);
+    for (int j = 0; j < K; ++j) {                      // results slot-major and in the caller's pool order, as the C-ABI hands them out
+        delta[(size_t)j * b.m + o] = fmax(-y[j], 0.0);
+        lambda[(size_t)j * b.m + o] = fmax(y[j], 0.0);
     }
 }
 

@@ -477,8 +477,9 @@ smooth_trades_kernel(Bucket2 b, const double *__restrict__ nu, const double *__r
             smooth_pool<KIND>(b, i, pa, pb, mu, ab, ba);
             if (slo) { apply_slo(ab, pa, -ab.L1 * pb, slo[ia], slo[ib]); apply_slo(ba, pb, -ba.L1 * pa, slo[ib], slo[ia]); }
         }
-        delta[i] = ab.D;   delta[b.m + i] = ba.D;
-        lambda[i] = ba.L;  lambda[b.m + i] = ab.L;
+        const long long o = b.perm ? b.perm[i] : i;
+        delta[o] = ab.D;   delta[b.m + o] = ba.D;
+        lambda[o] = ba.L;  lambda[b.m + o] = ab.L;
     }
 }
 
