@@ -41,7 +41,13 @@ def attach_oneshot(prob, dist):
     mine = ctx.oneshot_export()
     box = [None] * dist.get_world_size()
     dist.all_gather_object(box, mine)
-    ctx.oneshot_import(dist.get_world_size(), dist.get_rank(), box)
+    try:
+        ctx.oneshot_import(dist.get_world_size(), dist.get_rank(), box)
+    finally:
+        # cfmm_oneshot_attach clears this rank's mailbox once more after the (slow) handle imports: no peer may start an
+        # exchange -- and raise its flag in that mailbox -- before EVERY rank has finished attaching (a rank whose
+        # import failed still meets the others here: the collectives of all ranks stay matched)
+        dist.barrier()
 
 
 def attach_oneshot_checked(prob, dist, evaluations=4, solve_evals=18):
@@ -65,6 +71,7 @@ def attach_oneshot_checked(prob, dist, evaluations=4, solve_evals=18):
     u = prob.utility
     base = np.where(u.c > 0, u.c, 1.0)
     pts = [base * np.exp(0.01 * np.sin(1.0 + k + np.arange(prob.n))) for k in range(evaluations)]
+    prob._send_utility()                         # (cfmm_solve refuses a context without a utility; sharded_problem only uploaded pools)
 
     def run():
         out = [prob.eval_dual(nu) for nu in pts]
@@ -72,9 +79,9 @@ def attach_oneshot_checked(prob, dist, evaluations=4, solve_evals=18):
         nu, psi = ctx.get_solution()
         return out, (st["evals"], st["dual_value"], nu, psi)
 
-    ref, ref_solve = run()                       # RCCL
     ok = True
     try:
+        ref, ref_solve = run()                   # RCCL
         ctx.oneshot_enable(True)
         got, got_solve = run()
         for (f0, p0), (f1, p1) in zip(ref, got):

@@ -462,6 +462,22 @@ class Problem:
         self.utility = utility       # (a new object, or the same object mutated: call this to re-send it)
         self._dev_utility = None
 
+    def _send_utility(self):
+        """the device-side utility is re-sent only when it changed (each call is a synchronisation).  Everything that
+        runs a solve on the raw context (Problem.solve, cfmm.distributed.attach_oneshot_checked) goes through here:
+        cfmm_solve refuses a context that never received a utility (CFMM_E_STATE)."""
+        if self.utility is None:
+            raise ValueError("no utility set")
+        ctx = self._ensure_ctx()
+        u = self.utility
+        if self._dev_utility is not u:
+            if self._host:
+                # the utility is replicated: every rank must hold the same one (checked when it is sent to the device, once
+                # per utility object -- the host-side collectives of a solve are off its steady-state path)
+                self._host.assert_identical(np.concatenate([u.c, u.h, u.ctype.astype(np.float64)]), "the utilities")
+            ctx.set_utility(u.c, u.h, u.ctype)
+            self._dev_utility = u
+
     def init_comm(self, n_ranks, rank, uid):
         """pool-sharding: this process holds one shard; see cfmm.distributed"""
         self._ensure_ctx().comm_init(n_ranks, rank, uid)
@@ -481,14 +497,7 @@ class Problem:
             raise ValueError("no utility set")
         ctx = self._ensure_ctx()
         u = self.utility
-        # device-side utility / tie state is re-sent only when it changed (each call is a synchronisation)
-        if self._dev_utility is not u:
-            if self._host:
-                # the utility is replicated: every rank must hold the same one (checked when it is sent to the device, once
-                # per utility object -- the host-side collectives of a solve are off its steady-state path)
-                self._host.assert_identical(np.concatenate([u.c, u.h, u.ctype.astype(np.float64)]), "the utilities")
-            ctx.set_utility(u.c, u.h, u.ctype)
-            self._dev_utility = u
+        self._send_utility()
         if self._dev_ties:
             ctx.set_ties(None, None)
             if "sum2" in self.net:

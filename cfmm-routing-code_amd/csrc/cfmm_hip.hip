@@ -88,10 +88,14 @@ struct PoolStore {
     // token-block ordering still to be done (reorder.hpp): the arena's column bytes, 0 = nothing pending.  Done lazily, in
     // front of the first kernel that reads the pools, so that the uploads' copies are not queued behind sort kernels
     size_t ro2[CFMM_POOL_KINDS2] = {}, ron[CFMM_MAX_POOL_SIZE + 1] = {};
-    std::vector<void *> landed;                    // landing arenas whose permuted copies have been enqueued: freed by release_landed
+    // landing arenas whose permuted copies have been enqueued, with the stream they were enqueued on: freed by release_landed
+    // of the SAME context behind its own synchronisation.  A context and its clones share this store and may be driven from
+    // different host threads (Problem.solve_many): `mu` guards landed and the pending flags ro2 / ron.
+    std::vector<std::pair<void *, hipStream_t>> landed;
+    std::mutex mu;
     ~PoolStore()
     {
-        for (void *q : landed) (void)hipFree(q);
+        for (auto &q : landed) (void)hipFree(q.first);
         for (void *q : b2mem) if (q) (void)hipFree(q);
         for (void *q : bnmem) if (q) (void)hipFree(q);
     }
@@ -467,7 +471,7 @@ void parallel_fill(const Col &c, char *out, size_t off, size_t len)
     });
 }
 // returns CFMM_E_ARG (no message set) when a fill flagged bad data: the caller describes what is wrong
-int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const UploadScan *scan = nullptr, int64_t reorder_m = 0, size_t *total_out = nullptr)
+int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const UploadScan *scan = nullptr, size_t *total_out = nullptr)
 {
     size_t total = 0;
     std::vector<size_t> offs;
@@ -477,7 +481,6 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const 
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto tA = now();
-    (void)reorder_m;
     HIP_TRY(ctx, hipMalloc((void **)&base, total + 256));
     if (total_out) *total_out = total;
     const auto tB = now();
@@ -1516,6 +1519,7 @@ int cfmm_clone(cfmm_ctx *src, cfmm_ctx **out)
     HIP_TRY(src, hipSetDevice(src->device));
     pools_ready(src);
     HIP_TRY(src, hipStreamSynchronize(src->stream));         // (the pools the clone will read may still be arriving)
+    release_landed(src);                                     // (behind that synchronisation: clones never see a non-empty landing list)
     cfmm_ctx *c = nullptr;
     int rc = cfmm_create(src->device, src->n, &c);
     if (rc) { src->err = g_create_error; return rc; }
@@ -1627,6 +1631,7 @@ static bool reorder_bucketN(cfmm_ctx *ctx, int k, BucketN &b, void **arena, size
 static void pools_ready(cfmm_ctx *ctx)
 {
     PoolStore &ps = *ctx->pools;
+    std::lock_guard<std::mutex> guard(ps.mu);
     {   // Is there anything to gain?  A K-asset pool localises two of its K legs; the other K - 2 land anywhere, and once a
         // workgroup's share of those stray legs is of the order of the token count its psi tile is dense whatever the order of
         // the two-asset pools (C3: 1e5 K-asset pools, ~1400 stray legs per workgroup over 1000 tokens: the ordering bought
@@ -1645,12 +1650,12 @@ static void pools_ready(cfmm_ctx *ctx)
     }
     for (int k = 0; k < CFMM_POOL_KINDS2; ++k) if (ps.ro2[k]) {
         void *old = ps.b2mem[k];
-        if (reorder_bucket2(ctx, ps.b2[k], &ps.b2mem[k], ps.ro2[k])) ps.landed.push_back(old);
+        if (reorder_bucket2(ctx, ps.b2[k], &ps.b2mem[k], ps.ro2[k])) ps.landed.emplace_back(old, ctx->stream);
         ps.ro2[k] = 0;
     }
     for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) if (ps.ron[k]) {
         void *old = ps.bnmem[k];
-        if (reorder_bucketN(ctx, k, ps.bn[k], &ps.bnmem[k], ps.ron[k])) ps.landed.push_back(old);
+        if (reorder_bucketN(ctx, k, ps.bn[k], &ps.bnmem[k], ps.ron[k])) ps.landed.emplace_back(old, ctx->stream);
         ps.ron[k] = 0;
     }
 }
@@ -1660,8 +1665,14 @@ static void pools_ready(cfmm_ctx *ctx)
 static void release_landed(cfmm_ctx *ctx)
 {
     PoolStore &ps = *ctx->pools;
-    for (void *q : ps.landed) (void)hipFree(q);
-    ps.landed.clear();
+    std::vector<void *> mine;                      // (only what THIS context's stream permuted: a clone's synchronisation says nothing
+    {                                              //  about copies another context enqueued; freed outside the lock)
+        std::lock_guard<std::mutex> guard(ps.mu);
+        size_t keep = 0;
+        for (auto &q : ps.landed) { if (q.second == ctx->stream) mine.push_back(q.first); else ps.landed[keep++] = q; }
+        ps.landed.resize(keep);
+    }
+    for (void *q : mine) (void)hipFree(q);
 }
 
 int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, const double *Rb, const double *fee,
@@ -1711,7 +1722,7 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
         }
         size_t total = 0;
         const bool ro = reorder_applies(ctx, kind, m);
-        int rc = upload_arena(ctx, cols, &arena, &scan, ro ? m : 0, &total);
+        int rc = upload_arena(ctx, cols, &arena, &scan, &total);
         if (rc == CFMM_E_ARG && scan.bad.load()) {
             // something failed its check: find the first offender for the message (the slow path)
             for (int64_t i = 0; i < m; ++i) {
@@ -1772,7 +1783,7 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
         }
         size_t total = 0;
         const bool ro = reorder_applies(ctx, k, m);
-        int rc = upload_arena(ctx, cols, &arena, &scan, ro ? m : 0, &total);
+        int rc = upload_arena(ctx, cols, &arena, &scan, &total);
         if (rc == CFMM_E_ARG && scan.bad.load()) {
             for (int64_t i = 0; i < (int64_t)k * m; ++i)
                 if (idx[i] < 0 || idx[i] >= ctx->n) return fail(ctx, CFMM_E_ARG, "upload_poolsN: token id %d outside [0,%d)", idx[i], ctx->n);
@@ -2223,6 +2234,8 @@ int cfmm_solve_batch(cfmm_ctx *const *ctxs, int nb, const double *const *nu0, co
     cfmm_ctx *c0 = ctxs[0];
     HIP_TRY(c0, hipSetDevice(c0->device));
     pools_ready(c0);
+    struct AtExit { cfmm_ctx *c; ~AtExit() { release_landed(c); } } at_exit{c0};      // (as cfmm_solve: every path out ends behind a synchronisation,
+                                                                                       //  or before anything read the pools)
     const int n = c0->n;
     if (nb > batch_capacity(n)) return fail(c0, CFMM_E_LIMIT, "solve_batch: %d solves, at most %d fit the LDS tile at %d tokens", nb, batch_capacity(n), n);
     cfmm_opts o;

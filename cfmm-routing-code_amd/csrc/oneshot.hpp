@@ -9,6 +9,7 @@
 //
 //   mailbox of a rank (device memory, exported to the peers with hipIpcGetMemHandle, one process per GPU):
 //       flag[2][ONESHOT_MAX_RANKS]            epoch of the last vector rank r delivered into parity slot p
+//       poison                                non-zero: some rank's wait has expired (sticky, see below)
 //       slot[2][ONESHOT_MAX_RANKS][cap]       the vectors, 8-byte elements
 //   Two parity slots: a rank can run at most one all-reduce ahead of a peer (it needs the peer's vector of epoch e + 1
 //   to finish e + 1, and the peer sends that only after it has finished reading epoch e), so epoch e + 1 never lands on
@@ -17,7 +18,10 @@
 // system-scope fence between payload and flag: nothing of it may linger in an L2 that the other GPU cannot see.
 // One workgroup per rank: the kernels of all ranks must be running at the same time for the exchange to complete, and one
 // workgroup per GPU always is.  The spin is bounded; on expiry the result is poisoned with NaN (the solve then ends with
-// CFMM_E_NUMERIC instead of hanging).
+// CFMM_E_NUMERIC instead of hanging) AND the expiry is published: the rank raises the poison word in EVERY mailbox, every
+// later exchange of every rank -- and every wait in progress -- sees it and returns NaN too, so a rank skew beyond the
+// bound ends as one collective error on all ranks instead of one rank failing while its peers carry on with valid data
+// and hang on the next exchange.  The poison stays until the mailboxes are attached again.
 //
 // RCCL stays the default and the checker (CFMM_ALLREDUCE=oneshot, or cfmm_oneshot_import, selects this path).
 #pragma once
@@ -29,7 +33,8 @@ constexpr int ONESHOT_MAX_RANKS = 16;
 constexpr int ONESHOT_THREADS = 1024;
 enum { ONESHOT_SUM_F64 = 0, ONESHOT_SUM_I64 = 1, ONESHOT_MAX_F64 = 2 };
 
-__host__ __device__ inline size_t oneshot_flag_words() { return 2 * ONESHOT_MAX_RANKS; }
+__host__ __device__ inline size_t oneshot_flag_words() { return 2 * ONESHOT_MAX_RANKS + 8; }     // flags | poison word (+ padding: slots stay 64-byte aligned)
+__host__ __device__ inline size_t oneshot_poison_word() { return 2 * ONESHOT_MAX_RANKS; }
 __host__ __device__ inline size_t oneshot_bytes(size_t cap) { return (oneshot_flag_words() + 2 * (size_t)ONESHOT_MAX_RANKS * cap) * 8; }
 // (+ one private word behind the mailbox: the rank's epoch counter)
 __host__ __device__ inline size_t oneshot_alloc_bytes(size_t cap) { return oneshot_bytes(cap) + 64; }
@@ -79,13 +84,17 @@ oneshot_allreduce_kernel(OneShotArgs a)
     __syncthreads();
     if (tid < R) {
         const unsigned long long *f = a.mail[a.rank] + par * ONESHOT_MAX_RANKS + tid;
+        const unsigned long long *poison = a.mail[a.rank] + oneshot_poison_word();
         long spins = 0;
         while (sys_load(f) != epoch) {
             __builtin_amdgcn_s_sleep(2);
+            if ((spins & 1023) == 1023 && sys_load(poison) != 0) { ok = 0; break; }     // another rank has given up: fail with it
             if (++spins > (1L << 26)) { ok = 0; break; }   // (~ seconds: a peer has died)
         }
+        if (sys_load(poison) != 0) ok = 0;                 // (sticky: an exchange behind a failed one fails on every rank)
     }
     __syncthreads();
+    if (!ok && tid < R) sys_store(a.mail[tid] + oneshot_poison_word(), 1ull);        // publish the expiry to every rank (own mailbox included)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     // 3. reduce in rank order: the same bits on every rank
     const unsigned long long *mine = a.mail[a.rank] + oneshot_flag_words() + (size_t)par * ONESHOT_MAX_RANKS * a.cap;

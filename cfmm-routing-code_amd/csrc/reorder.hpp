@@ -10,8 +10,10 @@
 // A counting sort with 256 keys: histogram, exclusive scan, scatter (workgroup-local ranks through LDS, one global
 // reservation per workgroup and key).  The order INSIDE a key is whatever the reservations make it -- it carries no
 // meaning (psi is a sum) -- and perm[position] = original index lets the tenders go back out in the caller's order.
-// The pools land in the first half of their arena and are permuted into the second (cfmm_hip.hip: the arena is allocated
-// twice the size; no second allocation, nothing to free while copies are in flight).
+// The sort runs lazily, in front of the first kernel that reads the pools (cfmm_hip.hip: pools_ready), from the arena
+// the upload landed the columns in into a NEW arena (+ the permutation, + the 256 counters); the landing arena is freed
+// by release_landed of the same context, behind that entry point's own synchronisation.  A context and its clones share
+// the pool store: its landing list and pending flags are guarded by PoolStore::mu.
 #pragma once
 #include "kernels.hpp"
 

@@ -58,7 +58,14 @@ class OracleContext:
     def eval_dual(self, nu, want_diag=False):
         return self._build().eval(nu, want_diag)
 
+    def _need_utility(self):
+        # as libcfmm_hip.so: cfmm_solve on a context that never received a utility is CFMM_E_STATE (cfmm_hip.hip: cfmm_solve)
+        if self.util is None:
+            from cfmm._lib import CfmmError
+            raise CfmmError("cfmm_solve: cfmm_set_utility has not been called")
+
     def solve(self, nu0=None, tol=1e-6, max_evals=2000, memory=0, iters_per_graph=8, pg_rule=0, **kw):
+        self._need_utility()
         o = self._build()
         r = o.solve(nu0 if nu0 is not None else self._nu, tol=tol, max_evals=max_evals, memory=memory, pg_rule=pg_rule)
         self._nu, self._psi = r["nu"], r["psi"]
@@ -123,6 +130,7 @@ class ShardedOracleContext(OracleContext):
         return (buf[n], buf[:n].copy(), buf[n + 1:].copy()) if want_diag else (buf[n], buf[:n].copy())
 
     def solve(self, nu0=None, tol=1e-6, max_evals=2000, memory=0, iters_per_graph=8, pg_rule=0, **kw):
+        self._need_utility()
         o = self._build()
         nu0 = nu0 if nu0 is not None else self._nu
         self.start_prices.append(np.array(nu0, dtype=np.float64))
