@@ -131,6 +131,7 @@ struct cfmm_ctx {
     double *hnu0 = nullptr;           // pinned [n]: staging of cfmm_set_nu
     bool hsol_valid = false;
     hipEvent_t ev[2] = {nullptr, nullptr}, ev_t0 = nullptr, ev_t1 = nullptr;
+    int walk_parity[2] = {0, 0};       // direction of the next evaluation launch's tile walk (launch_eval), per tile space
     int nslices = 2;                   // accumulator slices the workgroups flush into (blockIdx % nslices): flat from 2 upward for the flush, and every slice is one more vector the in-launch update of EVERY workgroup reads (27.4 vs 28.4 us per iteration at 2 vs 4, C3)
     int eval_grid_mult = 1;
     int eval_blocks_per_cu = 1;        // resident EVAL_THREADS-workgroups per CU (occupancy query at create)
@@ -155,7 +156,7 @@ struct cfmm_ctx {
     double g_max_reserve = 0.0;        // ... and over all ranks
     double nu_max = 1.0;               // largest price last handed in (scales the diagonal metric's limbs)
     double det_ref_reserve = 0.0, det_ref_fee = 0.0;   // (test hook) exponent reference instead of this context's own maxima
-    double *acc3 = nullptr, *xs3 = nullptr, *S5 = nullptr, *Y5 = nullptr, *rho5 = nullptr;
+    double *acc3 = nullptr, *xs3 = nullptr;
     DevState *st3 = nullptr;
     DevState *hst3 = nullptr;          // pinned [2][3]
     int iter_blocks_per_cu = 1;
@@ -672,11 +673,29 @@ void eval_geometry(cfmm_ctx *ctx, int ntiles, int &grid, int &threads)
     if (grid < 1) grid = 1;
 }
 
-template <bool WITH_D, bool STABLE>
-void launch_eval(cfmm_ctx *ctx, const EvalArgs &a, hipStream_t stream = nullptr)
+// ping-pong walk (kernels.hpp: eval_tiles_and_flush): consecutive launches over the same tile space walk it in opposite
+// directions, so that a launch starts on what its predecessor left in the L2s and the Infinity Cache
+// Taken where the two-asset buckets make up (nearly) all the bytes: their tiles cost the same, so the order of the walk is
+// free.  With many K-asset pools (C3: half the wave-tiles) the walk stays heaviest-first in every launch -- backwards the
+// K-asset tiles would end up in the tail, where uneven tiles cost most, and measured there was nothing to gain (C3's 43 MB
+// are Infinity-Cache resident and its tile phase is issue-bound: 21.68 us per iteration either way).
+static bool pingpong_on(const cfmm_ctx *ctx)
 {
-    if (a.ntiles == 0) return;
+    static const int mode = getenv("CFMM_PINGPONG") ? atoi(getenv("CFMM_PINGPONG")) : -1;      // (A/B: 0 never, 1 always)
+    if (mode >= 0) return mode != 0;
+    double b2 = 0.0, bn = 0.0;
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) b2 += (double)ctx->pools->b2[k].m * ((k == CFMM_POOL_W2 || k == CFMM_POOL_CURVE2) ? 40.0 : 32.0);
+    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) bn += (double)ctx->pools->bn[k].m * (20.0 + 20.0 * k);
+    return bn <= 0.1 * (b2 + bn);
+}
+
+template <bool WITH_D, bool STABLE>
+void launch_eval(cfmm_ctx *ctx, const EvalArgs &a_in, hipStream_t stream = nullptr)
+{
+    if (a_in.ntiles == 0) return;
     if (!stream) stream = ctx->stream;
+    EvalArgs a = a_in;
+    if (pingpong_on(ctx)) { a.rev = ctx->walk_parity[STABLE ? 1 : 0] & 1; ctx->walk_parity[STABLE ? 1 : 0] ^= 1; }
     int grid, threads;
     eval_geometry(ctx, a.ntiles, grid, threads);
     if (ctx->det) hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE, true>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D, true), stream, a);
@@ -808,7 +827,6 @@ IterArgs make_iter_args(cfmm_ctx *ctx, const cfmm_opts &o)
     a.acc3 = ctx->acc3; a.acc_set = (long long)acc_set_doubles(ctx);
     a.xs = ctx->xs3; a.xs_set = (long long)XS_VECS * a.xvs;
     a.st3 = ctx->st3;
-    a.S = ctx->S5; a.Y = ctx->Y5; a.rho = ctx->rho5;
     a.c = ctx->c; a.h = ctx->h; a.glo = ctx->glo; a.ghi = ctx->ghi; a.ctype = ctx->ctype;
     a.Ds = ctx->Ds;
     a.nu = ctx->nu; a.nu_acc = ctx->nu_acc; a.psi_acc = ctx->psi_acc;
@@ -830,6 +848,7 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
 {
     IterArgs a = base;
     a.phase = t % 3;
+    a.ev.rev = pingpong_on(ctx) ? (t & 1) : 0;
     const int n = ctx->n, E = (n <= EVAL_THREADS && ITER_E_SMALL == 1) ? 1 : 2;
     int grid, threads;
     {
@@ -1455,8 +1474,6 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
         want(&ctx->st, 1);
         want(&ctx->acc3, 3 * (size_t)ctx->nslices * acc_stride(n) + 4);
         want(&ctx->xs3, 3 * (size_t)XS_VECS * iter_xvs(n) + 4);
-        want(&ctx->S5, (size_t)ITER_RING * hist_stride(n) + 4); want(&ctx->Y5, (size_t)ITER_RING * hist_stride(n) + 4);
-        want(&ctx->rho5, ITER_RING + 3);
         want(&ctx->st3, 3);
         want(&ctx->acc_l, 6 * (size_t)n + 4);
         want(&ctx->ts, 64 + 8 * 4096 + 2048);
@@ -2316,7 +2333,9 @@ int cfmm_solve_batch(cfmm_ctx *const *ctxs, int nb, const double *const *nu0, co
             if (!running) break;
             if (t > o.max_evals + 1) { HIP_TRY(c0, hipStreamSynchronize(stream)); break; }      // the device ends every solve at its budget (status 3)
             if (t - done <= c0->run_ahead) {
-                hipLaunchKernelGGL(eval_batch_kernel, dim3(egrid), dim3(ethreads), elds, stream, ea, bt);
+                EvalArgs eb = ea;
+                eb.rev = pingpong_on(c0) ? (t & 1) : 0;
+                hipLaunchKernelGGL(eval_batch_kernel, dim3(egrid), dim3(ethreads), elds, stream, eb, bt);
                 launch_update_batch();
                 ++t; spins = 0;
                 continue;

@@ -38,12 +38,12 @@ constexpr int ITER_E_SMALL = ITER_E_SMALL_DEF;  // variables per thread of the i
 // reduce-scatter, two vectors less to load in every workgroup
 constexpr int ITER_MM = 3;                  // history pairs kept by the in-launch update
 constexpr int ITER_P = ITER_MM + 1;         // + the new pair
-constexpr int ITER_RING = ITER_MM + 1;      // physical history slots (window ITER_MM)
 // layout of the batched scalars (8 + 2 P + P (P - 1) / 2 + P (P + 1) / 2 = 32 for P = 4)
 constexpr int GI_U = 8, GI_V = GI_U + ITER_P, GI_SY = GI_V + ITER_P, GI_YHY = GI_SY + ITER_P * (ITER_P - 1) / 2,
               GI_END = GI_YHY + ITER_P * (ITER_P + 1) / 2;
 static_assert(GI_END <= 32, "the batch must fit one 32-value reduce-scatter");
-constexpr int XS_VECS = 5;                  // s | s_t | Gs | d | trial prices, per state set
+constexpr int XS_HIST = 5;                  // s | s_t | Gs | d | trial prices | S window (ITER_MM, newest first) | Y window, per state set
+constexpr int XS_VECS = XS_HIST + 2 * ITER_MM;
 __host__ __device__ inline int iter_xvs(int n) { return (n + 3) & ~1; }      // vector stride of a state set: >= n + 2 (the stop flag rides at [n]), even
 
 struct IterArgs {
@@ -55,7 +55,6 @@ struct IterArgs {
     double *acc3; long long acc_set;        // 3 sets of nslices * acc_stride(n) doubles
     double *xs; long long xs_set;           // 3 sets of XS_VECS * xvs doubles
     DevState *st3;                          // 3 sets
-    double *S, *Y, *rho;                    // rings of ITER_RING slots (row stride hist_stride(n))
     const double *c, *h, *glo, *ghi;
     const int *ctype;
     double *Ds;
@@ -83,6 +82,14 @@ template <int E> __device__ __forceinline__ void stE(double *p, int first, int l
 {
     if (E == 2 && first + 1 < len) { *reinterpret_cast<double2 *>(p + first) = make_double2(v[0], v[E - 1]); return; }
     if (first < len) p[first] = v[0];
+}
+
+// store E adjacent doubles at `first` < n into a vector of a state set: its stride (iter_xvs) leaves room behind element
+// n - 1, so the store is always whole (no tail variants: lanes beyond the end hold zeros)
+template <int E> __device__ __forceinline__ void stX(double *p, int first, const double (&v)[E])
+{
+    if (E == 2) *reinterpret_cast<double2 *>(p + first) = make_double2(v[0], v[E - 1]);
+    else p[first] = v[0];
 }
 
 // what one thread contributes to the batched scalars:
@@ -220,12 +227,24 @@ __host__ __device__ inline int iter_extra_lds_doubles(int n) { return 4 * iter_x
 
 // PLAIN: the utility has h == 0, every token CFMM_GE and no upper bounds (linear-utility arbitrage, arbitrage.py:57,77):
 // three of the update's vectors are never read and their registers do not exist (the other instantiation spills a few)
+//
+// Round 3: the update as a LATENCY CHAIN.  Measured (phase timers, C3): its ~8 us were not arithmetic but (i) two
+// dependent global round trips (state record -> history ring slots / rho, addressed through the ring head), (ii) a scalar
+// section of ~650 instructions issued by EVERY wave with variables (2 per SIMD at 1000 tokens, 4 at 2000: 14 us there),
+// (iii) waves without variables executing the direction / reduction code on zeros beside the ones that had work, (iv)
+// five barriers.  Now: the history window travels in the rotating state set in WINDOW ORDER and its rho's in the state
+// record, so every load address depends on the rotation phase alone and all loads go out at once; ONE wave runs the scalar
+// section and hands ten numbers over through LDS; waves without variables only meet the others at the barriers (one of
+// them lays out the tile-range table meanwhile); the next trial point is computed speculatively at step 1 under the
+// direction's reduction; every thread recycles its OWN stash entries (trial point -> price, trial gradient -> zeroed psi
+// entry), which merges the last two barriers into one.
 template <int E, bool DET = false, bool PLAIN = false>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 iter_kernel(IterArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int MM = ITER_MM, P = ITER_P, RS = ITER_RING;
+    constexpr int MM = ITER_MM, P = ITER_P;
+    static_assert(MM == 3, "DevState::rhow holds a window of 3");
     const int n = a.n, M = a.M;
     const int tid = threadIdx.x, lane = tid & 63, wave = uni((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     // LDS carve of eval_kernel<false, .>; the update borrows the waves' exchange strips (16 KB, free until the tile loop)
@@ -239,35 +258,53 @@ iter_kernel(IterArgs a)
     double *xw = strips;                                 // [16][32] per-wave sums
     double *xm = xw + 16 * 32;                           // [16][2] maxima
     BlockRed red(xm + 32);                               // [2][12][16]
+    double *ctl = xm + 32 + 2 * BlockRed::NRED * 16;     // [2 P + 2] what the scalar section hands to the other waves: alpha | gamma | step | sum |pg|
+    int *ctli = reinterpret_cast<int *>(ctl + 2 * ITER_P + 2);       // [4] accept | new direction | status | pair accepted
     double *gst_s = psi_s;                               // [n] trial gradient, stashed between the two halves of the update
     double *sts_s = nu_s;                                // [n] trial point, likewise (the prices are written at the very end)
     double *glo_s = strips + 2 * 64 * (EVAL_THREADS / 64);   // [xvs] lower bounds | [xvs] upper bounds
     double *ghi_s = glo_s + a.xvs;
     double *psi_k = ghi_s + a.xvs, *nu_k = psi_k + a.xvs;    // workgroup 0 only
 
-    PHASE_STAMP(a.ev.ts, 16);
+#ifdef CFMM_PHASE_TIMERS
+    const long long ts_c16 = clock64(), ts_w16 = wall_clock64();     // (stored only by launches that go on to evaluate: the idle ones behind the end of a solve must not overwrite them)
+#endif
     const int p = a.phase, pr = (p + 2) % 3, pz = (p + 1) % 3;
-    const int hs = hist_stride(n), stride = acc_stride(n), xvs = a.xvs;
+    const int stride = acc_stride(n), xvs = a.xvs;
     const double *Xr = a.xs + (size_t)pr * a.xs_set;
     double *Xw = a.xs + (size_t)p * a.xs_set;
     const double *Ar = a.acc3 + (size_t)pr * a.acc_set;
-    const bool wr = blockIdx.x == 0;                     // the one workgroup that stores the new state
-    const int nS = wr ? n : 0;
+    // Every workgroup computes the same new state; WHO stores which piece of it is spread over the first workgroups, one
+    // vector each (workgroup 0 alone storing all sixteen -- state set, history window, accepted point -- ran 1-1.6 us behind
+    // the others, and a launch ends with its slowest workgroup).  Role r is taken by workgroup r % gridDim.
+    enum { R_STATE = 0, R_S = 0, R_ST = 1, R_GS = 2, R_D = 3, R_NU = 4, R_SW = 5, R_YW = 5 + ITER_MM, R_PSI_ACC = 5 + 2 * ITER_MM, R_NU_ACC, R_DS };
+    const bool wide = gridDim.x > R_DS;                  // (the usual case: no division on the way)
+    const bool has_role = !wide || blockIdx.x <= R_DS;   // (all other workgroups pass every store site on ONE test)
+    auto mine = [&](int role) { return wide ? blockIdx.x == (unsigned)role : blockIdx.x == (unsigned)role % gridDim.x; };
+    const bool wr = mine(R_STATE);                       // the workgroup that stores the state record, the prices and the progress word
     const int r0 = tid * E;
     const int ld0 = (r0 < n) ? r0 : 0;                   // threads past the end load element 0 and are masked out
     bool tin[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) tin[e] = r0 + e < n;
-    // Waves that own no variable skip the update's vector work altogether (wave-uniform branch) and only meet the
-    // others at the barriers: every scalar section below is executed by every wave of a SIMD in turn, so the fewer
-    // waves carry variables the shorter it gets (E = 2: 8 waves at 1000 tokens)
+    // Waves that own no variable take no part in the update's vector work (wave-uniform branches): they only meet the
+    // others at the barriers (E = 2: 8 of 16 waves carry variables at 1000 tokens)
     const bool wave_active = wave * 64 * E < n;
-    // the loads whose addresses the rotation phase alone determines go out BEFORE the solver state is waited for (one
-    // dependent memory round trip less on the chain: state -> history slots -> products)
+    const int nwa = (n + 64 * E - 1) / (64 * E);         // waves with variables: the first nwa
+    red.nw = nwa;
+    // EVERY load of the update goes out here, before the solver state is waited for: all addresses follow from the rotation
+    // phase (the history window is stored in window order with the state set; which of its pairs count -- st.hist -- is
+    // needed only when they are used)
+    GramIn<E> in;
     double s[E], s_t[E], Gs[E], nuj[E], Ds[E], glo[E], ghi[E], hj[E], cj[E], psi[E];
     int ct[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) { s[e] = s_t[e] = Gs[e] = nuj[e] = Ds[e] = glo[e] = cj[e] = 0.0; psi[e] = 0.0; ghi[e] = __builtin_inf(); hj[e] = 0.0; ct[e] = 0; }
+    for (int e = 0; e < E; ++e) {
+        s[e] = s_t[e] = Gs[e] = nuj[e] = Ds[e] = glo[e] = cj[e] = 0.0; psi[e] = 0.0; ghi[e] = __builtin_inf(); hj[e] = 0.0; ct[e] = 0;
+        in.q0[e] = in.H0[e] = in.hq[e] = 0.0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) { in.S[k][e] = 0.0; in.Y[k][e] = 0.0; }
+    }
     if (wave_active) {
         ldE<E>(Xr, ld0, s); ldE<E>(Xr + xvs, ld0, s_t); ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 4 * xvs, ld0, nuj);
         ldE<E>(a.Ds, ld0, Ds); ldE<E>(a.glo, ld0, glo); ldE<E>(a.c, ld0, cj);
@@ -278,15 +315,25 @@ iter_kernel(IterArgs a)
 #pragma unroll
             for (int e = 0; e < E; ++e) psi[e] += t1[e];
         }
+#pragma unroll
+        for (int k = 0; k < MM; ++k) {                   // stored pairs, newest first, at in.S[k + 1]
+            ldE<E>(Xr + (size_t)(XS_HIST + k) * xvs, ld0, in.S[k + 1]);
+            ldE<E>(Xr + (size_t)(XS_HIST + MM + k) * xvs, ld0, in.Y[k + 1]);
+        }
     }
+    if (DET) for (int j = n + tid; j < tile; j += blockDim.x) psi_s[j] = 0.0;      // (limbs behind the stash: entries [0, n) are recycled by their owners below)
     DevState st = a.st3[pr];
     if (st.status != 0) {                                // the solve has ended: every workgroup of every later launch leaves here;
         if (blockIdx.x == 0 && tid == 0) a.st3[p] = st;  // the final state is handed on, or the launch after next would read a set
         return;                                          // from before the end (status 0) and resume from stale state
     }
-    st.evals = uni(st.evals); st.iters = uni(st.iters); st.first = uni(st.first); st.hist = uni(st.hist); st.head = uni(st.head);
+    st.evals = uni(st.evals); st.iters = uni(st.iters); st.first = uni(st.first); st.hist = uni(st.hist);
     st.nrej = uni(st.nrej); st.f = uni(st.f); st.t_step = uni(st.t_step);
-    PHASE_STAMP(a.ev.ts, 17);
+    // (tuning builds: only launches that go on to evaluate leave stamps, so that all of them come from ONE launch -- the
+    //  budget-limited solves of tools/microbench.py end on the evaluation count)
+    long long *const tsb = (st.evals + 1 < a.max_evals) ? a.ev.ts : nullptr;
+    (void)tsb;
+    PHASE_STAMP(tsb, 17);
 
     // the set the NEXT launch flushes into was last read one launch ago: one workgroup clears it now
     if (blockIdx.x == gridDim.x - 1) {
@@ -294,31 +341,19 @@ iter_kernel(IterArgs a)
         const int len = a.ev.nslices * stride;
         for (int j = tid; j < len; j += blockDim.x) Z[j] = 0.0;
     }
-    double rho[P];
-    rho[0] = 0.0;
-#pragma unroll
-    for (int k = 0; k < MM; ++k) {                       // (every wave runs the scalar recursion: every wave needs the rho's)
-        const bool have = k < st.hist;
-        rho[k + 1] = have ? uni(a.rho[(st.head - 1 - k + 2 * RS) % RS]) : 0.0;
-    }
 
     // ================= first half: everything that feeds the batched reduction.  Its inputs (state, bounds,
-    // accumulators: ~20 registers per variable) die here; the second half reloads the few it needs ================
-    GramIn<E> in;
+    // accumulators: ~20 registers per variable) die here; the second half takes the few it needs from an LDS stash ========
     bool act[E];
-    double mx[2] = {0.0, 0.0};
-    double qa = 0.0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        act[e] = true; in.q0[e] = in.H0[e] = in.hq[e] = 0.0;
-#pragma unroll
-        for (int k = 0; k < P; ++k) { in.S[k][e] = 0.0; in.Y[k][e] = 0.0; }
-    }
+    for (int e = 0; e < E; ++e) act[e] = true;
+    const bool keeps_acc = has_role && (mine(R_PSI_ACC) || mine(R_NU_ACC));
     if (wave_active) {
-        double dg[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) dg[e] = 0.0;
+        double mx[2] = {0.0, 0.0};
         if (st.first) {                                  // first update of a solve: the diagonal metric rides along
+            double dg[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) dg[e] = 0.0;
             for (int sl = 0; sl < a.nread; ++sl) {
                 double t2[E];
                 ldE<E>(Ar + (size_t)sl * stride + acc_diag(n), ld0, t2);
@@ -327,15 +362,13 @@ iter_kernel(IterArgs a)
             }
 #pragma unroll
             for (int e = 0; e < E; ++e) Ds[e] = dg[e];
-            if (r0 < n) stE<E>(a.Ds, r0, nS, Ds);        // (the first trial point is always accepted)
+            if (has_role && r0 < n && mine(R_DS)) stE<E>(a.Ds, r0, n, Ds);      // (the first trial point is always accepted)
         }
 #pragma unroll
-        for (int k = 0; k < MM; ++k) {                   // stored pairs, newest first, at in.S[k + 1]
+        for (int k = 0; k < MM; ++k) {                   // (pairs beyond the window's fill, lanes beyond the end: zero)
             const bool have = k < st.hist;
-            const int slot = have ? (st.head - 1 - k + 2 * RS) % RS : 0;
-            if (have) { ldE<E>(a.S + (size_t)slot * hs, ld0, in.S[k + 1]); ldE<E>(a.Y + (size_t)slot * hs, ld0, in.Y[k + 1]); }
 #pragma unroll
-            for (int e = 0; e < E; ++e) if (!tin[e]) { in.S[k + 1][e] = 0.0; in.Y[k + 1][e] = 0.0; }
+            for (int e = 0; e < E; ++e) if (!have || !tin[e]) { in.S[k + 1][e] = 0.0; in.Y[k + 1][e] = 0.0; }
         }
         double fpools = 0.0;
         if (tid < a.nread) fpools = Ar[(size_t)tid * stride + acc_arb(n)];
@@ -373,111 +406,142 @@ iter_kernel(IterArgs a)
                 gst_s[r0 + e] = Gs_t[e];
                 sts_s[r0 + e] = s_t[e]; glo_s[r0 + e] = glo[e];
                 if (!PLAIN) ghi_s[r0 + e] = ghi[e];
-                if (wr) { psi_k[r0 + e] = psi[e]; nu_k[r0 + e] = nuj[e]; }
+                if (keeps_acc) { psi_k[r0 + e] = psi[e]; nu_k[r0 + e] = nuj[e]; }
             }
         }
-        PHASE_STAMP(a.ev.ts, 18);
-        qa = gram_reduce32<E>(in, lane);
-        PHASE_STAMP(a.ev.ts, 19);
+        PHASE_STAMP(tsb, 18);
+        const double qa = gram_reduce32<E>(in, lane);
+        PHASE_STAMP(tsb, 19);
         mx[0] = wave_allmax(mx[0]); mx[1] = wave_allmax(mx[1]);
+        if (lane < 32) xw[wave * 32 + lane] = qa;
+        if (lane == 0) { xm[wave * 2] = mx[0]; xm[wave * 2 + 1] = mx[1]; }
     }
-    if (lane < 32) xw[wave * 32 + lane] = qa;
-    if (lane == 0) { xm[wave * 2] = mx[0]; xm[wave * 2 + 1] = mx[1]; }
+    // (the last wave -- one without variables up to 960 tokens -- lays out the workgroup's tile ranges meanwhile: the tile
+    //  loop starts without a table-building prologue and its two barriers)
+    if (wave == nw - 1) build_tile_table(a.ev, next_tile, lane);
     __syncthreads();
-    // every wave sums the per-wave rows itself: lane l ends with total l, and the scalar sections below fetch a total
-    // with two v_readlane (into SGPRs: no second barrier, no LDS broadcast round trips on the dependent chain)
-    double tl = 0.0;
-    if (lane < 32) for (int w = 0; w < nw; ++w) tl += xw[w * 32 + lane];
-    const int tl_lo = __double2loint(tl), tl_hi = __double2hiint(tl);
-    auto T = [&](int i) { return __hiloint2double(__builtin_amdgcn_readlane(tl_hi, i), __builtin_amdgcn_readlane(tl_lo, i)); };
-    PHASE_STAMP(a.ev.ts, 20);
-    double viol = 0.0, scale = 0.0;
-    for (int w = 0; w < nw; ++w) { viol = fmax(viol, xm[w * 2]); scale = fmax(scale, xm[w * 2 + 1]); }
-    const double f_t = T(0), gapv = T(1);
     st.evals += 1;
 
-    // ---- accept test --------------------------------------------------------------------------------------------
-    bool accept = st.first != 0;
-    if (!st.first)
-        accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * T(2)) ||
-                                  (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && T(3) <= 0.8 * fabs(T(2))));
-    bool new_dir = false;
+    // ================= the scalar section: accept test, curvature pair, stopping rule, two-loop recursion.  ONE wave runs
+    // it; the others sleep at the next barrier and pick the results up from LDS =============================================
+    bool accept = false, new_dir = false, pair_ok = false;
     double al[P], ga[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) { al[k] = 0.0; ga[k] = 0.0; }
     double gp_sq = 0.0;
-    if (!accept) {
-        st.t_step *= 0.5;
-        st.nrej += 1;
-        if (st.t_step < 1e-9) st.status = 2;
-    } else {
-        // ---- curvature pair, move the accepted point ---------------------------------------------------------
-        bool pair_ok = false;
-        const int old_hist0 = st.hist;
-        if (!st.first) {
-            const double sy = T(4);
-            if (sy > 0.0 && sy * sy > 1e-24 * T(5) * T(6)) {          // (s'y > 1e-12 |s| |y|, without the square roots)
-                pair_ok = true;
-                if (wave_active && r0 < n) { stE<E>(a.S + (size_t)st.head * hs, r0, nS, in.S[0]); stE<E>(a.Y + (size_t)st.head * hs, r0, nS, in.Y[0]); }
-                if (wr && tid == 0) a.rho[st.head] = rcp_nr(sy);
-                st.head = (st.head + 1) % RS;
-                if (st.hist < M) st.hist += 1;
-            }
-            st.iters += 1;
-        }
-        st.f = f_t;
-        const double rf = rcp_nr(fmax(1.0, fabs(f_t)));      // (v_rcp_f64 + two Newton steps: ~1 ulp, a fifth of the IEEE division's chain)
-        st.gap = fabs(gapv) * rf;
-        st.infeas = viol * rcp_nr(fmax(scale, 1e-300));
-        st.primal = f_t - gapv;                   // c'psi = g - (nu - c)'(psi + h)
-        st.pg = T(7) * rf;
-        gp_sq = T(7);                              // (sum |projected gradient|: positive iff some free variable has a gradient)
-        const bool was_first = st.first != 0;
-        st.first = 0;
-        const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
-        if (conv) {
-            st.status = 1;
+    if (wave == 0) {
+        // lane l < 32 ends with total l; a total is fetched with two v_readlane (into SGPRs: no LDS broadcast round trips on
+        // the dependent chain)
+        double tl = 0.0;
+        if (lane < 32) for (int w = 0; w < nwa; ++w) tl += xw[w * 32 + lane];
+        const int tl_lo = __double2loint(tl), tl_hi = __double2hiint(tl);
+        auto T = [&](int i) { return __hiloint2double(__builtin_amdgcn_readlane(tl_hi, i), __builtin_amdgcn_readlane(tl_lo, i)); };
+        PHASE_STAMP(tsb, 20);
+        double viol = 0.0, scale = 0.0;
+        for (int w = 0; w < nwa; ++w) { viol = fmax(viol, xm[w * 2]); scale = fmax(scale, xm[w * 2 + 1]); }
+        double rho[P];
+        rho[0] = 0.0;
+#pragma unroll
+        for (int k = 0; k < MM; ++k) rho[k + 1] = (k < st.hist) ? uni(st.rhow[k]) : 0.0;
+        const double f_t = T(0), gapv = T(1);
+
+        // ---- accept test ----------------------------------------------------------------------------------------
+        accept = st.first != 0;
+        if (!st.first)
+            accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * T(2)) ||
+                                      (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && T(3) <= 0.8 * fabs(T(2))));
+        if (!accept) {
+            st.t_step *= 0.5;
+            st.nrej += 1;
+            if (st.t_step < 1e-9) st.status = 2;
         } else {
-            // ---- the two-loop recursion on scalars -----------------------------------------------------------
-            // which pairs are in the window: the new one if it passed, then the newest stored ones
-            new_dir = true;
-            if (wave_active) {                           // (waves without variables need no direction: they wait at the next barrier)
-            const int keep_old = was_first ? 0 : (pair_ok ? (old_hist0 < M ? old_hist0 : M - 1) : old_hist0);
-            rho[0] = pair_ok ? rcp_nr(T(4)) : 0.0;
-#pragma unroll
-            for (int k = 1; k < P; ++k) if (k - 1 >= keep_old) rho[k] = 0.0;
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                double t = T(GI_U + k);
-#pragma unroll
-                for (int j = 0; j < k; ++j) t -= al[j] * T(GI_SY + k * (k - 1) / 2 + j);
-                al[k] = uni(rho[k] * t);           // (wave-uniform: lives in SGPRs)
+            // ---- curvature pair, move the accepted point -----------------------------------------------------
+            const int old_hist0 = st.hist;
+            if (!st.first) {
+                const double sy = T(4);
+                if (sy > 0.0 && sy * sy > 1e-24 * T(5) * T(6)) {          // (s'y > 1e-12 |s| |y|, without the square roots)
+                    pair_ok = true;
+                    rho[0] = rcp_nr(sy);
+                    if (st.hist < M) st.hist += 1;
+                }
+                st.iters += 1;
             }
+            st.f = f_t;
+            const double rf = rcp_nr(fmax(1.0, fabs(f_t)));      // (v_rcp_f64 + two Newton steps: ~1 ulp, a fifth of the IEEE division's chain)
+            st.gap = fabs(gapv) * rf;
+            st.infeas = viol * rcp_nr(fmax(scale, 1e-300));
+            st.primal = f_t - gapv;                   // c'psi = g - (nu - c)'(psi + h)
+            st.pg = T(7) * rf;
+            gp_sq = T(7);                              // (sum |projected gradient|: positive iff some free variable has a gradient)
+            const bool was_first = st.first != 0;
+            st.first = 0;
+            const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
+            if (conv) {
+                st.status = 1;
+            } else {
+                // ---- the two-loop recursion on scalars -------------------------------------------------------
+                // which pairs are in the window: the new one if it passed, then the newest stored ones
+                new_dir = true;
+                const int keep_old = was_first ? 0 : (pair_ok ? (old_hist0 < M ? old_hist0 : M - 1) : old_hist0);
 #pragma unroll
-            for (int k = P - 1; k >= 0; --k) {
-                double t = T(GI_V + k);
+                for (int k = 1; k < P; ++k) if (k - 1 >= keep_old) rho[k] = 0.0;
 #pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const int hi = j > k ? j : k, lo = j > k ? k : j;
-                    t -= al[j] * T(GI_YHY + hi * (hi + 1) / 2 + lo);
+                for (int k = 0; k < P; ++k) {
+                    double t = T(GI_U + k);
+#pragma unroll
+                    for (int j = 0; j < k; ++j) t -= al[j] * T(GI_SY + k * (k - 1) / 2 + j);
+                    al[k] = rho[k] * t;
                 }
 #pragma unroll
-                for (int j = k + 1; j < P; ++j) t += ga[j] * T(GI_SY + j * (j - 1) / 2 + k);
-                ga[k] = uni(al[k] - rho[k] * t);
+                for (int k = P - 1; k >= 0; --k) {
+                    double t = T(GI_V + k);
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        const int hi = j > k ? j : k, lo = j > k ? k : j;
+                        t -= al[j] * T(GI_YHY + hi * (hi + 1) / 2 + lo);
+                    }
+#pragma unroll
+                    for (int j = k + 1; j < P; ++j) t += ga[j] * T(GI_SY + j * (j - 1) / 2 + k);
+                    ga[k] = al[k] - rho[k] * t;
+                }
             }
-            }
+            if (pair_ok) { st.rhow[2] = st.rhow[1]; st.rhow[1] = st.rhow[0]; st.rhow[0] = rho[0]; }      // the window moves on
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) { ctl[k] = al[k]; ctl[P + k] = ga[k]; }
+            ctl[2 * P] = st.t_step; ctl[2 * P + 1] = gp_sq;
+            ctli[0] = accept ? 1 : 0; ctli[1] = new_dir ? 1 : 0; ctli[2] = st.status; ctli[3] = pair_ok ? 1 : 0;
         }
     }
-    PHASE_STAMP(a.ev.ts, 21);
+    PHASE_STAMP(tsb, 21);
+    __syncthreads();
+    // every wave (wave 0 too: its vector copies of alpha / gamma die at the barrier) takes the uniform results into SGPRs
+    accept = uni(ctli[0]) != 0; new_dir = uni(ctli[1]) != 0; pair_ok = uni(ctli[3]) != 0;
+    gp_sq = uni(ctl[2 * P + 1]);
+    if (wave != 0) { st.status = uni(ctli[2]); st.t_step = uni(ctl[2 * P]); }      // (wave 0 holds the complete record, which it stores at the end)
+    if (new_dir && wave_active) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) { al[k] = uni(ctl[k]); ga[k] = uni(ctl[P + k]); }
+    }
+    // the history window of the next launch, in window order, with the state set this launch writes
+    if (has_role && wave_active && r0 < n) {
+        const int sh = (accept && pair_ok) ? 0 : 1;      // (the new pair enters at the front, or the window stays)
+#pragma unroll
+        for (int k = 0; k < MM; ++k) {
+            if (mine(R_SW + k)) { if (sh) stX<E>(Xw + (size_t)(XS_HIST + k) * xvs, r0, in.S[k + 1]); else stX<E>(Xw + (size_t)(XS_HIST + k) * xvs, r0, in.S[k]); }
+            if (mine(R_YW + k)) { if (sh) stX<E>(Xw + (size_t)(XS_HIST + MM + k) * xvs, r0, in.Y[k + 1]); else stX<E>(Xw + (size_t)(XS_HIST + MM + k) * xvs, r0, in.Y[k]); }
+        }
+    }
 
     // ================= second half: the direction, the next trial point =================================================
-    // second half's inputs come back from the LDS stash (keeping them in registers across the reduction spills; global
-    // reloads cost an L2 round trip on the chain): the accepted point (s moves to the trial point, or stays), its
-    // gradient (the stashed trial gradient, or the old one), the bounds; a rejected trial point reloads the old point,
-    // gradient and direction from the state set
-    double d[E];
+    // its inputs come back from the LDS stash (keeping them in registers across the reduction spills; global reloads cost
+    // an L2 round trip on the chain): the accepted point (s moves to the trial point, or stays), its gradient (the stashed
+    // trial gradient, or the old one), the bounds; a rejected trial point reloads the old point, gradient and direction
+    // from the state set.  Every thread reads and then recycles its OWN stash entries: no barrier in between.
+    double d[E], v[E], nn[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) { s[e] = Gs[e] = d[e] = glo[e] = 0.0; ghi[e] = __builtin_inf(); }
+    for (int e = 0; e < E; ++e) { s[e] = Gs[e] = d[e] = glo[e] = 0.0; ghi[e] = __builtin_inf(); v[e] = nn[e] = 0.0; }
     if (wave_active) {
 #pragma unroll
         for (int e = 0; e < E; ++e) if (tin[e]) { glo[e] = glo_s[r0 + e]; if (!PLAIN) ghi[e] = ghi_s[r0 + e]; }
@@ -485,25 +549,41 @@ iter_kernel(IterArgs a)
 #pragma unroll
             for (int e = 0; e < E; ++e) if (tin[e]) { s[e] = sts_s[r0 + e]; Gs[e] = gst_s[r0 + e]; }
         } else { ldE<E>(Xr, ld0, s); ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 3 * xvs, ld0, d); }
-        if (wr && accept && r0 < n) {                    // the accepted prices and their net trade, for the read-back
-            double pk[E], nk[E];                         // (from the stash: a reload through L2 sat on workgroup 0's chain, and
-#pragma unroll                                           //  the kernel ends with its slowest workgroup)
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (tin[e]) psi_s[r0 + e] = 0.0;       // (the stash entry becomes this thread's share of the zeroed psi tile)
+        if (keeps_acc && accept && r0 < n) {             // the accepted prices and their net trade, for the read-back
+            double pk[E], nk[E];                         // (from the stash: a reload through L2 would sit on the chain)
+#pragma unroll
             for (int e = 0; e < E; ++e) { pk[e] = tin[e] ? psi_k[r0 + e] : 0.0; nk[e] = tin[e] ? nu_k[r0 + e] : 0.0; }
-            stE<E>(a.psi_acc, r0, n, pk); stE<E>(a.nu_acc, r0, n, nk);
+            if (mine(R_PSI_ACC)) stE<E>(a.psi_acc, r0, n, pk);
+            if (mine(R_NU_ACC)) stE<E>(a.nu_acc, r0, n, nk);
         }
     }
 
-    if (new_dir) {
-        double F[2] = {0.0, 0.0};              // d.G | max |d|
+    auto trial = [&](double step) {                      // next trial point of this thread's variables
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            double qm = in.q0[e], rs = 0.0;
-#pragma unroll
-            for (int k = 0; k < P; ++k) { qm -= al[k] * in.Y[k][e]; rs += ga[k] * in.S[k][e]; }
-            d[e] = (tin[e] && !act[e]) ? -(in.H0[e] * qm + rs) : 0.0;
-            F[0] += d[e] * Gs[e]; F[1] = fmax(F[1], fabs(d[e]));
+            v[e] = fmax(s[e] + step * d[e], glo[e]);
+            if (!PLAIN) v[e] = fmin(v[e], ghi[e]);
+            nn[e] = tin[e] ? exp(v[e]) : 0.0;
         }
-        red.run<1, 1>(F);
+    };
+    if (new_dir) {
+        double F[2] = {0.0, 0.0};              // d.G | max |d|
+        if (wave_active) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                double qm = in.q0[e], rs = 0.0;
+#pragma unroll
+                for (int k = 0; k < P; ++k) { qm -= al[k] * in.Y[k][e]; rs += ga[k] * in.S[k][e]; }
+                d[e] = (tin[e] && !act[e]) ? -(in.H0[e] * qm + rs) : 0.0;
+                F[0] += d[e] * Gs[e]; F[1] = fmax(F[1], fabs(d[e]));
+            }
+        }
+        red.put<1, 1>(F, wave_active);
+        if (wave_active) trial(1.0);           // (speculation: the full step is the common case; under the reduction's barrier wait)
+        red.get<1, 1>(F);
+        bool redo = false;
         if (!(F[0] < 0.0) && gp_sq > 0.0) {       // not a descent direction: restart from the metric
             st.hist = 0;
             double m1[1] = {0.0};
@@ -512,27 +592,27 @@ iter_kernel(IterArgs a)
                 d[e] = (!tin[e] || act[e]) ? 0.0 : -Gs[e] * in.H0[e];
                 m1[0] = fmax(m1[0], fabs(d[e]));
             }
-            red.run<0, 1>(m1);
+            red.put<0, 1>(m1, wave_active);
+            red.get<0, 1>(m1);
             F[1] = m1[0];
+            redo = true;
         }
         st.t_step = (F[1] > a.max_step) ? a.max_step * rcp_nr(F[1]) : 1.0;
-    }
-    PHASE_STAMP(a.ev.ts, 22);
+        if ((redo || st.t_step != 1.0) && wave_active) trial(st.t_step);
+    } else if (st.status == 0 && wave_active) trial(st.t_step);
 
-    // ---- next trial point: into this workgroup's LDS copy of the prices; workgroup 0 also stores the state ------------
-    double v[E], nn[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        v[e] = fmax(s[e] + st.t_step * d[e], glo[e]);
-        if (!PLAIN) v[e] = fmin(v[e], ghi[e]);
-        nn[e] = (st.status == 0 && tin[e]) ? exp(v[e]) : 0.0;
-    }
+    // ---- workgroup 0 stores the state; the trial prices go into this workgroup's LDS table ---------------------------------
+    // (a solve that has ended above took no trial point: its price entries stay zero)
     if (st.status == 0 && st.evals >= a.max_evals) st.status = 3;
+    if (has_role && wave_active && r0 < n) {
+        if (mine(R_S)) stX<E>(Xw, r0, s);
+        if (mine(R_ST)) stX<E>(Xw + xvs, r0, v);
+        if (mine(R_GS)) stX<E>(Xw + 2 * xvs, r0, Gs);
+        if (mine(R_D)) stX<E>(Xw + 3 * xvs, r0, d);
+        if (mine(R_NU)) stX<E>(Xw + 4 * xvs, r0, nn);
+        if (wr) stE<E>(a.nu, r0, n, nn);
+    }
     if (wr) {
-        if (wave_active && r0 < n) {
-            stE<E>(Xw, r0, n, s); stE<E>(Xw + xvs, r0, n, v); stE<E>(Xw + 2 * xvs, r0, n, Gs); stE<E>(Xw + 3 * xvs, r0, n, d);
-            stE<E>(Xw + 4 * xvs, r0, n, nn); stE<E>(a.nu, r0, n, nn);
-        }
         if (tid == 0) {
             a.st3[p] = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0;
             // progress word for the host (system-scope store into pinned host memory: no copy, no API call on the host side)
@@ -541,15 +621,23 @@ iter_kernel(IterArgs a)
         }
     }
     if (st.status != 0) return;                          // ended (converged / stalled / out of budget): nothing to evaluate
-    __syncthreads();                                     // (the scratch in the exchange strips and the psi tile is free from here on)
+    PHASE_STAMP(a.ev.ts, 22);
 #pragma unroll
-    for (int e = 0; e < E; ++e) if (tin[e]) nu_s[r0 + e] = nn[e];
-    for (int j = tid; j < tile; j += blockDim.x) psi_s[j] = 0.0;
-    if (tid == 0) *next_tile = 0;
-    __syncthreads();
-    PHASE_STAMP(a.ev.ts, 23);
+    for (int e = 0; e < E; ++e) if (tin[e]) nu_s[r0 + e] = nn[e];        // (over this thread's own stash entry)
+    __syncthreads();                                     // (the scratch in the exchange strips is free from here on; the tile table
+    PHASE_STAMP(a.ev.ts, 23);                            //  and the ticket counter have been ready since the first barrier)
+#ifdef CFMM_PHASE_TIMERS
+    if (a.ev.ts && tid == 0) {
+        if (blockIdx.x == 0) { a.ev.ts[2 * 16] = ts_c16; a.ev.ts[2 * 16 + 1] = ts_w16; }
+        if (blockIdx.x < 256) { long long *tb = a.ev.ts + 64 + 8 * 4096; tb[2 * blockIdx.x] = ts_w16; tb[2 * (blockIdx.x + 256)] = wall_clock64(); }     // block start | update done
+    }
+#endif
     double2 *xs = reinterpret_cast<double2 *>(strips) + 64 * wave;
     eval_tiles_and_flush<false, false, DET>(a.ev, a.acc3 + (size_t)p * a.acc_set, nu_s, psi_s, nullptr, fpart, next_tile, xs);
+#ifdef CFMM_PHASE_TIMERS
+    __syncthreads();
+    if (a.ev.ts && tid == 0 && blockIdx.x < 256) a.ev.ts[64 + 8 * 4096 + 2 * blockIdx.x + 1] = wall_clock64();    // block end
+#endif
 }
 
 }  // namespace cfmm

@@ -55,6 +55,7 @@ constexpr int N_BUCKETS = 10;         // gn8 gn7 gn6 gn5 gn4 gn3 curve2 w2 cp2 s
 struct DevState {
     int status, evals, iters, first, hist, head, nrej, pad;
     double f, t_step, gap, infeas, primal, pg;
+    double rhow[3];                   // iter_kernel only: 1 / s'y of its history window, newest first (iterate.hpp)
 };
 
 struct Bucket2 {
@@ -76,7 +77,8 @@ struct EvalArgs {
     Bucket2 b2[4];                    // indexed by CFMM_POOL_* kind
     BucketN bn[6];                    // bn[k - 3], k = 3..8
     int tile_end[N_BUCKETS];          // cumulative wave-tile counts in processing order
-    int ntiles, n, nslices, pad;
+    int ntiles, n, nslices;
+    int rev;                          // 1: this launch walks every workgroup's tile range BACKWARDS (see eval_tiles_and_flush)
     const double *nu;                 // [n + 1]: prices, then the stop flag (non-zero = solve has ended)
     double *acc;
     long long *ts;                    // phase timers (tuning builds only)
@@ -352,6 +354,31 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
 }
 
 // ------------------------------------------------------------------------------------------
+// The workgroup's tile-range table (see eval_tiles_and_flush), built by the first N_BUCKETS lanes of ONE wave: lane q takes
+// bucket q's range [b n_q / G, (b + 1) n_q / G), an inclusive scan over the lanes (DPP row_shr inside the row of 16: no
+// LDS round trips, no barrier of its own) gives the cumulative counts.  Also arms the ticket counter: the first ticket of
+// wave w is w.  The caller passes a barrier between this and the tile loop.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void build_tile_table(const EvalArgs &a, int *next_tile, int lane)
+{
+    int *tab = next_tile + 2;
+    int cnt = 0, s = 0;
+    if (lane < N_BUCKETS) {
+        const int nq = a.tile_end[lane] - (lane ? a.tile_end[lane - 1] : 0);
+        const double G = (double)gridDim.x;           // (products < 2^47: exact in fp64, and the floors below cannot be off by one)
+        s = (int)(((double)blockIdx.x * nq) / G);
+        cnt = (int)(((double)(blockIdx.x + 1) * nq) / G) - s;
+    }
+    int c = cnt;
+    c += __builtin_amdgcn_update_dpp(0, c, 0x111, 0xf, 0xf, true);     // row_shr:1 (lanes without a source read 0)
+    c += __builtin_amdgcn_update_dpp(0, c, 0x112, 0xf, 0xf, true);     // row_shr:2
+    c += __builtin_amdgcn_update_dpp(0, c, 0x114, 0xf, 0xf, true);     // row_shr:4
+    c += __builtin_amdgcn_update_dpp(0, c, 0x118, 0xf, 0xf, true);     // row_shr:8
+    if (lane < N_BUCKETS) { tab[lane] = c; tab[N_BUCKETS + lane] = s; }
+    if (lane == 0) *next_tile = (int)(blockDim.x >> 6);
+}
+
+// ------------------------------------------------------------------------------------------
 // The dual evaluation, ONE launch for every bucket:  psi(nu) = sum_i A_i (L_i - D_i),
 // sum_i arb_i(A_i' nu), optionally the diagonal metric.                reference: arbitrage.py:54
 //
@@ -365,7 +392,7 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
 // STABLE = false: every bucket but the stableswap one; STABLE = true: the stableswap bucket alone (its Newton loops need
 // ~20 more VGPRs than anything else: kept out of the main instantiation, it lets that one run at 6 waves per SIMD)
 // the tile loop and the flush, shared by eval_kernel (below) and iter_kernel (iterate.hpp).  On entry nu_s holds the
-// prices, psi_s (diag_s) are zero, *next_tile is 0 and a barrier has been passed; `acc` is the accumulator set to flush into.
+// prices, psi_s (diag_s) are zero, build_tile_table has run and a barrier has been passed; `acc` is the accumulator set to flush into.
 // BATCH: `bc` describes the B price vectors / psi tiles in LDS, `acc_b[b]` is where vector b's tile is flushed; sum arb
 // is formed at the flush as nu' psi per vector (sum_i arb_i = sum_i nu' y_i) instead of being carried per lane.
 // FLUSH = false: the tiles stay in LDS (psi_t, diag_t, fpart[wave] = per-wave partial of sum arb) for a consumer in the same
@@ -390,34 +417,38 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
     // sends a few hundred atomics instead of n, the LDS gathers / scatters stay in a small window (C4 shard: evaluation
     // 16.1 -> 10.5 us).  Its waves draw the index i into the concatenation of its ranges from an LDS ticket counter
     // (ds_add_rtn, ~100 cycles against >= 1 us per tile), so they all finish within one tile of each other however
-    // uneven the tile costs are.  Range table (LDS, behind the ticket): tab[q] = tiles of buckets <= q in this workgroup,
-    // tab[N_BUCKETS + q] = first tile of its range inside bucket q.
-    int *tab = next_tile + 2;
-    if (threadIdx.x < N_BUCKETS) {
-        const int q = threadIdx.x;
-        const int nq = a.tile_end[q] - (q ? a.tile_end[q - 1] : 0);
-        const double G = (double)gridDim.x;           // (products < 2^47: exact in fp64, and the floors below cannot be off by one)
-        const int s = (int)(((double)blockIdx.x * nq) / G), e = (int)(((double)(blockIdx.x + 1) * nq) / G);
-        tab[N_BUCKETS + q] = s;
-        tab[q] = e - s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { int c = 0; for (int q = 0; q < N_BUCKETS; ++q) { c += tab[q]; tab[q] = c; } }
-    __syncthreads();
+    // uneven the tile costs are.  Range table (LDS, behind the ticket; build_tile_table, by ONE wave in the caller's
+    // prologue, in front of a barrier the caller has anyway): tab[q] = tiles of buckets <= q in this workgroup,
+    // tab[N_BUCKETS + q] = first tile of its range inside bucket q.  The first ticket of wave w is w (the counter starts
+    // at the number of waves).
+    // a.rev: the launch walks the concatenation BACKWARDS.  The host alternates the direction from launch to launch
+    // (ping-pong): what a launch read LAST -- and what therefore still sits in the XCD's L2 (4 MB for its 32 workgroups)
+    // and in the Infinity Cache (256 MB) -- is what the next launch reads FIRST.  A forward-only walk of a pool set larger
+    // than a cache level gets nothing out of an LRU-like level (cyclic access); the ping-pong walk finds up to the
+    // level's capacity of it still there.
+    const int *tab = next_tile + 2;
     const int nlocal = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS - 1]);
-    int bk = 0, cstart = 0;
-    int cend = __builtin_amdgcn_readfirstlane(tab[0]), sfirst = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS]);
-    int ticket = 0;
-    if (lane == 0) ticket = atomicAdd(next_tile, 1);
+    const bool rev = a.rev != 0;
+    int bk = rev ? N_BUCKETS - 1 : 0;
+    int cstart = rev ? __builtin_amdgcn_readfirstlane(tab[N_BUCKETS - 2]) : 0;
+    int cend = __builtin_amdgcn_readfirstlane(tab[bk]), sfirst = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS + bk]);
+    int ticket = wib;
     for (;;) {
-        const int i = __builtin_amdgcn_readfirstlane(ticket);
-        if (i >= nlocal) break;
+        const int i0 = __builtin_amdgcn_readfirstlane(ticket);
+        if (i0 >= nlocal) break;
         // the NEXT ticket is drawn before this tile's work, so its LDS round trip (behind the
         // previous tile's scatter atomics) overlaps the tile instead of separating two tiles
         if (lane == 0) ticket = atomicAdd(next_tile, 1);
-        while (i >= cend) {                              // (a wave's tickets only grow: the bucket pointer only moves forward)
+        const int i = rev ? nlocal - 1 - i0 : i0;
+        // (a wave's tickets only grow: its bucket pointer only moves one way)
+        while (i >= cend) {
             ++bk; cstart = cend;
             cend = __builtin_amdgcn_readfirstlane(tab[bk]);
+            sfirst = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS + bk]);
+        }
+        while (i < cstart) {
+            --bk; cend = cstart;
+            cstart = bk ? __builtin_amdgcn_readfirstlane(tab[bk - 1]) : 0;
             sfirst = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS + bk]);
         }
         const int tb = sfirst + (i - cstart);
@@ -524,8 +555,8 @@ eval_kernel(EvalArgs a)
     double *psi_s = lds, *diag_s = lds + tile;
     double *nu_s = lds + (WITH_D ? 2 : 1) * tile;       // [n + 1]
     double *fpart = nu_s + n + 2;                       // [16]
-    int *next_tile = reinterpret_cast<int *>(fpart + 16);   // the workgroup's tile ticket counter
-    if (threadIdx.x == 0) *next_tile = 0;
+    int *next_tile = reinterpret_cast<int *>(fpart + 16);   // the workgroup's tile ticket counter, the tile-range table behind it
+    if (threadIdx.x < 64) build_tile_table(a, next_tile, threadIdx.x);
     double2 *xs = reinterpret_cast<double2 *>(lds + eval_lds_doubles(n, WITH_D, DET)) + 64 * (threadIdx.x >> 6);   // wave-private [64]
     // prices and the stop flag arrive in ONE round trip (the flag rides behind the prices)
     for (int j = threadIdx.x; j <= n; j += blockDim.x) nu_s[j] = a.nu[j];
@@ -572,7 +603,7 @@ eval_batch_kernel(EvalArgs a, BatchArgs bt)
     double *nu_s = lds + nb * n;                        // [nb][nus]: prices, then the stop flag
     double *fpart = nu_s + nb * nus;                    // [BATCH_MAX][16]
     int *next_tile = reinterpret_cast<int *>(fpart + BATCH_MAX * 16);
-    if (threadIdx.x == 0) *next_tile = 0;
+    if (threadIdx.x < 64) build_tile_table(a, next_tile, threadIdx.x);
     double2 *xs = reinterpret_cast<double2 *>(lds + batch_lds_doubles(n, nb)) + 64 * (threadIdx.x >> 6);
     for (int b = 0; b < nb; ++b) {
         const double *src = bt.nu[b];
@@ -987,18 +1018,34 @@ struct BlockRed {
     template <int NS, int NM>
     __device__ __forceinline__ void run(double (&v)[NS + NM])
     {
+        put<NS, NM>(v, true);
+        if (nw == 1) return;
+        get<NS, NM>(v);
+    }
+    // the same in two halves, for callers that have work to put between the wave-level part and the barrier, or whose
+    // waves do not all contribute (`mine` false: the wave only keeps the parity; set nw to the number of contributing
+    // waves -- the first nw -- before the first use): put = wave butterflies + one LDS row per wave, get = the barrier and the
+    // sum over the rows, in every thread
+    template <int NS, int NM>
+    __device__ __forceinline__ void put(double (&v)[NS + NM], bool mine)
+    {
         static_assert(NS + NM <= NRED, "BlockRed: too many values");
         double *sl = scratch + parity * (NRED * 16);
-        parity ^= 1;
+        if (!mine) return;
 #pragma unroll
         for (int k = 0; k < NS; ++k) v[k] = wave_allsum(v[k]);
 #pragma unroll
         for (int k = NS; k < NS + NM; ++k) v[k] = wave_allmax(v[k]);
-        if (nw == 1) return;
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < NS + NM; ++k) sl[k * 16 + wave] = v[k];
         }
+    }
+    template <int NS, int NM>
+    __device__ __forceinline__ void get(double (&v)[NS + NM])
+    {
+        const double *sl = scratch + parity * (NRED * 16);
+        parity ^= 1;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NS; ++k) { double r = 0.0; for (int w = 0; w < nw; ++w) r += sl[k * 16 + w]; v[k] = r; }
@@ -1817,7 +1864,7 @@ start_kernel(UpdArgs a0, const double *nu0_, double *zero, long long nzero, DevS
     __syncthreads();
     for (int j = tid; j < n; j += nt) { const double v = exp(sum[a.grp[j]] + a.off[j]); a.nu[j] = v; a.nu_acc[j] = v; }
     if (tid == 0) {
-        DevState st;
+        DevState st = {};
         st.status = 0; st.evals = 0; st.iters = 0; st.first = 1; st.hist = 0; st.head = 0; st.nrej = 0; st.pad = 0;
         st.f = 0.0; st.t_step = 1.0; st.gap = 0.0; st.infeas = 0.0; st.primal = 0.0; st.pg = 0.0;
         *a.st = st;

@@ -73,7 +73,7 @@ solve_tiny_kernel(EvalArgs ev, UpdArgs a, int iters)
 
     for (int it = 0; it < iters; ++it) {
         for (int j = tid; j < 2 * tile; j += blockDim.x) lds[j] = 0.0;
-        if (tid == 0) *next_tile = 0;
+        if (tid < 64) build_tile_table(ev, next_tile, tid);          // (also re-arms the ticket counter)
         __syncthreads();
         if (it == 0) eval_tiles_and_flush<true, false, false, false, false>(ev, nullptr, nu_s, psi_s, diag_s, fpart, next_tile, xs);
         else eval_tiles_and_flush<false, false, false, false, false>(ev, nullptr, nu_s, psi_s, diag_s, fpart, next_tile, xs);

@@ -76,8 +76,8 @@ if ts.any():
     cyc = cyc[:, :7]; bk = bk[:, :7]
     per_wave = cyc.sum(axis=1) / 2400.0
     out["wave_busy_us(min,mean,max)"] = [round(float(x), 2) for x in (per_wave[per_wave > 0].min(), per_wave[per_wave > 0].mean(), per_wave.max())]
-    prob.solve(tol=1e-6, max_evals=12)
-    tu, _, _ = prob.ctx.debug_timers()
+    prob.solve(tol=1e-6, max_evals=12, method="lbfgs")
+    tu, _, tbi = prob.ctx.debug_timers()
     d = lambda t, i, j: (int(t[j, 0] - t[i, 0]), round((t[j, 1] - t[i, 1]) * 0.01, 2))   # (cycles, us)
     tb = tb[tb[:, 1] > 0]
     t0 = tb[:, 0].min()
@@ -92,6 +92,14 @@ if ts.any():
         out["iter_phases(cyc,us)"] = dict(st=d(tu, 16, 17), loads_grad=d(tu, 17, 18), gram_reduce=d(tu, 18, 19), lds_exchange=d(tu, 19, 20),
                                           recursion=d(tu, 20, 21), direction_F=d(tu, 21, 22), trial=d(tu, 22, 23), tiles=d(tu, 23, 2),
                                           reduce=d(tu, 2, 3), flush=d(tu, 3, 4), total=d(tu, 16, 4))
+    if tu[16].any() and tbi[:256, 0].all():
+        # the last full launch of that solve, per workgroup (100 MHz wall clock): start | update done | end
+        st0 = tbi[:256, 0].min()
+        b_st, b_up, b_en = (tbi[:256, 0] - st0) * 0.01, (tbi[256:512, 0] - st0) * 0.01, (tbi[:256, 1] - st0) * 0.01
+        pc = lambda x: [round(float(v), 2) for v in np.percentile(x, [0, 10, 50, 90, 100])]
+        out["iter_blocks"] = dict(start=pc(b_st), update_done=pc(b_up), end=pc(b_en), update_us=pc(b_up - b_st), tiles_us=pc(b_en - b_up),
+                                  wg0=[round(float(b_st[0]), 2), round(float(b_up[0]), 2), round(float(b_en[0]), 2)],
+                                  slowest_end_wg=int(np.argmax(b_en)), slowest_update_wg=int(np.argmax(b_up)))
     if tu[19].any() and not tu[16].any():
         out["upd_A_detail(cyc,us)"] = dict(grad=d(tu, 10, 19), partials=d(tu, 19, 20), reduce_scatter=d(tu, 20, 21), lds_exchange=d(tu, 21, 22), tail=d(tu, 22, 11))
 print(json.dumps(out), flush=True)
