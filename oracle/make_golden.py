@@ -14,6 +14,15 @@ Three independent sources per instance, all stored:
               and by closed-form dual decomposition + L-BFGS-B, agreeing to >= 9 digits).
 Neither is cvxpy output: cvxpy and every conic solver are absent from this container, so the
 reference itself cannot be run here (PARITY UNPINNED by the reference; it holds no expected values).
+
+  * "cvxpy":  THE REFERENCE'S OWN STACK, wherever it is importable: the three programs exactly as the scripts
+              state them (tests/cvx_models.py: the same text the cfmm.cvx tests run) through `import cvxpy`,
+              `prob.solve()` with cvxpy's default solver as in arbitrage.py:81-82 -- objective, psi, tenders,
+              solver name and versions.  `python -B oracle/make_golden.py --cvxpy` adds / refreshes this key in
+              the existing fixture without touching the other three; with cvxpy absent it says so and leaves the
+              file alone.  tests/test_oracle.py::test_known_answers_against_the_reference_stack compares the
+              other derivations (and, on the GPU, the HIP path through the same fixture) with it whenever the
+              key exists -- the one route by which parity becomes pinned BY THE REFERENCE.
 """
 import json
 import os
@@ -48,13 +57,60 @@ SURVEY = {
 }
 
 
-def main():
-    out = {}
+def cases_all():
     cases = [("arbitrage", I.arbitrage()), ("liquidation", I.liquidation())]
     sweep = I.two_asset_sweep()
     for j in (0, 1, 10, 25, 49):
         cases.append((f"two_asset_{j}", I.two_asset(sweep[j])))
-    for name, inst in cases:
+    return cases
+
+
+def cvxpy_leg(inst):
+    """the instance through the reference's own solver stack (arbitrage.py:39-84 as restated in tests/cvx_models.py);
+    None when cvxpy is not importable"""
+    try:
+        import cvxpy
+    except ImportError:
+        return None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.path.join(root, "tests") not in sys.path:
+        sys.path.insert(0, os.path.join(root, "tests"))
+    import cvx_models
+    prob, goal, net, tender, receive = cvx_models.build(cvxpy, inst)
+    prob.solve()                                   # (the scripts' call: default solver, default tolerances)
+    stats = getattr(prob, "solver_stats", None)
+    return dict(value=float(prob.value), status=str(prob.status), psi=np.asarray(net.value, float).tolist(),
+                y=[(np.asarray(l.value, float) - np.asarray(d.value, float)).tolist() for d, l in zip(tender, receive)],
+                solver=str(getattr(stats, "solver_name", "")), cvxpy_version=str(cvxpy.__version__))
+
+
+def golden_path():
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "shipped_instances.json")
+
+
+def add_cvxpy():
+    """--cvxpy: add / refresh the "cvxpy" key of the committed fixture, nothing else"""
+    try:
+        import cvxpy  # noqa: F401
+    except ImportError:
+        print("cvxpy is not importable here: the fixture keeps its three derivations (parity unpinned by the reference)")
+        return 1
+    with open(golden_path()) as f:
+        out = json.load(f)
+    for name, inst in cases_all():
+        out[name]["cvxpy"] = cvxpy_leg(inst)
+        print(name, out[name]["cvxpy"]["value"], out[name]["kkt"]["value_str"], out[name]["cvxpy"]["solver"])
+    with open(golden_path(), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", golden_path())
+    return 0
+
+
+def main():
+    if "--cvxpy" in sys.argv[1:]:
+        return add_cvxpy()
+    out = {}
+    for name, inst in cases_all():
         r = solve_primal(I.normalise(inst))
         k = kkt_mp.polish(I.normalise(inst), SURVEY[name]["nu"], TIED.get(name, {}))
         out[name] = dict(
@@ -62,12 +118,15 @@ def main():
             primal=dict(value=r["value"], psi=r["psi"].tolist(), y=[v.tolist() for v in r["y"]]),
             survey=SURVEY[name],
             t=inst["utility"].get("h", [0])[0] if inst["name"] == "two_asset" else None)
+        cv = cvxpy_leg(inst)
+        if cv is not None:
+            out[name]["cvxpy"] = cv
         print(name, k["value_str"], r["value"], SURVEY[name]["value"])
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "shipped_instances.json")
+    path = golden_path()
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -188,6 +188,10 @@ def test_shipped_instances_through_hip(name, inst):
         assert np.all(d >= 0) and np.all(l >= 0) and np.all(d * l == 0)
         assert np.abs((l - d) - np.asarray(y)).max() <= 1e-6
         assert np.abs((l - d) - np.asarray(y)).max() <= 5e-8
+    if "cvxpy" in g:            # the reference's own output, where the fixture was made with cvxpy installed (oracle/make_golden.py --cvxpy)
+        cv = g["cvxpy"]
+        assert abs(v - cv["value"]) <= 1e-6 * max(1, abs(v))                 # BASELINE.json: "objective within 1e-6 relative of cvxpy"
+        assert np.abs(p.psi - np.asarray(cv["psi"])).max() <= 1e-4 * max(np.abs(np.asarray(y)).max() for y in g["kkt"]["y"])
     p.close()
 
 
