@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's metric on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C4] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5] [--no-cpu] [--share-gpu]
 
 One *step* = one complete solve of the hot path (dual-decomposition routing, projected L-BFGS on
 log-prices, on device) from a cold start to the 1e-6 certificates on one batch of synthetic input.
@@ -11,6 +11,16 @@ log-prices, on device) from a cold start to the 1e-6 certificates on one batch o
       1e6-pool shard of an N x 1e6 network over the same tokens: WEAK scaling.
   --config C4: BASELINE config 4 exactly -- 1e7 constant-product pools / 2000 tokens -- split N ways (1.25e6 pools
       per GPU at N = 8): STRONG scaling.  At N = 1 the whole 320 MB set streams from HBM on one GPU.
+
+  --config C2: BASELINE config 2 -- 1e4 constant-product pools / 100 tokens, linear-utility arbitrage (launch-latency
+      bound: 0.3 MB of pool data per evaluation).
+  --config C5: BASELINE config 5 -- 5e5 stableswap + 5e4 constant-product pools / 1000 tokens, a 10-token basket
+      liquidation (liquidation.py:57,77-80) -- through the second-order path (barrier-smoothed dual Newton); its
+      dominant kernel is the dense factorisation of a Newton step, priced against the fp64 vector peak.
+  --share-gpu (with --gpus N > 1 on a box with ONE GPU): the N ranks are N processes on device 0 -- gloo for the host
+      side, no RCCL (it refuses two ranks on one device), the per-evaluation exchange through the hipIpc-mapped
+      one-shot mailboxes: the whole multi-rank path of this file (self-launch, torch.distributed.run, pool shards,
+      per-iteration split, max-over-ranks clock, one JSON line) end to end without a second GPU.  Not a scaling number.
 
 With N > 1 there is one process per GPU and the library all-reduces [psi | sum arb] over RCCL once per dual
 evaluation.  `python bench.py --gpus N` launches those processes itself (torch.distributed.run on 127.0.0.1) when it
@@ -43,9 +53,15 @@ for p in (ROOT, os.path.join(ROOT, "cfmm-routing-code_amd")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # AMD's MI355X figure for vector fp64 (256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2.4 GHz x 2)
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock
 TRAFFIC_NOTE = {"C3": "C3's 43.4 MB working set fits the 256 MiB Infinity Cache: back-to-back launches are cache-served; "
                       "profiles/ holds the PMC traffic and the HBM-streaming (>= 1e7 pools) variant",
-                "C4": "320 MB per launch at N = 1: streams from HBM (larger than the 256 MiB Infinity Cache)"}
+                "C4": "320 MB per launch at N = 1: streams from HBM (larger than the 256 MiB Infinity Cache); consecutive launches walk "
+                      "the pools in opposite directions (ping-pong), so ~10 % of a launch -- what the 8 x 4 MB of L2 still hold -- is not re-read",
+                "C2": "0.32 MB of pool data per evaluation: launch-latency bound -- neither fraction says much",
+                "C5": "second-order path: the dominant kernel group is the dense n x n Cholesky of a Newton step (a latency chain of "
+                      "dependent launches, priced against the fp64 vector peak); the smoothed evaluation is fp64-issue / divergence bound"}
 
 BYTES_PER_POOL = {"cp2": 32, "w2": 40, "sum2": 32, "curve2": 40}     # SURVEY 8(d); k-asset: 20 + 20 k (+ log fee)
 KIND_ID = {"cp2": 0, "w2": 1, "sum2": 2, "curve2": 3}
@@ -59,19 +75,21 @@ def profile_record(config):
     (the one launch per outer iteration; averages over its FULL launches, the idle run-ahead launches behind the end of a
     solve excluded) from tools/profile_iter.py's trace, "eval" = eval_kernel alone from tools/profile_eval.py's."""
     import json
-    out = {k: dict(traffic=None, traffic_file=None, rocprof_avg_us=None, rocprof_file=None) for k in ("iter", "eval")}
+    out = {k: dict(traffic=None, traffic_file=None, rocprof_avg_us=None, rocprof_file=None, valu_busy=None) for k in ("iter", "eval")}
     pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_pmc_medians.csv")))
     for which, cfg, name in (("iter", config + "iter", "iter_kernel"), ("eval", config, "eval_kernel")):
         for f in reversed(pmc):
             rows = {}
             for r in csv.DictReader(open(f)):
-                if r["config"] == cfg and name in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                if r["config"] == cfg and name in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU"):
                     rows.setdefault(r["kernel"], {})[r["counter"]] = float(r["median"])
-            rows = {k: v for k, v in rows.items() if len(v) == 2}
+            rows = {k: v for k, v in rows.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
             if rows:                                   # the instantiation that moves the most bytes: the dominant one
                 v = max(rows.values(), key=lambda v: v["FETCH_SIZE"])
                 out[which]["traffic"] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
                 out[which]["traffic_file"] = os.path.relpath(f, ROOT)
+                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs: x 4 = SIMD-cycles the vector ALU was issuing
+                out[which]["valu_busy"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] if "SQ_ACTIVE_INST_VALU" in v else None
                 break
     for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_durations.json")))):
         d = json.load(open(f)).get(config + "iter", {})
@@ -135,7 +153,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default=os.environ.get("BENCH_CONFIG", "C3"), choices=["C3", "C4"])
+    ap.add_argument("--config", default=os.environ.get("BENCH_CONFIG", "C3"), choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--no-cpu", action="store_true")
@@ -145,6 +163,8 @@ def main():
     ap.add_argument("--kernel-reps", type=int, default=50)
     ap.add_argument("--allreduce", default=os.environ.get("CFMM_ALLREDUCE", "auto"), choices=["auto", "rccl", "oneshot"],
                     help="the per-evaluation all-reduce: RCCL (default) or the one-shot xGMI exchange (csrc/oneshot.hpp)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="with --gpus N on a one-GPU box: N processes on device 0 (gloo + the one-shot exchange, no RCCL): exercises the whole multi-rank path")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the pool-sharded code path (process group, RCCL communicator, all-reduce per evaluation) even with one rank")
     args = ap.parse_args()
@@ -170,21 +190,47 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
-        if torch.cuda.device_count() < world:
-            raise SystemExit(f"bench.py: rank {rank} of {world}: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            # the ranks are processes on ONE device: gloo carries the host side, the library's per-evaluation exchange goes
+            # through the hipIpc-mapped one-shot mailboxes (RCCL refuses two ranks on one device)
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            if torch.cuda.device_count() < world:
+                raise SystemExit(f"bench.py: rank {rank} of {world}: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible "
+                                 "(--share-gpu runs the ranks as processes on one device)")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    shard_kw = dict(dist=dist, device=local_rank, allreduce=("oneshot" if args.share_gpu else args.allreduce))
+    if args.share_gpu:
+        shard_kw["rccl"] = False
 
     strong = args.config == "C4"
+    solve_kw = {}
     if strong:
         # strong scaling: ONE fixed network (same seed on every rank), contiguous pool shards
         net = synthetic.config("C4", seed=0, scale=args.scale)
         total_pools = cfmm.problem.network_pool_count(net)
-        prob = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=local_rank, shard=True, allreduce=args.allreduce)
+        utility = cfmm.Arbitrage(net["c"])
+        prob = cfmm.distributed.sharded_problem(net, utility, shard=True, **shard_kw)
     else:
-        # weak scaling: every rank generates its OWN 1e6-pool shard (same tokens / prices / utility)
-        net = synthetic.config("C3", seed=0, scale=args.scale, pool_seed=(rank if world > 1 else None))
-        prob = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=local_rank, shard=False, allreduce=args.allreduce)
+        # weak scaling: every rank generates its OWN shard of the config (same tokens / prices / utility)
+        net = synthetic.config(args.config, seed=0, scale=args.scale, pool_seed=(rank if world > 1 else None))
+        if args.config == "C5":
+            # the basket of tools/profile_newton.py: ten tokens worth ~70 units each to be sold for token t (liquidation.py:57,77-80)
+            rng = np.random.default_rng(1)
+            n = net["n_tokens"]
+            h = np.zeros(n); idx = rng.choice(n, 10, replace=False); h[idx] = np.exp(rng.normal(2, 0.5, 10)) / net["prices"][idx] * 10
+            t_out = int(rng.integers(0, n)); h[t_out] = 0
+            utility = cfmm.Liquidate(h, t_out)
+            if args.share_gpu:
+                raise SystemExit("bench.py: --config C5 all-reduces a Hessian per Newton step: it needs RCCL, not --share-gpu")
+        else:
+            utility = cfmm.Arbitrage(net["c"])
+        if args.share_gpu:
+            solve_kw["method"] = "lbfgs"       # (the second-order fall-back would all-reduce a Hessian: RCCL)
+        prob = cfmm.distributed.sharded_problem(net, utility, shard=False, **shard_kw)
         total_pools = prob.m * world
     prob._ensure_ctx()
 
@@ -196,15 +242,17 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        prob.solve(tol=args.tol)
+        prob.solve(tol=args.tol, **solve_kw)
     sync()
     evals = 0
     dev_s = 0.0
+    newton_steps = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        prob.solve(tol=args.tol)
+        prob.solve(tol=args.tol, **solve_kw)
         evals += prob.stats["evals"]
         dev_s += prob.stats["device_seconds"]
+        newton_steps += prob.stats.get("newton_steps", 0)
         # the metric is "to 1e-6 rel-gap": both certificates at the requested tolerance, checked here and not only
         # through the status string
         if prob.status != "optimal" or not (prob.gap <= args.tol and prob.infeas <= args.tol):
@@ -213,7 +261,7 @@ def main():
     dt = time.perf_counter() - t0
     if sharded:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     subproblems = evals * total_pools          # every rank runs the same number of evaluations over its own pools
@@ -223,6 +271,10 @@ def main():
     fold_s, ar_s = prob.ctx.time_collective(args.kernel_reps) if sharded else (0.0, 0.0)
     # the evaluation launch at prices ~1 % off the market (about 88 % of the pools trade, as in the first iterations
     # of a solve and in tools/profile_eval.py, whose rocprofv3 trace is committed under profiles/)
+    second_order = prob.stats.get("method") == 2
+    newton_kernels = None
+    if second_order and not sharded:
+        newton_kernels = prob.ctx.time_newton_kernels(max(prob.stats.get("barrier_mu", 0.0), 1e-12), 5)      # at the solution just found
     prob.ctx.set_nu(net["c"] * np.exp(np.random.default_rng(0).normal(0, 0.01, net["n_tokens"])))
     rows = kernel_table(prob, args.kernel_reps)
 
@@ -238,9 +290,19 @@ def main():
         if strong:
             workload = (f"C4: {total_pools} constant-product pools / {net['n_tokens']} tokens split over {world} GPU(s) "
                         f"({prob.m} per GPU: {mix}), linear-utility arbitrage, cold-start solve to gap,infeas <= {args.tol:g}")
+        elif args.config == "C5":
+            workload = (f"C5: {prob.m} pools per GPU ({mix}) / {net['n_tokens']} tokens, liquidation of a 10-token basket "
+                        f"(liquidation.py:57,77-80), cold-start solve to gap,infeas <= {args.tol:g} (second-order path)")
         else:
-            workload = (f"C3: {prob.m} pools per GPU ({mix}) / {net['n_tokens']} tokens, "
+            workload = (f"{args.config}: {prob.m} pools per GPU ({mix}) / {net['n_tokens']} tokens, "
                         f"linear-utility arbitrage, cold-start solve to gap,infeas <= {args.tol:g}")
+        if args.share_gpu:
+            workload += f"; --share-gpu: the {world} ranks are processes on ONE device (functional run of the multi-rank path, not a scaling number)"
+        # the binding roofline of the dominant kernel: the algorithmic bytes against the HBM peak, and the cycles its
+        # vector ALUs were issuing (PMC, newest profile) against all SIMD-cycles of the launch; `bound` names the larger
+        hbm_frac = dom["bytes"] / (us_iter * 1e-6) / 1e9 / HBM_PEAK_GBS
+        valu_frac = (prof[pk]["valu_busy"] / (SIMDS * CLOCK_HZ * us_iter * 1e-6)) if prof[pk]["valu_busy"] else None
+        ev_valu = (prof["eval"]["valu_busy"] / (SIMDS * CLOCK_HZ * dom["seconds"])) if prof["eval"]["valu_busy"] else None
         out = {
             "metric": METRIC,
             "value": value, "unit": "pool-subproblems/s", "n_gpus": world, "steps": args.steps,
@@ -265,19 +327,47 @@ def main():
             # the timed region is the device time per iteration (HIP events around the outer loop, one launch per iteration,
             # back to back); the algorithmic bytes are those of the evaluation.  `evaluation_only` is the same tile code
             # launched without the update (eval_kernel, what cfmm_eval_dual runs), timed as back-to-back launches.
-            "roofline": {"bound": "hbm", "kernel": "iter_kernel (nu update + evaluation, one launch per iteration)" if prob.stats.get("method") == 1 else dom["kernel"],
+            "roofline": {"bound": "valu" if (valu_frac is not None and valu_frac > hbm_frac) else "hbm",
+                         "kernel": "iter_kernel (nu update + evaluation, one launch per iteration)" if prob.stats.get("method") == 1 else dom["kernel"],
                          "achieved": dom["bytes"] / (us_iter * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dom["bytes"] / (us_iter * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": prof[pk]["traffic"],
+                         "unit": "GB/s", "frac": hbm_frac, "hbm_frac": hbm_frac, "valu_frac": valu_frac,
+                         "valu_frac_note": "SQ_ACTIVE_INST_VALU x 4 (SIMD-cycles of vector issue per launch, newest PMC file under profiles/) / "
+                                           "(1024 SIMDs x 2.4 GHz x the live launch duration)",
+                         "traffic": prof[pk]["traffic"],
                          "traffic_source": prof[pk]["traffic_file"],
                          "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": us_iter,
                          "rocprof_avg_launch_us": prof[pk]["rocprof_avg_us"], "rocprof_source": prof[pk]["rocprof_file"],
                          "evaluation_only": {"kernel": "eval_kernel", "avg_launch_us": dom["seconds"] * 1e6, "achieved": dom["GBps"],
-                                             "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": prof["eval"]["traffic"],
+                                             "frac": dom["GBps"] / HBM_PEAK_GBS, "hbm_frac": dom["GBps"] / HBM_PEAK_GBS, "valu_frac": ev_valu,
+                                             "bound": "valu" if (ev_valu is not None and ev_valu > dom["GBps"] / HBM_PEAK_GBS) else "hbm",
+                                             "traffic": prof["eval"]["traffic"],
                                              "rocprof_avg_launch_us": prof["eval"]["rocprof_avg_us"], "rocprof_source": prof["eval"]["rocprof_file"]},
                          "note": TRAFFIC_NOTE[args.config],
                          "all_kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]},
         }
-        if not sharded and not strong and not args.no_batch:
+        if second_order:
+            # the second-order path: `value` counts its dual evaluations (smoothed and exact) like any other; the time goes
+            # into the dense solve of each Newton step, so THAT is the dominant kernel group and its ceiling is the fp64
+            # vector rate (no MFMA in it).  The smoothed evaluation is priced against both ceilings beside it.
+            out["newton_steps_per_solve"] = newton_steps / args.steps
+            if newton_kernels:
+                nk = newton_kernels
+                nr = (net["n_tokens"] + 31) // 32 * 32
+                flops = nr ** 3 / 3.0
+                sm_bytes = dom["bytes"] + 16 * sum(len(prob.net[k]["Ra"]) for k in ("cp2", "w2", "curve2") if k in prob.net)     # + the warm starts: 8 B per direction
+                tf = flops / nk["factor"] / 1e12
+                out["roofline"].update({
+                    "bound": "valu", "kernel": "chol_panel_kernel + chol_update_kernel (the dense Cholesky of one Newton step, all its launches)",
+                    "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+                    "valu_frac": tf / FP64_VECTOR_PEAK_TFLOPS, "hbm_frac": None, "traffic": None, "traffic_source": None,
+                    "valu_frac_note": f"n^3/3 flops of the {nr} x {nr} factorisation / its measured time, against the fp64 vector peak",
+                    "avg_launch_us": nk["factor"] * 1e6, "algorithmic_bytes_per_launch": None,
+                    "newton_step_us": {"smoothed_evaluation_with_hessian": nk["smooth_hess"] * 1e6, "smoothed_evaluation": nk["smooth"] * 1e6,
+                                       "factorisation": nk["factor"] * 1e6, "back_substitution": nk["backsolve"] * 1e6},
+                    "smoothed_evaluation": {"kernel": "smooth_kernel<false>", "avg_launch_us": nk["smooth"] * 1e6,
+                                            "algorithmic_bytes_per_launch": sm_bytes, "hbm_frac": sm_bytes / nk["smooth"] / 1e9 / HBM_PEAK_GBS},
+                })
+        if not sharded and not strong and not args.no_batch and not second_order and "curve2" not in prob.net and "sum2" not in prob.net:
             # B price vectors per pool read (cfmm_solve_batch; the parametric-sweep use of two-asset.py:34-100): B solves
             # of the same pools under B utilities in lock-step.  Not `value` (the metric is quoted on ONE solve of this
             # config): an extra figure in the same unit.
@@ -302,7 +392,7 @@ def main():
                                       "(eval_batch_kernel + one update workgroup per solve); wall time includes the host-side start "
                                       "prices and certificate checks of every solve"}
             prob.set_utility(cfmm.Arbitrage(net["c"]))
-        if not sharded and not strong:
+        if not sharded and not strong and not second_order:
             # the same solve with the host-buffer hand-over inside the clock (never `value`): a fresh context, the pool columns
             # uploaded from pageable NumPy buffers, utility, one cold solve, prices and psi read back -- through the raw
             # C-ABI calls INTEGRATION.md's stub makes
@@ -346,6 +436,22 @@ def main():
                 if best is None or dt1 < best[1]:
                     best = (th, dt1, o)
             cores, eval_s, o = best
+            if second_order:
+                # the CPU twin of this path is the first-order iteration (the oracle has no second-order method): dual
+                # evaluations of the same network at the same prices are what is comparable, timed for the same duration
+                t0 = time.perf_counter(); ce = 0
+                while time.perf_counter() - t0 < args.cpu_seconds:
+                    o.eval(net["prices"]); ce += 1
+                cdt = time.perf_counter() - t0
+                out["cpu_baseline"] = {"value": ce * prob.m / cdt, "unit": "pool-subproblems/s", "cores": cores, "kind": "port",
+                                       "sample": f"{ce} exact dual evaluations of the same {prob.m}-pool network by oracle/cfmm_oracle.c (OpenMP, {cores} "
+                                                 f"threads), {cdt:.1f} s: the oracle has no second-order method, and its first-order iteration needs "
+                                                 "thousands of evaluations on this instance (DESIGN.md); cvxpy is not installed in this image",
+                                       "single_evaluation_ms": eval_s * 1e3}
+                print(json.dumps(out))
+                if sharded:
+                    dist.barrier(); dist.destroy_process_group()
+                return
             o.solve(net["c"], tol=args.tol)          # warm the OpenMP pool
             t0 = time.perf_counter(); ce = 0; ns = 0
             while ns < args.cpu_solves or time.perf_counter() - t0 < args.cpu_seconds:     # >= 10 s: past any cgroup burst allowance

@@ -58,7 +58,7 @@ SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm
            "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_comm_unique_id", "cfmm_comm_init",
            "cfmm_oneshot_export", "cfmm_oneshot_import", "cfmm_oneshot_attach", "cfmm_oneshot_mailbox", "cfmm_oneshot_enable",
-           "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
+           "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_time_newton_kernels", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
 
 
 def lib():
@@ -103,6 +103,7 @@ def lib():
     L.cfmm_oneshot_enable.argtypes = [vp, C.c_int]
     L.cfmm_time_eval_kernel.argtypes = [vp, C.c_int, C.c_int, dp]
     L.cfmm_time_collective.argtypes = [vp, C.c_int, dp, dp]
+    L.cfmm_time_newton_kernels.argtypes = [vp, C.c_double, C.c_int, dp]
     L.cfmm_selftest.argtypes = [vp]
     L.cfmm_debug_timers.argtypes = [vp, C.POINTER(C.c_int64)]
     L.cfmm_pool_count.restype = C.c_int64; L.cfmm_pool_count.argtypes = [vp]
@@ -333,6 +334,13 @@ class Context:
         f, a = C.c_double(), C.c_double()
         self._chk(self.L.cfmm_time_collective(self.h, reps, C.byref(f), C.byref(a)))
         return f.value, a.value
+
+    def time_newton_kernels(self, mu, reps=5):
+        """seconds per launch group of one second-order step at the current prices: smoothed evaluation with the Hessian,
+        smoothed evaluation alone, dense factorisation, back substitution"""
+        out = np.zeros(4)
+        self._chk(self.L.cfmm_time_newton_kernels(self.h, float(mu), int(reps), _d(out)))
+        return dict(smooth_hess=out[0], smooth=out[1], factor=out[2], backsolve=out[3])
 
     def selftest(self):
         self._chk(self.L.cfmm_selftest(self.h))

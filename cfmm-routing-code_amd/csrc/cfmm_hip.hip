@@ -1007,7 +1007,7 @@ int hess_ld(int n) { return hess_nr(n) + CH_NB; }                   // + the blo
 
 // in-place Cholesky of the lower triangle of ctx->H with the right-hand side in row nr (chol.hpp), then the back
 // substitution into `x`; *sm_info (device) = 0 or 1 + the first block column with a non-positive pivot
-int launch_cholesky(cfmm_ctx *ctx, int n, double *x)
+int launch_factor(cfmm_ctx *ctx, int n)
 {
     const int nr = hess_nr(n), ld = hess_ld(n), nrows = nr + 1;
     HIP_TRY(ctx, hipMemsetAsync(ctx->sm_info, 0, sizeof(int), ctx->stream));
@@ -1019,10 +1019,21 @@ int launch_cholesky(cfmm_ctx *ctx, int n, double *x)
             hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, ctx->stream, ctx->H, ld, nrows, nr, k0);
         }
     }
+    HIP_TRY(ctx, hipGetLastError());
+    return CFMM_OK;
+}
+int launch_backsolve(cfmm_ctx *ctx, int n, double *x)
+{
+    const int nr = hess_nr(n), ld = hess_ld(n);
     hipLaunchKernelGGL(chol_back_kernel, dim3(1), dim3(CH_SOLVE_THREADS), (size_t)(nr + CH_NB) * sizeof(double), ctx->stream,
                        (const double *)ctx->H, ld, nr, n, (const double *)ctx->Dinv, x);
     HIP_TRY(ctx, hipGetLastError());
     return CFMM_OK;
+}
+int launch_cholesky(cfmm_ctx *ctx, int n, double *x)
+{
+    int rc = launch_factor(ctx, n);
+    return rc ? rc : launch_backsolve(ctx, n, x);
 }
 
 bool newton_supported(cfmm_ctx *ctx, const char **why)
@@ -2639,6 +2650,73 @@ int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_lau
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
     *sec_per_launch = ms * 1e-3 / reps;
+    return CFMM_OK;
+}
+
+// bench.py --config C5: the kernels of one second-order step, each timed as `reps` launches with HIP events on the library's
+// stream at the prices cfmm_set_nu / the last solve left: out4 = seconds per {smoothed evaluation with the Hessian
+// assembly, smoothed evaluation alone (a line-search point), dense factorisation (all its launches), back substitution}
+int cfmm_time_newton_kernels(cfmm_ctx *ctx, double mu, int reps, double *out4)
+{
+    if (!ctx || reps < 1 || !out4 || !(mu > 0.0)) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pools_ready(ctx);
+    const char *why = "";
+    if (!newton_supported(ctx, &why)) return fail(ctx, CFMM_E_UNSUPPORTED, "time_newton_kernels: %s", why);
+    const int n = ctx->n, nr = hess_nr(n), ld = hess_ld(n);
+    int rc = smooth_buffers(ctx, true); if (rc) return rc;
+    if (!ctx->have_nu) return fail(ctx, CFMM_E_STATE, "time_newton_kernels: no prices (cfmm_set_nu or a solve first)");
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));       // (the accepted prices)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->sm_mask, 0, n * sizeof(int), ctx->stream));
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k)
+        if (ctx->sm_ws[k]) HIP_TRY(ctx, hipMemsetAsync(ctx->sm_ws[k], 0, 2 * (size_t)ctx->pools->b2[k].m * sizeof(double), ctx->stream));
+    float ms = 0.f;
+    for (int which = 0; which < 2; ++which) {            // 0: with the Hessian, 1: without (warm-started from the first)
+        if ((rc = launch_smooth(ctx, mu, which == 0, true, false))) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+        for (int i = 0; i < reps; ++i) if ((rc = launch_smooth(ctx, mu, which == 0, true, false))) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+        out4[which] = ms * 1e-3 / reps;
+    }
+    // the system of a step: the assembled Hessian + a diagonal shift that makes it safely positive definite, right-hand side 1
+    if ((rc = launch_smooth(ctx, mu, true, true, false))) return rc;
+    std::vector<double> hd(n, 0.0), rhs(n, 1.0);
+    {
+        std::vector<double> col(n);
+        double mx = 0.0;
+        for (int j = 0; j < n; j += std::max(1, n / 64)) {      // (a sample of the diagonal is enough for the scale of the shift)
+            HIP_TRY(ctx, hipMemcpy(&col[j], ctx->H + (size_t)j * ld + j, sizeof(double), hipMemcpyDeviceToHost));
+            mx = std::max(mx, std::fabs(col[j]));
+        }
+        for (int j = 0; j < n; ++j) hd[j] = 1e-3 * std::max(mx, 1e-300);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, hd.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec + n, rhs.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, nr, ld, (const double *)ctx->sm_vec,
+                       (const int *)ctx->sm_mask, (const double *)(ctx->sm_vec + n));
+    double *keep = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&keep, (size_t)ld * nr * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpyAsync(keep, ctx->H, (size_t)ld * nr * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    double fac = 0.0, back = 0.0;
+    hipEvent_t ev_end = nullptr;
+    if (hipEventCreate(&ev_end) != hipSuccess) { (void)hipFree(keep); return fail(ctx, CFMM_E_HIP, "time_newton_kernels: hipEventCreate failed"); }
+    for (int i = 0; i < reps && rc == CFMM_OK; ++i) {
+        if (hipMemcpyAsync(ctx->H, keep, (size_t)ld * nr * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { rc = CFMM_E_HIP; break; }
+        (void)hipEventRecord(ctx->ev_t0, ctx->stream);
+        rc = launch_factor(ctx, n);
+        (void)hipEventRecord(ctx->ev_t1, ctx->stream);
+        if (rc == CFMM_OK) rc = launch_backsolve(ctx, n, ctx->sm_vec + n);
+        (void)hipEventRecord(ev_end, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = CFMM_E_HIP; break; }
+        (void)hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1); fac += ms * 1e-3;
+        (void)hipEventElapsedTime(&ms, ctx->ev_t1, ev_end); back += ms * 1e-3;
+    }
+    (void)hipEventDestroy(ev_end);
+    (void)hipFree(keep);
+    if (rc) { const std::string prev = ctx->err; return fail(ctx, rc, "time_newton_kernels: the factorisation launches failed (%s; %s)", prev.c_str(), hipGetErrorString(hipGetLastError())); }
+    out4[2] = fac / reps; out4[3] = back / reps;
     return CFMM_OK;
 }
 

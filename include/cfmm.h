@@ -213,6 +213,10 @@ int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_lau
  * back-to-back launches of the accumulator-slice fold, and `reps` back-to-back RCCL all-reduces of [psi | sum arb]
  * (n + 1 doubles) -- the latter only on a context with a communicator, and then EVERY rank must make this call */
 int cfmm_time_collective(cfmm_ctx *ctx, int reps, double *fold_sec, double *allreduce_sec);
+/* the kernels of one second-order step (bench.py --config C5), each timed over `reps` launches at the current prices and
+ * barrier weight mu: out4 = seconds per {smoothed evaluation with Hessian assembly, smoothed evaluation alone, dense
+ * factorisation (all its launches), back substitution} */
+int cfmm_time_newton_kernels(cfmm_ctx *ctx, double mu, int reps, double *out4);
 /* checks the cross-lane primitives of the update kernels (DPP / v_permlane*_swap / ds_swizzle butterflies and the
  * 64-value reduce-scatter) against exact integer sums on this device; 0 = pass */
 int cfmm_selftest(cfmm_ctx *ctx);
