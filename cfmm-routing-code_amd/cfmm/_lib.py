@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("CFMM_LIB") or os.path.join(_HERE, "libcfmm_hip.so")
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
-POOL_CP2, POOL_W2, POOL_SUM2, POOL_CURVE2 = 0, 1, 2, 3
+POOL_CP2, POOL_W2, POOL_SUM2, POOL_CURVE2, POOL_POW2 = 0, 1, 2, 3, 4
 TIME_ALL = 100
 GE, EQ, FREE = 0, 1, 2
 MAX_POOL_SIZE = 8
@@ -44,7 +44,7 @@ class Stats(C.Structure):
 
 def build(force=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("cfmm_hip.hip", "kernels.hpp", "iterate.hpp", "tiny.hpp", "reorder.hpp", "oneshot.hpp", "pool_math.hpp", "smooth.hpp", "chol.hpp")]
+    srcs = [os.path.join(_CSRC, f) for f in ("cfmm_hip.hip", "kernels.hpp", "iterate.hpp", "tiny.hpp", "reorder.hpp", "oneshot.hpp", "pool_math.hpp", "phi2.hpp", "smooth.hpp", "chol.hpp")]
     srcs.append(os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "cfmm.h"))
     if force or not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _CSRC, "-s"])

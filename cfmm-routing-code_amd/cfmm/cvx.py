@@ -13,6 +13,10 @@ problem's vocabulary and refuses anything else with `NotImplementedError`:
 
   * `geo_mean(R + gamma*D - L, p=w) >= geo_mean(R[, p=w])`      -> a (weighted) geometric-mean pool   arbitrage.py:65,68-70
   * `sum(R + gamma*D - L) >= sum(R)` with `R + gamma*D - L >= 0` -> a constant-sum pool               arbitrage.py:73-74
+  * `sum(x) - alpha*inv_prod(x) >= sum(R) - alpha*inv_prod(R)`,  x = R + gamma*D - L (two assets)  -> a stableswap pool
+  * `sum(power(x, q)) >= sum(power(R, q))`, 0 < q < 1, x as above (two assets)                        -> a power-sum pool
+    (neither is in the reference's scripts: they are how its pattern -- "a pool is whatever constraint line is written",
+     arbitrage.py:63-74 -- extends to the library's other trading functions, in DCP-valid cvxpy)
   * rows of  psi + h (>= | ==) 0  with  psi = sum_i A_i (L_i - D_i)  and a linear objective in psi     -> the utility
     (arbitrage.py:57,77; liquidation.py:57,77-80; two-asset.py:66,86)
 
@@ -84,9 +88,9 @@ class Expression:
             coefs[v] = coefs[v] + sign * c if v in coefs else sign * c
         return Expression(coefs, a.const + sign * b.const, scalar=a.scalar and b.scalar)
 
-    def __add__(self, other): return self._binary(other, 1.0)
+    def __add__(self, other): return NotImplemented if isinstance(other, _ScaledAtom) else self._binary(other, 1.0)
     __radd__ = __add__
-    def __sub__(self, other): return self._binary(other, -1.0)
+    def __sub__(self, other): return NotImplemented if isinstance(other, _ScaledAtom) else self._binary(other, -1.0)
     def __rsub__(self, other): return (-self)._binary(other, 1.0)
     def __neg__(self): return Expression({v: -c for v, c in self.coefs.items()}, -self.const, self.scalar)
 
@@ -189,6 +193,65 @@ class _GeoConstraint:
         self.expr, self.w, self.rhs = expr, w, rhs
 
 
+class _ScaledAtom:
+    """k * inv_prod(x) of an affine x: only ever subtracted from sum(x) (the stableswap trading function)"""
+
+    def __init__(self, expr, k=1.0):
+        self.expr, self.k = expr, float(k)
+
+    def __mul__(self, k): return _ScaledAtom(self.expr, self.k * float(k))
+    __rmul__ = __mul__
+    def __neg__(self): return _ScaledAtom(self.expr, -self.k)
+
+    def __rsub__(self, lin):           # lin - k * inv_prod(x)
+        if not isinstance(lin, Expression) or lin.size != 1 or not self.k > 0:
+            raise NotImplementedError("cfmm.cvx: inv_prod appears only as  sum(x) - alpha * inv_prod(x)  with alpha > 0")
+        return _FnExpr("curve", self.expr, self.k, lin)
+
+    def __radd__(self, lin):           # lin + (-k) * inv_prod(x)
+        return (-self).__rsub__(lin)
+
+
+class _Power:
+    """cp.power(x, q), elementwise, of an affine x: only ever summed (the power-sum trading function)"""
+
+    def __init__(self, expr, q):
+        self.expr, self.q = expr, float(q)
+
+
+class _FnExpr:
+    """a two-asset trading function of x = R + gamma*D - L, waiting for its `>= constant`"""
+
+    def __init__(self, kind, expr, param, lin=None):
+        self.kind, self.expr, self.param, self.lin = kind, expr, param, lin
+
+    def __ge__(self, rhs):
+        if not np.isscalar(rhs) and not (isinstance(rhs, np.ndarray) and rhs.ndim == 0):
+            raise NotImplementedError("cfmm.cvx: a trading function is compared with its value at the current reserves (a number)")
+        return _FnConstraint(self.kind, self.expr, self.param, self.lin, float(rhs))
+
+
+class _FnConstraint:
+    def __init__(self, kind, expr, param, lin, rhs):
+        self.kind, self.expr, self.param, self.lin, self.rhs = kind, expr, param, lin, rhs
+
+
+def inv_prod(x):
+    """cp.inv_prod(x) = 1 / prod(x): a number for a constant x (the right-hand sides)"""
+    if isinstance(x, Expression):
+        return _ScaledAtom(x, 1.0)
+    return float(1.0 / np.prod(np.asarray(x, dtype=np.float64)))
+
+
+def power(x, p):
+    """cp.power(x, p), elementwise: an array for a constant x"""
+    if isinstance(x, Expression):
+        if not 0.0 < float(p) < 1.0:
+            raise NotImplementedError("cfmm.cvx: power(x, p) of a variable needs 0 < p < 1 (the concave range)")
+        return _Power(x, p)
+    return np.power(np.asarray(x, dtype=np.float64), float(p))
+
+
 def geo_mean(x, p=None):
     """cp.geo_mean(x, p): prod_k x_k^(p_k / sum p); a plain number for a constant x (the right-hand sides)"""
     if isinstance(x, Expression):
@@ -206,6 +269,8 @@ def sum(x, axis=None):        # noqa: A001 (mirrors cp.sum)
     """cp.sum: a list of expressions adds elementwise (arbitrage.py:54); an expression or array sums its entries"""
     if isinstance(x, (list, tuple)):
         return builtins.sum(x[1:], x[0])
+    if isinstance(x, _Power):
+        return _FnExpr("powersum", x.expr, 1.0 - x.q)
     if isinstance(x, Expression):
         return np.ones(x.size) @ x
     return float(np.sum(x))
@@ -289,6 +354,26 @@ class Problem:
                 if D in pools:
                     raise NotImplementedError("cfmm.cvx: two trading functions for one pool")
                 pools[D] = dict(D=D, L=L, R=R, fee=g, kind="geomean", w=con.w)
+            elif isinstance(con, _FnConstraint):
+                pl = _pool_of(con.expr)
+                if pl is None or con.expr.size != 2:
+                    raise NotImplementedError("cfmm.cvx: a stableswap / power-sum function must be taken of a two-asset R + gamma*Delta - Lambda")
+                D, L, R, g = pl
+                if con.kind == "curve":
+                    lin = con.lin                  # must be sum(x) of the SAME x
+                    same = set(lin.coefs) == set(con.expr.coefs) and abs(lin.const[0] - R.sum()) <= 1e-12 * R.sum() and \
+                        all(np.allclose(lin.coefs[v], np.ones(2) @ con.expr.coefs[v]) for v in lin.coefs)
+                    if not same:
+                        raise NotImplementedError("cfmm.cvx: inv_prod(x) must be subtracted from sum(x) of the same x")
+                    want = float(R.sum() - con.param / np.prod(R))
+                else:
+                    want = float(np.sum(R ** (1.0 - con.param)))
+                if abs(con.rhs - want) > 1e-9 * max(1.0, abs(want)):
+                    raise NotImplementedError("cfmm.cvx: the right-hand side must be the pool's trading function at its current "
+                                              f"reserves ({want:.12g}), got {con.rhs:.12g}")
+                if D in pools:
+                    raise NotImplementedError("cfmm.cvx: two trading functions for one pool")
+                pools[D] = dict(D=D, L=L, R=R, fee=g, kind=con.kind, w=None, param=float(con.param))
             elif isinstance(con, Constraint):
                 pl = _pool_of(con.expr) if (con.op == ">=" and con.expr.size > 1) else None
                 if pl is not None:
@@ -401,8 +486,8 @@ class Problem:
         pools, local, n, util = self._match()
         tol = float(kw.pop("tol", 1e-9))
         p = _RoutingProblem(n, local, [pl["R"] for pl in pools], [pl["fee"] for pl in pools],
-                            ["geomean" if pl["kind"] == "geomean" else "sum" for pl in pools],
-                            [pl["w"] for pl in pools], utility=util)
+                            [pl["kind"] for pl in pools], [pl["w"] for pl in pools],
+                            [pl.get("param") for pl in pools], utility=util)
         if CONTEXT_FACTORY is not None:
             p.ctx = CONTEXT_FACTORY(n)
         p.solve(tol=tol, **kw)

@@ -18,9 +18,11 @@ Host logic that stays in Python (tiny, O(n) or O(#constant-sum pools)):
 import numpy as np
 
 from . import _lib
-from ._lib import GE, EQ, FREE, POOL_CP2, POOL_W2, POOL_SUM2, POOL_CURVE2, MAX_POOL_SIZE, CfmmError
+from ._lib import GE, EQ, FREE, POOL_CP2, POOL_W2, POOL_SUM2, POOL_CURVE2, POOL_POW2, MAX_POOL_SIZE, CfmmError
 
-KIND2 = dict(cp2=POOL_CP2, w2=POOL_W2, sum2=POOL_SUM2, curve2=POOL_CURVE2)
+KIND2 = dict(cp2=POOL_CP2, w2=POOL_W2, sum2=POOL_SUM2, curve2=POOL_CURVE2, pow2=POOL_POW2)
+# the name of a two-asset bucket's parameter column (None: the kind has none)
+PARAM2 = dict(cp2=None, w2="wa", sum2=None, curve2="alpha", pow2="t")
 
 
 # ------------------------------------------------------------------------------- utilities
@@ -60,13 +62,14 @@ def Swap(current_assets, target):
 def pack(n_tokens, local_indices, reserves, fees, kinds=None, weights=None, params=None):
     """Ragged pool list (reference vocabulary) -> SoA buckets + `where[i] = (bucket, position)`.
 
-    kinds[i]: "geomean" (default) | "sum" | "curve";  weights[i]: geo-mean exponents (None =
-    equal, i.e. Uniswap v2 for two assets);  params[i]: alpha of a curve pool."""
+    kinds[i]: "geomean" (default) | "sum" | "curve" | "powersum";  weights[i]: geo-mean exponents (None =
+    equal, i.e. Uniswap v2 for two assets);  params[i]: alpha of a curve pool, the exponent t of a power-sum pool
+    (x^(1-t) + y^(1-t): the generic bucket's first tenant, include/cfmm.h CFMM_POOL_POW2)."""
     m = len(local_indices)
     kinds = ["geomean"] * m if kinds is None else list(kinds)
     weights = [None] * m if weights is None else list(weights)
     params = [None] * m if params is None else list(params)
-    rows = dict(cp2=[], w2=[], sum2=[], curve2=[])
+    rows = dict(cp2=[], w2=[], sum2=[], curve2=[], pow2=[])
     rows_n = {}
     where = []
     for i in range(m):
@@ -108,10 +111,15 @@ def pack(n_tokens, local_indices, reserves, fees, kinds=None, weights=None, para
                 raise ValueError(f"pool {i}: curve pools are two-asset and need params[i] = alpha")
             where.append(("curve2", len(rows["curve2"])))
             rows["curve2"].append((R[0], R[1], fees[i], float(params[i]), l[0], l[1]))
+        elif kind == "powersum":
+            if k != 2 or params[i] is None or not (1e-3 <= float(params[i]) <= 0.999):
+                raise ValueError(f"pool {i}: power-sum pools are two-asset and need params[i] = t in [0.001, 0.999]")
+            where.append(("pow2", len(rows["pow2"])))
+            rows["pow2"].append((R[0], R[1], fees[i], float(params[i]), l[0], l[1]))
         else:
             raise ValueError(f"pool {i}: unknown kind {kind!r}")
     net = dict(n_tokens=int(n_tokens))
-    pname = dict(cp2=None, w2="wa", sum2=None, curve2="alpha")
+    pname = PARAM2
     for key, rr in rows.items():
         if not rr:
             continue
@@ -171,10 +179,10 @@ def start_prices(net, util):
     eu, ev, elr = [], [], []          # log p_u - log p_v = lr
     # a rough guess is all this has to be (the solvers start by repairing it): on large networks every bucket is
     # thinned to an evenly strided sample, ~64 price relations per token in all
-    total = sum(len(net[k]["Ra"]) for k in ("cp2", "w2", "sum2", "curve2") if k in net) + \
+    total = sum(len(net[k]["Ra"]) for k in KIND2 if k in net) + \
         sum((kk - 1) * b["R"].shape[1] for kk, b in net.get("gn", {}).items())
     stride = max(1, total // (64 * n))
-    for key in ("cp2", "w2", "sum2", "curve2"):
+    for key in KIND2:
         if key not in net:
             continue
         b = net[key]
@@ -187,6 +195,8 @@ def start_prices(net, util):
             lr = np.log(wa * Rb / ((1 - wa) * Ra))
         elif key == "sum2":
             lr = np.zeros(len(Ra))
+        elif key == "pow2":
+            lr = b["t"][sl] * np.log(Rb / Ra)
         else:
             al = b["alpha"][sl]
             lr = np.log((1 + al / (Ra * Ra * Rb)) / (1 + al / (Ra * Rb * Rb)))
@@ -359,7 +369,7 @@ class Problem:
         from as many host threads."""
         utilities = list(utilities)
         ctx = self._ensure_ctx()
-        can_batch = (hasattr(ctx, "solve_batch") and "sum2" not in self.net and "curve2" not in self.net and self._host is None
+        can_batch = (hasattr(ctx, "solve_batch") and "sum2" not in self.net and "curve2" not in self.net and "pow2" not in self.net and self._host is None
                      and not self.deterministic and kw.get("method", "auto") in ("auto", "lbfgs"))
         if batch is None:
             batch = ctx.batch_capacity() if can_batch else 0
@@ -451,7 +461,7 @@ class Problem:
             for key, kind in KIND2.items():
                 if key in self.net:
                     b = self.net[key]
-                    param = b.get("wa") if key == "w2" else (b.get("alpha") if key == "curve2" else None)
+                    param = b.get(PARAM2[key]) if PARAM2[key] else None
                     self.ctx.upload_pools2(kind, b["Ra"], b["Rb"], b["fee"], b["ia"], b["ib"], param)
             for k, b in self.net.get("gn", {}).items():
                 self.ctx.upload_poolsN(b["idx"], b["R"], b["w"], b["fee"])
@@ -789,7 +799,7 @@ class Problem:
         return self._trade_cache
 
     def bucket_trades(self, key):
-        """(delta, lambda), slot-major [k][m], of one bucket ('cp2', 'w2', 'sum2', 'curve2' or a pool size)"""
+        """(delta, lambda), slot-major [k][m], of one bucket ('cp2', 'w2', 'sum2', 'curve2', 'pow2' or a pool size)"""
         return self._trades()[key]
 
     def _per_pool(self, which):

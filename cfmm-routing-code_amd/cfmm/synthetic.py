@@ -31,7 +31,7 @@ def _pairs(rng, n, m, zipf_s=None):
 
 
 def make_network(n_tokens, m_cp2=0, m_w2=0, m_gn=0, m_curve2=0, seed=0, zipf_s=None,
-                 gn_sizes=(3, 8), mispricing=0.02, pool_seed=None):
+                 gn_sizes=(3, 8), mispricing=0.02, pool_seed=None, m_pow2=0):
     """Returns a dict of SoA buckets:
 
       prices   : latent pi[n]
@@ -94,6 +94,16 @@ def make_network(n_tokens, m_cp2=0, m_w2=0, m_gn=0, m_curve2=0, seed=0, zipf_s=N
             R[0] *= np.exp(rng.normal(0.0, mispricing, mk))
             gn[k] = dict(R=R, w=w, idx=idx, fee=FEES[rng.integers(0, len(FEES), mk)])
         out["gn"] = gn
+    if m_pow2:
+        # power-sum pools x^(1-t) + y^(1-t) (the generic bucket's tenant): marginal price p_a / p_b = (Rb / Ra)^t, so reserves
+        # with Ra^t pi_a = Rb^t pi_b sit at the market; value L on the first leg, a mispricing like everyone else's
+        ia, ib = _pairs(rng, n, m_pow2, zipf_s)
+        t = np.array([0.2, 0.35, 0.5, 0.65, 0.8])[rng.integers(0, 5, m_pow2)]
+        L = value(m_pow2)
+        Ra = L / pi[ia]
+        Rb = Ra * (pi[ia] / pi[ib]) ** (1.0 / t)
+        Ra = Ra * np.exp(rng.normal(0.0, mispricing, m_pow2))
+        out["pow2"] = dict(Ra=Ra, Rb=Rb, fee=FEES[rng.integers(0, len(FEES), m_pow2)], t=t, ia=ia, ib=ib)
     if m_curve2:
         # stable pairs: a Curve pool joins two tokens of one peg group (4 consecutive token ids
         # share a latent price up to 0.2 %, see `peg` below), so it sits near its 1:1 point.
@@ -137,6 +147,8 @@ def config(name, seed=0, scale=1.0, pool_seed=None):
         return make_network(2000, m_cp2=s(10_000_000), seed=seed)
     if name == "C4shard":  # one GPU's share of C4
         return make_network(2000, m_cp2=s(1_250_000), seed=seed)
+    if name == "G4":      # the generic bucket: power-sum pools among constant-product and weighted ones (tests; not a BASELINE config)
+        return make_network(200, m_cp2=s(20_000), m_w2=s(5_000), m_gn=s(3_000), m_pow2=s(20_000), seed=seed)
     if name == "C5":      # 5e5 Curve pools + basket liquidation
         return make_network(1000, m_cp2=s(50_000), m_curve2=s(500_000), seed=seed)
     raise ValueError(name)

@@ -620,7 +620,8 @@ size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 16 * 64 + 64 + 32 + 2 * 
 
 // processing order of the fused evaluation kernel (heaviest first): bucket code = -k for the
 // k-asset geo-mean buckets, CFMM_POOL_* for the two-asset ones
-const int kOrder[N_BUCKETS] = {-8, -7, -6, -5, -4, -3, CFMM_POOL_CURVE2, CFMM_POOL_W2, CFMM_POOL_CP2, CFMM_POOL_SUM2};
+const int kOrder[N_BUCKETS] = {-8, -7, -6, -5, -4, -3, CFMM_POOL_CURVE2, CFMM_POOL_POW2, CFMM_POOL_W2, CFMM_POOL_CP2, CFMM_POOL_SUM2};
+static_assert(N_KINDS2 == CFMM_POOL_KINDS2, "kernels.hpp and include/cfmm.h disagree on the two-asset kinds");
 
 // reproducible mode: contributions to psi are bounded by (largest reserve) / (smallest fee); they are scaled by 2^F with
 // F such that their 96-bit fixed-point image keeps 10 bits of head-room (kernels.hpp: Scatter<true>).  The diagonal
@@ -649,7 +650,7 @@ EvalArgs make_eval_args(cfmm_ctx *ctx, bool stable, int only = 0x7fffffff)
         const int code = kOrder[q];
         const long long m = code < 0 ? ctx->pools->bn[-code].m : ctx->pools->b2[code].m;
         const int wt = wave_tile_pools(code);
-        if ((only == 0x7fffffff || only == code) && ((code == CFMM_POOL_CURVE2) == stable)) tiles += (m + wt - 1) / wt;
+        if ((only == 0x7fffffff || only == code) && ((code >= 0 && heavy_kind(code)) == stable)) tiles += (m + wt - 1) / wt;
         a.tile_end[q] = (int)tiles;
     }
     a.ntiles = (int)tiles;
@@ -684,7 +685,7 @@ static bool pingpong_on(const cfmm_ctx *ctx)
     static const int mode = getenv("CFMM_PINGPONG") ? atoi(getenv("CFMM_PINGPONG")) : -1;      // (A/B: 0 never, 1 always)
     if (mode >= 0) return mode != 0;
     double b2 = 0.0, bn = 0.0;
-    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) b2 += (double)ctx->pools->b2[k].m * ((k == CFMM_POOL_W2 || k == CFMM_POOL_CURVE2) ? 40.0 : 32.0);
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) b2 += (double)ctx->pools->b2[k].m * ((k == CFMM_POOL_CP2 || k == CFMM_POOL_SUM2) ? 32.0 : 40.0);
     for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) bn += (double)ctx->pools->bn[k].m * (20.0 + 20.0 * k);
     return bn <= 0.1 * (b2 + bn);
 }
@@ -714,12 +715,20 @@ int det_finish(cfmm_ctx *ctx, double *out, const double *nu, bool with_d)
     return CFMM_OK;
 }
 
-// one dual evaluation of every bucket: one launch, plus one for the stableswap bucket when there is one
+// pools of the "heavy" two-asset kinds (kernels.hpp: heavy_kind): they are evaluated by eval_kernel<., STABLE = true>
+int64_t heavy_pools(const cfmm_ctx *ctx)
+{
+    int64_t m = 0;
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) if (heavy_kind(k)) m += ctx->pools->b2[k].m;
+    return m;
+}
+
+// one dual evaluation of every bucket: one launch, plus one for the heavy buckets (stableswap, generic) when there are any
 template <bool WITH_D>
 void launch_all_evals(cfmm_ctx *ctx)
 {
     launch_eval<WITH_D, false>(ctx, make_eval_args(ctx, false));
-    if (ctx->pools->b2[CFMM_POOL_CURVE2].m > 0) launch_eval<WITH_D, true>(ctx, make_eval_args(ctx, true));
+    if (heavy_pools(ctx) > 0) launch_eval<WITH_D, true>(ctx, make_eval_args(ctx, true));
 }
 
 template <class F>
@@ -803,7 +812,7 @@ UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
 // ---- tiny networks (the reference's own instances): the whole solve in one launch of one workgroup (tiny.hpp) -----
 bool tiny_applies(cfmm_ctx *ctx, const EvalArgs &ea, const cfmm_opts &o)
 {
-    return ctx->tiny_path && !sharded(ctx) && !ctx->det && ctx->pools->b2[CFMM_POOL_CURVE2].m == 0 && ea.ntiles >= 1 &&
+    return ctx->tiny_path && !sharded(ctx) && !ctx->det && heavy_pools(ctx) == 0 && ea.ntiles >= 1 &&
            ea.ntiles <= TINY_MAX_TILES && ctx->n <= TINY_N && o.memory <= MAX_MEMORY;
 }
 
@@ -839,7 +848,7 @@ IterArgs make_iter_args(cfmm_ctx *ctx, const cfmm_opts &o)
 // collectives can be skipped on the device, so the host may run ahead of it as on a single GPU
 bool oneshot_runahead(cfmm_ctx *ctx)
 {
-    return ctx->os_ready && !ctx->det && (size_t)acc_stride(ctx->n) <= ctx->os_cap && ctx->pools->b2[CFMM_POOL_CURVE2].m == 0;
+    return ctx->os_ready && !ctx->det && (size_t)acc_stride(ctx->n) <= ctx->os_cap && heavy_pools(ctx) == 0;
 }
 
 // outer iteration t >= 1 as ONE launch (+ the stableswap bucket's own evaluation launch, + fold / all-reduce when
@@ -870,7 +879,7 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
     if (E == 1) ITER_LAUNCH(ITER_E_SMALL); else ITER_LAUNCH(2);
 #undef ITER_LAUNCH
     double *acc_p = ctx->acc3 + (size_t)a.phase * acc_set_doubles(ctx);
-    if (ctx->pools->b2[CFMM_POOL_CURVE2].m > 0) {              // the stableswap bucket has its own instantiation: it reads the
+    if (heavy_pools(ctx) > 0) {                                // the heavy buckets have their own instantiation: it reads the
         EvalArgs es = make_eval_args(ctx, true);              // prices (and the stop flag) workgroup 0 has just stored
         es.nu = ctx->nu; es.acc = acc_p;
         launch_eval<false, true>(ctx, es);
@@ -1092,7 +1101,7 @@ int smooth_buffers(cfmm_ctx *ctx, bool hess)
         if ((rc = set_lds_attr(ctx, smooth_kernel<false>, lds))) return rc;
         if ((rc = set_lds_attr(ctx, smooth_kernel<true>, lds))) return rc;
     }
-    for (int k : {CFMM_POOL_CP2, CFMM_POOL_W2, CFMM_POOL_CURVE2}) {           // warm starts: sized by the bucket as it is NOW (pools may be re-uploaded)
+    for (int k : {CFMM_POOL_CP2, CFMM_POOL_W2, CFMM_POOL_CURVE2, CFMM_POOL_POW2}) {           // warm starts: sized by the bucket as it is NOW (pools may be re-uploaded)
         const long long m = ctx->pools->b2[k].m;
         if (ctx->sm_ws_m[k] == m) continue;
         if (ctx->sm_ws[k]) { (void)hipFree(ctx->sm_ws[k]); ctx->sm_ws[k] = nullptr; }
@@ -1118,9 +1127,9 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm, bool with_slo)
     for (int k = 0; k < CFMM_POOL_KINDS2; ++k) a.b2[k] = ctx->pools->b2[k];
     a.b2[CFMM_POOL_SUM2].flags = ctx->flags2;
     for (int k = 0; k < CFMM_POOL_KINDS2; ++k) a.ws[k] = warm ? ctx->sm_ws[k] : nullptr;
-    const int order[4] = {CFMM_POOL_CURVE2, CFMM_POOL_W2, CFMM_POOL_CP2, CFMM_POOL_SUM2};
+    const int order[CFMM_POOL_KINDS2] = {CFMM_POOL_CURVE2, CFMM_POOL_POW2, CFMM_POOL_W2, CFMM_POOL_CP2, CFMM_POOL_SUM2};
     long long tiles = 0;
-    for (int q = 0; q < 4; ++q) { tiles += (a.b2[order[q]].m + 63) / 64; a.tile_end[q] = (int)tiles; }
+    for (int q = 0; q < CFMM_POOL_KINDS2; ++q) { tiles += (a.b2[order[q]].m + 63) / 64; a.tile_end[q] = (int)tiles; }
     a.ntiles = (int)tiles; a.n = n; a.nu = ctx->nu; a.slo = with_slo ? ctx->sm_slo : nullptr; a.mu = mu; a.out = ctx->sm_out; a.H = hess ? ctx->H : nullptr; a.ldh = hess_ld(n);
     HIP_TRY(ctx, hipMemsetAsync(ctx->sm_out, 0, (size_t)(n + 2) * sizeof(double), ctx->stream));
     if (hess) HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, (size_t)hess_ld(n) * hess_nr(n) * sizeof(double), ctx->stream));
@@ -1571,7 +1580,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     ctx->pools.reset();
     if (ctx->flags2) (void)hipFree(ctx->flags2);
     if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
-    for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_ws[4], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
     if (ctx->dev_arena) (void)hipFree(ctx->dev_arena);
     if (ctx->host_arena) (void)hipHostFree(ctx->host_arena);
     if (ctx->hstat_h) (void)hipHostFree((void *)ctx->hstat_h);
@@ -1703,6 +1712,18 @@ static void release_landed(cfmm_ctx *ctx)
     for (void *q : mine) (void)hipFree(q);
 }
 
+// The two-asset kinds as the upload layer sees them: one generic bucket (columns Ra, Rb, fee, [param], ia, ib), per kind
+// only whether a parameter column is required and which values it may hold.  A new trading function is one row here and
+// one Phi2<KIND> in phi2.hpp.
+struct Kind2Info { const char *name; bool needs_param; bool (*param_ok)(double); const char *param_rule; };
+static const Kind2Info kKind2[CFMM_POOL_KINDS2] = {
+    {"constant product", false, nullptr, ""},
+    {"weighted geometric mean", true, [](double x) { return x > 0.0 && x < 1.0; }, "a weight in (0, 1)"},
+    {"constant sum", false, nullptr, ""},
+    {"stableswap", true, [](double x) { return x > 0.0 && x <= std::numeric_limits<double>::max(); }, "alpha > 0"},
+    {"power sum", true, [](double x) { return x >= 1e-3 && x <= 0.999; }, "an exponent t in [0.001, 0.999]"},
+};
+
 int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, const double *Rb, const double *fee,
                        const double *param, const int32_t *ia, const int32_t *ib)
 {
@@ -1710,7 +1731,7 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
     if (kind < 0 || kind >= CFMM_POOL_KINDS2 || m < 0) return fail(ctx, CFMM_E_ARG, "upload_pools2: kind %d, m %lld", kind, (long long)m);
     if (m >= (1ll << 29)) return fail(ctx, CFMM_E_LIMIT, "upload_pools2: %lld pools in one bucket (the kernels address a column with 32-bit byte offsets: < 2^29)", (long long)m);
     if (m > 0 && (!Ra || !Rb || !fee || !ia || !ib)) return fail(ctx, CFMM_E_ARG, "upload_pools2: NULL column");
-    if (m > 0 && (kind == CFMM_POOL_W2 || kind == CFMM_POOL_CURVE2) && !param) return fail(ctx, CFMM_E_ARG, "upload_pools2: kind %d needs param", kind);
+    if (m > 0 && kKind2[kind].needs_param && !param) return fail(ctx, CFMM_E_ARG, "upload_pools2: kind %d (%s) needs param", kind, kKind2[kind].name);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_pools2: the pools are shared with a clone (cfmm_clone); destroy the clones first");
     if (ctx->pools->b2mem[kind]) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // (replacing a bucket kernels may still be reading)
@@ -1730,8 +1751,7 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
         cols.push_back(checked_col<double>(Rb, m, (void **)&b.Rb, &scan, 0, reserve_ok));
         cols.push_back(checked_col<double>(fee, m, (void **)&b.fee, &scan, 1, [](double x) { return x > 0.0 && x <= 1.0; }));
         if (param) {
-            if (kind == CFMM_POOL_W2) cols.push_back(checked_col<double>(param, m, (void **)&b.param, &scan, 2, [](double x) { return x > 0.0 && x < 1.0; }));
-            else if (kind == CFMM_POOL_CURVE2) cols.push_back(checked_col<double>(param, m, (void **)&b.param, &scan, 2, [](double x) { return x > 0.0; }));
+            if (kKind2[kind].param_ok) cols.push_back(checked_col<double>(param, m, (void **)&b.param, &scan, 2, kKind2[kind].param_ok));
             else cols.push_back(plain_col(param, m * sizeof(double), (void **)&b.param));
         }
         cols.push_back(checked_col<int32_t>(ia, m, (void **)&b.ia, &scan, 2, [ntok](int32_t v) { return (uint32_t)v < (uint32_t)ntok; }));
@@ -1760,6 +1780,8 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
                 if (!(fee[i] > 0.0 && fee[i] <= 1.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has fee %g outside (0, 1]", q, fee[i]);
                 if (kind == CFMM_POOL_W2 && !(param[i] > 0.0 && param[i] < 1.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has weight %g outside (0, 1)", q, param[i]);
                 if (kind == CFMM_POOL_CURVE2 && !(param[i] > 0.0)) return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld has alpha %g <= 0", q, param[i]);
+                if (param && kKind2[kind].param_ok && !kKind2[kind].param_ok(param[i]))
+                    return fail(ctx, CFMM_E_ARG, "upload_pools2: pool %lld (%s) has parameter %g: expected %s", q, kKind2[kind].name, param[i], kKind2[kind].param_rule);
             }
             return fail(ctx, CFMM_E_ARG, "upload_pools2: a column failed its checks");
         }
@@ -2286,7 +2308,7 @@ int cfmm_solve_batch(cfmm_ctx *const *ctxs, int nb, const double *const *nu0, co
         HIP_TRY(c0, hipStreamSynchronize(c->stream));
     }
     if (cfmm_pool_count(c0) == 0) return fail(c0, CFMM_E_STATE, "solve_batch: no pools uploaded");
-    if (c0->pools->b2[CFMM_POOL_CURVE2].m > 0) return fail(c0, CFMM_E_UNSUPPORTED, "solve_batch: stableswap pools take the second-order path, one solve at a time");
+    if (heavy_pools(c0) > 0) return fail(c0, CFMM_E_UNSUPPORTED, "solve_batch: stableswap / generic-bucket pools are evaluated by their own launch: one solve at a time");
     if (!c0->upd_batch_d) {
         HIP_TRY(c0, hipMalloc((void **)&c0->upd_batch_d, BATCH_MAX * sizeof(UpdArgs)));
         HIP_TRY(c0, hipHostMalloc((void **)&c0->upd_batch_h, BATCH_MAX * sizeof(UpdArgs), hipHostMallocDefault));
@@ -2410,14 +2432,16 @@ int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda)
         case 0: hipLaunchKernelGGL(smooth_trades_kernel<0>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, slo, mu, dd, dl); break;
         case 1: hipLaunchKernelGGL(smooth_trades_kernel<1>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, slo, mu, dd, dl); break;
         case 2: hipLaunchKernelGGL(smooth_trades_kernel<2>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, slo, mu, dd, dl); break;
-        default: hipLaunchKernelGGL(smooth_trades_kernel<3>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, slo, mu, dd, dl); break;
+        case 3: hipLaunchKernelGGL(smooth_trades_kernel<3>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, slo, mu, dd, dl); break;
+        default: hipLaunchKernelGGL(smooth_trades_kernel<4>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, slo, mu, dd, dl); break;
         }
     } else
     switch (kind) {
     case 0: hipLaunchKernelGGL(trades2_kernel<0>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;
     case 1: hipLaunchKernelGGL(trades2_kernel<1>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;
     case 2: hipLaunchKernelGGL(trades2_kernel<2>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;
-    default: hipLaunchKernelGGL(trades2_kernel<3>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;
+    case 3: hipLaunchKernelGGL(trades2_kernel<3>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;
+    default: hipLaunchKernelGGL(trades2_kernel<4>, grid, blk, 0, ctx->stream, b, (const double *)ctx->nu_acc, dd, dl); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "get_trades2 -> %s", hipGetErrorString(e));
@@ -2609,11 +2633,12 @@ int cfmm_selftest(cfmm_ctx *ctx)
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
     hipLaunchKernelGGL(selftest_gram_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
     hipLaunchKernelGGL(selftest_log_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
+    hipLaunchKernelGGL(selftest_generic_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
     hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "selftest -> %s", hipGetErrorString(e));
-    if (h != 0) return fail(ctx, CFMM_E_NUMERIC, "selftest: %d results of the cross-lane reductions / the fast logarithm are wrong on this device / ROCm", h);
+    if (h != 0) return fail(ctx, CFMM_E_NUMERIC, "selftest: %d results of the cross-lane reductions / the fast logarithm / the generic pool solver are wrong on this device / ROCm", h);
     return CFMM_OK;
 }
 

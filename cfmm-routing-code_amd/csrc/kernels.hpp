@@ -16,6 +16,7 @@
 // The second-order outer iteration lives in smooth.hpp (barrier-smoothed evaluation, Hessian) and chol.hpp (dense solve).
 #pragma once
 #include "pool_math.hpp"
+#include "phi2.hpp"
 
 namespace cfmm {
 
@@ -50,7 +51,12 @@ __host__ __device__ constexpr int wave_tile_pools(int code)     // code: CFMM_PO
     return code < 0 ? 64 / (-code)                     // k-asset geo-mean: one LEG per lane
                     : ((code == 0 || code == 2) ? WT_LIGHT : WT_HEAVY);
 }
-constexpr int N_BUCKETS = 10;         // gn8 gn7 gn6 gn5 gn4 gn3 curve2 w2 cp2 sum2 (processing order)
+constexpr int N_BUCKETS = 11;         // gn8 gn7 gn6 gn5 gn4 gn3 curve2 pow2 w2 cp2 sum2 (processing order)
+constexpr int N_KINDS2 = 5;           // CFMM_POOL_KINDS2: cp2, w2, sum2, curve2, and the generic bucket's first tenant pow2 (phi2.hpp)
+// "heavy" two-asset kinds: evaluated by an iteration per pool (stableswap's own Newton loop; every kind that goes through
+// pool_generic2).  They live in the tile space of eval_kernel<., STABLE = true>, a launch of its own: their loops need
+// ~20 more VGPRs than the closed forms, which the main instantiation cannot spare.
+__host__ __device__ constexpr bool heavy_kind(int kind) { return kind == 3 || kind == 4; }
 
 struct DevState {
     int status, evals, iters, first, hist, head, nrej, pad;
@@ -74,7 +80,7 @@ struct BucketN {
 };
 
 struct EvalArgs {
-    Bucket2 b2[4];                    // indexed by CFMM_POOL_* kind
+    Bucket2 b2[N_KINDS2];             // indexed by CFMM_POOL_* kind
     BucketN bn[6];                    // bn[k - 3], k = 3..8
     int tile_end[N_BUCKETS];          // cumulative wave-tile counts in processing order
     int ntiles, n, nslices;
@@ -203,7 +209,7 @@ struct BatchCtl { unsigned alive; int nu_stride, tile_stride; };
 // ------------------------------------------------------------------------------------------
 // one wave-tile of a two-asset bucket: lane l solves pools i0 + l + 64 u, u < U.  All 5U column
 // loads are issued before the first use (each 512 B coalesced per wave).
-// 32 B (CP2, SUM2) or 40 B (W2, CURVE2) of HBM per pool, read once.
+// 32 B (CP2, SUM2) or 40 B (W2, CURVE2, POW2: + the parameter column) of HBM per pool, read once.
 // ------------------------------------------------------------------------------------------
 template <int KIND, bool WITH_D, bool DET, bool BATCH = false>
 __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, const double *nu_s,
@@ -224,7 +230,7 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
         i = live[u] ? i : (unsigned)b.m - 1u;
         Ra[u] = ld_off(b.Ra, i); Rb[u] = ld_off(b.Rb, i); g[u] = ld_off(b.fee, i);
         ia[u] = ld_off(b.ia, i); ib[u] = ld_off(b.ib, i);
-        prm[u] = (KIND == 1 || KIND == 3) ? ld_off(b.param, i) : 0.0;
+        prm[u] = (KIND == 1 || KIND >= 3) ? ld_off(b.param, i) : 0.0;
         fl[u] = (KIND == 2 && b.flags) ? ld_off(b.flags, i) : 0;
     }
 #pragma unroll 1
@@ -248,7 +254,8 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
             if (KIND == 0) y = pool_cp2(Ra[u], Rb[u], g[u], pa, pb);
             else if (KIND == 1) y = pool_w2<DET>(Ra[u], Rb[u], g[u], prm[u], pa, pb);
             else if (KIND == 2) { y = pool_sum2(Ra[u], Rb[u], g[u], pa, pb); if (fl[u]) { y.ya = 0.0; y.yb = 0.0; } }
-            else y = pool_curve2(Ra[u], Rb[u], g[u], prm[u], pa, pb);
+            else if (KIND == 3) y = pool_curve2(Ra[u], Rb[u], g[u], prm[u], pa, pb);
+            else y = pool_generic2<(KIND >= 4 ? KIND : 4)>(Ra[u], Rb[u], g[u], prm[u], pa, pb);      // every kind without a hand-tuned closed form
             if (live[u] && (y.ya != 0.0 || y.yb != 0.0)) {
                 ps.add(ia[u], y.ya);
                 ps.add(ib[u], y.yb);
@@ -258,7 +265,8 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
                 double da = 0.0, db = 0.0;
                 if (KIND == 0) { da = 0.5 * pa * Ra[u]; db = 0.5 * pb * Rb[u]; }
                 else if (KIND == 1) { da = (1.0 - prm[u]) * pa * Ra[u]; db = prm[u] * pb * Rb[u]; }
-                else curve_diag(Ra[u], Rb[u], prm[u], pa, pb, da, db);
+                else if (KIND == 3) curve_diag(Ra[u], Rb[u], prm[u], pa, pb, da, db);
+                else generic_diag<(KIND >= 4 ? KIND : 4)>(Ra[u], Rb[u], prm[u], pa, pb, da, db);
                 diag_s.add(ia[u], da);
                 diag_s.add(ib[u], db);
             }
@@ -464,8 +472,9 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
         case 4: if constexpr (!STABLE) { tilen<4, WITH_D, DET, BATCH>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
         case 5: if constexpr (!STABLE) { tilen<3, WITH_D, DET, BATCH>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
         case 6: if constexpr (STABLE) { tile2<3, WITH_D, DET, BATCH>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
-        case 7: if constexpr (!STABLE) { tile2<1, WITH_D, DET, BATCH>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
-        case 8: if constexpr (!STABLE) { tile2<0, WITH_D, DET, BATCH>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 7: if constexpr (STABLE) { tile2<4, WITH_D, DET, BATCH>(a.b2[4], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 8: if constexpr (!STABLE) { tile2<1, WITH_D, DET, BATCH>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 9: if constexpr (!STABLE) { tile2<0, WITH_D, DET, BATCH>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
         default: if constexpr (!STABLE) { tile2<2, WITH_D, DET, BATCH>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
         }
 #ifdef CFMM_PHASE_TIMERS
@@ -634,7 +643,8 @@ trades2_kernel(Bucket2 b, const double *__restrict__ nu, double *__restrict__ de
     if (KIND == 0) y = pool_cp2(Ra, Rb, g, pa, pb);
     else if (KIND == 1) y = pool_w2(Ra, Rb, g, b.param[i], pa, pb);
     else if (KIND == 2) { y = pool_sum2(Ra, Rb, g, pa, pb); if (b.flags && b.flags[i]) { y.ya = 0.0; y.yb = 0.0; } }
-    else y = pool_curve2(Ra, Rb, g, b.param[i], pa, pb);
+    else if (KIND == 3) y = pool_curve2(Ra, Rb, g, b.param[i], pa, pb);
+    else y = pool_generic2<(KIND >= 4 ? KIND : 4)>(Ra, Rb, g, b.param[i], pa, pb);
     const long long o = b.perm ? b.perm[i] : i;          // (the tenders go out in the caller's pool order)
     delta[o] = fmax(-y.ya, 0.0);  delta[b.m + o] = fmax(-y.yb, 0.0);
     lambda[o] = fmax(y.ya, 0.0);  lambda[b.m + o] = fmax(y.yb, 0.0);
@@ -1807,6 +1817,56 @@ selftest_kernel(int *out)
     double want = 0.0;
     for (int l = 0; l < 64; ++l) want += (double)(((l + 3) * (lane + 5)) % 23) - 7.0;      // total of quantity `lane`
     if (wave_reduce_scatter64(V, lane) != want) ++bad;
+    atomicAdd(out, bad);
+}
+
+// self-test of the generic exact pool (phi2.hpp): pool_generic2 -- the root search on the table entry's L', started from
+// D = 0, no closed form used -- against the hand-tuned closed forms of the constant-product, weighted and stableswap kinds
+// on 64 x 48 random pools and prices from 30 % below to 30 % above the pools' own; and the power-sum entry against ITS
+// closed form (which the exact path never uses).  Counts tenders more than 1e-11 of the reserve apart.
+__global__ void __launch_bounds__(64)
+selftest_generic_kernel(int *out)
+{
+    int bad = 0;
+    unsigned long long st = 0x9E3779B97F4A7C15ull * (threadIdx.x + 1);
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) * (1.0 / 9007199254740992.0); };
+    for (int k = 0; k < 48; ++k) {
+        const double Ra = exp(10.0 * rnd() - 2.0), Rb = exp(10.0 * rnd() - 2.0);
+        const double g = 1.0 - 0.01 * rnd();
+        const double pa = exp(0.6 * rnd() - 0.3), wa = 0.1 + 0.8 * rnd(), t = 0.05 + 0.9 * rnd();
+        auto cmp = [&](const Y2 &a, const Y2 &b) {
+            if (!(fabs(a.ya - b.ya) <= 1e-11 * Ra && fabs(a.yb - b.yb) <= 1e-11 * Rb)) ++bad;
+        };
+        {   // constant product: the pool's own price ratio is Rb / Ra ... (pa / pb = Rb / Ra at no trade)
+            const double pb = pa * Ra / Rb * exp(0.6 * rnd() - 0.3);
+            cmp(pool_generic2<0>(Ra, Rb, g, 0.0, pa, pb), pool_cp2(Ra, Rb, g, pa, pb));
+        }
+        {   // weighted: pa / pb = (wa / wb) Rb / Ra
+            const double pb = pa * (1.0 - wa) / wa * Ra / Rb * exp(0.6 * rnd() - 0.3);
+            cmp(pool_generic2<1>(Ra, Rb, g, wa, pa, pb), pool_w2(Ra, Rb, g, wa, pa, pb));
+        }
+        {   // stableswap near its peg
+            const double Rb2 = Ra * exp(0.4 * rnd() - 0.2), al = Ra * Ra * Rb2 * (0.05 + rnd());
+            const double pb = pa * exp(0.02 * rnd() - 0.01);
+            const Y2 a = pool_generic2<3>(Ra, Rb2, g, al, pa, pb), b = pool_curve2(Ra, Rb2, g, al, pa, pb);
+            if (!(fabs(a.ya - b.ya) <= 1e-10 * Ra && fabs(a.yb - b.yb) <= 1e-10 * Rb2)) ++bad;
+        }
+        {   // power sum: pa / pb = (Rb / Ra)^t; closed form: (y / x)^t = nu_in / (gamma nu_out) on the level set
+            const double pb = pa * exp(t * log(Ra / Rb)) * exp(0.6 * rnd() - 0.3);
+            const Y2 a = pool_generic2<4>(Ra, Rb, g, t, pa, pb);
+            Y2 b; b.ya = 0.0; b.yb = 0.0;
+            const double q = 1.0 - t, K = exp(q * log(Ra)) + exp(q * log(Rb));
+            auto dir = [&](double Rin, double Rout, double ni, double no, double &yin, double &yout) {
+                if (!(no * g * exp(t * log(Rout / Rin)) > ni)) return false;
+                const double rho = ni / (g * no);
+                const double x = exp(log(K / (1.0 + exp((q / t) * log(rho)))) / q), y = x * exp(log(rho) / t);
+                yin = -(x - Rin) / g; yout = Rout - y;
+                return true;
+            };
+            if (!dir(Ra, Rb, pa, pb, b.ya, b.yb)) dir(Rb, Ra, pb, pa, b.yb, b.ya);
+            if (!(fabs(a.ya - b.ya) <= 1e-10 * Ra && fabs(a.yb - b.yb) <= 1e-10 * Rb)) ++bad;
+        }
+    }
     atomicAdd(out, bad);
 }
 

@@ -23,119 +23,9 @@
 //   smooth_trades_kernel       the interior tenders cfmm_get_trades2 returns after a second-order solve
 //   hess_finish_kernel         diagonal terms, pinned tokens, padding, right-hand side -> chol.hpp's layout
 #pragma once
-#include "kernels.hpp"
+#include "kernels.hpp"       // (phi2.hpp: the trading-function table, shared with the exact evaluation)
 
 namespace cfmm {
-
-struct Fwd { double L, L1, L2; };       // L(D), L'(D), L''(D)
-
-// (reciprocals and square roots through rcp_nr / rsqrt_nr, pool_math.hpp: <= ~1 ulp, a third of the
-//  instructions of the IEEE sequences -- this path is fp64-issue bound like the exact evaluation)
-
-__device__ __forceinline__ double curve_y_stable(double x, double ix, double C, double al)
-{
-    const double b = C - x, q = 4.0 * al * ix;
-    const double sq = sqrt_nr(fma(b, b, q));
-    return b >= 0.0 ? 0.5 * (b + sq) : 0.5 * q * rcp_nr(sq - b);
-}
-
-// ---- the trading-function table of the second-order path ---------------------------------------
-// A two-asset trading function enters the smoothed evaluation, its Hessian and the interior tenders ONLY through the five
-// members below: a new function is one more Phi2<KIND> (plus its bucket in the upload layer and its closed form -- or a
-// generic root search on the same L' -- in pool_math.hpp for the exact first-order evaluation).
-//   fwd(D, Rin, Rout, g, r, C)   L(D), L'(D), L''(D) of the forward exchange function L(D) = R_out - Y(R_in + g D) on the
-//                                pool's level set (arbitrage.py:60,63-74), formed without cancellation
-//   marginal0(Rin, Rout, g, r)   L'(0), without a curve solve
-//   ratio(prm, a_to_b)           the direction's parameter r from the pool's stored parameter
-//   level(Ra, Rb, prm)           a per-pool constant C handed to fwd (0 where the function needs none)
-//   start(...)                   a starting tender on the trade side: the exact mu = 0 root where it is closed form, an
-//                                estimate otherwise, <= 0 for "none" (the barrier model at D = 0 is used then)
-template <int KIND> struct Phi2;
-
-template <> struct Phi2<0> {                       // constant product (arbitrage.py:68-70)
-    static __device__ __forceinline__ Fwd fwd(double D, double Rin, double Rout, double g, double, double)
-    {
-        Fwd o;
-        const double ix = rcp_nr(fma(g, D, Rin));
-        const double gy = g * Rout * ix;                   // L = gamma D R_out / x  (no cancellation)
-        o.L = D * gy;
-        o.L1 = gy * Rin * ix;                              // gamma k / x^2
-        o.L2 = -2.0 * g * o.L1 * ix;
-        return o;
-    }
-    static __device__ __forceinline__ double marginal0(double Rin, double Rout, double g, double) { return g * Rout * rcp_nr(Rin); }
-    static __device__ __forceinline__ double ratio(double, bool) { return 0.0; }
-    static __device__ __forceinline__ double level(double, double, double) { return 0.0; }
-    static __device__ __forceinline__ double start(double Rin, double Rout, double g, double, double, double ni, double no)
-    {
-        return (sqrt_nr(g * no * Rin * Rout * rcp_nr(ni)) - Rin) * rcp_nr(g);
-    }
-};
-
-template <> struct Phi2<1> {                       // weighted geometric mean, r = w_in / w_out (arbitrage.py:65 with two tokens)
-    static __device__ __forceinline__ Fwd fwd(double D, double Rin, double Rout, double g, double r, double)
-    {
-        Fwd o;
-        const double ix = rcp_nr(fma(g, D, Rin));
-        const double lq = -r * log1p(g * D * rcp_nr(Rin)); // log (R_in / x)^r
-        const double q = exp(lq);
-        o.L = -Rout * expm1(lq);
-        o.L1 = g * Rout * r * q * ix;
-        o.L2 = -g * (r + 1.0) * o.L1 * ix;
-        return o;
-    }
-    static __device__ __forceinline__ double marginal0(double Rin, double Rout, double g, double r) { return g * r * Rout * rcp_nr(Rin); }
-    static __device__ __forceinline__ double ratio(double wa, bool a_to_b) { return a_to_b ? wa / (1.0 - wa) : (1.0 - wa) / wa; }
-    static __device__ __forceinline__ double level(double, double, double) { return 0.0; }
-    static __device__ __forceinline__ double start(double Rin, double Rout, double g, double r, double, double ni, double no)
-    {
-        return Rin * expm1(log(g * no * Rout * r / (ni * Rin)) / (r + 1.0)) / g;
-    }
-};
-
-template <> struct Phi2<3> {                       // stableswap  x + y - alpha / (x y),  r = alpha, C = the pool's level
-    static __device__ __forceinline__ Fwd fwd(double D, double Rin, double Rout, double g, double al, double C)
-    {
-        Fwd o;
-        const double x = fma(g, D, Rin);
-        const double ix = rcp_nr(x);
-        const double y = curve_y_stable(x, ix, C, al);
-        const double iy = rcp_nr(y);
-        const double t = al * ix * iy;                     // alpha / (x y)
-        const double fx = fma(t, ix, 1.0), fy = fma(t, iy, 1.0);
-        const double ify = rcp_nr(fy);
-        const double y1 = -fx * ify;
-        const double fxx = -2.0 * t * ix * ix, fxy = -t * ix * iy, fyy = -2.0 * t * iy * iy;
-        const double y2 = -(fxx + 2.0 * fxy * y1 + fyy * y1 * y1) * ify;
-        o.L = Rout - y;
-        o.L1 = -g * y1;
-        o.L2 = -g * g * y2;
-        return o;
-    }
-    static __device__ __forceinline__ double marginal0(double Rin, double Rout, double g, double al)
-    {
-        const double t = al * rcp_nr(Rin * Rout);
-        return g * fma(t, rcp_nr(Rin), 1.0) * rcp_nr(fma(t, rcp_nr(Rout), 1.0));
-    }
-    static __device__ __forceinline__ double ratio(double al, bool) { return al; }
-    static __device__ __forceinline__ double level(double Ra, double Rb, double al) { return Ra + Rb - al / (Ra * Rb); }
-    // where the marginal price m = phi_x / phi_y has dropped to rho = nu_in / (gamma nu_out): for y << x,
-    // 1 - m ~ alpha rho / (x y^2) with x ~ C - y (three fixed-point sweeps) -- a few per cent off the root at the 80/20
-    // imbalance such trades end at, from where the iteration converges in 5-6 steps (from D = 0 it first overshoots the
-    // knee and needs 12-16)
-    static __device__ __forceinline__ double start(double Rin, double Rout, double g, double al, double C, double ni, double no)
-    {
-        if (!(no * marginal0(Rin, Rout, g, al) - ni > 0.0)) return 0.0;       // no-trade side
-        const double rho = ni * rcp_nr(g * no);
-        if (!(rho < 1.0)) return 0.0;
-        const double k = al * rho * rcp_nr(1.0 - rho);
-        double y = sqrt_nr(k * rcp_nr(C));
-        y = sqrt_nr(k * rcp_nr(C - y));
-        y = sqrt_nr(k * rcp_nr(C - y));
-        const double D0 = (C - y - Rin) * rcp_nr(g);
-        return (D0 > 0.0 && D0 < 1e300) ? D0 : 0.0;
-    }
-};
 
 template <int KIND>
 __device__ __forceinline__ Fwd fwd2(double D, double Rin, double Rout, double g, double r, double C) { return Phi2<KIND>::fwd(D, Rin, Rout, g, r, C); }
@@ -260,9 +150,9 @@ __device__ __forceinline__ Branch smooth_branch_sum(double Rout, double g, doubl
 }
 
 struct SmoothArgs {
-    Bucket2 b2[4];
-    double *ws[4];              // per kind: [2][m] roots of the previous evaluation (warm start), or null
-    int tile_end[4];            // cumulative wave-tiles (64 pools) in the order curve2, w2, cp2, sum2
+    Bucket2 b2[N_KINDS2];
+    double *ws[N_KINDS2];       // per kind: [2][m] roots of the previous evaluation (warm start), or null
+    int tile_end[N_KINDS2];     // cumulative wave-tiles (64 pools) in the order curve2, pow2, w2, cp2, sum2
     int ntiles, n;
     const double *nu;           // [n] prices
     const double *slo;          // [n] low-order part of the log-prices (see smooth_tile), or null
@@ -361,12 +251,13 @@ smooth_kernel(SmoothArgs a)
         if (lane == 0) ticket = atomicAdd(next_tile, 1);
         int bk = 0;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bk += (t >= a.tile_end[q]) ? 1 : 0;
+        for (int q = 0; q < N_KINDS2 - 1; ++q) bk += (t >= a.tile_end[q]) ? 1 : 0;
         const long long i0 = (long long)(t - (bk ? a.tile_end[bk - 1] : 0)) * 64;
         switch (bk) {
         case 0: smooth_tile<3, HESS>(a.b2[3], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
-        case 1: smooth_tile<1, HESS>(a.b2[1], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
-        case 2: smooth_tile<0, HESS>(a.b2[0], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
+        case 1: smooth_tile<4, HESS>(a.b2[4], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
+        case 2: smooth_tile<1, HESS>(a.b2[1], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
+        case 3: smooth_tile<0, HESS>(a.b2[0], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
         default: smooth_tile<2, HESS>(a.b2[2], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
         }
     }

@@ -58,7 +58,12 @@ enum {
     CFMM_POOL_W2 = 1,       /* weighted geo-mean x^wa y^(1-wa)    arbitrage.py:65 (2 assets); param = wa */
     CFMM_POOL_SUM2 = 2,     /* constant sum x+y, x,y >= 0         arbitrage.py:73-74; param = NULL  */
     CFMM_POOL_CURVE2 = 3,   /* x + y - alpha/(xy) (StableSwap at fixed D)  not in reference; param = alpha */
-    CFMM_POOL_KINDS2 = 4
+    CFMM_POOL_POW2 = 4,     /* power sum x^(1-t) + y^(1-t) (YieldSpace's curve; t -> 0: constant sum, t -> 1: towards constant
+                               product)  not in reference; param = t in [0.001, 0.999].  The first tenant of the GENERIC
+                               bucket: it has no code of its own beyond one table entry (csrc/phi2.hpp: Phi2<4>) -- the exact
+                               pool solution, the diagonal metric, the smoothed solution and the tenders all come from the
+                               generic root search on that entry's forward exchange function, on both outer iterations   */
+    CFMM_POOL_KINDS2 = 5
 };
 #define CFMM_MAX_POOL_SIZE 8    /* n-asset geo-mean pools: 3..8 assets, one bucket per size */
 

@@ -20,7 +20,7 @@ pinned against finite differences of themselves and, through the solves they dri
 """
 import numpy as np
 
-KCP, KW, KSUM, KCV = 0, 1, 2, 3          # CFMM_POOL_* codes
+KCP, KW, KSUM, KCV, KPW = 0, 1, 2, 3, 4          # CFMM_POOL_* codes
 
 
 def branches(net):
@@ -38,6 +38,8 @@ def branches(net):
         b = net["w2"]; add(KW, "w2", b, b["wa"] / (1 - b["wa"]), (1 - b["wa"]) / b["wa"])
     if "curve2" in net:
         b = net["curve2"]; add(KCV, "curve2", b, b["alpha"], b["alpha"])
+    if "pow2" in net:
+        b = net["pow2"]; add(KPW, "pow2", b, b["t"], b["t"])
     if "sum2" in net: add(KSUM, "sum2", net["sum2"])
     out = {k: np.concatenate(v) for k, v in cols.items() if v}
     out["Ri"] = out["Ri"].astype(float); out["Ro"] = out["Ro"].astype(float)
@@ -62,9 +64,17 @@ def forward(br, D):
         fxx = -2 * al / (x ** 3 * Y); fxy = -al / (x * x * Y * Y); fyy = -2 * al / (x * Y ** 3)
         Y2 = -(fxx + 2 * fxy * Y1 + fyy * Y1 * Y1) / fy
         Lc = Ro - Y; L1c = -fee * Y1; L2c = -fee * fee * Y2
-    L = np.select([kind == KCP, kind == KW, kind == KCV], [Lp, Lw, Lc], fee * D)
-    L1 = np.select([kind == KCP, kind == KW, kind == KCV], [L1p, L1w, L1c], fee)
-    L2 = np.select([kind == KCP, kind == KW, kind == KCV], [L2p, L2w, L2c], 0.0)
+        # power sum x^q + y^q, q = 1 - t (par = t): y from the level set directly (a different route from the library's
+        # log1p / expm1 form), L' = gamma (y / x)^t, L'' = -t L' (L' / y + gamma / x)
+        tq = np.where(kind == KPW, par, 0.5); qq = 1.0 - tq
+        yq = np.maximum(Ro ** qq - (x ** qq - Ri ** qq), 0.0)
+        Yp = yq ** (1.0 / qq)
+        Lpw = Ro - Yp; L1pw = np.where(Yp > 0, fee * (Yp / x) ** tq, 0.0)
+        L2pw = np.where(Yp > 0, -tq * L1pw * (L1pw / np.where(Yp > 0, Yp, 1.0) + fee / x), -1e-300)
+    ks = [kind == KCP, kind == KW, kind == KCV, kind == KPW]
+    L = np.select(ks, [Lp, Lw, Lc, Lpw], fee * D)
+    L1 = np.select(ks, [L1p, L1w, L1c, L1pw], fee)
+    L2 = np.select(ks, [L2p, L2w, L2c, L2pw], 0.0)
     return L, L1, L2
 
 

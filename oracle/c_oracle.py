@@ -10,8 +10,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libcfmm_oracle.so")
 
-K_CP2, K_W2, K_SUM2, K_CURVE2 = 0, 1, 2, 3
-KIND2 = dict(cp2=K_CP2, w2=K_W2, sum2=K_SUM2, curve2=K_CURVE2)
+K_CP2, K_W2, K_SUM2, K_CURVE2, K_POW2 = 0, 1, 2, 3, 4
+KIND2 = dict(cp2=K_CP2, w2=K_W2, sum2=K_SUM2, curve2=K_CURVE2, pow2=K_POW2)
 
 
 def build(force=False):
@@ -118,6 +118,8 @@ class Oracle:
             b = net["sum2"]; self.add_pools2("sum2", b["Ra"], b["Rb"], b["fee"], b["ia"], b["ib"], tied=b.get("tied"))
         if "curve2" in net:
             b = net["curve2"]; self.add_pools2("curve2", b["Ra"], b["Rb"], b["fee"], b["ia"], b["ib"], param=b["alpha"])
+        if "pow2" in net:
+            b = net["pow2"]; self.add_pools2("pow2", b["Ra"], b["Rb"], b["fee"], b["ia"], b["ib"], param=b["t"])
         for k in sorted(net.get("gn", {})):
             b = net["gn"][k]; self.add_poolsN(b["idx"], b["R"], b["w"], b["fee"])
 

@@ -180,7 +180,38 @@ static inline void curve_diag(double Ra, double Rb, double al, double pa, double
 
 /* ---------------------------------------------------------------- problem container */
 
-enum { K_CP2 = 0, K_W2 = 1, K_SUM2 = 2, K_CURVE2 = 3 };
+enum { K_CP2 = 0, K_W2 = 1, K_SUM2 = 2, K_CURVE2 = 3, K_POW2 = 4 };
+
+/* power sum  x^(1-t) + y^(1-t)  (not in the reference; the generic bucket's tenant, include/cfmm.h CFMM_POOL_POW2): the
+ * CLOSED FORM -- (y/x)^t = pin / (gamma pout) on the level set -- which the library's exact path does not use (it runs
+ * a generic root search on the forward exchange function): the two derivations are independent. */
+static inline int pow2_dir(double Rin, double Rout, double g, double t, double pin, double pout, double *yin, double *yout)
+{
+    if (!(g * pout * pow(Rout / Rin, t) > pin)) return 0;
+    /* x^q = K / (1 + rho^(q/t)), y = x rho^(1/t), in logarithms of x / R_in and y / R_out: forming R - x directly loses the
+     * trade (and the profit, a difference of the two legs' values) of a pool with very unequal reserves to cancellation */
+    const double q = 1.0 - t, lrho = log(pin / (g * pout));
+    const double a = pow(Rout / Rin, q), b = exp(lrho * q / t);
+    const double lx = log1p((a - b) / (1.0 + b)) / q;      /* the price condition fixes the tender ... */
+    const double z = expm1(q * lx) / a;                    /* ... and the level set what is received: (x^q - R_in^q) / R_out^q */
+    const double ly = log1p(-z) / q;                       /* (y = x rho^(1/t) in logarithms keeps five digits of a 1e-12 change) */
+    *yin = -Rin * expm1(lx) / g; *yout = -Rout * expm1(ly);
+    return 1;
+}
+static inline void pool_pow2(double Ra, double Rb, double g, double t, double pa, double pb, double *ya, double *yb)
+{
+    *ya = 0.0; *yb = 0.0;
+    if (pow2_dir(Ra, Rb, g, t, pa, pb, ya, yb)) return;
+    pow2_dir(Rb, Ra, g, t, pb, pa, yb, ya);
+}
+/* its share of the diagonal metric: nu_in L'(0) / |L''(0)| per direction with L' = (y/x)^t, L'' = -t L' (L'/y + 1/x) at
+ * gamma = 1 (the general rule of csrc/phi2.hpp: generic_diag) */
+static inline void pow2_diag(double Ra, double Rb, double t, double pa, double pb, double *da, double *db)
+{
+    const double la = pow(Rb / Ra, t), lb = pow(Ra / Rb, t);
+    *da = pa * la / (t * la * (la / Rb + 1.0 / Ra));
+    *db = pb * lb / (t * lb * (lb / Ra + 1.0 / Rb));
+}
 
 typedef struct {
     int kind; int64_t m;
@@ -298,6 +329,7 @@ double oracle_eval(oracle_t *o, const double *nu, double *psi, double *diag)
                 case K_CP2:    pool_geomean2(Ra, Rb, g, 0.5, pa, pb, &ya, &yb); break;
                 case K_W2:     pool_geomean2(Ra, Rb, g, B->param[i], pa, pb, &ya, &yb); break;
                 case K_SUM2:   pool_sum2(Ra, Rb, g, pa, pb, B->tied ? B->tied[i] : 0, &ya, &yb); break;
+                case K_POW2:   pool_pow2(Ra, Rb, g, B->param[i], pa, pb, &ya, &yb); break;
                 default:       pool_curve2(Ra, Rb, g, B->param[i], pa, pb, &ya, &yb); break;
                 }
                 lp[ia] += ya; lp[ib] += yb;
@@ -306,6 +338,7 @@ double oracle_eval(oracle_t *o, const double *nu, double *psi, double *diag)
                     if (B->kind == K_CP2) { ld[ia] += 0.5 * pa * Ra; ld[ib] += 0.5 * pb * Rb; }
                     else if (B->kind == K_W2) { double wa = B->param[i]; ld[ia] += (1.0 - wa) * pa * Ra; ld[ib] += wa * pb * Rb; }
                     else if (B->kind == K_CURVE2) { double da, db; curve_diag(Ra, Rb, B->param[i], pa, pb, &da, &db); ld[ia] += da; ld[ib] += db; }
+                    else if (B->kind == K_POW2) { double da, db; pow2_diag(Ra, Rb, B->param[i], pa, pb, &da, &db); ld[ia] += da; ld[ib] += db; }
                 }
             }
         }
@@ -349,6 +382,7 @@ void oracle_trades2(oracle_t *o, int b, const double *nu, double *ya, double *yb
         case K_CP2:    pool_geomean2(B->Ra[i], B->Rb[i], B->fee[i], 0.5, pa, pb, &ya[i], &yb[i]); break;
         case K_W2:     pool_geomean2(B->Ra[i], B->Rb[i], B->fee[i], B->param[i], pa, pb, &ya[i], &yb[i]); break;
         case K_SUM2:   pool_sum2(B->Ra[i], B->Rb[i], B->fee[i], pa, pb, B->tied ? B->tied[i] : 0, &ya[i], &yb[i]); break;
+        case K_POW2:   pool_pow2(B->Ra[i], B->Rb[i], B->fee[i], B->param[i], pa, pb, &ya[i], &yb[i]); break;
         default:       pool_curve2(B->Ra[i], B->Rb[i], B->fee[i], B->param[i], pa, pb, &ya[i], &yb[i]); break;
         }
     }

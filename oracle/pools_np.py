@@ -168,3 +168,33 @@ def arb_curve2(Ra, Rb, gamma, alpha, pa, pb, iters=60):
         else:
             ya = yb = 0.0
     return np.array([ya, yb]), float(pa * ya + pb * yb)
+
+
+def arb_power2(Ra, Rb, gamma, t, pa, pb):
+    """Power-sum pool  phi(x, y) = x^(1-t) + y^(1-t),  0 < t < 1  (YieldSpace's curve; not in the reference -- the first
+    tenant of the library's GENERIC two-asset bucket, include/cfmm.h CFMM_POOL_POW2).  CLOSED FORM, which the library's
+    exact path deliberately does not use (it finds the same root by a safeguarded Newton search on the table entry's L'):
+    marginal price of a in units of b at reserves (x, y):  m = phi_x / phi_y = (y / x)^t.  Tender a iff
+    gamma pb m(R) > pa; at the optimum (y / x)^t = rho := pa / (gamma pb), on the level set x^q + y^q = K, q = 1 - t:
+        x = (K / (1 + rho^(q/t)))^(1/q),   y = x rho^(1/t).
+    Vectorised over pools."""
+    Ra, Rb, gamma, t, pa, pb = (np.asarray(v, float) for v in (Ra, Rb, gamma, t, pa, pb))
+    q = 1.0 - t
+
+    def one_dir(Rin, Rout, pin, pout):
+        # (in logarithms of x / R_in and y / R_out: R - x formed directly loses the trade of a pool whose reserves differ by
+        #  ten orders of magnitude -- and its profit, a difference of the two legs' values -- to cancellation)
+        trade = gamma * pout * (Rout / Rin) ** t > pin
+        lrho = np.log(pin / (gamma * pout))
+        a, bb = (Rout / Rin) ** q, np.exp(lrho * q / t)
+        lx = np.log1p((a - bb) / (1.0 + bb)) / q               # log(x / R_in),  x^q = K / (1 + rho^(q/t))  [the price condition]
+        # what is received follows from the level set, not from y = x rho^(1/t): out of a reserve 1e10 times the other one
+        # log(y / R_out) is ~1e-12, and lx - log(R_out / R_in) + log(rho) / t would keep five digits of it
+        z = np.expm1(q * lx) / a                               # (x^q - R_in^q) / R_out^q
+        ly = np.log1p(-z) / q
+        return trade, np.where(trade, -Rin * np.expm1(lx) / gamma, 0.0), np.where(trade, -Rout * np.expm1(ly), 0.0)
+    tab, ya1, yb1 = one_dir(Ra, Rb, pa, pb)
+    tba, yb2, ya2 = one_dir(Rb, Ra, pb, pa)
+    ya = np.where(tab, ya1, np.where(tba, ya2, 0.0))
+    yb = np.where(tab, yb1, np.where(tba, yb2, 0.0))
+    return ya, yb, pa * ya + pb * yb

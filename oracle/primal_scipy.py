@@ -17,7 +17,8 @@ from scipy.optimize import minimize
 
 def solve_primal(inst, x0=None, ftol=1e-15, maxiter=2000):
     """inst: a dict produced by oracle.instances.normalise (or the same fields).
-    Extra pool kind "curve" takes inst["params"][i] = alpha.
+    Extra pool kinds: "curve" takes inst["params"][i] = alpha (x + y - alpha / (xy)); "powersum" takes params[i] = t
+    (x^(1-t) + y^(1-t)).
     Returns dict(value, psi, deltas, lambdas, y) with y[i] = lambdas[i] - deltas[i]."""
     n = inst["n_tokens"]
     L = inst["local_indices"]
@@ -69,6 +70,11 @@ def solve_primal(inst, x0=None, ftol=1e-15, maxiter=2000):
                 xp = np.maximum(xi, 1e-9 * Ri)                   # inv_prod's domain is x > 0
                 out.append(np.sum(xi) - al / np.prod(xp) - (np.sum(Ri) - al / np.prod(Ri)))
                 out.extend(xi - 1e-9 * Ri)
+            elif K[i] == "powersum":
+                q = 1.0 - P[i]
+                xp = np.maximum(xi, 1e-12 * Ri)
+                out.append((np.sum(xp ** q) - np.sum(Ri ** q)) / np.sum(Ri ** q))
+                out.extend(xi - 1e-12 * Ri)
             else:
                 raise ValueError(K[i])
         psi = psi_of(z)
@@ -98,6 +104,13 @@ def solve_primal(inst, x0=None, ftol=1e-15, maxiter=2000):
                 al = P[i]
                 xp = np.maximum(xi, 1e-9 * R[i])
                 rows.append(row_from(1.0 + al / (np.prod(xp) * xp)))
+                for k in range(sizes[i]):
+                    e = np.zeros(sizes[i]); e[k] = 1.0
+                    rows.append(row_from(e))
+            elif K[i] == "powersum":
+                q = 1.0 - P[i]
+                xp = np.maximum(xi, 1e-12 * R[i])
+                rows.append(row_from(q * xp ** (q - 1.0) / np.sum(R[i] ** q)))
                 for k in range(sizes[i]):
                     e = np.zeros(sizes[i]); e[k] = 1.0
                     rows.append(row_from(e))

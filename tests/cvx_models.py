@@ -19,12 +19,18 @@ def build(cp, inst):
     net = cp.sum([S @ (lam - dlt) for S, dlt, lam in zip(select, tender, receive)])
     after = [np.asarray(R, float) + fee * dlt - lam for (_, R, fee, _, _), dlt, lam in zip(pools, tender, receive)]
     cons = []
-    for (idx, R, fee, kind, w), x in zip(pools, after):
+    for i, ((idx, R, fee, kind, w), x) in enumerate(zip(pools, after)):
         R = np.asarray(R, float)
         if kind == "geomean" and w is not None:
             cons.append(cp.geo_mean(x, p=np.asarray(w, float)) >= cp.geo_mean(R, p=np.asarray(w, float)))
         elif kind == "geomean":
             cons.append(cp.geo_mean(x) >= cp.geo_mean(R))
+        elif kind == "curve":          # (not in the reference: the same pattern for the library's stableswap pool, DCP-valid cvxpy)
+            al = float(inst["params"][i])
+            cons.append(cp.sum(x) - al * cp.inv_prod(x) >= float(np.sum(R) - al / np.prod(R)))
+        elif kind == "powersum":       # (likewise: the generic bucket's power-sum pool)
+            q = 1.0 - float(inst["params"][i])
+            cons.append(cp.sum(cp.power(x, q)) >= float(np.sum(R ** q)))
         else:
             cons += [cp.sum(x) >= cp.sum(R), x >= 0]
     u = inst["utility"]

@@ -40,7 +40,7 @@ def shipped_cases():
     return cases
 
 
-def random_instance(seed, n_tokens=6, n_pools=12, with_sum=True, with_curve=False, utility="arbitrage", two_asset_only=False):
+def random_instance(seed, n_tokens=6, n_pools=12, with_sum=True, with_curve=False, utility="arbitrage", two_asset_only=False, with_power=False):
     """small random instance in the reference's vocabulary, connected enough to be interesting"""
     rng = np.random.default_rng(seed)
     price = np.exp(rng.normal(0, 0.5, n_tokens))
@@ -52,7 +52,7 @@ def random_instance(seed, n_tokens=6, n_pools=12, with_sum=True, with_curve=Fals
             kind = "geomean"
         else:
             k = 2
-            kind = "sum" if (with_sum and r > 0.9) else ("curve" if (with_curve and r > 0.75) else "geomean")
+            kind = "sum" if (with_sum and r > 0.9) else ("curve" if (with_curve and r > 0.75) else ("powersum" if (with_power and r > 0.5) else "geomean"))
         l = rng.choice(n_tokens, size=k, replace=False)
         val = np.exp(rng.normal(3, 1))
         if kind == "geomean":
@@ -63,6 +63,11 @@ def random_instance(seed, n_tokens=6, n_pools=12, with_sum=True, with_curve=Fals
             W.append(w); P.append(None)
         elif kind == "sum":
             res = val / price[l].mean() * np.exp(rng.normal(0, 0.1, k)); W.append(None); P.append(None)
+        elif kind == "powersum":       # marginal price (Rb / Ra)^t: reserves that sit near the market
+            t = float(rng.choice([0.25, 0.5, 0.7]))
+            ra = val / price[l[0]]
+            res = np.array([ra, ra * (price[l[0]] / price[l[1]]) ** (1.0 / t)]) * np.exp(rng.normal(0, 0.05, 2))
+            W.append(None); P.append(t)
         else:
             res = val / price[l].mean() * np.exp(rng.normal(0, 0.05, k)); W.append(None)
             P.append(float(_syn.curve_alpha_from_A(res[0], res[1], 20.0)))

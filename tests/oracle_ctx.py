@@ -5,7 +5,7 @@ import numpy as np
 
 from oracle.c_oracle import Oracle
 
-_K = {0: "cp2", 1: "w2", 2: "sum2", 3: "curve2"}
+_K = {0: "cp2", 1: "w2", 2: "sum2", 3: "curve2", 4: "pow2"}
 
 
 class OracleContext:

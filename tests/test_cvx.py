@@ -119,6 +119,51 @@ def test_models_outside_the_routing_class_are_refused(oracle_device):
         cp.Problem(cp.Maximize((l - d)[0]), [cp.geo_mean(R + 0.99 * d - l) >= 5.0, (l - d)[1] + 1 >= 0]).solve()
 
 
+def _other_functions_instance(seed):
+    """a small network in which the stableswap and the power-sum pool appear as cvxpy constraint lines"""
+    from helpers import random_instance
+    inst = random_instance(40 + seed, n_tokens=5, n_pools=9, with_sum=False, with_curve=True, with_power=True)
+    assert "curve" in inst["kinds"] and "powersum" in inst["kinds"]
+    return inst
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_stableswap_and_power_sum_constraint_lines_are_recognised(oracle_device, seed):
+    """`cp.sum(x) - alpha*cp.inv_prod(x) >= ...` and `cp.sum(cp.power(x, q)) >= ...` (DCP-valid cvxpy for the library's two
+    trading functions the reference does not ship) map onto the curve / power-sum buckets: same optimum as the primal
+    SciPy model of the same program"""
+    from helpers import normalise_with_params
+    from oracle.primal_scipy import solve_primal
+    inst = _other_functions_instance(seed)
+    prob, goal, net, tender, receive = cvx_models.build(cp, inst)
+    v = prob.solve(tol=1e-9)
+    r = solve_primal(normalise_with_params(inst))
+    assert prob.status == cp.OPTIMAL and abs(v - r["value"]) <= 2e-6 * max(1.0, abs(v))
+    assert sorted(k for k in ("curve2", "pow2") if k in prob.routing.net) == ["curve2", "pow2"]
+    # a right-hand side that is not the function's value at the current reserves is refused, as for geo_mean
+    d, l = cp.Variable(2, nonneg=True), cp.Variable(2, nonneg=True)
+    R = np.array([3.0, 4.0])
+    x = R + 0.99 * d - l
+    with pytest.raises(NotImplementedError, match="current"):
+        cp.Problem(cp.Maximize((l - d)[0]), [cp.sum(cp.power(x, 0.5)) >= 1.0, (l - d)[1] + 1 >= 0]).solve()
+    with pytest.raises(NotImplementedError, match="same x"):
+        cp.Problem(cp.Maximize((l - d)[0]), [cp.sum(R + 0.98 * d - l) - 2.0 * cp.inv_prod(x) >= float(R.sum() - 2.0 / R.prod()), (l - d)[1] + 1 >= 0]).solve()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(2))
+def test_stableswap_and_power_sum_constraint_lines_on_the_gpu(seed):
+    from helpers import normalise_with_params
+    from oracle.primal_scipy import solve_primal
+    cp.CONTEXT_FACTORY = None
+    inst = _other_functions_instance(seed)
+    prob, goal, net, tender, receive = cvx_models.build(cp, inst)
+    v = prob.solve(tol=1e-9)
+    r = solve_primal(normalise_with_params(inst))
+    assert prob.status == cp.OPTIMAL and abs(v - r["value"]) <= 2e-6 * max(1.0, abs(v))
+    prob.routing.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,inst", shipped_cases())
 def test_shipped_programs_through_the_shim_on_the_gpu(name, inst):

@@ -250,6 +250,69 @@ def test_random_small_instances_vs_primal(seed):
     p.close()
 
 
+def test_generic_bucket_power_sum_pools_end_to_end(oracle_lib):
+    """SURVEY 8(f) rank 4 on the device: a trading function that exists in the library as ONE table entry (csrc/phi2.hpp:
+    Phi2<4>, the power sum x^(1-t) + y^(1-t)) and rides in the generic two-asset bucket.  Its exact pool solution, its share of
+    the diagonal metric, its tenders, its barrier-smoothed solution and Hessian term all come from the generic code on that
+    entry; the oracle's closed form (which the device never uses) is the independent check.  20 000 such pools among
+    28 000 pools of the reference's kinds, 200 tokens."""
+    from oracle import barrier_np
+    net = synthetic.config("G4", seed=2)
+    n = net["n_tokens"]
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    p._ensure_ctx().selftest()             # includes pool_generic2 on the three closed-form kinds, started from D = 0
+    o = _oracle_for(oracle_lib, net)
+    nu = net["c"] * np.exp(np.random.default_rng(7).normal(0, 0.04, n))
+    f, psi, diag = p.eval_dual(nu, want_diag=True)
+    f0, psi0, diag0 = o.eval(nu, True)
+    assert abs(f - f0) <= 1e-10 * abs(f0) and np.abs(psi - psi0).max() <= 1e-10 * np.abs(psi0).max()
+    assert np.abs(diag - diag0).max() <= 1e-10 * np.abs(diag0).max()
+    # the pool-by-pool tenders of the generic bucket, and the invariant they preserve
+    p.ctx.set_nu(nu)
+    d, l = p.bucket_trades("pow2")
+    ya, yb = o.trades2([k for k, _ in o.b2].index("pow2"), nu)
+    b = net["pow2"]
+    assert np.all(d >= 0) and np.all(l >= 0) and np.all(d * l == 0)
+    assert np.abs((l - d)[0] - ya).max() <= 1e-10 * b["Ra"].max() and np.abs((l - d)[1] - yb).max() <= 1e-10 * b["Rb"].max()
+    q = 1.0 - b["t"]
+    xa, xb = b["Ra"] + b["fee"] * d[0] - l[0], b["Rb"] + b["fee"] * d[1] - l[1]
+    assert np.abs((xa ** q + xb ** q) / (b["Ra"] ** q + b["Rb"] ** q) - 1).max() <= 1e-12
+    assert ((l - d)[0] != 0).mean() > 0.5
+    # the solve, first order and second order, against the oracle's solver
+    r = o.solve(net["c"], tol=1e-6)
+    v1 = p.solve(tol=1e-6, method="lbfgs")
+    assert p.status == "optimal" and abs(v1 - r["primal_value"]) <= 2e-6 * abs(v1)
+    v2 = p.solve(tol=1e-6, method="newton")
+    assert p.status == "optimal" and abs(v2 - r["primal_value"]) <= 2e-6 * abs(v2) and p.stats["newton_steps"] >= 2
+    # the smoothed evaluation (value, psi, Hessian) against its NumPy restatement
+    small = synthetic.make_network(40, m_cp2=300, m_pow2=500, seed=9)
+    ps = cfmm.Problem.from_network(small, utility=cfmm.Arbitrage(small["c"]))
+    nus = small["prices"] * np.exp(np.random.default_rng(1).normal(0, 0.03, 40))
+    for mu in (1e-2, 1e-6):
+        val, tr, psm, H = ps._ensure_ctx().eval_smooth(nus, mu, want_hessian=True)
+        ref = barrier_np.smooth_eval(small, nus, mu, hessian=True)
+        assert abs(val - ref["value"]) <= 1e-9 * max(1.0, abs(ref["value"])) and np.abs(psm - ref["psi"]).max() <= 1e-9 * np.abs(ref["psi"]).max()
+        assert np.abs(np.tril(H) - np.tril(ref["H"])).max() <= 1e-7 * np.abs(ref["H"]).max()
+    ps.close(); p.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_small_instances_with_power_sum_pools_vs_primal(seed):
+    """the generic bucket on the reference's own scale: 5 tokens / 10 pools with power-sum pools among geo-mean ones,
+    both outer iterations, against the primal program solved by SciPy with the same phi"""
+    from oracle.primal_scipy import solve_primal
+    inst = random_instance(30 + seed, n_tokens=5, n_pools=10, with_sum=False, with_power=True, utility=["arbitrage", "swap"][seed % 2])
+    r = solve_primal(normalise_with_params(inst))
+    p = problem_of(inst)
+    for method in ("lbfgs", "newton"):
+        v = p.solve(tol=1e-9, method=method)
+        assert p.status == "optimal", (method, p.status)
+        assert abs(v - r["value"]) <= 2e-6 * max(1.0, abs(v)), (method, v, r["value"])
+        for d, l, y in zip(p.deltas, p.lambdas, r["y"]):
+            assert np.abs((l - d) - y).max() <= 2e-4 * max(1.0, np.abs(y).max())
+    p.close()
+
+
 def test_error_behaviour():
     ctx = _lib.Context(4)
     with pytest.raises(cfmm.CfmmError, match="token ids"):

@@ -280,3 +280,61 @@ def test_barrier_oracle_k_asset_block_by_finite_differences():
         gp = np.exp(s0 + d) * barrier_np.smooth_eval(net, np.exp(s0 + d), mu)["psi"]
         gm = np.exp(s0 - d) * barrier_np.smooth_eval(net, np.exp(s0 - d), mu)["psi"]
         assert np.abs((gp - gm) / (2 * eps) - hess[:, j]).max() <= 2e-5 * np.abs(hess).max(), j
+
+
+# ---- the generic bucket's first tenant: power-sum pools  x^(1-t) + y^(1-t)  (include/cfmm.h: CFMM_POOL_POW2) --------------
+def test_power_sum_closed_form_numpy_vs_c_and_its_optimality_conditions(oracle_lib):
+    """oracle/pools_np.arb_power2 == oracle/cfmm_oracle.c:pool_pow2, and the point satisfies what defines it: it stays on
+    the level set, the marginal price after the trade equals the price ratio over the fee, untraded pools sit inside
+    their no-trade band"""
+    net = synthetic.make_network(50, m_pow2=4000, seed=5)
+    b = net["pow2"]
+    o = oracle_lib.Oracle(net["n_tokens"]); o.add_network(net); o.set_utility(net["c"])
+    nu = net["c"] * np.exp(np.random.default_rng(2).normal(0, 0.05, net["n_tokens"]))
+    pa, pb = nu[b["ia"]], nu[b["ib"]]
+    ya, yb, arb = P.arb_power2(b["Ra"], b["Rb"], b["fee"], b["t"], pa, pb)
+    ca, cb = o.trades2(0, nu)
+    assert np.abs(ya - ca).max() <= 1e-12 * b["Ra"].max() and np.abs(yb - cb).max() <= 1e-12 * b["Rb"].max()
+    f, psi = o.eval(nu)
+    assert abs(f - arb.sum()) <= 1e-11 * abs(f)
+    assert np.abs(psi - (np.bincount(b["ia"], ya, net["n_tokens"]) + np.bincount(b["ib"], yb, net["n_tokens"]))).max() <= 1e-10 * np.abs(psi).max()
+    q = 1.0 - b["t"]
+    g = b["fee"]
+    xa = b["Ra"] + g * np.maximum(-ya, 0) - np.maximum(ya, 0)          # arbitrage.py:60
+    xb = b["Rb"] + g * np.maximum(-yb, 0) - np.maximum(yb, 0)
+    assert np.abs((xa ** q + xb ** q) / (b["Ra"] ** q + b["Rb"] ** q) - 1).max() <= 1e-13
+    m = (xb / xa) ** b["t"]                                              # marginal price of a in units of b after the trade
+    ab, ba = ya < 0, yb < 0
+    assert (ab | ba).mean() > 0.5 and not (ab & ba).any()
+    assert np.abs(m[ab] * g[ab] * pb[ab] / pa[ab] - 1).max() <= 1e-12
+    assert np.abs(pa[ba] * g[ba] / (m[ba] * pb[ba]) - 1).max() <= 1e-12
+    idle = ~(ab | ba)
+    assert np.all(g[idle] * pb[idle] * m[idle] <= pa[idle] * (1 + 1e-15)) and np.all(g[idle] * pa[idle] <= pb[idle] * m[idle] * (1 + 1e-15))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_power_sum_pools_dual_decomposition_vs_the_primal_model(oracle_lib, seed):
+    """small random networks that hold power-sum pools among the reference's kinds: the primal program with
+    phi(x) = sum x^(1-t) as its trading-function constraint (oracle/primal_scipy.py, arbitrage.py:63-74's pattern) against
+    dual decomposition with the closed-form pool (C oracle behind the product's host logic)"""
+    from oracle_ctx import OracleContext
+    from helpers import problem_of
+    inst = random_instance(30 + seed, n_tokens=5, n_pools=10, with_sum=False, with_power=True, utility=["arbitrage", "swap"][seed % 2])
+    assert "powersum" in inst["kinds"]
+    r = solve_primal(normalise_with_params(inst))
+    p = problem_of(inst, ctx=OracleContext(inst["n_tokens"]))
+    v = p.solve(tol=1e-9)
+    assert p.status == "optimal"
+    assert abs(v - r["value"]) <= 2e-6 * max(1.0, abs(v))
+    for d, l, y in zip(p.deltas, p.lambdas, r["y"]):
+        assert np.abs((l - d) - y).max() <= 2e-4 * max(1.0, np.abs(y).max())
+
+
+def test_pack_takes_power_sum_pools_and_refuses_bad_exponents():
+    net, where = cfmm.pack(3, [[0, 1], [1, 2]], [[10.0, 20.0], [5.0, 5.0]], [0.997, 0.999], ["powersum", "geomean"], None, [0.4, None])
+    assert where == [("pow2", 0), ("cp2", 0)] and net["pow2"]["t"].tolist() == [0.4] and net["pow2"]["ia"].tolist() == [0]
+    for bad in (None, 0.0, 1.0, -0.2):
+        with pytest.raises(ValueError):
+            cfmm.pack(3, [[0, 1]], [[10.0, 20.0]], [0.997], ["powersum"], None, [bad])
+    with pytest.raises(ValueError):
+        cfmm.pack(3, [[0, 1, 2]], [[10.0, 20.0, 5.0]], [0.997], ["powersum"], None, [0.5])
