@@ -129,6 +129,12 @@ struct cfmm_ctx {
     DevState *hst = nullptr;          // pinned, 2 slots
     double *hsol = nullptr;           // pinned [2][n]: nu | psi of the last solve (saves cfmm_get_solution a synchronisation)
     double *hnu0 = nullptr;           // pinned [n]: staging of cfmm_set_nu
+    // the pinned arena is mapped into the device's address space: a first-order solve reads its start prices straight out of
+    // hnu0 (start_kernel) and leaves its result -- accepted prices, their net trade, the final state record -- straight in
+    // hsol / hst (iter_kernel), instead of one H2D and three D2H copies of a few KB each per solve (~25 us of a 0.5 ms solve)
+    double *hnu0_d = nullptr, *hsol_d = nullptr;
+    DevState *hst_d = nullptr;
+    bool nu0_deferred = false;        // inside cfmm_solve only: the start prices are in hnu0 and not yet in nu_acc
     bool hsol_valid = false;
     hipEvent_t ev[2] = {nullptr, nullptr}, ev_t0 = nullptr, ev_t1 = nullptr;
     int walk_parity[2] = {0, 0};       // direction of the next evaluation launch's tile walk (launch_eval), per tile space
@@ -1507,9 +1513,14 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
         const size_t hb[5] = {2 * sizeof(DevState), 6 * sizeof(DevState), 2 * (size_t)n * sizeof(double), (size_t)n * sizeof(double), ctx->util_span};
         size_t ho[6] = {0, 0, 0, 0, 0, 0};
         for (int q = 0; q < 5; ++q) ho[q + 1] = ho[q] + ((hb[q] + 255) & ~(size_t)255);
-        TRY_C(hipHostMalloc((void **)&ctx->host_arena, ho[5], hipHostMallocDefault));
+        TRY_C(hipHostMalloc((void **)&ctx->host_arena, ho[5], hipHostMallocDefault));      // (pinned, host-cached, and reachable from the device through hipHostGetDevicePointer)
         ctx->hst = (DevState *)(ctx->host_arena + ho[0]); ctx->hst3 = (DevState *)(ctx->host_arena + ho[1]);
         ctx->hsol = (double *)(ctx->host_arena + ho[2]); ctx->hnu0 = (double *)(ctx->host_arena + ho[3]);
+        {
+            char *base_d = nullptr;
+            TRY_C(hipHostGetDevicePointer((void **)&base_d, ctx->host_arena, 0));
+            ctx->hst_d = (DevState *)(base_d + ho[0]); ctx->hsol_d = (double *)(base_d + ho[2]); ctx->hnu0_d = (double *)(base_d + ho[3]);
+        }
         ctx->util_h = ctx->host_arena + ho[4];
         std::memset(ctx->util_h, 0, ctx->util_span);
     }
@@ -2085,7 +2096,22 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     // nu0 == NULL continues from the previous solution: its prices and, for the second-order method, (a multiple of) its
     // final barrier weight -- the warm start of a parametric sweep (two-asset.py:34-100)
     ctx->warm_mu = nu0 ? 0.0 : ctx->mu_last;
-    if (nu0) { int rc = cfmm_set_nu(ctx, nu0); if (rc) return rc; }
+    if (nu0) {
+        // as cfmm_set_nu, minus the copy to the device: the first-order solve's start kernel reads the prices where they are
+        // (mapped pinned memory) and writes nu_acc itself; a solve that goes straight to the second-order method sends them first
+        for (int j = 0; j < ctx->n; ++j) if (!(nu0[j] > 0.0) || !std::isfinite(nu0[j])) return fail(ctx, CFMM_E_ARG, "solve: nu0[%d] = %g is not a positive finite price", j, nu0[j]);
+        { double mx = 0.0; for (int j = 0; j < ctx->n; ++j) mx = std::max(mx, nu0[j]); ctx->nu_max = mx; }
+        std::memcpy(ctx->hnu0, nu0, ctx->n * sizeof(double));     // (every entry point leaves the stream synchronised: nothing still reads hnu0)
+        ctx->nu0_deferred = true;
+        ctx->have_nu = true; ctx->hsol_valid = false; ctx->mu_last = 0.0; ctx->slo_active = false;
+    }
+    struct Flush { cfmm_ctx *c; ~Flush() { c->nu0_deferred = false; } } flush_guard{ctx};      // (the flag never outlives this call)
+    auto send_nu0 = [&]() -> int {
+        if (!ctx->nu0_deferred) return CFMM_OK;
+        ctx->nu0_deferred = false;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->nu_acc, ctx->hnu0, ctx->n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        return CFMM_OK;
+    };
     if (!ctx->have_nu) return fail(ctx, CFMM_E_STATE, "solve: no start prices (pass nu0 or call cfmm_set_nu)");
     const char *why = "";
     const bool can_newton = newton_supported(ctx, &why);
@@ -2105,6 +2131,7 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
             if (out->status == 1) return CFMM_OK;                          // (it can happen: nothing left to do)
             used = out->evals; w0 = out->wall_seconds; d0 = out->device_seconds;
         }
+        { int rc = send_nu0(); if (rc) return rc; }
         int rc = solve_newton(ctx, o, out, used);
         out->wall_seconds += w0; out->device_seconds += d0;
         return rc;
@@ -2146,8 +2173,15 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     const bool use_graph = !tiny && (!shard || (ctx->multi_graph && !ctx->os_ready)) && !ctx->no_graph && (!fused || shard || graph_forced);
     if (use_graph && (!ctx->g_valid || !same_opts(o, ctx->g_opts))) { int rc = build_graph(ctx, o); if (rc) return rc; }
     UpdArgs ua = make_upd_args(ctx, o);
-    const IterArgs ia = make_iter_args(ctx, o);
+    IterArgs ia = make_iter_args(ctx, o);
     const size_t aset = acc_set_doubles(ctx);
+    // the start prices: nu_acc, or -- handed over by cfmm_solve without a copy -- the mapped pinned staging vector
+    const double *nu_src = ctx->nu0_deferred ? ctx->hnu0_d : ctx->nu_acc;
+    ctx->nu0_deferred = false;                             // (the start kernel writes nu_acc)
+    // single GPU, one launch per iteration, eager run-ahead: the kernels leave the result in pinned memory themselves
+    static const bool zc_off = getenv("CFMM_ZERO_COPY") && atoi(getenv("CFMM_ZERO_COPY")) == 0;     // (A/B)
+    const bool zero_copy = fused && !shard && !use_graph_opt && !ctx->det && !zc_off;
+    if (zero_copy) { ia.h_nu_acc = ctx->hsol_d; ia.h_psi_acc = ctx->hsol_d + n; ia.h_final = ctx->hst_d; ctx->hst[0] = DevState{}; }
 
     // ---- timed region: the outer loop (upload and trade read-back excluded) ----------------
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2161,7 +2195,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
         //  prices where they are: three fill / copy operations less on the stream per solve)
         double *x0 = ctx->xs3;
         ua.s = x0; ua.s_t = x0 + ia.xvs; ua.Gs = x0 + 2 * ia.xvs; ua.d = x0 + 3 * ia.xvs; ua.nu = x0 + 4 * ia.xvs; ua.st = ctx->st3;
-        hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
+        hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, nu_src,
                            ctx->acc3, (long long)(3 * aset), ctx->st3 + 1, 2);
         for (int stable = 0; stable < 2; ++stable) {
             EvalArgs e0 = make_eval_args(ctx, stable != 0);
@@ -2177,12 +2211,12 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     } else if (tiny) {
         // one workgroup, one launch: every evaluation and update of the solve, nothing of it in global memory (tiny.hpp);
         // the device ends it: converged, stalled, or out of budget
-        hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
+        hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, nu_src,
                            ctx->acc, (long long)((size_t)ctx->nslices * acc_stride(n)), (DevState *)nullptr, 0);
         const int threads = 64 * std::min(TINY_THREADS / 64, std::max(1, ea_tiny.ntiles));
         hipLaunchKernelGGL(solve_tiny_kernel, dim3(1), dim3(threads), (size_t)tiny_lds_doubles(n) * sizeof(double), ctx->stream, ea_tiny, ua, o.max_evals + 1);
     } else {
-        hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, (const double *)ctx->nu_acc,
+        hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, nu_src,
                            ctx->acc, (long long)((size_t)ctx->nslices * acc_stride(n)), (DevState *)nullptr, 0);
         { int rc = enqueue_iteration<true>(ctx, ua); if (rc) return rc; }      // first evaluation also builds the metric
     }
@@ -2247,10 +2281,22 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
         }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+    if (zero_copy) {
+        // the kernels have left the result in pinned memory themselves (iterate.hpp: h_nu_acc / h_psi_acc / h_final)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        hring[0] = ctx->hst[0];
+        for (int q = 1; q < nst; ++q) hring[q] = DevState{};
+        if (hring[0].status == 0) {              // (the device ended without a final record: cannot happen -- read it the slow way)
+            HIP_TRY(ctx, hipMemcpy(hring, dst, nst * sizeof(DevState), hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(ctx->hsol, ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(ctx->hsol + n, ctx->psi_acc, n * sizeof(double), hipMemcpyDeviceToHost));
+        }
+    } else {
     HIP_TRY(ctx, hipMemcpyAsync(hring, dst, nst * sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->hsol, ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->hsol + n, ctx->psi_acc, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->hsol_valid = true;
     { double mx = 0.0; for (int j = 0; j < n; ++j) mx = std::max(mx, ctx->hsol[j]); if (mx > 0.0 && std::isfinite(mx)) ctx->nu_max = mx; }
     const auto t1 = std::chrono::steady_clock::now();

@@ -61,6 +61,10 @@ struct IterArgs {
     double *nu, *nu_acc, *psi_acc;          // written by workgroup 0: trial prices (+ stop flag at [n]), accepted point
     double tol_gap, tol_infeas, armijo, max_step;
     unsigned long long *hstat;              // pinned HOST word (zero-copy): evals | status << 32, for the host's run-ahead control
+    // pinned HOST mirrors (mapped; null = none): the accepted prices / net trade are stored there as well whenever a point is
+    // accepted, the state record when the solve ends -- the host reads its result after one synchronisation, no copies
+    double *h_nu_acc, *h_psi_acc;
+    DevState *h_final;
 };
 
 template <int E> __device__ __forceinline__ void ldE(const double *p, int first, double (&v)[E]);
@@ -555,8 +559,8 @@ iter_kernel(IterArgs a)
             double pk[E], nk[E];                         // (from the stash: a reload through L2 would sit on the chain)
 #pragma unroll
             for (int e = 0; e < E; ++e) { pk[e] = tin[e] ? psi_k[r0 + e] : 0.0; nk[e] = tin[e] ? nu_k[r0 + e] : 0.0; }
-            if (mine(R_PSI_ACC)) stE<E>(a.psi_acc, r0, n, pk);
-            if (mine(R_NU_ACC)) stE<E>(a.nu_acc, r0, n, nk);
+            if (mine(R_PSI_ACC)) { stE<E>(a.psi_acc, r0, n, pk); if (a.h_psi_acc) stE<E>(a.h_psi_acc, r0, n, pk); }
+            if (mine(R_NU_ACC)) { stE<E>(a.nu_acc, r0, n, nk); if (a.h_nu_acc) stE<E>(a.h_nu_acc, r0, n, nk); }
         }
     }
 
@@ -615,6 +619,7 @@ iter_kernel(IterArgs a)
     if (wr) {
         if (tid == 0) {
             a.st3[p] = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0;
+            if (st.status != 0 && a.h_final) *a.h_final = st;
             // progress word for the host (system-scope store into pinned host memory: no copy, no API call on the host side)
             if (a.hstat) __hip_atomic_store(a.hstat, (unsigned long long)(unsigned)st.evals | ((unsigned long long)(unsigned)st.status << 32),
                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
