@@ -29,7 +29,6 @@
 #include "kernels.hpp"
 #include "iterate.hpp"
 #include "tiny.hpp"
-#include "coop.hpp"
 #include "reorder.hpp"
 #include "oneshot.hpp"
 #include "smooth.hpp"
@@ -155,9 +154,6 @@ struct cfmm_ctx {
     // fused iteration (iterate.hpp): three rotating sets of accumulators / solver state, a history ring of M + 1 slots
     bool fused = true;                 // CFMM_FUSED=0: the two-launch iteration of round 1 (A/B)
     bool tiny_path = true;             // CFMM_TINY=0: tiny networks through the grid-wide path too (A/B)
-    bool coop_path = true;             // CFMM_COOP=0: mid-size networks through the grid-wide path too (A/B); cleared when an exchange timed out
-    unsigned long long *coop_mem = nullptr;      // coop.hpp: slab [2][COOP_MAX_WGS][stride] | flags [2][COOP_MAX_WGS]
-    unsigned long long coop_epoch = 0;           // flag values handed out so far (monotone over the life of the context)
     bool plain = false;                // utility has h == 0 and only CFMM_GE tokens (IterArgs::plain)
     // reproducible mode (kernels.hpp: Scatter<true>): psi accumulated as exact fixed-point integers
     bool det = false;
@@ -783,7 +779,6 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, start_kernel<true>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, eval_batch_kernel, batch_lds_bytes(ctx->n, batch_capacity(ctx->n))))) return rc;
     if (ctx->n <= TINY_N && (rc = set_lds_attr(ctx, solve_tiny_kernel, (size_t)tiny_lds_doubles(ctx->n) * sizeof(double)))) return rc;
-    if (ctx->n <= COOP_N && (rc = set_lds_attr(ctx, solve_coop_kernel, (size_t)coop_lds_doubles(ctx->n) * sizeof(double)))) return rc;
     const size_t il = iter_lds_bytes(ctx->n);
     if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, false>, il))) return rc;
     if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, true>, il))) return rc;
@@ -826,14 +821,6 @@ bool tiny_applies(cfmm_ctx *ctx, const EvalArgs &ea, const cfmm_opts &o)
     return ctx->tiny_path && !sharded(ctx) && !ctx->det && heavy_pools(ctx) == 0 && ea.ntiles >= 1 &&
            ea.ntiles <= TINY_MAX_TILES && ctx->n <= TINY_N && o.memory <= MAX_MEMORY;
 }
-
-// ---- mid-size networks (BASELINE config 2): the whole solve in one launch of a few cooperating workgroups (coop.hpp) ----
-bool coop_applies(cfmm_ctx *ctx, const EvalArgs &ea, const cfmm_opts &o)
-{
-    return ctx->coop_path && !sharded(ctx) && !ctx->det && heavy_pools(ctx) == 0 && ctx->n <= COOP_N && o.memory <= MAX_MEMORY &&
-           ea.ntiles > 0 && ea.ntiles <= COOP_MAX_TILES && !(ea.ntiles <= TINY_MAX_TILES && ctx->n <= TINY_N);
-}
-int coop_grid(const EvalArgs &ea) { return std::max(2, std::min(COOP_MAX_WGS, (ea.ntiles + COOP_THREADS / 64 - 1) / (COOP_THREADS / 64))); }
 
 // ---- the fused iteration (iterate.hpp) ---------------------------------------------------------------------------
 // applies when the update fits the evaluation launch: no price ties, <= 2048 tokens, memory <= 4
@@ -1491,7 +1478,6 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if (const char *s = getenv("CFMM_NO_GRAPH")) ctx->no_graph = atoi(s) != 0;
     if (const char *s = getenv("CFMM_FUSED")) ctx->fused = atoi(s) != 0;
     if (const char *s = getenv("CFMM_TINY")) ctx->tiny_path = atoi(s) != 0;
-    if (const char *s = getenv("CFMM_COOP")) ctx->coop_path = atoi(s) != 0;
     if (const char *s = getenv("CFMM_RUN_AHEAD")) ctx->run_ahead = std::max(1, atoi(s));
     if (const char *s = getenv("CFMM_DETERMINISTIC")) ctx->det = atoi(s) != 0;
     const int n = n_tokens;
@@ -1609,7 +1595,6 @@ int cfmm_destroy(cfmm_ctx *ctx)
     if (ctx->dev_arena) (void)hipFree(ctx->dev_arena);
     if (ctx->host_arena) (void)hipHostFree(ctx->host_arena);
     if (ctx->hstat_h) (void)hipHostFree((void *)ctx->hstat_h);
-    if (ctx->coop_mem) (void)hipFree(ctx->coop_mem);
     if (ctx->upd_batch_d) (void)hipFree(ctx->upd_batch_d);
     if (ctx->upd_batch_h) (void)hipHostFree(ctx->upd_batch_h);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -2172,14 +2157,8 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     // One launch per iteration (iterate.hpp) whenever the update fits the evaluation launch; otherwise the
     // two-launch iteration (evaluation kernel, single-workgroup update kernel).
     const EvalArgs ea_tiny = make_eval_args(ctx, false);
-    const bool coop = coop_applies(ctx, ea_tiny, o);
-    const bool tiny = coop || tiny_applies(ctx, ea_tiny, o);          // (both: one launch per solve, the device ends it)
+    const bool tiny = tiny_applies(ctx, ea_tiny, o);
     const bool fused = !tiny && fused_applies(ctx, o);
-    if (coop && !ctx->coop_mem) {
-        const size_t words = 2 * (size_t)COOP_MAX_WGS * coop_stride(COOP_N) + 2 * COOP_MAX_WGS;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->coop_mem, words * sizeof(unsigned long long)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->coop_mem, 0, words * sizeof(unsigned long long), ctx->stream));
-    }
     if (fused) o.iters_per_graph = (o.iters_per_graph + 2) / 3 * 3;       // the rotation phase t % 3 is baked into captured launches
     // pool-sharded through RCCL: the chunked scheme polls one chunk behind, so a solve leaves up to two chunks of iterations
     // -- each with a live collective and RCCL's ~35 us of host time per call -- behind its end: short chunks
@@ -2234,18 +2213,8 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
         // the device ends it: converged, stalled, or out of budget
         hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, nu_src,
                            ctx->acc, (long long)((size_t)ctx->nslices * acc_stride(n)), (DevState *)nullptr, 0);
-        if (coop) {
-            CoopArgs ca;
-            ca.stride = coop_stride(n);
-            ca.slab = ctx->coop_mem; ca.flags = ctx->coop_mem + 2 * (size_t)COOP_MAX_WGS * coop_stride(COOP_N);
-            ca.epoch0 = ctx->coop_epoch;
-            ctx->coop_epoch += (unsigned long long)o.max_evals + 4;
-            hipLaunchKernelGGL(solve_coop_kernel, dim3(coop_grid(ea_tiny)), dim3(COOP_THREADS), (size_t)coop_lds_doubles(n) * sizeof(double), ctx->stream,
-                               ea_tiny, ua, ca, o.max_evals + 1);
-        } else {
         const int threads = 64 * std::min(TINY_THREADS / 64, std::max(1, ea_tiny.ntiles));
         hipLaunchKernelGGL(solve_tiny_kernel, dim3(1), dim3(threads), (size_t)tiny_lds_doubles(n) * sizeof(double), ctx->stream, ea_tiny, ua, o.max_evals + 1);
-        }
     } else {
         hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, nu_src,
                            ctx->acc, (long long)((size_t)ctx->nslices * acc_stride(n)), (DevState *)nullptr, 0);
@@ -2335,13 +2304,6 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
 
     const DevState st = newest(hring);
-    if (coop && st.status == COOP_STATUS_TIMEOUT) {
-        // an exchange of the cooperating workgroups ran out of its poll bound (they were not co-resident: the device is
-        // shared): this context leaves that path and the solve is repeated launch by launch, from the last point the
-        // one-launch solve had accepted (its start prices if it got nowhere)
-        ctx->coop_path = false;
-        return solve_lbfgs(ctx, o_in, out);
-    }
     std::memset(out, 0, sizeof *out);
     out->evals = st.evals; out->iters = st.iters; out->status = st.status ? st.status : 3;
     out->n_ranks = ctx->n_ranks;

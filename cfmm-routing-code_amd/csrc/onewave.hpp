@@ -1,5 +1,5 @@
 // The projected L-BFGS step of the outer iteration as ONE WAVE (gfx950, wave64, fp64) -- the form the one-launch solves use
-// (tiny.hpp: one workgroup, <= 64 tokens; coop.hpp: a handful of cooperating workgroups, <= 128 tokens).
+// (tiny.hpp: one workgroup, <= 64 tokens, E = 1; E = 2 served the cooperating-workgroups solve of DESIGN.md's "tried" table).
 //
 // Lane L owns tokens / group variables L + 64 e, e < E: every vector of the update is E registers per lane, every reduction
 // one DPP butterfly (no barrier, no LDS round trip, no memory), the history pairs sit in LDS rows of 64 E.  The solver

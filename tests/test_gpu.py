@@ -232,45 +232,6 @@ def test_tiny_one_launch_solve_matches_the_grid_path(seed, monkeypatch):
     assert e1 <= 2 * e0 + 20 and e0 <= 2 * e1 + 20
 
 
-@pytest.mark.parametrize("cfg,scale,tokens", [("C2", 1.0, None), ("C2", 0.3, None), ("C2", 4.0, None), ("mixed", 1.0, 128), ("ties", 1.0, 90)])
-def test_cooperating_workgroups_one_launch_solve_matches_the_grid_path(oracle_lib, cfg, scale, tokens, monkeypatch):
-    """BASELINE config 2's regime (<= 128 tokens, more wave-tiles than one workgroup takes): the whole solve is ONE launch of
-    2..32 cooperating workgroups (coop.hpp: tiles stay in LDS, partial psi all-gathered through a global slab with agent-scope
-    atomics, the step taken by one wave of every workgroup).  CFMM_COOP=0 sends the same instance through the launch-per-
-    iteration kernels: same optimum, same certificates, comparable evaluation counts; both agree with the oracle's solver.
-    `mixed`: every pool family the tile code knows (K-asset pools included) at the token limit; `ties`: constant-sum pools,
-    i.e. the host's active-set loop over kinks re-entering the one-launch solve with price ties set."""
-    if cfg == "C2":
-        net = synthetic.config("C2", scale=scale, seed=1)
-    elif cfg == "mixed":
-        net = synthetic.make_network(tokens, m_cp2=9000, m_w2=3000, m_gn=1500, seed=2)
-    else:
-        net = synthetic.make_network(tokens, m_cp2=7000, m_w2=2000, seed=3)
-        rng = np.random.default_rng(0)
-        m = 40; ia = rng.integers(0, tokens, m); ib = (ia + 1 + rng.integers(0, tokens - 1, m)) % tokens
-        net["sum2"] = dict(Ra=np.exp(rng.normal(3, 1, m)), Rb=np.exp(rng.normal(3, 1, m)), fee=np.full(m, 0.999),
-                           ia=ia.astype(np.int32), ib=ib.astype(np.int32))
-        net["sum2"]["Rb"] = net["sum2"]["Ra"] * net["prices"][ia] / net["prices"][ib] * np.exp(rng.normal(0, 0.3, m))
-    res = {}
-    for coop in ("1", "0"):
-        monkeypatch.setenv("CFMM_COOP", coop)
-        p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
-        v = p.solve(tol=1e-8)
-        res[coop] = (v, p.status, p.psi.copy(), p.stats["evals"], p.gap, p.infeas, p.stats["wall_seconds"])
-        if coop == "1" and cfg == "C2":           # a second solve on the same context: the exchange's epochs carry on
-            v2 = p.solve(tol=1e-8)
-            assert abs(v2 - v) <= 1e-12 * abs(v)
-        p.close()
-    (v1, s1, psi1, e1, g1, i1, w1), (v0, s0, psi0, e0, g0, i0, w0) = res["1"], res["0"]
-    assert s1 == s0 == "optimal" and max(g1, g0, i1, i0) <= 1e-8
-    assert abs(v1 - v0) <= 1e-7 * max(1.0, abs(v0))
-    assert np.abs(psi1 - psi0).max() <= 1e-5 * max(1.0, np.abs(psi0).max())
-    assert e1 <= 2 * e0 + 20 and e0 <= 2 * e1 + 20
-    if cfg != "ties":
-        r = _oracle_for(oracle_lib, net).solve(net["c"], tol=1e-8)
-        assert abs(v1 - r["primal_value"]) <= 2e-6 * abs(v1)
-
-
 @pytest.mark.parametrize("seed", range(6))
 def test_random_small_instances_vs_primal(seed):
     from oracle.primal_scipy import solve_primal
