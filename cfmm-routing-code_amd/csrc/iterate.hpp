@@ -451,63 +451,37 @@ iter_kernel(IterArgs a)
 
         // ---- accept test ----------------------------------------------------------------------------------------
         accept = st.first != 0;
-        if (!st.first)
-            accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * T(2)) ||
-                                      (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && T(3) <= 0.8 * fabs(T(2))));
+        if (!st.first) accept = lbfgs::accept(f_t, st.f, a.armijo, T(2), T(3));
         if (!accept) {
-            st.t_step *= 0.5;
-            st.nrej += 1;
-            if (st.t_step < 1e-9) st.status = 2;
+            lbfgs::reject(st);
         } else {
             // ---- curvature pair, move the accepted point -----------------------------------------------------
             const int old_hist0 = st.hist;
             if (!st.first) {
                 const double sy = T(4);
-                if (sy > 0.0 && sy * sy > 1e-24 * T(5) * T(6)) {          // (s'y > 1e-12 |s| |y|, without the square roots)
+                if (lbfgs::pair_ok(sy, T(5), T(6))) {
                     pair_ok = true;
                     rho[0] = rcp_nr(sy);
                     if (st.hist < M) st.hist += 1;
                 }
                 st.iters += 1;
             }
-            st.f = f_t;
-            const double rf = rcp_nr(fmax(1.0, fabs(f_t)));      // (v_rcp_f64 + two Newton steps: ~1 ulp, a fifth of the IEEE division's chain)
-            st.gap = fabs(gapv) * rf;
-            st.infeas = viol * rcp_nr(fmax(scale, 1e-300));
-            st.primal = f_t - gapv;                   // c'psi = g - (nu - c)'(psi + h)
-            st.pg = T(7) * rf;
             gp_sq = T(7);                              // (sum |projected gradient|: positive iff some free variable has a gradient)
+            lbfgs::certify(st, f_t, gapv, viol, scale, gp_sq);
             const bool was_first = st.first != 0;
             st.first = 0;
-            const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
-            if (conv) {
+            if (lbfgs::converged(st, a.pg_rule, a.tol_gap, a.tol_infeas)) {
                 st.status = 1;
             } else {
                 // ---- the two-loop recursion on scalars -------------------------------------------------------
                 // which pairs are in the window: the new one if it passed, then the newest stored ones
                 new_dir = true;
-                const int keep_old = was_first ? 0 : (pair_ok ? (old_hist0 < M ? old_hist0 : M - 1) : old_hist0);
+                const int keep_old = lbfgs::keep_old(was_first, pair_ok, old_hist0, M);
 #pragma unroll
                 for (int k = 1; k < P; ++k) if (k - 1 >= keep_old) rho[k] = 0.0;
-#pragma unroll
-                for (int k = 0; k < P; ++k) {
-                    double t = T(GI_U + k);
-#pragma unroll
-                    for (int j = 0; j < k; ++j) t -= al[j] * T(GI_SY + k * (k - 1) / 2 + j);
-                    al[k] = rho[k] * t;
-                }
-#pragma unroll
-                for (int k = P - 1; k >= 0; --k) {
-                    double t = T(GI_V + k);
-#pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        const int hi = j > k ? j : k, lo = j > k ? k : j;
-                        t -= al[j] * T(GI_YHY + hi * (hi + 1) / 2 + lo);
-                    }
-#pragma unroll
-                    for (int j = k + 1; j < P; ++j) t += ga[j] * T(GI_SY + j * (j - 1) / 2 + k);
-                    ga[k] = al[k] - rho[k] * t;
-                }
+                lbfgs::gram_two_loop<P>(rho, [&](int k) { return T(GI_U + k); }, [&](int k) { return T(GI_V + k); },
+                                        [&](int k, int j) { return T(GI_SY + k * (k - 1) / 2 + j); },
+                                        [&](int k, int j) { return T(GI_YHY + k * (k + 1) / 2 + j); }, al, ga);
             }
             if (pair_ok) { st.rhow[2] = st.rhow[1]; st.rhow[1] = st.rhow[0]; st.rhow[0] = rho[0]; }      // the window moves on
         }
@@ -601,7 +575,7 @@ iter_kernel(IterArgs a)
             F[1] = m1[0];
             redo = true;
         }
-        st.t_step = (F[1] > a.max_step) ? a.max_step * rcp_nr(F[1]) : 1.0;
+        st.t_step = lbfgs::step_cap(F[1], a.max_step);
         if ((redo || st.t_step != 1.0) && wave_active) trial(st.t_step);
     } else if (st.status == 0 && wave_active) trial(st.t_step);
 

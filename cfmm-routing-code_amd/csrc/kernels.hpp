@@ -17,6 +17,7 @@
 #pragma once
 #include "pool_math.hpp"
 #include "phi2.hpp"
+#include "lbfgs_rules.hpp"
 
 namespace cfmm {
 
@@ -861,14 +862,11 @@ __device__ __forceinline__ int update_generic_body(const UpdArgs &a, double *lds
         double dummy[1] = {0.0};
         for (int r = tid; r < ng; r += nt) { const double ds = a.s_t[r] - a.s[r]; dd[0] += a.Gs[r] * ds; dd[1] += a.Gs_t[r] * ds; }
         block_reduce<2, 0>(dd, dummy, scratch);
-        accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * dd[0]) ||
-                                  (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && dd[1] <= 0.8 * fabs(dd[0])));
+        accept = lbfgs::accept(f_t, st.f, a.armijo, dd[0], dd[1]);
     }
 
     if (!accept) {
-        st.t_step *= 0.5;
-        st.nrej += 1;
-        if (st.t_step < 1e-9) st.status = 2;
+        lbfgs::reject(st);
     } else {
         // ---- C. curvature pair, move the accepted point ----------------------------------
         if (!st.first) {
@@ -881,8 +879,8 @@ __device__ __forceinline__ int update_generic_body(const UpdArgs &a, double *lds
                 t3[0] += s1 * y1; t3[1] += s1 * s1; t3[2] += y1 * y1;
             }
             block_reduce<3, 0>(t3, dummy, scratch);
-            if (t3[0] > 1e-12 * sqrt(t3[1]) * sqrt(t3[2])) {
-                if (tid == 0) a.rho[st.head] = 1.0 / t3[0];
+            if (lbfgs::pair_ok(t3[0], t3[1], t3[2])) {
+                if (tid == 0) a.rho[st.head] = rcp_nr(t3[0]);
                 st.head = (st.head + 1) % M;
                 if (st.hist < M) st.hist += 1;
             }
@@ -890,28 +888,17 @@ __device__ __forceinline__ int update_generic_body(const UpdArgs &a, double *lds
         }
         for (int r = tid; r < ng; r += nt) { a.s[r] = a.s_t[r]; a.Gs[r] = a.Gs_t[r]; }
         for (int j = tid; j < n; j += nt) { a.psi_acc[j] = a.psi_t[j]; a.nu_acc[j] = a.nu[j]; }
-        st.f = f_t; st.first = 0;
-        st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
-        st.infeas = viol / fmax(scale, 1e-300);
-        st.primal = f_t - gapv;               // c'psi = g - (nu - c)'(psi + h)
+        st.first = 0;
         // value of the projected reduced gradient: sum_r |P(Gs)_r| / max(1,|f|)  (>= gap)
         {
             double pgs[1] = {0.0};
             double dummy[1] = {0.0};
-            for (int r = tid; r < ng; r += nt) {
-                const double G = a.Gs[r], sr = a.s[r];
-                double v = G;
-                if (a.glo[r] == a.ghi[r]) v = 0.0;
-                else if (sr <= a.glo[r] + 1e-14) v = fmin(G, 0.0);
-                else if (sr >= a.ghi[r] - 1e-14) v = fmax(G, 0.0);
-                pgs[0] += fabs(v);
-            }
+            for (int r = tid; r < ng; r += nt) pgs[0] += lbfgs::pg_entry(a.Gs[r], a.s[r], a.glo[r], a.ghi[r]);
             __syncthreads();
             block_reduce<1, 0>(pgs, dummy, scratch);
-            st.pg = pgs[0] / fmax(1.0, fabs(f_t));
+            lbfgs::certify(st, f_t, gapv, viol, scale, pgs[0]);
         }
-        const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
-        if (conv) {
+        if (lbfgs::converged(st, a.pg_rule, a.tol_gap, a.tol_infeas)) {
             st.status = 1;
         } else {
             // ---- D. two-loop recursion with the diagonal metric --------------------------
@@ -974,7 +961,7 @@ __device__ __forceinline__ int update_generic_body(const UpdArgs &a, double *lds
                 }
                 block_reduce<1, 1>(z1, dmx, scratch);
             }
-            st.t_step = (dmx[0] > a.max_step) ? a.max_step / dmx[0] : 1.0;
+            st.t_step = lbfgs::step_cap(dmx[0], a.max_step);
         }
     }
     __syncthreads();
@@ -1266,24 +1253,21 @@ update_reg_kernel(UpdArgs a0)
     // ---- B. accept test ------------------------------------------------------------------------
     bool accept = st.first != 0;
     if (!st.first)
-        accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * A[2]) ||
-                                  (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && A[3] <= 0.8 * fabs(A[2])));
+        accept = lbfgs::accept(f_t, st.f, a.armijo, A[2], A[3]);
     PHASE_STAMP(a.ts, 12);
 
     bool new_dir = false;
     if (!accept) {
-        st.t_step *= 0.5;
-        st.nrej += 1;
-        if (st.t_step < 1e-9) st.status = 2;
+        lbfgs::reject(st);
     } else {
         // ---- C. curvature pair, move the accepted point ---------------------------------------
         bool pair_ok = false;
         double rho_new = 0.0;
         if (!st.first) {
             if (r0 < ng) { stv<E>(a.S + (size_t)st.head * hs, r0, ngS, sv); stv<E>(a.Y + (size_t)st.head * hs, r0, ngS, yv); }
-            if (A[4] > 1e-12 * sqrt(A[5]) * sqrt(A[6])) {
+            if (lbfgs::pair_ok(A[4], A[5], A[6])) {
                 pair_ok = true;
-                rho_new = 1.0 / A[4];
+                rho_new = rcp_nr(A[4]);
                 if (wr && tid == 0) a.rho[st.head] = rho_new;
                 st.head = (st.head + 1) % M;
                 if (st.hist < M) st.hist += 1;
@@ -1294,16 +1278,11 @@ update_reg_kernel(UpdArgs a0)
         for (int e = 0; e < E; ++e) if (gin[e]) { s[e] = s_t[e]; Gs[e] = Gs_t[e]; }
         if (r0 < ng) { stv<E>(a.s, r0, ngS, s); stv<E>(a.Gs, r0, ngS, Gs); if (st.first) stv<E>(a.Ds, r0, ngS, Ds); }
         if (r0 < n) { stv<E>(a.psi_acc, r0, nS, psi); stv<E>(a.nu_acc, r0, nS, nuj); }
-        st.f = f_t;
-        st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
-        st.infeas = viol / fmax(scale, 1e-300);
-        st.primal = f_t - gapv;                   // c'psi = g - (nu - c)'(psi + h)
-        st.pg = A[7] / fmax(1.0, fabs(f_t));
+        lbfgs::certify(st, f_t, gapv, viol, scale, A[7]);
         const double gp_sq = A[8];
         const bool was_first = st.first != 0;
         st.first = 0;
-        const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
-        if (conv) {
+        if (lbfgs::converged(st, a.pg_rule, a.tol_gap, a.tol_infeas)) {
             st.status = 1;
         } else {
             PHASE_STAMP(a.ts, 13);
@@ -1363,7 +1342,7 @@ update_reg_kernel(UpdArgs a0)
                 red.run<0, 1>(mx);
                 F[1] = mx[0];
             }
-            st.t_step = (F[1] > a.max_step) ? a.max_step / F[1] : 1.0;
+            st.t_step = lbfgs::step_cap(F[1], a.max_step);
         }
     }
 
@@ -1673,24 +1652,21 @@ update_gram_kernel(UpdArgs a0)
     // ---- B. accept test ---------------------------------------------------------------------------------
     bool accept = st.first != 0;
     if (!st.first)
-        accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * T[2]) ||
-                                  (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && T[3] <= 0.8 * fabs(T[2])));
+        accept = lbfgs::accept(f_t, st.f, a.armijo, T[2], T[3]);
     PHASE_STAMP(a.ts, 12);
 
     bool new_dir = false;
     if (!accept) {
-        st.t_step *= 0.5;
-        st.nrej += 1;
-        if (st.t_step < 1e-9) st.status = 2;
+        lbfgs::reject(st);
     } else {
         // ---- C. curvature pair, move the accepted point ------------------------------------------------
         bool pair_ok = false;
         const int old_hist0 = st.hist;
         if (!st.first) {
             if (r0 < ng) { stv<E>(a.S + (size_t)st.head * hs, r0, ngS, Sx[0]); stv<E>(a.Y + (size_t)st.head * hs, r0, ngS, Yx[0]); }
-            if (T[4] > 1e-12 * sqrt(T[5]) * sqrt(T[6])) {
+            if (lbfgs::pair_ok(T[4], T[5], T[6])) {
                 pair_ok = true;
-                if (wr && tid == 0) a.rho[st.head] = 1.0 / T[4];
+                if (wr && tid == 0) a.rho[st.head] = rcp_nr(T[4]);
                 st.head = (st.head + 1) % M;
                 if (st.hist < M) st.hist += 1;
             }
@@ -1700,46 +1676,25 @@ update_gram_kernel(UpdArgs a0)
         for (int e = 0; e < E; ++e) if (gin[e]) { s[e] = s_t[e]; Gs[e] = Gs_t[e]; }
         if (r0 < ng) { stv<E>(a.s, r0, ngS, s); stv<E>(a.Gs, r0, ngS, Gs); if (st.first) stv<E>(a.Ds, r0, ngS, Ds); }
         if (r0 < n) { stv<E>(a.psi_acc, r0, nS, psi); stv<E>(a.nu_acc, r0, nS, nuj); }
-        st.f = f_t;
-        st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
-        st.infeas = viol / fmax(scale, 1e-300);
-        st.primal = f_t - gapv;
-        st.pg = T[7] / fmax(1.0, fabs(f_t));
+        lbfgs::certify(st, f_t, gapv, viol, scale, T[7]);
         const double gp_sq = T[8];
         const bool was_first = st.first != 0;
         st.first = 0;
-        const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
-        if (conv) {
+        if (lbfgs::converged(st, a.pg_rule, a.tol_gap, a.tol_infeas)) {
             st.status = 1;
         } else {
             PHASE_STAMP(a.ts, 13);
             // ---- D. the two-loop recursion on scalars ---------------------------------------------------
             new_dir = true;
             // which pairs are in the window: the new one if it passed, then the newest stored ones
-            const int keep_old = was_first ? 0 : (pair_ok ? (old_hist0 < M ? old_hist0 : M - 1) : old_hist0);
-            rho[0] = pair_ok ? 1.0 / T[4] : 0.0;
+            const int keep_old = lbfgs::keep_old(was_first, pair_ok, old_hist0, M);
+            rho[0] = pair_ok ? rcp_nr(T[4]) : 0.0;
 #pragma unroll
             for (int k = 1; k < P; ++k) if (k - 1 >= keep_old) rho[k] = 0.0;
             double al[P], ga[P];
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                double t = T[9 + k];
-#pragma unroll
-                for (int j = 0; j < k; ++j) t -= al[j] * T[19 + k * (k - 1) / 2 + j];
-                al[k] = rho[k] * t;
-            }
-#pragma unroll
-            for (int k = P - 1; k >= 0; --k) {
-                double t = T[14 + k];
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const int hi = j > k ? j : k, lo = j > k ? k : j;
-                    t -= al[j] * T[29 + hi * (hi + 1) / 2 + lo];
-                }
-#pragma unroll
-                for (int j = k + 1; j < P; ++j) t += ga[j] * T[19 + j * (j - 1) / 2 + k];
-                ga[k] = al[k] - rho[k] * t;
-            }
+            lbfgs::gram_two_loop<P>(rho, [&](int k) { return T[9 + k]; }, [&](int k) { return T[14 + k]; },
+                                    [&](int k, int j) { return T[19 + k * (k - 1) / 2 + j]; },
+                                    [&](int k, int j) { return T[29 + k * (k + 1) / 2 + j]; }, al, ga);
             double F[2] = {0.0, 0.0};              // d.G | max |d|
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -1761,7 +1716,7 @@ update_gram_kernel(UpdArgs a0)
                 red.run<0, 1>(m1);
                 F[1] = m1[0];
             }
-            st.t_step = (F[1] > a.max_step) ? a.max_step / F[1] : 1.0;
+            st.t_step = lbfgs::step_cap(F[1], a.max_step);
         }
     }
 

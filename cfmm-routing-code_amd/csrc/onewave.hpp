@@ -101,13 +101,10 @@ struct WaveUpdate {
         bool accept = first;
         if (!first) {
             const double dd0 = wsum([&](int e) { return Gs[e] * ds[e]; }), dd1 = wsum([&](int e) { return Gs_t[e] * ds[e]; });
-            accept = (f_t == f_t) && ((f_t <= st.f + a.armijo * dd0) ||
-                                      (f_t <= st.f + 1e-11 * fmax(1.0, fabs(st.f)) && dd1 <= 0.8 * fabs(dd0)));
+            accept = lbfgs::accept(f_t, st.f, a.armijo, dd0, dd1);
         }
         if (!accept) {
-            st.t_step *= 0.5;
-            st.nrej += 1;
-            if (st.t_step < 1e-9) st.status = 2;
+            lbfgs::reject(st);
         } else {
             // ---- C. curvature pair, move the accepted point ------------------------------------------------------------
             if (!first) {
@@ -116,8 +113,8 @@ struct WaveUpdate {
                 for (int e = 0; e < E; ++e) { y1[e] = gin[e] ? Gs_t[e] - Gs[e] : 0.0; Sh[st.head * W + L + 64 * e] = ds[e]; Yh[st.head * W + L + 64 * e] = y1[e]; }
                 const double sy = wsum([&](int e) { return ds[e] * y1[e]; }), ss = wsum([&](int e) { return ds[e] * ds[e]; }),
                              yy = wsum([&](int e) { return y1[e] * y1[e]; });
-                if (sy > 1e-12 * sqrt(ss) * sqrt(yy)) {
-                    if (L == st.head) rho_l = 1.0 / sy;
+                if (lbfgs::pair_ok(sy, ss, yy)) {
+                    if (L == st.head) rho_l = rcp_nr(sy);
                     st.head = (st.head + 1) % M;
                     if (st.hist < M) st.hist += 1;
                 }
@@ -125,18 +122,9 @@ struct WaveUpdate {
             }
 #pragma unroll
             for (int e = 0; e < E; ++e) { s[e] = s_t[e]; Gs[e] = Gs_t[e]; psi_a[e] = psi[e]; nu_a[e] = nuj[e]; }
-            st.f = f_t; st.first = 0;
-            st.gap = fabs(gapv) / fmax(1.0, fabs(f_t));
-            st.infeas = viol / fmax(scale, 1e-300);
-            st.primal = f_t - gapv;               // c'psi = g - (nu - c)'(psi + h)
-            st.pg = wsum([&](int e) {
-                double v = Gs[e];
-                if (glo[e] == ghi[e]) v = 0.0;
-                else if (s[e] <= glo[e] + 1e-14) v = fmin(Gs[e], 0.0);
-                else if (s[e] >= ghi[e] - 1e-14) v = fmax(Gs[e], 0.0);
-                return gin[e] ? fabs(v) : 0.0; }) / fmax(1.0, fabs(f_t));
-            const bool conv = a.pg_rule ? (st.pg <= a.tol_gap) : (st.gap <= a.tol_gap && st.infeas <= a.tol_infeas);
-            if (conv) {
+            st.first = 0;
+            lbfgs::certify(st, f_t, gapv, viol, scale, wsum([&](int e) { return gin[e] ? lbfgs::pg_entry(Gs[e], s[e], glo[e], ghi[e]) : 0.0; }));
+            if (lbfgs::converged(st, a.pg_rule, a.tol_gap, a.tol_infeas)) {
                 st.status = 1;
             } else {
                 // ---- D. two-loop recursion with the diagonal metric ----------------------------------------------------
@@ -181,7 +169,7 @@ struct WaveUpdate {
                 }
 #pragma unroll
                 for (int e = 0; e < E; ++e) d[e] = dv[e];
-                st.t_step = (dmx > a.max_step) ? a.max_step / dmx : 1.0;
+                st.t_step = lbfgs::step_cap(dmx, a.max_step);
             }
         }
         // ---- E. next trial point -----------------------------------------------------------------------------------------------
