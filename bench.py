@@ -357,7 +357,7 @@ def main():
                 sm_bytes = dom["bytes"] + 16 * sum(len(prob.net[k]["Ra"]) for k in ("cp2", "w2", "curve2") if k in prob.net)     # + the warm starts: 8 B per direction
                 tf = flops / nk["factor"] / 1e12
                 out["roofline"].update({
-                    "bound": "valu", "kernel": "chol_panel_kernel + chol_update_kernel (the dense Cholesky of one Newton step, all its launches)",
+                    "bound": "valu", "kernel": "chol_step_kernel (the dense Cholesky of one Newton step: one launch per block column, all 32 of them)",
                     "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
                     "valu_frac": tf / FP64_VECTOR_PEAK_TFLOPS, "hbm_frac": None, "traffic": None, "traffic_source": None,
                     "valu_frac_note": f"n^3/3 flops of the {nr} x {nr} factorisation / its measured time, against the fp64 vector peak",

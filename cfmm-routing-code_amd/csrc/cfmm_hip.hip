@@ -1026,13 +1026,13 @@ int launch_factor(cfmm_ctx *ctx, int n)
 {
     const int nr = hess_nr(n), ld = hess_ld(n), nrows = nr + 1;
     HIP_TRY(ctx, hipMemsetAsync(ctx->sm_info, 0, sizeof(int), ctx->stream));
-    for (int k0 = 0; k0 < nr; k0 += CH_NB) {
-        const int below = nrows - k0 - CH_NB;
-        hipLaunchKernelGGL(chol_panel_kernel, dim3(1 + (below + 63) / 64), dim3(256), 0, ctx->stream, ctx->H, ld, nrows, k0, ctx->Dinv, ctx->sm_info);
-        if (nr - k0 - CH_NB > 0) {
-            const int T = (below + 63) / 64;
-            hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, ctx->stream, ctx->H, ld, nrows, nr, k0);
-        }
+    // one launch per block column: panel k1 beside the trailing update of panel k1 - NB (chol.hpp: chol_step_kernel)
+    for (int k1 = 0; k1 < nr; k1 += CH_NB) {
+        const int below = nrows - k1 - CH_NB;                  // rows under the diagonal block, the right-hand side's included
+        const int npanel = 1 + (below + 63) / 64;
+        int ntiles = 0;
+        if (k1 > 0 && nr - k1 - CH_NB > 0) { const int T = (below + 63) / 64; ntiles = T * (T + 1) / 2; }
+        hipLaunchKernelGGL(chol_step_kernel, dim3(npanel + ntiles), dim3(256), 0, ctx->stream, ctx->H, ld, nrows, nr, k1, npanel, ctx->Dinv, ctx->sm_info);
     }
     HIP_TRY(ctx, hipGetLastError());
     return CFMM_OK;
@@ -1040,7 +1040,7 @@ int launch_factor(cfmm_ctx *ctx, int n)
 int launch_backsolve(cfmm_ctx *ctx, int n, double *x)
 {
     const int nr = hess_nr(n), ld = hess_ld(n);
-    hipLaunchKernelGGL(chol_back_kernel, dim3(1), dim3(CH_SOLVE_THREADS), (size_t)(nr + CH_NB) * sizeof(double), ctx->stream,
+    hipLaunchKernelGGL(chol_back_kernel, dim3(1), dim3(CH_SOLVE_THREADS), (size_t)(nr + CH_NB + 2 * CH_NB * CH_NB) * sizeof(double), ctx->stream,
                        (const double *)ctx->H, ld, nr, n, (const double *)ctx->Dinv, x);
     HIP_TRY(ctx, hipGetLastError());
     return CFMM_OK;
@@ -1120,7 +1120,7 @@ int smooth_buffers(cfmm_ctx *ctx, bool hess)
         int rc = dev_upload<double>(ctx, &ctx->H, nullptr, ld * nr, nullptr); if (rc) return rc;
         rc = dev_upload<double>(ctx, &ctx->Dinv, nullptr, nr * CH_NB, nullptr); if (rc) return rc;
         rc = dev_upload<int>(ctx, &ctx->sm_info, nullptr, 4, nullptr); if (rc) return rc;
-        if ((rc = set_lds_attr(ctx, chol_back_kernel, (nr + CH_NB) * sizeof(double)))) return rc;
+        if ((rc = set_lds_attr(ctx, chol_back_kernel, (nr + CH_NB + 2 * CH_NB * CH_NB) * sizeof(double)))) return rc;
     }
     return CFMM_OK;
 }
@@ -1273,9 +1273,13 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     std::vector<double> slo(n, 0.0), slo2(n, 0.0);       // low-order log-prices (smooth.hpp: apply_slo)
     bool slo_on = false;
     SmoothEval e, e2;
+    bool have_e = false;                        // the accepted line-search point was evaluated with its Hessian already
     for (;;) {
-        if ((rc = smooth_eval_host(ctx, nu, mu, true, e, true, slo_on ? &slo : nullptr))) return rc;
-        ++evals;
+        if (!have_e) {
+            if ((rc = smooth_eval_host(ctx, nu, mu, true, e, true, slo_on ? &slo : nullptr))) return rc;
+            ++evals;
+        }
+        have_e = false;
         const double gmu = assemble(nu, e, mu, &G, &Hd);
         if (!std::isfinite(gmu)) { status = CFMM_E_NUMERIC; break; }
         // certificates: exact dual value (an upper bound) against the smoothed, pool-feasible primal point.  Each
@@ -1364,15 +1368,19 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
                 gd += G[j] * ((s2[j] + slo2[j]) - (s[j] + slo[j]));
             }
             slo2_on = small;
-            if ((rc = smooth_eval_host(ctx, nu2, mu, false, e2, true, slo2_on ? &slo2 : nullptr))) return rc;
+            // the first trial is nearly always taken: when the barrier weight stays as it is, the next step starts with exactly
+            // this evaluation plus the Hessian -- so ask for the Hessian now (+50%) and save that evaluation and its round trip
+            const bool with_h = ls == 0 && (final_mu || !(dec < 10.0 * mu * (double)nbar));
+            if ((rc = smooth_eval_host(ctx, nu2, mu, with_h, e2, true, slo2_on ? &slo2 : nullptr))) return rc;
             ++evals;
             const double g2 = assemble(nu2, e2, mu, nullptr, nullptr);
-            if (g2 <= gmu + o.armijo * gd || dec <= 1e-13 * std::fabs(gmu)) { moved = true; break; }
+            if (g2 <= gmu + o.armijo * gd || dec <= 1e-13 * std::fabs(gmu)) { moved = true; have_e = with_h; break; }
             t *= 0.5;
         }
         if (trace) fprintf(stderr, "[newton]    dec %.3e |d| %.3e t %.3e (first %.3e) moved %d\n", dec, dmax, t, t_first, (int)moved);
         if (!moved) { status = 2; break; }
         s = s2; nu = nu2; slo = slo2; slo_on = slo2_on;
+        if (have_e) std::swap(e, e2);
         {                                       // a price that has collapsed by e^-60 since the start: a token that must be traded away
             bool collapsed = false;             // but that no pool takes (the program is infeasible); no point in going on
             for (int j = 0; j < n; ++j) collapsed = collapsed || (!mask[j] && s[j] < s_start[j] - 60.0);
@@ -2118,9 +2126,10 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     if (o.method == CFMM_METHOD_NEWTON || (o.method == CFMM_METHOD_AUTO && can_newton && near_linear_pools(ctx) && !o.pg_rule)) {
         // Large problems from a cold start: a handful of first-order evaluations first.  They are cheap (an evaluation
         // and an on-device update, no factorisation) and move the start prices most of the way, which the second-order
-        // method would otherwise spend its first ~8 capped steps on (config 5: liquidation 18 -> 10 steps, 23 -> 14.8 ms;
-        // linear arbitrage 17 -> 10 steps, 22 -> 15 ms).
-        static const int prelude = getenv("CFMM_NEWTON_PRELUDE") ? atoi(getenv("CFMM_NEWTON_PRELUDE")) : 16;     // tuning knob
+        // method would otherwise spend its first ~8 capped steps on (config 5, round 2: liquidation 18 -> 10 steps, 23 -> 14.8 ms;
+        // linear arbitrage 17 -> 10 steps, 22 -> 15 ms).  Round 3, with a Newton step at 0.8 ms instead of 1.2: 8 / 12 / 16 / 24
+        // evaluations give liquidation 8.7 / 9.1 / 9.8 / 10.9 ms and linear arbitrage 12.3 / 11.1 / 10.7 / 11.1 ms: 12.
+        static const int prelude = getenv("CFMM_NEWTON_PRELUDE") ? atoi(getenv("CFMM_NEWTON_PRELUDE")) : 12;     // tuning knob
         int used = 0;
         double w0 = 0.0, d0 = 0.0;
         if (prelude > 0 && can_newton && ctx->warm_mu == 0.0 && ctx->g_total >= 50000 && !o.pg_rule) {

@@ -7,20 +7,17 @@
 // Layout: column-major, lower triangle.  nr = n rounded up to the block size NB = 32 (padding rows / columns
 // carry an identity diagonal); the right-hand side rides along as ONE EXTRA ROW at index nr, so the
 // factorisation forward-substitutes it for free (row nr of L is y = L^-1 b); ld = nr + NB.
-// Right-looking, two launches per block column:
-//   chol_panel_kernel   every workgroup (256 threads) factors the NB x NB diagonal block itself, operands in
-//                       registers, one column exchanged through LDS per elimination step (one barrier per
-//                       step), then solves its own 64 rows of the panel against it column by column.
-//                       Workgroup 0 writes the factor back and leaves the inverse of the diagonal block in
-//                       `Dinv` for the back substitution.  (A one-wave variant with row-per-lane registers and
-//                       v_readlane broadcasts needed no barrier but issued ~3300 instructions from a single
-//                       wave: 24 us per launch against 16.6 us.  NB = 64 halves the launches but the per-step
-//                       rank-one work quadruples: 50 us per panel launch, 1.06 ms per factorisation against
-//                       0.85 ms at NB = 32.)
-//   chol_update_kernel  trailing update C_ij -= P_i P_j' on the lower 64 x 64 tiles (C prefetched into
-//                       registers before the panel is staged in LDS, 32 columns at a time).
-// chol_back_kernel: L' x = y, one workgroup, dot form (every pass over L reads contiguous columns: wave w
-// owns NB/16 columns of the block), the diagonal block applied as an NB x NB mat-vec with its inverse.
+// Right-looking with a look-ahead of one block column, ONE launch per block column (chol_step_kernel below): the panel
+// workgroups of column k + 1 apply their own share of update k, factor the diagonal block (one wave, in registers, factor and
+// inverse together: WaveFactor) and form their rows as a product with that inverse, while the other workgroups of the same
+// launch give update k to the columns from k + 2 on.  1000 x 1000: 0.75 ms (round 2: two launches per column, barrier-stepped
+// block routines) -> 0.35 ms.
+// chol_back_kernel: L' x = y, one workgroup, dot form (every pass over L reads contiguous columns: wave w owns NB/16 columns
+// of the block), the diagonal block applied as an NB x NB mat-vec with its inverse.
+// (Tried and dropped: NB = 64 -- half the launches, but the diagonal block's elimination chain grows fourfold: 1.06 ms;
+//  round 2's one-launch scheme with the panel rows formed through an inverse that took a 16-18 us barrier-stepped chain of
+//  its own; a barrier-stepped four-wave block factorisation, two columns per barrier: 16 300 cycles a block against 11 700
+//  for the single wave, and it does not yield the inverse.)
 #pragma once
 #include "kernels.hpp"
 
@@ -28,161 +25,127 @@ namespace cfmm {
 
 constexpr int CH_NB = 32;
 
-// shared scratch of the 32 x 32 block routines below
-struct BlockLds {
-    double Lc[CH_NB][CH_NB + 1];         // Lc[j][r]: FINAL column j of the block, rows r >= j (unscaled while factoring)
-    double E0[2][CH_NB], E1[2][CH_NB];   // exchange: column j (final) and column j + 1 (still missing column j's update)
-    double X0[2][64], X1[2][64];         // the same for the panel solve
-    double piv[CH_NB];                   // 1 / L[j][j]
+// v of lane `src` (a compile-time lane) to every lane: two v_readlane_b32
+template <int SRC> __device__ __forceinline__ double lane_bcast(double v)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC), hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
+    return __hiloint2double(hi, lo);
+}
+
+// Cholesky factor AND its inverse of a 32 x 32 block by ONE wave, in registers, no barrier.  Lane c < 32 holds column c
+// (= row c) of the symmetric block in a[0..32), lane 32 + c column c of the identity.  Elimination step j is the same
+// instruction stream on both halves: d = 1 / sqrt(pivot); row j scaled by d (lane c now holds L[c][j], lane 32 + c holds
+// Linv[j][c]); row r > j minus L[r][j] times row j.  The left half is the right-looking Cholesky on the full symmetric
+// square, the right half the same row operations on I, i.e. L^-1.
+// What bounds it is the DEPENDENT chain from one pivot to the next (a lone wave waits out every fp64 result: ~16 cycles an
+// operation), so that chain is kept to [rsq, 3 operations of a third-order correction, 2 operations for the next pivot]:
+//   * the next pivot is formed from uniform values, p' = c - (b y)^2 with b = a[j] and c = a[j + 1] of lane j + 1, both
+//     broadcast (v_readlane) BEFORE y = 1 / sqrt(p) is known -- no lane traffic and no scalar-unit round trip inside the chain;
+//   * the pivot's sign test is off the chain (a non-positive pivot yields NaNs and the `false` the caller reports);
+//   * rows j + 1 and j + 2 take step j's update at once, through uniform multipliers (a[j] of lanes j + 1, j + 2 times y);
+//     the other 29 - j rows have two steps of slack: they are updated one step LATE, in the shadow of step j + 1's chain,
+//     with L[r][j] broadcast out of a 2 x 64 LDS buffer (ds_read_b128: one LDS instruction and two fmas per pair of terms,
+//     against two v_readlane, a hazard nop and an fma per term), so no LDS latency sits inside the chain either.
+// `Lb`: 128 doubles of LDS.  On return lane c < 32: a[j] = L[c][j] (j <= c), lane 32 + c: a[j] = Linv[j][c] (exactly 0 for j < c).
+template <int J> struct WaveFactor {
+    // late rows J + 2 + K, J + 2 + K + NS, ...: a[r] -= L[r][J - 1] lp, the multipliers in lv (read from LDS a step ago)
+    template <int K, int NS> static __device__ __forceinline__ void slot(double (&a)[CH_NB], const double (&lv)[CH_NB], double lp)
+    {
+        if constexpr (J > 0) {
+#pragma unroll
+            for (int r = J + 2 + K; r < CH_NB; r += NS) a[r] = fma(-lv[r], lp, a[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // p: the pivot a[J][J] with every earlier column's update applied, the same value in every lane.  lp: column J - 1 (this lane's
+    // entry), lv[r] = L[r][J - 1] for the rows r >= J + 2 that still lack column J - 1's update.
+    // The issue order is pinned (sched_barrier): one operation of the chain, then a share of the late rows -- a lone wave issues in
+    // order, and left alone the scheduler puts the chain first (seven stalls on fp64 latency) and the independent fmas behind it.
+    static __device__ __forceinline__ bool run(double (&a)[CH_NB], double p, double lp, const double (&lv)[CH_NB], double *Lb, int lane)
+    {
+        if constexpr (J < CH_NB) {
+            constexpr int NS = 6;
+            const double y0 = __builtin_amdgcn_rsq(p);
+            double b1 = 0.0, b2 = 0.0, c = 0.0;
+            if constexpr (J + 1 < CH_NB) { b1 = lane_bcast<J + 1>(a[J]); c = lane_bcast<J + 1>(a[J + 1]); }
+            if constexpr (J + 2 < CH_NB) b2 = lane_bcast<J + 2>(a[J]);
+            __builtin_amdgcn_sched_barrier(0);
+            const double t = -p * y0;
+            slot<0, NS>(a, lv, lp);
+            const double e = fma(t, y0, 1.0);                             // y = y0 (1 + e / 2 + 3 e^2 / 8): relative error O(e^3)
+            slot<1, NS>(a, lv, lp);
+            const double q = y0 * e, h = fma(0.375, e, 0.5);
+            slot<2, NS>(a, lv, lp);
+            const double y = fma(q, h, y0);
+            slot<3, NS>(a, lv, lp);
+            const double m1 = b1 * y, l = a[J] * y, m2 = b2 * y;          // m1 = L[J + 1][J], m2 = L[J + 2][J]
+            Lb[(J & 1) * 64 + lane] = l;                                  // (no branch: the identity half's lanes write slots nobody reads)
+            double lvn[CH_NB];
+#pragma unroll
+            for (int r = J + 3; r < CH_NB; ++r) lvn[r] = Lb[(J & 1) * 64 + r];     // (the next step's late rows: issued now, used a chain later)
+            slot<4, NS>(a, lv, lp);
+            const double pn = fma(-m1, m1, c);
+            a[J] = l;
+            slot<5, NS>(a, lv, lp);
+            if constexpr (J + 1 < CH_NB) a[J + 1] = fma(-m1, l, a[J + 1]);
+            if constexpr (J + 2 < CH_NB) a[J + 2] = fma(-m2, l, a[J + 2]);
+            const bool pos = p > 0.0 && p < 1.7976931348623157e308;
+            return WaveFactor<J + 1>::run(a, pn, l, lvn, Lb, lane) && pos;
+        } else return true;
+    }
 };
 
-// In-place Cholesky of a 32 x 32 block by 256 threads.  Thread (r = tid % 32, g = tid / 32) holds the block's elements
-// (r, c = g + 8 q), q < 4, in a[] (entries above the diagonal must be 0).  TWO columns per barrier: with column j final
-// and column j + 1 published as it stands, every thread finishes column j + 1 for its own rows itself
-// (f = e1 - e0 l, l = D[j+1][j] / p_j) and applies the rank-two update; the dependent chain per pair is one LDS round
-// trip, two reciprocals and one barrier.  On return S.Lc[c][r] = L[r][c] (r >= c), S.piv[j] = 1 / L[j][j].
-__device__ __forceinline__ bool block_factor(double (&a)[CH_NB / 8], BlockLds &S)
-{
-    constexpr int NB = CH_NB, G = 256 / NB, Q = NB / G;
-    static_assert(NB % 2 == 0 && Q == CH_NB / 8, "columns are eliminated in pairs; 256 threads");
-    const int tid = threadIdx.x, r = tid % NB, g = tid / NB;
-    if (g == 0) { S.E0[0][r] = a[0]; S.Lc[0][r] = a[0]; }
-    if (g == 1 % G) S.E1[0][r] = a[1 / G];
-    __syncthreads();
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < NB; j += 2) {
-        const int pb = (j >> 1) & 1;
-        const double p0 = S.E0[pb][j], d10 = S.E0[pb][j + 1];
-        const bool pos0 = p0 > 0.0 && p0 < 1.7976931348623157e308;
-        const double ip0 = rcp_nr(pos0 ? p0 : 1.0);
-        const double m = d10 * ip0;
-        const double p1 = fma(-d10, m, S.E1[pb][j + 1]);
-        const bool pos1 = p1 > 0.0 && p1 < 1.7976931348623157e308;
-        ok = ok && pos0 && pos1;
-        const double ip1 = rcp_nr(pos1 ? p1 : 1.0);
-        const double e0r = S.E0[pb][r];
-        const double fr = fma(-e0r, m, S.E1[pb][r]);           // final column j + 1, own row
-        const double s0 = e0r * ip0, s1 = fr * ip1;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int c = g + G * q;
-            if (c > j + 1 && c <= r) {
-                const double e0c = S.E0[pb][c];
-                const double fc = fma(-e0c, m, S.E1[pb][c]);
-                a[q] = fma(-s0, e0c, fma(-s1, fc, a[q]));
-            }
-        }
-        if (g == ((j + 1) % G)) { a[(j + 1) / G] = (r >= j + 1) ? fr : 0.0; S.Lc[j + 1][r] = a[(j + 1) / G]; }
-        if (j + 2 < NB) {
-            if (g == ((j + 2) % G)) { S.E0[pb ^ 1][r] = a[(j + 2) / G]; S.Lc[j + 2][r] = a[(j + 2) / G]; }
-            if (g == ((j + 3) % G)) S.E1[pb ^ 1][r] = a[(j + 3) / G];
-        }
-        __syncthreads();
-    }
-    if (tid < NB) { const double p = S.Lc[tid][tid]; S.piv[tid] = rsqrt_nr(p > 0.0 && p < 1.7976931348623157e308 ? p : 1.0); }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < Q; ++q) { const int c = g + G * q; if (c < r) S.Lc[c][r] *= S.piv[c]; }      // L[r][c]
-    if (g == 0) S.Lc[r][r] *= S.piv[r];                                                              // sqrt(p)
-    __syncthreads();
-    return ok;
-}
-
-// X L' = B for 64 rows against the factor left in S by block_factor.  Thread (rr = tid % 64, h = tid / 64) holds
-// x[rr][c = h + 4 q], q < 8.  Two columns per barrier:  x_j = raw_j / L_jj,  x_{j+1} = (raw_{j+1} - x_j L[j+1][j]) / L_{j+1,j+1}.
-__device__ __forceinline__ void block_solve(double (&x)[CH_NB / 4], BlockLds &S)
-{
-    constexpr int NB = CH_NB, H = 4, QX = NB / H;
-    const int tid = threadIdx.x, rr = tid & 63, h = tid >> 6;
-    if (h == 0) S.X0[0][rr] = x[0];
-    if (h == 1) S.X1[0][rr] = x[0];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NB; j += 2) {
-        const int pb = (j >> 1) & 1;
-        const double xj = S.X0[pb][rr] * S.piv[j];
-        const double xj1 = fma(-xj, S.Lc[j][j + 1], S.X1[pb][rr]) * S.piv[j + 1];
-#pragma unroll
-        for (int q = 0; q < QX; ++q) { const int c = h + H * q; if (c > j + 1) x[q] = fma(-xj, S.Lc[j][c], fma(-xj1, S.Lc[j + 1][c], x[q])); }
-        if (h == (j % H)) x[j / H] = xj;
-        if (h == ((j + 1) % H)) x[(j + 1) / H] = xj1;
-        if (j + 2 < NB) {
-            if (h == ((j + 2) % H)) S.X0[pb ^ 1][rr] = x[(j + 2) / H];
-            if (h == ((j + 3) % H)) S.X1[pb ^ 1][rr] = x[(j + 3) / H];
-        }
-        __syncthreads();
-    }
-}
-
+// ------------------------------------------------------------------------------------------------------------------------
+// One launch per block column (round 3): panel k + 1 and the trailing update of panel k run SIDE BY SIDE.
+//
+// The two-launch scheme of round 2 serialised [panel k: a 32-column elimination chain, ~13 us] -> [update k: ~10 us of mostly
+// latency] 32 times.  But block column k + 1 is the only part of the trailing matrix the next panel needs, and it needs
+// only ITS OWN share of update k: so the workgroups that will factor / solve column k + 1 apply that share themselves --
+// D = A_dd - P_d P_d' for the diagonal block (redundantly in every panel workgroup, like its factorisation), B_i = A_i -
+// P_i P_d' for their 64 rows -- and go straight on to the panel, while other workgroups of the SAME launch give panel k's
+// update to the columns from k + 2 on.  No workgroup waits for another: what a launch writes (column k + 1 by the panel
+// workgroups, columns >= k + 2 by the update workgroups) is disjoint, and what it reads of panel k was finished by the
+// previous launch.  32 launches instead of 63.
+//
+// The panel role, per workgroup of four waves (cycles at 2.4 GHz measured in the first version -> this one):
+//   stage    every global operand (own 64 rows of the column, the diagonal block, the previous panel's rows for both) into
+//            registers, then LDS                                                                    3700
+//   D        A_dd - P_d P_d', full symmetric square, 2 x 2 register tiles                            2700 -> ~800
+//   factor   WaveFactor in wave 0 (factor + inverse)  ||  waves 2-3: B = A_i - P_i P_d' (4 x 4 tiles)  16 300 + 5700 -> ~9000
+//   solve    X = B Linv' as a 64 x 32 x 32 product out of LDS (the triangular solve it replaces was a 32-step chain
+//            with a barrier every other step)                                                        9400 -> ~1500
+// blockIdx < npanel: panel role for block column k1 (workgroup 0 has no rows: it writes the factor and its inverse); the
+// others: tile (ti, tj) of the trailing update with panel k0 = k1 - NB over the rows / columns from k1 + NB on.
+// ------------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-chol_panel_kernel(double *__restrict__ A, int ld, int nrows, int k0, double *__restrict__ Dinv, int *__restrict__ info)
+chol_step_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k1, int npanel, double *__restrict__ Dinv, int *__restrict__ info)
 {
-    constexpr int NB = CH_NB, G = 256 / NB, Q = NB / G, H = 4, QX = NB / H;
-    __shared__ BlockLds S;
+    constexpr int NB = CH_NB;
+    __shared__ __attribute__((aligned(16))) double lds[NB * NB + NB * 64 + NB * 64 + NB * (NB + 1) + NB * NB + 2 * 64];      // 57.25 KB (the tile role uses 33 KB of it)
     const int tid = threadIdx.x;
-    {
-        const int r = tid % NB, g = tid / NB;
-        double a[Q];
+    const bool have_prev = k1 > 0;
+    const int k0 = k1 - NB;
+    if ((int)blockIdx.x >= npanel) {
+        // ---- trailing update with panel k0 over rows / columns >= k1 + NB: 64 x 64 tile (ti, tj) of the lower triangle ---------
+        double (*Pi)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(lds), (*Pj)[64 + 1] = Pi + 32;
+        int t = (int)blockIdx.x - npanel, ti = 0;
+        while (t > ti) { t -= ti + 1; ++ti; }
+        const int tj = t;
+        const int base = k1 + NB;
+        const int i0 = base + 64 * ti, j0 = base + 64 * tj;
+        const int tx = tid & 15, ty = tid >> 4;      // rows tx + 16 u, columns ty + 16 v
+        double cv[4][4];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) { const int c = g + G * q; const double v = A[(size_t)(k0 + c) * ld + k0 + r]; a[q] = (c <= r) ? v : 0.0; }
-        const bool ok = block_factor(a, S);
-        if (blockIdx.x == 0) {
-            if (!ok && tid == 0) atomicMax(info, k0 + 1);
+        for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int q = 0; q < Q; ++q) { const int c = g + G * q; A[(size_t)(k0 + c) * ld + k0 + r] = (c <= r) ? S.Lc[c][r] : 0.0; }
-        }
-    }
-    // ---- solve X L' = B for 64 rows (workgroup 0: B = I, giving X = L^-T, i.e. the inverse transposed)
-    const int rr = tid & 63, h = tid >> 6;
-    const int row = k0 + NB + 64 * ((int)blockIdx.x - 1) + rr;
-    const bool diag_wg = blockIdx.x == 0;
-    const bool live = diag_wg ? rr < NB : row < nrows;
-    double x[QX];
-#pragma unroll
-    for (int q = 0; q < QX; ++q) {
-        const int c = h + H * q;
-        if (diag_wg) x[q] = (c == rr) ? 1.0 : 0.0;
-        else x[q] = A[(size_t)(k0 + c) * ld + (live ? row : k0)];
-    }
-    block_solve(x, S);
-    if (live) {
-#pragma unroll
-        for (int q = 0; q < QX; ++q) {
-            const int c = h + H * q;
-            if (diag_wg) Dinv[(size_t)(k0 / NB) * NB * NB + c * NB + rr] = x[q];      // Linv[c][rr] = X[rr][c]
-            else A[(size_t)(k0 + c) * ld + row] = x[q];
-        }
-    }
-}
-
-// trailing update after block column k0: tile (ti, tj), ti >= tj, of 64 x 64 over rows >= k0 + NB (< nrows) and
-// columns >= k0 + NB (< ncols)
-__global__ void __launch_bounds__(256)
-chol_update_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k0)
-{
-    __shared__ double Pi[32][64 + 1], Pj[32][64 + 1];
-    // linear tile index -> (ti, tj) in the lower triangle
-    int t = blockIdx.x, ti = 0;
-    while (t > ti) { t -= ti + 1; ++ti; }
-    const int tj = t;
-    const int base = k0 + CH_NB;
-    const int i0 = base + 64 * ti, j0 = base + 64 * tj;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // rows tx + 16 u, columns ty + 16 v
-    double cv[4][4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = i0 + tx + 16 * u, col = j0 + ty + 16 * v;
-            cv[u][v] = (row < nrows && col < ncols && row >= col) ? A[(size_t)col * ld + row] : 0.0;
-        }
-    for (int kk = 0; kk < CH_NB; kk += 32) {
-        if (kk) __syncthreads();
-        for (int e = threadIdx.x; e < 32 * 64; e += 256) {
+            for (int u = 0; u < 4; ++u) {
+                const int row = i0 + tx + 16 * u, col = j0 + ty + 16 * v;
+                cv[u][v] = (row < nrows && col < ncols && row >= col) ? A[(size_t)col * ld + row] : 0.0;
+            }
+        for (int e = tid; e < 32 * 64; e += 256) {
             const int c = e >> 6, rr = e & 63;
-            Pi[c][rr] = (i0 + rr < nrows) ? A[(size_t)(k0 + kk + c) * ld + i0 + rr] : 0.0;
-            Pj[c][rr] = (j0 + rr < ncols) ? A[(size_t)(k0 + kk + c) * ld + j0 + rr] : 0.0;
+            Pi[c][rr] = (i0 + rr < nrows) ? A[(size_t)(k0 + c) * ld + i0 + rr] : 0.0;
+            Pj[c][rr] = (j0 + rr < ncols) ? A[(size_t)(k0 + c) * ld + j0 + rr] : 0.0;
         }
         __syncthreads();
 #pragma unroll 8
@@ -195,15 +158,135 @@ chol_update_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k0)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) cv[u][v] = fma(-pi[u], pj[v], cv[u][v]);
         }
-    }
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int col = j0 + ty + 16 * v;
+        for (int v = 0; v < 4; ++v) {
+            const int col = j0 + ty + 16 * v;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = i0 + tx + 16 * u;
-            if (row < nrows && col < ncols && row >= col) A[(size_t)col * ld + row] = cv[u][v];
+            for (int u = 0; u < 4; ++u) {
+                const int row = i0 + tx + 16 * u;
+                if (row < nrows && col < ncols && row >= col) A[(size_t)col * ld + row] = cv[u][v];
+            }
         }
+        return;
+    }
+    // ---- panel role for block column k1 ----------------------------------------------------------------------------------
+    double *Pd = lds;                        // Pd[m * NB + r]   = panel k0, column m, row k1 + r (the diagonal block's rows)
+    double *Pr = Pd + NB * NB;               // Pr[m * 64 + rr]  = panel k0, column m, this workgroup's row rr
+    double *Xs = Pr + NB * 64;               // Xs[c * 64 + rr]  = block column k1, column c, this workgroup's row rr
+    double *Dd = Xs + NB * 64;               // Dd[r * (NB + 1) + c]: the diagonal block, full symmetric square
+    double *Li = Dd + NB * (NB + 1);         // Li[k * NB + c]   = Linv[c][k]
+    double *Lb = Li + NB * NB;               // WaveFactor's exchange
+    const bool diag_wg = blockIdx.x == 0;
+    const int row0 = k1 + NB + 64 * ((int)blockIdx.x - 1);           // (row-panel workgroups) first of the 64 rows
+    {
+        // every load first, then the LDS stores (written as a load-store loop the round trips ran one after the other)
+        double xv[NB * 64 / 256], prv[NB * 64 / 256], pdv[NB * NB / 256], dv[NB * NB / 256];
+        if (!diag_wg) {
+#pragma unroll
+            for (int i = 0; i < NB * 64 / 256; ++i) {
+                const int e = tid + 256 * i, rw = row0 + (e & 63);
+                xv[i] = rw < nrows ? A[(size_t)(k1 + (e >> 6)) * ld + rw] : 0.0;
+                if (have_prev) prv[i] = rw < nrows ? A[(size_t)(k0 + (e >> 6)) * ld + rw] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB * NB / 256; ++i) {
+            const int e = tid + 256 * i, c = e / NB, r = e % NB;
+            dv[i] = A[(size_t)(k1 + c) * ld + k1 + r];                                    // (the lower triangle is what counts: c <= r)
+            if (have_prev) pdv[i] = A[(size_t)(k0 + c) * ld + k1 + r];
+        }
+        if (!diag_wg) {
+#pragma unroll
+            for (int i = 0; i < NB * 64 / 256; ++i) { const int e = tid + 256 * i; Xs[e] = xv[i]; if (have_prev) Pr[e] = prv[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < NB * NB / 256; ++i) {
+            const int e = tid + 256 * i, c = e / NB, r = e % NB;
+            if (c <= r) { Dd[r * (NB + 1) + c] = dv[i]; Dd[c * (NB + 1) + r] = dv[i]; }
+            if (have_prev) Pd[e] = pdv[i];
+        }
+    }
+    __syncthreads();
+    if (have_prev) {
+        // D -= P_d P_d' on the whole square (both triangles come out bitwise equal: the same products in the same order)
+        const int r2 = 2 * (tid & 15), c2 = 2 * (tid >> 4);
+        double d00 = Dd[r2 * (NB + 1) + c2], d01 = Dd[r2 * (NB + 1) + c2 + 1], d10 = Dd[(r2 + 1) * (NB + 1) + c2], d11 = Dd[(r2 + 1) * (NB + 1) + c2 + 1];
+#pragma unroll 8
+        for (int m = 0; m < NB; ++m) {
+            const double2 pr = *reinterpret_cast<const double2 *>(Pd + m * NB + r2), pc = *reinterpret_cast<const double2 *>(Pd + m * NB + c2);
+            d00 = fma(-pr.x, pc.x, d00); d01 = fma(-pr.x, pc.y, d01); d10 = fma(-pr.y, pc.x, d10); d11 = fma(-pr.y, pc.y, d11);
+        }
+        Dd[r2 * (NB + 1) + c2] = d00; Dd[r2 * (NB + 1) + c2 + 1] = d01; Dd[(r2 + 1) * (NB + 1) + c2] = d10; Dd[(r2 + 1) * (NB + 1) + c2 + 1] = d11;
+        __syncthreads();
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave == 0) {
+        double a[NB];
+        const int c = lane & (NB - 1);
+#pragma unroll
+        for (int r = 0; r < NB; ++r) a[r] = lane < NB ? Dd[c * (NB + 1) + r] : (r == c ? 1.0 : 0.0);
+        double lv0[NB];
+        const bool ok = WaveFactor<0>::run(a, lane_bcast<0>(a[0]), 0.0, lv0, Lb, lane);
+        if (lane >= NB) {
+#pragma unroll
+            for (int j = 0; j < NB; j += 2) *reinterpret_cast<double2 *>(Li + c * NB + j) = make_double2(a[j], a[j + 1]);      // Li[k = c][j] = Linv[j][c]
+        }
+        if (diag_wg) {
+            if (!ok && lane == 0) atomicMax(info, k1 + 1);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (lane < NB) A[(size_t)(k1 + j) * ld + k1 + c] = (j <= c) ? a[j] : 0.0;       // L[c][j]
+                else Dinv[(size_t)(k1 / NB) * NB * NB + j * NB + c] = a[j];                      // Linv[j][c]
+            }
+        }
+    } else if (wave >= 2 && have_prev && !diag_wg) {
+        // B = A_i - P_i P_d' for the 64 rows, in place in Xs: 4 x 4 tiles over the 128 threads of waves 2-3
+        const int t2 = tid - 128, rq = 4 * (t2 & 15), cq = 4 * (t2 >> 4);
+        double acc[4][4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double2 lo = *reinterpret_cast<const double2 *>(Xs + (cq + v) * 64 + rq), hi = *reinterpret_cast<const double2 *>(Xs + (cq + v) * 64 + rq + 2);
+            acc[0][v] = lo.x; acc[1][v] = lo.y; acc[2][v] = hi.x; acc[3][v] = hi.y;
+        }
+#pragma unroll 4
+        for (int m = 0; m < NB; ++m) {
+            const double2 p0 = *reinterpret_cast<const double2 *>(Pr + m * 64 + rq), p1 = *reinterpret_cast<const double2 *>(Pr + m * 64 + rq + 2);
+            const double2 q0 = *reinterpret_cast<const double2 *>(Pd + m * NB + cq), q1 = *reinterpret_cast<const double2 *>(Pd + m * NB + cq + 2);
+            const double pr[4] = {p0.x, p0.y, p1.x, p1.y}, pc[4] = {q0.x, q0.y, q1.x, q1.y};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = fma(-pr[u], pc[v], acc[u][v]);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            *reinterpret_cast<double2 *>(Xs + (cq + v) * 64 + rq) = make_double2(acc[0][v], acc[1][v]);
+            *reinterpret_cast<double2 *>(Xs + (cq + v) * 64 + rq + 2) = make_double2(acc[2][v], acc[3][v]);
+        }
+    }
+    if (diag_wg) return;
+    __syncthreads();
+    // ---- X = B Linv':  X[rr][c] = sum_{k <= c} B[rr][k] Linv[c][k]; thread: rows rq..rq+3, columns c2, c2 + 1 ------------------
+    {
+        const int rq = 4 * (tid & 15), c2 = 2 * (tid >> 4);
+        const int kmax = 2 * (4 * wave + 3) + 1;                 // the wave's largest column (Linv is lower triangular: exact zeros beyond)
+        double acc[4][2] = {};
+#pragma unroll 4
+        for (int k = 0; k <= kmax; ++k) {
+            const double2 b0 = *reinterpret_cast<const double2 *>(Xs + k * 64 + rq), b1 = *reinterpret_cast<const double2 *>(Xs + k * 64 + rq + 2);
+            const double2 li = *reinterpret_cast<const double2 *>(Li + k * NB + c2);
+            acc[0][0] = fma(b0.x, li.x, acc[0][0]); acc[0][1] = fma(b0.x, li.y, acc[0][1]);
+            acc[1][0] = fma(b0.y, li.x, acc[1][0]); acc[1][1] = fma(b0.y, li.y, acc[1][1]);
+            acc[2][0] = fma(b1.x, li.x, acc[2][0]); acc[2][1] = fma(b1.x, li.y, acc[2][1]);
+            acc[3][0] = fma(b1.y, li.x, acc[3][0]); acc[3][1] = fma(b1.y, li.y, acc[3][1]);
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rw = row0 + rq + u;
+                if (rw < nrows) A[(size_t)(k1 + c2 + v) * ld + rw] = acc[u][v];
+            }
     }
 }
 
@@ -214,19 +297,31 @@ chol_back_kernel(const double *__restrict__ L, int ld, int nr, int n, const doub
 {
     constexpr int NB = CH_NB, CW = NB / 16;       // columns per wave
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *x = lds, *dsum = lds + nr;
+    double *x = lds, *dsum = lds + nr, *Dblk = dsum + NB;          // Dblk[2][NB * NB]: the inverse diagonal blocks, staged a step ahead
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < nr; i += blockDim.x) x[i] = L[(size_t)i * ld + nr];
+    Dblk[tid] = Dinv[(size_t)(nr / NB - 1) * NB * NB + tid];       // (NB * NB == CH_SOLVE_THREADS)
     __syncthreads();
+    int buf = 0;
     for (int k0 = nr - NB; k0 >= 0; k0 -= NB) {
+        // (the next step's inverse block does not depend on x: it travels while this step's dots are formed, instead of 32
+        //  dependent global loads inside the block solve)
+        if (k0 >= NB) Dblk[(buf ^ 1) * NB * NB + tid] = Dinv[(size_t)(k0 / NB - 1) * NB * NB + tid];
         // wave w: columns k0 + 2 w, k0 + 2 w + 1 of L dotted with the part of x already solved
         {
-            static_assert(CW == 2, "two columns per wave");
+            static_assert(CW == 2 && NB * NB == CH_SOLVE_THREADS, "two columns per wave; one inverse-block entry per thread");
             const int c0 = k0 + 2 * wave;
             double p0 = 0.0, p1 = 0.0;
             const double *L0 = L + (size_t)c0 * ld, *L1 = L0 + ld;
             int j = k0 + NB + lane;
-            for (; j + 192 < nr; j += 256) {              // four independent row strips in flight per pass
+            for (; j + 448 < nr; j += 512) {              // eight independent row strips of both columns in flight per pass
+                double a[8], b[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { a[s] = L0[j + 64 * s]; b[s] = L1[j + 64 * s]; }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { const double xs = x[j + 64 * s]; p0 = fma(a[s], xs, p0); p1 = fma(b[s], xs, p1); }
+            }
+            for (; j + 192 < nr; j += 256) {              // four
                 const double a0 = L0[j], a1 = L0[j + 64], a2 = L0[j + 128], a3 = L0[j + 192];
                 const double b0 = L1[j], b1 = L1[j + 64], b2 = L1[j + 128], b3 = L1[j + 192];
                 p0 = fma(a0, x[j], p0); p0 = fma(a1, x[j + 64], p0); p0 = fma(a2, x[j + 128], p0); p0 = fma(a3, x[j + 192], p0);
@@ -243,13 +338,14 @@ chol_back_kernel(const double *__restrict__ L, int ld, int nr, int n, const doub
         __syncthreads();
         if (wave == 0 && lane < NB) {
             // x_r = sum_{c >= r} Linv[c][r] (y_c - d_c)
-            const double *D = Dinv + (size_t)(k0 / NB) * NB * NB;
+            const double *D = Dblk + buf * NB * NB;
             double acc = 0.0;
 #pragma unroll 8
             for (int c = 0; c < NB; ++c) acc = fma(D[c * NB + lane], x[k0 + c] - dsum[c], acc);
             x[k0 + lane] = acc;
         }
         __syncthreads();
+        buf ^= 1;
     }
     for (int i = tid; i < n; i += blockDim.x) out[i] = x[i];
 }
