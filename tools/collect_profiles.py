@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Copies the judged summaries of the last `tools/gpu_profile.sh` run (gpurun_out/p, scratch) into profiles/
-(tracked): bench line, rocprofv3 --kernel-trace --stats tables, per-kernel PMC medians."""
+(tracked): bench lines, rocprofv3 --kernel-trace --stats tables, per-kernel PMC medians.
+Empty the LOCAL gpurun_out/p before the gpurun call: gpurun merges new files into it and leaves old ones where they are."""
 import csv
 import glob
 import json
@@ -17,7 +18,11 @@ os.makedirs(DST, exist_ok=True)
 for name in ("bench.json", "bench_C2.json", "bench_C3.json", "bench_C4.json", "bench_C5.json", "bench_dist1.json", "bench_share2.json", "upload.json",
              "kernel_durations.json", "small.json", "batch_C3.jsonl", "batch_C4shard.jsonl", "host_overhead.json"):
     if os.path.exists(os.path.join(SRC, name)):
-        shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{tag}_{name}"))
+        if name.startswith("bench"):                 # the JSON line alone (a multi-rank run's stdout also carries gloo's banner)
+            lines = [l for l in open(os.path.join(SRC, name)).read().splitlines() if l.startswith("{")]
+            open(os.path.join(DST, f"{tag}_{name}"), "w").write("\n".join(lines[-1:]) + "\n")
+        else:
+            shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{tag}_{name}"))
 for d in sorted(glob.glob(os.path.join(SRC, "trace_*"))):
     name = os.path.basename(d)[len("trace_"):]
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
