@@ -154,8 +154,9 @@ int cfmm_debug_cholesky(cfmm_ctx *ctx, int n, const double *A, const double *b, 
  * contribution is converted exactly to a 96-bit fixed-point integer and accumulated with integer atomics (associative:
  * any order gives the same bits), all-reduced as integers when pool-sharded, and converted back in a fixed order:
  * psi, the iterates and the evaluation count are then BITWISE identical from run to run and for any number of pool
- * shards / GPUs.  Costs about 2x in the evaluation kernel (three LDS atomics per leg instead of one) plus one small launch
- * per evaluation.  First-order path and cfmm_eval_dual; needs <= ~2600 tokens; fees >= 1e-3.  Also: CFMM_DETERMINISTIC=1. */
+ * shards / GPUs.  Cost, measured (DESIGN.md "Reproducible mode"): the evaluation kernel +20..30 % (three LDS atomics per leg
+ * instead of one: 20.1 against 16.6 us at 1e6 mixed pools), the outer iteration +24..30 % (one small extra launch per
+ * evaluation).  First-order path and cfmm_eval_dual; needs <= ~2600 tokens; fees >= 1e-3.  Also: CFMM_DETERMINISTIC=1. */
 int cfmm_set_deterministic(cfmm_ctx *ctx, int on);
 /* test hook of the reproducible mode: one dual evaluation returning the RAW integer limbs of psi ([3][n], limb-major, value =
  * (limb2 2^64 + limb1 2^32 + limb0) / 2^F, every limb a wrapped signed 64-bit sum) with the fixed-point exponent F derived from

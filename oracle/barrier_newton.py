@@ -65,7 +65,8 @@ def solve(net, c, h=None, ctype=None, nu0=None, tol=1e-7, shrink=0.2, centring=2
     while True:
         for _ in range(centring if not final else 50):
             g, G, e = smooth(s, mu, True)
-            pin = free | (np.isfinite(lob) & (s <= np.where(np.isfinite(lob), lob + 1e-13 * np.maximum(1.0, np.abs(lob)), 0.0)) & (G > 0))
+            lobf = np.where(np.isfinite(lob), lob, 0.0)
+            pin = free | (np.isfinite(lob) & (s <= lobf + 1e-13 * np.maximum(1.0, np.abs(lobf))) & (G > 0))
             G = np.where(pin, 0.0, G)
             H = e["H"] + np.diag(np.maximum(G, 0.0))
             H[pin, :] = 0.0; H[:, pin] = 0.0; H[pin, pin] = 1.0
@@ -111,6 +112,7 @@ def solve(net, c, h=None, ctype=None, nu0=None, tol=1e-7, shrink=0.2, centring=2
             if steps >= max_steps:
                 final = True
         if not final:
+            dual = g2                                   # (the smoothed dual value at the current centre: within mu nbar of the exact one)
             if mu * nbar <= 0.25 * tol * max(1.0, abs(dual)):
                 final = True
             else:

@@ -5,10 +5,10 @@ independent NumPy second-order solver of oracle/barrier_newton.py, certificates 
 No SciPy primal reaches this size and the C oracle's first-order iteration is 0.4% from the optimum after 2000 evaluations,
 so this is the only CPU solve the HIP library's config-5 optimum can be compared with (tests/test_gpu_newton.py).
 
-    python oracle/make_c5_fixture.py            # ~20-30 minutes on 8 cores (53 smoothed evaluations of 1.1e6 pool directions)
+    python oracle/make_c5_fixture.py            # ~30 minutes on 8 cores (~65 smoothed evaluations of 1.1e6 pool directions)
 
 The instance is rebuilt from seeds by the test (cfmm.synthetic.config("C5"), basket seed 1): the fixture holds only the
-solver's results and a digest of its prices.
+solver's results and its final prices (at which the test also compares the exact dual evaluations).
 """
 import json
 import os
@@ -51,7 +51,7 @@ def main():
                pools=int(sum(len(net[k]["Ra"]) for k in ("cp2", "w2", "curve2", "pow2", "sum2") if k in net)), tokens=n, target=t,
                dual_value=r["dual_value"], primal_value=r["primal_value"], gap=r["gap"], infeas=r["infeas"], steps=r["steps"],
                smoothed_evaluations=r["evals"], barrier_mu=r["mu"], seconds=round(time.time() - t0, 1),
-               nu_head=[float(x) for x in r["nu"][:8]], log_nu_sum=float(np.log(r["nu"]).sum()))
+               nu=[float(x) for x in r["nu"]])
     path = os.path.join(ROOT, "tests", "golden", "c5_liquidation.json" if scale == 1.0 else "c5_liquidation_scale%g.json" % scale)
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
