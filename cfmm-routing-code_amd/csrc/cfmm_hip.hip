@@ -1302,7 +1302,9 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         // changes below fp64 resolution and the feasibility of psi_mu stops improving).
         double sub = mu * (double)nbar;
         dual = lin + e.trade + sub;
-        if (steps == 0 || sub <= 10.0 * o.tol_gap * std::max(1.0, std::fabs(dual))) {
+        // (the exact evaluation is also skipped while psi_mu is still far from feasible: no certificate can hold at this point,
+        //  and the bound serves the barrier schedule just as well -- three evaluations of ~0.14 ms less per config-5 solve)
+        if (steps == 0 || (sub <= 10.0 * o.tol_gap * std::max(1.0, std::fabs(dual)) && infeas <= 10.0 * o.tol_infeas)) {
             if (steps > 0 && (rc = exact(nu))) return rc;
             dual = lin + arb_x;
             sub = std::max(arb_x - e.trade, 0.0);

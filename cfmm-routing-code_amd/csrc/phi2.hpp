@@ -182,6 +182,7 @@ __device__ __forceinline__ bool generic_dir(double Rin, double Rout, double g, d
         const Fwd f = Phi2<KIND>::fwd(D, Rin, Rout, g, r, C);
         const double A = no * f.L1 - ni, A1 = fmin(no * f.L2, -1e-300);
         if (A > 0.0) lo = D; else hi = D;
+        if (fabs(A) <= 1e-15 * ni) break;              // (the price condition met to rounding: pool_math.hpp, curve_dir)
         double Dn = D - A / A1;
         if (!(Dn > lo && Dn < hi)) Dn = hi < 1e308 ? 0.5 * (lo + hi) : 2.0 * D;
         const bool done = fabs(Dn - D) <= 2e-15 * fmax(Dn, D);

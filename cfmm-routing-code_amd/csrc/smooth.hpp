@@ -86,7 +86,15 @@ __device__ __forceinline__ Branch smooth_branch(double Rin, double Rout, double 
     for (int it = 0; it < 120; ++it) {
         const Fwd f = fwd2<KIND>(D, Rin, Rout, g, r, C);
         const double A = no * f.L1 - ni, A1 = fmin(no * f.L2, -1e-300);
-        const double F = fma(mu, rcp_nr(D), A);
+        const double bD = mu * rcp_nr(D), F = bD + A;
+        // (the stationarity condition met to rounding: below ~4 ulp of its largest term the sign of F is noise -- a lane on the
+        //  flat part of a stableswap curve would otherwise jitter until its bracket has been closed step by step)
+        if (fabs(F) <= 1e-15 * fmax(ni, bD)) {
+#ifdef CFMM_SMOOTH_HIST
+            atomicAdd(&g_smooth_hist[it < 127 ? it : 127], 1ULL);
+#endif
+            break;
+        }
         if (F > 0.0) { lo = D; Flo = F; } else { hi = D; Fhi = F; }
         double Dn = barrier_root(A1, A - A1 * D, mu);
         if (warm && (Dn > 8.0 * D || 8.0 * Dn < D)) {          // regime switch since the last evaluation: start over
