@@ -1103,9 +1103,8 @@ int smooth_buffers(cfmm_ctx *ctx, bool hess)
         rc = dev_upload<double>(ctx, &ctx->sm_vec, nullptr, 2 * (size_t)n + 4, nullptr); if (rc) return rc;
         rc = dev_upload<int>(ctx, &ctx->sm_mask, nullptr, n + 4, nullptr); if (rc) return rc;
         rc = dev_upload<double>(ctx, &ctx->sm_slo, nullptr, n + 4, nullptr); if (rc) return rc;
-        const size_t lds = (size_t)(2 * n + 32) * sizeof(double);
-        if ((rc = set_lds_attr(ctx, smooth_kernel<false>, lds))) return rc;
-        if ((rc = set_lds_attr(ctx, smooth_kernel<true>, lds))) return rc;
+        if ((rc = set_lds_attr(ctx, smooth_kernel<false>, smooth_lds_bytes(n, false)))) return rc;
+        if ((rc = set_lds_attr(ctx, smooth_kernel<true>, smooth_lds_bytes(n, true)))) return rc;
     }
     for (int k : {CFMM_POOL_CP2, CFMM_POOL_W2, CFMM_POOL_CURVE2, CFMM_POOL_POW2}) {           // warm starts: sized by the bucket as it is NOW (pools may be re-uploaded)
         const long long m = ctx->pools->b2[k].m;
@@ -1144,7 +1143,7 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm, bool with_slo)
     static const int grid_mult = getenv("CFMM_SMOOTH_GRID_MULT") ? std::max(1, atoi(getenv("CFMM_SMOOTH_GRID_MULT"))) : 1;     // tuning knob
     if (grid > (long long)grid_mult * ctx->cus) grid = (long long)grid_mult * ctx->cus;
     if (grid < 1) grid = 1;
-    const size_t lds = (size_t)(2 * n + 32) * sizeof(double);
+    const size_t lds = smooth_lds_bytes(n, hess);
     if (tiles > 0) {
         if (hess) hipLaunchKernelGGL(smooth_kernel<true>, dim3((unsigned)grid), dim3(SMOOTH_THREADS), lds, ctx->stream, a);
         else hipLaunchKernelGGL(smooth_kernel<false>, dim3((unsigned)grid), dim3(SMOOTH_THREADS), lds, ctx->stream, a);

@@ -200,9 +200,35 @@ __device__ __forceinline__ void apply_slo(Branch &br, double u, double v, double
     br.L = fma(br.L1, dD, br.L);
 }
 
+// The Hessian terms of a workgroup, collected in LDS before they go to the n x n array in HBM.  Three global fp64 atomics per
+// pool were two thirds of smooth_kernel<true> (104 of 138 us at config 5): 1.65 M atomics on 1000 diagonal addresses and --
+// stableswap pools concentrate on few pairs: 5e5 pools on 1500 of them -- ~330 per off-diagonal address.  Now the diagonal
+// is an LDS tile like psi (n atomics per workgroup at the flush), and the off-diagonal entries go through a small
+// open-addressed table in LDS keyed by the entry's index (two probes, claim by compare-and-swap; a miss on both falls
+// through to the global atomic): with the workgroup walking a CONTIGUOUS range of every bucket and the pools ordered by
+// token blocks (reorder.hpp) its few thousand pools touch one or two hundred pairs.
+struct HessCache {
+    static constexpr int SLOTS = 2048;           // 8 KB of keys + 16 KB of values
+    double *diag;                                // [n]
+    double *val;                                 // [SLOTS]
+    int *key;                                    // [SLOTS], -1 = free
+    __device__ __forceinline__ void add(int k, double v, double *H) const
+    {
+        unsigned h = ((unsigned)k * 2654435761u) >> 21;
+#pragma unroll
+        for (int probe = 0; probe < 2; ++probe) {
+            int t = key[h];
+            if (t == -1) t = atomicCAS(&key[h], -1, k), t = (t == -1) ? k : t;
+            if (t == k) { unsafeAtomicAdd(&val[h], v); return; }
+            h = (h + 1) & (SLOTS - 1);
+        }
+        unsafeAtomicAdd(&H[k], v);
+    }
+};
+
 template <int KIND, bool HESS>
 __device__ __forceinline__ void smooth_tile(const Bucket2 &b, long long i0, int lane, const double *nu_s, double *psi_s,
-                                            const SmoothArgs &a, double &vsum, double &tsum)
+                                            const SmoothArgs &a, const HessCache &hc, double &vsum, double &tsum)
 {
     long long i = i0 + lane;
     const bool live = i < b.m && !(KIND == 2 && b.flags && b.flags[i]);
@@ -229,15 +255,21 @@ __device__ __forceinline__ void smooth_tile(const Bucket2 &b, long long i0, int 
         const double hbb = ab.kappa * v1 * v1 + ba.kappa * v2 * v2;
         const double hab = ab.kappa * u1 * v1 + ba.kappa * u2 * v2;
         const int row = ia > ib ? ia : ib, col = ia > ib ? ib : ia;
-        unsafeAtomicAdd(&a.H[(size_t)ia * a.ldh + ia], haa);
-        unsafeAtomicAdd(&a.H[(size_t)ib * a.ldh + ib], hbb);
-        unsafeAtomicAdd(&a.H[(size_t)col * a.ldh + row], hab);
+        // the diagonal through an LDS tile like psi; the off-diagonal entry through the workgroup's pair cache (HessCache)
+        unsafeAtomicAdd(&hc.diag[ia], haa);
+        unsafeAtomicAdd(&hc.diag[ib], hbb);
+        hc.add(col * a.ldh + row, hab, a.H);
     }
 }
 
 constexpr int SMOOTH_THREADS = 512;
 
-// LDS: psi_s[n] | nu_s[n] | red[2 * 8] | ticket
+// LDS: psi_s[n] | nu_s[n] | red[2 * 8] | ticket, tile-range table | HESS: diag[n] | pair-cache values | pair-cache keys
+__host__ __device__ inline size_t smooth_lds_bytes(int n, bool hess)
+{
+    return (size_t)(2 * n + 32 + (hess ? n + (n & 1) + HessCache::SLOTS : 0)) * sizeof(double) + (hess ? HessCache::SLOTS * sizeof(int) : 0);
+}
+
 template <bool HESS>
 __global__ void __launch_bounds__(SMOOTH_THREADS)
 smooth_kernel(SmoothArgs a)
@@ -245,28 +277,48 @@ smooth_kernel(SmoothArgs a)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = a.n;
     double *psi_s = lds, *nu_s = lds + n, *red = lds + 2 * n;
-    int *next_tile = reinterpret_cast<int *>(red + 16);
-    if (threadIdx.x == 0) *next_tile = 0;
+    int *next_tile = reinterpret_cast<int *>(red + 16);          // [0] ticket, [2 + q] tiles of buckets <= q in this workgroup, [2 + N_KINDS2 + q] its first tile in bucket q
+    HessCache hc = {};
+    if (HESS) {
+        hc.diag = lds + 2 * n + 32;
+        hc.val = hc.diag + n + (n & 1);
+        hc.key = reinterpret_cast<int *>(hc.val + HessCache::SLOTS);
+        for (int j = threadIdx.x; j < n; j += blockDim.x) hc.diag[j] = 0.0;
+        for (int j = threadIdx.x; j < HessCache::SLOTS; j += blockDim.x) { hc.val[j] = 0.0; hc.key[j] = -1; }
+    }
+    // workgroup b walks a contiguous share of every bucket, [b n_q / G, (b + 1) n_q / G) of its n_q tiles (as the exact
+    // evaluation does): with the pools ordered by token blocks its pairs are few -- what the pair cache lives on
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int q = 0; q < N_KINDS2; ++q) {
+            const int nq = a.tile_end[q] - (q ? a.tile_end[q - 1] : 0);
+            const int s0 = (int)(((double)blockIdx.x * nq) / (double)gridDim.x), s1 = (int)(((double)(blockIdx.x + 1) * nq) / (double)gridDim.x);
+            c += s1 - s0;
+            next_tile[2 + q] = c; next_tile[2 + N_KINDS2 + q] = s0;
+        }
+        *next_tile = 0;
+    }
     for (int j = threadIdx.x; j < n; j += blockDim.x) { nu_s[j] = a.nu[j]; psi_s[j] = 0.0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int nlocal = next_tile[2 + N_KINDS2 - 1];
     double vsum = 0.0, tsum = 0.0;
     int ticket = 0;
     if (lane == 0) ticket = atomicAdd(next_tile, 1);
     for (;;) {
-        const int t = blockIdx.x + gridDim.x * __builtin_amdgcn_readfirstlane(ticket);
-        if (t >= a.ntiles) break;
+        const int t = __builtin_amdgcn_readfirstlane(ticket);
+        if (t >= nlocal) break;
         if (lane == 0) ticket = atomicAdd(next_tile, 1);
         int bk = 0;
 #pragma unroll
-        for (int q = 0; q < N_KINDS2 - 1; ++q) bk += (t >= a.tile_end[q]) ? 1 : 0;
-        const long long i0 = (long long)(t - (bk ? a.tile_end[bk - 1] : 0)) * 64;
+        for (int q = 0; q < N_KINDS2 - 1; ++q) bk += (t >= next_tile[2 + q]) ? 1 : 0;
+        const long long i0 = (long long)(next_tile[2 + N_KINDS2 + bk] + t - (bk ? next_tile[2 + bk - 1] : 0)) * 64;
         switch (bk) {
-        case 0: smooth_tile<3, HESS>(a.b2[3], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
-        case 1: smooth_tile<4, HESS>(a.b2[4], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
-        case 2: smooth_tile<1, HESS>(a.b2[1], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
-        case 3: smooth_tile<0, HESS>(a.b2[0], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
-        default: smooth_tile<2, HESS>(a.b2[2], i0, lane, nu_s, psi_s, a, vsum, tsum); break;
+        case 0: smooth_tile<3, HESS>(a.b2[3], i0, lane, nu_s, psi_s, a, hc, vsum, tsum); break;
+        case 1: smooth_tile<4, HESS>(a.b2[4], i0, lane, nu_s, psi_s, a, hc, vsum, tsum); break;
+        case 2: smooth_tile<1, HESS>(a.b2[1], i0, lane, nu_s, psi_s, a, hc, vsum, tsum); break;
+        case 3: smooth_tile<0, HESS>(a.b2[0], i0, lane, nu_s, psi_s, a, hc, vsum, tsum); break;
+        default: smooth_tile<2, HESS>(a.b2[2], i0, lane, nu_s, psi_s, a, hc, vsum, tsum); break;
         }
     }
     vsum = wave_allsum(vsum); tsum = wave_allsum(tsum);
@@ -281,6 +333,13 @@ smooth_kernel(SmoothArgs a)
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const double v = psi_s[j];
         if (v != 0.0) unsafeAtomicAdd(&a.out[j], v);
+        if (HESS) { const double d = hc.diag[j]; if (d != 0.0) unsafeAtomicAdd(&a.H[(size_t)j * a.ldh + j], d); }
+    }
+    if (HESS) {
+        for (int j = threadIdx.x; j < HessCache::SLOTS; j += blockDim.x) {
+            const int k = hc.key[j];
+            if (k >= 0) unsafeAtomicAdd(&a.H[k], hc.val[j]);
+        }
     }
 }
 
