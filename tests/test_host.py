@@ -124,7 +124,7 @@ def test_committed_bench_lines_keep_the_contract(cfg):
     if cfg == "C5":                                   # second-order path: the dense factorisation against the fp64 vector peak
         assert rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6 and rf["bound"] == "valu" and d["newton_steps_per_solve"] >= 3
         assert set(rf["newton_step_us"]) == {"smoothed_evaluation_with_hessian", "smoothed_evaluation", "factorisation", "back_substitution"}
-        assert d["ms_per_step"] <= 10.0               # (round 2: 13.6)
+        assert d["ms_per_step"] <= 8.0                # (round 2: 13.6; the round-2 verdict asked for 8)
     else:
         assert rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["hbm_frac"] == rf["frac"]
         assert rf["bound"] == ("valu" if (rf["valu_frac"] or 0.0) > rf["hbm_frac"] else "hbm")
