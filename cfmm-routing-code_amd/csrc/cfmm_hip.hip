@@ -124,6 +124,7 @@ struct cfmm_ctx {
     DevState *st = nullptr;
     long long *ts = nullptr;           // phase timers (tuning builds)
     char *dev_arena = nullptr, *host_arena = nullptr;   // every per-context device / pinned host buffer below is a piece of these
+    double *pin = nullptr; size_t pin_cap = 0;          // pinned staging for the small per-call vectors of cfmm_eval_dual and the second-order loop (pin_scratch)
     char *util_h = nullptr;            // pinned mirror of the device span c | h | glo | ghi | ctype
     size_t util_span = 0;
     DevState *hst = nullptr;          // pinned, 2 slots
@@ -1095,6 +1096,19 @@ int refresh_global_counts(cfmm_ctx *ctx)
     return CFMM_OK;
 }
 
+// Pinned staging for the few-KB vectors that cross the bus inside a call (prices in, psi / a Newton direction out): a
+// hipMemcpyAsync on PAGEABLE memory is staged and effectively synchronous, ~10-20 us apiece -- with nine of them per Newton
+// step the device idled ~130 us per step of config 5.  Grown on demand, reused by every call (each call ends synchronised).
+double *pin_scratch(cfmm_ctx *ctx, size_t doubles)
+{
+    if (doubles > ctx->pin_cap) {
+        if (ctx->pin) { (void)hipHostFree(ctx->pin); ctx->pin = nullptr; ctx->pin_cap = 0; }
+        if (hipHostMalloc((void **)&ctx->pin, doubles * sizeof(double), hipHostMallocDefault) != hipSuccess) { ctx->pin = nullptr; return nullptr; }
+        ctx->pin_cap = doubles;
+    }
+    return ctx->pin;
+}
+
 int smooth_buffers(cfmm_ctx *ctx, bool hess)
 {
     const int n = ctx->n;
@@ -1178,14 +1192,20 @@ int smooth_eval_host(cfmm_ctx *ctx, const std::vector<double> &nu, double mu, bo
 {
     const int n = ctx->n;
     int rc = smooth_buffers(ctx, hess); if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, nu.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if (slo) HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_slo, slo->data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    double *pin = pin_scratch(ctx, 8 * (size_t)n + 64);
+    if (!pin) return fail(ctx, CFMM_E_HIP, "pinned staging (%d tokens)", n);
+    double *pin_nu = pin, *pin_slo = pin + n, *pin_out = pin + 2 * n;             // [n] | [n] | [n + 2]
+    std::memcpy(pin_nu, nu.data(), n * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, pin_nu, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (slo) {
+        std::memcpy(pin_slo, slo->data(), n * sizeof(double));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_slo, pin_slo, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
     if ((rc = launch_smooth(ctx, mu, hess, warm, slo != nullptr))) return rc;
-    e.psi.resize(n + 2);
-    HIP_TRY(ctx, hipMemcpyAsync(e.psi.data(), ctx->sm_out, (size_t)(n + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(pin_out, ctx->sm_out, (size_t)(n + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    e.value = e.psi[n]; e.trade = e.psi[n + 1];
-    e.psi.resize(n);
+    e.psi.assign(pin_out, pin_out + n);
+    e.value = pin_out[n]; e.trade = pin_out[n + 1];
     return CFMM_OK;
 }
 
@@ -1322,17 +1342,22 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             if (pin[j]) G[j] = 0.0;
             rhs[j] = -G[j]; Hd[j] += reg;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, pin.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, Hd.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec + n, rhs.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        // (through the pinned staging, behind smooth_eval_host's three vectors: [Hd | rhs] in one copy, the pin mask, the direction back)
+        double *pin_vec = ctx->pin + 4 * (size_t)n, *pin_d = ctx->pin + 6 * (size_t)n;
+        int *pin_mask = reinterpret_cast<int *>(ctx->pin + 7 * (size_t)n), *pin_info = pin_mask + n + (n & 1);
+        std::memcpy(pin_mask, pin.data(), n * sizeof(int));
+        std::memcpy(pin_vec, Hd.data(), n * sizeof(double)); std::memcpy(pin_vec + n, rhs.data(), n * sizeof(double));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, pin_mask, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, pin_vec, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, hess_nr(n), hess_ld(n), (const double *)ctx->sm_vec,
                            (const int *)ctx->sm_mask, (const double *)(ctx->sm_vec + n));
         HIP_TRY(ctx, hipGetLastError());
         if ((rc = launch_cholesky(ctx, n, ctx->sm_vec + n))) return rc;
-        int info = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&info, ctx->sm_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d.data(), ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(pin_info, ctx->sm_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(pin_d, ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const int info = *pin_info;
+        d.assign(pin_d, pin_d + n);
         if (info != 0) {                       // not positive definite: shift the diagonal and assemble again
             double md = 0.0;
             for (int j = 0; j < n; ++j) md = std::max(md, std::max(Hd[j], std::fabs(G[j])));
@@ -1603,6 +1628,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_ws[4], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
     if (ctx->dev_arena) (void)hipFree(ctx->dev_arena);
     if (ctx->host_arena) (void)hipHostFree(ctx->host_arena);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->hstat_h) (void)hipHostFree((void *)ctx->hstat_h);
     if (ctx->upd_batch_d) (void)hipFree(ctx->upd_batch_d);
     if (ctx->upd_batch_h) (void)hipHostFree(ctx->upd_batch_h);
@@ -1997,27 +2023,31 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
     pools_ready(ctx);
     const int n = ctx->n;
     for (int j = 0; j < n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "eval_dual: nu[%d] = %g is not a positive finite price", j, nu[j]);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, nu, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const int len = acc_stride(n);
+    // (through pinned staging: pin_scratch.  The second-order loop keeps its own vectors in the first 8 n + 64 doubles.)
+    double *pinb = pin_scratch(ctx, 8 * (size_t)n + 64 + n + (size_t)len);
+    if (!pinb) return fail(ctx, CFMM_E_HIP, "pinned staging (%d tokens)", n);
+    double *pin_nu = pinb + 8 * (size_t)n + 64, *pin_acc = pin_nu + n;
+    std::memcpy(pin_nu, nu, n * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, pin_nu, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->nu + n, 0, sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
     { double mx = 0.0; for (int j = 0; j < n; ++j) mx = std::max(mx, nu[j]); ctx->nu_max = mx; }
     if (ctx->det && sharded(ctx)) { int rc = refresh_global_counts(ctx); if (rc) return rc; }      // (the fixed-point exponent is a global quantity)
     if (ctx->det) HIP_TRY(ctx, hipMemsetAsync(ctx->acc_l, 0, 6 * (size_t)n * sizeof(unsigned long long), ctx->stream));
     if (diag) launch_all_evals<true>(ctx); else launch_all_evals<false>(ctx);
-    const int len = acc_stride(n);
     if (ctx->det) { int rc = det_finish(ctx, ctx->acc, ctx->nu, diag != nullptr); if (rc) return rc; }
     else hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, n, ctx->nslices, 1, (const DevState *)nullptr);
     HIP_TRY(ctx, hipGetLastError());
     if (sharded(ctx) && !ctx->det) {            // pool-sharded (a communicator of one rank runs the same path)
         int rc = all_reduce(ctx, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc;
     }
-    std::vector<double> host(len);
-    HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->acc, len * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(pin_acc, ctx->acc, len * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)len * sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (psi) std::memcpy(psi, host.data(), n * sizeof(double));
-    if (arb_sum) *arb_sum = host[acc_arb(n)];
-    if (diag) std::memcpy(diag, host.data() + acc_diag(n), n * sizeof(double));
+    if (psi) std::memcpy(psi, pin_acc, n * sizeof(double));
+    if (arb_sum) *arb_sum = pin_acc[acc_arb(n)];
+    if (diag) std::memcpy(diag, pin_acc + acc_diag(n), n * sizeof(double));
     release_landed(ctx);
     return CFMM_OK;
 }
