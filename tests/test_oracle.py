@@ -1,5 +1,7 @@
 """CPU suite, part 1: the oracle is pinned -- against the survey-derived known answers (golden
 fixture), against the independent SciPy primal model, and C against NumPy pool by pool."""
+import os
+
 import numpy as np
 import pytest
 
@@ -369,3 +371,18 @@ def test_independent_second_order_solver_against_the_scipy_primal(oracle_lib, se
     ref = solve_primal(normalise_with_params(inst))
     assert r["gap"] <= 1e-7 and r["infeas"] <= 1e-7
     assert abs(r["dual_value"] - ref["value"]) <= 2e-6 * max(1.0, abs(ref["value"])), (r["dual_value"], ref["value"])
+
+
+def test_c_oracle_is_clean_under_asan_and_ubsan():
+    """SURVEY section 5 ("ASAN on the CPU twin"): oracle/cfmm_oracle.c compiled with -fsanitize=address,undefined and driven
+    over a random network with every pool kind, the three utilities, tenders and whole solves, 1 and 4 threads
+    (oracle/asan_driver.c): no report, and the networks of smooth pools reach their certificates"""
+    import shutil, subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    od = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    b = subprocess.run(["make", "-C", od, "asan"], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stdout + b.stderr
+    r = subprocess.run([os.path.join(od, "_build", "asan_driver")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and "asan driver ok" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, (r.stdout + r.stderr)[-3000:]
