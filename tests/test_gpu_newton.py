@@ -126,12 +126,14 @@ def test_second_order_small_instances_vs_primal(seed):
     v = p.solve(tol=1e-8, method="newton")
     r = solve_primal(normalise_with_params(inst))
     if p.status != "optimal":                 # a token to sell that no pool lists: SLSQP fails on it too
-        assert not r["success"], (p.status, p.gap, p.infeas)
+        assert not r["success"], (seed, p.status, p.gap, p.infeas, v, r["value"], p.stats)
         return
-    assert p.gap <= 1e-7 and p.infeas <= 1e-7
-    assert r["value"] <= p.dual_value + 2e-6 * max(1, abs(v))                 # weak duality vs SLSQP's point
+    info = dict(seed=seed, status=p.status, value=v, dual=p.dual_value, gap=p.gap, infeas=p.infeas, slsqp=r["value"], slsqp_ok=r["success"],
+                steps=p.stats.get("newton_steps"), evals=p.stats.get("evals"))
+    assert p.gap <= 1e-7 and p.infeas <= 1e-7, info
+    assert r["value"] <= p.dual_value + 2e-6 * max(1, abs(v)), info           # weak duality vs SLSQP's point
     if r["success"]:
-        assert abs(v - r["value"]) <= 2e-6 * max(1, abs(v)), (v, r["value"])
+        assert abs(v - r["value"]) <= 2e-6 * max(1, abs(v)), info
     p.close()
 
 
