@@ -982,6 +982,10 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tmp_path):
     assert d["per_iteration_us"]["allreduce"] > 0.0 and d["gap"] <= 1e-6 and d["infeas"] <= 1e-6
     ds = _bench_line(tmp_path, "--gpus", "2", "--share-gpu", "--config", "C4", "--scale", "0.05", "--steps", "2", "--warmup", "1", "--no-cpu")
     assert ds["n_gpus"] == 2 and ds["scaling"] == "strong" and ds["config"]["pools_total"] == 500000 and ds["config"]["pools_per_gpu"] == 250000
+    # four ranks (the one-shot exchange with four mailboxes per rank, rank-ordered sums): what the driver's --gpus 4 runs per rank
+    d4 = _bench_line(tmp_path, "--gpus", "4", "--share-gpu", "--steps", "2", "--warmup", "1", "--no-cpu", "--scale", "0.1")
+    assert d4["n_gpus"] == 4 and d4["config"]["rccl_ranks"] == 4 and d4["config"]["allreduce"] == "oneshot"
+    assert d4["config"]["pools_total"] == 4 * d4["config"]["pools_per_gpu"] and d4["gap"] <= 1e-6 and d4["infeas"] <= 1e-6
 
 
 def json_load_baseline():
