@@ -154,6 +154,7 @@ struct cfmm_ctx {
 
     // fused iteration (iterate.hpp): three rotating sets of accumulators / solver state, a history ring of M + 1 slots
     bool fused = true;                 // CFMM_FUSED=0: the two-launch iteration of round 1 (A/B)
+    bool tile_dma = true;              // CFMM_TILE_DMA=0: tiles loaded at their own start instead of staged one tile ahead by LDS-DMA (A/B)
     bool tiny_path = true;             // CFMM_TINY=0: tiny networks through the grid-wide path too (A/B)
     bool plain = false;                // utility has h == 0 and only CFMM_GE tokens (IterArgs::plain)
     // reproducible mode (kernels.hpp: Scatter<true>): psi accumulated as exact fixed-point integers
@@ -621,8 +622,13 @@ void pools_changed(cfmm_ctx *ctx)
     ctx->hsol_valid = false; ctx->mu_last = 0.0; ctx->warm_mu = 0.0; ctx->slo_active = false;
 }
 
-size_t eval_lds_bytes(int n, bool with_d, bool det = false) { return (size_t)eval_lds_doubles(n, with_d, det) * sizeof(double) + (size_t)(EVAL_THREADS / 64) * 64 * 16; }
-size_t iter_lds_bytes(int n, bool det = false) { return eval_lds_bytes(n, false, det) + (size_t)iter_extra_lds_doubles(n) * sizeof(double); }
+// dma: the staged tile walk (kernels.hpp) -- one 4 KB slot per wave on top
+size_t eval_lds_bytes(int n, bool with_d, bool det = false, bool dma = false)
+{
+    return (size_t)eval_lds_doubles(n, with_d, det) * sizeof(double) + (size_t)(EVAL_THREADS / 64) * 64 * 16 + (dma ? (size_t)(EVAL_THREADS / 64) * STAGE_BYTES : 0);
+}
+size_t iter_lds_bytes(int n, bool det = false, bool dma = false) { return eval_lds_bytes(n, false, det) + (size_t)iter_extra_lds_doubles(n, dma) * sizeof(double); }
+constexpr size_t LDS_MAX = 160 * 1024;
 size_t upd_lds_bytes(int ng) { return (size_t)(2 * ng + 16 * 64 + 64 + 32 + 2 * 12 * 16 + 8) * sizeof(double); }
 
 // processing order of the fused evaluation kernel (heaviest first): bucket code = -k for the
@@ -697,6 +703,10 @@ static bool pingpong_on(const cfmm_ctx *ctx)
     return bn <= 0.1 * (b2 + bn);
 }
 
+// the staged tile walk: wherever its slots fit beside the tiles (<= ~3400 tokens with the metric, ~4900 without)
+static bool eval_dma(const cfmm_ctx *ctx, bool with_d) { return CFMM_STAGED_WALK && ctx->tile_dma && !ctx->det && eval_lds_bytes(ctx->n, with_d, false, true) <= LDS_MAX; }
+static bool iter_dma(const cfmm_ctx *ctx) { return CFMM_STAGED_WALK && ctx->tile_dma && !ctx->det && iter_lds_bytes(ctx->n, false, true) <= LDS_MAX; }
+
 template <bool WITH_D, bool STABLE>
 void launch_eval(cfmm_ctx *ctx, const EvalArgs &a_in, hipStream_t stream = nullptr)
 {
@@ -707,6 +717,9 @@ void launch_eval(cfmm_ctx *ctx, const EvalArgs &a_in, hipStream_t stream = nullp
     int grid, threads;
     eval_geometry(ctx, a.ntiles, grid, threads);
     if (ctx->det) hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE, true>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D, true), stream, a);
+#if CFMM_STAGED_WALK
+    else if (!STABLE && eval_dma(ctx, WITH_D)) hipLaunchKernelGGL((eval_kernel<WITH_D, false, false, true>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D, false, true), stream, a);
+#endif
     else hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), stream, a);
 }
 
@@ -767,6 +780,10 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, eval_kernel<true, false>, e1))) return rc;
     if ((rc = set_lds_attr(ctx, eval_kernel<false, true>, e0))) return rc;
     if ((rc = set_lds_attr(ctx, eval_kernel<true, true>, e1))) return rc;
+#if CFMM_STAGED_WALK
+    if (eval_lds_bytes(ctx->n, false, false, true) <= LDS_MAX && (rc = set_lds_attr(ctx, eval_kernel<false, false, false, true>, eval_lds_bytes(ctx->n, false, false, true)))) return rc;
+    if (eval_lds_bytes(ctx->n, true, false, true) <= LDS_MAX && (rc = set_lds_attr(ctx, eval_kernel<true, false, false, true>, eval_lds_bytes(ctx->n, true, false, true)))) return rc;
+#endif
     if ((rc = set_lds_attr(ctx, update_kernel<false>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 8, 2>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 4, 4>, upd_lds_bytes(ctx->n)))) return rc;
@@ -785,6 +802,13 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, true>, il))) return rc;
     if ((rc = set_lds_attr(ctx, iter_kernel<2, false, false>, il))) return rc;
     if ((rc = set_lds_attr(ctx, iter_kernel<2, false, true>, il))) return rc;
+#if CFMM_STAGED_WALK
+    if (ctx->n <= 2 * EVAL_THREADS && iter_lds_bytes(ctx->n, false, true) <= LDS_MAX) {
+        const size_t ilm = iter_lds_bytes(ctx->n, false, true);
+        if ((rc = set_lds_attr(ctx, iter_kernel<2, false, false, true>, ilm))) return rc;
+        if ((rc = set_lds_attr(ctx, iter_kernel<2, false, true, true>, ilm))) return rc;
+    }
+#endif
     if (eval_lds_bytes(ctx->n, true, true) <= 160 * 1024) {        // reproducible mode: tiles of 3 n integer limbs
         if ((rc = set_lds_attr(ctx, eval_kernel<false, false, true>, eval_lds_bytes(ctx->n, false, true)))) return rc;
         if ((rc = set_lds_attr(ctx, eval_kernel<true, false, true>, eval_lds_bytes(ctx->n, true, true)))) return rc;
@@ -878,10 +902,16 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
         if (grid > slots) grid = slots;
         if (grid < 1) grid = 1;                                 // (a shard without pools still takes the step)
     }
-    const size_t lds = iter_lds_bytes(n, ctx->det);
+    const bool dma = iter_dma(ctx);
+    const size_t lds = iter_lds_bytes(n, ctx->det, dma);
     const dim3 g(grid), b(threads);
+#if CFMM_STAGED_WALK
+#define ITER_LAUNCH_DMA if (dma) { if (a.plain) hipLaunchKernelGGL((iter_kernel<2, false, true, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<2, false, false, true>), g, b, lds, ctx->stream, a); }
+#else
+#define ITER_LAUNCH_DMA if (false) { }
+#endif
 #define ITER_LAUNCH(EE) do { \
-        if (ctx->det) { if (a.plain) hipLaunchKernelGGL((iter_kernel<EE, true, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<EE, true, false>), g, b, lds, ctx->stream, a); } \
+        ITER_LAUNCH_DMA else if (ctx->det) { if (a.plain) hipLaunchKernelGGL((iter_kernel<EE, true, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<EE, true, false>), g, b, lds, ctx->stream, a); } \
         else { if (a.plain) hipLaunchKernelGGL((iter_kernel<EE, false, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<EE, false, false>), g, b, lds, ctx->stream, a); } } while (0)
     if (E == 1) ITER_LAUNCH(ITER_E_SMALL); else ITER_LAUNCH(2);
 #undef ITER_LAUNCH
@@ -1511,6 +1541,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if (const char *s = getenv("CFMM_MULTI_GRAPH")) ctx->multi_graph = atoi(s) != 0;
     if (const char *s = getenv("CFMM_NO_GRAPH")) ctx->no_graph = atoi(s) != 0;
     if (const char *s = getenv("CFMM_FUSED")) ctx->fused = atoi(s) != 0;
+    if (const char *s = getenv("CFMM_TILE_DMA")) ctx->tile_dma = atoi(s) != 0;
     if (const char *s = getenv("CFMM_TINY")) ctx->tiny_path = atoi(s) != 0;
     if (const char *s = getenv("CFMM_RUN_AHEAD")) ctx->run_ahead = std::max(1, atoi(s));
     if (const char *s = getenv("CFMM_DETERMINISTIC")) ctx->det = atoi(s) != 0;

@@ -227,7 +227,12 @@ __device__ __forceinline__ double uni(double v)
 
 // extra LDS of iter_kernel behind eval_kernel's carve: the bounds (every workgroup) and the trial point's prices and net
 // trade (workgroup 0, which stores them when the point is accepted), stashed between the two halves of the update
-__host__ __device__ inline int iter_extra_lds_doubles(int n) { return 4 * iter_xvs(n); }
+//   staged tile walk (DMA, kernels.hpp): the bounds, and (in front of everything) one 4 KB slot per wave; the accepted-point
+//   stash of the two workgroups that store it borrows the LAST slots (their waves issue their first DMA behind the update)
+__host__ __device__ inline int iter_extra_lds_doubles(int n, bool dma = false)
+{
+    return dma ? 2 * iter_xvs(n) + (STAGE_BYTES / 8) * (EVAL_THREADS / 64) : 4 * iter_xvs(n);
+}
 
 // PLAIN: the utility has h == 0, every token CFMM_GE and no upper bounds (linear-utility arbitrage, arbitrage.py:57,77):
 // three of the update's vectors are never read and their registers do not exist (the other instantiation spills a few)
@@ -242,11 +247,19 @@ __host__ __device__ inline int iter_extra_lds_doubles(int n) { return 4 * iter_x
 // them lays out the tile-range table meanwhile); the next trial point is computed speculatively at step 1 under the
 // direction's reduction; every thread recycles its OWN stash entries (trial point -> price, trial gradient -> zeroed psi
 // entry), which merges the last two barriers into one.
-template <int E, bool DET = false, bool PLAIN = false>
+// DMA: the evaluation's tiles come through the staged walk (kernels.hpp), and every wave's FIRST tile is requested as soon
+// as the scalar section has decided that this launch evaluates at all -- its columns arrive while the direction and the
+// trial point are still being formed
+template <int E, bool DET = false, bool PLAIN = false, bool DMA = false>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 iter_kernel(IterArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    constexpr int SLOT = STAGE_BYTES / 8, NSLOT = EVAL_THREADS / 64;
+    // DMA: [NSLOT][SLOT] staged tiles, one slot per wave, FIRST in the carve (their LDS addresses travel through M0 and stay
+    // below 64 KB that way); the accepted-point stash of the workgroups that store it borrows the last slots
+    double *const stage0 = lds_raw;
+    double *const lds = lds_raw + (DMA ? NSLOT * SLOT : 0);
     constexpr int MM = ITER_MM, P = ITER_P;
     static_assert(MM == 3, "DevState::rhow holds a window of 3");
     const int n = a.n, M = a.M;
@@ -268,7 +281,8 @@ iter_kernel(IterArgs a)
     double *sts_s = nu_s;                                // [n] trial point, likewise (the prices are written at the very end)
     double *glo_s = strips + 2 * 64 * (EVAL_THREADS / 64);   // [xvs] lower bounds | [xvs] upper bounds
     double *ghi_s = glo_s + a.xvs;
-    double *psi_k = ghi_s + a.xvs, *nu_k = psi_k + a.xvs;    // workgroup 0 only
+    double *psi_k = DMA ? stage0 + NSLOT * SLOT - 2 * a.xvs : ghi_s + a.xvs, *nu_k = psi_k + a.xvs;    // the workgroups that store the accepted point only
+    const int first_late = (NSLOT * SLOT - 2 * a.xvs) / SLOT;    // DMA: the slots from here on hold that stash during the update
 
 #ifdef CFMM_PHASE_TIMERS
     const long long ts_c16 = clock64(), ts_w16 = wall_clock64();     // (stored only by launches that go on to evaluate: the idle ones behind the end of a solve must not overwrite them)
@@ -498,6 +512,17 @@ iter_kernel(IterArgs a)
     accept = uni(ctli[0]) != 0; new_dir = uni(ctli[1]) != 0; pair_ok = uni(ctli[3]) != 0;
     gp_sq = uni(ctl[2 * P + 1]);
     if (wave != 0) { st.status = uni(ctli[2]); st.t_step = uni(ctl[2 * P]); }      // (wave 0 holds the complete record, which it stores at the end)
+    // the columns of this wave's first tile: requested now (unless the solve has just ended or runs out of budget here: such
+    // a launch does not evaluate), they land while the direction and the trial point are formed
+    const bool dma_late = keeps_acc && wave >= first_late;
+    if constexpr (DMA) {
+        // (every load of the update has long been consumed -- but the compiler cannot see that the waves that issued them are
+        //  the waves that consumed them (two `if (wave_active)` regions with barriers in between), so it re-waits for them at
+        //  their next use, and at run time such a vmcnt(N) waits for the DMA pieces issued here.  This wait costs nothing
+        //  and tells it that nothing of its own is pending any more.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), nothing else
+        if (st.status == 0 && st.evals < a.max_evals && !dma_late) tiles_dma_first(a.ev, next_tile, lds_addr(stage0 + SLOT * wave), lane, wave);
+    }
     if (new_dir && wave_active) {
 #pragma unroll
         for (int k = 0; k < P; ++k) { al[k] = uni(ctl[k]); ga[k] = uni(ctl[P + k]); }
@@ -526,7 +551,12 @@ iter_kernel(IterArgs a)
         if (accept) {                                    // the trial point and its gradient: from the LDS stash
 #pragma unroll
             for (int e = 0; e < E; ++e) if (tin[e]) { s[e] = sts_s[r0 + e]; Gs[e] = gst_s[r0 + e]; }
-        } else { ldE<E>(Xr, ld0, s); ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 3 * xvs, ld0, d); }
+        } else {
+            ldE<E>(Xr, ld0, s); ldE<E>(Xr + 2 * xvs, ld0, Gs); ldE<E>(Xr + 3 * xvs, ld0, d);
+            // (waited for HERE: left pending, the compiler places its vmcnt(0) at their first use on the common path behind the
+            //  join, where at run time it waits for the first tiles' LDS-DMA instead -- the accepted branch stood still for ~1 us)
+            if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), nothing else
+        }
 #pragma unroll
         for (int e = 0; e < E; ++e) if (tin[e]) psi_s[r0 + e] = 0.0;       // (the stash entry becomes this thread's share of the zeroed psi tile)
         if (keeps_acc && accept && r0 < n) {             // the accepted prices and their net trade, for the read-back
@@ -560,7 +590,7 @@ iter_kernel(IterArgs a)
         }
         red.put<1, 1>(F, wave_active);
         if (wave_active) trial(1.0);           // (speculation: the full step is the common case; under the reduction's barrier wait)
-        red.get<1, 1>(F);
+        red.template get<1, 1, DMA>(F);
         bool redo = false;
         if (!(F[0] < 0.0) && gp_sq > 0.0) {       // not a descent direction: restart from the metric
             st.hist = 0;
@@ -571,7 +601,7 @@ iter_kernel(IterArgs a)
                 m1[0] = fmax(m1[0], fabs(d[e]));
             }
             red.put<0, 1>(m1, wave_active);
-            red.get<0, 1>(m1);
+            red.template get<0, 1, DMA>(m1);
             F[1] = m1[0];
             redo = true;
         }
@@ -603,6 +633,7 @@ iter_kernel(IterArgs a)
     PHASE_STAMP(a.ev.ts, 22);
 #pragma unroll
     for (int e = 0; e < E; ++e) if (tin[e]) nu_s[r0 + e] = nn[e];        // (over this thread's own stash entry)
+    if constexpr (DMA) lds_barrier(); else               // (LDS only: a fence would wait for the first tiles' DMA -- and for nothing else that matters here)
     __syncthreads();                                     // (the scratch in the exchange strips is free from here on; the tile table
     PHASE_STAMP(a.ev.ts, 23);                            //  and the ticket counter have been ready since the first barrier)
 #ifdef CFMM_PHASE_TIMERS
@@ -612,6 +643,10 @@ iter_kernel(IterArgs a)
     }
 #endif
     double2 *xs = reinterpret_cast<double2 *>(strips) + 64 * wave;
+    if constexpr (DMA)
+        eval_tiles_and_flush<false, false, DET, false, true, true>(a.ev, a.acc3 + (size_t)p * a.acc_set, nu_s, psi_s, nullptr, fpart, next_tile, xs,
+                                                                   BatchCtl{1u, 0, 0}, nullptr, stage0 + SLOT * wave, !dma_late);
+    else
     eval_tiles_and_flush<false, false, DET>(a.ev, a.acc3 + (size_t)p * a.acc_set, nu_s, psi_s, nullptr, fpart, next_tile, xs);
 #ifdef CFMM_PHASE_TIMERS
     __syncthreads();

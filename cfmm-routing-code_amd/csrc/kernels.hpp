@@ -47,9 +47,20 @@ constexpr int MAX_MEMORY = 8;         // L-BFGS pairs kept (register-resident in
 #endif
 constexpr int WT_LIGHT = WT_LIGHT_DEF;  // cp2, sum2: two pools per lane
 constexpr int WT_HEAVY = 64;          // w2, curve2: one pool per lane
+// The staged tile walk (LDS-DMA one tile ahead, below) is compiled in with -DCFMM_STAGED_WALK=1 (`make variant TAG=staged
+// DEFS=-DCFMM_STAGED_WALK=1`) and then taken unless CFMM_TILE_DMA=0.  Round 4 built it, validated it (the whole -m gpu suite
+// passes through it) and measured it SLOWER than the direct walk on every BASELINE config (tried and rejected):
+// it is kept as an A/B variant, not as the default.
+#ifndef CFMM_STAGED_WALK
+#define CFMM_STAGED_WALK 0
+#endif
+// pools of a K-asset wave-tile: 64 / K with one leg per lane.  Staged-walk builds take K = 3 as 20 (not 21) and K = 7 as 8
+// (not 9) pools, so that every tile starts on a multiple of 4 legs and of 2 pools: its idx / R / w / fee segments are then
+// 16-byte aligned, which is what the 16-byte LDS-DMA pieces (tile_dma_issue) move
+__host__ __device__ constexpr int ktile_pools(int k) { return CFMM_STAGED_WALK ? (k == 3 ? 20 : (k == 7 ? 8 : 64 / k)) : 64 / k; }
 __host__ __device__ constexpr int wave_tile_pools(int code)     // code: CFMM_POOL_* kind, or -k
 {
-    return code < 0 ? 64 / (-code)                     // k-asset geo-mean: one LEG per lane
+    return code < 0 ? ktile_pools(-code)               // k-asset geo-mean: one LEG per lane
                     : ((code == 0 || code == 2) ? WT_LIGHT : WT_HEAVY);
 }
 constexpr int N_BUCKETS = 11;         // gn8 gn7 gn6 gn5 gn4 gn3 curve2 pow2 w2 cp2 sum2 (processing order)
@@ -208,13 +219,62 @@ constexpr int BATCH_MAX = 8;
 struct BatchCtl { unsigned alive; int nu_stride, tile_stride; };
 
 // ------------------------------------------------------------------------------------------
+// The STAGED tile walk (round 4): every wave owns a 4 KB LDS slot, and the pool columns of its NEXT wave-tile are brought
+// into it by LDS-DMA (global_load_lds_dwordx4: 16 B per lane, 1 KB per wave-instruction, no VGPRs, asynchronous) while it
+// computes the current tile -- and, in iter_kernel, the FIRST tile of every wave while the in-launch nu update's latency
+// chain still runs (the memory system idles there: 7 us of every 21 at C3, 13 of 59 at C4).  Per tile:
+//     s_waitcnt vmcnt(0)          this tile's columns have landed (the only thing outstanding)
+//     tile_stage_read             LDS slot -> 6 doubles + 4 ints per lane (lane-linear ds_reads)
+//     s_waitcnt lgkmcnt(0)        ... and are in registers: the slot is free
+//     tile_dma_issue(next)        2-4 DMA instructions for the next ticket's tile (any bucket)
+//     tile2 / tilen <..., PRE>    the pool arithmetic on the registers
+// so no tile of the launch waits for HBM / L2 latency, head and tail of the launch included (a wave-tile loaded at its
+// own start exposes one full memory latency: at C3 a wave runs only ~4 tiles per launch).  The DMA instructions are
+// inline asm: hipcc neither orders ds_reads behind the builtin form nor lets ordinary loads pass it (it drains vmcnt(0)),
+// so the two waits above are placed by hand and the walk contains no compiler-visible global load.  Slot layouts (bytes):
+//   two pools per lane (cp2, sum2; 128 pools): Ra 0 | Rb 1024 | fee 2048 | ia 3072 | ib 3584
+//   one pool per lane (w2, curve2, pow2; 64):  Ra 0 | Rb 512 | fee 1024 | param 1536 | ia 2048 | ib 2304
+//   K-asset, leg per lane:                     R 0 | w 512 | idx 1024 | fee 1280 (32 pools) | log fee 1536
+// Every piece is 16-byte aligned in global memory (columns are 256-byte aligned, tiles start on multiples of 64 / 128 pools,
+// K-asset tiles on multiples of 4 legs and 2 pools: ktile_pools); chunks past a column's end are clamped to its last chunk
+// (the lanes that would use them are not live; a column is followed by >= 16 readable bytes: cfmm_hip.hip, upload_arena).
+// ------------------------------------------------------------------------------------------
+constexpr int STAGE_BYTES = 4096;                       // per wave
+struct TileRegs { double d[6]; int i[4]; };            // a staged wave-tile's columns, as one lane holds them
+
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)      // lane l: 16 B at gsrc -> LDS lds_dst + 16 l
+{
+    unsigned keep;                                      // (M0 is compiler-reserved: saved and restored inside the statement)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// a workgroup barrier that orders LDS traffic only.  __syncthreads() carries a fence, and wherever ANY path into it has a
+// global store or load pending the compiler places s_waitcnt vmcnt(0) in front of the barrier -- which at run time also waits
+// for the LDS-DMA pieces in flight (they count on vmcnt): the update chain of iter_kernel stood still until its first tiles
+// had landed (+1.8 us per launch at C4).  Nothing that crosses these barriers goes through global memory.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)p); }   // (flat -> LDS offset: the low 32 bits)
+// a column base out of the kernel arguments, pinned to SGPRs: without this the compiler turns `lane < 32 ? b.R : b.w` into a
+// per-lane VECTOR load of the pointer from the argument block (a load the walk would have to wait for)
+__device__ __forceinline__ const char *uni_ptr(const void *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+}
+
+// ------------------------------------------------------------------------------------------
 // one wave-tile of a two-asset bucket: lane l solves pools i0 + l + 64 u, u < U.  All 5U column
 // loads are issued before the first use (each 512 B coalesced per wave).
 // 32 B (CP2, SUM2) or 40 B (W2, CURVE2, POW2: + the parameter column) of HBM per pool, read once.
 // ------------------------------------------------------------------------------------------
-template <int KIND, bool WITH_D, bool DET, bool BATCH = false>
+// PRE: the columns come from `pre` (the staged walk: tile_stage_read) instead of global memory
+template <int KIND, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false>
 __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, const double *nu_s,
-                                      const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double &fsum, const BatchCtl &bc)
+                                      const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double &fsum, const BatchCtl &bc,
+                                      const TileRegs *pre = nullptr)
 {
     static_assert(!(BATCH && WITH_D), "the batched evaluation does not build the metric");
     constexpr int U = wave_tile_pools(KIND) / 64;
@@ -229,9 +289,15 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
         unsigned i = (unsigned)i0 + u * 64 + lane;
         live[u] = i < (unsigned long long)b.m;
         i = live[u] ? i : (unsigned)b.m - 1u;
-        Ra[u] = ld_off(b.Ra, i); Rb[u] = ld_off(b.Rb, i); g[u] = ld_off(b.fee, i);
-        ia[u] = ld_off(b.ia, i); ib[u] = ld_off(b.ib, i);
-        prm[u] = (KIND == 1 || KIND >= 3) ? ld_off(b.param, i) : 0.0;
+        if constexpr (PRE) {
+            Ra[u] = pre->d[u]; Rb[u] = pre->d[U + u]; g[u] = pre->d[2 * U + u];
+            ia[u] = live[u] ? pre->i[u] : 0; ib[u] = live[u] ? pre->i[U + u] : 0;     // (a dead lane holds a clamped chunk's tail: not a token id)
+            prm[u] = (KIND == 1 || KIND >= 3) ? pre->d[U == 1 ? 3 : 0] : 0.0;
+        } else {
+            Ra[u] = ld_off(b.Ra, i); Rb[u] = ld_off(b.Rb, i); g[u] = ld_off(b.fee, i);
+            ia[u] = ld_off(b.ia, i); ib[u] = ld_off(b.ib, i);
+            prm[u] = (KIND == 1 || KIND >= 3) ? ld_off(b.param, i) : 0.0;
+        }
         fl[u] = (KIND == 2 && b.flags) ? ld_off(b.flags, i) : 0;
     }
 #pragma unroll 1
@@ -291,11 +357,12 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
 // ~350 instructions instead of ~2000 for one-pool-per-lane at K = 8.
 // ------------------------------------------------------------------------------------------
 template <int K>
-__host__ __device__ constexpr int pools_per_wave() { return 64 / K; }
+__host__ __device__ constexpr int pools_per_wave() { return ktile_pools(K); }
 
-template <int K, bool WITH_D, bool DET, bool BATCH = false>
+template <int K, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false>
 __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, const double *nu_s,
-                                      const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double2 *xs, double &fsum, const BatchCtl &bc)
+                                      const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double2 *xs, double &fsum, const BatchCtl &bc,
+                                      const TileRegs *pre = nullptr)
 {
     static_assert(!(BATCH && WITH_D), "the batched evaluation does not build the metric");
     constexpr int P = pools_per_wave<K>();
@@ -308,10 +375,10 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
     const unsigned pool = (unsigned)tb * P + g;
     const bool live = (g < P) && (pool < (unsigned long long)b.m);
     const unsigned leg = live ? pool * K + j : 0u, pl = live ? pool : 0u;
-    const int tok = ld_off(b.idx, leg);
-    const double R = ld_off(b.R, leg), w = ld_off(b.w, leg);
-    const double fee = ld_off(b.fee, pl);
-    const double lg = ld_off(b.lfee, pl);
+    int tok;
+    double R, w, fee, lg;
+    if constexpr (PRE) { tok = live ? pre->i[0] : 0; R = pre->d[0]; w = pre->d[1]; fee = pre->d[2]; lg = pre->d[3]; (void)leg; (void)pl; }     // (dead lanes: a neighbouring tile's legs or a clamped chunk's tail)
+    else { tok = ld_off(b.idx, leg); R = ld_off(b.R, leg); w = ld_off(b.w, leg); fee = ld_off(b.fee, pl); lg = ld_off(b.lfee, pl); }
     const int gb = (g < P ? g : 0) * K;
 #pragma unroll 1
     for (unsigned mask = BATCH ? bc.alive : 1u; mask; mask &= mask - 1) {
@@ -349,7 +416,7 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
         __builtin_amdgcn_wave_barrier();
         SCHED_FENCE();
         double y = 0.0;
-        if (den > 0.0 && (wd || dp)) {
+        if (live && den > 0.0 && (wd || dp)) {             // (live: a dead lane's numbers must not push the wave off expm1_wave's short path)
             const double t = num * rcp_nr(den);
             const double rx = -R * expm1_wave<DET>(wd ? t - t1 : t - t2);    // R - x,  x = R e^{f(t - a_j)}
             y = wd ? rx : rx * rcp_nr(fee);
@@ -360,6 +427,134 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
             if (WITH_D) diag_s.add(tok, (1.0 - w) * p * R);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The staged walk's two halves around a tile (layouts: above).  bk = the tile's bucket in processing order
+// (0..5: K-asset, K = 8 - bk; 6 curve2, 7 pow2, 8 w2: one pool per lane; 9 cp2, 10 sum2: two per lane), tb = the tile's index
+// inside its bucket.  Both are wave-uniform; the bucket's column pointers come out of the kernel arguments by index.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int bucket_kind2(int bk) { return bk == 6 ? 3 : (bk == 7 ? 4 : (bk == 8 ? 1 : (bk == 9 ? 0 : 2))); }
+
+__device__ __forceinline__ void tile_dma_issue(const EvalArgs &a, int bk, int tb, unsigned stage, int lane)
+{
+    // (every column base and every source address is formed BEFORE the first DMA statement: the asm statements are memory
+    //  barriers to the compiler, a scalar load of a base placed between two of them would be waited for in between)
+    const int l32 = lane & 31, l16 = lane & 15;
+    const bool hi = lane >= 32;
+    if (bk <= 5) {
+        const int K = 8 - bk;
+        const BucketN &b = a.bn[5 - bk];
+        const char *pR = uni_ptr(b.R), *pW = uni_ptr(b.w), *pI = uni_ptr(b.idx), *pF = uni_ptr(b.fee), *pL = uni_ptr(b.lfee);
+        const unsigned P = (unsigned)((0x14100c0a0808ull >> (8 * bk)) & 0xff);          // ktile_pools(K)
+        const unsigned m = (unsigned)b.m, nleg = m * (unsigned)K;
+        const unsigned pool0 = (unsigned)tb * P, leg0 = pool0 * (unsigned)K;
+        // lanes 0-31: R[leg0 + 2 l ..], lanes 32-63: w[...]  ->  slot bytes [0, 512) | [512, 1024)
+        unsigned e = leg0 + 2u * l32;
+        const unsigned lim = (nleg - 1u) & ~1u;
+        e = e < lim ? e : lim;
+        const char *s0 = (hi ? pW : pR) + (size_t)e * 8u;
+        // lanes 0-15: idx[leg0 + 4 l ..] -> [1024, 1280); 16-31: fee[pool0 + 2 (l - 16) ..] -> [1280, 1536); 32-47: log fee -> [1536, 1792)
+        unsigned e4 = leg0 + 4u * l16, e2 = pool0 + 2u * l16;
+        const unsigned lim4 = (nleg - 1u) & ~3u, lim2 = (m - 1u) & ~1u;
+        e4 = e4 < lim4 ? e4 : lim4; e2 = e2 < lim2 ? e2 : lim2;
+        const char *s1 = lane < 16 ? pI + (size_t)e4 * 4u : (hi ? pL : pF) + (size_t)e2 * 8u;
+        glds16(s0, stage);
+        if (lane < 48) glds16(s1, stage + 1024u);
+    } else if (bk <= 8) {
+        const Bucket2 &b = a.b2[bucket_kind2(bk)];
+        const char *pA = uni_ptr(b.Ra), *pB = uni_ptr(b.Rb), *pF = uni_ptr(b.fee), *pP = uni_ptr(b.param), *pIa = uni_ptr(b.ia), *pIb = uni_ptr(b.ib);
+        const unsigned m = (unsigned)b.m, e0 = (unsigned)tb * WT_HEAVY;
+        unsigned e = e0 + 2u * l32, e4 = e0 + 4u * l16;
+        const unsigned lim = (m - 1u) & ~1u, lim4 = (m - 1u) & ~3u;
+        e = e < lim ? e : lim; e4 = e4 < lim4 ? e4 : lim4;
+        const char *s0 = (hi ? pB : pA) + (size_t)e * 8u, *s1 = (hi ? pP : pF) + (size_t)e * 8u, *s2 = (lane >= 16 ? pIb : pIa) + (size_t)e4 * 4u;
+        glds16(s0, stage);                                   // Ra | Rb
+        glds16(s1, stage + 1024u);                           // fee | param
+        if (lane < 32) glds16(s2, stage + 2048u);            // ia | ib
+    } else {
+        const Bucket2 &b = a.b2[bk == 9 ? 0 : 2];
+        const char *pA = uni_ptr(b.Ra), *pB = uni_ptr(b.Rb), *pF = uni_ptr(b.fee), *pIa = uni_ptr(b.ia), *pIb = uni_ptr(b.ib);
+        const unsigned m = (unsigned)b.m, e0 = (unsigned)tb * WT_LIGHT;
+        unsigned e = e0 + 2u * lane, e4 = e0 + 4u * l32;
+        const unsigned lim = (m - 1u) & ~1u, lim4 = (m - 1u) & ~3u;
+        e = e < lim ? e : lim; e4 = e4 < lim4 ? e4 : lim4;
+        const size_t off = (size_t)e * 8u;
+        static_assert(WT_LIGHT == 128, "slot layout of the two-pools-per-lane tiles");
+        const char *s0 = pA + off, *s1 = pB + off, *s2 = pF + off, *s3 = (hi ? pIb : pIa) + (size_t)e4 * 4u;
+        glds16(s0, stage);
+        glds16(s1, stage + 1024u);
+        glds16(s2, stage + 2048u);
+        glds16(s3, stage + 3072u);                           // ia | ib
+    }
+}
+
+__device__ __forceinline__ void tile_stage_read(int bk, const double *sd, int lane, TileRegs &r)
+{
+    const int *si = reinterpret_cast<const int *>(sd);
+    if (bk <= 5) {
+        const int g = (lane * (int)((0x55900334ab24c80ull >> (10 * bk)) & 0x3ff)) >> 10;      // lane / K  (ceil(1024 / K), exact for lane < 64)
+        r.d[0] = sd[lane]; r.d[1] = sd[64 + lane]; r.d[2] = sd[160 + g]; r.d[3] = sd[192 + g];
+        r.i[0] = si[256 + lane];
+        r.d[4] = r.d[5] = 0.0; r.i[1] = r.i[2] = r.i[3] = 0;
+    } else if (bk <= 8) {
+        r.d[0] = sd[lane]; r.d[1] = sd[64 + lane]; r.d[2] = sd[128 + lane]; r.d[3] = sd[192 + lane];
+        r.i[0] = si[512 + lane]; r.i[1] = si[576 + lane];
+        r.d[4] = r.d[5] = 0.0; r.i[2] = r.i[3] = 0;
+    } else {
+        r.d[0] = sd[lane]; r.d[1] = sd[64 + lane]; r.d[2] = sd[128 + lane]; r.d[3] = sd[192 + lane];
+        r.d[4] = sd[256 + lane]; r.d[5] = sd[320 + lane];
+        r.i[0] = si[768 + lane]; r.i[1] = si[832 + lane]; r.i[2] = si[896 + lane]; r.i[3] = si[960 + lane];
+    }
+}
+
+// where a walk index lies: the bucket pointer of a wave only ever moves one way (its tickets grow)
+struct TileCursor {
+    int bk, cstart, cend, sfirst;
+    __device__ __forceinline__ void init(const int *tab, bool rev)
+    {
+        bk = rev ? N_BUCKETS - 1 : 0;
+        cstart = rev ? __builtin_amdgcn_readfirstlane(tab[N_BUCKETS - 2]) : 0;
+        cend = __builtin_amdgcn_readfirstlane(tab[bk]); sfirst = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS + bk]);
+    }
+    // the same for ANY walk index in two LDS round trips (lanes 0..N_BUCKETS-1 compare one table entry each): the first
+    // ticket of a wave, which the serial walk reaches only after up to N_BUCKETS - 1 dependent steps
+    __device__ __forceinline__ int find(const int *tab, int i, int lane)
+    {
+        const int c = lane < N_BUCKETS ? tab[lane] : 0x7fffffff;
+        const unsigned long long below = __ballot(c <= i) & ((1ull << N_BUCKETS) - 1);
+        bk = __builtin_popcountll(below);                // buckets that end at or before i (the counts are cumulative: a prefix)
+        cend = __builtin_amdgcn_readlane(c, bk);
+        cstart = bk ? __builtin_amdgcn_readlane(c, bk - 1) : 0;
+        sfirst = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS + bk]);
+        return sfirst + (i - cstart);
+    }
+    __device__ __forceinline__ int seek(const int *tab, int i)      // -> the tile's index inside bucket `bk`
+    {
+        while (i >= cend) {
+            ++bk; cstart = cend;
+            cend = __builtin_amdgcn_readfirstlane(tab[bk]);
+            sfirst = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS + bk]);
+        }
+        while (i < cstart) {
+            --bk; cend = cstart;
+            cstart = bk ? __builtin_amdgcn_readfirstlane(tab[bk - 1]) : 0;
+            sfirst = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS + bk]);
+        }
+        return sfirst + (i - cstart);
+    }
+};
+
+// the first DMA of a wave's staged walk (its first ticket is its own index): iter_kernel issues it under the update
+__device__ __forceinline__ void tiles_dma_first(const EvalArgs &a, const int *next_tile, unsigned stage, int lane, int wib)
+{
+    const int *tab = next_tile + 2;
+    const int nlocal = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS - 1]);
+    if (wib >= nlocal) return;
+    const bool rev = a.rev != 0;
+    TileCursor c;
+    const int tb = c.find(tab, rev ? nlocal - 1 - wib : wib, lane);
+    tile_dma_issue(a, c.bk, tb, stage, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -406,16 +601,57 @@ __device__ __forceinline__ void build_tile_table(const EvalArgs &a, int *next_ti
 // is formed at the flush as nu' psi per vector (sum_i arb_i = sum_i nu' y_i) instead of being carried per lane.
 // FLUSH = false: the tiles stay in LDS (psi_t, diag_t, fpart[wave] = per-wave partial of sum arb) for a consumer in the same
 // workgroup (tiny.hpp)
-template <bool WITH_D, bool STABLE, bool DET = false, bool BATCH = false, bool FLUSH = true>
+// DMA: the staged walk (above) -- `stage` is this wave's 4 KB LDS slot, `first_issued` says that the caller has already
+// issued the DMA of the wave's first tile (tiles_dma_first)
+template <bool WITH_D, bool STABLE, bool DET = false, bool BATCH = false, bool FLUSH = true, bool DMA = false>
 __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *acc, const double *nu_s, double *psi_t, double *diag_t,
                                                      double *fpart, int *next_tile, double2 *xs, const BatchCtl &bc = BatchCtl{1u, 0, 0},
-                                                     double *const *acc_b = nullptr)
+                                                     double *const *acc_b = nullptr, const double *stage = nullptr, bool first_issued = false)
 {
     const int n = a.n;
     const Scatter<DET> psi_s{psi_t, n, a.det_scale}, diag_s{diag_t, n, a.det_scale_d};
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double fsum = 0.0;
+    if constexpr (DMA) {
+        static_assert(!STABLE && !BATCH && FLUSH, "the staged walk serves the main tile space only");
+        const int *tab = next_tile + 2;
+        const int nlocal = __builtin_amdgcn_readfirstlane(tab[N_BUCKETS - 1]);
+        const bool rev = a.rev != 0;
+        const unsigned slot = lds_addr(stage);
+        TileCursor cur; cur.init(tab, rev);
+        int i0 = wib, bk = 0, tb = 0, ticket = 0;
+        if (i0 < nlocal) {
+            tb = cur.find(tab, rev ? nlocal - 1 - i0 : i0, lane); bk = cur.bk;
+            if (!first_issued) tile_dma_issue(a, bk, tb, slot, lane);
+        }
+        while (i0 < nlocal) {
+            if (lane == 0) ticket = atomicAdd(next_tile, 1);           // the next ticket: its LDS round trip rides under the read-out
+            TileRegs r;
+            dma_wait();                                                // this tile's columns have landed in the slot
+            tile_stage_read(bk, stage, lane, r);
+            lds_wait();                                                // ... and sit in registers: the slot is free for the next tile
+            const int n0 = __builtin_amdgcn_readfirstlane(ticket);
+            int nbk = 0, ntb = 0;
+            if (n0 < nlocal) {
+                ntb = cur.seek(tab, rev ? nlocal - 1 - n0 : n0); nbk = cur.bk;
+                tile_dma_issue(a, nbk, ntb, slot, lane);
+            }
+            switch (bk) {
+            case 0: tilen<8, WITH_D, DET, false, true>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
+            case 1: tilen<7, WITH_D, DET, false, true>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
+            case 2: tilen<6, WITH_D, DET, false, true>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
+            case 3: tilen<5, WITH_D, DET, false, true>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
+            case 4: tilen<4, WITH_D, DET, false, true>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
+            case 5: tilen<3, WITH_D, DET, false, true>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
+            case 8: tile2<1, WITH_D, DET, false, true>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc, &r); break;
+            case 9: tile2<0, WITH_D, DET, false, true>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc, &r); break;
+            case 10: tile2<2, WITH_D, DET, false, true>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc, &r); break;
+            default: break;                                            // (6, 7: the heavy kinds live in the other tile space)
+            }
+            i0 = n0; bk = nbk; tb = ntb;
+        }
+    } else {
 #ifdef CFMM_PHASE_TIMERS
     int nlog = 0;
     long long t_prev = clock64(), t_out = 0;         // time spent between tiles (ticket, bucket search, dispatch)
@@ -493,6 +729,7 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
         if (gw < 4096) a.ts[64 + 8 * gw + 7] = (15ll << 48) | (t_out + (clock64() - t_prev));
     }
 #endif
+    }
     PHASE_STAMP(a.ts, 2);
     if constexpr (BATCH) {
         // every live vector's tile into its own accumulator; fpart: [BATCH_MAX][16] wave partials of nu' psi
@@ -552,11 +789,14 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
     PHASE_STAMP(a.ts, 4);
 }
 
-template <bool WITH_D, bool STABLE, bool DET = false>
+// DMA: the staged tile walk; the launch then carries one 4 KB slot per wave behind the exchange strips
+template <bool WITH_D, bool STABLE, bool DET = false, bool DMA = false>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 eval_kernel(EvalArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    // (the staged walk's slots come FIRST: their LDS addresses travel through M0 and stay below 64 KB that way)
+    double *const lds = lds_raw + (DMA ? (STAGE_BYTES / 8) * (EVAL_THREADS / 64) : 0);
     PHASE_STAMP(a.ts, 0);
 #ifdef CFMM_PHASE_TIMERS
     if (a.ts && threadIdx.x == 0 && blockIdx.x < 1024) a.ts[64 + 8 * 4096 + 2 * blockIdx.x] = wall_clock64();    // block start
@@ -574,6 +814,10 @@ eval_kernel(EvalArgs a)
     __syncthreads();
     if (nu_s[n] != 0.0) return;
     PHASE_STAMP(a.ts, 1);
+    if constexpr (DMA) {
+        const double *stage = lds_raw + (STAGE_BYTES / 8) * (threadIdx.x >> 6);
+        eval_tiles_and_flush<WITH_D, STABLE, DET, false, true, true>(a, a.acc, nu_s, psi_s, diag_s, fpart, next_tile, xs, BatchCtl{1u, 0, 0}, nullptr, stage, false);
+    } else
     eval_tiles_and_flush<WITH_D, STABLE, DET>(a, a.acc, nu_s, psi_s, diag_s, fpart, next_tile, xs);
 #ifdef CFMM_PHASE_TIMERS
     __syncthreads();
@@ -1040,12 +1284,13 @@ struct BlockRed {
             for (int k = 0; k < NS + NM; ++k) sl[k * 16 + wave] = v[k];
         }
     }
-    template <int NS, int NM>
+    // LDS_ONLY: lds_barrier() instead of __syncthreads() (callers with LDS-DMA in flight)
+    template <int NS, int NM, bool LDS_ONLY = false>
     __device__ __forceinline__ void get(double (&v)[NS + NM])
     {
         const double *sl = scratch + parity * (NRED * 16);
         parity ^= 1;
-        __syncthreads();
+        if constexpr (LDS_ONLY) lds_barrier(); else __syncthreads();
 #pragma unroll
         for (int k = 0; k < NS; ++k) { double r = 0.0; for (int w = 0; w < nw; ++w) r += sl[k * 16 + w]; v[k] = r; }
 #pragma unroll
