@@ -57,8 +57,12 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # AMD's MI355X figure for vector fp64 (256 CUs x
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock
 TRAFFIC_NOTE = {"C3": "C3's 43.4 MB working set fits the 256 MiB Infinity Cache: back-to-back launches are cache-served; "
                       "profiles/ holds the PMC traffic and the HBM-streaming (>= 1e7 pools) variant",
-                "C4": "320 MB per launch at N = 1: streams from HBM (larger than the 256 MiB Infinity Cache); consecutive launches walk "
-                      "the pools in opposite directions (ping-pong), so ~10 % of a launch -- what the 8 x 4 MB of L2 still hold -- is not re-read",
+                "C4": "320 MB per launch at N = 1 against a 256 MiB Infinity Cache: PARTLY CACHE-SERVED, not an HBM-streaming figure -- consecutive "
+                      "launches walk the pools in opposite directions (ping-pong), so most of a launch finds its data still in the Infinity Cache "
+                      "(FETCH_SIZE counts Infinity-Cache hits: MI355X_MICROARCH.md); the evaluation alone runs ABOVE the ~6.3 TB/s HBM can deliver. "
+                      "The honest HBM fraction is --config C4x4 (1.28 GB per launch)",
+                "C4x4": "1.28 GB of pool columns per launch (4e7 constant-product pools), five times the Infinity Cache: this set MUST stream "
+                        "from HBM whatever the walk direction -- the figure SURVEY 8(d)'s cache caveat asks for",
                 "C2": "0.32 MB of pool data per evaluation: launch-latency bound -- neither fraction says much",
                 "C5": "second-order path: the dominant kernel group is the dense n x n Cholesky of a Newton step (a latency chain of "
                       "dependent launches, priced against the fp64 vector peak); the smoothed evaluation is fp64-issue / divergence bound"}
@@ -68,28 +72,36 @@ KIND_ID = {"cp2": 0, "w2": 1, "sum2": 2, "curve2": 3}
 METRIC = "pool-subproblems/sec to 1e-6 rel-gap; 1e6 pools / 1k tokens; 1/2/4/8 GPU"
 
 
-def profile_record(config):
+def profile_record(config, tag=""):
     """HBM bytes per launch (PMC, corrected as MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE doubled on gfx950,
     + WRITE_SIZE) and the rocprofv3 kernel-trace average of the same launch, from the NEWEST summaries committed under
     profiles/ -- read at run time so that the bench line cannot go stale silently.  Two records: "iter" = iter_kernel
     (the one launch per outer iteration; averages over its FULL launches, the idle run-ahead launches behind the end of a
     solve excluded) from tools/profile_iter.py's trace, "eval" = eval_kernel alone from tools/profile_eval.py's."""
     import json
-    out = {k: dict(traffic=None, traffic_file=None, rocprof_avg_us=None, rocprof_file=None, valu_busy=None) for k in ("iter", "eval")}
+    out = {k: dict(traffic=None, traffic_file=None, rocprof_avg_us=None, rocprof_file=None, valu_busy=None, gui_active=None,
+                   l2_hit_rate=None) for k in ("iter", "eval")}
+    config = config + tag                              # (e.g. "C3" + "zipf": the stress variant's own profile rows)
     pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_pmc_medians.csv")))
+    wanted = ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum")
     for which, cfg, name in (("iter", config + "iter", "iter_kernel"), ("eval", config, "eval_kernel")):
         for f in reversed(pmc):
             rows = {}
             for r in csv.DictReader(open(f)):
-                if r["config"] == cfg and name in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU"):
+                if r["config"] == cfg and name in r["kernel"] and r["counter"] in wanted:
                     rows.setdefault(r["kernel"], {})[r["counter"]] = float(r["median"])
             rows = {k: v for k, v in rows.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
             if rows:                                   # the instantiation that moves the most bytes: the dominant one
                 v = max(rows.values(), key=lambda v: v["FETCH_SIZE"])
                 out[which]["traffic"] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
                 out[which]["traffic_file"] = os.path.relpath(f, ROOT)
-                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs: x 4 = SIMD-cycles the vector ALU was issuing
+                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs: x 4 = SIMD-cycles the vector ALU was issuing;
+                # GRBM_GUI_ACTIVE = the shader clock's cycles over the same dispatch (the effective clock under the profiler,
+                # not the 2.4 GHz maximum): their ratio is a fraction in which neither a clock nor a live duration is assumed
                 out[which]["valu_busy"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] if "SQ_ACTIVE_INST_VALU" in v else None
+                out[which]["gui_active"] = v.get("GRBM_GUI_ACTIVE")
+                if "TCC_HIT_sum" in v and "TCC_MISS_sum" in v and v["TCC_HIT_sum"] + v["TCC_MISS_sum"] > 0:
+                    out[which]["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
                 break
     for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_durations.json")))):
         d = json.load(open(f)).get(config + "iter", {})
@@ -153,7 +165,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default=os.environ.get("BENCH_CONFIG", "C3"), choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--config", default=os.environ.get("BENCH_CONFIG", "C3"), choices=["C2", "C3", "C4", "C4x4", "C5"])
+    ap.add_argument("--zipf", type=float, default=None, help="SURVEY 8(d)'s stress variant: token pairs drawn Zipf(s) hub-weighted instead of uniform (s = 1.1)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--no-cpu", action="store_true")
@@ -206,17 +219,17 @@ def main():
     if args.share_gpu:
         shard_kw["rccl"] = False
 
-    strong = args.config == "C4"
+    strong = args.config in ("C4", "C4x4")
     solve_kw = {}
     if strong:
         # strong scaling: ONE fixed network (same seed on every rank), contiguous pool shards
-        net = synthetic.config("C4", seed=0, scale=args.scale)
+        net = synthetic.config(args.config, seed=0, scale=args.scale, zipf_s=args.zipf)
         total_pools = cfmm.problem.network_pool_count(net)
         utility = cfmm.Arbitrage(net["c"])
         prob = cfmm.distributed.sharded_problem(net, utility, shard=True, **shard_kw)
     else:
         # weak scaling: every rank generates its OWN shard of the config (same tokens / prices / utility)
-        net = synthetic.config(args.config, seed=0, scale=args.scale, pool_seed=(rank if world > 1 else None))
+        net = synthetic.config(args.config, seed=0, scale=args.scale, pool_seed=(rank if world > 1 else None), zipf_s=args.zipf)
         if args.config == "C5":
             # the basket of tools/profile_newton.py: ten tokens worth ~70 units each to be sold for token t (liquidation.py:57,77-80)
             rng = np.random.default_rng(1)
@@ -266,6 +279,17 @@ def main():
         dt = float(t.item())
     subproblems = evals * total_pools          # every rank runs the same number of evaluations over its own pools
     value = subproblems / dt
+    # Utilities that leave prices open (liquidation, swap: C5) start from prices propagated through the pools' marginal
+    # prices -- a ~2 ms host-side walk that cfmm.problem.start_prices keeps with the utility object after the first solve, so
+    # the timed steps above (behind the warm-up) did not pay it.  The same steps again with that memo dropped before every
+    # solve: what a FIRST solve of a new basket costs.
+    cold_start_ms = None
+    if args.config == "C5" and not sharded:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            utility._start_memo = None
+            prob.solve(tol=args.tol, **solve_kw)
+        cold_start_ms = 1e3 * (time.perf_counter() - t0) / args.steps
 
     # per-iteration split (all ranks: the all-reduce timing is a collective)
     fold_s, ar_s = prob.ctx.time_collective(args.kernel_reps) if sharded else (0.0, 0.0)
@@ -284,11 +308,11 @@ def main():
         mix = ", ".join(f"{k}={len(prob.net[k]['Ra'])}" for k in ("cp2", "w2", "curve2", "sum2") if k in prob.net)
         if "gn" in prob.net:
             mix += ", gn3-8=" + str(sum(b["R"].shape[1] for b in prob.net["gn"].values()))
-        prof = profile_record(args.config)
+        prof = profile_record(args.config, "zipf" if args.zipf else "")
         pk = "iter" if prob.stats.get("method") == 1 and prof["iter"]["rocprof_avg_us"] else "eval"
         us_iter = 1e6 * dev_s / max(evals, 1)
         if strong:
-            workload = (f"C4: {total_pools} constant-product pools / {net['n_tokens']} tokens split over {world} GPU(s) "
+            workload = (f"{args.config}: {total_pools} constant-product pools / {net['n_tokens']} tokens split over {world} GPU(s) "
                         f"({prob.m} per GPU: {mix}), linear-utility arbitrage, cold-start solve to gap,infeas <= {args.tol:g}")
         elif args.config == "C5":
             workload = (f"C5: {prob.m} pools per GPU ({mix}) / {net['n_tokens']} tokens, liquidation of a 10-token basket "
@@ -296,13 +320,26 @@ def main():
         else:
             workload = (f"{args.config}: {prob.m} pools per GPU ({mix}) / {net['n_tokens']} tokens, "
                         f"linear-utility arbitrage, cold-start solve to gap,infeas <= {args.tol:g}")
+        if args.zipf:
+            workload += f"; token pairs Zipf({args.zipf:g}) hub-weighted (SURVEY 8(d) stress variant)"
         if args.share_gpu:
             workload += f"; --share-gpu: the {world} ranks are processes on ONE device (functional run of the multi-rank path, not a scaling number)"
         # the binding roofline of the dominant kernel: the algorithmic bytes against the HBM peak, and the cycles its
         # vector ALUs were issuing (PMC, newest profile) against all SIMD-cycles of the launch; `bound` names the larger
         hbm_frac = dom["bytes"] / (us_iter * 1e-6) / 1e9 / HBM_PEAK_GBS
-        valu_frac = (prof[pk]["valu_busy"] / (SIMDS * CLOCK_HZ * us_iter * 1e-6)) if prof[pk]["valu_busy"] else None
-        ev_valu = (prof["eval"]["valu_busy"] / (SIMDS * CLOCK_HZ * dom["seconds"])) if prof["eval"]["valu_busy"] else None
+
+        def valu_fraction(pr, live_seconds):
+            """vector-issue fraction of a profiled launch.  With GRBM_GUI_ACTIVE in the same PMC summary: VALU-issue cycles /
+            (SIMDs x shader-clock cycles of the SAME dispatches) -- profile-only, no clock assumed; otherwise (older
+            summaries) the old estimate against 2.4 GHz x the live duration, flagged as such."""
+            if not pr["valu_busy"]:
+                return None, None
+            if pr["gui_active"]:
+                return pr["valu_busy"] / (SIMDS * pr["gui_active"]), "profiled: 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE), both from " + str(pr["traffic_file"])
+            return pr["valu_busy"] / (SIMDS * CLOCK_HZ * live_seconds), "estimate: 4 x SQ_ACTIVE_INST_VALU (" + str(pr["traffic_file"]) + ") / (1024 SIMDs x 2.4 GHz x the LIVE launch duration)"
+        valu_frac, valu_src = valu_fraction(prof[pk], us_iter * 1e-6)
+        ev_valu, _ = valu_fraction(prof["eval"], dom["seconds"])
+        eff_clock = (prof[pk]["gui_active"] / (prof[pk]["rocprof_avg_us"] * 1e3)) if (prof[pk]["gui_active"] and prof[pk]["rocprof_avg_us"]) else None
         out = {
             "metric": METRIC,
             "value": value, "unit": "pool-subproblems/s", "n_gpus": world, "steps": args.steps,
@@ -331,8 +368,7 @@ def main():
                          "kernel": "iter_kernel (nu update + evaluation, one launch per iteration)" if prob.stats.get("method") == 1 else dom["kernel"],
                          "achieved": dom["bytes"] / (us_iter * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": hbm_frac, "hbm_frac": hbm_frac, "valu_frac": valu_frac,
-                         "valu_frac_note": "SQ_ACTIVE_INST_VALU x 4 (SIMD-cycles of vector issue per launch, newest PMC file under profiles/) / "
-                                           "(1024 SIMDs x 2.4 GHz x the live launch duration)",
+                         "valu_frac_note": valu_src, "effective_clock_ghz_under_profiler": eff_clock, "l2_hit_rate": prof[pk]["l2_hit_rate"],
                          "traffic": prof[pk]["traffic"],
                          "traffic_source": prof[pk]["traffic_file"],
                          "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": us_iter,
@@ -350,6 +386,11 @@ def main():
             # into the dense solve of each Newton step, so THAT is the dominant kernel group and its ceiling is the fp64
             # vector rate (no MFMA in it).  The smoothed evaluation is priced against both ceilings beside it.
             out["newton_steps_per_solve"] = newton_steps / args.steps
+            if cold_start_ms is not None:
+                out["start_prices"] = {"ms_per_step_memoised": 1e3 * dt / args.steps, "ms_per_step_recomputed": cold_start_ms,
+                                       "note": "`ms_per_step` / `value` are measured behind the warm-up, with the host-side start-price propagation "
+                                               "of this utility memoised (cfmm/problem.py: start_prices); `ms_per_step_recomputed` repeats the timed "
+                                               "steps with the memo dropped before every solve"}
             if newton_kernels:
                 nk = newton_kernels
                 nr = (net["n_tokens"] + 31) // 32 * 32
@@ -359,8 +400,10 @@ def main():
                 out["roofline"].update({
                     "bound": "valu", "kernel": "chol_step_kernel (the dense Cholesky of one Newton step: one launch per block column, all 32 of them)",
                     "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
-                    "valu_frac": tf / FP64_VECTOR_PEAK_TFLOPS, "hbm_frac": None, "traffic": None, "traffic_source": None,
-                    "valu_frac_note": f"n^3/3 flops of the {nr} x {nr} factorisation / its measured time, against the fp64 vector peak",
+                    "flop_frac": tf / FP64_VECTOR_PEAK_TFLOPS, "valu_frac": None, "hbm_frac": None, "traffic": None, "traffic_source": None,
+                    "flop_frac_note": f"n^3/3 flops of the {nr} x {nr} factorisation / its measured time, against the fp64 vector peak "
+                                      "(a flop rate, not the PMC issue fraction the other configs report as valu_frac)",
+                    "valu_frac_note": None,
                     "avg_launch_us": nk["factor"] * 1e6, "algorithmic_bytes_per_launch": None,
                     "newton_step_us": {"smoothed_evaluation_with_hessian": nk["smooth_hess"] * 1e6, "smoothed_evaluation": nk["smooth"] * 1e6,
                                        "factorisation": nk["factor"] * 1e6, "back_substitution": nk["backsolve"] * 1e6},
@@ -444,6 +487,8 @@ def main():
                     o.eval(net["prices"]); ce += 1
                 cdt = time.perf_counter() - t0
                 out["cpu_baseline"] = {"value": ce * prob.m / cdt, "unit": "pool-subproblems/s", "cores": cores, "kind": "port",
+                                       "measures": "dual EVALUATIONS only -- not solves to 1e-6 (the only CPU solve of this instance is the "
+                                                   "half-hour NumPy barrier-Newton run behind tests/golden/c5_liquidation.json)",
                                        "sample": f"{ce} exact dual evaluations of the same {prob.m}-pool network by oracle/cfmm_oracle.c (OpenMP, {cores} "
                                                  f"threads), {cdt:.1f} s: the oracle has no second-order method, and its first-order iteration needs "
                                                  "thousands of evaluations on this instance (DESIGN.md); cvxpy is not installed in this image",

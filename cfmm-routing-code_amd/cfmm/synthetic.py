@@ -134,17 +134,21 @@ def curve_alpha_from_A(Ra, Rb, A, iters=64):
     return D ** 3 / (16 * A)
 
 
-def config(name, seed=0, scale=1.0, pool_seed=None):
-    """BASELINE.json configs 2-5 (config 1 is the shipped script)."""
+def config(name, seed=0, scale=1.0, pool_seed=None, zipf_s=None):
+    """BASELINE.json configs 2-5 (config 1 is the shipped script).  zipf_s: SURVEY 8(d)'s hub-weighted stress variant of the
+    token choice (Zipf(s) instead of uniform); "C4x4": the HBM-STREAMING variant 8(d)'s cache caveat asks for -- 4e7
+    constant-product pools = 1.28 GB per evaluation, five times the 256 MiB Infinity Cache."""
     s = lambda m: max(1, int(round(m * scale)))
     import functools
-    make_network = functools.partial(globals()["make_network"], pool_seed=pool_seed)
+    make_network = functools.partial(globals()["make_network"], pool_seed=pool_seed, zipf_s=zipf_s)
     if name == "C2":      # 1e4 constant-product pools, 100 tokens
         return make_network(100, m_cp2=s(10_000), seed=seed)
     if name == "C3":      # 1e6 mixed Uniswap-v2 + Balancer pools, 1000 tokens
         return make_network(1000, m_cp2=s(700_000), m_w2=s(200_000), m_gn=s(100_000), seed=seed)
     if name == "C4":      # 1e7 constant-product pools, 2000 tokens (sharded over 8 GPUs)
         return make_network(2000, m_cp2=s(10_000_000), seed=seed)
+    if name == "C4x4":    # 4e7 constant-product pools, 2000 tokens: 1.28 GB of pool columns per evaluation -- must stream from HBM
+        return make_network(2000, m_cp2=s(40_000_000), seed=seed)
     if name == "C4shard":  # one GPU's share of C4
         return make_network(2000, m_cp2=s(1_250_000), seed=seed)
     if name == "G4":      # the generic bucket: power-sum pools among constant-product and weighted ones (tests; not a BASELINE config)

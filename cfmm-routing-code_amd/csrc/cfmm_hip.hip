@@ -751,9 +751,14 @@ void launch_all_evals(cfmm_ctx *ctx)
     if (heavy_pools(ctx) > 0) launch_eval<WITH_D, true>(ctx, make_eval_args(ctx, true));
 }
 
+// (a kernel whose tiles do not fit the CU's LDS at this token count is never launched at it -- the fused iteration stops at
+//  2048 tokens, the batched evaluation sizes itself, the second-order path says "unsupported": newton_supported -- so its
+//  limit is simply not raised; asking for more than 160 KB made cfmm_create FAIL above ~3000 tokens, where the plain
+//  evaluation and the generic update still fit: found by the round-4 token-limit test)
 template <class F>
 int set_lds_attr(cfmm_ctx *ctx, F f, size_t bytes)
 {
+    if (bytes > 160 * 1024) return CFMM_OK;
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return CFMM_OK;
 }
@@ -1085,7 +1090,10 @@ int launch_cholesky(cfmm_ctx *ctx, int n, double *x)
 bool newton_supported(cfmm_ctx *ctx, const char **why)
 {
     if (ctx->ng != ctx->n) { *why = "price ties are set"; return false; }
-    if ((size_t)(2 * ctx->n + 32) * sizeof(double) > 160 * 1024) { *why = "too many tokens for the LDS tile"; return false; }
+    // (the Hessian instantiation of smooth_kernel carries the diagonal / pair cache on top of the psi tile: 24 n + 24832 bytes,
+    //  i.e. 5792 tokens -- not the (2 n + 32) doubles of the round-2 kernel, which let 5.8k .. 10.2k tokens through to a launch
+    //  failure)
+    if (smooth_lds_bytes(ctx->n, true) > LDS_MAX) { *why = "too many tokens for the second-order path's LDS tiles (psi, Hessian diagonal and pair cache: 5792 tokens)"; return false; }
     *why = "";
     return true;
 }
@@ -1999,12 +2007,23 @@ int cfmm_set_ties(cfmm_ctx *ctx, int n_groups, const int32_t *grp, const double 
     return recompute_bounds(ctx);
 }
 
+// start prices handed in by the caller (cfmm_set_nu, cfmm_solve(nu0)): positive and finite, or CFMM_E_ARG; records their maximum
+static int check_prices(cfmm_ctx *ctx, const char *who, const double *nu)
+{
+    double mx = 0.0;
+    for (int j = 0; j < ctx->n; ++j) {
+        if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "%s[%d] = %g is not a positive finite price", who, j, nu[j]);
+        mx = std::max(mx, nu[j]);
+    }
+    ctx->nu_max = mx;
+    return CFMM_OK;
+}
+
 int cfmm_set_nu(cfmm_ctx *ctx, const double *nu)
 {
     if (!ctx || !nu) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    for (int j = 0; j < ctx->n; ++j) if (!(nu[j] > 0.0) || !std::isfinite(nu[j])) return fail(ctx, CFMM_E_ARG, "set_nu: nu[%d] = %g is not a positive finite price", j, nu[j]);
-    { double mx = 0.0; for (int j = 0; j < ctx->n; ++j) mx = std::max(mx, nu[j]); ctx->nu_max = mx; }
+    { int rc = check_prices(ctx, "set_nu: nu", nu); if (rc) return rc; }
     // through the context's own pinned vector: the caller's (pageable) buffer may go away after we return, and copying it
     // here spares a stream synchronisation per solve (the previous copy out of hnu0 has completed: every solve ends synchronised)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2169,13 +2188,21 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     if (nu0) {
         // as cfmm_set_nu, minus the copy to the device: the first-order solve's start kernel reads the prices where they are
         // (mapped pinned memory) and writes nu_acc itself; a solve that goes straight to the second-order method sends them first
-        for (int j = 0; j < ctx->n; ++j) if (!(nu0[j] > 0.0) || !std::isfinite(nu0[j])) return fail(ctx, CFMM_E_ARG, "solve: nu0[%d] = %g is not a positive finite price", j, nu0[j]);
-        { double mx = 0.0; for (int j = 0; j < ctx->n; ++j) mx = std::max(mx, nu0[j]); ctx->nu_max = mx; }
+        { int rc = check_prices(ctx, "solve: nu0", nu0); if (rc) return rc; }
         std::memcpy(ctx->hnu0, nu0, ctx->n * sizeof(double));     // (every entry point leaves the stream synchronised: nothing still reads hnu0)
         ctx->nu0_deferred = true;
         ctx->have_nu = true; ctx->hsol_valid = false; ctx->mu_last = 0.0; ctx->slo_active = false;
     }
-    struct Flush { cfmm_ctx *c; ~Flush() { c->nu0_deferred = false; } } flush_guard{ctx};      // (the flag never outlives this call)
+    // (the flag never outlives this call -- and neither are the prices lost: if a path leaves before anything has consumed
+    //  them (an error in front of the start kernel), they are sent now, so that nu_acc holds what have_nu promises)
+    struct Flush {
+        cfmm_ctx *c;
+        ~Flush()
+        {
+            if (c->nu0_deferred) (void)hipMemcpyAsync(c->nu_acc, c->hnu0, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+            c->nu0_deferred = false;
+        }
+    } flush_guard{ctx};
     auto send_nu0 = [&]() -> int {
         if (!ctx->nu0_deferred) return CFMM_OK;
         ctx->nu0_deferred = false;
@@ -2803,6 +2830,7 @@ int cfmm_time_newton_kernels(cfmm_ctx *ctx, double mu, int reps, double *out4)
     if (!ctx || reps < 1 || !out4 || !(mu > 0.0)) return CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     pools_ready(ctx);
+    struct AtExit { cfmm_ctx *c; ~AtExit() { (void)hipStreamSynchronize(c->stream); release_landed(c); } } at_exit{ctx};
     const char *why = "";
     if (!newton_supported(ctx, &why)) return fail(ctx, CFMM_E_UNSUPPORTED, "time_newton_kernels: %s", why);
     const int n = ctx->n, nr = hess_nr(n), ld = hess_ld(n);
@@ -2838,12 +2866,16 @@ int cfmm_time_newton_kernels(cfmm_ctx *ctx, double mu, int reps, double *out4)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec + n, rhs.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, nr, ld, (const double *)ctx->sm_vec,
                        (const int *)ctx->sm_mask, (const double *)(ctx->sm_vec + n));
-    double *keep = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&keep, (size_t)ld * nr * sizeof(double)));
+    struct Scratch {                                   // (freed on every way out)
+        double *keep = nullptr; hipEvent_t ev_end = nullptr;
+        ~Scratch() { if (ev_end) (void)hipEventDestroy(ev_end); if (keep) (void)hipFree(keep); }
+    } sc;
+    HIP_TRY(ctx, hipMalloc((void **)&sc.keep, (size_t)ld * nr * sizeof(double)));
+    double *const keep = sc.keep;
     HIP_TRY(ctx, hipMemcpyAsync(keep, ctx->H, (size_t)ld * nr * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     double fac = 0.0, back = 0.0;
-    hipEvent_t ev_end = nullptr;
-    if (hipEventCreate(&ev_end) != hipSuccess) { (void)hipFree(keep); return fail(ctx, CFMM_E_HIP, "time_newton_kernels: hipEventCreate failed"); }
+    HIP_TRY(ctx, hipEventCreate(&sc.ev_end));
+    const hipEvent_t ev_end = sc.ev_end;
     for (int i = 0; i < reps && rc == CFMM_OK; ++i) {
         if (hipMemcpyAsync(ctx->H, keep, (size_t)ld * nr * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { rc = CFMM_E_HIP; break; }
         (void)hipEventRecord(ctx->ev_t0, ctx->stream);
@@ -2855,8 +2887,9 @@ int cfmm_time_newton_kernels(cfmm_ctx *ctx, double mu, int reps, double *out4)
         (void)hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1); fac += ms * 1e-3;
         (void)hipEventElapsedTime(&ms, ctx->ev_t1, ev_end); back += ms * 1e-3;
     }
-    (void)hipEventDestroy(ev_end);
-    (void)hipFree(keep);
+    // this hook overwrote the Hessian, the pin mask and the warm starts of the smoothed per-direction solves: the next
+    // second-order solve must not continue from them (it starts its barrier path afresh)
+    ctx->mu_last = 0.0; ctx->warm_mu = 0.0; ctx->slo_active = false;
     if (rc) { const std::string prev = ctx->err; return fail(ctx, rc, "time_newton_kernels: the factorisation launches failed (%s; %s)", prev.c_str(), hipGetErrorString(hipGetLastError())); }
     out4[2] = fac / reps; out4[3] = back / reps;
     return CFMM_OK;

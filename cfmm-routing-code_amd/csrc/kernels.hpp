@@ -841,7 +841,16 @@ struct BatchArgs {
 __host__ __device__ inline int batch_nu_stride(int n) { return (n + 3) & ~1; }
 // (rounded up to even: the wave-private exchange strips behind it are double2 -- at an odd offset every ds_read/write_b128 of
 //  the k-asset tiles is a misaligned access and the batched evaluation takes twice as long: 139 against 68 us at C3, B = 8)
-__host__ __device__ inline int batch_lds_doubles(int n, int nb) { return (nb * n + nb * batch_nu_stride(n) + BATCH_MAX * 16 + 2 + N_BUCKETS + 1) & ~1; }
+// (-DCFMM_TEST_MISALIGN_STRIPS=1 re-creates that bug on purpose: the variant tools/kernel_budget.py must flag -- the proof that the
+//  kernel-time guard of tests/test_gpu_perf.py sees what the parity tests cannot)
+#ifndef CFMM_TEST_MISALIGN_STRIPS
+#define CFMM_TEST_MISALIGN_STRIPS 0
+#endif
+__host__ __device__ inline int batch_lds_doubles(int n, int nb)
+{
+    const int d = (nb * n + nb * batch_nu_stride(n) + BATCH_MAX * 16 + 2 + N_BUCKETS + 1) & ~1;
+    return CFMM_TEST_MISALIGN_STRIPS ? d + 1 : d;
+}
 __host__ __device__ inline size_t batch_lds_bytes(int n, int nb) { return (size_t)(batch_lds_doubles(n, nb) + 2 * 64 * (EVAL_THREADS / 64)) * sizeof(double); }
 __host__ __device__ inline int batch_capacity(int n)          // price vectors per launch that fit 160 KB of LDS
 {

@@ -48,7 +48,10 @@ enum {
     CFMM_METHOD_AUTO = 0,       /* second order when the network holds >= CFMM_AUTO_NEWTON_MIN_STABLE stableswap pools
                                    (the near-linear case the first-order iteration crawls on at scale), else first
                                    order; a first-order run that ends without its certificates is handed on         */
-    CFMM_METHOD_LBFGS = 1,      /* projected L-BFGS in log-prices, fully on-device (hipGraph)                       */
+    CFMM_METHOD_LBFGS = 1,      /* projected L-BFGS in log-prices, fully on-device: ONE launch per outer iteration
+                                   (iter_kernel, enqueued eagerly with run-ahead on a pinned progress word; no hipGraph
+                                   on this default path -- graph replay serves the two-launch iteration only: price
+                                   ties, > 2048 tokens, memory > 3)                                                 */
     CFMM_METHOD_NEWTON = 2      /* barrier-smoothed dual Newton: dense n x n Hessian, blocked Cholesky on-device    */
 };
 
@@ -77,7 +80,9 @@ typedef struct {
     double max_step;        /* cap on one step in log-price (2.0)                                  */
     int32_t max_evals;      /* cap on dual evaluations (2000); a hand-over to the second-order method starts a fresh count */
     int32_t memory;         /* L-BFGS pairs kept, 1..8; 0 = auto (8 up to 32 tokens, else 3: no more evaluations than 4..6 on average and the cheapest update)                                        */
-    int32_t iters_per_graph;/* outer iterations captured per hipGraph replay (4)                   */
+    int32_t iters_per_graph;/* two-launch iteration only (price ties, > 2048 tokens, memory > 3): outer iterations
+                               captured per hipGraph replay (4) -- also the chunk length of the pool-sharded RCCL path; the
+                               default one-launch-per-iteration path (run-ahead on a progress word) ignores it */
     int32_t pg_rule;        /* 1: stop on the projected-gradient value <= tol_gap instead (used when
                                constant-sum pools are tied: psi then lacks their fill)           */
     int32_t method;         /* CFMM_METHOD_*  (0 = auto)                                                            */
@@ -222,6 +227,8 @@ int cfmm_time_collective(cfmm_ctx *ctx, int reps, double *fold_sec, double *allr
 /* the kernels of one second-order step (bench.py --config C5), each timed over `reps` launches at the current prices and
  * barrier weight mu: out4 = seconds per {smoothed evaluation with Hessian assembly, smoothed evaluation alone, dense
  * factorisation (all its launches), back substitution} */
+/* NOTE: the hook overwrites the Hessian, the pin mask and the warm starts of the smoothed per-direction solves; a following
+ * cfmm_solve(nu0 = NULL) therefore starts its barrier path afresh instead of continuing the previous one */
 int cfmm_time_newton_kernels(cfmm_ctx *ctx, double mu, int reps, double *out4);
 /* checks the cross-lane primitives of the update kernels (DPP / v_permlane*_swap / ds_swizzle butterflies and the
  * 64-value reduce-scatter) against exact integer sums on this device; 0 = pass */

@@ -239,6 +239,23 @@ def test_second_order_refuses_what_it_cannot_take():
     p.close()
 
 
+def test_second_order_token_limit_is_refused_not_launched():
+    """Between ~5.8k and ~6.1k tokens the evaluation's LDS tiles still fit but the Hessian instantiation of the smoothed kernel
+    (psi tile + diagonal + pair cache) does not: the second-order path must say so (CFMM_E_UNSUPPORTED) instead of failing
+    in its launch, AUTO must stay first order, and the first-order path must still solve."""
+    net = synthetic.make_network(6000, m_cp2=40000, seed=3)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    ctx = p._ensure_ctx()
+    ctx.set_utility(net["c"])
+    with pytest.raises(cfmm.CfmmError, match="5792 tokens"):
+        ctx.solve(net["c"], method="newton")
+    with pytest.raises(cfmm.CfmmError, match="5792 tokens"):
+        ctx.eval_smooth(net["prices"], 1e-3)
+    p.solve(tol=1e-6)
+    assert p.status == "optimal" and p.stats["method"] == _lib.METHODS["lbfgs"]
+    p.close()
+
+
 @pytest.mark.parametrize("mu", [1e-2, 1e-8])
 def test_smoothed_evaluation_with_k_asset_pools(mu):
     """k-asset geo-mean pools ride along unsmoothed: exact solution, exact generalised Hessian"""

@@ -1,0 +1,29 @@
+"""GPU suite (-m gpu): the kernel-time regression guard.  profiles/budget.json holds, per BASELINE configuration, the
+measured time of each dominant kernel / launch group on MI355X + 10 %; this test re-times them with the library's own
+hooks (tools/kernel_budget.py: minimum over rounds of a mean over back-to-back launches -- a busy box can only make a
+round slower, never faster) and fails when one is over.  Round 3's silent 2x slip of eval_batch_kernel (exchange strips
+pushed off their 16-byte boundary by an odd-sized tile table, kernels.hpp: batch_lds_doubles) would have failed here."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("group", ["C3", "C4shard", "C5"])
+def test_dominant_kernels_stay_inside_their_time_budget(group):
+    import kernel_budget as kb
+    if not os.path.exists(kb.BUDGET):
+        pytest.skip("profiles/budget.json has not been written yet (tools/kernel_budget.py --write on an MI355X)")
+    budget = json.load(open(kb.BUDGET))
+    measured = kb.measure(rounds=5, only=[group])
+    assert measured and all(k in budget["allowed_us"] for k in measured), (sorted(measured), sorted(budget["allowed_us"]))
+    over = kb.compare(measured, budget)
+    if over:                                  # one retry: a kernel that is really slower is slower twice
+        again = kb.measure(rounds=5, only=[group])
+        over = [(k, min(v, again[k]), a) for k, v, a in over if again[k] > a]
+    assert not over, "over budget (key, measured us, allowed us): %s" % over

@@ -18,6 +18,7 @@ for p in (ROOT, os.path.join(ROOT, "cfmm-routing-code_amd")):
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C3")
+ap.add_argument("--zipf", type=float, default=None, help="token pairs Zipf(s) hub-weighted (SURVEY 8(d) stress variant)")
 ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--only", type=int, default=None, help="one bucket alone: 0 cp2, 1 w2, 2 sum2, 3 curve2, -k the k-asset bucket")
@@ -28,7 +29,7 @@ import cfmm  # noqa: E402
 from cfmm import synthetic, _lib  # noqa: E402
 import bench  # noqa: E402
 
-net = synthetic.config(args.config, seed=0, scale=args.scale)
+net = synthetic.config(args.config, seed=0, scale=args.scale, zipf_s=args.zipf)
 prob = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
 ctx = prob._ensure_ctx()
 # prices a few percent off the market values: ~88 % of the pools trade, as at the first iterations of a solve

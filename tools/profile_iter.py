@@ -18,13 +18,14 @@ for p in (ROOT, os.path.join(ROOT, "cfmm-routing-code_amd")):
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C3")
+ap.add_argument("--zipf", type=float, default=None, help="token pairs Zipf(s) hub-weighted (SURVEY 8(d) stress variant)")
 ap.add_argument("--solves", type=int, default=10)
 args = ap.parse_args()
 
 import cfmm  # noqa: E402
 from cfmm import synthetic  # noqa: E402
 
-net = synthetic.config(args.config, seed=0)
+net = synthetic.config(args.config, seed=0, zipf_s=args.zipf)
 prob = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
 ev = dev = 0
 for _ in range(args.solves):
