@@ -14,6 +14,7 @@ POOL_CP2, POOL_W2, POOL_SUM2, POOL_CURVE2, POOL_POW2 = 0, 1, 2, 3, 4
 TIME_ALL = 100
 GE, EQ, FREE = 0, 1, 2
 MAX_POOL_SIZE = 8
+POOLK = {"stable": 0, "sum": 1}     # the K-asset table's kinds (include/cfmm.h: CFMM_POOLK_*)
 STATUS = {1: "optimal", 2: "stalled", 3: "max_evals"}
 
 
@@ -54,9 +55,9 @@ def build(force=False):
 _lib = None
 
 SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm_backend", "cfmm_default_opts",
-           "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_set_pool_flags", "cfmm_set_utility",
+           "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_upload_poolsG", "cfmm_set_pool_flags", "cfmm_set_utility",
            "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
-           "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_comm_unique_id", "cfmm_comm_init",
+           "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_get_tradesG", "cfmm_comm_unique_id", "cfmm_comm_init",
            "cfmm_oneshot_export", "cfmm_oneshot_import", "cfmm_oneshot_attach", "cfmm_oneshot_mailbox", "cfmm_oneshot_enable",
            "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_time_newton_kernels", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
 
@@ -79,6 +80,7 @@ def lib():
     L.cfmm_default_opts.restype = None; L.cfmm_default_opts.argtypes = [C.POINTER(Opts)]
     L.cfmm_upload_pools2.argtypes = [vp, C.c_int, C.c_int64, dp, dp, dp, dp, ip, ip]
     L.cfmm_upload_poolsN.argtypes = [vp, C.c_int, C.c_int64, ip, dp, dp, dp]
+    L.cfmm_upload_poolsG.argtypes = [vp, C.c_int, C.c_int, C.c_int64, ip, dp, dp, dp]
     L.cfmm_set_pool_flags.argtypes = [vp, C.c_int, ip]
     L.cfmm_set_utility.argtypes = [vp, dp, dp, ip]
     L.cfmm_set_ties.argtypes = [vp, C.c_int, ip, dp]
@@ -94,6 +96,7 @@ def lib():
     L.cfmm_get_solution.argtypes = [vp, dp, dp]
     L.cfmm_get_trades2.argtypes = [vp, C.c_int, dp, dp]
     L.cfmm_get_tradesN.argtypes = [vp, C.c_int, dp, dp]
+    L.cfmm_get_tradesG.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.cfmm_comm_unique_id.argtypes = [C.c_void_p]
     L.cfmm_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
     L.cfmm_oneshot_export.argtypes = [vp, C.c_void_p]
@@ -177,6 +180,13 @@ class Context:
         idx, R, w, fee = i32(idx), f64(R), f64(w), f64(fee)
         k, m = R.shape
         self._chk(self.L.cfmm_upload_poolsN(self.h, k, m, _i(idx), _d(R), _d(w), _d(fee)))
+
+    def upload_poolsG(self, kind, idx, R, fee, param=None):
+        """a bucket of the K-asset table (POOLK_*: csrc/phik.hpp): idx, R [k][m], fee [m], param [m] or None"""
+        idx, R, fee = i32(idx), f64(R), f64(fee)
+        param = None if param is None else f64(param)
+        k, m = R.shape
+        self._chk(self.L.cfmm_upload_poolsG(self.h, kind, k, m, _i(idx), _d(R), _d(fee), _d(param) if param is not None else None))
 
     def set_pool_flags(self, kind, flags):
         flags = i32(flags)
@@ -297,6 +307,12 @@ class Context:
         d = np.zeros((k, m)); l = np.zeros((k, m))
         if m:
             self._chk(self.L.cfmm_get_tradesN(self.h, k, _d(d), _d(l)))
+        return d, l
+
+    def get_tradesG(self, kind, k, m):
+        d = np.zeros((k, m)); l = np.zeros((k, m))
+        if m:
+            self._chk(self.L.cfmm_get_tradesG(self.h, kind, k, _d(d), _d(l)))
         return d, l
 
     def comm_init(self, n_ranks, rank, uid):

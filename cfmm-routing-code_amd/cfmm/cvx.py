@@ -13,7 +13,7 @@ problem's vocabulary and refuses anything else with `NotImplementedError`:
 
   * `geo_mean(R + gamma*D - L, p=w) >= geo_mean(R[, p=w])`      -> a (weighted) geometric-mean pool   arbitrage.py:65,68-70
   * `sum(R + gamma*D - L) >= sum(R)` with `R + gamma*D - L >= 0` -> a constant-sum pool               arbitrage.py:73-74
-  * `sum(x) - alpha*inv_prod(x) >= sum(R) - alpha*inv_prod(R)`,  x = R + gamma*D - L (two assets)  -> a stableswap pool
+  * `sum(x) - alpha*inv_prod(x) >= sum(R) - alpha*inv_prod(R)`,  x = R + gamma*D - L (2..8 assets)  -> a stableswap pool
   * `sum(power(x, q)) >= sum(power(R, q))`, 0 < q < 1, x as above (two assets)                        -> a power-sum pool
     (neither is in the reference's scripts: they are how its pattern -- "a pool is whatever constraint line is written",
      arbitrage.py:63-74 -- extends to the library's other trading functions, in DCP-valid cvxpy)
@@ -356,13 +356,14 @@ class Problem:
                 pools[D] = dict(D=D, L=L, R=R, fee=g, kind="geomean", w=con.w)
             elif isinstance(con, _FnConstraint):
                 pl = _pool_of(con.expr)
-                if pl is None or con.expr.size != 2:
-                    raise NotImplementedError("cfmm.cvx: a stableswap / power-sum function must be taken of a two-asset R + gamma*Delta - Lambda")
+                # (power sum: two assets; stableswap: 2..8 -- three and more ride in the K-asset table, csrc/phik.hpp)
+                if pl is None or (con.expr.size != 2 and not (con.kind == "curve" and 3 <= con.expr.size <= 8)):
+                    raise NotImplementedError("cfmm.cvx: a stableswap function must be taken of R + gamma*Delta - Lambda over 2..8 tokens, a power-sum function over two")
                 D, L, R, g = pl
                 if con.kind == "curve":
                     lin = con.lin                  # must be sum(x) of the SAME x
                     same = set(lin.coefs) == set(con.expr.coefs) and abs(lin.const[0] - R.sum()) <= 1e-12 * R.sum() and \
-                        all(np.allclose(lin.coefs[v], np.ones(2) @ con.expr.coefs[v]) for v in lin.coefs)
+                        all(np.allclose(lin.coefs[v], np.ones(con.expr.size) @ con.expr.coefs[v]) for v in lin.coefs)
                     if not same:
                         raise NotImplementedError("cfmm.cvx: inv_prod(x) must be subtracted from sum(x) of the same x")
                     want = float(R.sum() - con.param / np.prod(R))
@@ -396,8 +397,8 @@ class Problem:
             rest.remove(hit)
             if D in pools:
                 raise NotImplementedError("cfmm.cvx: two trading functions for one pool")
-            if len(R) != 2:
-                raise NotImplementedError("cfmm.cvx: constant-sum pools are two-asset (as in the reference)")
+            if not 2 <= len(R) <= 8:
+                raise NotImplementedError("cfmm.cvx: constant-sum pools hold 2..8 tokens")
             pools[D] = dict(D=D, L=L, R=R, fee=g, kind="sum", w=None)
         pools = list(pools.values())
         if not pools:

@@ -64,13 +64,16 @@ def pack(n_tokens, local_indices, reserves, fees, kinds=None, weights=None, para
 
     kinds[i]: "geomean" (default) | "sum" | "curve" | "powersum";  weights[i]: geo-mean exponents (None =
     equal, i.e. Uniswap v2 for two assets);  params[i]: alpha of a curve pool, the exponent t of a power-sum pool
-    (x^(1-t) + y^(1-t): the generic bucket's first tenant, include/cfmm.h CFMM_POOL_POW2)."""
+    (x^(1-t) + y^(1-t): the generic bucket's first tenant, include/cfmm.h CFMM_POOL_POW2).
+    "sum" and "curve" pools over 3..8 tokens go to the K-asset table's buckets (net["gk"][(kind, k)]: csrc/phik.hpp,
+    include/cfmm.h CFMM_POOLK_*): `where` then holds (("stable" | "sum", k), position)."""
     m = len(local_indices)
     kinds = ["geomean"] * m if kinds is None else list(kinds)
     weights = [None] * m if weights is None else list(weights)
     params = [None] * m if params is None else list(params)
     rows = dict(cp2=[], w2=[], sum2=[], curve2=[], pow2=[])
     rows_n = {}
+    rows_g = {}
     where = []
     for i in range(m):
         l = np.asarray(local_indices[i], dtype=np.int64)
@@ -102,15 +105,27 @@ def pack(n_tokens, local_indices, reserves, fees, kinds=None, weights=None, para
             else:
                 raise ValueError(f"pool {i}: geo-mean pools hold 2..{MAX_POOL_SIZE} tokens, got {k}")
         elif kind == "sum":
-            if k != 2:
-                raise ValueError(f"pool {i}: constant-sum pools are two-asset (as in the reference)")
-            where.append(("sum2", len(rows["sum2"])))
-            rows["sum2"].append((R[0], R[1], fees[i], 0.0, l[0], l[1]))
+            if k == 2:
+                where.append(("sum2", len(rows["sum2"])))
+                rows["sum2"].append((R[0], R[1], fees[i], 0.0, l[0], l[1]))
+            elif 3 <= k <= MAX_POOL_SIZE:                  # arbitrage.py:73-74 over more than two tokens: the K-asset table
+                b = rows_g.setdefault(("sum", k), [])
+                where.append((("sum", k), len(b)))
+                b.append((l, R, fees[i], 0.0))
+            else:
+                raise ValueError(f"pool {i}: constant-sum pools hold 2..{MAX_POOL_SIZE} tokens, got {k}")
         elif kind == "curve":
-            if k != 2 or params[i] is None:
-                raise ValueError(f"pool {i}: curve pools are two-asset and need params[i] = alpha")
-            where.append(("curve2", len(rows["curve2"])))
-            rows["curve2"].append((R[0], R[1], fees[i], float(params[i]), l[0], l[1]))
+            if params[i] is None or not (float(params[i]) > 0):
+                raise ValueError(f"pool {i}: curve pools need params[i] = alpha > 0")
+            if k == 2:
+                where.append(("curve2", len(rows["curve2"])))
+                rows["curve2"].append((R[0], R[1], fees[i], float(params[i]), l[0], l[1]))
+            elif 3 <= k <= MAX_POOL_SIZE:                  # sum x - alpha / prod x over more than two tokens: the K-asset table
+                b = rows_g.setdefault(("stable", k), [])
+                where.append((("stable", k), len(b)))
+                b.append((l, R, fees[i], float(params[i])))
+            else:
+                raise ValueError(f"pool {i}: curve pools hold 2..{MAX_POOL_SIZE} tokens, got {k}")
         elif kind == "powersum":
             if k != 2 or params[i] is None or not (1e-3 <= float(params[i]) <= 0.999):
                 raise ValueError(f"pool {i}: power-sum pools are two-asset and need params[i] = t in [0.001, 0.999]")
@@ -136,19 +151,27 @@ def pack(n_tokens, local_indices, reserves, fees, kinds=None, weights=None, para
                                 R=np.array([r[1] for r in rr]).T.copy(),
                                 w=np.array([r[2] for r in rr]).T.copy(),
                                 fee=np.array([r[3] for r in rr], dtype=np.float64))
+    if rows_g:
+        net["gk"] = {}
+        for key, rr in rows_g.items():
+            net["gk"][key] = dict(idx=np.array([r[0] for r in rr], dtype=np.int32).T.copy(),
+                                  R=np.array([r[1] for r in rr]).T.copy(),
+                                  fee=np.array([r[2] for r in rr], dtype=np.float64),
+                                  param=np.array([r[3] for r in rr], dtype=np.float64))
     return net, where
 
 
 def network_pool_count(net):
     m = sum(len(net[k]["Ra"]) for k in KIND2 if k in net)
     m += sum(b["R"].shape[1] for b in net.get("gn", {}).values())
+    m += sum(b["R"].shape[1] for b in net.get("gk", {}).values())
     return m
 
 
 def shard_network(net, rank, world):
     """Pool-sharding: contiguous equal-count slices of every bucket; tokens,
     prices and the utility stay replicated."""
-    out = {k: v for k, v in net.items() if k not in KIND2 and k != "gn"}
+    out = {k: v for k, v in net.items() if k not in KIND2 and k not in ("gn", "gk")}
 
     def sl(m):
         lo = (m * rank) // world
@@ -163,6 +186,11 @@ def shard_network(net, rank, world):
         for k, b in net["gn"].items():
             s = sl(b["R"].shape[1])
             out["gn"][k] = dict(idx=b["idx"][:, s], R=b["R"][:, s], w=b["w"][:, s], fee=b["fee"][s])
+    if "gk" in net:
+        out["gk"] = {}
+        for key, b in net["gk"].items():
+            s = sl(b["R"].shape[1])
+            out["gk"][key] = dict(idx=b["idx"][:, s], R=b["R"][:, s], fee=b["fee"][s], param=b["param"][s])
     return out
 
 
@@ -480,6 +508,8 @@ class Problem:
                     self.ctx.upload_pools2(kind, b["Ra"], b["Rb"], b["fee"], b["ia"], b["ib"], param)
             for k, b in self.net.get("gn", {}).items():
                 self.ctx.upload_poolsN(b["idx"], b["R"], b["w"], b["fee"])
+            for (kind, k), b in self.net.get("gk", {}).items():       # the K-asset table's buckets (csrc/phik.hpp)
+                self.ctx.upload_poolsG(_lib.POOLK[kind], b["idx"], b["R"], b["fee"], b["param"] if kind == "stable" else None)
             self._uploaded = True
         return self.ctx
 
@@ -558,7 +588,7 @@ class Problem:
         self._tol = tol
         kw = dict(max_evals=max_evals, memory=memory, iters_per_graph=iters_per_graph)
         total = dict(evals=0, iters=0, wall_seconds=0.0, device_seconds=0.0, rounds=0)
-        can_second = getattr(ctx, "second_order", False)
+        can_second = getattr(ctx, "second_order", False) and not self.net.get("gk")      # (K-asset table pools: first-order path only)
         if method not in _lib.METHODS:
             raise ValueError(f"method {method!r}: expected one of {sorted(_lib.METHODS)}")
         # auto: many stableswap pools -> second order straight away (first order needs thousands of evaluations there);
@@ -801,6 +831,8 @@ class Problem:
                     tr[key] = ctx.get_trades2(kind, len(self.net[key]["Ra"]))
             for k, b in self.net.get("gn", {}).items():
                 tr[k] = ctx.get_tradesN(k, b["R"].shape[1])
+            for (kind, k), b in self.net.get("gk", {}).items():
+                tr[(kind, k)] = ctx.get_tradesG(_lib.POOLK[kind], k, b["R"].shape[1])
             if self._theta and "sum2" in tr:
                 d, l = tr["sum2"]
                 rank = self._host.rank if self._host else 0

@@ -31,7 +31,7 @@ def _pairs(rng, n, m, zipf_s=None):
 
 
 def make_network(n_tokens, m_cp2=0, m_w2=0, m_gn=0, m_curve2=0, seed=0, zipf_s=None,
-                 gn_sizes=(3, 8), mispricing=0.02, pool_seed=None, m_pow2=0):
+                 gn_sizes=(3, 8), mispricing=0.02, pool_seed=None, m_pow2=0, m_gk_stable=0, m_gk_sum=0, gk_sizes=(3, 4)):
     """Returns a dict of SoA buckets:
 
       prices   : latent pi[n]
@@ -41,11 +41,14 @@ def make_network(n_tokens, m_cp2=0, m_w2=0, m_gn=0, m_curve2=0, seed=0, zipf_s=N
       gn       : dict(size -> dict(R[k,m], w[k,m], idx[k,m], fee[m]))  n-asset weighted geo-mean,
                  one slot-major ("size-class SoA") bucket per pool size  (arbitrage.py:65)
       curve2   : dict(Ra, Rb, fee, alpha, ia, ib)        phi = x + y - alpha/(xy)
+      gk       : dict(("stable" | "sum", k) -> dict(idx[k,m], R[k,m], fee[m], param[m]))  the K-asset table's buckets
+                 (csrc/phik.hpp): n-asset stableswap sum x - alpha / prod x among the tokens of one peg group, n-asset constant
+                 sum over arbitrary tokens (distinct market prices: its LP vertex is then not degenerate)
     """
     rng = np.random.default_rng(seed)
     n = n_tokens
     pi = np.exp(rng.normal(0.0, 1.0, n))
-    if m_curve2:   # peg groups of 4 tokens
+    if m_curve2 or m_gk_stable:   # peg groups of 4 tokens
         pi = pi[(np.arange(n) // 4) * 4] * np.exp(rng.normal(0.0, 0.002, n))
     c = pi * np.exp(rng.normal(0.0, 0.01, n))
     out = dict(n_tokens=n, prices=pi, c=c, seed=seed)
@@ -118,6 +121,42 @@ def make_network(n_tokens, m_cp2=0, m_w2=0, m_gn=0, m_curve2=0, seed=0, zipf_s=N
         A = np.array([10.0, 50.0, 100.0, 200.0])[rng.integers(0, 4, m_curve2)]
         out["curve2"] = dict(Ra=Ra, Rb=Rb, fee=FEES[rng.integers(0, len(FEES), m_curve2)],
                              alpha=curve_alpha_from_A(Ra, Rb, A), ia=ia, ib=ib)
+    if m_gk_stable or m_gk_sum:
+        gk = {}
+        lo, hi = gk_sizes
+        for kind, m_all in (("stable", m_gk_stable), ("sum", m_gk_sum)):
+            if not m_all:
+                continue
+            sizes = rng.integers(lo, hi + 1, m_all)
+            for k in range(lo, hi + 1):
+                mk = int(np.sum(sizes == k))
+                if mk == 0:
+                    continue
+                if kind == "stable":           # k of the 4 tokens of one peg group (k <= 4), in random order
+                    if k > 4:
+                        raise ValueError("synthetic stableswap table pools: 3 or 4 tokens of one peg group")
+                    grp = rng.integers(0, max(1, n // 4), mk) * 4
+                    perm = np.argsort(rng.random((mk, 4)), axis=1)[:, :k]
+                    idx = np.minimum(grp[:, None] + perm, n - 1)
+                else:                          # k distinct tokens anywhere
+                    idx = rng.integers(0, n, size=(mk, k))
+                while True:
+                    srt = np.sort(idx, axis=1)
+                    bad = np.any(srt[:, 1:] == srt[:, :-1], axis=1)
+                    if not bad.any():
+                        break
+                    idx[bad] = rng.integers(0, n, size=(int(bad.sum()), k))
+                idx = np.ascontiguousarray(idx.T).astype(np.int32)
+                L = value(mk)
+                R = L[None, :] / pi[idx] * np.exp(rng.normal(0.0, mispricing, (k, mk)))
+                fee = FEES[rng.integers(0, len(FEES), mk)]
+                if kind == "stable":
+                    A = np.array([10.0, 50.0, 100.0, 200.0])[rng.integers(0, 4, mk)]
+                    param = np.prod(R, axis=0) * R.mean(axis=0) / (2.0 * A)
+                else:
+                    param = np.zeros(mk)
+                gk[(kind, k)] = dict(idx=idx, R=R, fee=fee, param=param)
+        out["gk"] = gk
     return out
 
 
@@ -151,6 +190,8 @@ def config(name, seed=0, scale=1.0, pool_seed=None, zipf_s=None):
         return make_network(2000, m_cp2=s(40_000_000), seed=seed)
     if name == "C4shard":  # one GPU's share of C4
         return make_network(2000, m_cp2=s(1_250_000), seed=seed)
+    if name == "GK":      # the K-asset table: n-asset stableswap and constant-sum pools among constant-product ones (tests)
+        return make_network(200, m_cp2=s(20_000), m_gn=s(2_000), m_gk_stable=s(4_000), m_gk_sum=s(1_000), seed=seed)
     if name == "G4":      # the generic bucket: power-sum pools among constant-product and weighted ones (tests; not a BASELINE config)
         return make_network(200, m_cp2=s(20_000), m_w2=s(5_000), m_gn=s(3_000), m_pow2=s(20_000), seed=seed)
     if name == "C5":      # 5e5 Curve pools + basket liquidation

@@ -33,6 +33,7 @@
 #include "oneshot.hpp"
 #include "smooth.hpp"
 #include "chol.hpp"
+#include "phik.hpp"
 
 using namespace cfmm;
 
@@ -83,6 +84,8 @@ struct PoolStore {
     void *b2mem[CFMM_POOL_KINDS2] = {};           // one arena (one hipMalloc) per bucket: every column lives in it
     BucketN bn[CFMM_MAX_POOL_SIZE + 1] = {};
     void *bnmem[CFMM_MAX_POOL_SIZE + 1] = {};
+    BucketG bg[CFMM_POOLK_KINDS][CFMM_MAX_POOL_SIZE + 1] = {};      // the K-asset table's buckets (phik.hpp): [kind][k]
+    void *bgmem[CFMM_POOLK_KINDS][CFMM_MAX_POOL_SIZE + 1] = {};
     double mxr2[CFMM_POOL_KINDS2] = {}, mnf2[CFMM_POOL_KINDS2] = {1.0, 1.0, 1.0, 1.0};       // largest reserve / smallest fee per bucket
     double mxrn[CFMM_MAX_POOL_SIZE + 1] = {}, mnfn[CFMM_MAX_POOL_SIZE + 1] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
     // token-block ordering still to be done (reorder.hpp): the arena's column bytes, 0 = nothing pending.  Done lazily, in
@@ -98,6 +101,7 @@ struct PoolStore {
         for (auto &q : landed) (void)hipFree(q.first);
         for (void *q : b2mem) if (q) (void)hipFree(q);
         for (void *q : bnmem) if (q) (void)hipFree(q);
+        for (auto &row : bgmem) for (void *q : row) if (q) (void)hipFree(q);
     }
 };
 
@@ -456,6 +460,7 @@ Col transposed_col(const T *src, int k, int64_t m, void **dst, UploadScan *scan,
         const size_t e = off / sizeof(T), cnt = len / sizeof(T);
         bool ok = true; T mx = T(0);
         switch (k) {
+        case 2: transpose_fill<T, 2>(o, src, m, e, cnt, pred, ok, mx); break;
         case 3: transpose_fill<T, 3>(o, src, m, e, cnt, pred, ok, mx); break;
         case 4: transpose_fill<T, 4>(o, src, m, e, cnt, pred, ok, mx); break;
         case 5: transpose_fill<T, 5>(o, src, m, e, cnt, pred, ok, mx); break;
@@ -743,12 +748,45 @@ int64_t heavy_pools(const cfmm_ctx *ctx)
     return m;
 }
 
+// pools of the K-asset trading-function table (phik.hpp): one small launch per (kind, size) bucket behind the main evaluation
+int64_t table_pools(const cfmm_ctx *ctx)
+{
+    int64_t m = 0;
+    for (auto &row : ctx->pools->bg) for (auto &b : row) m += b.m;
+    return m;
+}
+// both read the prices (and the stop flag) the evaluation / iteration launch in front of them has left in `nu`
+int64_t extra_launch_pools(const cfmm_ctx *ctx) { return heavy_pools(ctx) + table_pools(ctx); }
+
+template <int KIND, bool WITH_D>
+void launch_table_kind(cfmm_ctx *ctx, int k, const BucketG &b, const double *nu, double *acc)
+{
+    const int n = ctx->n;
+    const dim3 grid((unsigned)((b.m + GK_THREADS - 1) / GK_THREADS)), blk(GK_THREADS);
+    switch (k) {
+#define GK_CASE(KK) case KK: hipLaunchKernelGGL((evalg_kernel<KIND, KK, WITH_D>), grid, blk, 0, ctx->stream, b, n, nu, acc, acc_arb(n), acc_diag(n)); break;
+    GK_CASE(2) GK_CASE(3) GK_CASE(4) GK_CASE(5) GK_CASE(6) GK_CASE(7) default: GK_CASE(8)
+#undef GK_CASE
+    }
+}
+// psi, sum arb (and the metric) of every table bucket, added into accumulator slice 0 at `acc`
+template <bool WITH_D>
+void launch_table_evals(cfmm_ctx *ctx, const double *nu, double *acc)
+{
+    for (int k = 2; k <= CFMM_MAX_POOL_SIZE; ++k) {
+        if (ctx->pools->bg[CFMM_POOLK_STABLE][k].m) launch_table_kind<CFMM_POOLK_STABLE, WITH_D>(ctx, k, ctx->pools->bg[CFMM_POOLK_STABLE][k], nu, acc);
+        if (ctx->pools->bg[CFMM_POOLK_SUM][k].m) launch_table_kind<CFMM_POOLK_SUM, WITH_D>(ctx, k, ctx->pools->bg[CFMM_POOLK_SUM][k], nu, acc);
+    }
+}
+
 // one dual evaluation of every bucket: one launch, plus one for the heavy buckets (stableswap, generic) when there are any
+// and one per K-asset table bucket
 template <bool WITH_D>
 void launch_all_evals(cfmm_ctx *ctx)
 {
     launch_eval<WITH_D, false>(ctx, make_eval_args(ctx, false));
     if (heavy_pools(ctx) > 0) launch_eval<WITH_D, true>(ctx, make_eval_args(ctx, true));
+    if (table_pools(ctx) > 0) launch_table_evals<WITH_D>(ctx, ctx->nu, ctx->acc);
 }
 
 // (a kernel whose tiles do not fit the CU's LDS at this token count is never launched at it -- the fused iteration stops at
@@ -848,7 +886,7 @@ UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
 // ---- tiny networks (the reference's own instances): the whole solve in one launch of one workgroup (tiny.hpp) -----
 bool tiny_applies(cfmm_ctx *ctx, const EvalArgs &ea, const cfmm_opts &o)
 {
-    return ctx->tiny_path && !sharded(ctx) && !ctx->det && heavy_pools(ctx) == 0 && ea.ntiles >= 1 &&
+    return ctx->tiny_path && !sharded(ctx) && !ctx->det && extra_launch_pools(ctx) == 0 && ea.ntiles >= 1 &&
            ea.ntiles <= TINY_MAX_TILES && ctx->n <= TINY_N && o.memory <= MAX_MEMORY;
 }
 
@@ -884,7 +922,7 @@ IterArgs make_iter_args(cfmm_ctx *ctx, const cfmm_opts &o)
 // collectives can be skipped on the device, so the host may run ahead of it as on a single GPU
 bool oneshot_runahead(cfmm_ctx *ctx)
 {
-    return ctx->os_ready && !ctx->det && (size_t)acc_stride(ctx->n) <= ctx->os_cap && heavy_pools(ctx) == 0;
+    return ctx->os_ready && !ctx->det && (size_t)acc_stride(ctx->n) <= ctx->os_cap && extra_launch_pools(ctx) == 0;
 }
 
 // outer iteration t >= 1 as ONE launch (+ the stableswap bucket's own evaluation launch, + fold / all-reduce when
@@ -926,6 +964,7 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
         es.nu = ctx->nu; es.acc = acc_p;
         launch_eval<false, true>(ctx, es);
     }
+    if (table_pools(ctx) > 0) launch_table_evals<false>(ctx, ctx->nu, acc_p);
     if (ctx->det) return det_finish(ctx, acc_p, ctx->nu, false);     // (the prices workgroup 0 has just stored)
     if (sharded(ctx)) {
         // a launch enqueued behind the end of the solve has evaluated nothing: with the one-shot exchange its fold and
@@ -1090,6 +1129,7 @@ int launch_cholesky(cfmm_ctx *ctx, int n, double *x)
 bool newton_supported(cfmm_ctx *ctx, const char **why)
 {
     if (ctx->ng != ctx->n) { *why = "price ties are set"; return false; }
+    if (table_pools(ctx) > 0) { *why = "the network holds K-asset table pools (phik.hpp): first-order path only"; return false; }
     // (the Hessian instantiation of smooth_kernel carries the diagonal / pair cache on top of the psi tile: 24 n + 24832 bytes,
     //  i.e. 5792 tokens -- not the (2 n + 32) doubles of the round-2 kernel, which let 5.8k .. 10.2k tokens through to a launch
     //  failure)
@@ -1689,6 +1729,7 @@ int64_t cfmm_pool_count(cfmm_ctx *ctx)
     int64_t m = 0;
     for (auto &b : ctx->pools->b2) m += b.m;
     for (auto &b : ctx->pools->bn) m += b.m;
+    for (auto &row : ctx->pools->bg) for (auto &b : row) m += b.m;
     return m;
 }
 
@@ -1939,6 +1980,77 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
     ctx->pools->ron[k] = ro_total;
     ctx->pools->mxrn[k] = mxr; ctx->pools->mnfn[k] = mnf;
     pools_changed(ctx);
+    return CFMM_OK;
+}
+
+// the K-asset table's buckets (phik.hpp): columns idx, R slot-major [k][m] as cfmm_upload_poolsN takes them, fee[m], param[m]
+int cfmm_upload_poolsG(cfmm_ctx *ctx, int kind, int k, int64_t m, const int32_t *idx, const double *R, const double *fee, const double *param)
+{
+    if (!ctx) return CFMM_E_ARG;
+    if (kind < 0 || kind >= CFMM_POOLK_KINDS || k < 2 || k > CFMM_MAX_POOL_SIZE || m < 0) return fail(ctx, CFMM_E_ARG, "upload_poolsG: kind %d, %d assets, %lld pools", kind, k, (long long)m);
+    if (m > 0 && (!idx || !R || !fee)) return fail(ctx, CFMM_E_ARG, "upload_poolsG: null column");
+    if (m > 0 && kind == CFMM_POOLK_STABLE && !param) return fail(ctx, CFMM_E_ARG, "upload_poolsG: stableswap pools need param = alpha");
+    if (m > (1ll << 26)) return fail(ctx, CFMM_E_LIMIT, "upload_poolsG: a bucket holds < 2^26 pools");
+    if (ctx->det) return fail(ctx, CFMM_E_UNSUPPORTED, "upload_poolsG: K-asset table pools are not available in the reproducible mode");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->pools->bgmem[kind][k]) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BucketG b = {};
+    b.m = m;
+    void *arena = nullptr;
+    UploadScan scan;
+    if (m > 0) {
+        const int ntok = ctx->n;
+        std::vector<Col> cols;
+        cols.push_back(transposed_col<int32_t>(idx, k, m, (void **)&b.idx, &scan, false, [ntok](int32_t v) { return (uint32_t)v < (uint32_t)ntok; }));
+        cols.push_back(transposed_col<double>(R, k, m, (void **)&b.R, &scan, true, [](double x) { return x > 0.0 && x <= std::numeric_limits<double>::max(); }));
+        cols.push_back(checked_col<double>(fee, m, (void **)&b.fee, &scan, 1, [](double x) { return x > 0.0 && x <= 1.0; }));
+        if (param) cols.push_back(checked_col<double>(param, m, (void **)&b.param, &scan, 2, [](double x) { return x > 0.0 && x <= std::numeric_limits<double>::max(); }));
+        int rc = upload_arena(ctx, cols, &arena, &scan);
+        if (rc == CFMM_E_ARG && scan.bad.load()) {
+            for (int64_t i = 0; i < (int64_t)k * m; ++i) {
+                if (idx[i] < 0 || idx[i] >= ctx->n) return fail(ctx, CFMM_E_ARG, "upload_poolsG: token id %d outside [0,%d)", idx[i], ctx->n);
+                if (!(R[i] > 0.0) || !std::isfinite(R[i])) return fail(ctx, CFMM_E_ARG, "upload_poolsG: leg %lld has reserve %g (need R > 0)", (long long)i, R[i]);
+            }
+            for (int64_t i = 0; i < m; ++i) {
+                if (!(fee[i] > 0.0 && fee[i] <= 1.0)) return fail(ctx, CFMM_E_ARG, "upload_poolsG: pool %lld has fee %g outside (0, 1]", (long long)i, fee[i]);
+                if (param && (!(param[i] > 0.0) || !std::isfinite(param[i]))) return fail(ctx, CFMM_E_ARG, "upload_poolsG: pool %lld has parameter %g (need > 0)", (long long)i, param[i]);
+            }
+            return fail(ctx, CFMM_E_ARG, "upload_poolsG: a column failed its checks");
+        }
+        if (rc) return rc;
+    }
+    if (ctx->pools->bgmem[kind][k]) (void)hipFree(ctx->pools->bgmem[kind][k]);
+    ctx->pools->bgmem[kind][k] = arena;
+    ctx->pools->bg[kind][k] = b;
+    pools_changed(ctx);
+    return CFMM_OK;
+}
+
+int cfmm_get_tradesG(cfmm_ctx *ctx, int kind, int k, double *delta, double *lambda)
+{
+    if (!ctx || kind < 0 || kind >= CFMM_POOLK_KINDS || k < 2 || k > CFMM_MAX_POOL_SIZE) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const BucketG &b = ctx->pools->bg[kind][k];
+    if (b.m == 0) return CFMM_OK;
+    const size_t cnt = (size_t)k * b.m;
+    double *dd = nullptr, *dl = nullptr;
+    { int rc = trade_scratch(ctx, cnt, &dd, &dl); if (rc) return rc; }
+    const dim3 grid((unsigned)((b.m + GK_THREADS - 1) / GK_THREADS)), blk(GK_THREADS);
+    const double *nu = ctx->nu_acc;
+#define GK_T(KIND_) switch (k) { case 2: hipLaunchKernelGGL((tradesg_kernel<KIND_, 2>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; \
+                                 case 3: hipLaunchKernelGGL((tradesg_kernel<KIND_, 3>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; \
+                                 case 4: hipLaunchKernelGGL((tradesg_kernel<KIND_, 4>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; \
+                                 case 5: hipLaunchKernelGGL((tradesg_kernel<KIND_, 5>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; \
+                                 case 6: hipLaunchKernelGGL((tradesg_kernel<KIND_, 6>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; \
+                                 case 7: hipLaunchKernelGGL((tradesg_kernel<KIND_, 7>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; \
+                                 default: hipLaunchKernelGGL((tradesg_kernel<KIND_, 8>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; }
+    if (kind == CFMM_POOLK_STABLE) { GK_T(CFMM_POOLK_STABLE) } else { GK_T(CFMM_POOLK_SUM) }
+#undef GK_T
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "get_tradesG -> %s", hipGetErrorString(e));
+    if (delta) { int rc = download_staged(ctx, delta, dd, cnt * sizeof(double)); if (rc) return rc; }
+    if (lambda) { int rc = download_staged(ctx, lambda, dl, cnt * sizeof(double)); if (rc) return rc; }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CFMM_OK;
 }
 
@@ -2300,6 +2412,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
             e0.nu = ua.nu; e0.acc = ctx->acc3;
             if (stable) launch_eval<true, true>(ctx, e0); else launch_eval<true, false>(ctx, e0);
         }
+        if (table_pools(ctx) > 0) launch_table_evals<true>(ctx, ua.nu, ctx->acc3);
         if (ctx->det) { int rc = det_finish(ctx, ctx->acc3, ua.nu, true); if (rc) return rc; }
         else if (shard) {
             const int len = acc_stride(n);
@@ -2452,7 +2565,7 @@ int cfmm_solve_batch(cfmm_ctx *const *ctxs, int nb, const double *const *nu0, co
         HIP_TRY(c0, hipStreamSynchronize(c->stream));
     }
     if (cfmm_pool_count(c0) == 0) return fail(c0, CFMM_E_STATE, "solve_batch: no pools uploaded");
-    if (heavy_pools(c0) > 0) return fail(c0, CFMM_E_UNSUPPORTED, "solve_batch: stableswap / generic-bucket pools are evaluated by their own launch: one solve at a time");
+    if (extra_launch_pools(c0) > 0) return fail(c0, CFMM_E_UNSUPPORTED, "solve_batch: stableswap / generic-bucket / K-asset table pools are evaluated by their own launch: one solve at a time");
     if (!c0->upd_batch_d) {
         HIP_TRY(c0, hipMalloc((void **)&c0->upd_batch_d, BATCH_MAX * sizeof(UpdArgs)));
         HIP_TRY(c0, hipHostMalloc((void **)&c0->upd_batch_h, BATCH_MAX * sizeof(UpdArgs), hipHostMallocDefault));
@@ -2663,6 +2776,7 @@ int cfmm_set_deterministic(cfmm_ctx *ctx, int on)
     if (!ctx) return CFMM_E_ARG;
     if (on && eval_lds_bytes(ctx->n, true, true) > 160 * 1024)
         return fail(ctx, CFMM_E_LIMIT, "set_deterministic: %d tokens exceed the LDS tile of the reproducible mode (7 n doubles)", ctx->n);
+    if (on && table_pools(ctx) > 0) return fail(ctx, CFMM_E_UNSUPPORTED, "set_deterministic: K-asset table pools accumulate psi with fp64 atomics");
     if ((on != 0) != ctx->det) { ctx->g_valid = false; ctx->g_counts_valid = false; }
     ctx->det = on != 0;
     return CFMM_OK;

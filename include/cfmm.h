@@ -70,6 +70,18 @@ enum {
 };
 #define CFMM_MAX_POOL_SIZE 8    /* n-asset geo-mean pools: 3..8 assets, one bucket per size */
 
+/* K-asset trading functions OTHER than the weighted geometric mean: the K-asset table (csrc/phik.hpp: one PhiK<KIND> struct per
+ * function -- SURVEY 8(f) rank 4; "a pool is whatever constraint line is written", arbitrage.py:63-74), 3..8 assets, one
+ * bucket per (kind, size).  First-order path only: a network that holds such pools is refused by CFMM_METHOD_NEWTON. */
+enum {
+    CFMM_POOLK_STABLE = 0,  /* n-asset stableswap  sum x - alpha / prod x  (the paper's concave form; 2 assets: CFMM_POOL_CURVE2);
+                               param = alpha.  Solved by the table's generic two-level search (no closed form)              */
+    CFMM_POOLK_SUM = 1,     /* n-asset constant sum  sum x, x >= 0  (arbitrage.py:73-74 with more than two tokens); param = NULL.
+                               Exact LP vertex on the device; an optimum that ends ON one of its kinks is not recovered (the
+                               host's active-set loop knows two-asset pools): such a solve ends without its certificates */
+    CFMM_POOLK_KINDS = 2
+};
+
 /* token constraint types of the unified utility  max c'psi :  psi_k + h_k (>=, =, free) 0 */
 enum { CFMM_GE = 0, CFMM_EQ = 1, CFMM_FREE = 2 };
 
@@ -129,6 +141,13 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
  * weights normalised to sum 1 per pool */
 int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, const double *R,
                        const double *w, const double *fee);
+/* pools of the K-asset table (CFMM_POOLK_*), k = 3..8 assets (2 is accepted too: the cross-check of the table's generic search
+ * against the two-asset buckets' closed forms, tests/test_gpu_table.py): idx, R slot-major [k][m] like cfmm_upload_poolsN, fee[m],
+ * param[m] (alpha for CFMM_POOLK_STABLE, NULL for CFMM_POOLK_SUM).  Replaces a constraint line such as
+ * `cp.sum(new_reserves) - alpha * cp.inv_prod(new_reserves) >= ...` / `cp.sum(new_reserves) >= cp.sum(reserves)` over k > 2
+ * tokens (arbitrage.py:63-74 in the reference's style; the reference itself ships the two-token forms) */
+int cfmm_upload_poolsG(cfmm_ctx *ctx, int kind, int k, int64_t m, const int32_t *idx, const double *R,
+                       const double *fee, const double *param);
 /* constant-sum pools sitting on their kink are `tied` (flag 1): they are skipped by the
  * kernels and their fill fraction is assigned by the host's primal recovery */
 int cfmm_set_pool_flags(cfmm_ctx *ctx, int kind, const int32_t *flags /* [m] or NULL */);
@@ -192,6 +211,7 @@ int cfmm_get_solution(cfmm_ctx *ctx, double *nu, double *psi);     /* both with 
 /* tenders at the accepted prices; slot-major [2][m] / [k][m]; either pointer may be NULL */
 int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda);
 int cfmm_get_tradesN(cfmm_ctx *ctx, int k, double *delta, double *lambda);
+int cfmm_get_tradesG(cfmm_ctx *ctx, int kind, int k, double *delta, double *lambda);      /* K-asset table buckets, [k][m] */
 
 /* pool-sharding over the GPUs of a node: one process per GPU, one RCCL all-reduce of
  * [psi | sum arb] per dual evaluation.  `uid` is the 128-byte ncclUniqueId made by rank 0. */

@@ -198,3 +198,78 @@ def arb_power2(Ra, Rb, gamma, t, pa, pb):
     ya = np.where(tab, ya1, np.where(tba, ya2, 0.0))
     yb = np.where(tab, yb1, np.where(tba, yb2, 0.0))
     return ya, yb, pa * ya + pb * yb
+
+
+# --------------------------------------------------------------------------------------
+# n-asset stableswap  phi(x) = sum x - alpha / prod x                  (not in reference; the K-asset table's first
+# smooth tenant: csrc/phik.hpp PhiK<0>; K = 2 is arb_curve2's function)
+# --------------------------------------------------------------------------------------
+def arb_stable_n(R, alpha, gamma, p, outer=80, inner=64):
+    """Vectorised over pools: R, p are [k, m], alpha, gamma [m].  KKT with multiplier mu and coupling s = alpha / prod x:
+    phi_j = 1 + s / x_j, so x_j = clip(R_j, s / (p_j / (gamma mu) - 1), s / (p_j / mu - 1)); nested bisection on
+    (log mu, log s) -- the restatement of pool_generic_k (same two scalar equations, NumPy arithmetic)."""
+    R = np.asarray(R, float); p = np.asarray(p, float)
+    k, m = R.shape
+    alpha = np.broadcast_to(np.asarray(alpha, float), (m,)); gamma = np.broadcast_to(np.asarray(gamma, float), (m,))
+    lR = np.log(R); la = np.log(alpha)
+    lsR = la - lR.sum(axis=0); sR = np.exp(lsR)
+    lmax = np.log(p.min(axis=0) / gamma)
+
+    def legs(lm, ls):
+        with np.errstate(all="ignore"):
+            qd = p * np.exp(-lm)[None, :] / gamma[None, :]; qw = p * np.exp(-lm)[None, :]
+            gd = np.where(qd > 1.0, np.log(np.maximum(qd - 1.0, 1e-300)), -np.inf)
+            gw = np.where(qw > 1.0, np.log(np.maximum(qw - 1.0, 1e-300)), -np.inf)
+        return np.clip(lR, ls[None, :] - gd, ls[None, :] - gw), np.isinf(gd).any(axis=0)
+
+    def coupling(lm):
+        a = lsR - 90.0; b = lsR + 90.0
+        for _ in range(inner):
+            ls = 0.5 * (a + b)
+            lx, _open = legs(lm, ls)
+            hi = ls - (la - lx.sum(axis=0)) > 0.0
+            b = np.where(hi, ls, b); a = np.where(hi, a, ls)
+        ls = 0.5 * (a + b)
+        lx, op = legs(lm, ls)
+        return ls, lx, op
+
+    def gap(lm):
+        ls, lx, op = coupling(lm)
+        dx = np.where(lx == lR, 0.0, np.exp(np.minimum(lx, 700.0)) - R).sum(axis=0)
+        return np.where(op, 1.0, dx - (np.exp(ls) - sR)), lx
+
+    lo = lmax - 90.0; hi = lmax.copy()
+    for _ in range(outer):
+        lm = 0.5 * (lo + hi)
+        v, _ = gap(lm)
+        neg = v < 0.0
+        lo = np.where(neg, lm, lo); hi = np.where(neg, hi, lm)
+    _, lx = gap(hi)
+    d = np.where(lx == lR, 0.0, R - np.exp(lx))
+    y = np.where(d > 0.0, d, d / gamma[None, :])
+    return y, (p * y).sum(axis=0)
+
+
+def arb_pool_primal(R, gamma, p, phi, dphi, x_floor=1e-9):
+    """ONE pool's arbitrage subproblem as the reference writes it (arbitrage.py:51-52,60,63-74), by SLSQP: independent of
+    every dual-side solver.  phi / dphi: the trading function and its gradient on the new reserves."""
+    from scipy.optimize import minimize
+    R = np.asarray(R, float); p = np.asarray(p, float)
+    k = len(R)
+    scale = float(p @ R)
+
+    def newres(z):
+        return R + gamma * z[:k] - z[k:]
+    cons = [dict(type="ineq", fun=lambda z: (phi(np.maximum(newres(z), x_floor * R)) - phi(R)) / R.sum(),
+                 jac=lambda z: np.concatenate([gamma * dphi(np.maximum(newres(z), x_floor * R)), -dphi(np.maximum(newres(z), x_floor * R))]) / R.sum()),
+            dict(type="ineq", fun=lambda z: (newres(z) - x_floor * R) / R, jac=lambda z: np.hstack([gamma * np.eye(k), -np.eye(k)]) / R[:, None])]
+    best = None
+    for z0 in (np.zeros(2 * k), np.concatenate([0.1 * R, 0.1 * R])):
+        res = minimize(lambda z: -float(p @ (z[k:] - z[:k])) / scale, z0, jac=lambda z: -np.concatenate([-p, p]) / scale,
+                       bounds=[(0, None)] * (2 * k), constraints=cons, method="SLSQP", options=dict(ftol=1e-16, maxiter=500))
+        if best is None or res.fun < best.fun:
+            best = res
+    z = best.x
+    # (Delta_j and Lambda_j both positive on one leg is never optimal with gamma < 1, but SLSQP may leave a little of it)
+    y = z[k:] - z[:k]
+    return y, float(p @ y)

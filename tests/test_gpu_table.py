@@ -1,0 +1,174 @@
+"""GPU suite (-m gpu): the K-asset trading-function table (csrc/phik.hpp): n-asset stableswap and n-asset
+constant-sum pools through the generic K-asset bucket -- evaluation against the NumPy restatement (oracle/pools_np.py:
+arb_stable_n, arb_sum; themselves pinned against the per-pool SLSQP primal in tests/test_oracle.py), the table's generic
+search against the two-asset stableswap bucket's closed-form iteration at k = 2, tenders and their invariant, and whole solves
+against the SciPy primal with the same phi (k = 3, 4).  Tolerances: evaluation 1e-10 relative (fp64, different root
+searches), objectives 2e-6 relative."""
+import numpy as np
+import pytest
+
+import cfmm
+from cfmm import synthetic, _lib
+from oracle import pools_np, primal_scipy
+from helpers import problem_of, normalise_with_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _table_reference(net, nu):
+    """psi and sum arb of the table buckets alone, by the NumPy restatements"""
+    n = net["n_tokens"]
+    psi = np.zeros(n); f = 0.0
+    for (kind, k), b in net.get("gk", {}).items():
+        p = nu[b["idx"]]
+        if kind == "stable":
+            y, arb = pools_np.arb_stable_n(b["R"], b["param"], b["fee"], p)
+        else:
+            y = np.zeros_like(b["R"]); arb = np.zeros(b["R"].shape[1])
+            for i in range(b["R"].shape[1]):
+                y[:, i], arb[i] = pools_np.arb_sum(b["R"][:, i], b["fee"][i], p[:, i])
+        np.add.at(psi, b["idx"].ravel(), y.ravel())
+        f += float(arb.sum())
+    return f, psi
+
+
+def test_table_pools_evaluation_tenders_and_invariants(oracle_lib):
+    """5 000 table pools (n-asset stableswap k = 3, 4; n-asset constant sum k = 3, 4) among 22 000 pools of the reference's kinds"""
+    net = synthetic.config("GK", seed=3)
+    n = net["n_tokens"]
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    o = oracle_lib.Oracle(n, threads=4); o.add_network(net); o.set_utility(net["c"])        # (the C twin knows the reference's kinds only)
+    nu = net["c"] * np.exp(np.random.default_rng(7).normal(0, 0.01, n))
+    f, psi = p.eval_dual(nu)
+    f0, psi0 = o.eval(nu)
+    f1, psi1 = _table_reference(net, nu)
+    assert np.abs(psi1).max() > 0.05 * np.abs(psi0).max()                  # the table pools carry real weight in psi
+    assert abs(f - (f0 + f1)) <= 1e-10 * abs(f0 + f1)
+    assert np.abs(psi - (psi0 + psi1)).max() <= 1e-10 * np.abs(psi0 + psi1).max()
+    # metric of the first evaluation: finite, positive where table pools sit
+    _, _, diag = p.eval_dual(nu, want_diag=True)
+    assert np.all(np.isfinite(diag)) and np.all(diag >= 0)
+    # tenders pool by pool + the invariant they preserve
+    p.ctx.set_nu(nu)
+    for (kind, k), b in net["gk"].items():
+        d, l = p.bucket_trades((kind, k))
+        assert np.all(d >= 0) and np.all(l >= 0) and np.all(d * l == 0)
+        x = b["R"] + b["fee"][None, :] * d - l
+        if kind == "stable":
+            y, _ = pools_np.arb_stable_n(b["R"], b["param"], b["fee"], nu[b["idx"]])
+            assert np.abs((l - d) - y).max() <= 1e-10 * b["R"].max()
+            phi = lambda z: z.sum(axis=0) - b["param"] / np.prod(z, axis=0)
+            assert np.abs(phi(x) - phi(b["R"])).max() <= 1e-9 * b["R"].sum(axis=0).max()
+            assert (np.abs(l - d).sum(axis=0) > 0).mean() > 0.5
+        else:
+            assert np.all(x >= -1e-9 * b["R"].max()) and np.abs(x.sum(axis=0) - b["R"].sum(axis=0)).max() <= 1e-9 * b["R"].sum(axis=0).max()
+    with pytest.raises(cfmm.CfmmError, match="first-order path only"):
+        p.solve(method="newton")
+    p.close()
+
+
+def test_table_pools_first_order_solve_at_scale(oracle_lib):
+    """1 000 n-asset stableswap pools among 22 000 pools of the reference's kinds: the first-order solve reaches its 1e-6
+    certificates (~540 evaluations: near their peg these pools are almost linear, the regime the second-order path exists
+    for -- which does not take table pools yet), and the evaluation at the prices it ends on is the restatement's.
+    n-asset constant-sum pools in numbers end ON their kinks -- the LP's dual prices settle there -- and such a solve stalls:
+    the host's active-set loop knows two-asset pools only.  1 000 of them: not certified, and reported as such."""
+    net = synthetic.make_network(200, m_cp2=20000, m_gn=2000, m_gk_stable=1000, seed=3)
+    n = net["n_tokens"]
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    o = oracle_lib.Oracle(n, threads=4); o.add_network(net); o.set_utility(net["c"])
+    v = p.solve(tol=1e-6, max_evals=4000)
+    assert p.status == "optimal" and p.stats["method"] == _lib.METHODS["lbfgs"] and p.gap <= 1e-6 and p.infeas <= 1e-6
+    nu = p.nu.copy()
+    f, psi = p.eval_dual(nu)
+    f0, psi0 = o.eval(nu); f1, psi1 = _table_reference(net, nu)
+    assert np.abs(psi - (psi0 + psi1)).max() <= 1e-10 * np.abs(psi0 + psi1).max()
+    assert abs(float(net["c"] @ (psi0 + psi1)) - v) <= 2e-6 * abs(v)
+    p.close()
+    hard = synthetic.make_network(200, m_cp2=20000, m_gk_sum=1000, seed=3)
+    q = cfmm.Problem.from_network(hard, utility=cfmm.Arbitrage(hard["c"]))
+    q.solve(tol=1e-6, max_evals=1500)
+    assert q.status != "optimal"                      # honest: not certified, and it says so
+    q.close()
+
+
+def test_table_search_reproduces_the_two_asset_stableswap_bucket():
+    """k = 2: the SAME pools once as the CFMM_POOL_CURVE2 bucket (pool_curve2: safeguarded Newton in x with the closed-form
+    y(x)) and once as a two-asset bucket of the table (the generic two-level search): same psi to 1e-10"""
+    net = synthetic.make_network(64, m_cp2=500, m_curve2=6000, seed=5)
+    n = net["n_tokens"]
+    b = net["curve2"]
+    nu = net["prices"] * np.exp(np.random.default_rng(3).normal(0, 0.01, n))
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    f, psi = p.eval_dual(nu)
+    net2 = {k: v for k, v in net.items() if k != "curve2"}
+    q = cfmm.Problem.from_network(net2, utility=cfmm.Arbitrage(net["c"]))
+    q._ensure_ctx().upload_poolsG(_lib.POOLK["stable"], np.stack([b["ia"], b["ib"]]), np.stack([b["Ra"], b["Rb"]]), b["fee"], b["alpha"])
+    f2, psi2 = q.eval_dual(nu)
+    assert np.abs(psi).max() > 0
+    assert abs(f - f2) <= 1e-10 * abs(f) and np.abs(psi - psi2).max() <= 1e-10 * np.abs(psi).max()
+    p.close(); q.close()
+
+
+def _small_instance(seed, k_stable, with_sum):
+    """a few constant-product pools + n-asset stableswap pools (+ an n-asset constant-sum pool over tokens of clearly
+    different value: its LP vertex is then not degenerate) in the reference's vocabulary"""
+    rng = np.random.default_rng(seed)
+    n = 7
+    price = np.exp(rng.normal(0, 0.05, n)); price[5] *= 2.0; price[6] *= 0.5
+    L, R, F, K, W, P = [], [], [], [], [], []
+    for _ in range(8):
+        l = rng.choice(n, 2, replace=False); val = np.exp(rng.normal(4, 0.5))
+        L.append(l.tolist()); R.append((val / price[l] * np.exp(rng.normal(0, 0.05, 2))).tolist()); F.append(float(rng.choice([0.997, 0.999])))
+        K.append("geomean"); W.append([1.0, 1.0]); P.append(None)
+    for _ in range(3):
+        l = rng.choice(5, k_stable, replace=False); val = np.exp(rng.normal(4, 0.5))
+        res = val / price[l] * np.exp(rng.normal(0, 0.03, k_stable))
+        L.append(l.tolist()); R.append(res.tolist()); F.append(0.999); K.append("curve"); W.append(None)
+        P.append(float(np.prod(res) * res.mean() / 40.0))
+    if with_sum:
+        l = np.array([5, 6, 0])
+        L.append(l.tolist()); R.append((30.0 / price[l]).tolist()); F.append(0.997); K.append("sum"); W.append(None); P.append(None)
+    c = price * np.exp(rng.normal(0, 0.02, n))
+    return dict(name=f"table{seed}", n_tokens=n, local_indices=L, reserves=R, fees=F, kinds=K, weights=W, params=P,
+                utility=dict(type="arbitrage", c=c.tolist()))
+
+
+@pytest.mark.parametrize("seed,k,with_sum", [(0, 3, False), (1, 4, False), (2, 3, True), (3, 4, True)])
+def test_table_pools_solve_matches_the_scipy_primal(seed, k, with_sum):
+    """the reference's primal model (arbitrage.py:51-78) with `sum(x) - alpha * inv_prod(x)` over k = 3, 4 tokens (and a
+    three-token constant-sum pool), by SLSQP, against the device's dual solve"""
+    inst = _small_instance(seed, k, with_sum)
+    ref = primal_scipy.solve_primal(normalise_with_params(inst))      # (SLSQP at ftol 1e-15 usually ends on "positive directional
+    p = problem_of(inst)                                              #  derivative": at its precision, not declared converged)
+    v = p.solve(tol=1e-8, method="lbfgs")
+    assert p.status == "optimal" and p.gap <= 1e-8 and p.infeas <= 1e-8, (p.status, p.gap, p.infeas)      # self-certifying
+    assert ref["value"] <= v + 2e-6 * max(1.0, abs(v))                # weak duality against SLSQP's feasible point
+    assert abs(v - ref["value"]) <= 2e-6 * max(1.0, abs(v)), (v, ref["value"])
+    assert np.abs(p.psi - ref["psi"]).max() <= 1e-4 * max(1.0, np.abs(ref["psi"]).max())
+    # per-pool tenders in the reference's order (two-asset.py:94,98), table pools included
+    for i, (d, l) in enumerate(zip(p.deltas, p.lambdas)):
+        y_ref = ref["y"][i]
+        assert np.abs((l - d) - y_ref).max() <= 2e-4 * max(1.0, np.abs(y_ref).max()), (i, l - d, y_ref)
+    p.close()
+
+
+@pytest.mark.parametrize("seed,k", [(0, 3), (3, 4)])
+def test_k_asset_constraint_lines_through_the_cvx_shim(seed, k):
+    """`cp.sum(x) - alpha * cp.inv_prod(x) >= ...` over k > 2 tokens and the constant-sum pair of constraints over three --
+    the reference's style (arbitrage.py:63-74) for pools it does not ship -- recognised by cfmm.cvx and routed to the K-asset
+    table's buckets; .value of the variables in pool-local order as the scripts read them (two-asset.py:94,98)"""
+    import cfmm.cvx as cp
+    import cvx_models
+    cp.CONTEXT_FACTORY = None
+    inst = _small_instance(seed, k, with_sum=(seed == 3))
+    prob, goal, net, tender, receive = cvx_models.build(cp, inst)
+    v = prob.solve(tol=1e-9)
+    ref = primal_scipy.solve_primal(normalise_with_params(inst))
+    assert prob.status == cp.OPTIMAL and abs(v - ref["value"]) <= 2e-6 * max(1.0, abs(ref["value"]))
+    assert ("stable", k) in prob.routing.net["gk"] and (("sum", 3) in prob.routing.net["gk"]) == (seed == 3)
+    for i, kind in enumerate(inst["kinds"]):
+        if kind != "geomean":
+            y = receive[i].value - tender[i].value
+            assert np.abs(y - ref["y"][i]).max() <= 2e-4 * max(1.0, np.abs(ref["y"][i]).max())
+    prob.routing.close()

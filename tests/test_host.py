@@ -159,8 +159,14 @@ def test_pack_roundtrip_and_validation():
         cfmm.pack(3, [[0, 5]], [[1, 1]], [0.99])
     with pytest.raises(ValueError):
         cfmm.pack(3, [[0, 1]], [[1, -1]], [0.99])
+    # three-token constant-sum / stableswap pools: the K-asset table's buckets (round 4; they were refused before)
+    net3, where3 = cfmm.pack(3, [[0, 1, 2], [2, 0, 1]], [[1, 1, 1], [2, 3, 4]], [0.99, 0.999], kinds=["sum", "curve"], params=[None, 5.0])
+    assert where3 == [(("sum", 3), 0), (("stable", 3), 0)] and cfmm.problem.network_pool_count(net3) == 2
+    assert net3["gk"][("stable", 3)]["idx"][:, 0].tolist() == [2, 0, 1] and net3["gk"][("stable", 3)]["param"][0] == 5.0
     with pytest.raises(ValueError):
-        cfmm.pack(3, [[0, 1, 2]], [[1, 1, 1]], [0.99], kinds=["sum"])
+        cfmm.pack(3, [[0, 1, 2]], [[1, 1, 1]], [0.99], kinds=["curve"])              # alpha missing
+    with pytest.raises(ValueError):
+        cfmm.pack(12, [list(range(9))], [[1.0] * 9], [0.99], kinds=["sum"])          # more than 8 tokens
     # empty problem object
     net, where = cfmm.pack(3, [], [], [])
     assert where == [] and cfmm.problem.network_pool_count(net) == 0
@@ -173,6 +179,12 @@ def test_shard_network_partitions_every_bucket():
         assert np.array_equal(np.concatenate([p[key]["Ra"] for p in parts]), net[key]["Ra"])
     for k in net["gn"]:
         assert np.array_equal(np.concatenate([p["gn"][k]["R"] for p in parts], axis=1), net["gn"][k]["R"])
+    netk = synthetic.config("GK", scale=0.02)
+    parts = [cfmm.shard_network(netk, r, 3) for r in range(3)]
+    for key in netk["gk"]:
+        assert np.array_equal(np.concatenate([p["gk"][key]["R"] for p in parts], axis=1), netk["gk"][key]["R"])
+        assert np.array_equal(np.concatenate([p["gk"][key]["param"] for p in parts]), netk["gk"][key]["param"])
+    assert sum(cfmm.problem.network_pool_count(p) for p in parts) == cfmm.problem.network_pool_count(netk)
 
 
 def test_start_prices_propagate_through_pools():

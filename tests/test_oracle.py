@@ -386,3 +386,31 @@ def test_c_oracle_is_clean_under_asan_and_ubsan():
     r = subprocess.run([os.path.join(od, "_build", "asan_driver")], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0 and "asan driver ok" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, (r.stdout + r.stderr)[-3000:]
+
+
+def test_stableswap_n_restatement_against_the_two_asset_oracle_and_the_per_pool_primal():
+    """oracle/pools_np.py: arb_stable_n (the K-asset table's two-level search restated in NumPy) -- at k = 2 against arb_curve2
+    (bisection on the marginal price along the level set), at k = 3, 4 against ONE pool's primal by SLSQP (arb_pool_primal)"""
+    from oracle import pools_np as P
+    from cfmm.synthetic import curve_alpha_from_A
+    rng = np.random.default_rng(0)
+    m = 60
+    Ra = np.exp(rng.normal(7, 1, m)); Rb = Ra * np.exp(rng.normal(0, 0.05, m))
+    al = curve_alpha_from_A(Ra, Rb, rng.choice([10., 50., 100.], m)); g = rng.choice([0.997, 0.999, 0.9995], m)
+    pa = np.exp(rng.normal(0, 0.01, m)); pb = np.exp(rng.normal(0, 0.01, m))
+    y, arb = P.arb_stable_n(np.stack([Ra, Rb]), al, g, np.stack([pa, pb]))
+    for i in range(m):
+        y2, a2 = P.arb_curve2(Ra[i], Rb[i], g[i], al[i], pa[i], pb[i])
+        assert np.abs(y[:, i] - y2).max() <= 1e-11 * max(Ra[i], Rb[i]) and abs(arb[i] - a2) <= 1e-11 * (pa[i] * Ra[i] + pb[i] * Rb[i])
+    assert (np.abs(y).sum(axis=0) > 0).mean() > 0.5
+    for k in (3, 4):
+        m = 6
+        R = np.exp(rng.normal(7, 0.3, (k, m)))
+        al = np.prod(R, axis=0) * R.mean(axis=0) / (16 * 50.0)
+        g = rng.choice([0.997, 0.999], m); p = np.exp(rng.normal(0, 0.02, (k, m)))
+        y, arb = P.arb_stable_n(R, al, g, p)
+        for i in range(m):
+            phi = lambda x, a=al[i]: x.sum() - a / np.prod(x)
+            dphi = lambda x, a=al[i]: 1 + a / (np.prod(x) * x)
+            _, ap = P.arb_pool_primal(R[:, i], g[i], p[:, i], phi, dphi)
+            assert abs(ap - arb[i]) <= 1e-9 * float(p[:, i] @ R[:, i]), (k, i, ap, arb[i])
