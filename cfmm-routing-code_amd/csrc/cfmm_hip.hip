@@ -199,6 +199,8 @@ struct cfmm_ctx {
 
     // second-order method (allocated on first use)
     double *sm_out = nullptr, *sm_vec = nullptr, *H = nullptr, *Dinv = nullptr;
+    double *Winv = nullptr, *Rinv = nullptr;     // the inverse factor riding the factorisation, and its running residual (chol.hpp: round 4)
+    bool inverse_factor = true;                 // CFMM_BACKSUB=classic: the one-workgroup back substitution instead (A/B)
     double *sm_ws[CFMM_POOL_KINDS2] = {};   // warm starts of the smoothed per-direction solves
     long long sm_ws_m[CFMM_POOL_KINDS2] = {};
     double *sm_slo = nullptr;               // low-order log-prices of the last second-order solve (smooth.hpp)
@@ -1099,15 +1101,21 @@ int hess_ld(int n) { return hess_nr(n) + CH_NB; }                   // + the blo
 // substitution into `x`; *sm_info (device) = 0 or 1 + the first block column with a non-positive pivot
 int launch_factor(cfmm_ctx *ctx, int n)
 {
-    const int nr = hess_nr(n), ld = hess_ld(n), nrows = nr + 1;
+    const int nr = hess_nr(n), ld = hess_ld(n), nrows = nr + 1, nbk = nr / CH_NB;
     HIP_TRY(ctx, hipMemsetAsync(ctx->sm_info, 0, sizeof(int), ctx->stream));
+    const bool inv = ctx->inverse_factor && ctx->Winv;
+    if (inv) HIP_TRY(ctx, hipMemsetAsync(ctx->Rinv, 0, (size_t)nr * nr * sizeof(double), ctx->stream));       // (R = I: the diagonal blocks are implied)
     // one launch per block column: panel k1 beside the trailing update of panel k1 - NB (chol.hpp: chol_step_kernel)
     for (int k1 = 0; k1 < nr; k1 += CH_NB) {
         const int below = nrows - k1 - CH_NB;                  // rows under the diagonal block, the right-hand side's included
         const int npanel = 1 + (below + 63) / 64;
         int ntiles = 0;
         if (k1 > 0 && nr - k1 - CH_NB > 0) { const int T = (below + 63) / 64; ntiles = T * (T + 1) / 2; }
-        hipLaunchKernelGGL(chol_step_kernel, dim3(npanel + ntiles), dim3(256), 0, ctx->stream, ctx->H, ld, nrows, nr, k1, npanel, ctx->Dinv, ctx->sm_info);
+        // the inverse factor's block row q = k1 / NB - 1 (chol.hpp): (nbk - 1 - q)(q + 1) tiles behind the factorisation's own
+        const int q = k1 / CH_NB - 1;
+        const int ntw = (inv && q >= 0) ? (nbk - 1 - q) * (q + 1) : 0;
+        hipLaunchKernelGGL(chol_step_kernel, dim3(npanel + ntw + ntiles), dim3(256), 0, ctx->stream, ctx->H, ld, nrows, nr, k1, npanel, ctx->Dinv, ctx->sm_info,
+                           npanel + ntw, ctx->Winv, ctx->Rinv, nr);
     }
     HIP_TRY(ctx, hipGetLastError());
     return CFMM_OK;
@@ -1115,6 +1123,12 @@ int launch_factor(cfmm_ctx *ctx, int n)
 int launch_backsolve(cfmm_ctx *ctx, int n, double *x)
 {
     const int nr = hess_nr(n), ld = hess_ld(n);
+    if (ctx->inverse_factor && ctx->Winv) {              // x = W' y: one matrix-vector product over the whole chip
+        hipLaunchKernelGGL(chol_wt_kernel, dim3((nr + CH_WT_THREADS / 64 - 1) / (CH_WT_THREADS / 64)), dim3(CH_WT_THREADS), 0, ctx->stream,
+                           (const double *)ctx->H, ld, nr, n, (const double *)ctx->Dinv, (const double *)ctx->Winv, (const double *)ctx->Rinv, nr, x);
+        HIP_TRY(ctx, hipGetLastError());
+        return CFMM_OK;
+    }
     hipLaunchKernelGGL(chol_back_kernel, dim3(1), dim3(CH_SOLVE_THREADS), (size_t)(nr + CH_NB + 2 * CH_NB * CH_NB) * sizeof(double), ctx->stream,
                        (const double *)ctx->H, ld, nr, n, (const double *)ctx->Dinv, x);
     HIP_TRY(ctx, hipGetLastError());
@@ -1210,6 +1224,11 @@ int smooth_buffers(cfmm_ctx *ctx, bool hess)
         const size_t ld = hess_ld(n), nr = hess_nr(n);
         int rc = dev_upload<double>(ctx, &ctx->H, nullptr, ld * nr, nullptr); if (rc) return rc;
         rc = dev_upload<double>(ctx, &ctx->Dinv, nullptr, nr * CH_NB, nullptr); if (rc) return rc;
+        if (ctx->inverse_factor) {
+            rc = dev_upload<double>(ctx, &ctx->Winv, nullptr, nr * nr, nullptr); if (rc) return rc;
+            rc = dev_upload<double>(ctx, &ctx->Rinv, nullptr, nr * nr, nullptr); if (rc) return rc;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->Winv, 0, nr * nr * sizeof(double), ctx->stream));
+        }
         rc = dev_upload<int>(ctx, &ctx->sm_info, nullptr, 4, nullptr); if (rc) return rc;
         if ((rc = set_lds_attr(ctx, chol_back_kernel, (nr + CH_NB + 2 * CH_NB * CH_NB) * sizeof(double)))) return rc;
     }
@@ -1590,6 +1609,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if (const char *s = getenv("CFMM_NO_GRAPH")) ctx->no_graph = atoi(s) != 0;
     if (const char *s = getenv("CFMM_FUSED")) ctx->fused = atoi(s) != 0;
     if (const char *s = getenv("CFMM_TILE_DMA")) ctx->tile_dma = atoi(s) != 0;
+    if (const char *s = getenv("CFMM_BACKSUB")) ctx->inverse_factor = std::string(s) != "classic";
     if (const char *s = getenv("CFMM_TINY")) ctx->tiny_path = atoi(s) != 0;
     if (const char *s = getenv("CFMM_RUN_AHEAD")) ctx->run_ahead = std::max(1, atoi(s));
     if (const char *s = getenv("CFMM_DETERMINISTIC")) ctx->det = atoi(s) != 0;
@@ -1704,7 +1724,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     ctx->pools.reset();
     if (ctx->flags2) (void)hipFree(ctx->flags2);
     if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
-    for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_ws[4], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->Winv, (void *)ctx->Rinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_ws[4], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
     if (ctx->dev_arena) (void)hipFree(ctx->dev_arena);
     if (ctx->host_arena) (void)hipHostFree(ctx->host_arena);
     if (ctx->pin) (void)hipHostFree(ctx->pin);

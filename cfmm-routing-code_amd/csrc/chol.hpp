@@ -117,18 +117,88 @@ template <int J> struct WaveFactor {
 // blockIdx < npanel: panel role for block column k1 (workgroup 0 has no rows: it writes the factor and its inverse); the
 // others: tile (ti, tj) of the trailing update with panel k0 = k1 - NB over the rows / columns from k1 + NB on.
 // ------------------------------------------------------------------------------------------------------------------------
+// Round 4, a third role: the INVERSE FACTOR W = L^-1 rides along (workgroups >= nfac), so that the back substitution
+// L' x = y -- 118 us in ONE workgroup, a chain of 32 dependent block steps -- becomes ONE matrix-vector product x = W' y over
+// the whole chip (chol_wt_kernel).  Right-looking, one block row of W per launch, one launch behind the factorisation:
+//   R starts as the identity (its strictly lower blocks as zeros in `Rm`);  launch t finishes block row q = t - 1,
+//       W_qj = Linv_qq R_qj   (j <= q;  Linv_qq, the inverse diagonal block, came out of launch q's WaveFactor),
+//   and gives its update to every row below,  R_ij -= L_iq W_qj  (i > q;  L_iq is panel q, finished by launch q).
+// Workgroup (i, j) forms W_qj ITSELF (one 32^3 product, redundantly in the nb - 1 - q workgroups of column j) and applies it to
+// its R_ij (a second one): no workgroup waits for another, what a launch reads was finished by earlier launches, what it
+// writes is disjoint -- the scheme of the factorisation's own look-ahead.  The workgroup with i = q + 1 also stores W_qj.
+// Balanced (every workgroup: two block products) where the row-sum form  W_qj = -Linv_qq sum_k L_qk W_kj  would put q products
+// on one workgroup -- as long as the panel's chain.  The last block row is never formed: chol_wt_kernel applies it as
+// R_last' (Linv_last' y_last).  Fixed summation orders throughout: bitwise the same on every rank of a pool-sharded solve.
 __global__ void __launch_bounds__(256)
-chol_step_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k1, int npanel, double *__restrict__ Dinv, int *__restrict__ info)
+chol_step_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k1, int npanel, double *__restrict__ Dinv, int *__restrict__ info,
+                 int nfac, double *__restrict__ Wm, double *__restrict__ Rm, int ldw)
 {
     constexpr int NB = CH_NB;
     __shared__ __attribute__((aligned(16))) double lds[NB * NB + NB * 64 + NB * 64 + NB * (NB + 1) + NB * NB + 2 * 64];      // 57.25 KB (the tile role uses 33 KB of it)
     const int tid = threadIdx.x;
     const bool have_prev = k1 > 0;
     const int k0 = k1 - NB;
-    if ((int)blockIdx.x >= npanel) {
+    // (workgroup order: panel | inverse-factor tiles | trailing-update tiles -- the dispatcher hands workgroups out in index order, and
+    //  the inverse-factor tiles are the longer of the two side roles: `nfac` = where the trailing tiles begin)
+    if ((int)blockIdx.x >= npanel && (int)blockIdx.x < nfac) {
+        // ---- inverse factor: block row q = k1 / NB - 1, tile (i, j), j <= q < i < ncols / NB ------------------------------------------
+        const int q = k1 / NB - 1, nbk = ncols / NB;
+        const int t = (int)blockIdx.x - npanel, j = t % (q + 1), i = q + 1 + t / (q + 1);
+        double *Li = lds, *Rq = Li + NB * NB, *Wq = Rq + NB * NB, *Lq = Wq + NB * NB;       // 4 x 8 KB: Linv_qq | R_qj | W_qj | L_iq
+        (void)nbk;
+        const int r2 = 2 * (tid & 15), c2 = 2 * (tid >> 4);      // this thread's 2 x 2 sub-tile: rows r2, r2 + 1, columns c2, c2 + 1
+        double lv[4], rv[4], av[4], xv[2][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                             // (all loads first)
+            const int e = tid + 256 * u, rr = e & 31, cc = e >> 5;
+            lv[u] = Dinv[(size_t)q * NB * NB + e];                // Dinv[q][row * NB + col] = Linv[row][col]
+            rv[u] = j == q ? (rr == cc ? 1.0 : 0.0) : Rm[(size_t)(j * NB + cc) * ldw + q * NB + rr];
+            av[u] = A[(size_t)(q * NB + cc) * ld + i * NB + rr];  // L_iq: rows i NB + rr, column q NB + cc
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) xv[u][v] = Rm[(size_t)(j * NB + c2 + v) * ldw + i * NB + r2 + u];
+        // (every LDS operand k-major, so that a step of a product is two 16-byte reads: [k][row pair] and [k][column pair] --
+        //  the first layout read Linv row-major, sixteen lanes on one bank: the tiles took 12 us, longer than the panel's chain)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, rr = e & 31, cc = e >> 5;
+            Li[rr * NB + cc] = lv[u];                             // Linv[row = cc][col = rr] -> Li[k = rr][r = cc]
+            Rq[rr * NB + cc] = rv[u];                             // R_qj[rr][cc] -> Rq[k = rr][c = cc]
+            Lq[cc * NB + rr] = av[u];                             // L_iq[rr][cc] -> Lq[k = cc][r = rr]
+        }
+        __syncthreads();
+        double w00 = 0.0, w01 = 0.0, w10 = 0.0, w11 = 0.0;        // W_qj = Linv_qq R_qj
+#pragma unroll 8
+        for (int k = 0; k < NB; ++k) {
+            const double2 a = *reinterpret_cast<const double2 *>(Li + k * NB + r2), b = *reinterpret_cast<const double2 *>(Rq + k * NB + c2);
+            w00 = fma(a.x, b.x, w00); w01 = fma(a.x, b.y, w01); w10 = fma(a.y, b.x, w10); w11 = fma(a.y, b.y, w11);
+        }
+        *reinterpret_cast<double2 *>(Wq + r2 * NB + c2) = make_double2(w00, w01);            // Wq[k = row][c]
+        *reinterpret_cast<double2 *>(Wq + (r2 + 1) * NB + c2) = make_double2(w10, w11);
+        if (i == q + 1) {                                        // the finished block row: W_qj (strictly lower blocks; the diagonal ones stay in Dinv)
+            if (j < q) {
+                Wm[(size_t)(j * NB + c2) * ldw + q * NB + r2] = w00; Wm[(size_t)(j * NB + c2 + 1) * ldw + q * NB + r2] = w01;
+                Wm[(size_t)(j * NB + c2) * ldw + q * NB + r2 + 1] = w10; Wm[(size_t)(j * NB + c2 + 1) * ldw + q * NB + r2 + 1] = w11;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < NB; ++k) {                            // R_ij -= L_iq W_qj
+            const double2 a = *reinterpret_cast<const double2 *>(Lq + k * NB + r2), b = *reinterpret_cast<const double2 *>(Wq + k * NB + c2);
+            xv[0][0] = fma(-a.x, b.x, xv[0][0]); xv[0][1] = fma(-a.x, b.y, xv[0][1]); xv[1][0] = fma(-a.y, b.x, xv[1][0]); xv[1][1] = fma(-a.y, b.y, xv[1][1]);
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) Rm[(size_t)(j * NB + c2 + v) * ldw + i * NB + r2 + u] = xv[u][v];
+        return;
+    }
+    if ((int)blockIdx.x >= nfac) {
         // ---- trailing update with panel k0 over rows / columns >= k1 + NB: 64 x 64 tile (ti, tj) of the lower triangle ---------
         double (*Pi)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(lds), (*Pj)[64 + 1] = Pi + 32;
-        int t = (int)blockIdx.x - npanel, ti = 0;
+        int t = (int)blockIdx.x - nfac, ti = 0;
         while (t > ti) { t -= ti + 1; ++ti; }
         const int tj = t;
         const int base = k1 + NB;
@@ -348,6 +418,41 @@ chol_back_kernel(const double *__restrict__ L, int ld, int nr, int n, const doub
         buf ^= 1;
     }
     for (int i = tid; i < n; i += blockDim.x) out[i] = x[i];
+}
+
+// x = L^-T y through the inverse factor (above): y = row nr of the factored array (the forward substitution the factorisation
+// carried along), x -> out[0..n).  One wave per column c of W (block jb = c / NB):
+//     x_c = sum_{j >= c in the diagonal block} Linv_jb[j][c] y_j  +  sum_{k in blocks jb < i <= nb - 2} W[k][c] y_k
+//           +  sum_r R[(nb - 1) NB + r][c] u_r,      u = Linv_last' y_last   (the last block row, never formed: W_last = Linv_last R_last)
+// contiguous reads down column c, a fixed summation order (lane-strided partial sums, one butterfly): ~5 us for 1024 columns.
+constexpr int CH_WT_THREADS = 256;
+__global__ void __launch_bounds__(CH_WT_THREADS)
+chol_wt_kernel(const double *__restrict__ A, int ld, int nr, int n, const double *__restrict__ Dinv, const double *__restrict__ Wm,
+               const double *__restrict__ Rm, int ldw, double *__restrict__ out)
+{
+    constexpr int NB = CH_NB;
+    __shared__ double u_s[NB];
+    const int nb = nr / NB, last = nb - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < NB) {                            // u_c = sum_j Linv_last[j][c] y_(last NB + j)
+        double acc = 0.0;
+        for (int j = threadIdx.x; j < NB; ++j) acc = fma(Dinv[(size_t)last * NB * NB + j * NB + threadIdx.x], A[(size_t)(last * NB + j) * ld + nr], acc);
+        u_s[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    const int c = (int)blockIdx.x * (CH_WT_THREADS / 64) + wave;
+    if (c >= nr) return;
+    const int jb = c / NB, cc = c - jb * NB;
+    double acc = 0.0;
+    if (jb == last) acc = lane == 0 ? u_s[cc] : 0.0;
+    else {
+        if (lane < NB && lane >= cc) acc = Dinv[(size_t)jb * NB * NB + lane * NB + cc] * A[(size_t)(jb * NB + lane) * ld + nr];
+        const double *Wc = Wm + (size_t)c * ldw;
+        for (int k = (jb + 1) * NB + lane; k < last * NB; k += 64) acc = fma(Wc[k], A[(size_t)k * ld + nr], acc);
+        if (lane < NB) acc = fma(Rm[(size_t)c * ldw + last * NB + lane], u_s[lane], acc);
+    }
+    acc = wave_allsum(acc);
+    if (lane == 0 && c < n) out[c] = acc;
 }
 
 }  // namespace cfmm

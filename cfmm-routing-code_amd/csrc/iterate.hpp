@@ -439,6 +439,23 @@ iter_kernel(IterArgs a)
     if (wave == nw - 1) build_tile_table(a.ev, next_tile, lane);
     __syncthreads();
     st.evals += 1;
+    // DMA, workgroups with waves that carry no variables (up to 960 tokens: half of them at 1000): THOSE waves request every
+    // wave's first tile, now -- they idle until the tile phase anyway, while on the waves that run the update's chain the issue
+    // of four 1 KB DMA pieces each (and the wait for the vector-memory queue they fill) was measured to cost 0.5-1 us of
+    // chain.  Slots are dealt round-robin; the two workgroups that stash the accepted point in the last slots leave those to
+    // their owners (behind the update).  Should the scalar section end the solve, the pieces are waited for before the exit.
+    const bool keeps_acc0 = has_role && (mine(R_PSI_ACC) || mine(R_NU_ACC));
+    const bool helper_mode = DMA && nwa < nw;
+    if constexpr (DMA) {
+        if (helper_mode && !wave_active && st.evals < a.max_evals) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);           // (nothing of the compiler's own is pending: see below)
+            const int nhelp = nw - nwa, h = wave - nwa;
+            for (int sl = h; sl < nw; sl += nhelp) {     // slots h, h + nhelp, ...: every slot exactly once over the helpers
+                if (keeps_acc0 && sl >= first_late) continue;
+                tiles_dma_first(a.ev, next_tile, lds_addr(stage0 + SLOT * sl), lane, sl);
+            }
+        }
+    }
 
     // ================= the scalar section: accept test, curvature pair, stopping rule, two-loop recursion.  ONE wave runs
     // it; the others sleep at the next barrier and pick the results up from LDS =============================================
@@ -507,6 +524,7 @@ iter_kernel(IterArgs a)
         }
     }
     PHASE_STAMP(tsb, 21);
+    if constexpr (DMA) lds_barrier(); else               // (LDS only: the helpers' DMA pieces may be in flight)
     __syncthreads();
     // every wave (wave 0 too: its vector copies of alpha / gamma die at the barrier) takes the uniform results into SGPRs
     accept = uni(ctli[0]) != 0; new_dir = uni(ctli[1]) != 0; pair_ok = uni(ctli[3]) != 0;
@@ -521,7 +539,7 @@ iter_kernel(IterArgs a)
         //  their next use, and at run time such a vmcnt(N) waits for the DMA pieces issued here.  This wait costs nothing
         //  and tells it that nothing of its own is pending any more.)
         __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), nothing else
-        if (st.status == 0 && st.evals < a.max_evals && !dma_late) tiles_dma_first(a.ev, next_tile, lds_addr(stage0 + SLOT * wave), lane, wave);
+        if (!helper_mode && st.status == 0 && st.evals < a.max_evals && !dma_late) tiles_dma_first(a.ev, next_tile, lds_addr(stage0 + SLOT * wave), lane, wave);
     }
     if (new_dir && wave_active) {
 #pragma unroll
@@ -629,11 +647,17 @@ iter_kernel(IterArgs a)
                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (st.status != 0) return;                          // ended (converged / stalled / out of budget): nothing to evaluate
+    if (st.status != 0) {                                // ended (converged / stalled / out of budget): nothing to evaluate
+        if constexpr (DMA) dma_wait();                   // (a helper's pieces must have landed before its LDS goes back)
+        return;
+    }
     PHASE_STAMP(a.ev.ts, 22);
 #pragma unroll
     for (int e = 0; e < E; ++e) if (tin[e]) nu_s[r0 + e] = nn[e];        // (over this thread's own stash entry)
-    if constexpr (DMA) lds_barrier(); else               // (LDS only: a fence would wait for the first tiles' DMA -- and for nothing else that matters here)
+    if constexpr (DMA) {
+        if (helper_mode && !wave_active) dma_wait();     // (what a helper requested for the other waves is in LDS before they pass the barrier)
+        lds_barrier();                                   // (LDS only: a fence would wait for the first tiles' DMA -- and for nothing else that matters here)
+    } else
     __syncthreads();                                     // (the scratch in the exchange strips is free from here on; the tile table
     PHASE_STAMP(a.ev.ts, 23);                            //  and the ticket counter have been ready since the first barrier)
 #ifdef CFMM_PHASE_TIMERS
