@@ -56,7 +56,7 @@ _lib = None
 
 SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm_backend", "cfmm_default_opts",
            "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_upload_poolsG", "cfmm_set_pool_flags", "cfmm_set_utility",
-           "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
+           "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_debug_cholesky_apply", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_get_tradesG", "cfmm_comm_unique_id", "cfmm_comm_init",
            "cfmm_oneshot_export", "cfmm_oneshot_import", "cfmm_oneshot_attach", "cfmm_oneshot_mailbox", "cfmm_oneshot_enable",
            "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_time_newton_kernels", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
@@ -89,6 +89,7 @@ def lib():
     L.cfmm_eval_dual.argtypes = [vp, dp, dp, dp, dp]
     L.cfmm_eval_smooth.argtypes = [vp, dp, C.c_double, dp, dp, dp, dp]
     L.cfmm_debug_cholesky.argtypes = [vp, C.c_int, dp, dp, dp, ip]
+    L.cfmm_debug_cholesky_apply.argtypes = [vp, C.c_int, dp, dp]
     L.cfmm_solve.argtypes = [vp, dp, C.POINTER(Opts), C.POINTER(Stats)]
     L.cfmm_solve_batch.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(dp), C.POINTER(Opts), C.POINTER(Stats)]
     L.cfmm_batch_capacity.argtypes = [C.c_int]
@@ -237,6 +238,12 @@ class Context:
         x = np.zeros(self.n); info = C.c_int32()
         self._chk(self.L.cfmm_debug_cholesky(self.h, self.n, _d(A), _d(b), _d(x), C.byref(info)))
         return x, info.value
+
+    def debug_cholesky_apply(self, b):
+        """A^-1 b for a new right-hand side through the factor the last debug_cholesky left (the chord step's two products)"""
+        b = f64(b); x = np.zeros(self.n)
+        self._chk(self.L.cfmm_debug_cholesky_apply(self.h, self.n, _d(b), _d(x)))
+        return x
 
     def default_opts(self):
         o = Opts()

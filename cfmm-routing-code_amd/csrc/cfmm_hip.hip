@@ -200,6 +200,7 @@ struct cfmm_ctx {
     // second-order method (allocated on first use)
     double *sm_out = nullptr, *sm_vec = nullptr, *H = nullptr, *Dinv = nullptr;
     double *Winv = nullptr, *Rinv = nullptr;     // the inverse factor riding the factorisation, and its running residual (chol.hpp: round 4)
+    double *chord_y = nullptr;                  // [nr] the intermediate of a chord step (launch_chord)
     bool inverse_factor = true;                 // CFMM_BACKSUB=classic: the one-workgroup back substitution instead (A/B)
     double *sm_ws[CFMM_POOL_KINDS2] = {};   // warm starts of the smoothed per-direction solves
     long long sm_ws_m[CFMM_POOL_KINDS2] = {};
@@ -1125,12 +1126,25 @@ int launch_backsolve(cfmm_ctx *ctx, int n, double *x)
     const int nr = hess_nr(n), ld = hess_ld(n);
     if (ctx->inverse_factor && ctx->Winv) {              // x = W' y: one matrix-vector product over the whole chip
         hipLaunchKernelGGL(chol_wt_kernel, dim3((nr + CH_WT_THREADS / 64 - 1) / (CH_WT_THREADS / 64)), dim3(CH_WT_THREADS), 0, ctx->stream,
-                           (const double *)ctx->H, ld, nr, n, (const double *)ctx->Dinv, (const double *)ctx->Winv, (const double *)ctx->Rinv, nr, x);
+                           (const double *)(ctx->H + nr), ld, nr, n, (const double *)ctx->Dinv, (const double *)ctx->Winv, (const double *)ctx->Rinv, nr, x);
         HIP_TRY(ctx, hipGetLastError());
         return CFMM_OK;
     }
     hipLaunchKernelGGL(chol_back_kernel, dim3(1), dim3(CH_SOLVE_THREADS), (size_t)(nr + CH_NB + 2 * CH_NB * CH_NB) * sizeof(double), ctx->stream,
                        (const double *)ctx->H, ld, nr, n, (const double *)ctx->Dinv, x);
+    HIP_TRY(ctx, hipGetLastError());
+    return CFMM_OK;
+}
+// x = H_old^-1 g through the factor and inverse factor the LAST factorisation left (chol.hpp: chol_w_kernel, chol_wt_kernel): two
+// matrix-vector products.  g: device vector [n], masked by the caller; x may alias g.
+int launch_chord(cfmm_ctx *ctx, int n, const double *g, double *x)
+{
+    const int nr = hess_nr(n);
+    if (!(ctx->inverse_factor && ctx->Winv)) return fail(ctx, CFMM_E_STATE, "chord step: no inverse factor (CFMM_BACKSUB=classic)");
+    hipLaunchKernelGGL(chol_w_kernel, dim3((nr + CH_W_THREADS - 1) / CH_W_THREADS), dim3(CH_W_THREADS), 0, ctx->stream,
+                       g, nr, n, (const double *)ctx->Dinv, (const double *)ctx->Winv, (const double *)ctx->Rinv, nr, ctx->chord_y);
+    hipLaunchKernelGGL(chol_wt_kernel, dim3((nr + CH_WT_THREADS / 64 - 1) / (CH_WT_THREADS / 64)), dim3(CH_WT_THREADS), 0, ctx->stream,
+                       (const double *)ctx->chord_y, 1, nr, n, (const double *)ctx->Dinv, (const double *)ctx->Winv, (const double *)ctx->Rinv, nr, x);
     HIP_TRY(ctx, hipGetLastError());
     return CFMM_OK;
 }
@@ -1227,6 +1241,7 @@ int smooth_buffers(cfmm_ctx *ctx, bool hess)
         if (ctx->inverse_factor) {
             rc = dev_upload<double>(ctx, &ctx->Winv, nullptr, nr * nr, nullptr); if (rc) return rc;
             rc = dev_upload<double>(ctx, &ctx->Rinv, nullptr, nr * nr, nullptr); if (rc) return rc;
+            rc = dev_upload<double>(ctx, &ctx->chord_y, nullptr, nr + 4, nullptr); if (rc) return rc;
             HIP_TRY(ctx, hipMemsetAsync(ctx->Winv, 0, nr * nr * sizeof(double), ctx->stream));
         }
         rc = dev_upload<int>(ctx, &ctx->sm_info, nullptr, 4, nullptr); if (rc) return rc;
@@ -1389,11 +1404,36 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     std::vector<double> slo(n, 0.0), slo2(n, 0.0);       // low-order log-prices (smooth.hpp: apply_slo)
     bool slo_on = false;
     SmoothEval e, e2;
-    bool have_e = false;                        // the accepted line-search point was evaluated with its Hessian already
+    bool have_e = false;                        // the accepted line-search point was evaluated already (at this barrier weight) ...
+    bool e_has_h = false;                       // ... together with its Hessian
+    // Chord steps (round 4).  A step's direction needs H^-1 G; with the inverse factor W = L^-1 riding the factorisation
+    // (chol.hpp) the factor of an EARLIER step applies to a new gradient in two matrix-vector products (~20 us against ~400 for a
+    // fresh factorisation + solve), and such a step needs no Hessian assembly either.  Between two steps of the path the
+    // ONLY at an unchanged barrier weight: measured on config 5, a factor from the previous weight (10x larger) gives
+    // directions whose full step the Armijo test refuses (t = 1/8 .. 1/16) and the solve takes 20-24 steps instead of 9,
+    // 10.2-12.4 ms instead of 6.3 -- near their peg the stableswap pools' curvature terms kappa = 1 / (mu / D^2 - nu L'') follow
+    // the weight.  At the SAME weight (the centring steps at the final weight, which is where the step count of the path is
+    // decided) the Hessian barely moves: up to `chord_max` such steps in a row reuse the last factor; a chord direction that is not
+    // a descent direction, or whose full step the Armijo test refuses, sends the step back to a fresh factorisation.
+    // CFMM_CHORD=0 switches it off (A/B).
+    static const int chord_max = getenv("CFMM_CHORD") ? atoi(getenv("CFMM_CHORD")) : 3;
+    // ... and only behind a step that was taken in full: where the Armijo test has just cut a fresh Newton step (the shipped
+    // instances' partially filled constant-sum pool: t = 1/4) the iteration is outside the region in which an old Hessian
+    // serves -- chord steps there were cut to 1/8 .. 1/128 and the solve took 34 steps instead of 10.
+    bool fac_valid = false, chord_bad = false, last_full = false;
+    double dec_prev = 0.0;                      // the decrement G' H^-1 G of the last accepted step
+    double move_prev = 0.0;                     // ... and its largest log-price move
+    int chord_run = 0, chord_steps = 0;
+    double fac_mu = 0.0;
     for (;;) {
-        if (!have_e) {
-            if ((rc = smooth_eval_host(ctx, nu, mu, true, e, true, slo_on ? &slo : nullptr))) return rc;
+        // (not in the low-order regime either -- moves below ~1e-10 in log-price, where a partially filled constant-sum pool's
+        //  fill reacts to price changes under the fp64 resolution of the prices: the Hessian changes by orders of magnitude from
+        //  step to step there, and steps on a stale one only feed the stall counter)
+        const bool use_chord = fac_valid && fac_mu == mu && last_full && !slo_on && move_prev > 1e-10 && !chord_bad && chord_run < chord_max && reg == 0.0 && ctx->inverse_factor && ctx->Winv != nullptr && !sharded(ctx);
+        if (!have_e || (!use_chord && !e_has_h)) {
+            if ((rc = smooth_eval_host(ctx, nu, mu, !use_chord, e, true, slo_on ? &slo : nullptr))) return rc;
             ++evals;
+            e_has_h = !use_chord;
         }
         have_e = false;
         const double gmu = assemble(nu, e, mu, &G, &Hd);
@@ -1446,21 +1486,41 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         std::memcpy(pin_vec, Hd.data(), n * sizeof(double)); std::memcpy(pin_vec + n, rhs.data(), n * sizeof(double));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, pin_mask, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, pin_vec, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, hess_nr(n), hess_ld(n), (const double *)ctx->sm_vec,
-                           (const int *)ctx->sm_mask, (const double *)(ctx->sm_vec + n));
-        HIP_TRY(ctx, hipGetLastError());
-        if ((rc = launch_cholesky(ctx, n, ctx->sm_vec + n))) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(pin_info, ctx->sm_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(pin_d, ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        const int info = *pin_info;
+        int info = 0;
+        if (use_chord) {
+            if ((rc = launch_chord(ctx, n, ctx->sm_vec + n, ctx->sm_vec + n))) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(pin_d, ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        } else {
+            hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, hess_nr(n), hess_ld(n), (const double *)ctx->sm_vec,
+                               (const int *)ctx->sm_mask, (const double *)(ctx->sm_vec + n));
+            HIP_TRY(ctx, hipGetLastError());
+            if ((rc = launch_cholesky(ctx, n, ctx->sm_vec + n))) return rc;
+            e_has_h = false;                       // (factored in place: the assembled Hessian is gone)
+            HIP_TRY(ctx, hipMemcpyAsync(pin_info, ctx->sm_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(pin_d, ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            info = *pin_info;
+            fac_valid = info == 0; fac_mu = mu; chord_run = 0; chord_bad = false;
+        }
         d.assign(pin_d, pin_d + n);
         if (info != 0) {                       // not positive definite: shift the diagonal and assemble again
             double md = 0.0;
             for (int j = 0; j < n; ++j) md = std::max(md, std::max(Hd[j], std::fabs(G[j])));
             reg = reg == 0.0 ? 1e-12 * std::max(md, 1e-300) : reg * 100.0;
             if (!(reg < 1e300)) { status = CFMM_E_NUMERIC; break; }
+            have_e = true;                         // (same point, same weight: only the Hessian has to be assembled again)
             continue;
+        }
+        if (use_chord) {                           // the old factor must still give a descent direction on the free tokens
+            double dc = 0.0;
+            bool fin = true;
+            for (int j = 0; j < n; ++j) { if (!pin[j]) dc -= G[j] * d[j]; fin = fin && std::isfinite(d[j]); }
+            // ... and the iteration must be contracting fast under it: a chord step shrinks the decrement by the square of its
+            // contraction factor, so "at least a hundredfold since the last step" = a factor <= 0.1 per step.  The shipped
+            // instances' final centring (a partially filled constant-sum pool, steps below the resolution of the log-prices)
+            // contracts only 3x per chord step where ONE fresh Newton step finishes: 30 steps instead of 24 without this test.
+            if (!fin || !(dc > 0.0) || !(dc <= 1e-2 * dec_prev)) { chord_bad = true; have_e = true; continue; }      // back to a fresh factorisation, at this point
         }
         ++steps;
         reg = reg > 0.0 ? 0.1 * reg : 0.0;      // a singular Hessian (tokens no pool connects) tends to stay singular: keep most of the shift
@@ -1493,15 +1553,31 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             slo2_on = small;
             // the first trial is nearly always taken: when the barrier weight stays as it is, the next step starts with exactly
             // this evaluation plus the Hessian -- so ask for the Hessian now (+50%) and save that evaluation and its round trip
-            const bool with_h = ls == 0 && (final_mu || !(dec < 10.0 * mu * (double)nbar));
+            // (a next step that reuses this step's factor -- a chord step -- needs no Hessian: the plain evaluation serves it)
+            const bool stay = final_mu || !(dec < 10.0 * mu * (double)nbar);
+            const bool next_chord = ls == 0 && stay && !slo2_on && t * dmax > 1e-10 && fac_valid && fac_mu == mu && chord_run + (use_chord ? 1 : 0) < chord_max && reg == 0.0 && ctx->inverse_factor && ctx->Winv != nullptr && !sharded(ctx);
+            const bool with_h = ls == 0 && stay && !next_chord;
             if ((rc = smooth_eval_host(ctx, nu2, mu, with_h, e2, true, slo2_on ? &slo2 : nullptr))) return rc;
             ++evals;
             const double g2 = assemble(nu2, e2, mu, nullptr, nullptr);
-            if (g2 <= gmu + o.armijo * gd || dec <= 1e-13 * std::fabs(gmu)) { moved = true; have_e = with_h; break; }
+            if (g2 <= gmu + o.armijo * gd || dec <= 1e-13 * std::fabs(gmu)) {
+                moved = true;
+                have_e = stay && (with_h || next_chord);           // reusable where the weight stays: with its Hessian, or for a chord step
+                e_has_h = with_h;
+                if (use_chord && ls > 0) chord_bad = true;         // the old factor's full step was refused: factor afresh next time
+                break;
+            }
             t *= 0.5;
         }
-        if (trace) fprintf(stderr, "[newton]    dec %.3e |d| %.3e t %.3e (first %.3e) moved %d\n", dec, dmax, t, t_first, (int)moved);
+        if (trace) fprintf(stderr, "[newton]    dec %.3e |d| %.3e t %.3e (first %.3e) moved %d%s\n", dec, dmax, t, t_first, (int)moved, use_chord ? " (chord)" : "");
+        if (!moved && use_chord) {                     // the old factor gave no acceptable step at all: this step again, with a fresh one
+            chord_bad = true; have_e = true; --steps;
+            continue;
+        }
         if (!moved) { status = 2; break; }
+        if (use_chord) { ++chord_run; ++chord_steps; }
+        last_full = t == t_first;
+        dec_prev = dec; move_prev = t * dmax;
         s = s2; nu = nu2; slo = slo2; slo_on = slo2_on;
         if (have_e) std::swap(e, e2);
         {                                       // a price that has collapsed by e^-60 since the start: a token that must be traded away
@@ -1510,8 +1586,9 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             if (collapsed) { status = 2; break; }
         }
         if (final_mu) continue;                                        // the weight is small enough: finish centring at it
-        if (dec < 10.0 * mu * (double)nbar && (t == t_first || dec < 1e-3 * mu * (double)nbar)) mu *= sigma;
+        if (dec < 10.0 * mu * (double)nbar && (t == t_first || dec < 1e-3 * mu * (double)nbar)) { mu *= sigma; have_e = false; }      // (an evaluation belongs to its weight)
     }
+    if (trace) fprintf(stderr, "[newton] %d steps, %d of them chord steps (no factorisation)\n", steps, chord_steps);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
     // leave the solution where the read-backs expect it: prices, the smoothed psi, the barrier weight for the tenders
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu_acc, nu.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -1724,7 +1801,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     ctx->pools.reset();
     if (ctx->flags2) (void)hipFree(ctx->flags2);
     if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
-    for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->Winv, (void *)ctx->Rinv, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_ws[4], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->Winv, (void *)ctx->Rinv, (void *)ctx->chord_y, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_ws[4], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
     if (ctx->dev_arena) (void)hipFree(ctx->dev_arena);
     if (ctx->host_arena) (void)hipHostFree(ctx->host_arena);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
@@ -2271,6 +2348,18 @@ int cfmm_debug_cholesky(cfmm_ctx *ctx, int n, const double *A, const double *b, 
     HIP_TRY(ctx, hipMemcpyAsync(x, ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (info) *info = inf;
+    return CFMM_OK;
+}
+
+// (test hook) x = A^-1 b for a NEW right-hand side through the factor cfmm_debug_cholesky left: the chord step's two products
+int cfmm_debug_cholesky_apply(cfmm_ctx *ctx, int n, const double *b, double *x)
+{
+    if (!ctx || !b || !x || n != ctx->n || !ctx->H) return ctx ? fail(ctx, CFMM_E_STATE, "debug_cholesky_apply: call cfmm_debug_cholesky first") : CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec + n, b, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    { int rc = launch_chord(ctx, n, ctx->sm_vec + n, ctx->sm_vec); if (rc) return rc; }
+    HIP_TRY(ctx, hipMemcpyAsync(x, ctx->sm_vec, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CFMM_OK;
 }
 

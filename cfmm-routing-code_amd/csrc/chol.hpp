@@ -427,16 +427,17 @@ chol_back_kernel(const double *__restrict__ L, int ld, int nr, int n, const doub
 // contiguous reads down column c, a fixed summation order (lane-strided partial sums, one butterfly): ~5 us for 1024 columns.
 constexpr int CH_WT_THREADS = 256;
 __global__ void __launch_bounds__(CH_WT_THREADS)
-chol_wt_kernel(const double *__restrict__ A, int ld, int nr, int n, const double *__restrict__ Dinv, const double *__restrict__ Wm,
+chol_wt_kernel(const double *__restrict__ yv, int ys, int nr, int n, const double *__restrict__ Dinv, const double *__restrict__ Wm,
                const double *__restrict__ Rm, int ldw, double *__restrict__ out)
 {
+    // y_k = yv[k ys]: row nr of the factored array (yv = A + nr, ys = ld) or a plain vector (ys = 1: chol_w_kernel's output)
     constexpr int NB = CH_NB;
     __shared__ double u_s[NB];
     const int nb = nr / NB, last = nb - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < NB) {                            // u_c = sum_j Linv_last[j][c] y_(last NB + j)
         double acc = 0.0;
-        for (int j = threadIdx.x; j < NB; ++j) acc = fma(Dinv[(size_t)last * NB * NB + j * NB + threadIdx.x], A[(size_t)(last * NB + j) * ld + nr], acc);
+        for (int j = threadIdx.x; j < NB; ++j) acc = fma(Dinv[(size_t)last * NB * NB + j * NB + threadIdx.x], yv[(size_t)(last * NB + j) * ys], acc);
         u_s[threadIdx.x] = acc;
     }
     __syncthreads();
@@ -446,13 +447,53 @@ chol_wt_kernel(const double *__restrict__ A, int ld, int nr, int n, const double
     double acc = 0.0;
     if (jb == last) acc = lane == 0 ? u_s[cc] : 0.0;
     else {
-        if (lane < NB && lane >= cc) acc = Dinv[(size_t)jb * NB * NB + lane * NB + cc] * A[(size_t)(jb * NB + lane) * ld + nr];
+        if (lane < NB && lane >= cc) acc = Dinv[(size_t)jb * NB * NB + lane * NB + cc] * yv[(size_t)(jb * NB + lane) * ys];
         const double *Wc = Wm + (size_t)c * ldw;
-        for (int k = (jb + 1) * NB + lane; k < last * NB; k += 64) acc = fma(Wc[k], A[(size_t)k * ld + nr], acc);
+        for (int k = (jb + 1) * NB + lane; k < last * NB; k += 64) acc = fma(Wc[k], yv[(size_t)k * ys], acc);
         if (lane < NB) acc = fma(Rm[(size_t)c * ldw + last * NB + lane], u_s[lane], acc);
     }
     acc = wave_allsum(acc);
     if (lane == 0 && c < n) out[c] = acc;
+}
+
+// y = W g = L^-1 g for a NEW right-hand side against the factor (and inverse factor) of an earlier factorisation: with
+// chol_wt_kernel behind it,  x = W' (W g) = H_old^-1 g  costs two matrix-vector products (~20 us) where a fresh factorisation
+// costs ~400 -- the "chord" steps of the second-order iteration (cfmm_hip.hip: solve_newton).  One thread per row k (adjacent
+// rows are adjacent in the column-major W: coalesced), a fixed summation order:
+//     k in block i <= nb - 2:   y_k = sum_{c < i NB} W[k][c] g_c + sum_{c <= k in the block} Linv_i[k][c] g_c
+//     last block:               y = Linv_last (g_last + sum_{c < last NB} R[last rows][c] g_c)
+// g is masked (pinned tokens carry identity rows in the factored matrix: their g is what comes out).
+constexpr int CH_W_THREADS = 64;
+__global__ void __launch_bounds__(CH_W_THREADS)
+chol_w_kernel(const double *__restrict__ g, int nr, int n, const double *__restrict__ Dinv, const double *__restrict__ Wm,
+              const double *__restrict__ Rm, int ldw, double *__restrict__ y)
+{
+    constexpr int NB = CH_NB;
+    __shared__ double t_s[CH_W_THREADS];
+    const int nb = nr / NB, last = nb - 1;
+    const int k = (int)blockIdx.x * CH_W_THREADS + threadIdx.x;
+    const int ib = k / NB, kk = k - ib * NB;
+    const bool islast = ib == last;
+    const double *M = islast ? Rm : Wm;                       // strictly-lower part: finished W rows, or the last row's residual
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const int cend = ib * NB;
+    if (k < nr) {
+        for (int c = 0; c + 4 <= cend; c += 4) {
+            a0 = fma(M[(size_t)c * ldw + k], c < n ? g[c] : 0.0, a0);
+            a1 = fma(M[(size_t)(c + 1) * ldw + k], c + 1 < n ? g[c + 1] : 0.0, a1);
+            a2 = fma(M[(size_t)(c + 2) * ldw + k], c + 2 < n ? g[c + 2] : 0.0, a2);
+            a3 = fma(M[(size_t)(c + 3) * ldw + k], c + 3 < n ? g[c + 3] : 0.0, a3);
+        }
+    }
+    double acc = (a0 + a1) + (a2 + a3);
+    if (islast && k < nr) acc += k < n ? g[k] : 0.0;          // t = g_last + R_last g
+    t_s[threadIdx.x] = islast ? acc : (k < n ? g[k] : 0.0);   // the diagonal block's input: t (last block) or g (the others)
+    __syncthreads();
+    if (k >= nr) return;
+    const int base = (threadIdx.x / NB) * NB;                 // this row's block inside the workgroup's 64 rows
+    double d = 0.0;
+    for (int cc = 0; cc <= kk; ++cc) d = fma(Dinv[(size_t)ib * NB * NB + kk * NB + cc], t_s[base + cc], d);
+    y[k] = islast ? d : acc + d;
 }
 
 }  // namespace cfmm

