@@ -1105,7 +1105,6 @@ int launch_factor(cfmm_ctx *ctx, int n)
     const int nr = hess_nr(n), ld = hess_ld(n), nrows = nr + 1, nbk = nr / CH_NB;
     HIP_TRY(ctx, hipMemsetAsync(ctx->sm_info, 0, sizeof(int), ctx->stream));
     const bool inv = ctx->inverse_factor && ctx->Winv;
-    if (inv) HIP_TRY(ctx, hipMemsetAsync(ctx->Rinv, 0, (size_t)nr * nr * sizeof(double), ctx->stream));       // (R = I: the diagonal blocks are implied)
     // one launch per block column: panel k1 beside the trailing update of panel k1 - NB (chol.hpp: chol_step_kernel)
     for (int k1 = 0; k1 < nr; k1 += CH_NB) {
         const int below = nrows - k1 - CH_NB;                  // rows under the diagonal block, the right-hand side's included
@@ -1415,7 +1414,8 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     // the weight.  At the SAME weight (the centring steps at the final weight, which is where the step count of the path is
     // decided) the Hessian barely moves: up to `chord_max` such steps in a row reuse the last factor; a chord direction that is not
     // a descent direction, or whose full step the Armijo test refuses, sends the step back to a fresh factorisation.
-    // CFMM_CHORD=0 switches it off (A/B).
+    // Pool-sharded: every rank holds the same all-reduced Hessian, factors it identically (fixed summation orders: chol.hpp) and
+    // takes these decisions on the same numbers -- the ranks stay in step.  CFMM_CHORD=0 switches it off (A/B).
     static const int chord_max = getenv("CFMM_CHORD") ? atoi(getenv("CFMM_CHORD")) : 3;
     // ... and only behind a step that was taken in full: where the Armijo test has just cut a fresh Newton step (the shipped
     // instances' partially filled constant-sum pool: t = 1/4) the iteration is outside the region in which an old Hessian
@@ -1429,7 +1429,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         // (not in the low-order regime either -- moves below ~1e-10 in log-price, where a partially filled constant-sum pool's
         //  fill reacts to price changes under the fp64 resolution of the prices: the Hessian changes by orders of magnitude from
         //  step to step there, and steps on a stale one only feed the stall counter)
-        const bool use_chord = fac_valid && fac_mu == mu && last_full && !slo_on && move_prev > 1e-10 && !chord_bad && chord_run < chord_max && reg == 0.0 && ctx->inverse_factor && ctx->Winv != nullptr && !sharded(ctx);
+        const bool use_chord = fac_valid && fac_mu == mu && last_full && !slo_on && move_prev > 1e-10 && !chord_bad && chord_run < chord_max && reg == 0.0 && ctx->inverse_factor && ctx->Winv != nullptr;
         if (!have_e || (!use_chord && !e_has_h)) {
             if ((rc = smooth_eval_host(ctx, nu, mu, !use_chord, e, true, slo_on ? &slo : nullptr))) return rc;
             ++evals;
@@ -1555,7 +1555,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             // this evaluation plus the Hessian -- so ask for the Hessian now (+50%) and save that evaluation and its round trip
             // (a next step that reuses this step's factor -- a chord step -- needs no Hessian: the plain evaluation serves it)
             const bool stay = final_mu || !(dec < 10.0 * mu * (double)nbar);
-            const bool next_chord = ls == 0 && stay && !slo2_on && t * dmax > 1e-10 && fac_valid && fac_mu == mu && chord_run + (use_chord ? 1 : 0) < chord_max && reg == 0.0 && ctx->inverse_factor && ctx->Winv != nullptr && !sharded(ctx);
+            const bool next_chord = ls == 0 && stay && !slo2_on && t * dmax > 1e-10 && fac_valid && fac_mu == mu && chord_run + (use_chord ? 1 : 0) < chord_max && reg == 0.0 && ctx->inverse_factor && ctx->Winv != nullptr;
             const bool with_h = ls == 0 && stay && !next_chord;
             if ((rc = smooth_eval_host(ctx, nu2, mu, with_h, e2, true, slo2_on ? &slo2 : nullptr))) return rc;
             ++evals;

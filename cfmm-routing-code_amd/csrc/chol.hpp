@@ -120,7 +120,7 @@ template <int J> struct WaveFactor {
 // Round 4, a third role: the INVERSE FACTOR W = L^-1 rides along (workgroups >= nfac), so that the back substitution
 // L' x = y -- 118 us in ONE workgroup, a chain of 32 dependent block steps -- becomes ONE matrix-vector product x = W' y over
 // the whole chip (chol_wt_kernel).  Right-looking, one block row of W per launch, one launch behind the factorisation:
-//   R starts as the identity (its strictly lower blocks as zeros in `Rm`);  launch t finishes block row q = t - 1,
+//   R starts as the identity (implied: a block's first update, from row j, starts from zero);  launch t finishes block row q = t - 1,
 //       W_qj = Linv_qq R_qj   (j <= q;  Linv_qq, the inverse diagonal block, came out of launch q's WaveFactor),
 //   and gives its update to every row below,  R_ij -= L_iq W_qj  (i > q;  L_iq is panel q, finished by launch q).
 // Workgroup (i, j) forms W_qj ITSELF (one 32^3 product, redundantly in the nb - 1 - q workgroups of column j) and applies it to
@@ -144,6 +144,9 @@ chol_step_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k1, i
         // ---- inverse factor: block row q = k1 / NB - 1, tile (i, j), j <= q < i < ncols / NB ------------------------------------------
         const int q = k1 / NB - 1, nbk = ncols / NB;
         const int t = (int)blockIdx.x - npanel, j = t % (q + 1), i = q + 1 + t / (q + 1);
+#ifdef CFMM_W_NOOP
+        if (CFMM_W_NOOP == 1) return;                             // (diagnostic: the cost of the extra workgroups alone)
+#endif
         double *Li = lds, *Rq = Li + NB * NB, *Wq = Rq + NB * NB, *Lq = Wq + NB * NB;       // 4 x 8 KB: Linv_qq | R_qj | W_qj | L_iq
         (void)nbk;
         const int r2 = 2 * (tid & 15), c2 = 2 * (tid >> 4);      // this thread's 2 x 2 sub-tile: rows r2, r2 + 1, columns c2, c2 + 1
@@ -158,7 +161,7 @@ chol_step_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k1, i
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) xv[u][v] = Rm[(size_t)(j * NB + c2 + v) * ldw + i * NB + r2 + u];
+            for (int u = 0; u < 2; ++u) xv[u][v] = j == q ? 0.0 : Rm[(size_t)(j * NB + c2 + v) * ldw + i * NB + r2 + u];      // (R_ij's first update comes from row j: it starts from zero -- no memset of R per factorisation)
         // (every LDS operand k-major, so that a step of a product is two 16-byte reads: [k][row pair] and [k][column pair] --
         //  the first layout read Linv row-major, sixteen lanes on one bank: the tiles took 12 us, longer than the panel's chain)
 #pragma unroll
@@ -169,6 +172,9 @@ chol_step_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k1, i
             Lq[cc * NB + rr] = av[u];                             // L_iq[rr][cc] -> Lq[k = cc][r = rr]
         }
         __syncthreads();
+#ifdef CFMM_W_NOOP
+        if (CFMM_W_NOOP == 2) return;                             // (diagnostic: loads only)
+#endif
         double w00 = 0.0, w01 = 0.0, w10 = 0.0, w11 = 0.0;        // W_qj = Linv_qq R_qj
 #pragma unroll 8
         for (int k = 0; k < NB; ++k) {
@@ -291,6 +297,9 @@ chol_step_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k1, i
     }
     const int wave = tid >> 6, lane = tid & 63;
     if (wave == 0) {
+        // (the launch's critical path is THIS wave's dependent chain -- a lone fp64 wave, issue-bound: it must not queue behind the
+        //  inverse-factor / trailing-update waves that share its SIMD)
+        __builtin_amdgcn_s_setprio(3);
         double a[NB];
         const int c = lane & (NB - 1);
 #pragma unroll
