@@ -712,6 +712,16 @@ static bool pingpong_on(const cfmm_ctx *ctx)
 }
 
 // the staged tile walk: wherever its slots fit beside the tiles (<= ~3400 tokens with the metric, ~4900 without)
+// non-temporal column loads (kernels.hpp: ld_off<NT>): where one evaluation's pool columns are several times the Infinity Cache
+static bool stream_nt(const cfmm_ctx *ctx)
+{
+    static const int mode = getenv("CFMM_NT") ? atoi(getenv("CFMM_NT")) : -1;       // (A/B: 0 never, 1 always)
+    if (mode >= 0) return mode != 0 && !ctx->det;
+    double bytes = 0.0;
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) if (!heavy_kind(k)) bytes += (double)ctx->pools->b2[k].m * ((k == CFMM_POOL_CP2 || k == CFMM_POOL_SUM2) ? 32.0 : 40.0);
+    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) bytes += (double)ctx->pools->bn[k].m * (20.0 + 20.0 * k);
+    return !ctx->det && bytes > 2.0 * 256.0 * 1048576.0;
+}
 static bool eval_dma(const cfmm_ctx *ctx, bool with_d) { return CFMM_STAGED_WALK && ctx->tile_dma && !ctx->det && eval_lds_bytes(ctx->n, with_d, false, true) <= LDS_MAX; }
 static bool iter_dma(const cfmm_ctx *ctx) { return CFMM_STAGED_WALK && ctx->tile_dma && !ctx->det && iter_lds_bytes(ctx->n, false, true) <= LDS_MAX; }
 
@@ -728,6 +738,7 @@ void launch_eval(cfmm_ctx *ctx, const EvalArgs &a_in, hipStream_t stream = nullp
 #if CFMM_STAGED_WALK
     else if (!STABLE && eval_dma(ctx, WITH_D)) hipLaunchKernelGGL((eval_kernel<WITH_D, false, false, true>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D, false, true), stream, a);
 #endif
+    else if (!STABLE && stream_nt(ctx)) hipLaunchKernelGGL((eval_kernel<WITH_D, false, false, false, true>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), stream, a);
     else hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), stream, a);
 }
 
@@ -826,6 +837,8 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, eval_kernel<true, false>, e1))) return rc;
     if ((rc = set_lds_attr(ctx, eval_kernel<false, true>, e0))) return rc;
     if ((rc = set_lds_attr(ctx, eval_kernel<true, true>, e1))) return rc;
+    if ((rc = set_lds_attr(ctx, eval_kernel<false, false, false, false, true>, e0))) return rc;
+    if ((rc = set_lds_attr(ctx, eval_kernel<true, false, false, false, true>, e1))) return rc;
 #if CFMM_STAGED_WALK
     if (eval_lds_bytes(ctx->n, false, false, true) <= LDS_MAX && (rc = set_lds_attr(ctx, eval_kernel<false, false, false, true>, eval_lds_bytes(ctx->n, false, false, true)))) return rc;
     if (eval_lds_bytes(ctx->n, true, false, true) <= LDS_MAX && (rc = set_lds_attr(ctx, eval_kernel<true, false, false, true>, eval_lds_bytes(ctx->n, true, false, true)))) return rc;
@@ -848,6 +861,8 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, true>, il))) return rc;
     if ((rc = set_lds_attr(ctx, iter_kernel<2, false, false>, il))) return rc;
     if ((rc = set_lds_attr(ctx, iter_kernel<2, false, true>, il))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<2, false, false, false, true>, il))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<2, false, true, false, true>, il))) return rc;
 #if CFMM_STAGED_WALK
     if (ctx->n <= 2 * EVAL_THREADS && iter_lds_bytes(ctx->n, false, true) <= LDS_MAX) {
         const size_t ilm = iter_lds_bytes(ctx->n, false, true);
@@ -948,7 +963,7 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
         if (grid > slots) grid = slots;
         if (grid < 1) grid = 1;                                 // (a shard without pools still takes the step)
     }
-    const bool dma = iter_dma(ctx);
+    const bool dma = iter_dma(ctx), nt = !dma && stream_nt(ctx);
     const size_t lds = iter_lds_bytes(n, ctx->det, dma);
     const dim3 g(grid), b(threads);
 #if CFMM_STAGED_WALK
@@ -957,7 +972,8 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
 #define ITER_LAUNCH_DMA if (false) { }
 #endif
 #define ITER_LAUNCH(EE) do { \
-        ITER_LAUNCH_DMA else if (ctx->det) { if (a.plain) hipLaunchKernelGGL((iter_kernel<EE, true, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<EE, true, false>), g, b, lds, ctx->stream, a); } \
+        ITER_LAUNCH_DMA else if (nt) { if (a.plain) hipLaunchKernelGGL((iter_kernel<2, false, true, false, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<2, false, false, false, true>), g, b, lds, ctx->stream, a); } \
+        else if (ctx->det) { if (a.plain) hipLaunchKernelGGL((iter_kernel<EE, true, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<EE, true, false>), g, b, lds, ctx->stream, a); } \
         else { if (a.plain) hipLaunchKernelGGL((iter_kernel<EE, false, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<EE, false, false>), g, b, lds, ctx->stream, a); } } while (0)
     if (E == 1) ITER_LAUNCH(ITER_E_SMALL); else ITER_LAUNCH(2);
 #undef ITER_LAUNCH

@@ -250,7 +250,8 @@ __host__ __device__ inline int iter_extra_lds_doubles(int n, bool dma = false)
 // DMA: the evaluation's tiles come through the staged walk (kernels.hpp), and every wave's FIRST tile is requested as soon
 // as the scalar section has decided that this launch evaluates at all -- its columns arrive while the direction and the
 // trial point are still being formed
-template <int E, bool DET = false, bool PLAIN = false, bool DMA = false>
+// NT: the pool columns through non-temporal loads (kernels.hpp: ld_off) -- pool sets several times the Infinity Cache
+template <int E, bool DET = false, bool PLAIN = false, bool DMA = false, bool NT = false>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 iter_kernel(IterArgs a)
 {
@@ -671,7 +672,7 @@ iter_kernel(IterArgs a)
         eval_tiles_and_flush<false, false, DET, false, true, true>(a.ev, a.acc3 + (size_t)p * a.acc_set, nu_s, psi_s, nullptr, fpart, next_tile, xs,
                                                                    BatchCtl{1u, 0, 0}, nullptr, stage0 + SLOT * wave, !dma_late);
     else
-    eval_tiles_and_flush<false, false, DET>(a.ev, a.acc3 + (size_t)p * a.acc_set, nu_s, psi_s, nullptr, fpart, next_tile, xs);
+    eval_tiles_and_flush<false, false, DET, false, true, false, NT>(a.ev, a.acc3 + (size_t)p * a.acc_set, nu_s, psi_s, nullptr, fpart, next_tile, xs);
 #ifdef CFMM_PHASE_TIMERS
     __syncthreads();
     if (a.ev.ts && tid == 0 && blockIdx.x < 256) a.ev.ts[64 + 8 * 4096 + 2 * blockIdx.x + 1] = wall_clock64();    // block end

@@ -182,10 +182,17 @@ __device__ __forceinline__ double wave_max(double v) { return wave_allmax(v); }
 //     conversion back to fp64 happens in a fixed order (det_fold_kernel).  F is chosen per problem from the largest reserve.
 // ------------------------------------------------------------------------------------------
 // element `i` of a column whose base is wave-uniform: byte offset formed in 32 bits (columns stay below 4 GB)
-template <class T>
+// NT: non-temporal.  A pool set several times the size of the Infinity Cache (256 MiB) gets nothing out of the cache levels on
+// its way to the CU -- every byte is used once per launch and evicted before the next -- and letting it allocate there costs
+// bandwidth: at 1.28 GB per evaluation (4e7 constant-product pools) the `nt` loads run the evaluation at 6.59 TB/s instead of
+// 6.16 (194 against 208 us).  At 320 MB, where the ping-pong walk finds most of a launch still cached, they LOSE (52.4 against
+// 47.8 us): the host takes the NT instantiations above twice the cache size only (cfmm_hip.hip: stream_nt).
+template <bool NT = false, class T>
 __device__ __forceinline__ T ld_off(const T *base, unsigned i)
 {
-    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(i * (unsigned)sizeof(T)));
+    const T *p = reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(i * (unsigned)sizeof(T)));
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
 
 template <bool DET> struct Scatter;
@@ -271,7 +278,7 @@ __device__ __forceinline__ const char *uni_ptr(const void *p)
 // 32 B (CP2, SUM2) or 40 B (W2, CURVE2, POW2: + the parameter column) of HBM per pool, read once.
 // ------------------------------------------------------------------------------------------
 // PRE: the columns come from `pre` (the staged walk: tile_stage_read) instead of global memory
-template <int KIND, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false>
+template <int KIND, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false, bool NT = false>
 __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, const double *nu_s,
                                       const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double &fsum, const BatchCtl &bc,
                                       const TileRegs *pre = nullptr)
@@ -294,9 +301,9 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
             ia[u] = live[u] ? pre->i[u] : 0; ib[u] = live[u] ? pre->i[U + u] : 0;     // (a dead lane holds a clamped chunk's tail: not a token id)
             prm[u] = (KIND == 1 || KIND >= 3) ? pre->d[U == 1 ? 3 : 0] : 0.0;
         } else {
-            Ra[u] = ld_off(b.Ra, i); Rb[u] = ld_off(b.Rb, i); g[u] = ld_off(b.fee, i);
-            ia[u] = ld_off(b.ia, i); ib[u] = ld_off(b.ib, i);
-            prm[u] = (KIND == 1 || KIND >= 3) ? ld_off(b.param, i) : 0.0;
+            Ra[u] = ld_off<NT>(b.Ra, i); Rb[u] = ld_off<NT>(b.Rb, i); g[u] = ld_off<NT>(b.fee, i);
+            ia[u] = ld_off<NT>(b.ia, i); ib[u] = ld_off<NT>(b.ib, i);
+            prm[u] = (KIND == 1 || KIND >= 3) ? ld_off<NT>(b.param, i) : 0.0;
         }
         fl[u] = (KIND == 2 && b.flags) ? ld_off(b.flags, i) : 0;
     }
@@ -359,7 +366,7 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
 template <int K>
 __host__ __device__ constexpr int pools_per_wave() { return ktile_pools(K); }
 
-template <int K, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false>
+template <int K, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false, bool NT = false>
 __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, const double *nu_s,
                                       const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double2 *xs, double &fsum, const BatchCtl &bc,
                                       const TileRegs *pre = nullptr)
@@ -378,7 +385,7 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
     int tok;
     double R, w, fee, lg;
     if constexpr (PRE) { tok = live ? pre->i[0] : 0; R = pre->d[0]; w = pre->d[1]; fee = pre->d[2]; lg = pre->d[3]; (void)leg; (void)pl; }     // (dead lanes: a neighbouring tile's legs or a clamped chunk's tail)
-    else { tok = ld_off(b.idx, leg); R = ld_off(b.R, leg); w = ld_off(b.w, leg); fee = ld_off(b.fee, pl); lg = ld_off(b.lfee, pl); }
+    else { tok = ld_off<NT>(b.idx, leg); R = ld_off<NT>(b.R, leg); w = ld_off<NT>(b.w, leg); fee = ld_off<NT>(b.fee, pl); lg = ld_off<NT>(b.lfee, pl); }
     const int gb = (g < P ? g : 0) * K;
 #pragma unroll 1
     for (unsigned mask = BATCH ? bc.alive : 1u; mask; mask &= mask - 1) {
@@ -603,7 +610,7 @@ __device__ __forceinline__ void build_tile_table(const EvalArgs &a, int *next_ti
 // workgroup (tiny.hpp)
 // DMA: the staged walk (above) -- `stage` is this wave's 4 KB LDS slot, `first_issued` says that the caller has already
 // issued the DMA of the wave's first tile (tiles_dma_first)
-template <bool WITH_D, bool STABLE, bool DET = false, bool BATCH = false, bool FLUSH = true, bool DMA = false>
+template <bool WITH_D, bool STABLE, bool DET = false, bool BATCH = false, bool FLUSH = true, bool DMA = false, bool NT = false>
 __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *acc, const double *nu_s, double *psi_t, double *diag_t,
                                                      double *fpart, int *next_tile, double2 *xs, const BatchCtl &bc = BatchCtl{1u, 0, 0},
                                                      double *const *acc_b = nullptr, const double *stage = nullptr, bool first_issued = false)
@@ -702,17 +709,17 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
         t_out += tc0 - t_prev;
 #endif
         switch (bk) {
-        case 0: if constexpr (!STABLE) { tilen<8, WITH_D, DET, BATCH>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 1: if constexpr (!STABLE) { tilen<7, WITH_D, DET, BATCH>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 2: if constexpr (!STABLE) { tilen<6, WITH_D, DET, BATCH>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 3: if constexpr (!STABLE) { tilen<5, WITH_D, DET, BATCH>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 4: if constexpr (!STABLE) { tilen<4, WITH_D, DET, BATCH>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 5: if constexpr (!STABLE) { tilen<3, WITH_D, DET, BATCH>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 6: if constexpr (STABLE) { tile2<3, WITH_D, DET, BATCH>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
-        case 7: if constexpr (STABLE) { tile2<4, WITH_D, DET, BATCH>(a.b2[4], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
-        case 8: if constexpr (!STABLE) { tile2<1, WITH_D, DET, BATCH>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
-        case 9: if constexpr (!STABLE) { tile2<0, WITH_D, DET, BATCH>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
-        default: if constexpr (!STABLE) { tile2<2, WITH_D, DET, BATCH>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 0: if constexpr (!STABLE) { tilen<8, WITH_D, DET, BATCH, false, NT>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 1: if constexpr (!STABLE) { tilen<7, WITH_D, DET, BATCH, false, NT>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 2: if constexpr (!STABLE) { tilen<6, WITH_D, DET, BATCH, false, NT>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 3: if constexpr (!STABLE) { tilen<5, WITH_D, DET, BATCH, false, NT>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 4: if constexpr (!STABLE) { tilen<4, WITH_D, DET, BATCH, false, NT>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 5: if constexpr (!STABLE) { tilen<3, WITH_D, DET, BATCH, false, NT>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 6: if constexpr (STABLE) { tile2<3, WITH_D, DET, BATCH, false, NT>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 7: if constexpr (STABLE) { tile2<4, WITH_D, DET, BATCH, false, NT>(a.b2[4], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 8: if constexpr (!STABLE) { tile2<1, WITH_D, DET, BATCH, false, NT>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 9: if constexpr (!STABLE) { tile2<0, WITH_D, DET, BATCH, false, NT>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        default: if constexpr (!STABLE) { tile2<2, WITH_D, DET, BATCH, false, NT>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
         }
 #ifdef CFMM_PHASE_TIMERS
         if (a.ts && lane == 0) {                       // per-wave tile log: ts[64 + 8 gw + i] = bucket << 48 | cycles
@@ -790,7 +797,7 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
 }
 
 // DMA: the staged tile walk; the launch then carries one 4 KB slot per wave behind the exchange strips
-template <bool WITH_D, bool STABLE, bool DET = false, bool DMA = false>
+template <bool WITH_D, bool STABLE, bool DET = false, bool DMA = false, bool NT = false>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 eval_kernel(EvalArgs a)
 {
@@ -818,7 +825,7 @@ eval_kernel(EvalArgs a)
         const double *stage = lds_raw + (STAGE_BYTES / 8) * (threadIdx.x >> 6);
         eval_tiles_and_flush<WITH_D, STABLE, DET, false, true, true>(a, a.acc, nu_s, psi_s, diag_s, fpart, next_tile, xs, BatchCtl{1u, 0, 0}, nullptr, stage, false);
     } else
-    eval_tiles_and_flush<WITH_D, STABLE, DET>(a, a.acc, nu_s, psi_s, diag_s, fpart, next_tile, xs);
+    eval_tiles_and_flush<WITH_D, STABLE, DET, false, true, false, NT>(a, a.acc, nu_s, psi_s, diag_s, fpart, next_tile, xs);
 #ifdef CFMM_PHASE_TIMERS
     __syncthreads();
     if (a.ts && threadIdx.x == 0 && blockIdx.x < 1024) a.ts[64 + 8 * 4096 + 2 * blockIdx.x + 1] = wall_clock64();    // block end
