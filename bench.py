@@ -394,14 +394,17 @@ def main():
             if newton_kernels:
                 nk = newton_kernels
                 nr = (net["n_tokens"] + 31) // 32 * 32
-                flops = nr ** 3 / 3.0
+                # n^3 / 3 for the factorisation + 2 n^3 / 3 for the inverse factor that rides its launches (chol.hpp, round 4: two
+                # 32^3 products per tile, ~n^3 / (6 x 32^3) tiles) -- the price of a back substitution that is one matrix-vector product
+                inverse_factor = os.environ.get("CFMM_BACKSUB", "") != "classic"
+                flops = nr ** 3 / 3.0 * (3.0 if inverse_factor else 1.0)
                 sm_bytes = dom["bytes"] + 16 * sum(len(prob.net[k]["Ra"]) for k in ("cp2", "w2", "curve2") if k in prob.net)     # + the warm starts: 8 B per direction
                 tf = flops / nk["factor"] / 1e12
                 out["roofline"].update({
-                    "bound": "valu", "kernel": "chol_step_kernel (the dense Cholesky of one Newton step: one launch per block column, all 32 of them)",
+                    "bound": "valu", "kernel": "chol_step_kernel (the dense Cholesky of one Newton step with its inverse factor: one launch per block column, all 32 of them)",
                     "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
                     "flop_frac": tf / FP64_VECTOR_PEAK_TFLOPS, "valu_frac": None, "hbm_frac": None, "traffic": None, "traffic_source": None,
-                    "flop_frac_note": f"n^3/3 flops of the {nr} x {nr} factorisation / its measured time, against the fp64 vector peak "
+                    "flop_frac_note": f"n^3/3 flops of the {nr} x {nr} factorisation (+ 2n^3/3 of the inverse factor riding along) / its measured time, against the fp64 vector peak "
                                       "(a flop rate, not the PMC issue fraction the other configs report as valu_frac)",
                     "valu_frac_note": None,
                     "avg_launch_us": nk["factor"] * 1e6, "algorithmic_bytes_per_launch": None,

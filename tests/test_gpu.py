@@ -991,3 +991,36 @@ def test_bench_multi_rank_path_end_to_end_on_one_gpu(tmp_path):
 def json_load_baseline():
     import json
     return json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "BASELINE.json")))
+
+
+def test_non_temporal_instantiations_match_the_oracle(oracle_lib, tmp_path):
+    """pool sets beyond twice the Infinity Cache stream their columns with non-temporal loads (kernels.hpp: ld_off<NT>; own
+    instantiations of eval_kernel / iter_kernel, taken automatically at >= 512 MB).  CFMM_NT=1 forces them on a small network,
+    in a process of its own (the knob is read once): same evaluation as the oracle to 1e-10, same certified solve."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json, numpy as np\n"
+        f"sys.path[:0] = [{root!r}, {os.path.join(root, 'cfmm-routing-code_amd')!r}]\n"
+        "import cfmm\nfrom cfmm import synthetic\n"
+        "net = synthetic.config('C3', scale=0.05)\n"
+        "p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net['c']))\n"
+        "nu = net['c'] * np.exp(np.random.default_rng(0).normal(0, 0.03, net['n_tokens']))\n"
+        "f, psi, diag = p.eval_dual(nu, want_diag=True)\n"
+        "v = p.solve(tol=1e-6)\n"
+        "print(json.dumps(dict(f=f, psi=psi.tolist(), diag=diag.tolist(), v=v, status=p.status, gap=p.gap, infeas=p.infeas)))\n")
+    env = dict(os.environ, CFMM_NT="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    net = synthetic.config("C3", scale=0.05)
+    o = _oracle_for(oracle_lib, net)
+    nu = net["c"] * np.exp(np.random.default_rng(0).normal(0, 0.03, net["n_tokens"]))
+    f0, psi0, diag0 = o.eval(nu, True)
+    assert abs(out["f"] - f0) <= 1e-10 * abs(f0) and np.abs(np.array(out["psi"]) - psi0).max() <= 1e-10 * np.abs(psi0).max()
+    assert np.abs(np.array(out["diag"]) - diag0).max() <= 1e-10 * np.abs(diag0).max()
+    ref = o.solve(net["c"], tol=1e-6)
+    assert out["status"] == "optimal" and out["gap"] <= 1e-6 and out["infeas"] <= 1e-6
+    assert abs(out["v"] - ref["primal_value"]) <= 2e-6 * abs(out["v"])
