@@ -34,6 +34,7 @@
 #include "smooth.hpp"
 #include "chol.hpp"
 #include "phik.hpp"
+#include "handoff.hpp"
 
 using namespace cfmm;
 
@@ -129,6 +130,9 @@ struct cfmm_ctx {
     long long *ts = nullptr;           // phase timers (tuning builds)
     char *dev_arena = nullptr, *host_arena = nullptr;   // every per-context device / pinned host buffer below is a piece of these
     double *pin = nullptr; size_t pin_cap = 0;          // pinned staging for the small per-call vectors of cfmm_eval_dual and the second-order loop (pin_scratch)
+    double *pin_dev = nullptr;                          // ... as the device sees it (handoff.hpp: the kernels read / write it themselves)
+    unsigned long long io_seq = 0;                      // sequence number of the last hand-off that publishes a flag
+    bool lean_io = true;                                // CFMM_NEWTON_IO=blit: hipMemcpyAsync / hipMemsetAsync + stream synchronisation instead (A/B)
     char *util_h = nullptr;            // pinned mirror of the device span c | h | glo | ghi | ctype
     size_t util_span = 0;
     DevState *hst = nullptr;          // pinned, 2 slots
@@ -1116,10 +1120,10 @@ int hess_ld(int n) { return hess_nr(n) + CH_NB; }                   // + the blo
 
 // in-place Cholesky of the lower triangle of ctx->H with the right-hand side in row nr (chol.hpp), then the back
 // substitution into `x`; *sm_info (device) = 0 or 1 + the first block column with a non-positive pivot
-int launch_factor(cfmm_ctx *ctx, int n)
+int launch_factor(cfmm_ctx *ctx, int n, bool info_zeroed = false)
 {
     const int nr = hess_nr(n), ld = hess_ld(n), nrows = nr + 1, nbk = nr / CH_NB;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->sm_info, 0, sizeof(int), ctx->stream));
+    if (!info_zeroed) HIP_TRY(ctx, hipMemsetAsync(ctx->sm_info, 0, sizeof(int), ctx->stream));
     const bool inv = ctx->inverse_factor && ctx->Winv;
     // one launch per block column: panel k1 beside the trailing update of panel k1 - NB (chol.hpp: chol_step_kernel)
     for (int k1 = 0; k1 < nr; k1 += CH_NB) {
@@ -1163,9 +1167,9 @@ int launch_chord(cfmm_ctx *ctx, int n, const double *g, double *x)
     HIP_TRY(ctx, hipGetLastError());
     return CFMM_OK;
 }
-int launch_cholesky(cfmm_ctx *ctx, int n, double *x)
+int launch_cholesky(cfmm_ctx *ctx, int n, double *x, bool info_zeroed = false)
 {
-    int rc = launch_factor(ctx, n);
+    int rc = launch_factor(ctx, n, info_zeroed);
     return rc ? rc : launch_backsolve(ctx, n, x);
 }
 
@@ -1220,14 +1224,56 @@ int refresh_global_counts(cfmm_ctx *ctx)
 // Pinned staging for the few-KB vectors that cross the bus inside a call (prices in, psi / a Newton direction out): a
 // hipMemcpyAsync on PAGEABLE memory is staged and effectively synchronous, ~10-20 us apiece -- with nine of them per Newton
 // step the device idled ~130 us per step of config 5.  Grown on demand, reused by every call (each call ends synchronised).
+// Layout (doubles), n = tokens: [0, 8n + 64) the second-order loop's vectors and the hand-off flag, behind it cfmm_eval_dual's.
+constexpr size_t PIN_FLAG_BACK = 8;             // the flag sits 8 doubles before the end of the loop's part
 double *pin_scratch(cfmm_ctx *ctx, size_t doubles)
 {
+    doubles = std::max(doubles, 8 * (size_t)ctx->n + 64);
     if (doubles > ctx->pin_cap) {
-        if (ctx->pin) { (void)hipHostFree(ctx->pin); ctx->pin = nullptr; ctx->pin_cap = 0; }
-        if (hipHostMalloc((void **)&ctx->pin, doubles * sizeof(double), hipHostMallocDefault) != hipSuccess) { ctx->pin = nullptr; return nullptr; }
+        if (ctx->pin) { (void)hipHostFree(ctx->pin); ctx->pin = nullptr; ctx->pin_dev = nullptr; ctx->pin_cap = 0; }
+        // (coherent: the kernels of handoff.hpp store results here and the host polls a flag behind them, without a stream synchronisation)
+        if (hipHostMalloc((void **)&ctx->pin, doubles * sizeof(double), hipHostMallocCoherent) != hipSuccess) { ctx->pin = nullptr; return nullptr; }
+        if (hipHostGetDevicePointer((void **)&ctx->pin_dev, ctx->pin, 0) != hipSuccess) { (void)hipHostFree(ctx->pin); ctx->pin = nullptr; ctx->pin_dev = nullptr; return nullptr; }
         ctx->pin_cap = doubles;
+        std::memset(ctx->pin, 0, doubles * sizeof(double));
     }
     return ctx->pin;
+}
+inline unsigned long long *io_flag_host(cfmm_ctx *ctx) { return reinterpret_cast<unsigned long long *>(ctx->pin + 8 * (size_t)ctx->n + 64 - PIN_FLAG_BACK); }
+template <class T> inline T *pin_device(cfmm_ctx *ctx, T *host) { return reinterpret_cast<T *>(reinterpret_cast<char *>(ctx->pin_dev) + (reinterpret_cast<char *>(host) - reinterpret_cast<char *>(ctx->pin))); }
+
+// One launch for a list of small copies / fills (handoff.hpp).  `publish`: a one-workgroup launch that ends with the next
+// sequence number in the pinned flag -- wait_io() polls it.
+struct IoList {
+    IoArgs a{};
+    size_t maxb = 0;
+    void copy(void *dst, const void *src, size_t bytes) { a.j[a.njobs++] = IoJob{dst, src, (unsigned long long)((bytes + 7) & ~(size_t)7)}; maxb = std::max(maxb, bytes); }
+    void zero(void *dst, size_t bytes) { copy(dst, nullptr, bytes); }
+};
+int launch_io(cfmm_ctx *ctx, IoList &l, bool publish)
+{
+    if (l.a.njobs < 1 || l.a.njobs > IO_MAX_JOBS) return fail(ctx, CFMM_E_STATE, "hand-off: %d jobs", l.a.njobs);
+    unsigned grid = 1;
+    if (publish) { l.a.flag = pin_device(ctx, io_flag_host(ctx)); l.a.seq = ++ctx->io_seq; }
+    else grid = (unsigned)std::min<size_t>(std::max<size_t>((l.maxb + 256 * 64 - 1) / (256 * 64), 1), 2 * (size_t)ctx->cus);
+    hipLaunchKernelGGL(io_kernel, dim3(grid), dim3(256), 0, ctx->stream, l.a);
+    HIP_TRY(ctx, hipGetLastError());
+    return CFMM_OK;
+}
+int wait_io(cfmm_ctx *ctx)
+{
+    volatile unsigned long long *f = io_flag_host(ctx);
+    const unsigned long long want = ctx->io_seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 1;; ++spin) {
+        if (*f == want) { std::atomic_thread_fence(std::memory_order_acquire); return CFMM_OK; }
+        __builtin_ia32_pause();
+        if ((spin & 0x3fff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+    }
+    // (two seconds without the flag: a fault, or a device shared with something long-running -- let the runtime say which)
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (*f == want) { std::atomic_thread_fence(std::memory_order_acquire); return CFMM_OK; }
+    return fail(ctx, CFMM_E_HIP, "hand-off: the stream drained without the kernel's flag (%llu, expected %llu)", (unsigned long long)*f, want);
 }
 
 int smooth_buffers(cfmm_ctx *ctx, bool hess)
@@ -1266,7 +1312,7 @@ int smooth_buffers(cfmm_ctx *ctx, bool hess)
 }
 
 // one smoothed evaluation at the prices already in ctx->nu (device)
-int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm, bool with_slo)
+int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm, bool with_slo, bool zeroed = false)
 {
     const int n = ctx->n;
     SmoothArgs a = {};
@@ -1277,8 +1323,10 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm, bool with_slo)
     long long tiles = 0;
     for (int q = 0; q < CFMM_POOL_KINDS2; ++q) { tiles += (a.b2[order[q]].m + 63) / 64; a.tile_end[q] = (int)tiles; }
     a.ntiles = (int)tiles; a.n = n; a.nu = ctx->nu; a.slo = with_slo ? ctx->sm_slo : nullptr; a.mu = mu; a.out = ctx->sm_out; a.H = hess ? ctx->H : nullptr; a.ldh = hess_ld(n);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->sm_out, 0, (size_t)(n + 2) * sizeof(double), ctx->stream));
-    if (hess) HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, (size_t)hess_ld(n) * hess_nr(n) * sizeof(double), ctx->stream));
+    if (!zeroed) {                           // (the second-order loop zeroes them in its hand-off launch: smooth_eval_host)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->sm_out, 0, (size_t)(n + 2) * sizeof(double), ctx->stream));
+        if (hess) HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, (size_t)hess_ld(n) * hess_nr(n) * sizeof(double), ctx->stream));
+    }
     const int per_block = SMOOTH_THREADS / 64;
     long long grid = (tiles + per_block - 1) / per_block;
     static const int grid_mult = getenv("CFMM_SMOOTH_GRID_MULT") ? std::max(1, atoi(getenv("CFMM_SMOOTH_GRID_MULT"))) : 1;     // tuning knob
@@ -1323,14 +1371,27 @@ int smooth_eval_host(cfmm_ctx *ctx, const std::vector<double> &nu, double mu, bo
     if (!pin) return fail(ctx, CFMM_E_HIP, "pinned staging (%d tokens)", n);
     double *pin_nu = pin, *pin_slo = pin + n, *pin_out = pin + 2 * n;             // [n] | [n] | [n + 2]
     std::memcpy(pin_nu, nu.data(), n * sizeof(double));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, pin_nu, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if (slo) {
-        std::memcpy(pin_slo, slo->data(), n * sizeof(double));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_slo, pin_slo, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (slo) std::memcpy(pin_slo, slo->data(), n * sizeof(double));
+    if (ctx->lean_io) {
+        // one launch: prices (and low-order part) down, output and Hessian zeroed; the evaluation; one launch: output up + flag
+        IoList l;
+        l.copy(ctx->nu, pin_device(ctx, pin_nu), n * sizeof(double));
+        if (slo) l.copy(ctx->sm_slo, pin_device(ctx, pin_slo), n * sizeof(double));
+        l.zero(ctx->sm_out, (size_t)(n + 2) * sizeof(double));
+        if (hess) l.zero(ctx->H, (size_t)hess_ld(n) * hess_nr(n) * sizeof(double));
+        if ((rc = launch_io(ctx, l, false))) return rc;
+        if ((rc = launch_smooth(ctx, mu, hess, warm, slo != nullptr, true))) return rc;
+        IoList p;
+        p.copy(pin_device(ctx, pin_out), ctx->sm_out, (size_t)(n + 2) * sizeof(double));
+        if ((rc = launch_io(ctx, p, true))) return rc;
+        if ((rc = wait_io(ctx))) return rc;
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, pin_nu, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if (slo) HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_slo, pin_slo, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = launch_smooth(ctx, mu, hess, warm, slo != nullptr))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(pin_out, ctx->sm_out, (size_t)(n + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    if ((rc = launch_smooth(ctx, mu, hess, warm, slo != nullptr))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(pin_out, ctx->sm_out, (size_t)(n + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     e.psi.assign(pin_out, pin_out + n);
     e.value = pin_out[n]; e.trade = pin_out[n + 1];
     return CFMM_OK;
@@ -1352,8 +1413,19 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     std::vector<double> s(n), nu(n), d(n), G(n), Hd(n), rhs(n), s2(n), nu2(n), psi_x(n);
     std::vector<int> mask(n), pin(n);
     std::vector<double> lob(n);                 // lower bound of the log-price: log c for a GE token with c > 0 (handled by projection)
-    HIP_TRY(ctx, hipMemcpyAsync(nu.data(), ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!pin_scratch(ctx, 8 * (size_t)n + 64 + n + (size_t)acc_stride(n))) return fail(ctx, CFMM_E_HIP, "pinned staging (%d tokens)", n);      // (the loop's part + cfmm_eval_dual's: no regrowth inside the loop)
+    if (ctx->lean_io) {                          // the start prices up; the warm starts of the per-direction solves zeroed (handoff.hpp)
+        IoList z;
+        for (int k = 0; k < CFMM_POOL_KINDS2; ++k) if (ctx->sm_ws[k]) z.zero(ctx->sm_ws[k], 2 * (size_t)ctx->pools->b2[k].m * sizeof(double));
+        if (z.a.njobs && (rc = launch_io(ctx, z, false))) return rc;
+        IoList p;
+        p.copy(pin_device(ctx, ctx->pin), ctx->nu_acc, n * sizeof(double));
+        if ((rc = launch_io(ctx, p, true)) || (rc = wait_io(ctx))) return rc;
+        std::memcpy(nu.data(), ctx->pin, n * sizeof(double));
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(nu.data(), ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     long long nbar = 0;
     for (int k = 0; k < CFMM_POOL_KINDS2; ++k) nbar += 2 * ctx->pools->b2[k].m;
     nbar += 2 * ctx->pools->b2[CFMM_POOL_SUM2].m;
@@ -1368,7 +1440,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         } else sj = std::max(sj, lob[j]);
         s[j] = sj; nu[j] = std::exp(sj);
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, mask.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    // (the pin mask goes down with every step's right-hand side; nothing reads sm_mask before that)
     if (sharded(ctx)) {                     // the barrier terms of the pools of every rank (the utility's are replicated)
         long long ge = 0;
         for (int j = 0; j < n; ++j) ge += ct[j] == CFMM_GE && !(c[j] > 0.0);
@@ -1401,8 +1473,9 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         return g;
     };
 
-    for (int k = 0; k < CFMM_POOL_KINDS2; ++k)
-        if (ctx->sm_ws[k]) HIP_TRY(ctx, hipMemsetAsync(ctx->sm_ws[k], 0, 2 * (size_t)ctx->pools->b2[k].m * sizeof(double), ctx->stream));
+    if (!ctx->lean_io)
+        for (int k = 0; k < CFMM_POOL_KINDS2; ++k)
+            if (ctx->sm_ws[k]) HIP_TRY(ctx, hipMemsetAsync(ctx->sm_ws[k], 0, 2 * (size_t)ctx->pools->b2[k].m * sizeof(double), ctx->stream));
     if ((rc = exact(nu))) return rc;
     double dual = arb_x;
     for (int j = 0; j < n; ++j) dual += (nu[j] - c[j]) * h[j];
@@ -1500,22 +1573,41 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         int *pin_mask = reinterpret_cast<int *>(ctx->pin + 7 * (size_t)n), *pin_info = pin_mask + n + (n & 1);
         std::memcpy(pin_mask, pin.data(), n * sizeof(int));
         std::memcpy(pin_vec, Hd.data(), n * sizeof(double)); std::memcpy(pin_vec + n, rhs.data(), n * sizeof(double));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, pin_mask, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, pin_vec, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        const bool lean = ctx->lean_io;
+        if (lean) {                                // [mask | diagonal | right-hand side] down and the factorisation's flag zeroed: one launch
+            IoList l;
+            l.copy(ctx->sm_mask, pin_device(ctx, pin_mask), n * sizeof(int));
+            l.copy(ctx->sm_vec, pin_device(ctx, pin_vec), 2 * (size_t)n * sizeof(double));
+            if (!use_chord) l.zero(ctx->sm_info, 2 * sizeof(int));
+            if ((rc = launch_io(ctx, l, false))) return rc;
+        } else {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, pin_mask, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, pin_vec, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        }
+        auto fetch = [&](bool with_info) -> int {   // the direction (and the factorisation's flag) back
+            if (lean) {
+                IoList p;
+                p.copy(pin_device(ctx, pin_d), ctx->sm_vec + n, n * sizeof(double));
+                if (with_info) p.copy(pin_device(ctx, pin_info), ctx->sm_info, 2 * sizeof(int));
+                int r = launch_io(ctx, p, true);
+                return r ? r : wait_io(ctx);
+            }
+            if (with_info) HIP_TRY(ctx, hipMemcpyAsync(pin_info, ctx->sm_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(pin_d, ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            return CFMM_OK;
+        };
         int info = 0;
         if (use_chord) {
             if ((rc = launch_chord(ctx, n, ctx->sm_vec + n, ctx->sm_vec + n))) return rc;
-            HIP_TRY(ctx, hipMemcpyAsync(pin_d, ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if ((rc = fetch(false))) return rc;
         } else {
             hipLaunchKernelGGL(hess_finish_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->H, n, hess_nr(n), hess_ld(n), (const double *)ctx->sm_vec,
                                (const int *)ctx->sm_mask, (const double *)(ctx->sm_vec + n));
             HIP_TRY(ctx, hipGetLastError());
-            if ((rc = launch_cholesky(ctx, n, ctx->sm_vec + n))) return rc;
+            if ((rc = launch_cholesky(ctx, n, ctx->sm_vec + n, lean))) return rc;
             e_has_h = false;                       // (factored in place: the assembled Hessian is gone)
-            HIP_TRY(ctx, hipMemcpyAsync(pin_info, ctx->sm_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(pin_d, ctx->sm_vec + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if ((rc = fetch(true))) return rc;
             info = *pin_info;
             fac_valid = info == 0; fac_mu = mu; chord_run = 0; chord_bad = false;
         }
@@ -1607,15 +1699,24 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     if (trace) fprintf(stderr, "[newton] %d steps, %d of them chord steps (no factorisation)\n", steps, chord_steps);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
     // leave the solution where the read-backs expect it: prices, the smoothed psi, the barrier weight for the tenders
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu_acc, nu.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if ((int)e.psi.size() == n) HIP_TRY(ctx, hipMemcpyAsync(ctx->psi_acc, e.psi.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->lean_io) {
+        IoList l;
+        std::memcpy(ctx->pin, nu.data(), n * sizeof(double));
+        l.copy(ctx->nu_acc, pin_device(ctx, ctx->pin), n * sizeof(double));
+        if ((int)e.psi.size() == n) { std::memcpy(ctx->pin + 2 * (size_t)n, e.psi.data(), n * sizeof(double)); l.copy(ctx->psi_acc, pin_device(ctx, ctx->pin + 2 * (size_t)n), n * sizeof(double)); }
+        if (slo_on) { std::memcpy(ctx->pin + n, slo.data(), n * sizeof(double)); l.copy(ctx->sm_slo, pin_device(ctx, ctx->pin + n), n * sizeof(double)); }
+        if ((rc = launch_io(ctx, l, false))) return rc;
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->nu_acc, nu.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if ((int)e.psi.size() == n) HIP_TRY(ctx, hipMemcpyAsync(ctx->psi_acc, e.psi.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(ctx->hsol, nu.data(), n * sizeof(double));
     if ((int)e.psi.size() == n) std::memcpy(ctx->hsol + n, e.psi.data(), n * sizeof(double));
     ctx->hsol_valid = true; ctx->have_nu = true;
     ctx->mu_last = mu;
     ctx->slo_active = slo_on;
-    if (slo_on) { HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_slo, slo.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+    if (slo_on && !ctx->lean_io) { HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_slo, slo.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
     const auto t1 = std::chrono::steady_clock::now();
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
@@ -1703,6 +1804,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if (const char *s = getenv("CFMM_FUSED")) ctx->fused = atoi(s) != 0;
     if (const char *s = getenv("CFMM_TILE_DMA")) ctx->tile_dma = atoi(s) != 0;
     if (const char *s = getenv("CFMM_BACKSUB")) ctx->inverse_factor = std::string(s) != "classic";
+    if (const char *s = getenv("CFMM_NEWTON_IO")) ctx->lean_io = std::string(s) != "blit";
     if (const char *s = getenv("CFMM_TINY")) ctx->tiny_path = atoi(s) != 0;
     if (const char *s = getenv("CFMM_RUN_AHEAD")) ctx->run_ahead = std::max(1, atoi(s));
     if (const char *s = getenv("CFMM_DETERMINISTIC")) ctx->det = atoi(s) != 0;
@@ -2304,12 +2406,22 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
     if (!pinb) return fail(ctx, CFMM_E_HIP, "pinned staging (%d tokens)", n);
     double *pin_nu = pinb + 8 * (size_t)n + 64, *pin_acc = pin_nu + n;
     std::memcpy(pin_nu, nu, n * sizeof(double));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, pin_nu, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->nu + n, 0, sizeof(double), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
     { double mx = 0.0; for (int j = 0; j < n; ++j) mx = std::max(mx, nu[j]); ctx->nu_max = mx; }
     if (ctx->det && sharded(ctx)) { int rc = refresh_global_counts(ctx); if (rc) return rc; }      // (the fixed-point exponent is a global quantity)
-    if (ctx->det) HIP_TRY(ctx, hipMemsetAsync(ctx->acc_l, 0, 6 * (size_t)n * sizeof(unsigned long long), ctx->stream));
+    const bool lean = ctx->lean_io;
+    if (lean) {                                  // prices down, accumulators zeroed: one launch (handoff.hpp)
+        IoList l;
+        l.copy(ctx->nu, pin_device(ctx, pin_nu), n * sizeof(double));
+        l.zero(ctx->nu + n, sizeof(double));
+        l.zero(ctx->acc, (size_t)ctx->nslices * acc_stride(n) * sizeof(double));
+        if (ctx->det) l.zero(ctx->acc_l, 6 * (size_t)n * sizeof(unsigned long long));
+        int rc = launch_io(ctx, l, false); if (rc) return rc;
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, pin_nu, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->nu + n, 0, sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
+        if (ctx->det) HIP_TRY(ctx, hipMemsetAsync(ctx->acc_l, 0, 6 * (size_t)n * sizeof(unsigned long long), ctx->stream));
+    }
     if (diag) launch_all_evals<true>(ctx); else launch_all_evals<false>(ctx);
     if (ctx->det) { int rc = det_finish(ctx, ctx->acc, ctx->nu, diag != nullptr); if (rc) return rc; }
     else hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, n, ctx->nslices, 1, (const DevState *)nullptr);
@@ -2317,9 +2429,17 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
     if (sharded(ctx) && !ctx->det) {            // pool-sharded (a communicator of one rank runs the same path)
         int rc = all_reduce(ctx, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(pin_acc, ctx->acc, len * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)len * sizeof(double), ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (lean) {                                  // the folded slice up, then zeroed (same element -> thread mapping), + flag: one launch
+        IoList p;
+        p.copy(pin_device(ctx, pin_acc), ctx->acc, len * sizeof(double));
+        p.zero(ctx->acc, (size_t)len * sizeof(double));
+        int rc = launch_io(ctx, p, true); if (rc) return rc;
+        if ((rc = wait_io(ctx))) return rc;
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(pin_acc, ctx->acc, len * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)len * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (psi) std::memcpy(psi, pin_acc, n * sizeof(double));
     if (arb_sum) *arb_sum = pin_acc[acc_arb(n)];
     if (diag) std::memcpy(diag, pin_acc + acc_diag(n), n * sizeof(double));
