@@ -132,6 +132,7 @@ struct cfmm_ctx {
     double *pin = nullptr; size_t pin_cap = 0;          // pinned staging for the small per-call vectors of cfmm_eval_dual and the second-order loop (pin_scratch)
     double *pin_dev = nullptr;                          // ... as the device sees it (handoff.hpp: the kernels read / write it themselves)
     unsigned long long io_seq = 0;                      // sequence number of the last hand-off that publishes a flag
+    bool h_clean = false;                               // the Hessian buffer has been zeroed since its last use (solve_newton zeroes it behind a direction, under the host's own work)
     bool lean_io = true;                                // CFMM_NEWTON_IO=blit: hipMemcpyAsync / hipMemsetAsync + stream synchronisation instead (A/B)
     char *util_h = nullptr;            // pinned mirror of the device span c | h | glo | ghi | ctype
     size_t util_span = 0;
@@ -1160,7 +1161,7 @@ int launch_chord(cfmm_ctx *ctx, int n, const double *g, double *x)
 {
     const int nr = hess_nr(n);
     if (!(ctx->inverse_factor && ctx->Winv)) return fail(ctx, CFMM_E_STATE, "chord step: no inverse factor (CFMM_BACKSUB=classic)");
-    hipLaunchKernelGGL(chol_w_kernel, dim3((nr + CH_W_THREADS - 1) / CH_W_THREADS), dim3(CH_W_THREADS), 0, ctx->stream,
+    hipLaunchKernelGGL(chol_w_kernel, dim3((nr + CH_W_ROWS - 1) / CH_W_ROWS), dim3(CH_W_THREADS), 0, ctx->stream,
                        g, nr, n, (const double *)ctx->Dinv, (const double *)ctx->Winv, (const double *)ctx->Rinv, nr, ctx->chord_y);
     hipLaunchKernelGGL(chol_wt_kernel, dim3((nr + CH_WT_THREADS / 64 - 1) / (CH_WT_THREADS / 64)), dim3(CH_WT_THREADS), 0, ctx->stream,
                        (const double *)ctx->chord_y, 1, nr, n, (const double *)ctx->Dinv, (const double *)ctx->Winv, (const double *)ctx->Rinv, nr, x);
@@ -1378,7 +1379,8 @@ int smooth_eval_host(cfmm_ctx *ctx, const std::vector<double> &nu, double mu, bo
         l.copy(ctx->nu, pin_device(ctx, pin_nu), n * sizeof(double));
         if (slo) l.copy(ctx->sm_slo, pin_device(ctx, pin_slo), n * sizeof(double));
         l.zero(ctx->sm_out, (size_t)(n + 2) * sizeof(double));
-        if (hess) l.zero(ctx->H, (size_t)hess_ld(n) * hess_nr(n) * sizeof(double));
+        if (hess && !ctx->h_clean) l.zero(ctx->H, (size_t)hess_ld(n) * hess_nr(n) * sizeof(double));
+        if (hess) ctx->h_clean = false;
         if ((rc = launch_io(ctx, l, false))) return rc;
         if ((rc = launch_smooth(ctx, mu, hess, warm, slo != nullptr, true))) return rc;
         IoList p;
@@ -1453,6 +1455,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     }
 
     const std::vector<double> s_start = s;
+    ctx->h_clean = false;
     int evals = evals_before, steps = 0, status = 0;
     double arb_x = 0.0;
     auto exact = [&](const std::vector<double> &p) { ++evals; return cfmm_eval_dual(ctx, p.data(), &arb_x, psi_x.data(), nullptr); };
@@ -1609,6 +1612,12 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             e_has_h = false;                       // (factored in place: the assembled Hessian is gone)
             if ((rc = fetch(true))) return rc;
             info = *pin_info;
+            if (lean) {                            // the factor has served (chord steps go through the inverse factor): zero the 8.6 MB for the next
+                IoList z;                          // Hessian NOW, under the host's work on the trial point, instead of in front of that evaluation
+                z.zero(ctx->H, (size_t)hess_ld(n) * hess_nr(n) * sizeof(double));
+                if ((rc = launch_io(ctx, z, false))) return rc;
+                ctx->h_clean = true;
+            }
             fac_valid = info == 0; fac_mu = mu; chord_run = 0; chord_bad = false;
         }
         d.assign(pin_d, pin_d + n);

@@ -472,34 +472,45 @@ chol_wt_kernel(const double *__restrict__ yv, int ys, int nr, int n, const doubl
 //     k in block i <= nb - 2:   y_k = sum_{c < i NB} W[k][c] g_c + sum_{c <= k in the block} Linv_i[k][c] g_c
 //     last block:               y = Linv_last (g_last + sum_{c < last NB} R[last rows][c] g_c)
 // g is masked (pinned tokens carry identity rows in the factored matrix: their g is what comes out).
-constexpr int CH_W_THREADS = 64;
+constexpr int CH_W_ROWS = 64, CH_W_SLICES = 16, CH_W_THREADS = CH_W_ROWS * CH_W_SLICES;
 __global__ void __launch_bounds__(CH_W_THREADS)
 chol_w_kernel(const double *__restrict__ g, int nr, int n, const double *__restrict__ Dinv, const double *__restrict__ Wm,
               const double *__restrict__ Rm, int ldw, double *__restrict__ y)
 {
+    // 64 rows per workgroup, the columns dealt to 16 waves in groups of four (wave s: columns 4 s + 64 t ...): a row's sum is
+    // 1000 terms long, one thread per row with four loads in flight took 85 us for the 16 workgroups; partial sums meet in LDS
+    // and are added in wave order
     constexpr int NB = CH_NB;
-    __shared__ double t_s[CH_W_THREADS];
+    __shared__ double t_s[CH_W_ROWS];
+    __shared__ double part[CH_W_SLICES][CH_W_ROWS];
     const int nb = nr / NB, last = nb - 1;
-    const int k = (int)blockIdx.x * CH_W_THREADS + threadIdx.x;
+    const int r = threadIdx.x & (CH_W_ROWS - 1), sl = threadIdx.x / CH_W_ROWS;
+    const int k = (int)blockIdx.x * CH_W_ROWS + r;
     const int ib = k / NB, kk = k - ib * NB;
     const bool islast = ib == last;
     const double *M = islast ? Rm : Wm;                       // strictly-lower part: finished W rows, or the last row's residual
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    const int cend = ib * NB;
+    const int cend = ib * NB;                                 // (a multiple of 4)
     if (k < nr) {
-        for (int c = 0; c + 4 <= cend; c += 4) {
+        for (int c = 4 * sl; c + 4 <= cend; c += 4 * CH_W_SLICES) {
             a0 = fma(M[(size_t)c * ldw + k], c < n ? g[c] : 0.0, a0);
             a1 = fma(M[(size_t)(c + 1) * ldw + k], c + 1 < n ? g[c + 1] : 0.0, a1);
             a2 = fma(M[(size_t)(c + 2) * ldw + k], c + 2 < n ? g[c + 2] : 0.0, a2);
             a3 = fma(M[(size_t)(c + 3) * ldw + k], c + 3 < n ? g[c + 3] : 0.0, a3);
         }
     }
-    double acc = (a0 + a1) + (a2 + a3);
-    if (islast && k < nr) acc += k < n ? g[k] : 0.0;          // t = g_last + R_last g
-    t_s[threadIdx.x] = islast ? acc : (k < n ? g[k] : 0.0);   // the diagonal block's input: t (last block) or g (the others)
+    part[sl][r] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (k >= nr) return;
-    const int base = (threadIdx.x / NB) * NB;                 // this row's block inside the workgroup's 64 rows
+    double acc = 0.0;
+    if (sl == 0) {
+#pragma unroll
+        for (int q = 0; q < CH_W_SLICES; ++q) acc += part[q][r];
+        if (islast && k < nr) acc += k < n ? g[k] : 0.0;      // t = g_last + R_last g
+        t_s[r] = islast ? acc : (k < n ? g[k] : 0.0);         // the diagonal block's input: t (last block) or g (the others)
+    }
+    __syncthreads();
+    if (sl != 0 || k >= nr) return;
+    const int base = (r / NB) * NB;                           // this row's block inside the workgroup's 64 rows
     double d = 0.0;
     for (int cc = 0; cc <= kk; ++cc) d = fma(Dinv[(size_t)ib * NB * NB + kk * NB + cc], t_s[base + cc], d);
     y[k] = islast ? d : acc + d;
