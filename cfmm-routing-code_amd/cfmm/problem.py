@@ -171,7 +171,7 @@ def network_pool_count(net):
 def shard_network(net, rank, world):
     """Pool-sharding: contiguous equal-count slices of every bucket; tokens,
     prices and the utility stay replicated."""
-    out = {k: v for k, v in net.items() if k not in KIND2 and k not in ("gn", "gk")}
+    out = {k: v for k, v in net.items() if k not in KIND2 and k not in ("gn", "gk") and not str(k).startswith("_")}      # (not the per-network caches: _price_relations, _potentials)
 
     def sl(m):
         lo = (m * rank) // world
@@ -216,10 +216,14 @@ def start_prices(net, util):
     return out
 
 
-def _propagate_prices(net, c, known):
+def _price_relations(net):
+    """(eu, ev, lr): log p_eu - log p_ev = lr, the pools' marginal prices at their current reserves -- a property of the
+    network alone, built once per network (kept in the dict under a private key; shard_network builds new dicts)."""
+    rel = net.get("_price_relations")
+    if rel is not None:
+        return rel
     n = net["n_tokens"]
-    logp = np.where(known, np.log(np.where(known, c, 1.0)), 0.0)
-    eu, ev, elr = [], [], []          # log p_u - log p_v = lr
+    eu, ev, elr = [], [], []
     # a rough guess is all this has to be (the solvers start by repairing it): on large networks every bucket is
     # thinned to an evenly strided sample, ~64 price relations per token in all
     total = sum(len(net[k]["Ra"]) for k in KIND2 if k in net) + \
@@ -249,24 +253,83 @@ def _propagate_prices(net, c, known):
         for j in range(1, k):
             eu.append(b["idx"][j][sl]); ev.append(b["idx"][0][sl])
             elr.append(np.log(b["w"][j][sl] * b["R"][0][sl] / (b["w"][0][sl] * b["R"][j][sl])))
-    if not eu:
-        return np.where(known, c, 1.0)
-    eu = np.concatenate(eu); ev = np.concatenate(ev); elr = np.concatenate(elr)
-    for _ in range(64):
-        if known.all():
+    if eu:
+        rel = (np.concatenate(eu).astype(np.int64), np.concatenate(ev).astype(np.int64), np.concatenate(elr))
+    else:
+        rel = (np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0))
+    net["_price_relations"] = rel
+    return rel
+
+
+def _potentials(net):
+    """(phi, comp): log-price potentials of the tokens, the least-squares fit  min sum (phi_u - phi_v - lr)^2  over the
+    network's price relations (one free constant per connected component), and the component of every token.  A property of
+    the pools alone: solved once per network (sparse conjugate gradients; a few ms at 1000 tokens), after which the start prices of
+    ANY utility cost O(n).  (Round 3 walked the relations breadth-first from the utility's priced tokens on every new utility:
+    2-3 ms of host time per config-5 solve, hidden behind a per-utility memo.)"""
+    pot = net.get("_potentials")
+    if pot is not None:
+        return pot
+    n = net["n_tokens"]
+    eu, ev, lr = _price_relations(net)
+    if not len(eu):
+        pot = (np.zeros(n), np.arange(n))
+        net["_potentials"] = pot
+        return pot
+    # connected components: min-label propagation with pointer jumping (O(log n) rounds of two scatter-mins)
+    comp = np.arange(n)
+    while True:
+        new = comp.copy()
+        np.minimum.at(new, eu, comp[ev])
+        np.minimum.at(new, ev, comp[eu])
+        new = new[new]
+        if np.array_equal(new, comp):
             break
-        f1 = known[ev] & ~known[eu]
-        f2 = known[eu] & ~known[ev]
-        if not (f1.any() or f2.any()):
+        comp = new
+    comp = np.unique(comp, return_inverse=True)[1]
+    deg = (np.bincount(eu, minlength=n) + np.bincount(ev, minlength=n)).astype(float)
+
+    def adj(x):                                            # A x for the (multi-)graph's adjacency matrix: two gathers, two scatter-adds
+        return np.bincount(eu, weights=x[ev], minlength=n) + np.bincount(ev, weights=x[eu], minlength=n)
+    rhs = np.bincount(eu, weights=lr, minlength=n) - np.bincount(ev, weights=lr, minlength=n)
+    # Jacobi-preconditioned conjugate gradients on the graph Laplacian L = D - A (singular by one constant per component; the
+    # right-hand side is orthogonal to those, and the iteration started at zero never leaves their complement)
+    dinv = 1.0 / np.maximum(deg, 1.0)
+    phi = np.zeros(n)
+    r = rhs.copy()
+    z = dinv * r
+    pdir = z.copy()
+    rz = float(r @ z)
+    stop = 1e-12 * max(float(np.abs(rhs).max()), 1e-300)
+    for _ in range(4 * n + 100):
+        if float(np.abs(r).max()) <= stop:
             break
-        tok = np.concatenate([eu[f1], ev[f2]])
-        val = np.concatenate([logp[ev[f1]] + elr[f1], logp[eu[f2]] - elr[f2]])
-        cnt = np.bincount(tok, minlength=n)
-        s = np.bincount(tok, weights=val, minlength=n)
-        new = cnt > 0
-        logp[new] = s[new] / cnt[new]
-        known = known | new
-    return np.exp(logp)
+        q = deg * pdir - adj(pdir)
+        alpha = rz / float(pdir @ q)
+        phi += alpha * pdir
+        r -= alpha * q
+        z = dinv * r
+        rz_new = float(r @ z)
+        pdir = z + (rz_new / rz) * pdir
+        rz = rz_new
+    nc = int(comp.max()) + 1                              # gauge: zero mean per component
+    phi -= (np.bincount(comp, weights=phi, minlength=nc) / np.bincount(comp, minlength=nc))[comp]
+    pot = (phi, comp)
+    net["_potentials"] = pot
+    return pot
+
+
+def _propagate_prices(net, c, known):
+    """unpriced tokens from the network's potentials (above), shifted per connected component to agree on average with the
+    prices the utility names there; a component the utility prices nowhere gets 1"""
+    n = net["n_tokens"]
+    phi, comp = _potentials(net)
+    nc = int(comp.max()) + 1
+    lc = np.log(np.where(known, c, 1.0))
+    cnt = np.bincount(comp[known], minlength=nc)
+    off = np.bincount(comp[known], weights=(lc - phi)[known], minlength=nc) / np.maximum(cnt, 1)
+    logp = np.where(cnt[comp] > 0, phi + off[comp], 0.0)
+    return np.where(known, c, np.exp(logp))
 
 
 # ------------------------------------------------------------------------------- ties (kinks)
