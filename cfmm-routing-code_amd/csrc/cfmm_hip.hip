@@ -33,6 +33,7 @@
 #include "oneshot.hpp"
 #include "smooth.hpp"
 #include "chol.hpp"
+#include "chol2.hpp"
 #include "phik.hpp"
 #include "handoff.hpp"
 
@@ -206,6 +207,7 @@ struct cfmm_ctx {
     double *sm_out = nullptr, *sm_vec = nullptr, *H = nullptr, *Dinv = nullptr;
     double *Winv = nullptr, *Rinv = nullptr;     // the inverse factor riding the factorisation, and its running residual (chol.hpp: round 4)
     double *chord_y = nullptr;                  // [nr] the intermediate of a chord step (launch_chord)
+    bool chol_pairs = true;                     // CFMM_CHOL=single: one block column per launch (chol.hpp: chol_step_kernel) instead of two (chol2.hpp)  (A/B)
     bool inverse_factor = true;                 // CFMM_BACKSUB=classic: the one-workgroup back substitution instead (A/B)
     double *sm_ws[CFMM_POOL_KINDS2] = {};   // warm starts of the smoothed per-direction solves
     long long sm_ws_m[CFMM_POOL_KINDS2] = {};
@@ -1116,7 +1118,7 @@ extern "C" int64_t cfmm_pool_count(cfmm_ctx *ctx);
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-int hess_nr(int n) { return (n + CH_NB - 1) / CH_NB * CH_NB; }      // tokens rounded up to the Cholesky block
+int hess_nr(int n) { return (n + 2 * CH_NB - 1) / (2 * CH_NB) * (2 * CH_NB); }      // tokens rounded up to a PAIR of Cholesky blocks (chol2.hpp)
 int hess_ld(int n) { return hess_nr(n) + CH_NB; }                   // + the block row that carries the right-hand side
 
 // in-place Cholesky of the lower triangle of ctx->H with the right-hand side in row nr (chol.hpp), then the back
@@ -1126,6 +1128,27 @@ int launch_factor(cfmm_ctx *ctx, int n, bool info_zeroed = false)
     const int nr = hess_nr(n), ld = hess_ld(n), nrows = nr + 1, nbk = nr / CH_NB;
     if (!info_zeroed) HIP_TRY(ctx, hipMemsetAsync(ctx->sm_info, 0, sizeof(int), ctx->stream));
     const bool inv = ctx->inverse_factor && ctx->Winv;
+    if (ctx->chol_pairs) {
+        // one launch per PAIR of block columns (chol2.hpp: chol_step2_kernel) + one with the inverse-factor role alone
+        const size_t lds = (size_t)CH2_LDS_DOUBLES * sizeof(double);
+        for (int c0 = 0; c0 < nr; c0 += 2 * CH_NB) {
+            const int below = nrows - c0 - 2 * CH_NB;              // rows under the pair's diagonal region, the right-hand side's included
+            const int npanel = 1 + (below + CH2_ROWS - 1) / CH2_ROWS;
+            int ntiles = 0;
+            if (c0 > 0 && nr - c0 - 2 * CH_NB > 0) { const int T = (below + 63) / 64; ntiles = T * (T + 1) / 2; }
+            const int qb = c0 / CH_NB - 1;                         // the previous pair's block rows qb - 1, qb of the inverse factor
+            const int ntw = (inv && c0 > 0) ? (nbk - 1 - qb) * (qb + 1) : 0;
+            // (one workgroup per CU -- the panel role's LDS: side tasks beyond the chip's width ride with earlier ones)
+            const int nside = std::min(ntw + ntiles, std::max(ctx->cus - npanel, 1));
+            hipLaunchKernelGGL(chol_step2_kernel, dim3(npanel + nside), dim3(256), lds, ctx->stream, ctx->H, ld, nrows, nr, c0, npanel, ctx->Dinv, ctx->sm_info,
+                               npanel + ntw, ctx->Winv, ctx->Rinv, nr, 0, ntw + ntiles);
+        }
+        if (inv && nbk >= 2)                                       // block row nbk - 2 (the last one is never formed: chol_wt_kernel)
+            hipLaunchKernelGGL(chol_step2_kernel, dim3(nbk - 1), dim3(256), lds, ctx->stream, ctx->H, ld, nrows, nr, nr, 0, ctx->Dinv, ctx->sm_info,
+                               nbk - 1, ctx->Winv, ctx->Rinv, nr, 1, nbk - 1);
+        HIP_TRY(ctx, hipGetLastError());
+        return CFMM_OK;
+    }
     // one launch per block column: panel k1 beside the trailing update of panel k1 - NB (chol.hpp: chol_step_kernel)
     for (int k1 = 0; k1 < nr; k1 += CH_NB) {
         const int below = nrows - k1 - CH_NB;                  // rows under the diagonal block, the right-hand side's included
@@ -1307,6 +1330,7 @@ int smooth_buffers(cfmm_ctx *ctx, bool hess)
             HIP_TRY(ctx, hipMemsetAsync(ctx->Winv, 0, nr * nr * sizeof(double), ctx->stream));
         }
         rc = dev_upload<int>(ctx, &ctx->sm_info, nullptr, 4, nullptr); if (rc) return rc;
+        if ((rc = set_lds_attr(ctx, chol_step2_kernel, (size_t)CH2_LDS_DOUBLES * sizeof(double)))) return rc;
         if ((rc = set_lds_attr(ctx, chol_back_kernel, (nr + CH_NB + 2 * CH_NB * CH_NB) * sizeof(double)))) return rc;
     }
     return CFMM_OK;
@@ -1813,6 +1837,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
     if (const char *s = getenv("CFMM_FUSED")) ctx->fused = atoi(s) != 0;
     if (const char *s = getenv("CFMM_TILE_DMA")) ctx->tile_dma = atoi(s) != 0;
     if (const char *s = getenv("CFMM_BACKSUB")) ctx->inverse_factor = std::string(s) != "classic";
+    if (const char *s = getenv("CFMM_CHOL")) ctx->chol_pairs = std::string(s) != "single";
     if (const char *s = getenv("CFMM_NEWTON_IO")) ctx->lean_io = std::string(s) != "blit";
     if (const char *s = getenv("CFMM_TINY")) ctx->tiny_path = atoi(s) != 0;
     if (const char *s = getenv("CFMM_RUN_AHEAD")) ctx->run_ahead = std::max(1, atoi(s));
@@ -2456,6 +2481,14 @@ int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi
     return CFMM_OK;
 }
 
+#ifdef CFMM_CH2_STAMPS
+int cfmm_debug_ch2_stamps(cfmm_ctx *ctx, uint64_t *out64)
+{
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpyFromSymbol(out64, HIP_SYMBOL(cfmm::g_ch2_stamps), 64 * sizeof(uint64_t)));
+    return CFMM_OK;
+}
+#endif
 #ifdef CFMM_SMOOTH_HIST
 int cfmm_debug_smooth_hist(cfmm_ctx *ctx, uint64_t *out128, int reset)
 {

@@ -1,0 +1,21 @@
+import sys, os, ctypes as C
+sys.path[:0] = ['/root/repo', '/root/repo/cfmm-routing-code_amd']
+os.environ["CFMM_LIB"] = "/root/repo/cfmm-routing-code_amd/cfmm/variants/libcfmm_hip_ch2stamps.so"
+import numpy as np
+import cfmm
+from cfmm import synthetic
+net = synthetic.config("C5")
+n = net["n_tokens"]; rng = np.random.default_rng(1)
+h = np.zeros(n); idx = rng.choice(n, 10, replace=False); h[idx] = np.exp(rng.normal(2, 0.5, 10)) / net["prices"][idx] * 10
+t = int(rng.integers(0, n)); h[t] = 0
+p = cfmm.Problem.from_network(net, utility=cfmm.Liquidate(h, t))
+for _ in range(3): p.solve(method="newton")
+out = (C.c_uint64 * 64)()
+L = p.ctx.L
+L.cfmm_debug_ch2_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+L.cfmm_debug_ch2_stamps(p.ctx.h, out)
+s = np.array(out[:], dtype=np.int64).reshape(4, 16)
+t0 = s[0, 0]
+names = ["start", "loaded", "h0 pre done", "h0 work done", "h0 barrier", "h1 pre done", "h1 work done", "h1 barrier", "end"]
+for w in range(4):
+    print("wave", w, " ".join("%s=%.2f" % (names[i], (s[w, i] - t0) / 100.0) for i in range(9)))
