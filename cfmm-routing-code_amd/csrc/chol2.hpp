@@ -27,7 +27,7 @@
 namespace cfmm {
 
 constexpr int CH2_ROWS = 32;             // rows of a panel workgroup (64: the side waves' products outlast wave 0's factorisations)
-constexpr int CH2_PANEL_LDS = 2 * 2048 + 64 * CH2_ROWS + 2 * CH_NB * CH2_ROWS + 2 * (CH_NB * (CH_NB + 1)) + 4 * CH_NB * CH_NB + 128 + 8;      // doubles
+constexpr int CH2_PANEL_LDS = 2 * 2048 + 64 * CH2_ROWS + 2 * CH_NB * CH2_ROWS + 2 * (CH_NB * (CH_NB + 1)) + 6 * CH_NB * CH_NB + 128 + 8;      // doubles
 constexpr int CH2_TILE_LDS = 2 * 64 * 65;
 constexpr int CH2_W_LDS = 9 * CH_NB * CH_NB;
 constexpr int CH2_LDS_DOUBLES = CH2_PANEL_LDS > CH2_TILE_LDS ? (CH2_PANEL_LDS > CH2_W_LDS ? CH2_PANEL_LDS : CH2_W_LDS) : (CH2_TILE_LDS > CH2_W_LDS ? CH2_TILE_LDS : CH2_W_LDS);
@@ -61,7 +61,7 @@ __device__ __forceinline__ void mm_acc(double (&acc)[TM][TN], const double *Ak, 
 typedef double ch2_f64x4 __attribute__((ext_vector_type(4)));
 #ifdef CFMM_CH2_STAMPS
 __device__ unsigned long long g_ch2_stamps[64];
-#define CH2_STAMP(i) do { if (c0 == 512 && blockIdx.x == 1 && (tid & 63) == 0) g_ch2_stamps[(i) + 16 * (tid >> 6)] = wall_clock64(); } while (0)
+#define CH2_STAMP(i) do { if (c0 == 512 && blockIdx.x == CFMM_CH2_STAMP_WG && (tid & 63) == 0) g_ch2_stamps[(i) + 16 * (tid >> 6)] = wall_clock64(); } while (0)
 #else
 #define CH2_STAMP(i) do { } while (0)
 #endif
@@ -255,6 +255,7 @@ chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, 
     double *Lba = Lib + NB * NB;             // Lba[c * 32 + r] = L_ba[r][c]
     double *Lbx = Lba + NB * NB;             // WaveFactor's exchange (128)
     int *sub = reinterpret_cast<int *>(Lbx + 128);                // the side waves' own rendezvous (phase 4)
+    double *Lfac = Lbx + 128 + 8;            // workgroup 0: the two factored diagonal blocks on their way out, Lfac[h][j * 32 + c] = L[c][j]
     double *Xo = Pda;
     const bool diag_wg = blockIdx.x == 0;
     const int row0 = c0 + 2 * NB + RW * ((int)blockIdx.x - 1);
@@ -362,11 +363,12 @@ chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, 
                 for (int j = 0; j < NB; j += 2) *reinterpret_cast<double2 *>(Li + c * NB + j) = make_double2(a[j], a[j + 1]);      // Li[k = c][j] = Linv[j][c]
             }
             if (diag_wg) {
+                // (the factor leaves through LDS: the other waves write it out -- 64 scattered global stores per lane at the end of
+                //  BOTH factorisations made workgroup 0's chain 17 us where the row workgroups' is 13.8, and the launch lasts as long)
                 if (!ok && lane == 0) atomicMax(info, kcol + 1);
+                if (lane < NB) {
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    if (lane < NB) A[(size_t)(kcol + j) * ld + kcol + c] = (j <= c) ? a[j] : 0.0;       // L[c][j]
-                    else Dinv[(size_t)(kcol / NB) * NB * NB + j * NB + c] = a[j];                        // Linv[j][c]
+                    for (int j = 0; j < NB; ++j) Lfac[h * NB * NB + j * NB + c] = (j <= c) ? a[j] : 0.0;       // L[c][j]
                 }
             }
         } else if (h == 0) {
@@ -389,7 +391,14 @@ chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, 
                     }
                 }
             }
-        } else if (!diag_wg) {
+        } else if (diag_wg) {
+            // ---- 4 (waves 1-3 of workgroup 0): half a's factor and inverse out to global memory ----
+            for (int e = tid - 64; e < NB * NB; e += 192) {
+                const int j = e >> 5, c = e & 31;
+                A[(size_t)(ca + j) * ld + ca + c] = Lfac[e];
+                Dinv[(size_t)(ca / NB) * NB * NB + e] = Lia[c * NB + j];                                       // Linv[j][c]
+            }
+        } else {
             // ---- 4 (waves 1-3): X_b -= (previous pair), X_a = X_a Linv_a', X_b -= X_a L_ba': MT x 2 tiles each ----
             constexpr int MT = RW / 16;
             for (int w = wave - 1; w < 2 * MT; w += 3) {
@@ -423,7 +432,14 @@ chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, 
         __syncthreads();
         CH2_STAMP(4 + 3 * h);
     }
-    if (diag_wg) return;
+    if (diag_wg) {                                                // half b's factor and inverse out
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int j = e >> 5, c = e & 31;
+            A[(size_t)(cb + j) * ld + cb + c] = Lfac[NB * NB + e];
+            Dinv[(size_t)(cb / NB) * NB * NB + e] = Lib[c * NB + j];
+        }
+        return;
+    }
     // ---- 5: X_b = X_b Linv_b': one 16 x 16 tile per wave (MT x 2 of them) ----
     {
         constexpr int MT = RW / 16;
