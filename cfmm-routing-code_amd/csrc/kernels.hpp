@@ -278,7 +278,8 @@ __device__ __forceinline__ const char *uni_ptr(const void *p)
 // 32 B (CP2, SUM2) or 40 B (W2, CURVE2, POW2: + the parameter column) of HBM per pool, read once.
 // ------------------------------------------------------------------------------------------
 // PRE: the columns come from `pre` (the staged walk: tile_stage_read) instead of global memory
-template <int KIND, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false, bool NT = false>
+// CARRY: sum arb is carried per lane (fsum); without it the caller forms it at the flush as nu' psi (sum_i arb_i = sum_i nu' y_i)
+template <int KIND, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false, bool NT = false, bool CARRY = true>
 __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, const double *nu_s,
                                       const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double &fsum, const BatchCtl &bc,
                                       const TileRegs *pre = nullptr)
@@ -320,7 +321,7 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
                 if (live[u] && y.active) {
                     ps.add(y.ab ? ia[u] : ib[u], y.yin);
                     ps.add(y.ab ? ib[u] : ia[u], y.yout);
-                    if (!DET && !BATCH) fsum += y.arb;
+                    if (CARRY && !DET && !BATCH) fsum += y.arb;
                 }
                 continue;
             }
@@ -333,7 +334,7 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
             if (live[u] && (y.ya != 0.0 || y.yb != 0.0)) {
                 ps.add(ia[u], y.ya);
                 ps.add(ib[u], y.yb);
-                if (!DET && !BATCH) fsum += pa * y.ya + pb * y.yb;
+                if (CARRY && !DET && !BATCH) fsum += pa * y.ya + pb * y.yb;
             }
             if (WITH_D && live[u] && KIND != 2) {
                 double da = 0.0, db = 0.0;
@@ -366,7 +367,7 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
 template <int K>
 __host__ __device__ constexpr int pools_per_wave() { return ktile_pools(K); }
 
-template <int K, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false, bool NT = false>
+template <int K, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false, bool NT = false, bool CARRY = true>
 __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, const double *nu_s,
                                       const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double2 *xs, double &fsum, const BatchCtl &bc,
                                       const TileRegs *pre = nullptr)
@@ -401,13 +402,16 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
         // (NOT rewritten as min(u,0) + max(u,L) - L etc., two operations fewer per term: inside a pool's no-trade band F is
         //  EXACTLY zero in this form -- a sum of exact zeros -- and the strict sign tests below rely on it; the rewritten sums
         //  come out as +-1e-19 there and flag legs of pools that must not trade)
+        // (written as u - clamp(u, 0, -lg): the same three cases -- u, 0, u + lg -- bit for bit [x - (-y) IS x + y], one operation
+        //  fewer per term, and still an exact zero inside the band)
         double f1 = 0.0, f2 = 0.0;
+        const double nlg = -lg;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const double2 v = xs[gb + k];
             const double u1 = t1 - v.x, u2 = t2 - v.x;
-            f1 += v.y * (fmin(u1, 0.0) + fmax(u1 + lg, 0.0));
-            f2 += v.y * (fmin(u2, 0.0) + fmax(u2 + lg, 0.0));
+            f1 += v.y * (u1 - fmin(fmax(u1, 0.0), nlg));
+            f2 += v.y * (u2 - fmin(fmax(u2, 0.0), nlg));
         }
         SCHED_FENCE();
         const bool wd = f1 > 0.0;                           // withdrawn at the root: t* < a_j
@@ -430,7 +434,7 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
         }
         SCHED_FENCE();
         if (live) {
-            if (y != 0.0) { ps.add(tok, y); if (!DET && !BATCH) fsum += p * y; }
+            if (y != 0.0) { ps.add(tok, y); if (CARRY && !DET && !BATCH) fsum += p * y; }
             if (WITH_D) diag_s.add(tok, (1.0 - w) * p * R);
         }
     }
@@ -645,15 +649,15 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
                 tile_dma_issue(a, nbk, ntb, slot, lane);
             }
             switch (bk) {
-            case 0: tilen<8, WITH_D, DET, false, true>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
-            case 1: tilen<7, WITH_D, DET, false, true>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
-            case 2: tilen<6, WITH_D, DET, false, true>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
-            case 3: tilen<5, WITH_D, DET, false, true>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
-            case 4: tilen<4, WITH_D, DET, false, true>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
-            case 5: tilen<3, WITH_D, DET, false, true>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
-            case 8: tile2<1, WITH_D, DET, false, true>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc, &r); break;
-            case 9: tile2<0, WITH_D, DET, false, true>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc, &r); break;
-            case 10: tile2<2, WITH_D, DET, false, true>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc, &r); break;
+            case 0: tilen<8, WITH_D, DET, false, true, false, !FLUSH>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
+            case 1: tilen<7, WITH_D, DET, false, true, false, !FLUSH>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
+            case 2: tilen<6, WITH_D, DET, false, true, false, !FLUSH>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
+            case 3: tilen<5, WITH_D, DET, false, true, false, !FLUSH>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
+            case 4: tilen<4, WITH_D, DET, false, true, false, !FLUSH>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
+            case 5: tilen<3, WITH_D, DET, false, true, false, !FLUSH>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, &r); break;
+            case 8: tile2<1, WITH_D, DET, false, true, false, !FLUSH>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc, &r); break;
+            case 9: tile2<0, WITH_D, DET, false, true, false, !FLUSH>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc, &r); break;
+            case 10: tile2<2, WITH_D, DET, false, true, false, !FLUSH>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc, &r); break;
             default: break;                                            // (6, 7: the heavy kinds live in the other tile space)
             }
             i0 = n0; bk = nbk; tb = ntb;
@@ -709,17 +713,17 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
         t_out += tc0 - t_prev;
 #endif
         switch (bk) {
-        case 0: if constexpr (!STABLE) { tilen<8, WITH_D, DET, BATCH, false, NT>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 1: if constexpr (!STABLE) { tilen<7, WITH_D, DET, BATCH, false, NT>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 2: if constexpr (!STABLE) { tilen<6, WITH_D, DET, BATCH, false, NT>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 3: if constexpr (!STABLE) { tilen<5, WITH_D, DET, BATCH, false, NT>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 4: if constexpr (!STABLE) { tilen<4, WITH_D, DET, BATCH, false, NT>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 5: if constexpr (!STABLE) { tilen<3, WITH_D, DET, BATCH, false, NT>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 6: if constexpr (STABLE) { tile2<3, WITH_D, DET, BATCH, false, NT>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
-        case 7: if constexpr (STABLE) { tile2<4, WITH_D, DET, BATCH, false, NT>(a.b2[4], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
-        case 8: if constexpr (!STABLE) { tile2<1, WITH_D, DET, BATCH, false, NT>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
-        case 9: if constexpr (!STABLE) { tile2<0, WITH_D, DET, BATCH, false, NT>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
-        default: if constexpr (!STABLE) { tile2<2, WITH_D, DET, BATCH, false, NT>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 0: if constexpr (!STABLE) { tilen<8, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 1: if constexpr (!STABLE) { tilen<7, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 2: if constexpr (!STABLE) { tilen<6, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 3: if constexpr (!STABLE) { tilen<5, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 4: if constexpr (!STABLE) { tilen<4, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 5: if constexpr (!STABLE) { tilen<3, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 6: if constexpr (STABLE) { tile2<3, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 7: if constexpr (STABLE) { tile2<4, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[4], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 8: if constexpr (!STABLE) { tile2<1, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 9: if constexpr (!STABLE) { tile2<0, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        default: if constexpr (!STABLE) { tile2<2, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
         }
 #ifdef CFMM_PHASE_TIMERS
         if (a.ts && lane == 0) {                       // per-wave tile log: ts[64 + 8 gw + i] = bucket << 48 | cycles
@@ -762,8 +766,10 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
         }
         return;
     }
-    fsum = wave_sum(fsum);
-    if (lane == 0) fpart[wib] = fsum;
+    if constexpr (!FLUSH || DET) {                // (kept in LDS for a consumer in the workgroup: per-wave partials of the carried sum)
+        fsum = wave_sum(fsum);
+        if (lane == 0) fpart[wib] = fsum;
+    }
     __syncthreads();
     PHASE_STAMP(a.ts, 3);
     if constexpr (!FLUSH) return;
@@ -779,15 +785,20 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
         PHASE_STAMP(a.ts, 4);
         return;
     }
+    // sum arb = nu' psi, formed here from the workgroup's tile (one fma per token) instead of one per pool and lane in the tiles
     double *base = acc + (size_t)(blockIdx.x % a.nslices) * acc_stride(n);
+    double fw = 0.0;
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const double v = psi_t[j];
-        if (v != 0.0) unsafeAtomicAdd(&base[j], v);
+        if (v != 0.0) { unsafeAtomicAdd(&base[j], v); fw = fma(nu_s[j], v, fw); }
         if (WITH_D) {
             const double dv = diag_t[j];
             if (dv != 0.0) unsafeAtomicAdd(&base[acc_diag(n) + j], dv);
         }
     }
+    fw = wave_sum(fw);
+    if (lane == 0) fpart[wib] = fw;
+    __syncthreads();
     if (threadIdx.x == 0) {
         double f = 0.0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) f += fpart[w];
