@@ -2023,7 +2023,7 @@ static bool reorder_bucketN(cfmm_ctx *ctx, int k, BucketN &b, void **arena, size
     char *old = (char *)*arena, *na = reorder_arena(ctx, total, b.m, &perm, &hist);
     if (!na) return false;
     auto sh = [&](const void *p) { return (void *)(na + ((const char *)p - old)); };
-    ColsN d{(int *)sh(b.idx), (double *)sh(b.R), (double *)sh(b.w), (double *)sh(b.fee), (double *)sh(b.lfee)};
+    ColsN d{(int *)sh(b.idx), (double *)sh(b.R), (double *)sh(b.w), (double *)sh(b.fee), (double *)sh(b.lfee), (double *)sh(b.lrw)};
     const int bsz = (ctx->n + RO_NB - 1) / RO_NB;
     const int per = RO_THREADS * RO_PER, grid = (int)((b.m + per - 1) / per);
     const dim3 gh(std::min(grid, 2048)), gs(grid), blk(RO_THREADS);
@@ -2034,7 +2034,7 @@ static bool reorder_bucketN(cfmm_ctx *ctx, int k, BucketN &b, void **arena, size
     RO_CASE(3) RO_CASE(4) RO_CASE(5) RO_CASE(6) RO_CASE(7) default: RO_CASE(8)
 #undef RO_CASE
     }
-    b.idx = d.idx; b.R = d.R; b.w = d.w; b.fee = d.fee; b.lfee = d.lfee; b.perm = perm;
+    b.idx = d.idx; b.R = d.R; b.w = d.w; b.fee = d.fee; b.lfee = d.lfee; b.lrw = d.lrw; b.perm = perm;
     *arena = na;
     return true;
 }
@@ -2203,6 +2203,21 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
             c.fill = [fee](char *out, size_t off, size_t len) {
                 double *o = (double *)out; const double *f = fee + off / sizeof(double);
                 for (size_t i = 0; i < len / sizeof(double); ++i) o[i] = std::log(f[i]);
+            };
+            cols.push_back(c);
+        }
+        {   // log(R / w) per leg, pool-major like R and w: with the workgroup's table of log-prices the K-asset tiles form
+            // a = log(R p / w) as one add (kernels.hpp: tilen<LNU>)
+            Col c; c.bytes = (size_t)k * m * sizeof(double); c.dst = (void **)&b.lrw;
+            c.fill = [R, w, k, m](char *out, size_t off, size_t len) {
+                double *o = (double *)out;
+                const size_t e0 = off / sizeof(double), cnt = len / sizeof(double);
+                size_t pool = e0 / (size_t)k; int j = (int)(e0 - pool * (size_t)k);
+                for (size_t i = 0; i < cnt; ++i) {
+                    const size_t src = (size_t)j * (size_t)m + pool;
+                    o[i] = std::log(R[src] / w[src]);
+                    if (++j == k) { j = 0; ++pool; }
+                }
             };
             cols.push_back(c);
         }

@@ -273,6 +273,8 @@ iter_kernel(IterArgs a)
     double *fpart = nu_s + n + 2;                        // [16]
     int *next_tile = reinterpret_cast<int *>(fpart + 16);
     double *strips = lds + eval_lds_doubles(n, false, DET);
+    constexpr bool LNU = eval_has_lnu(false, DET) && !DMA;
+    double *lnu_s = lds + eval_lnu_offset(n, false, DET); // [n] log-prices for the K-asset tiles (kernels.hpp: tilen<LNU>)
     double *xw = strips;                                 // [16][32] per-wave sums
     double *xm = xw + 16 * 32;                           // [16][2] maxima
     BlockRed red(xm + 32);                               // [2][12][16]
@@ -654,7 +656,7 @@ iter_kernel(IterArgs a)
     }
     PHASE_STAMP(a.ev.ts, 22);
 #pragma unroll
-    for (int e = 0; e < E; ++e) if (tin[e]) nu_s[r0 + e] = nn[e];        // (over this thread's own stash entry)
+    for (int e = 0; e < E; ++e) if (tin[e]) { nu_s[r0 + e] = nn[e]; if constexpr (LNU) lnu_s[r0 + e] = v[e]; }        // (over this thread's own stash entry; v = log nn: the trial point itself)
     if constexpr (DMA) {
         if (helper_mode && !wave_active) dma_wait();     // (what a helper requested for the other waves is in LDS before they pass the barrier)
         lds_barrier();                                   // (LDS only: a fence would wait for the first tiles' DMA -- and for nothing else that matters here)
@@ -672,7 +674,8 @@ iter_kernel(IterArgs a)
         eval_tiles_and_flush<false, false, DET, false, true, true>(a.ev, a.acc3 + (size_t)p * a.acc_set, nu_s, psi_s, nullptr, fpart, next_tile, xs,
                                                                    BatchCtl{1u, 0, 0}, nullptr, stage0 + SLOT * wave, !dma_late);
     else
-    eval_tiles_and_flush<false, false, DET, false, true, false, NT>(a.ev, a.acc3 + (size_t)p * a.acc_set, nu_s, psi_s, nullptr, fpart, next_tile, xs);
+    eval_tiles_and_flush<false, false, DET, false, true, false, NT, LNU>(a.ev, a.acc3 + (size_t)p * a.acc_set, nu_s, psi_s, nullptr, fpart, next_tile, xs,
+                                                                         BatchCtl{1u, 0, 0}, nullptr, nullptr, false, lnu_s);
 #ifdef CFMM_PHASE_TIMERS
     __syncthreads();
     if (a.ev.ts && tid == 0 && blockIdx.x < 256) a.ev.ts[64 + 8 * 4096 + 2 * blockIdx.x + 1] = wall_clock64();    // block end

@@ -88,6 +88,8 @@ struct BucketN {
     const int *idx;
     const double *R, *w, *fee;
     const double *lfee;               // log(fee), computed once at upload (+8 B/pool instead of one log per wave-tile)
+    const double *lrw;                // log(R / w) per leg, computed once at upload: with the workgroup's table of log-prices a leg's
+                                      // a = log(R p / w) is ONE add where it was a 36-instruction log per leg and evaluation (round 4)
     const int *perm;                  // position -> the caller's pool index (reorder.hpp); null = the caller's order
 };
 
@@ -106,9 +108,16 @@ struct EvalArgs {
 
 // LDS carve of eval_kernel (doubles), 16-byte aligned pieces; then 64 double2 per wave
 __host__ __device__ inline int eval_tile_doubles(int n, bool det) { return (det ? 3 : 1) * n; }     // one scatter tile (psi or diag)
+// (+ ticket + the tile-range table: 2 x N_BUCKETS ints; + the table of log-prices for the K-asset tiles of the evaluations
+//  that do not build the metric -- every launch of a solve but its first -- outside the reproducible mode)
+__host__ __device__ constexpr bool eval_has_lnu(bool with_d, bool det) { return !with_d && !det; }
+__host__ __device__ inline int eval_lnu_offset(int n, bool with_d, bool det = false)
+{
+    return (((with_d ? 2 : 1) * eval_tile_doubles(n, det) + n + 2 + 16 + 2 + N_BUCKETS) + 1) & ~1;
+}
 __host__ __device__ inline int eval_lds_doubles(int n, bool with_d, bool det = false)
 {
-    return (((with_d ? 2 : 1) * eval_tile_doubles(n, det) + n + 2 + 16 + 2 + N_BUCKETS) + 1) & ~1;     // (+ ticket + the tile-range table: 2 x N_BUCKETS ints)
+    return eval_lnu_offset(n, with_d, det) + (eval_has_lnu(with_d, det) ? ((n + 1) & ~1) : 0);
 }
 
 // accumulator slice layout (np = n rounded up to even, so that every piece is 16-byte aligned):
@@ -367,12 +376,14 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
 template <int K>
 __host__ __device__ constexpr int pools_per_wave() { return ktile_pools(K); }
 
-template <int K, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false, bool NT = false, bool CARRY = true>
+// LNU: a = lrw + lnu_s[token] (the bucket's log(R / w) column and the workgroup's table of log-prices) instead of log(R p / w)
+template <int K, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false, bool NT = false, bool CARRY = true, bool LNU = false>
 __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, const double *nu_s,
                                       const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double2 *xs, double &fsum, const BatchCtl &bc,
-                                      const TileRegs *pre = nullptr)
+                                      const TileRegs *pre = nullptr, const double *lnu_s = nullptr)
 {
     static_assert(!(BATCH && WITH_D), "the batched evaluation does not build the metric");
+    static_assert(!LNU || (!BATCH && !PRE && !WITH_D && !CARRY), "the log-price table serves the plain evaluation tiles");
     constexpr int P = pools_per_wave<K>();
     // (opaque copy: otherwise the lane / K, lane % K and strip addresses of all six instantiations are hoisted out of
     //  the tile loop and stay live across it -- ~20 VGPRs on a kernel that sits on a register cliff)
@@ -387,14 +398,17 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
     double R, w, fee, lg;
     if constexpr (PRE) { tok = live ? pre->i[0] : 0; R = pre->d[0]; w = pre->d[1]; fee = pre->d[2]; lg = pre->d[3]; (void)leg; (void)pl; }     // (dead lanes: a neighbouring tile's legs or a clamped chunk's tail)
     else { tok = ld_off<NT>(b.idx, leg); R = ld_off<NT>(b.R, leg); w = ld_off<NT>(b.w, leg); fee = ld_off<NT>(b.fee, pl); lg = ld_off<NT>(b.lfee, pl); }
+    double lrw = 0.0;
+    if constexpr (LNU) lrw = ld_off<NT>(b.lrw, leg);
     const int gb = (g < P ? g : 0) * K;
 #pragma unroll 1
     for (unsigned mask = BATCH ? bc.alive : 1u; mask; mask &= mask - 1) {
         const int bb = BATCH ? __builtin_ctz(mask) : 0;
         const Scatter<DET> ps{BATCH ? psi_s.t + bb * bc.tile_stride : psi_s.t, psi_s.n, psi_s.sc};
-        const double p = (BATCH ? nu_s + bb * bc.nu_stride : nu_s)[tok];
+        const double p = LNU ? 0.0 : (BATCH ? nu_s + bb * bc.nu_stride : nu_s)[tok];
         SCHED_FENCE();
-        const double a = log_pos(R * p * rcp_nr(w));
+        double a;
+        if constexpr (LNU) a = lrw + lnu_s[tok]; else a = log_pos(R * p * rcp_nr(w));
         SCHED_FENCE();
         xs[lane] = make_double2(a, w);                     // ds_write_b128; same-wave LDS ops stay in order
         __builtin_amdgcn_wave_barrier();
@@ -614,11 +628,14 @@ __device__ __forceinline__ void build_tile_table(const EvalArgs &a, int *next_ti
 // workgroup (tiny.hpp)
 // DMA: the staged walk (above) -- `stage` is this wave's 4 KB LDS slot, `first_issued` says that the caller has already
 // issued the DMA of the wave's first tile (tiles_dma_first)
-template <bool WITH_D, bool STABLE, bool DET = false, bool BATCH = false, bool FLUSH = true, bool DMA = false, bool NT = false>
+// LNU: `lnu_s` = the workgroup's table of log-prices (filled by the caller next to nu_s): the K-asset tiles take a = log(R p / w) from it
+template <bool WITH_D, bool STABLE, bool DET = false, bool BATCH = false, bool FLUSH = true, bool DMA = false, bool NT = false, bool LNU = false>
 __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *acc, const double *nu_s, double *psi_t, double *diag_t,
                                                      double *fpart, int *next_tile, double2 *xs, const BatchCtl &bc = BatchCtl{1u, 0, 0},
-                                                     double *const *acc_b = nullptr, const double *stage = nullptr, bool first_issued = false)
+                                                     double *const *acc_b = nullptr, const double *stage = nullptr, bool first_issued = false,
+                                                     const double *lnu_s = nullptr)
 {
+    static_assert(!LNU || (!WITH_D && !DET && !BATCH && !DMA && FLUSH), "the log-price table: plain evaluations that flush");
     const int n = a.n;
     const Scatter<DET> psi_s{psi_t, n, a.det_scale}, diag_s{diag_t, n, a.det_scale_d};
     const int lane = threadIdx.x & 63;
@@ -713,12 +730,12 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
         t_out += tc0 - t_prev;
 #endif
         switch (bk) {
-        case 0: if constexpr (!STABLE) { tilen<8, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 1: if constexpr (!STABLE) { tilen<7, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 2: if constexpr (!STABLE) { tilen<6, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 3: if constexpr (!STABLE) { tilen<5, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 4: if constexpr (!STABLE) { tilen<4, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
-        case 5: if constexpr (!STABLE) { tilen<3, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc); } break;
+        case 0: if constexpr (!STABLE) { tilen<8, WITH_D, DET, BATCH, false, NT, !FLUSH, LNU>(a.bn[5], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, nullptr, lnu_s); } break;
+        case 1: if constexpr (!STABLE) { tilen<7, WITH_D, DET, BATCH, false, NT, !FLUSH, LNU>(a.bn[4], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, nullptr, lnu_s); } break;
+        case 2: if constexpr (!STABLE) { tilen<6, WITH_D, DET, BATCH, false, NT, !FLUSH, LNU>(a.bn[3], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, nullptr, lnu_s); } break;
+        case 3: if constexpr (!STABLE) { tilen<5, WITH_D, DET, BATCH, false, NT, !FLUSH, LNU>(a.bn[2], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, nullptr, lnu_s); } break;
+        case 4: if constexpr (!STABLE) { tilen<4, WITH_D, DET, BATCH, false, NT, !FLUSH, LNU>(a.bn[1], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, nullptr, lnu_s); } break;
+        case 5: if constexpr (!STABLE) { tilen<3, WITH_D, DET, BATCH, false, NT, !FLUSH, LNU>(a.bn[0], tb, lane, nu_s, psi_s, diag_s, xs, fsum, bc, nullptr, lnu_s); } break;
         case 6: if constexpr (STABLE) { tile2<3, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
         case 7: if constexpr (STABLE) { tile2<4, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[4], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
         case 8: if constexpr (!STABLE) { tile2<1, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
@@ -827,7 +844,13 @@ eval_kernel(EvalArgs a)
     if (threadIdx.x < 64) build_tile_table(a, next_tile, threadIdx.x);
     double2 *xs = reinterpret_cast<double2 *>(lds + eval_lds_doubles(n, WITH_D, DET)) + 64 * (threadIdx.x >> 6);   // wave-private [64]
     // prices and the stop flag arrive in ONE round trip (the flag rides behind the prices)
-    for (int j = threadIdx.x; j <= n; j += blockDim.x) nu_s[j] = a.nu[j];
+    constexpr bool LNU = eval_has_lnu(WITH_D, DET) && !STABLE && !DMA;
+    double *lnu_s = lds + eval_lnu_offset(n, WITH_D, DET);
+    for (int j = threadIdx.x; j <= n; j += blockDim.x) {
+        const double v = a.nu[j];
+        nu_s[j] = v;
+        if constexpr (LNU) { if (j < n) lnu_s[j] = log_pos(v); }
+    }
     for (int j = threadIdx.x; j < (WITH_D ? 2 : 1) * tile; j += blockDim.x) lds[j] = 0.0;      // (+0.0 is the all-zero bit pattern: limbs too)
     __syncthreads();
     if (nu_s[n] != 0.0) return;
@@ -836,7 +859,7 @@ eval_kernel(EvalArgs a)
         const double *stage = lds_raw + (STAGE_BYTES / 8) * (threadIdx.x >> 6);
         eval_tiles_and_flush<WITH_D, STABLE, DET, false, true, true>(a, a.acc, nu_s, psi_s, diag_s, fpart, next_tile, xs, BatchCtl{1u, 0, 0}, nullptr, stage, false);
     } else
-    eval_tiles_and_flush<WITH_D, STABLE, DET, false, true, false, NT>(a, a.acc, nu_s, psi_s, diag_s, fpart, next_tile, xs);
+    eval_tiles_and_flush<WITH_D, STABLE, DET, false, true, false, NT, LNU>(a, a.acc, nu_s, psi_s, diag_s, fpart, next_tile, xs, BatchCtl{1u, 0, 0}, nullptr, nullptr, false, lnu_s);
 #ifdef CFMM_PHASE_TIMERS
     __syncthreads();
     if (a.ts && threadIdx.x == 0 && blockIdx.x < 1024) a.ts[64 + 8 * 4096 + 2 * blockIdx.x + 1] = wall_clock64();    // block end

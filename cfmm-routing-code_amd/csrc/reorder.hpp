@@ -55,7 +55,7 @@ ro_scan_kernel(unsigned *hist)                    // counts -> exclusive offsets
 }
 
 struct Cols2 { double *Ra, *Rb, *fee, *param; int *ia, *ib; };
-struct ColsN { int *idx; double *R, *w, *fee, *lfee; };
+struct ColsN { int *idx; double *R, *w, *fee, *lfee, *lrw; };
 
 __global__ void __launch_bounds__(RO_THREADS)
 ro_scatter2_kernel(Bucket2 s, Cols2 d, int *__restrict__ perm, int bsz, unsigned *__restrict__ cursor)
@@ -110,7 +110,7 @@ ro_scatterN_kernel(BucketN s, ColsN d, int *__restrict__ perm, int bsz, unsigned
         const long long i = i0 + r * RO_THREADS + threadIdx.x;
         const long long p = (long long)base[key[r]] + rank[r];
 #pragma unroll
-        for (int j = 0; j < K; ++j) { d.idx[p * K + j] = s.idx[i * K + j]; d.R[p * K + j] = s.R[i * K + j]; d.w[p * K + j] = s.w[i * K + j]; }
+        for (int j = 0; j < K; ++j) { d.idx[p * K + j] = s.idx[i * K + j]; d.R[p * K + j] = s.R[i * K + j]; d.w[p * K + j] = s.w[i * K + j]; d.lrw[p * K + j] = s.lrw[i * K + j]; }
         d.fee[p] = s.fee[i]; d.lfee[p] = s.lfee[i];
         perm[p] = (int)i;
     }
