@@ -67,6 +67,61 @@ def test_dense_cholesky_against_lapack(n):
     ctx.close()
 
 
+def _with_env(monkeypatch, **env):
+    """a context created under tuning knobs that libcfmm_hip.so reads once per context (cfmm_create)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+
+
+@pytest.mark.parametrize("n", [33, 100, 200, 1000])
+def test_cholesky_pairs_of_block_columns_against_one_per_launch(n, monkeypatch):
+    """chol2.hpp (two block columns per launch, side products on the fp64 matrix pipe) against chol.hpp (one per launch):
+    solution, the chord step's apply through the inverse factor, the flag of an indefinite matrix"""
+    rng = np.random.default_rng(n)
+    M = rng.normal(size=(n, n)) / np.sqrt(n)
+    A = M @ M.T + np.diag(rng.uniform(0.5, 2.0, n))
+    b, b2 = rng.normal(size=n), rng.normal(size=n)
+    out = {}
+    for mode in ("pairs", "single"):
+        _with_env(monkeypatch, CFMM_CHOL=mode)
+        ctx = _lib.Context(n)
+        x, info = ctx.debug_cholesky(A, b)
+        x2 = ctx.debug_cholesky_apply(b2)
+        _, info_bad = ctx.debug_cholesky(A - 1e3 * np.eye(n), b)
+        ctx.close()
+        assert info == 0 and info_bad != 0
+        out[mode] = (x, x2)
+    xr, xr2 = np.linalg.solve(A, b), np.linalg.solve(A, b2)
+    for mode in out:
+        assert np.abs(out[mode][0] - xr).max() <= 1e-10 * np.abs(xr).max(), mode
+        assert np.abs(out[mode][1] - xr2).max() <= 1e-10 * np.abs(xr2).max(), mode
+    assert np.abs(out["pairs"][0] - out["single"][0]).max() <= 1e-11 * np.abs(xr).max()
+
+
+def test_second_order_hand_off_and_factorisation_variants_agree(monkeypatch):
+    """the lean host <-> device hand-off (handoff.hpp: one launch per group of small copies, a flag in pinned memory instead of a
+    stream synchronisation) against the hipMemcpyAsync / hipMemsetAsync path, and both factorisations: the same solve"""
+    net = synthetic.config("C5", scale=0.1)
+    n = net["n_tokens"]
+    rng = np.random.default_rng(2)
+    h = np.zeros(n); idx = rng.choice(n, 6, replace=False); h[idx] = rng.uniform(1.0, 20.0, 6)
+    t = int(np.setdiff1d(np.arange(n), idx)[0])
+    res = {}
+    for io, ch in (("lean", "pairs"), ("blit", "pairs"), ("lean", "single")):
+        _with_env(monkeypatch, CFMM_NEWTON_IO=io, CFMM_CHOL=ch)
+        p = cfmm.Problem.from_network(net, utility=cfmm.Liquidate(h, t))
+        v = p.solve(method="newton", tol=1e-7)
+        assert p.status == "optimal" and p.gap <= 1e-7 and p.infeas <= 1e-7, (io, ch, p.status)
+        res[(io, ch)] = (v, p.psi.copy(), p.stats["newton_steps"])
+        p.close()
+    v0, psi0, steps0 = res[("lean", "pairs")]
+    vb, psib, stepsb = res[("blit", "pairs")]
+    # (the hand-off moves bytes, not numbers: what differs is the order of the evaluation's fp64 atomics, run to run)
+    assert abs(vb - v0) <= 1e-9 * abs(v0) and np.abs(psib - psi0).max() <= 1e-6 * np.abs(psi0).max() and stepsb == steps0
+    vs, psis, _ = res[("lean", "single")]
+    assert abs(vs - v0) <= 2e-7 * abs(v0) and np.abs(psis - psi0).max() <= 1e-5 * np.abs(psi0).max()
+
+
 @pytest.mark.parametrize("mu", [1e-1, 1e-5, 1e-10])
 def test_smoothed_evaluation_matches_numpy_restatement(mu):
     net = _mixed_network()

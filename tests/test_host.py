@@ -212,6 +212,32 @@ def test_start_prices_propagate_through_pools():
     assert np.abs(nu0 / net["prices"] - 1).max() < 1e-9
 
 
+def test_start_prices_from_network_potentials():
+    """cfmm.problem._potentials: one least-squares fit per network (cached in the network dict, not inherited by shards), O(n)
+    per utility -- several priced tokens shift it by their mean, a component the utility prices nowhere gets 1, another utility
+    on the same network costs no new fit"""
+    net = synthetic.make_network(60, m_cp2=600, m_w2=100, m_gn=60, seed=3, mispricing=0.0)
+    pi = net["prices"]
+    c = np.zeros(60); c[[3, 17, 40]] = pi[[3, 17, 40]] * np.array([1.0, 1.02, 0.98])       # inconsistent by +-2 %: the fit takes their mean
+    nu0 = cfmm.start_prices(net, cfmm.Utility(c))
+    assert np.array_equal(nu0[[3, 17, 40]], c[[3, 17, 40]])                                  # priced tokens keep their price
+    free = np.setdiff1d(np.arange(60), [3, 17, 40])
+    shift = np.exp(np.mean(np.log([1.0, 1.02, 0.98])))
+    assert np.abs(nu0[free] / (pi[free] * shift) - 1).max() < 1e-9
+    fit = net["_potentials"]
+    c2 = np.zeros(60); c2[5] = 2.0 * pi[5]
+    nu1 = cfmm.start_prices(net, cfmm.Utility(c2))
+    assert net["_potentials"] is fit and np.abs(nu1 / (2.0 * pi) - 1).max() < 1e-9          # the same fit, another anchor
+    assert "_potentials" not in cfmm.shard_network(net, 0, 2) and "_price_relations" not in cfmm.shard_network(net, 0, 2)
+    # two components: tokens 0-29 and 30-59 never share a pool; the utility prices only the first
+    a = synthetic.make_network(30, m_cp2=300, seed=4, mispricing=0.0)
+    two = dict(n_tokens=60, prices=np.concatenate([a["prices"], a["prices"]]), c=np.concatenate([a["c"], a["c"]]), seed=0,
+               cp2={k: np.concatenate([a["cp2"][k], a["cp2"][k] + (30 if k in ("ia", "ib") else 0)]) for k in a["cp2"]})
+    c3 = np.zeros(60); c3[7] = a["prices"][7]
+    nu2 = cfmm.start_prices(two, cfmm.Utility(c3))
+    assert np.abs(nu2[:30] / a["prices"] - 1).max() < 1e-9 and np.all(nu2[30:] == 1.0)
+
+
 @pytest.mark.parametrize("name,inst", shipped_cases())
 def test_host_logic_reproduces_shipped_instances(oracle_lib, name, inst):
     """objective, psi and every pool's tenders, incl. the partially filled constant-sum pool"""
