@@ -309,9 +309,27 @@ struct StageRing {
     char *buf = nullptr;
     hipEvent_t ev[STAGE_SLOTS] = {};
     bool used[STAGE_SLOTS] = {};       // the slot's last copy may still be in flight (its event tells): kept ACROSS calls
+    hipStream_t last[STAGE_SLOTS] = {}; // ... and the stream it was enqueued on
     int next = 0;
 };
 StageRing g_stage;
+// The runtime refuses hipEventSynchronize on an event whose LAST record was on a stream that is capturing NOW -- a context
+// that goes on to capture a graph on its stream must not leave ring slots waiting on that stream for some other context's
+// upload to trip over (seen once in ~10 runs of the GPU suite: "operation not permitted on an event last recorded in a
+// capturing stream" out of an unrelated context's upload).  Called in front of hipStreamBeginCapture.
+void stage_ring_drain(hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lock(g_stage.mu);
+    for (int q = 0; q < STAGE_SLOTS; ++q)
+        if (g_stage.used[q] && g_stage.last[q] == stream) { (void)hipEventSynchronize(g_stage.ev[q]); g_stage.used[q] = false; }
+}
+// wait for a slot's last copy; if the runtime will not let us (above), the whole device idle says the same
+hipError_t stage_slot_wait(int slot)
+{
+    hipError_t e = hipEventSynchronize(g_stage.ev[slot]);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipDeviceSynchronize(); }
+    return e;
+}
 std::mutex g_stream_mu;
 std::vector<hipStream_t> g_free_streams[64];
 
@@ -557,7 +575,7 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const 
             for (size_t b = lo; b < hi; b += grain) jobs.push_back({q, b - offs[q], std::min(grain, hi - b), b - c0});
         }
         const auto t0 = now();
-        if (used[slot]) { hipError_t e = hipEventSynchronize(g_stage.ev[slot]); if (e != hipSuccess) return bail(e, "hipEventSynchronize"); }
+        if (used[slot]) { hipError_t e = stage_slot_wait(slot); if (e != hipSuccess) return bail(e, "hipEventSynchronize"); }
         const auto t1 = now();
         HostPool::get().run((int)jobs.size(), [&](int j) { const Job &w = jobs[j]; cols[w.q].fill(st + w.st_off, w.col_off, w.len); });
         const auto t2 = now();
@@ -566,7 +584,7 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const 
         if (e == hipSuccess) e = hipEventRecord(g_stage.ev[slot], ctx->stream);
         if (e != hipSuccess) return bail(e, "hipMemcpyAsync");
         t_wait += ms(t0, t1); t_fill += ms(t1, t2); t_enq += ms(t2, now());
-        used[slot] = true; slot = (slot + 1) % STAGE_SLOTS;
+        used[slot] = true; g_stage.last[slot] = ctx->stream; slot = (slot + 1) % STAGE_SLOTS;
     }
     for (size_t q = 0; q < cols.size(); ++q) *cols[q].dst = base + offs[q];
     g_stage.next = slot;
@@ -595,7 +613,7 @@ int download_staged(cfmm_ctx *ctx, void *host_dst, const void *dev_src, size_t b
         for (auto &ev : g_stage.ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     // (uploads may have left copies in flight out of the ring)
-    for (int q = 0; q < STAGE_SLOTS; ++q) if (g_stage.used[q]) { HIP_TRY(ctx, hipEventSynchronize(g_stage.ev[q])); g_stage.used[q] = false; }
+    for (int q = 0; q < STAGE_SLOTS; ++q) if (g_stage.used[q]) { HIP_TRY(ctx, stage_slot_wait(q)); g_stage.used[q] = false; }
     const size_t nchunks = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
     auto enqueue = [&](size_t c) -> hipError_t {
         const size_t off = c * STAGE_BYTES, len = std::min(STAGE_BYTES, bytes - off);
@@ -1086,6 +1104,7 @@ int build_graph(cfmm_ctx *ctx, const cfmm_opts &o)
     drop_graph(ctx);
     const UpdArgs ua = make_upd_args(ctx, o);
     hipGraph_t graph = nullptr;
+    stage_ring_drain(ctx->stream);
     HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     int rc = CFMM_OK;
     if (fused_applies(ctx, o)) {

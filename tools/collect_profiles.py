@@ -32,8 +32,14 @@ for f in sorted(glob.glob(os.path.join(SRC, "pmc_*", "**", "*counter_collection.
     cfg = os.path.basename(os.path.dirname(f) if os.path.basename(os.path.dirname(f)).startswith("pmc_") else os.path.dirname(os.path.dirname(f)))
     cfg = [p for p in f.split(os.sep) if p.startswith("pmc_")][0].split("_")[1]
     agg = {}
+    seen = set()
     for r in csv.DictReader(open(f)):
         agg.setdefault((r["Kernel_Name"], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+        # the dispatch's duration UNDER THIS PMC PASS, once per dispatch and pass (pseudo-counter DISPATCH_NS@<first counter of the
+        # pass>): what a counter of the same pass has to be divided by to become a rate
+        if (r["Dispatch_Id"], r["Kernel_Name"]) not in seen and r["Counter_Name"] in ("SQ_BUSY_CYCLES",):
+            seen.add((r["Dispatch_Id"], r["Kernel_Name"]))
+            agg.setdefault((r["Kernel_Name"], "DISPATCH_NS_of_the_SQ_BUSY_CYCLES_pass"), []).append(float(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     for (kn, cn), v in sorted(agg.items()):
         v.sort()
         rows.append(dict(config=cfg, kernel=kn, counter=cn, dispatches=len(v), median=v[len(v) // 2], min=v[0], max=v[-1]))
