@@ -200,11 +200,17 @@ def start_prices(net, util):
     pools' marginal prices at their current reserves (breadth-first, averaged in log space).
     The propagation depends on the pools and on c alone: its result is kept with the utility object (a re-solve with
     another basket h -- or the same one -- skips the ~2 ms walk over a 1000-token network)."""
-    n = net["n_tokens"]
     c = util.c
-    known = c > 0
-    if known.all():
+    if getattr(util, "_all_priced", None) is None:       # (kept with the utility object: Problem.set_utility drops it when the object is re-sent)
+        try:
+            util._all_priced = bool((c > 0).all())
+        except AttributeError:
+            pass
+    known = c > 0 if getattr(util, "_all_priced", None) is None else None
+    if getattr(util, "_all_priced", None) or (known is not None and known.all()):
         return c.copy()
+    if known is None:
+        known = c > 0
     memo = getattr(util, "_start_memo", None)
     if memo is not None and memo[0] is net and np.array_equal(memo[1], c):
         return memo[2].copy()
@@ -579,6 +585,11 @@ class Problem:
     def set_utility(self, utility):
         self.utility = utility       # (a new object, or the same object mutated: call this to re-send it)
         self._dev_utility = None
+        for attr in ("_all_priced", "_plain", "_start_memo"):        # (what was derived from its arrays)
+            try:
+                setattr(utility, attr, None)
+            except AttributeError:
+                pass
 
     def _send_utility(self):
         """the device-side utility is re-sent only when it changed (each call is a synchronisation).  Everything that
@@ -846,7 +857,8 @@ class Problem:
             plain = u._plain = bool(not u.h.any() and not u.ctype.any())
         r = psi if plain else psi + u.h
         self.value = float(u.c @ psi)
-        cs = float((nu - u.c) @ r)                            # complementary slackness (nu - c)'(psi + h)
+        nu_psi = float(nu @ psi) if plain else None           # (plain: (nu - c)'psi = nu'psi - c'psi, two dot products serve three quantities)
+        cs = nu_psi - self.value if plain else float((nu - u.c) @ r)      # complementary slackness (nu - c)'(psi + h)
         if st.get("method") == _lib.METHODS["newton"]:
             # psi is the barrier-smoothed primal point (strictly inside every pool's trading set); the dual value
             # and the gap against it were computed on the device from an exact evaluation at nu
@@ -854,11 +866,12 @@ class Problem:
             self.gap = abs(float(st["gap"]))
         else:
             # sum_i arb_i = nu'psi_pools; tied pools trade value-neutrally at their kink prices
-            self.dual_value = float(nu @ psi) if plain else float((nu - u.c) @ u.h + nu @ psi)
+            self.dual_value = nu_psi if plain else float((nu - u.c) @ u.h + nu @ psi)
             self.gap = abs(cs) / max(1.0, abs(self.dual_value))
         if plain:
-            viol = max(-float(r.min()), 0.0)
-            scale = max(float(psi.max()), -float(psi.min()), 1e-300)
+            lo, hi = float(psi.min()), float(psi.max())
+            viol = max(-lo, 0.0)
+            scale = max(hi, -lo, 1e-300)
         else:
             viol = float(np.where(u.ctype == GE, np.maximum(-r, 0.0), np.where(u.ctype == EQ, np.abs(r), 0.0)).max())
             scale = max(float(np.abs(psi).max()), float(np.abs(u.h).max()), 1e-300)

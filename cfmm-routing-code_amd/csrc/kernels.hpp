@@ -846,10 +846,12 @@ eval_kernel(EvalArgs a)
     // prices and the stop flag arrive in ONE round trip (the flag rides behind the prices)
     constexpr bool LNU = eval_has_lnu(WITH_D, DET) && !STABLE && !DMA;
     double *lnu_s = lds + eval_lnu_offset(n, WITH_D, DET);
+    // (the table of log-prices serves the K-asset tiles alone: a network without such pools does not pay for it)
+    const bool want_lnu = LNU && (a.bn[0].m | a.bn[1].m | a.bn[2].m | a.bn[3].m | a.bn[4].m | a.bn[5].m) != 0;
     for (int j = threadIdx.x; j <= n; j += blockDim.x) {
         const double v = a.nu[j];
         nu_s[j] = v;
-        if constexpr (LNU) { if (j < n) lnu_s[j] = log_pos(v); }
+        if (want_lnu && j < n) lnu_s[j] = log_pos(v);
     }
     for (int j = threadIdx.x; j < (WITH_D ? 2 : 1) * tile; j += blockDim.x) lds[j] = 0.0;      // (+0.0 is the all-zero bit pattern: limbs too)
     __syncthreads();
