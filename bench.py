@@ -259,6 +259,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # The per-kernel table of the line (the evaluation launch alone, HIP events on the library's stream, at prices ~1 % off the
+    # market: about 88 % of the pools trade, as in the first iterations of a solve and in tools/profile_eval.py, whose rocprofv3
+    # trace is committed under profiles/) is measured HERE, in front of the warm-up steps, not behind the timed ones: a few
+    # hundred launches that leave the device at its working clock.  With W = 5 cold solves (2.5 ms) alone the first timed steps
+    # still ran on a ramping clock -- 20.7 us per iteration where the same binary settles at 20.0 (W = 20).  Nothing of it is
+    # inside the timed region, which is K complete cold solves either way.
+    prob._send_utility()
+    prob.ctx.set_nu(net["c"] * np.exp(np.random.default_rng(0).normal(0, 0.01, net["n_tokens"])))
+    from cfmm import _lib as _l
+    prob.ctx.time_eval_kernel(_l.TIME_ALL, 300)            # (the table itself should not be measured on the ramp either: discarded)
+    rows = kernel_table(prob, args.kernel_reps)
     for _ in range(args.warmup):
         prob.solve(tol=args.tol, **solve_kw)
     sync()
@@ -308,9 +319,6 @@ def main():
     newton_kernels = None
     if second_order and not sharded:
         newton_kernels = prob.ctx.time_newton_kernels(max(prob.stats.get("barrier_mu", 0.0), 1e-12), 5)      # at the solution just found
-    prob.ctx.set_nu(net["c"] * np.exp(np.random.default_rng(0).normal(0, 0.01, net["n_tokens"])))
-    rows = kernel_table(prob, args.kernel_reps)
-
     out = None
     if rank == 0:
         dom = rows[0]
