@@ -144,9 +144,6 @@ chol_step_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k1, i
         // ---- inverse factor: block row q = k1 / NB - 1, tile (i, j), j <= q < i < ncols / NB ------------------------------------------
         const int q = k1 / NB - 1, nbk = ncols / NB;
         const int t = (int)blockIdx.x - npanel, j = t % (q + 1), i = q + 1 + t / (q + 1);
-#ifdef CFMM_W_NOOP
-        if (CFMM_W_NOOP == 1) return;                             // (diagnostic: the cost of the extra workgroups alone)
-#endif
         double *Li = lds, *Rq = Li + NB * NB, *Wq = Rq + NB * NB, *Lq = Wq + NB * NB;       // 4 x 8 KB: Linv_qq | R_qj | W_qj | L_iq
         (void)nbk;
         const int r2 = 2 * (tid & 15), c2 = 2 * (tid >> 4);      // this thread's 2 x 2 sub-tile: rows r2, r2 + 1, columns c2, c2 + 1
@@ -172,9 +169,6 @@ chol_step_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k1, i
             Lq[cc * NB + rr] = av[u];                             // L_iq[rr][cc] -> Lq[k = cc][r = rr]
         }
         __syncthreads();
-#ifdef CFMM_W_NOOP
-        if (CFMM_W_NOOP == 2) return;                             // (diagnostic: loads only)
-#endif
         double w00 = 0.0, w01 = 0.0, w10 = 0.0, w11 = 0.0;        // W_qj = Linv_qq R_qj
 #pragma unroll 8
         for (int k = 0; k < NB; ++k) {
