@@ -45,7 +45,7 @@ class Stats(C.Structure):
 
 def build(force=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("cfmm_hip.hip", "kernels.hpp", "iterate.hpp", "tiny.hpp", "onewave.hpp", "reorder.hpp", "oneshot.hpp", "pool_math.hpp", "phi2.hpp", "lbfgs_rules.hpp", "smooth.hpp", "chol.hpp")]
+    srcs = [os.path.join(_CSRC, f) for f in ("cfmm_hip.hip", "kernels.hpp", "iterate.hpp", "tiny.hpp", "onewave.hpp", "reorder.hpp", "oneshot.hpp", "pool_math.hpp", "phi2.hpp", "lbfgs_rules.hpp", "smooth.hpp", "chol.hpp", "chol2.hpp", "phik.hpp", "handoff.hpp")]
     srcs.append(os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "cfmm.h"))
     if force or not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _CSRC, "-s"])
