@@ -351,8 +351,12 @@ def main():
             summaries) the old estimate against 2.4 GHz x the live duration, flagged as such."""
             if not pr["valu_busy"]:
                 return None, None
-            if pr["sq_busy"]:
-                return pr["valu_busy"] / (SIMDS * pr["sq_busy"] / 32.0), "profiled: 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x SQ_BUSY_CYCLES / 32 shader engines), one PMC pass of " + str(pr["traffic_file"])
+            if pr["sq_busy"] and pr["pmc_ns"]:
+                # (NOT against the profiled dispatch's own cycles: a counter pass stretches the dispatch -- 21.8 us on one box, 35.6
+                #  on another for the same 20.5 us launch -- and the fraction of a stretched launch says nothing about the live one)
+                clk = pr["sq_busy"] / 32.0 / (pr["pmc_ns"] * 1e-9)
+                return pr["valu_busy"] / (SIMDS * clk * live_seconds), ("4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x effective clock x the LIVE launch duration); clock = "
+                                                                         "SQ_BUSY_CYCLES / 32 shader engines / the dispatch's duration under the same PMC pass = %.2f GHz (%s)" % (clk / 1e9, pr["traffic_file"]))
             return pr["valu_busy"] / (SIMDS * CLOCK_HZ * live_seconds), "estimate: 4 x SQ_ACTIVE_INST_VALU (" + str(pr["traffic_file"]) + ") / (1024 SIMDs x 2.4 GHz x the LIVE launch duration)"
         valu_frac, valu_src = valu_fraction(prof[pk], us_iter * 1e-6)
         ev_valu, _ = valu_fraction(prof["eval"], dom["seconds"])

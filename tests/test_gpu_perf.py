@@ -1,5 +1,5 @@
 """GPU suite (-m gpu): the kernel-time regression guard.  profiles/budget.json holds, per BASELINE configuration, the
-measured time of each dominant kernel / launch group on MI355X + 10 %; this test re-times them with the library's own
+measured time of each dominant kernel / launch group on MI355X + 12 % (launch chains: + 25 %); this test re-times them with the library's own
 hooks (tools/kernel_budget.py: minimum over rounds of a mean over back-to-back launches -- a busy box can only make a
 round slower, never faster) and fails when one is over.  Round 3's silent 2x slip of eval_batch_kernel (exchange strips
 pushed off their 16-byte boundary by an odd-sized tile table, kernels.hpp: batch_lds_doubles) would have failed here."""

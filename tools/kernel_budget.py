@@ -19,7 +19,12 @@ for p in (ROOT, os.path.join(ROOT, "cfmm-routing-code_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 BUDGET = os.path.join(ROOT, "profiles", "budget.json")
-MARGIN = 1.10
+MARGIN = 1.12
+# launch chains (the factorisation: 17 dependent launches of ~13 us of chain each) carry the BOX's dispatch latency 17 times: five
+# boxes of one round measured 313 ... 357 us for the same binary, where a single-launch kernel moves by 2-4 %
+MARGIN_CHAIN = 1.25
+def margin(key):
+    return MARGIN_CHAIN if "factor" in key else MARGIN
 
 
 def measure(rounds=5, reps=20, only=None):
@@ -95,9 +100,9 @@ if __name__ == "__main__":
     args = ap.parse_args()
     m = measure(args.rounds, only=args.only)
     if args.write:
-        json.dump({"note": "measured on MI355X by tools/kernel_budget.py --write (minimum over rounds of mean launch time, us); allowed = measured x %.2f" % MARGIN,
+        json.dump({"note": "measured on MI355X by tools/kernel_budget.py --write (minimum over rounds of mean launch time, us); allowed = measured x %.2f (launch chains: x %.2f)" % (MARGIN, MARGIN_CHAIN),
                    "measured_us": {k: round(v, 3) for k, v in m.items()},
-                   "allowed_us": {k: round(v * MARGIN, 3) for k, v in m.items()}}, open(BUDGET, "w"), indent=1)
+                   "allowed_us": {k: round(v * margin(k), 3) for k, v in m.items()}}, open(BUDGET, "w"), indent=1)
         print(json.dumps(m))
     else:
         b = json.load(open(BUDGET))
