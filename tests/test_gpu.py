@@ -993,6 +993,26 @@ def json_load_baseline():
     return json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "BASELINE.json")))
 
 
+def test_k_asset_tiles_with_and_without_the_log_price_table(oracle_lib):
+    """the evaluation that builds the metric keeps a = log(R p / w) per leg; every other evaluation takes it as log(R / w) (a
+    column written at upload) + log p (a table per workgroup): the same psi to rounding, both against the oracle, at a mix that
+    is mostly K-asset pools of every size -- and the sum of arbitrage profits formed at the flush as nu' psi"""
+    net = synthetic.make_network(300, m_cp2=2000, m_w2=1000, m_gn=40_000, seed=11)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    o = _oracle_for(oracle_lib, net)
+    rng = np.random.default_rng(3)
+    for spread in (0.002, 0.03, 0.3):
+        nu = net["c"] * np.exp(rng.normal(0, spread, net["n_tokens"]))
+        f1, psi1 = p.eval_dual(nu)                         # log-price table
+        f2, psi2, _ = p.eval_dual(nu, want_diag=True)      # per-leg log
+        f0, psi0 = o.eval(nu)
+        scale = np.abs(psi0).max()
+        assert np.abs(psi1 - psi2).max() <= 1e-12 * scale and abs(f1 - f2) <= 1e-11 * max(abs(f0), 1.0)
+        assert np.abs(psi1 - psi0).max() <= 1e-10 * scale and abs(f1 - f0) <= 1e-10 * max(abs(f0), 1.0)
+        assert abs(f1 - float(nu @ psi1)) <= 1e-10 * max(abs(f0), 1.0)       # sum_i arb_i = nu' psi
+    p.close()
+
+
 def test_non_temporal_instantiations_match_the_oracle(oracle_lib, tmp_path):
     """pool sets beyond twice the Infinity Cache stream their columns with non-temporal loads (kernels.hpp: ld_off<NT>; own
     instantiations of eval_kernel / iter_kernel, taken automatically at >= 512 MB).  CFMM_NT=1 forces them on a small network,
