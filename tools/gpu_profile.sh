@@ -28,6 +28,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ben
 echo "== kernel trace + vector-issue counters of the config-5 solve (second-order path)"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_C5newton -o t -- python $R/tools/profile_newton.py --solves 3 > $O/trace_C5newton.log 2>&1; echo "rc=$?"; tail -1 $O/trace_C5newton.log | cut -c1-300
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_C5newton_SQ -o c -- python $R/tools/profile_newton.py --solves 1 > $O/pmc_C5newton_SQ.log 2>&1; echo "pmc C5newton rc=$?"
+# the factorisation's side products run on the fp64 matrix pipe (chol2.hpp): instruction count and pipe-busy cycles
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $O/pmc_C5newton_MFMA -o c -- python $R/tools/profile_newton.py --solves 1 > $O/pmc_C5newton_MFMA.log 2>&1; echo "pmc C5newton MFMA rc=$?"
 # PMC passes (each its own run).  SQ: instruction mix / issue cycles + the shader clock's cycles over the same dispatch (the
 # effective clock under the profiler: bench.py's valu_frac divides by it, not by 2.4 GHz); WAIT: where the waves wait; TCC: L2 hit rate
 PMC_FULL=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "TCC_HIT_sum TCC_MISS_sum")
