@@ -13,6 +13,7 @@ _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 POOL_CP2, POOL_W2, POOL_SUM2, POOL_CURVE2, POOL_POW2 = 0, 1, 2, 3, 4
 TIME_ALL = 100
 GE, EQ, FREE = 0, 1, 2
+ULOG, UQUAD = 3, 4          # the utility table: u = c log(psi + h) / u = c psi - psi^2 / (2 h)   (include/cfmm.h)
 MAX_POOL_SIZE = 8
 POOLK = {"stable": 0, "sum": 1}     # the K-asset table's kinds (include/cfmm.h: CFMM_POOLK_*)
 STATUS = {1: "optimal", 2: "stalled", 3: "max_evals"}

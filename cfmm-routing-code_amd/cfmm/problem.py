@@ -18,7 +18,7 @@ Host logic that stays in Python (tiny, O(n) or O(#constant-sum pools)):
 import numpy as np
 
 from . import _lib
-from ._lib import GE, EQ, FREE, POOL_CP2, POOL_W2, POOL_SUM2, POOL_CURVE2, POOL_POW2, MAX_POOL_SIZE, CfmmError
+from ._lib import GE, EQ, FREE, ULOG, UQUAD, POOL_CP2, POOL_W2, POOL_SUM2, POOL_CURVE2, POOL_POW2, MAX_POOL_SIZE, CfmmError
 
 KIND2 = dict(cp2=POOL_CP2, w2=POOL_W2, sum2=POOL_SUM2, curve2=POOL_CURVE2, pow2=POOL_POW2)
 # the name of a two-asset bucket's parameter column (None: the kind has none)
@@ -27,7 +27,9 @@ PARAM2 = dict(cp2=None, w2="wa", sum2=None, curve2="alpha", pow2="t")
 
 # ------------------------------------------------------------------------------- utilities
 class Utility:
-    """maximise c'psi  s.t.  psi_k + h_k >= 0 (GE) | = 0 (EQ) | unconstrained (FREE)."""
+    """maximise c'psi  s.t.  psi_k + h_k >= 0 (GE) | = 0 (EQ) | unconstrained (FREE) -- the reference's utilities (arbitrage.py:57,77;
+    liquidation.py:57,77-80; two-asset.py:66,86).  Beyond them, per token, an entry of the utility table:
+    ctype ULOG: + c_k log(psi_k + h_k);  UQUAD: + c_k psi_k - psi_k^2 / (2 h_k)   (include/cfmm.h; first-order path)."""
 
     def __init__(self, c, h=None, ctype=None):
         self.c = np.asarray(c, dtype=np.float64)
@@ -49,6 +51,24 @@ def Liquidate(current_assets, target):
     h[target] = 0.0
     ctype = np.full(n, EQ, dtype=np.int32); ctype[target] = FREE
     return Utility(c, h, ctype)
+
+
+def LogUtility(weights, holdings):
+    """max sum_k weights[k] log(psi_k + holdings[k]): a logarithmic (Kelly / Cobb-Douglas) utility of the post-trade holdings.
+    Not in the reference (its objectives are linear); tokens with weight 0 are held at psi_k + holdings[k] >= 0 and worth nothing."""
+    a = np.asarray(weights, dtype=np.float64)
+    h = np.asarray(holdings, dtype=np.float64)
+    ctype = np.where(a > 0, ULOG, GE).astype(np.int32)
+    return Utility(a, h, ctype)
+
+
+def QuadraticUtility(marginal_value, depth):
+    """max sum_k marginal_value[k] psi_k - psi_k^2 / (2 depth[k]): a linear value with quadratic impact (an external order book of
+    finite depth behind every token).  depth[k] = inf is the linear-arbitrage token (psi_k >= 0 at value c_k)."""
+    c = np.asarray(marginal_value, dtype=np.float64)
+    d = np.asarray(depth, dtype=np.float64)
+    fin = np.isfinite(d)
+    return Utility(c, np.where(fin, d, 0.0), np.where(fin, UQUAD, GE).astype(np.int32))
 
 
 def Swap(current_assets, target):
@@ -201,6 +221,14 @@ def start_prices(net, util):
     The propagation depends on the pools and on c alone: its result is kept with the utility object (a re-solve with
     another basket h -- or the same one -- skips the ~2 ms walk over a 1000-token network)."""
     c = util.c
+    if (util.ctype >= ULOG).any():           # the utility table: a token starts at the price at which it would not trade (u'(0))
+        c = c.copy()
+        lg, qd = util.ctype == ULOG, util.ctype == UQUAD
+        with np.errstate(divide="ignore"):
+            c[lg] = np.where(util.h[lg] > 0, util.c[lg] / np.where(util.h[lg] > 0, util.h[lg], 1.0), 0.0)
+        c[qd] = util.c[qd]
+        known = c > 0
+        return c if known.all() else _propagate_prices(net, c, known)
     if getattr(util, "_all_priced", None) is None:       # (kept with the utility object: Problem.set_utility drops it when the object is re-sent)
         try:
             util._all_priced = bool((c > 0).all())
@@ -482,6 +510,7 @@ class Problem:
         utilities = list(utilities)
         ctx = self._ensure_ctx()
         can_batch = (hasattr(ctx, "solve_batch") and "sum2" not in self.net and "curve2" not in self.net and "pow2" not in self.net and self._host is None
+                     and not any((x.ctype >= ULOG).any() for x in utilities)
                      and not self.deterministic and kw.get("method", "auto") in ("auto", "lbfgs"))
         if batch is None:
             batch = ctx.batch_capacity() if can_batch else 0
@@ -662,7 +691,11 @@ class Problem:
         self._tol = tol
         kw = dict(max_evals=max_evals, memory=memory, iters_per_graph=iters_per_graph)
         total = dict(evals=0, iters=0, wall_seconds=0.0, device_seconds=0.0, rounds=0)
-        can_second = getattr(ctx, "second_order", False) and not self.net.get("gk")      # (K-asset table pools: first-order path only)
+        general = bool((u.ctype >= ULOG).any())      # entries of the utility table: first-order path, no ties
+        if general and n_sum:
+            raise ValueError("a utility with ULOG / UQUAD entries over a network with constant-sum pools: the kink recovery ties prices, "
+                             "the utility table's entries take no ties")
+        can_second = getattr(ctx, "second_order", False) and not self.net.get("gk") and not general      # (K-asset table pools, table utilities: first-order path only)
         if method not in _lib.METHODS:
             raise ValueError(f"method {method!r}: expected one of {sorted(_lib.METHODS)}")
         # auto: many stableswap pools -> second order straight away (first order needs thousands of evaluations there);
@@ -852,6 +885,19 @@ class Problem:
             psi = psi.copy()
             for rec, th in self._theta.values():
                 psi += th * self._fill_vector(rec)
+        if (u.ctype >= ULOG).any():
+            # a utility with entries of the table: value, dual value and certificates are the device's (Fenchel-Young gap of
+            # the pair (nu, psi): csrc/lbfgs_rules.hpp); recomputed here in NumPy only by the tests
+            self.value = float(st["primal_value"]); self.dual_value = float(st["dual_value"])
+            self.gap = abs(float(st["gap"])); self.infeas = float(st["infeas"])
+            self.nu, self.psi = nu, psi
+            self.status = _lib.STATUS.get(st["status"], f"error {st['status']}")
+            tolx = max(self._tol, 1e-12) * (1 + 1e-6) + 1e-15
+            if self.status == "optimal" and not (self.gap <= tolx and self.infeas <= tolx):
+                self.status = "inaccurate"
+            self.stats = dict(st)
+            self.stats.update(total)
+            return
         plain = getattr(u, "_plain", None)
         if plain is None:                    # h == 0 and psi >= 0 everywhere (arbitrage.py:57,77): a shorter certificate check
             plain = u._plain = bool(not u.h.any() and not u.ctype.any())

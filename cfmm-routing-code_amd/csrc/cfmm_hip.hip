@@ -157,6 +157,8 @@ struct cfmm_ctx {
     bool multi_graph = false;          // CFMM_MULTI_GRAPH=1: capture the pool-sharded iteration (with its all-reduce) too
     int upd_variant = 0;               // CFMM_UPDATE_VARIANT: A/B choice among the register-resident instantiations
     bool upd_generic = false;          // CFMM_UPDATE_GENERIC=1: force the generic update kernel (A/B testing)
+    bool general_utility = false;      // some token carries an entry of the utility table beyond linear-plus-box (lbfgs_rules.hpp):
+                                       // the generic two-launch first-order iteration serves it, nothing else
     bool have_utility = false, have_nu = false;
     // host copies needed to derive bounds
     std::vector<double> hc, hh, hoff;
@@ -929,7 +931,7 @@ UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
 // ---- tiny networks (the reference's own instances): the whole solve in one launch of one workgroup (tiny.hpp) -----
 bool tiny_applies(cfmm_ctx *ctx, const EvalArgs &ea, const cfmm_opts &o)
 {
-    return ctx->tiny_path && !sharded(ctx) && !ctx->det && extra_launch_pools(ctx) == 0 && ea.ntiles >= 1 &&
+    return ctx->tiny_path && !ctx->general_utility && !sharded(ctx) && !ctx->det && extra_launch_pools(ctx) == 0 && ea.ntiles >= 1 &&
            ea.ntiles <= TINY_MAX_TILES && ctx->n <= TINY_N && o.memory <= MAX_MEMORY;
 }
 
@@ -937,7 +939,7 @@ bool tiny_applies(cfmm_ctx *ctx, const EvalArgs &ea, const cfmm_opts &o)
 // applies when the update fits the evaluation launch: no price ties, <= 2048 tokens, memory <= 4
 bool fused_applies(cfmm_ctx *ctx, const cfmm_opts &o)
 {
-    return ctx->fused && ctx->ng == ctx->n && ctx->n <= 2 * EVAL_THREADS && o.memory <= ITER_MM;
+    return ctx->fused && !ctx->general_utility && ctx->ng == ctx->n && ctx->n <= 2 * EVAL_THREADS && o.memory <= ITER_MM;
 }
 
 size_t acc_set_doubles(cfmm_ctx *ctx) { return (size_t)ctx->nslices * acc_stride(ctx->n); }
@@ -1028,7 +1030,7 @@ void launch_update(cfmm_ctx *ctx, const UpdArgs &ua)
     const size_t lds = upd_lds_bytes(ctx->ng);
     auto thr = [n](int E) { return 64 * ((n + 64 * E - 1) / (64 * E)); };
     const int ug = ctx->upd_grid;                   // (tuning probe) identical redundant workgroups
-    const int v = ctx->upd_generic ? 9 : ctx->upd_variant;
+    const int v = (ctx->upd_generic || ctx->general_utility) ? 9 : ctx->upd_variant;
     // Gram form (two-loop recursion on scalars after ONE batched reduction): <= 1024 tokens, memory <= 4; with 4
     // variables per thread (<= 2048 tokens) its 64-value batch spills and loses to the sequential form (18.8 vs 14.8 us)
     if (v == 0 && n <= 1024 && ua.M <= GRAM_MM)
@@ -1220,6 +1222,7 @@ bool newton_supported(cfmm_ctx *ctx, const char **why)
 {
     if (ctx->ng != ctx->n) { *why = "price ties are set"; return false; }
     if (table_pools(ctx) > 0) { *why = "the network holds K-asset table pools (phik.hpp): first-order path only"; return false; }
+    if (ctx->general_utility) { *why = "the utility has entries beyond linear-plus-box (CFMM_ULOG / CFMM_UQUAD): first-order path only"; return false; }
     // (the Hessian instantiation of smooth_kernel carries the diagonal / pair cache on top of the psi tile: 24 n + 24832 bytes,
     //  i.e. 5792 tokens -- not the (2 n + 32) doubles of the round-2 kernel, which let 5.8k .. 10.2k tokens through to a launch
     //  failure)
@@ -2358,10 +2361,22 @@ int cfmm_set_utility(cfmm_ctx *ctx, const double *c, const double *h, const int3
     if (!ctx || !c) return ctx ? fail(ctx, CFMM_E_ARG, "set_utility: c is NULL") : CFMM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int n = ctx->n;
+    bool general = false;
     for (int j = 0; j < n; ++j) {
-        if (!(c[j] >= 0.0)) return fail(ctx, CFMM_E_ARG, "set_utility: c[%d] < 0 or NaN", j);
-        if (ctype && (ctype[j] < 0 || ctype[j] > 2)) return fail(ctx, CFMM_E_ARG, "set_utility: ctype[%d] = %d", j, ctype[j]);
+        if (!(c[j] >= 0.0) || !std::isfinite(c[j])) return fail(ctx, CFMM_E_ARG, "set_utility: c[%d] < 0 or not finite", j);
+        if (ctype && (ctype[j] < 0 || ctype[j] > CFMM_UQUAD)) return fail(ctx, CFMM_E_ARG, "set_utility: ctype[%d] = %d", j, ctype[j]);
+        if (ctype && ctype[j] >= CFMM_ULOG) {            // the utility table (lbfgs_rules.hpp): c and h are the entry's parameters
+            general = true;
+            const double hj = h ? h[j] : 0.0;
+            if (ctype[j] == CFMM_ULOG && !(c[j] > 0.0 && hj >= 0.0 && std::isfinite(hj)))
+                return fail(ctx, CFMM_E_ARG, "set_utility: token %d, u = c log(Psi + h) needs c > 0 and h >= 0 (c %g, h %g)", j, c[j], hj);
+            if (ctype[j] == CFMM_UQUAD && !(hj > 0.0 && std::isfinite(hj)))
+                return fail(ctx, CFMM_E_ARG, "set_utility: token %d, u = c Psi - Psi^2 / (2 h) needs h > 0 (h %g)", j, hj);
+        }
     }
+    if (general && ctx->ng != ctx->n) return fail(ctx, CFMM_E_UNSUPPORTED, "set_utility: price ties are set; the utility table's entries take none");
+    if (general != ctx->general_utility) ctx->g_valid = false;      // (another update kernel in the captured launches)
+    ctx->general_utility = general;
     ctx->hc.assign(c, c + n);
     if (h) ctx->hh.assign(h, h + n); else ctx->hh.assign(n, 0.0);
     if (ctype) ctx->hctype.assign(ctype, ctype + n); else ctx->hctype.assign(n, CFMM_GE);
@@ -2392,6 +2407,7 @@ int cfmm_set_ties(cfmm_ctx *ctx, int n_groups, const int32_t *grp, const double 
         for (int j = 0; j < n; ++j) { ctx->hgrp[j] = j; ctx->hoff[j] = 0.0; }
     } else {
         if (n_groups < 1 || n_groups > n || !off) return fail(ctx, CFMM_E_ARG, "set_ties: n_groups %d", n_groups);
+        if (ctx->general_utility) return fail(ctx, CFMM_E_UNSUPPORTED, "set_ties: the utility has entries beyond linear-plus-box, which take no price ties");
         for (int j = 0; j < n; ++j) if (grp[j] < 0 || grp[j] >= n_groups) return fail(ctx, CFMM_E_ARG, "set_ties: grp[%d] = %d", j, grp[j]);
         ctx->ng = n_groups;
         ctx->hgrp.assign(grp, grp + n); ctx->hoff.assign(off, off + n);
@@ -2608,7 +2624,9 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts_in, cfmm_
     struct AtExit { cfmm_ctx *c; ~AtExit() { release_landed(c); } } at_exit{ctx};      // (every path out of a solve ends behind a synchronisation)
     cfmm_opts o;
     if (opts_in) o = *opts_in; else cfmm_default_opts(&o);
-    if (o.memory == 0) o.memory = ctx->n <= 32 ? 8 : 3;      // auto: tiny problems afford (nearly) full quasi-Newton memory; else 3 (iterate.hpp: ITER_MM)
+    // auto: tiny problems afford (nearly) full quasi-Newton memory; else 3 (iterate.hpp: ITER_MM) -- and 8 for the utility table's
+    // smooth entries, whose dual has no box to lean on (5e4 pools / 1000 tokens, log utility: 257 / 145 / 107 evaluations at memory 3 / 5 / 8)
+    if (o.memory == 0) o.memory = (ctx->n <= 32 || ctx->general_utility) ? 8 : 3;
     if (o.memory < 1 || o.memory > MAX_MEMORY || o.iters_per_graph < 1 || o.iters_per_graph > 256 || o.max_evals < 1)
         return fail(ctx, CFMM_E_ARG, "solve: memory %d, iters_per_graph %d, max_evals %d", o.memory, o.iters_per_graph, o.max_evals);
     if (o.method < CFMM_METHOD_AUTO || o.method > CFMM_METHOD_NEWTON) return fail(ctx, CFMM_E_ARG, "solve: method %d", o.method);
@@ -2880,6 +2898,7 @@ int cfmm_solve_batch(cfmm_ctx *const *ctxs, int nb, const double *const *nu0, co
         if (c->ng != n || c->flags2) return fail(c0, CFMM_E_UNSUPPORTED, "solve_batch: context %d has price ties set", b);
         if (sharded(c) || c->det) return fail(c0, CFMM_E_UNSUPPORTED, "solve_batch: pool-sharded / reproducible contexts are solved one at a time");
         if (!c->have_utility) return fail(c0, CFMM_E_STATE, "solve_batch: context %d has no utility", b);
+        if (c->general_utility) return fail(c0, CFMM_E_UNSUPPORTED, "solve_batch: context %d has a utility beyond linear-plus-box (CFMM_ULOG / CFMM_UQUAD): solved one at a time", b);
         if (nu0 && nu0[b]) { int rc = cfmm_set_nu(c, nu0[b]); if (rc) { c0->err = c->err; return rc; } }
         if (!c->have_nu) return fail(c0, CFMM_E_STATE, "solve_batch: context %d has no start prices", b);
         c->warm_mu = 0.0; c->mu_last = 0.0;

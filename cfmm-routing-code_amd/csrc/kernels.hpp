@@ -1126,12 +1126,22 @@ __device__ __forceinline__ int update_generic_body(const UpdArgs &a, double *lds
         }
         a.psi_t[j] = psi;
         const double nuj = a.nu[j], hj = a.h[j], cj = a.c[j];
-        const double rj = psi + hj;
-        sums[0] += (nuj - cj) * hj;
-        sums[1] += (nuj - cj) * rj;
         const int ct = a.ctype[j];
-        maxs[0] = fmax(maxs[0], ct == 0 ? fmax(-rj, 0.0) : (ct == 1 ? fabs(rj) : 0.0));
-        maxs[1] = fmax(maxs[1], fmax(fabs(psi), fabs(hj)));
+        double rj = psi + hj;
+        if (lbfgs::smooth_utility(ct)) {       // a token of the utility table (lbfgs_rules.hpp): conjugate, its maximiser, the Fenchel-Young gap term
+            const lbfgs::UtilityTerm ut = lbfgs::utility_term(ct, cj, hj, nuj, psi);
+            rj = psi - ut.pstar;
+            sums[0] += ut.ubar;
+            sums[1] += ut.ubar + nuj * psi - ut.uval;
+            maxs[0] = fmax(maxs[0], ut.viol);
+            maxs[1] = fmax(maxs[1], fmax(fabs(psi), fabs(ut.pstar)));
+            if (st.first) dg += fmax(ut.curv, 0.0);
+        } else {
+            sums[0] += (nuj - cj) * hj;
+            sums[1] += (nuj - cj) * rj;
+            maxs[0] = fmax(maxs[0], ct == 0 ? fmax(-rj, 0.0) : (ct == 1 ? fabs(rj) : 0.0));
+            maxs[1] = fmax(maxs[1], fmax(fabs(psi), fabs(hj)));
+        }
         if (ties) {                          // group sums through LDS (ds_add_f64)
             unsafeAtomicAdd(&q[a.grp[j]], nuj * rj);
             if (st.first) unsafeAtomicAdd(&q2[a.grp[j]], dg);

@@ -17,6 +17,40 @@
 namespace cfmm {
 namespace lbfgs {
 
+// ---- the utility table (utilities beyond linear-plus-box) ------------------------------------------------
+// The reference's utilities are linear with a box: U(Psi) = c'Psi over Psi + h >= 0 (or = 0, or free), whose conjugate is the
+// linear term (nu - c)'h over the bounds nu >= c that the projected iteration carries.  A SEPARABLE concave utility
+// u_j(Psi_j) per token enters the same dual through its own conjugate ubar_j(nu_j) = sup_P (u_j(P) - nu_j P), attained at
+// P*_j(nu_j) = (u_j')^-1(nu_j):   g(nu) = sum_j ubar_j(nu_j) + sum_i arb_i(nu),   dg/dnu_j = psi_j - P*_j(nu_j),
+// no bound on nu_j, and by Fenchel-Young the duality gap of the pair (nu, psi) is sum_j [ubar_j(nu_j) + nu_j psi_j - u_j(psi_j)]
+// (>= 0, zero iff psi_j = P*_j) -- for the linear-box entry that IS (nu_j - c_j)(psi_j + h_j).  One entry = these five numbers.
+// Entries (ctype of the token; the token's c and h carry the entry's two parameters):
+//   CFMM_ULOG  = 3   u(P) = c log(P + h),  c > 0, h >= 0:   P* = c / nu - h,   ubar = c log(c / nu) - c + nu h
+//   CFMM_UQUAD = 4   u(P) = c P - P^2 / (2 h),  h > 0:       P* = h (c - nu),   ubar = h (c - nu)^2 / 2
+// Served by the generic (two-launch) outer iteration only: update_generic_body and oracle/cfmm_oracle.c:oracle_step.
+struct UtilityTerm { double pstar, ubar, uval, viol, curv; };        // curv: d^2/ds^2 of ubar(e^s), for the diagonal metric
+__host__ __device__ inline bool smooth_utility(int ctype) { return ctype >= 3; }
+__device__ __forceinline__ UtilityTerm utility_term(int ctype, double c, double h, double nu, double psi)
+{
+    UtilityTerm t;
+    if (ctype == 3) {
+        t.pstar = c / nu - h;
+        t.ubar = c * log(c / nu) - c + nu * h;
+        const double arg = psi + h;
+        t.viol = fmax(-arg, 0.0);
+        t.uval = c * log(fmax(arg, 1e-300));
+        t.curv = nu * h;
+    } else {
+        const double dlt = c - nu;
+        t.pstar = h * dlt;
+        t.ubar = 0.5 * h * dlt * dlt;
+        t.viol = 0.0;
+        t.uval = c * psi - 0.5 * psi * psi / h;
+        t.curv = h * nu * (2.0 * nu - c);
+    }
+    return t;
+}
+
 // the trial point is accepted: sufficient decrease of the dual value (Armijo on the projected move), or -- below the
 // rounding noise of the value -- the approximate Wolfe condition on the directional derivatives
 //   f_t, f: value at the trial / accepted point; gds = G's, gtds = G_t's with s the move, G / G_t the group gradients

@@ -83,7 +83,14 @@ enum {
 };
 
 /* token constraint types of the unified utility  max c'psi :  psi_k + h_k (>=, =, free) 0 */
-enum { CFMM_GE = 0, CFMM_EQ = 1, CFMM_FREE = 2 };
+enum { CFMM_GE = 0, CFMM_EQ = 1, CFMM_FREE = 2,
+       /* the utility table: separable concave utilities beyond the reference's linear-plus-box (not in the
+        * reference, whose objectives are linear: arbitrage.py:78, liquidation.py:80, two-asset.py:87).  The token's c and h carry
+        * the entry's two parameters; its price has no bound.  First-order path (two launches per iteration), no price ties,
+        * no batching.
+        *   CFMM_ULOG   u(Psi) = c log(Psi + h),        c > 0, h >= 0
+        *   CFMM_UQUAD  u(Psi) = c Psi - Psi^2 / (2 h),  h > 0 */
+       CFMM_ULOG = 3, CFMM_UQUAD = 4 };
 
 typedef struct {
     double tol_gap;         /* stop when |(nu-c)'(psi+h)| / max(1,|g|)      <= tol_gap     (1e-6) */

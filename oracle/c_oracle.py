@@ -160,7 +160,7 @@ class Oracle:
         takes the identical step.  `self` holds this rank's shard only."""
         nu0 = np.ascontiguousarray(nu0, dtype=np.float64)
         if memory == 0:
-            memory = 8 if self.n <= 32 else 3
+            memory = 8 if (self.n <= 32 or (getattr(self, 'ctype', None) is not None and (self.ctype >= 3).any())) else 3
         o = Opts(tol, tol, armijo, max_step, max_evals, memory, pg_rule, 0)
         n = self.n
         self.L.oracle_start(self.h, _d(nu0), memory)
@@ -185,7 +185,7 @@ class Oracle:
     def solve(self, nu0, tol=1e-6, max_evals=2000, memory=0, armijo=1e-4, max_step=2.0, pg_rule=0):
         nu0 = np.ascontiguousarray(nu0, dtype=np.float64)
         if memory == 0:                     # same auto rule as cfmm_solve
-            memory = 8 if self.n <= 32 else 3
+            memory = 8 if (self.n <= 32 or (getattr(self, 'ctype', None) is not None and (self.ctype >= 3).any())) else 3
         o = Opts(tol, tol, armijo, max_step, max_evals, memory, pg_rule, 0)
         st = Stats()
         nu = np.zeros(self.n); psi = np.zeros(self.n)

@@ -240,6 +240,7 @@ typedef struct {
     double f, t_step, f_t;
     int iter, evals, status, first;
     double gap, infeas, pg;
+    double primal; int general;   /* primal value f - gap term of the accepted point; the utility has table entries (ctype >= 3) */
     int nthreads;
 } oracle_t;
 
@@ -296,6 +297,8 @@ void oracle_clear_pools(oracle_t *o) { o->nb2 = 0; o->nbn = 0; }
 void oracle_set_utility(oracle_t *o, const double *c, const double *h, const int32_t *ctype)
 {
     memcpy(o->c, c, 8 * o->n); memcpy(o->h, h, 8 * o->n); memcpy(o->ctype, ctype, 4 * o->n);
+    o->general = 0;
+    for (int j = 0; j < o->n; ++j) if (ctype[j] >= 3) o->general = 1;
 }
 /* ties (kinks of constant-sum pools): log nu_j = s[grp[j]] + off[j] */
 void oracle_set_ties(oracle_t *o, int ng, const int32_t *grp, const double *off)
@@ -459,22 +462,45 @@ int oracle_step(oracle_t *o, double f_pools, const double *psi, const double *di
 {
     const int n = o->n, ng = o->ng, M = o->M;
     double f_t = f_pools, gapv = 0.0, viol = 0.0, scale = 0.0;
+    double *ucurv = calloc(n, 8);              /* the utility table's share of the diagonal metric (first call) */
     for (int r = 0; r < ng; ++r) o->Gs_t[r] = 0.0;
     for (int j = 0; j < n; ++j) {
-        double rj = psi[j] + o->h[j];
-        f_t += (o->nu[j] - o->c[j]) * o->h[j];
-        gapv += (o->nu[j] - o->c[j]) * rj;
+        double rj = psi[j] + o->h[j], v, a;
+        if (o->ctype[j] >= 3) {
+            /* the utility table (separable concave utilities beyond the reference's linear-plus-box: not in the reference, whose
+             * objectives are linear, arbitrage.py:78): conjugate ubar(nu) = sup_P (u(P) - nu P), its maximiser P*, and the
+             * Fenchel-Young gap term ubar + nu psi - u(psi).  ctype 3: u = c log(P + h); 4: u = c P - P^2 / (2 h). */
+            const double c = o->c[j], h = o->h[j], nu = o->nu[j], ps = psi[j];
+            double pstar, ubar, uval, curv;
+            v = 0.0;
+            if (o->ctype[j] == 3) {
+                pstar = c / nu - h; ubar = c * log(c / nu) - c + nu * h;
+                v = fmax(-(ps + h), 0.0); uval = c * log(fmax(ps + h, 1e-300)); curv = nu * h;
+            } else {
+                pstar = h * (c - nu); ubar = 0.5 * h * (c - nu) * (c - nu);
+                uval = c * ps - 0.5 * ps * ps / h; curv = h * nu * (2.0 * nu - c);
+            }
+            rj = ps - pstar;
+            f_t += ubar;
+            gapv += ubar + nu * ps - uval;
+            a = fmax(fabs(ps), fabs(pstar));
+            if (o->first) ucurv[j] = fmax(curv, 0.0);
+        } else {
+            f_t += (o->nu[j] - o->c[j]) * o->h[j];
+            gapv += (o->nu[j] - o->c[j]) * rj;
+            v = (o->ctype[j] == 0) ? fmax(-rj, 0.0) : (o->ctype[j] == 1 ? fabs(rj) : 0.0);
+            a = fmax(fabs(psi[j]), fabs(o->h[j]));
+        }
         o->Gs_t[o->grp[j]] += o->nu[j] * rj;
-        double v = (o->ctype[j] == 0) ? fmax(-rj, 0.0) : (o->ctype[j] == 1 ? fabs(rj) : 0.0);
         if (v > viol) viol = v;
-        double a = fmax(fabs(psi[j]), fabs(o->h[j]));
         if (a > scale) scale = a;
     }
     o->evals++;
     if (o->first) {
         for (int r = 0; r < ng; ++r) o->Ds[r] = 0.0;
-        for (int j = 0; j < n; ++j) o->Ds[o->grp[j]] += diag[j];
+        for (int j = 0; j < n; ++j) o->Ds[o->grp[j]] += diag[j] + ucurv[j];
     }
+    free(ucurv);
     int accept = o->first;
     if (!o->first) {
         /* Armijo on f; once the decrease is below the rounding noise of f (a sum over all pools),
@@ -500,6 +526,7 @@ int oracle_step(oracle_t *o, double f_pools, const double *psi, const double *di
         memcpy(o->psi, psi, 8 * n);
         o->f = f_t; o->first = 0;
         o->gap = fabs(gapv) / fmax(1.0, fabs(f_t));
+        o->primal = f_t - gapv;
         o->infeas = viol / fmax(scale, 1e-300);
         {   /* value of the projected reduced gradient: sum_r |P(Gs)_r| / max(1,|f|) (>= gap) */
             double pg = 0.0;
@@ -586,7 +613,7 @@ void oracle_get(oracle_t *o, double *nu_trial, double *nu_acc, oracle_stats_t *s
         st->dual_value = o->f; st->gap = o->gap; st->infeas = o->infeas; st->pg = o->pg; st->seconds = 0.0;
         double pv = 0.0;
         for (int j = 0; j < n; ++j) pv += o->c[j] * o->psi[j];
-        st->primal_value = pv;
+        st->primal_value = o->general ? o->primal : pv;      /* (table utilities: U(psi) = g - the Fenchel-Young gap terms) */
     }
 }
 
@@ -606,7 +633,7 @@ int oracle_solve(oracle_t *o, const double *nu0, const oracle_opts_t *opt, oracl
     st->dual_value = o->f; st->gap = o->gap; st->infeas = o->infeas; st->pg = o->pg;
     double pv = 0.0;
     for (int j = 0; j < n; ++j) { nu_out[j] = exp(o->s[o->grp[j]] + o->off[j]); psi_out[j] = o->psi[j]; pv += o->c[j] * o->psi[j]; }
-    st->primal_value = pv;
+    st->primal_value = o->general ? o->primal : pv;
     free(psi);
     return o->status;
 }

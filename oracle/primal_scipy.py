@@ -41,13 +41,27 @@ def solve_primal(inst, x0=None, ftol=1e-15, maxiter=2000):
         y = z[nnz:] - z[:nnz]
         return np.bincount(gidx, weights=y, minlength=n)
 
-    cvec = np.concatenate([-c[gidx], c[gidx]])          # d(c'psi)/dz
+    # utility: c'psi over the box the constraints below state -- the reference's (arbitrage.py:57,77) -- plus, per token, an entry
+    # of the separable table (NOT in the reference: ctype 3: c log(psi + h); 4: c psi - psi^2 / (2 h))
+    lin = ctype <= 2
+    lg, qd = ctype == 3, ctype == 4
+
+    def u_and_grad(psi):
+        val = float(c[lin] @ psi[lin])
+        g = np.where(lin, c, 0.0)
+        if lg.any():
+            arg = np.maximum(psi[lg] + h[lg], 1e-300)
+            val += float(c[lg] @ np.log(arg)); g[lg] = c[lg] / arg
+        if qd.any():
+            val += float(c[qd] @ psi[qd] - 0.5 * psi[qd] ** 2 @ (1.0 / h[qd])); g[qd] = c[qd] - psi[qd] / h[qd]
+        return val, g
 
     def fobj(z):
-        return -float(c @ psi_of(z))
+        return -u_and_grad(psi_of(z))[0]
 
     def gobj(z):
-        return -cvec
+        g = u_and_grad(psi_of(z))[1][gidx]
+        return -np.concatenate([-g, g])          # d U(psi) / dz,  psi = sum A (Lam - D)
 
     def newres(z):
         return Rf + gam * z[:nnz] - z[nnz:]
@@ -79,6 +93,7 @@ def solve_primal(inst, x0=None, ftol=1e-15, maxiter=2000):
                 raise ValueError(K[i])
         psi = psi_of(z)
         out.extend((psi + h)[ctype == 0])
+        out.extend((psi + h)[lg] - 1e-12 * (1.0 + np.abs(h[lg])))        # log's domain
         return np.asarray(out, float)
 
     def cons_j(z):
@@ -114,7 +129,7 @@ def solve_primal(inst, x0=None, ftol=1e-15, maxiter=2000):
                 for k in range(sizes[i]):
                     e = np.zeros(sizes[i]); e[k] = 1.0
                     rows.append(row_from(e))
-        for k in np.where(ctype == 0)[0]:
+        for k in list(np.where(ctype == 0)[0]) + list(np.where(lg)[0]):
             r = np.zeros(2 * nnz)
             sel = gidx == k
             r[:nnz][sel] = -1.0

@@ -414,3 +414,49 @@ def test_stableswap_n_restatement_against_the_two_asset_oracle_and_the_per_pool_
             dphi = lambda x, a=al[i]: 1 + a / (np.prod(x) * x)
             _, ap = P.arb_pool_primal(R[:, i], g[i], p[:, i], phi, dphi)
             assert abs(ap - arb[i]) <= 1e-9 * float(p[:, i] @ R[:, i]), (k, i, ap, arb[i])
+
+
+def _small_geomean_instance(seed=0, n=6, m=14):
+    rng = np.random.default_rng(seed)
+    pi = np.exp(rng.normal(0, 0.5, n))
+    L, R, G, K, W = [], [], [], [], []
+    for i in range(m):
+        k = 2 if i < 10 else 3
+        l = rng.choice(n, k, replace=False)
+        L.append(l); R.append(np.exp(rng.normal(3, 0.5)) / pi[l] * np.exp(rng.normal(0, 0.05, k))); G.append(0.997)
+        K.append("geomean"); W.append(np.full(k, 1.0 / k))
+    return pi, dict(n_tokens=n, local_indices=L, reserves=R, fees=G, kinds=K, weights=W)
+
+
+@pytest.mark.parametrize("which", ["log", "quadratic", "mixed"])
+def test_utility_table_twin_against_the_scipy_primal(oracle_lib, which):
+    """utilities beyond linear-plus-box (include/cfmm.h CFMM_ULOG / CFMM_UQUAD): the dual decomposition with the
+    token's conjugate in place of its linear term (oracle/cfmm_oracle.c: oracle_step) against the PRIMAL program with the same
+    utility handed to SLSQP (oracle/primal_scipy.py) -- no code and no algorithm in common"""
+    import cfmm
+    from oracle_ctx import OracleContext
+    from oracle.primal_scipy import solve_primal
+    pi, inst = _small_geomean_instance()
+    n = inst["n_tokens"]
+    rng = np.random.default_rng(1)
+    if which == "log":
+        u = cfmm.LogUtility([1.0, 2.0, 0.5, 1.5, 1.0, 0.7], [5.0, 2.0, 8.0, 3.0, 4.0, 6.0])
+    elif which == "quadratic":
+        u = cfmm.QuadraticUtility(pi * np.exp(rng.normal(0, 0.05, n)), [20.0, 30.0, np.inf, 25.0, 40.0, np.inf])
+    else:                                               # two log tokens, two quadratic ones, two of the reference's linear-arbitrage kind
+        c = np.array([1.0, 2.0, pi[2] * 1.03, pi[3] * 0.97, pi[4] * 1.02, pi[5]])
+        h = np.array([5.0, 2.0, 30.0, 20.0, 0.0, 0.0])
+        u = cfmm.Utility(c, h, np.array([cfmm.ULOG, cfmm.ULOG, cfmm.UQUAD, cfmm.UQUAD, cfmm.GE, cfmm.GE], dtype=np.int32))
+    p = cfmm.Problem(n, inst["local_indices"], inst["reserves"], inst["fees"], inst["kinds"], inst["weights"], utility=u)
+    p.ctx = OracleContext(n)
+    v = p.solve(tol=1e-9)
+    assert p.status == "optimal" and p.gap <= 1e-9 and p.infeas <= 1e-9
+    r = solve_primal(dict(inst, c=u.c, h=u.h, ctype=u.ctype))
+    assert abs(v - r["value"]) <= 2e-8 * max(1.0, abs(v)) and abs(p.dual_value - r["value"]) <= 2e-8 * max(1.0, abs(v))
+    assert np.abs(p.psi - r["psi"]).max() <= 2e-3 * max(1.0, np.abs(r["psi"]).max())      # (SLSQP's psi is good to ~1e-4)
+    # the optimality condition token by token: psi_j = P*_j(nu_j) on the table's tokens (the Fenchel-Young gap is QUADRATIC in
+    # this residual: a gap of 1e-9 leaves it at ~3e-5)
+    lg, qd = u.ctype == cfmm.ULOG, u.ctype == cfmm.UQUAD
+    assert np.abs(p.psi[lg] - (u.c[lg] / p.nu[lg] - u.h[lg])).max(initial=0.0) <= 3e-4 * (1 + np.abs(p.psi).max())
+    assert np.abs(p.psi[qd] - u.h[qd] * (u.c[qd] - p.nu[qd])).max(initial=0.0) <= 3e-4 * (1 + np.abs(p.psi).max())
+
