@@ -695,7 +695,7 @@ class Problem:
         if general and n_sum:
             raise ValueError("a utility with ULOG / UQUAD entries over a network with constant-sum pools: the kink recovery ties prices, "
                              "the utility table's entries take no ties")
-        can_second = getattr(ctx, "second_order", False) and not self.net.get("gk") and not general      # (K-asset table pools, table utilities: first-order path only)
+        can_second = getattr(ctx, "second_order", False) and not self.net.get("gk")      # (K-asset table pools: first-order path only)
         if method not in _lib.METHODS:
             raise ValueError(f"method {method!r}: expected one of {sorted(_lib.METHODS)}")
         # auto: many stableswap pools -> second order straight away (first order needs thousands of evaluations there);

@@ -1222,7 +1222,6 @@ bool newton_supported(cfmm_ctx *ctx, const char **why)
 {
     if (ctx->ng != ctx->n) { *why = "price ties are set"; return false; }
     if (table_pools(ctx) > 0) { *why = "the network holds K-asset table pools (phik.hpp): first-order path only"; return false; }
-    if (ctx->general_utility) { *why = "the utility has entries beyond linear-plus-box (CFMM_ULOG / CFMM_UQUAD): first-order path only"; return false; }
     // (the Hessian instantiation of smooth_kernel carries the diagonal / pair cache on top of the psi tile: 24 n + 24832 bytes,
     //  i.e. 5792 tokens -- not the (2 n + 32) doubles of the round-2 kernel, which let 5.8k .. 10.2k tokens through to a launch
     //  failure)
@@ -1445,6 +1444,22 @@ int smooth_eval_host(cfmm_ctx *ctx, const std::vector<double> &nu, double mu, bo
     return CFMM_OK;
 }
 
+// the utility table's entries on the host (the second-order loop keeps the utility on the host): the numbers of
+// lbfgs::utility_term (lbfgs_rules.hpp), + nu^2 ubar''(nu) for the Hessian's diagonal in log-prices
+struct HostUtilityTerm { double pstar, ubar, uval, viol, d2; };
+static HostUtilityTerm host_utility_term(int ctype, double c, double h, double nu, double psi)
+{
+    HostUtilityTerm t;
+    if (ctype == CFMM_ULOG) {
+        t.pstar = c / nu - h; t.ubar = c * std::log(c / nu) - c + nu * h;
+        t.viol = std::max(-(psi + h), 0.0); t.uval = c * std::log(std::max(psi + h, 1e-300)); t.d2 = c;
+    } else {
+        t.pstar = h * (c - nu); t.ubar = 0.5 * h * (c - nu) * (c - nu);
+        t.viol = 0.0; t.uval = c * psi - 0.5 * psi * psi / h; t.d2 = h * nu * nu;
+    }
+    return t;
+}
+
 int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_before)
 {
     const char *why = "";
@@ -1509,13 +1524,20 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     auto assemble = [&](const std::vector<double> &p, const SmoothEval &e, double mu, std::vector<double> *grad, std::vector<double> *hdiag) {
         double g = e.value;
         for (int j = 0; j < n; ++j) {
-            g += (p[j] - c[j]) * h[j];
-            double Gj = p[j] * (e.psi[j] + h[j]), hj = 0.0;
+            double Gj, hj = 0.0;
+            if (ct[j] >= CFMM_ULOG) {                     // the utility table: conjugate, gradient nu (psi - P*), nu^2 ubar'' on the diagonal
+                const HostUtilityTerm ut = host_utility_term(ct[j], c[j], h[j], p[j], e.psi[j]);
+                g += ut.ubar;
+                Gj = p[j] * (e.psi[j] - ut.pstar);
+                hj = ut.d2;
+            } else {
+                g += (p[j] - c[j]) * h[j];
+                Gj = p[j] * (e.psi[j] + h[j]);
+            }
             if (ct[j] == CFMM_GE && !(c[j] > 0.0)) {      // nu_j > 0: the barrier is -mu log nu_j, linear in the log-price
                 g -= mu * std::log(p[j]);
                 Gj -= mu;
             }
-            (void)hj;
             if (grad) (*grad)[j] = mask[j] ? 0.0 : Gj;
             if (hdiag) (*hdiag)[j] = std::max(Gj, 0.0) + hj;
         }
@@ -1527,7 +1549,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             if (ctx->sm_ws[k]) HIP_TRY(ctx, hipMemsetAsync(ctx->sm_ws[k], 0, 2 * (size_t)ctx->pools->b2[k].m * sizeof(double), ctx->stream));
     if ((rc = exact(nu))) return rc;
     double dual = arb_x;
-    for (int j = 0; j < n; ++j) dual += (nu[j] - c[j]) * h[j];
+    for (int j = 0; j < n; ++j) dual += ct[j] >= CFMM_ULOG ? host_utility_term(ct[j], c[j], h[j], nu[j], 0.0).ubar : (nu[j] - c[j]) * h[j];
     static const double mu0_scale = getenv("CFMM_NEWTON_MU0") ? atof(getenv("CFMM_NEWTON_MU0")) : 0.1;                      // tuning knob
     double mu = mu0_scale * std::max(std::fabs(dual), 1e-300) / (double)std::max<long long>(nbar, 1);
     static const double warm_mult = getenv("CFMM_NEWTON_WARM") ? atof(getenv("CFMM_NEWTON_WARM")) : 1e3;                    // tuning knob
@@ -1582,6 +1604,14 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         primal = 0.0;
         double cs = 0.0, viol = 0.0, scale = 0.0, lin = 0.0;
         for (int j = 0; j < n; ++j) {
+            if (ct[j] >= CFMM_ULOG) {                      // Fenchel-Young gap term of a table entry (lbfgs_rules.hpp)
+                const HostUtilityTerm ut = host_utility_term(ct[j], c[j], h[j], nu[j], e.psi[j]);
+                lin += ut.ubar; primal += ut.uval;
+                cs += ut.ubar + nu[j] * e.psi[j] - ut.uval;
+                viol = std::max(viol, ut.viol);
+                scale = std::max(scale, std::max(std::fabs(e.psi[j]), std::fabs(ut.pstar)));
+                continue;
+            }
             const double r = e.psi[j] + h[j];
             lin += (nu[j] - c[j]) * h[j];
             primal += c[j] * e.psi[j];

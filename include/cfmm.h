@@ -86,8 +86,8 @@ enum {
 enum { CFMM_GE = 0, CFMM_EQ = 1, CFMM_FREE = 2,
        /* the utility table: separable concave utilities beyond the reference's linear-plus-box (not in the
         * reference, whose objectives are linear: arbitrage.py:78, liquidation.py:80, two-asset.py:87).  The token's c and h carry
-        * the entry's two parameters; its price has no bound.  First-order path (two launches per iteration), no price ties,
-        * no batching.
+        * the entry's two parameters; its price has no bound.  Both outer iterations take them (the first-order one in its generic
+        * two-launch form); no price ties, no batching.
         *   CFMM_ULOG   u(Psi) = c log(Psi + h),        c > 0, h >= 0
         *   CFMM_UQUAD  u(Psi) = c Psi - Psi^2 / (2 h),  h > 0 */
        CFMM_ULOG = 3, CFMM_UQUAD = 4 };

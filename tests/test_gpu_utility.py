@@ -84,14 +84,12 @@ def test_utility_table_small_instances_against_the_scipy_primal():
 
 
 def test_utility_table_refusals():
-    """what does not take such utilities says so: the second-order path, the batched solves, price ties, bad parameters"""
+    """what does not take such utilities says so: the batched solves, price ties, bad parameters"""
     net = synthetic.config("C3", scale=0.01, seed=1)
     n = net["n_tokens"]
     u = _utilities(net)["log"]
     p = cfmm.Problem.from_network(net, utility=u)
-    with pytest.raises(_lib.CfmmError, match="first-order path only"):
-        p.solve(method="newton")
-    assert p.solve(tol=1e-6) is not None and p.status == "optimal"          # ... and the default method takes the first-order path
+    assert p.solve(tol=1e-6) is not None and p.status == "optimal"          # (the default method takes the first-order path)
     res = p.solve_many([u, _utilities(net, seed=3)["log"]], tol=1e-6)        # not batched (one at a time, on clones): still solved
     assert all(r["status"] == "optimal" for r in res)
     ctx = _lib.Context(n)
@@ -103,3 +101,26 @@ def test_utility_table_refusals():
     with pytest.raises(_lib.CfmmError, match="no price ties"):
         ctx.set_ties(np.arange(n, dtype=np.int32) // 2, np.zeros(n))
     ctx.close(); p.close()
+
+
+@pytest.mark.parametrize("which", ["log", "mixed"])
+def test_utility_table_through_the_second_order_path(which):
+    """the barrier-smoothed Newton iteration keeps the utility on the host (cfmm_hip.hip: solve_newton): a table entry adds its
+    conjugate, nu (psi - P*) to the gradient and nu^2 ubar'' to the Hessian's diagonal -- the same optimum as the first-order
+    path, in a dozen steps where an agent far from the market costs the first-order iteration hundreds of evaluations"""
+    net = synthetic.config("C3", scale=0.03, seed=4)
+    n = net["n_tokens"]
+    rng = np.random.default_rng(9)
+    hold = np.exp(rng.normal(3, 0.5, n)) / net["prices"]
+    far = cfmm.LogUtility(np.exp(rng.normal(0, 0.3, n)), hold)                 # values its holdings ~20x off the market
+    u = far if which == "log" else _utilities(net)["mixed"]
+    p = cfmm.Problem.from_network(net, utility=u)
+    v2 = p.solve(method="newton", tol=1e-7)
+    assert p.status == "optimal" and p.gap <= 1e-7 and p.infeas <= 1e-7, (p.status, p.gap, p.infeas)
+    steps, psi2 = p.stats["newton_steps"], p.psi.copy()
+    assert abs(v2 - _utility_value(u, psi2)) <= 1e-9 * max(1.0, abs(v2))
+    v1 = p.solve(method="lbfgs", tol=1e-7, max_evals=8000)
+    assert p.status == "optimal", (p.status, p.stats["evals"])
+    assert abs(v1 - v2) <= 1e-6 * max(1.0, abs(v1)) and steps <= 40
+    p.close()
+
