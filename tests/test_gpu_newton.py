@@ -73,7 +73,7 @@ def _with_env(monkeypatch, **env):
         monkeypatch.setenv(k, v)
 
 
-@pytest.mark.parametrize("n", [33, 100, 200, 1000])
+@pytest.mark.parametrize("n", [33, 100, 200, 1000, 2050])
 def test_cholesky_pairs_of_block_columns_against_one_per_launch(n, monkeypatch):
     """chol2.hpp (two block columns per launch, side products on the fp64 matrix pipe) against chol.hpp (one per launch):
     solution, the chord step's apply through the inverse factor, the flag of an indefinite matrix"""
