@@ -84,6 +84,8 @@ struct DevBuf {
 struct PoolStore {
     Bucket2 b2[CFMM_POOL_KINDS2] = {};
     void *b2mem[CFMM_POOL_KINDS2] = {};           // one arena (one hipMalloc) per bucket: every column lives in it
+    void *c2mem[CFMM_POOL_KINDS2] = {};           // the bucket's compact mirror (kernels.hpp: Bucket2::cid / cfee / ctab), built in pools_ready
+    bool c2tried[CFMM_POOL_KINDS2] = {};          // ... or found not to apply (more than 256 distinct fees)
     BucketN bn[CFMM_MAX_POOL_SIZE + 1] = {};
     void *bnmem[CFMM_MAX_POOL_SIZE + 1] = {};
     BucketG bg[CFMM_POOLK_KINDS][CFMM_MAX_POOL_SIZE + 1] = {};      // the K-asset table's buckets (phik.hpp): [kind][k]
@@ -102,6 +104,7 @@ struct PoolStore {
     {
         for (auto &q : landed) (void)hipFree(q.first);
         for (void *q : b2mem) if (q) (void)hipFree(q);
+        for (void *q : c2mem) if (q) (void)hipFree(q);
         for (void *q : bnmem) if (q) (void)hipFree(q);
         for (auto &row : bgmem) for (void *q : row) if (q) (void)hipFree(q);
     }
@@ -2092,10 +2095,37 @@ static bool reorder_bucketN(cfmm_ctx *ctx, int k, BucketN &b, void **arena, size
 }
 
 // in front of everything that reads the pools on the device: the pending token-block orderings, on this context's stream
+// The compact mirror of the large two-asset buckets of the main tile space (kernels.hpp: Bucket2::cid): built once per upload, on
+// the device, behind the token-block ordering.  One synchronisation per bucket and upload (the builder reports whether the
+// bucket's fees fit the 256-entry table).  CFMM_COMPACT = 0 / 1: never / whatever the size (A/B).
+static void build_compact_mirrors(cfmm_ctx *ctx, PoolStore &ps)
+{
+    static const int mode = getenv("CFMM_COMPACT") ? atoi(getenv("CFMM_COMPACT")) : -1;
+    if (mode == 0 || ctx->n > 65536) return;
+    for (int k : {CFMM_POOL_CP2, CFMM_POOL_W2, CFMM_POOL_SUM2}) {
+        Bucket2 &b = ps.b2[k];
+        if (ps.c2tried[k] || b.m == 0 || (mode < 0 && b.m < 1000000)) continue;
+        ps.c2tried[k] = true;
+        const size_t m = (size_t)b.m, off_fee = (4 * m + 255) & ~(size_t)255, off_tab = (off_fee + m + 255) & ~(size_t)255;
+        char *mem = nullptr;
+        if (hipMalloc((void **)&mem, off_tab + 256 * 8 + 64) != hipSuccess) { (void)hipGetLastError(); continue; }
+        (void)hipMemsetAsync(mem + off_tab, 0, 256 * 8 + 64, ctx->stream);
+        int *flag = (int *)(mem + off_tab + 256 * 8);
+        hipLaunchKernelGGL(compact_build_kernel, dim3((unsigned)std::min<size_t>((m + 255) / 256, 4096)), dim3(256), 0, ctx->stream, b,
+                           (unsigned *)mem, (unsigned char *)(mem + off_fee), (unsigned long long *)(mem + off_tab), flag);
+        int over = 1;
+        if (hipMemcpyAsync(&over, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) over = 1;
+        if (over) { (void)hipGetLastError(); (void)hipFree(mem); continue; }      // more than 256 distinct fees: the bucket keeps its columns
+        ps.c2mem[k] = mem;
+        b.cid = (const unsigned *)mem; b.cfee = (const unsigned char *)(mem + off_fee); b.ctab = (const double *)(mem + off_tab);
+    }
+}
+
 static void pools_ready(cfmm_ctx *ctx)
 {
     PoolStore &ps = *ctx->pools;
     std::lock_guard<std::mutex> guard(ps.mu);
+    struct Mirrors { cfmm_ctx *c; PoolStore &p; ~Mirrors() { build_compact_mirrors(c, p); } } mirrors{ctx, ps};      // (on every way out, behind the orderings)
     {   // Is there anything to gain?  A K-asset pool localises two of its K legs; the other K - 2 land anywhere, and once a
         // workgroup's share of those stray legs is of the order of the token count its psi tile is dense whatever the order of
         // the two-asset pools (C3: 1e5 K-asset pools, ~1400 stray legs per workgroup over 1000 tokens: the ordering bought
@@ -2217,6 +2247,8 @@ int cfmm_upload_pools2(cfmm_ctx *ctx, int kind, int64_t m, const double *Ra, con
     }
     const double mxr = scan.mxr, mnf = scan.mnf;
     if (ctx->pools->b2mem[kind]) (void)hipFree(ctx->pools->b2mem[kind]);
+    if (ctx->pools->c2mem[kind]) { (void)hipFree(ctx->pools->c2mem[kind]); ctx->pools->c2mem[kind] = nullptr; }
+    ctx->pools->c2tried[kind] = false;
     ctx->pools->b2mem[kind] = arena;
     ctx->pools->b2[kind] = b;
     ctx->pools->ro2[kind] = ro_total;

@@ -81,6 +81,14 @@ struct Bucket2 {
     const double *Ra, *Rb, *fee, *param;
     const int *ia, *ib, *flags;
     const int *perm;                  // position -> the caller's pool index (reorder.hpp); null = the caller's order
+    // the COMPACT MIRROR of the ids and the fee (round 4; built on the device behind the upload for buckets of >= 1e6 pools,
+    // compact_build_kernel): token ids as one 32-bit word (ia | ib << 16: fewer than 65536 tokens fit the LDS tiles anyway) and the
+    // fee as a one-byte index into a table of the bucket's distinct fees (<= 256 of them, else no mirror) -- 21 bytes per
+    // constant-product pool instead of 32, bit for bit the same numbers.  The evaluation tiles take it when present; a pool set
+    // of 160 MB .. 1.28 GB is evaluated at ~6.5 TB/s of bytes MOVED whatever its size, so the bytes are the time.
+    const unsigned *cid;
+    const unsigned char *cfee;
+    const double *ctab;
 };
 
 struct BucketN {
@@ -92,6 +100,25 @@ struct BucketN {
                                       // a = log(R p / w) is ONE add where it was a 36-instruction log per leg and evaluation (round 4)
     const int *perm;                  // position -> the caller's pool index (reorder.hpp); null = the caller's order
 };
+
+// builds a bucket's compact mirror; tab: 256 slots of fee BITS, zero = empty (a fee is > 0), open addressing
+__global__ void __launch_bounds__(256) compact_build_kernel(Bucket2 b, unsigned *cid, unsigned char *cfee, unsigned long long *tab, int *overflow)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < b.m; i += stride) {
+        cid[i] = (unsigned)b.ia[i] | ((unsigned)b.ib[i] << 16);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(b.fee[i]);
+        unsigned h = (unsigned)((bits * 0x9E3779B97F4A7C15ull) >> 56);
+        int slot = -1;
+        for (int probe = 0; probe < 256; ++probe, h = (h + 1) & 255u) {
+            unsigned long long cur = tab[h];
+            if (cur == 0ull) cur = atomicCAS(&tab[h], 0ull, bits), cur = cur == 0ull ? bits : cur;
+            if (cur == bits) { slot = (int)h; break; }
+        }
+        if (slot < 0) { *overflow = 1; slot = 0; }
+        cfee[i] = (unsigned char)slot;
+    }
+}
 
 struct EvalArgs {
     Bucket2 b2[N_KINDS2];             // indexed by CFMM_POOL_* kind
@@ -311,8 +338,15 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
             ia[u] = live[u] ? pre->i[u] : 0; ib[u] = live[u] ? pre->i[U + u] : 0;     // (a dead lane holds a clamped chunk's tail: not a token id)
             prm[u] = (KIND == 1 || KIND >= 3) ? pre->d[U == 1 ? 3 : 0] : 0.0;
         } else {
-            Ra[u] = ld_off<NT>(b.Ra, i); Rb[u] = ld_off<NT>(b.Rb, i); g[u] = ld_off<NT>(b.fee, i);
-            ia[u] = ld_off<NT>(b.ia, i); ib[u] = ld_off<NT>(b.ib, i);
+            Ra[u] = ld_off<NT>(b.Ra, i); Rb[u] = ld_off<NT>(b.Rb, i);
+            if (b.cid) {                    // the compact mirror (wave-uniform: a property of the bucket)
+                const unsigned pk = ld_off<NT>(b.cid, i);
+                ia[u] = (int)(pk & 0xffffu); ib[u] = (int)(pk >> 16);
+                g[u] = b.ctab[ld_off<NT>(b.cfee, i)];
+            } else {
+                g[u] = ld_off<NT>(b.fee, i);
+                ia[u] = ld_off<NT>(b.ia, i); ib[u] = ld_off<NT>(b.ib, i);
+            }
             prm[u] = (KIND == 1 || KIND >= 3) ? ld_off<NT>(b.param, i) : 0.0;
         }
         fl[u] = (KIND == 2 && b.flags) ? ld_off(b.flags, i) : 0;
@@ -505,7 +539,7 @@ __device__ __forceinline__ void tile_dma_issue(const EvalArgs &a, int bk, int tb
         const unsigned lim = (m - 1u) & ~1u, lim4 = (m - 1u) & ~3u;
         e = e < lim ? e : lim; e4 = e4 < lim4 ? e4 : lim4;
         const size_t off = (size_t)e * 8u;
-        static_assert(WT_LIGHT == 128, "slot layout of the two-pools-per-lane tiles");
+        static_assert(!CFMM_STAGED_WALK || WT_LIGHT == 128, "slot layout of the two-pools-per-lane tiles");
         const char *s0 = pA + off, *s1 = pB + off, *s2 = pF + off, *s3 = (hi ? pIb : pIa) + (size_t)e4 * 4u;
         glds16(s0, stage);
         glds16(s1, stage + 1024u);

@@ -1013,6 +1013,51 @@ def test_k_asset_tiles_with_and_without_the_log_price_table(oracle_lib):
     p.close()
 
 
+def test_compact_mirror_of_ids_and_fees_is_bit_identical(oracle_lib):
+    """buckets of >= 1e6 two-asset pools are evaluated from a compact mirror of their token ids (one 32-bit word) and fees (a
+    one-byte index into the bucket's distinct fees): kernels.hpp Bucket2::cid.  CFMM_COMPACT=1 forces it on a small network, in a
+    process of its own (the knob is read once): bit-identical psi in the reproducible mode, the oracle's evaluation otherwise, the
+    same certified solve -- and a bucket with more than 256 distinct fees keeps its columns and its answers"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json, numpy as np\n"
+        f"sys.path[:0] = [{root!r}, {os.path.join(root, 'cfmm-routing-code_amd')!r}]\n"
+        "import cfmm\nfrom cfmm import synthetic\n"
+        "out = {}\n"
+        "for tag in ('tiers', 'many'):\n"
+        "    net = synthetic.config('C3', scale=0.05)\n"
+        "    if tag == 'many':\n"
+        "        net['cp2']['fee'] = 0.99 + 0.009 * np.random.default_rng(1).random(len(net['cp2']['fee']))\n"
+        "    nu = net['c'] * np.exp(np.random.default_rng(0).normal(0, 0.03, net['n_tokens']))\n"
+        "    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net['c']))\n"
+        "    f, psi, diag = p.eval_dual(nu, want_diag=True)\n"
+        "    v = p.solve(tol=1e-6)\n"
+        "    q = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net['c']), deterministic=True)\n"
+        "    fd, psid = q.eval_dual(nu)\n"
+        "    out[tag] = dict(f=f, psi=psi.tolist(), diag=diag.tolist(), v=v, status=p.status, psid=[x.hex() for x in psid.tolist()])\n"
+        "print(json.dumps(out))\n")
+    res = {}
+    for mode in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CFMM_COMPACT=mode), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    for tag in ("tiers", "many"):
+        a, b = res["1"][tag], res["0"][tag]
+        assert a["psid"] == b["psid"]                                            # reproducible mode: bit for bit
+        assert a["status"] == b["status"] == "optimal" and abs(a["v"] - b["v"]) <= 2e-6 * abs(b["v"])
+        net = synthetic.config("C3", scale=0.05)
+        if tag == "many":
+            net["cp2"]["fee"] = 0.99 + 0.009 * np.random.default_rng(1).random(len(net["cp2"]["fee"]))
+        o = _oracle_for(oracle_lib, net)
+        nu = net["c"] * np.exp(np.random.default_rng(0).normal(0, 0.03, net["n_tokens"]))
+        f0, psi0, diag0 = o.eval(nu, True)
+        assert np.abs(np.array(a["psi"]) - psi0).max() <= 1e-10 * np.abs(psi0).max() and abs(a["f"] - f0) <= 1e-10 * abs(f0)
+        assert np.abs(np.array(a["diag"]) - diag0).max() <= 1e-10 * np.abs(diag0).max()
+
+
 def test_non_temporal_instantiations_match_the_oracle(oracle_lib, tmp_path):
     """pool sets beyond twice the Infinity Cache stream their columns with non-temporal loads (kernels.hpp: ld_off<NT>; own
     instantiations of eval_kernel / iter_kernel, taken automatically at >= 512 MB).  CFMM_NT=1 forces them on a small network,
