@@ -60,7 +60,7 @@ SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm
            "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_debug_cholesky_apply", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_get_tradesG", "cfmm_comm_unique_id", "cfmm_comm_init",
            "cfmm_oneshot_export", "cfmm_oneshot_import", "cfmm_oneshot_attach", "cfmm_oneshot_mailbox", "cfmm_oneshot_enable",
-           "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_time_newton_kernels", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_stream"]
+           "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_time_newton_kernels", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_eval_bytes", "cfmm_stream"]
 
 
 def lib():
@@ -112,6 +112,7 @@ def lib():
     L.cfmm_selftest.argtypes = [vp]
     L.cfmm_debug_timers.argtypes = [vp, C.POINTER(C.c_int64)]
     L.cfmm_pool_count.restype = C.c_int64; L.cfmm_pool_count.argtypes = [vp]
+    L.cfmm_eval_bytes.restype = C.c_int64; L.cfmm_eval_bytes.argtypes = [vp]
     L.cfmm_stream.restype = vp; L.cfmm_stream.argtypes = [vp]
     _lib = L
     return L
@@ -376,6 +377,10 @@ class Context:
 
     def pool_count(self):
         return int(self.L.cfmm_pool_count(self.h))
+
+    def eval_bytes(self):
+        """bytes of pool columns one dual evaluation loads as stored now (compact mirrors where built)"""
+        return int(self.L.cfmm_eval_bytes(self.h))
 
 
 def comm_unique_id():

@@ -690,17 +690,27 @@ void det_scales(cfmm_ctx *ctx, double &sc, double &scd)
 
 // `only` = a bucket code to evaluate that bucket alone (measurement hook), or 0x7fffffff for all;
 // `stable` selects the tile space of eval_kernel<.., STABLE>: the stableswap bucket alone, or everything else
-EvalArgs make_eval_args(cfmm_ctx *ctx, bool stable, int only = 0x7fffffff)
+static bool wide_tiles(const cfmm_ctx *ctx)
+{
+    static const int wide_mode = getenv("CFMM_WIDE") ? atoi(getenv("CFMM_WIDE")) : -1;
+    return !CFMM_STAGED_WALK && !ctx->det && (wide_mode > 0 || (wide_mode < 0 && ctx->pools->b2[CFMM_POOL_CP2].m >= 8000000));
+}
+// `big`: the caller launches through launch_eval / enqueue_fused_iteration, which pick the instantiation by large_set_mode()
+EvalArgs make_eval_args(cfmm_ctx *ctx, bool stable, int only = 0x7fffffff, bool big = true)
 {
     EvalArgs a = {};
     for (int k = 0; k < CFMM_POOL_KINDS2; ++k) a.b2[k] = ctx->pools->b2[k];
     a.b2[CFMM_POOL_SUM2].flags = ctx->flags2;
     for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) a.bn[k - 3] = ctx->pools->bn[k];
+    // wide constant-product tiles (kernels.hpp: EvalArgs::wide): for a bucket whose evaluation is bound by memory latency -- 4.8 ns per
+    // 1000 pools whatever level serves them, 64 KB in flight per CU -- twice the bytes in flight per wave: 4e7 pools 192 -> 166 us,
+    // 1e7 pools 40.5 -> 39.4; at 1.25e6 pools (the C4 shard) and at C3 the narrower tiles win.  CFMM_WIDE = 0 / 1 for A/B.
+    a.wide = (big && wide_tiles(ctx)) ? 1 : 0;
     long long tiles = 0;
     for (int q = 0; q < N_BUCKETS; ++q) {
         const int code = kOrder[q];
         const long long m = code < 0 ? ctx->pools->bn[-code].m : ctx->pools->b2[code].m;
-        const int wt = wave_tile_pools(code);
+        const int wt = (code == CFMM_POOL_CP2 && a.wide) ? WT_WIDE : wave_tile_pools(code);
         if ((only == 0x7fffffff || only == code) && ((code >= 0 && heavy_kind(code)) == stable)) tiles += (m + wt - 1) / wt;
         a.tile_end[q] = (int)tiles;
     }
@@ -752,6 +762,19 @@ static bool stream_nt(const cfmm_ctx *ctx)
     for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) bytes += (double)ctx->pools->bn[k].m * (20.0 + 20.0 * k);
     return !ctx->det && bytes > 2.0 * 256.0 * 1048576.0;
 }
+// The instantiation of eval_kernel / iter_kernel for this pool set (their NT parameter):
+//   0  the plain one: no mirror, no wide tiles -- everything below 1e6 pools per bucket (C2, C3, the C4 shard), whose inner
+//      loop must not carry a byte of the two large-set paths (C3 paid 0.5 us per launch, C2 0.3, for a test around its load clause);
+//   1  large sets read once per launch: compact mirror + wide tiles, non-temporal loads;
+//   2  large sets that stay partly cached between launches: compact mirror + wide tiles, cached loads.
+static int large_set_mode(const cfmm_ctx *ctx)
+{
+    if (ctx->det) return 0;
+    if (stream_nt(ctx)) return 1;
+    bool mirror = false;
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) mirror = mirror || ctx->pools->c2mem[k] != nullptr;
+    return (mirror || wide_tiles(ctx)) ? 2 : 0;
+}
 static bool eval_dma(const cfmm_ctx *ctx, bool with_d) { return CFMM_STAGED_WALK && ctx->tile_dma && !ctx->det && eval_lds_bytes(ctx->n, with_d, false, true) <= LDS_MAX; }
 static bool iter_dma(const cfmm_ctx *ctx) { return CFMM_STAGED_WALK && ctx->tile_dma && !ctx->det && iter_lds_bytes(ctx->n, false, true) <= LDS_MAX; }
 
@@ -768,7 +791,8 @@ void launch_eval(cfmm_ctx *ctx, const EvalArgs &a_in, hipStream_t stream = nullp
 #if CFMM_STAGED_WALK
     else if (!STABLE && eval_dma(ctx, WITH_D)) hipLaunchKernelGGL((eval_kernel<WITH_D, false, false, true>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D, false, true), stream, a);
 #endif
-    else if (!STABLE && stream_nt(ctx)) hipLaunchKernelGGL((eval_kernel<WITH_D, false, false, false, true>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), stream, a);
+    else if (!STABLE && large_set_mode(ctx) == 1) hipLaunchKernelGGL((eval_kernel<WITH_D, false, false, false, 1>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), stream, a);
+    else if (!STABLE && large_set_mode(ctx) == 2) hipLaunchKernelGGL((eval_kernel<WITH_D, false, false, false, 2>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), stream, a);
     else hipLaunchKernelGGL((eval_kernel<WITH_D, STABLE>), dim3(grid), dim3(threads), eval_lds_bytes(ctx->n, WITH_D), stream, a);
 }
 
@@ -867,8 +891,10 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, eval_kernel<true, false>, e1))) return rc;
     if ((rc = set_lds_attr(ctx, eval_kernel<false, true>, e0))) return rc;
     if ((rc = set_lds_attr(ctx, eval_kernel<true, true>, e1))) return rc;
-    if ((rc = set_lds_attr(ctx, eval_kernel<false, false, false, false, true>, e0))) return rc;
-    if ((rc = set_lds_attr(ctx, eval_kernel<true, false, false, false, true>, e1))) return rc;
+    if ((rc = set_lds_attr(ctx, eval_kernel<false, false, false, false, 1>, e0))) return rc;
+    if ((rc = set_lds_attr(ctx, eval_kernel<true, false, false, false, 1>, e1))) return rc;
+    if ((rc = set_lds_attr(ctx, eval_kernel<false, false, false, false, 2>, e0))) return rc;
+    if ((rc = set_lds_attr(ctx, eval_kernel<true, false, false, false, 2>, e1))) return rc;
 #if CFMM_STAGED_WALK
     if (eval_lds_bytes(ctx->n, false, false, true) <= LDS_MAX && (rc = set_lds_attr(ctx, eval_kernel<false, false, false, true>, eval_lds_bytes(ctx->n, false, false, true)))) return rc;
     if (eval_lds_bytes(ctx->n, true, false, true) <= LDS_MAX && (rc = set_lds_attr(ctx, eval_kernel<true, false, false, true>, eval_lds_bytes(ctx->n, true, false, true)))) return rc;
@@ -891,8 +917,10 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, true>, il))) return rc;
     if ((rc = set_lds_attr(ctx, iter_kernel<2, false, false>, il))) return rc;
     if ((rc = set_lds_attr(ctx, iter_kernel<2, false, true>, il))) return rc;
-    if ((rc = set_lds_attr(ctx, iter_kernel<2, false, false, false, true>, il))) return rc;
-    if ((rc = set_lds_attr(ctx, iter_kernel<2, false, true, false, true>, il))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<2, false, false, false, 1>, il))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<2, false, true, false, 1>, il))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<2, false, false, false, 2>, il))) return rc;
+    if ((rc = set_lds_attr(ctx, iter_kernel<2, false, true, false, 2>, il))) return rc;
 #if CFMM_STAGED_WALK
     if (ctx->n <= 2 * EVAL_THREADS && iter_lds_bytes(ctx->n, false, true) <= LDS_MAX) {
         const size_t ilm = iter_lds_bytes(ctx->n, false, true);
@@ -993,7 +1021,8 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
         if (grid > slots) grid = slots;
         if (grid < 1) grid = 1;                                 // (a shard without pools still takes the step)
     }
-    const bool dma = iter_dma(ctx), nt = !dma && stream_nt(ctx);
+    const bool dma = iter_dma(ctx);
+    const int big = dma ? 0 : large_set_mode(ctx);
     const size_t lds = iter_lds_bytes(n, ctx->det, dma);
     const dim3 g(grid), b(threads);
 #if CFMM_STAGED_WALK
@@ -1002,7 +1031,8 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
 #define ITER_LAUNCH_DMA if (false) { }
 #endif
 #define ITER_LAUNCH(EE) do { \
-        ITER_LAUNCH_DMA else if (nt) { if (a.plain) hipLaunchKernelGGL((iter_kernel<2, false, true, false, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<2, false, false, false, true>), g, b, lds, ctx->stream, a); } \
+        ITER_LAUNCH_DMA else if (big == 1) { if (a.plain) hipLaunchKernelGGL((iter_kernel<2, false, true, false, 1>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<2, false, false, false, 1>), g, b, lds, ctx->stream, a); } \
+        else if (big == 2) { if (a.plain) hipLaunchKernelGGL((iter_kernel<2, false, true, false, 2>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<2, false, false, false, 2>), g, b, lds, ctx->stream, a); } \
         else if (ctx->det) { if (a.plain) hipLaunchKernelGGL((iter_kernel<EE, true, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<EE, true, false>), g, b, lds, ctx->stream, a); } \
         else { if (a.plain) hipLaunchKernelGGL((iter_kernel<EE, false, true>), g, b, lds, ctx->stream, a); else hipLaunchKernelGGL((iter_kernel<EE, false, false>), g, b, lds, ctx->stream, a); } } while (0)
     if (E == 1) ITER_LAUNCH(ITER_E_SMALL); else ITER_LAUNCH(2);
@@ -1133,6 +1163,7 @@ bool same_opts(const cfmm_opts &a, const cfmm_opts &b) { return std::memcmp(&a, 
 
 extern "C" int cfmm_eval_dual(cfmm_ctx *ctx, const double *nu, double *arb_sum, double *psi, double *diag);
 extern "C" int64_t cfmm_pool_count(cfmm_ctx *ctx);
+extern "C" int64_t cfmm_eval_bytes(cfmm_ctx *ctx);
 
 // ---------------------------------------------------------------------------------------------
 // Second-order outer iteration (CFMM_METHOD_NEWTON): barrier-smoothed dual Newton, smooth.hpp.
@@ -2037,6 +2068,21 @@ int64_t cfmm_pool_count(cfmm_ctx *ctx)
     return m;
 }
 
+// The bytes of pool columns ONE dual evaluation loads, as the columns are stored now (after the first evaluation or solve: the
+// compact mirrors are built in front of it) -- what bench.py prices next to the algorithmic bytes of SURVEY 8(d).
+int64_t cfmm_eval_bytes(cfmm_ctx *ctx)
+{
+    if (!ctx) return 0;
+    int64_t bytes = 0;
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) {
+        const bool par = !(k == CFMM_POOL_CP2 || k == CFMM_POOL_SUM2);
+        const bool mirror = ctx->pools->c2mem[k] != nullptr && !ctx->det && !heavy_kind(k);
+        bytes += ctx->pools->b2[k].m * ((mirror ? 21 : 32) + (par ? 8 : 0));
+    }
+    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) bytes += ctx->pools->bn[k].m * (20 + 20 * k);
+    return bytes;
+}
+
 // ---- token-block ordering of a freshly uploaded bucket (reorder.hpp) -------------------------------------------------
 // Done lazily, in front of the first kernel that reads the pools (pools_ready): the upload's copies are not queued behind
 // sort kernels, and its arena is not twice the size (a 2x allocation slowed the H2D copies: 1.31 -> 2.2 ms for C3).  The
@@ -2767,7 +2813,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
     cfmm_opts o = o_in;
     // One launch per iteration (iterate.hpp) whenever the update fits the evaluation launch; otherwise the
     // two-launch iteration (evaluation kernel, single-workgroup update kernel).
-    const EvalArgs ea_tiny = make_eval_args(ctx, false);
+    const EvalArgs ea_tiny = make_eval_args(ctx, false, 0x7fffffff, false);
     const bool tiny = tiny_applies(ctx, ea_tiny, o);
     const bool fused = !tiny && fused_applies(ctx, o);
     if (fused) o.iters_per_graph = (o.iters_per_graph + 2) / 3 * 3;       // the rotation phase t % 3 is baked into captured launches
@@ -2984,7 +3030,7 @@ int cfmm_solve_batch(cfmm_ctx *const *ctxs, int nb, const double *const *nu0, co
     }
     UpdArgs lead = c0->upd_batch_h[0];
     lead.batch = c0->upd_batch_d;
-    const EvalArgs ea = make_eval_args(c0, false);
+    const EvalArgs ea = make_eval_args(c0, false, 0x7fffffff, false);
     int egrid, ethreads;
     eval_geometry(c0, ea.ntiles, egrid, ethreads);
     const size_t elds = batch_lds_bytes(n, nb), ulds = upd_lds_bytes(n);

@@ -251,7 +251,7 @@ __host__ __device__ inline int iter_extra_lds_doubles(int n, bool dma = false)
 // as the scalar section has decided that this launch evaluates at all -- its columns arrive while the direction and the
 // trial point are still being formed
 // NT: the pool columns through non-temporal loads (kernels.hpp: ld_off) -- pool sets several times the Infinity Cache
-template <int E, bool DET = false, bool PLAIN = false, bool DMA = false, bool NT = false>
+template <int E, bool DET = false, bool PLAIN = false, bool DMA = false, int NT = 0>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 iter_kernel(IterArgs a)
 {

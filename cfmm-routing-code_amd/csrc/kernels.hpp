@@ -47,6 +47,7 @@ constexpr int MAX_MEMORY = 8;         // L-BFGS pairs kept (register-resident in
 #endif
 constexpr int WT_LIGHT = WT_LIGHT_DEF;  // cp2, sum2: two pools per lane
 constexpr int WT_HEAVY = 64;          // w2, curve2: one pool per lane
+constexpr int WT_WIDE = 256;          // cp2 of a very large bucket (EvalArgs::wide): four pools per lane
 // The staged tile walk (LDS-DMA one tile ahead, below) is compiled in with -DCFMM_STAGED_WALK=1 (`make variant TAG=staged
 // DEFS=-DCFMM_STAGED_WALK=1`) and then taken unless CFMM_TILE_DMA=0.  Round 4 built it, validated it (the whole -m gpu suite
 // passes through it) and measured it SLOWER than the direct walk on every BASELINE config (tried and rejected):
@@ -126,6 +127,8 @@ struct EvalArgs {
     int tile_end[N_BUCKETS];          // cumulative wave-tile counts in processing order
     int ntiles, n, nslices;
     int rev;                          // 1: this launch walks every workgroup's tile range BACKWARDS (see eval_tiles_and_flush)
+    int wide;                         // 1: the constant-product bucket is walked in tiles of WT_WIDE pools (4 per lane) instead of WT_LIGHT:
+                                      //    twice the bytes in flight per wave for a bucket whose evaluation is bound by memory latency (>= 8e6 pools)
     const double *nu;                 // [n + 1]: prices, then the stop flag (non-zero = solve has ended)
     double *acc;
     long long *ts;                    // phase timers (tuning builds only)
@@ -223,6 +226,8 @@ __device__ __forceinline__ double wave_max(double v) { return wave_allmax(v); }
 // bandwidth: at 1.28 GB per evaluation (4e7 constant-product pools) the `nt` loads run the evaluation at 6.59 TB/s instead of
 // 6.16 (194 against 208 us).  At 320 MB, where the ping-pong walk finds most of a launch still cached, they LOSE (52.4 against
 // 47.8 us): the host takes the NT instantiations above twice the cache size only (cfmm_hip.hip: stream_nt).
+// The kernels' NT parameter is the host's large_set_mode(): 0 the plain instantiation (no mirror, no wide tiles compiled in),
+// 1 large sets with non-temporal loads, 2 large sets with cached loads.
 template <bool NT = false, class T>
 __device__ __forceinline__ T ld_off(const T *base, unsigned i)
 {
@@ -315,17 +320,24 @@ __device__ __forceinline__ const char *uni_ptr(const void *p)
 // ------------------------------------------------------------------------------------------
 // PRE: the columns come from `pre` (the staged walk: tile_stage_read) instead of global memory
 // CARRY: sum arb is carried per lane (fsum); without it the caller forms it at the flush as nu' psi (sum_i arb_i = sum_i nu' y_i)
-template <int KIND, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false, bool NT = false, bool CARRY = true>
+// UU: pools per lane (0 = the kind's own: wave_tile_pools / 64); the wide constant-product tiles of large buckets pass 4
+template <int KIND, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false, int NT = 0, bool CARRY = true, int UU = 0>
 __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, const double *nu_s,
                                       const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double &fsum, const BatchCtl &bc,
                                       const TileRegs *pre = nullptr)
 {
     static_assert(!(BATCH && WITH_D), "the batched evaluation does not build the metric");
-    constexpr int U = wave_tile_pools(KIND) / 64;
+    constexpr int U = UU ? UU : wave_tile_pools(KIND) / 64;
     asm volatile("" : "+v"(lane));              // (opaque: keeps per-kind lane arithmetic from being hoisted out of the tile loop)
     double Ra[U], Rb[U], g[U], prm[U];
     int ia[U], ib[U], fl[U];
+    unsigned idx[U];
     bool live[U];
+    // The compact mirror is compiled into the large-set instantiations only (NT >= 1), with ONE branch around their whole load
+    // clause; everything else keeps the loads inside the per-pool loop below, untouched.  Both mattered: with the test between
+    // the loads of a pool the compiler split the clause (C3 +0.8 us per launch), with the loads moved into a loop of their own
+    // behind the index loop it issued the two id loads, waited for them and only then issued the reserve loads (C3 +0.3, C2 +0.25).
+    constexpr bool BIG = !PRE && KIND <= 2 && NT >= 1;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         // (32-bit element offsets against the uniform column bases -- a bucket holds < 2^29 pools -- instead of seven 64-bit
@@ -333,23 +345,40 @@ __device__ __forceinline__ void tile2(const Bucket2 &b, long long i0, int lane, 
         unsigned i = (unsigned)i0 + u * 64 + lane;
         live[u] = i < (unsigned long long)b.m;
         i = live[u] ? i : (unsigned)b.m - 1u;
+        idx[u] = i;
         if constexpr (PRE) {
             Ra[u] = pre->d[u]; Rb[u] = pre->d[U + u]; g[u] = pre->d[2 * U + u];
             ia[u] = live[u] ? pre->i[u] : 0; ib[u] = live[u] ? pre->i[U + u] : 0;     // (a dead lane holds a clamped chunk's tail: not a token id)
             prm[u] = (KIND == 1 || KIND >= 3) ? pre->d[U == 1 ? 3 : 0] : 0.0;
-        } else {
-            Ra[u] = ld_off<NT>(b.Ra, i); Rb[u] = ld_off<NT>(b.Rb, i);
-            if (b.cid) {                    // the compact mirror (wave-uniform: a property of the bucket)
-                const unsigned pk = ld_off<NT>(b.cid, i);
-                ia[u] = (int)(pk & 0xffffu); ib[u] = (int)(pk >> 16);
-                g[u] = b.ctab[ld_off<NT>(b.cfee, i)];
-            } else {
-                g[u] = ld_off<NT>(b.fee, i);
-                ia[u] = ld_off<NT>(b.ia, i); ib[u] = ld_off<NT>(b.ib, i);
-            }
-            prm[u] = (KIND == 1 || KIND >= 3) ? ld_off<NT>(b.param, i) : 0.0;
+        } else if constexpr (!BIG) {
+            Ra[u] = ld_off<NT == 1>(b.Ra, i); Rb[u] = ld_off<NT == 1>(b.Rb, i); g[u] = ld_off<NT == 1>(b.fee, i);
+            ia[u] = ld_off<NT == 1>(b.ia, i); ib[u] = ld_off<NT == 1>(b.ib, i);
+            prm[u] = (KIND == 1 || KIND >= 3) ? ld_off<NT == 1>(b.param, i) : 0.0;
         }
-        fl[u] = (KIND == 2 && b.flags) ? ld_off(b.flags, i) : 0;
+        if constexpr (!BIG) fl[u] = (KIND == 2 && b.flags) ? ld_off(b.flags, i) : 0;
+    }
+    if constexpr (BIG) {
+        if (b.cid != nullptr) {                 // (wave-uniform: a property of the bucket)
+            unsigned pk[U];
+            unsigned char fi[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                Ra[u] = ld_off<NT == 1>(b.Ra, idx[u]); Rb[u] = ld_off<NT == 1>(b.Rb, idx[u]);
+                pk[u] = ld_off<NT == 1>(b.cid, idx[u]); fi[u] = ld_off<NT == 1>(b.cfee, idx[u]);
+                prm[u] = KIND == 1 ? ld_off<NT == 1>(b.param, idx[u]) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { g[u] = b.ctab[fi[u]]; ia[u] = (int)(pk[u] & 0xffffu); ib[u] = (int)(pk[u] >> 16); }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                Ra[u] = ld_off<NT == 1>(b.Ra, idx[u]); Rb[u] = ld_off<NT == 1>(b.Rb, idx[u]); g[u] = ld_off<NT == 1>(b.fee, idx[u]);
+                ia[u] = ld_off<NT == 1>(b.ia, idx[u]); ib[u] = ld_off<NT == 1>(b.ib, idx[u]);
+                prm[u] = KIND == 1 ? ld_off<NT == 1>(b.param, idx[u]) : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) fl[u] = (KIND == 2 && b.flags) ? ld_off(b.flags, idx[u]) : 0;
     }
 #pragma unroll 1
     for (unsigned mask = BATCH ? bc.alive : 1u; mask; mask &= mask - 1) {
@@ -411,7 +440,7 @@ template <int K>
 __host__ __device__ constexpr int pools_per_wave() { return ktile_pools(K); }
 
 // LNU: a = lrw + lnu_s[token] (the bucket's log(R / w) column and the workgroup's table of log-prices) instead of log(R p / w)
-template <int K, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false, bool NT = false, bool CARRY = true, bool LNU = false>
+template <int K, bool WITH_D, bool DET, bool BATCH = false, bool PRE = false, int NT = 0, bool CARRY = true, bool LNU = false>
 __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, const double *nu_s,
                                       const Scatter<DET> &psi_s, const Scatter<DET> &diag_s, double2 *xs, double &fsum, const BatchCtl &bc,
                                       const TileRegs *pre = nullptr, const double *lnu_s = nullptr)
@@ -431,9 +460,9 @@ __device__ __forceinline__ void tilen(const BucketN &b, long long tb, int lane, 
     int tok;
     double R, w, fee, lg;
     if constexpr (PRE) { tok = live ? pre->i[0] : 0; R = pre->d[0]; w = pre->d[1]; fee = pre->d[2]; lg = pre->d[3]; (void)leg; (void)pl; }     // (dead lanes: a neighbouring tile's legs or a clamped chunk's tail)
-    else { tok = ld_off<NT>(b.idx, leg); R = ld_off<NT>(b.R, leg); w = ld_off<NT>(b.w, leg); fee = ld_off<NT>(b.fee, pl); lg = ld_off<NT>(b.lfee, pl); }
+    else { tok = ld_off<NT == 1>(b.idx, leg); R = ld_off<NT == 1>(b.R, leg); w = ld_off<NT == 1>(b.w, leg); fee = ld_off<NT == 1>(b.fee, pl); lg = ld_off<NT == 1>(b.lfee, pl); }
     double lrw = 0.0;
-    if constexpr (LNU) lrw = ld_off<NT>(b.lrw, leg);
+    if constexpr (LNU) lrw = ld_off<NT == 1>(b.lrw, leg);
     const int gb = (g < P ? g : 0) * K;
 #pragma unroll 1
     for (unsigned mask = BATCH ? bc.alive : 1u; mask; mask &= mask - 1) {
@@ -663,7 +692,7 @@ __device__ __forceinline__ void build_tile_table(const EvalArgs &a, int *next_ti
 // DMA: the staged walk (above) -- `stage` is this wave's 4 KB LDS slot, `first_issued` says that the caller has already
 // issued the DMA of the wave's first tile (tiles_dma_first)
 // LNU: `lnu_s` = the workgroup's table of log-prices (filled by the caller next to nu_s): the K-asset tiles take a = log(R p / w) from it
-template <bool WITH_D, bool STABLE, bool DET = false, bool BATCH = false, bool FLUSH = true, bool DMA = false, bool NT = false, bool LNU = false>
+template <bool WITH_D, bool STABLE, bool DET = false, bool BATCH = false, bool FLUSH = true, bool DMA = false, int NT = 0, bool LNU = false>
 __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *acc, const double *nu_s, double *psi_t, double *diag_t,
                                                      double *fpart, int *next_tile, double2 *xs, const BatchCtl &bc = BatchCtl{1u, 0, 0},
                                                      double *const *acc_b = nullptr, const double *stage = nullptr, bool first_issued = false,
@@ -773,7 +802,10 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
         case 6: if constexpr (STABLE) { tile2<3, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[3], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
         case 7: if constexpr (STABLE) { tile2<4, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[4], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
         case 8: if constexpr (!STABLE) { tile2<1, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[1], (long long)tb * WT_HEAVY, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
-        case 9: if constexpr (!STABLE) { tile2<0, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
+        case 9: if constexpr (!STABLE) {
+                    if (NT >= 1 && a.wide) { if constexpr (NT >= 1) tile2<0, WITH_D, DET, BATCH, false, NT, !FLUSH, WT_WIDE / 64>(a.b2[0], (long long)tb * WT_WIDE, lane, nu_s, psi_s, diag_s, fsum, bc); }
+                    else tile2<0, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[0], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc);
+                } break;
         default: if constexpr (!STABLE) { tile2<2, WITH_D, DET, BATCH, false, NT, !FLUSH>(a.b2[2], (long long)tb * WT_LIGHT, lane, nu_s, psi_s, diag_s, fsum, bc); } break;
         }
 #ifdef CFMM_PHASE_TIMERS
@@ -859,7 +891,7 @@ __device__ __forceinline__ void eval_tiles_and_flush(const EvalArgs &a, double *
 }
 
 // DMA: the staged tile walk; the launch then carries one 4 KB slot per wave behind the exchange strips
-template <bool WITH_D, bool STABLE, bool DET = false, bool DMA = false, bool NT = false>
+template <bool WITH_D, bool STABLE, bool DET = false, bool DMA = false, int NT = 0>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_WAVES_PER_SIMD)
 eval_kernel(EvalArgs a)
 {

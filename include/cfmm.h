@@ -273,6 +273,10 @@ int cfmm_debug_smooth_hist(cfmm_ctx *ctx, uint64_t *out128, int reset);
 int cfmm_debug_smooth_samples(cfmm_ctx *ctx, double *out768);
 #endif
 int64_t cfmm_pool_count(cfmm_ctx *ctx);
+/* measurement hook: bytes of pool columns one dual evaluation loads AS STORED (behind the first evaluation / solve: large
+ * two-asset buckets then carry a compact mirror of their ids and fee, 21 B per constant-product pool instead of the 32 B
+ * SURVEY 8(d) counts) */
+int64_t cfmm_eval_bytes(cfmm_ctx *ctx);
 void *cfmm_stream(cfmm_ctx *ctx);                 /* the hipStream_t the library launches on */
 
 #ifdef __cplusplus
