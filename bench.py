@@ -274,6 +274,19 @@ def main():
     rows = kernel_table(prob, args.kernel_reps)
     for _ in range(args.warmup):
         prob.solve(tol=args.tol, **solve_kw)
+    # ... and, single process only, further UNTIMED solves until the host has settled too (reported as `extra_warmup_steps`): the
+    # first process on a fresh box has been seen enqueueing launches too slowly to keep the device fed (pageable uploads at 9 GB/s
+    # instead of 24, 30.7 us per iteration of device time for a 20.9 us launch) for its first tens of milliseconds.  Steady = the last
+    # four solves within 5 % of the fastest seen; bounded by 1 s and 400 solves.  The timed region is still exactly K cold solves.
+    extra_warmup = 0
+    if not sharded:
+        seen = []
+        t_lim = time.perf_counter() + 1.0
+        while extra_warmup < 400 and time.perf_counter() < t_lim:
+            ts = time.perf_counter(); prob.solve(tol=args.tol, **solve_kw); seen.append(time.perf_counter() - ts)
+            extra_warmup += 1
+            if len(seen) >= 8 and max(seen[-4:]) <= 1.05 * min(seen):
+                break
     sync()
     evals = 0
     dev_s = 0.0
@@ -372,7 +385,7 @@ def main():
         out = {
             "metric": METRIC,
             "value": value, "unit": "pool-subproblems/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "warmup": args.warmup, "extra_warmup_steps": extra_warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "pools_per_gpu": prob.m, "pools_total": total_pools, "tokens": net["n_tokens"], "seed": 0,
                        "parallelism": f"pool-sharding x{world}" if world > 1 else "single GPU",

@@ -215,13 +215,26 @@ def shard_network(net, rank, world):
 
 
 # ------------------------------------------------------------------------------- start prices
+def _is_general(util):
+    """does the utility hold entries of the utility table (ULOG / UQUAD)?  Kept with the utility object like the other facts derived
+    from its arrays (Problem.set_utility drops them when the object is re-sent): three array scans less per solve"""
+    g = getattr(util, "_general", None)
+    if g is None:
+        g = bool((util.ctype >= ULOG).any())
+        try:
+            util._general = g
+        except AttributeError:
+            pass
+    return g
+
+
 def start_prices(net, util):
     """Prices for every token: c where the utility names one, otherwise propagated through the
     pools' marginal prices at their current reserves (breadth-first, averaged in log space).
     The propagation depends on the pools and on c alone: its result is kept with the utility object (a re-solve with
     another basket h -- or the same one -- skips the ~2 ms walk over a 1000-token network)."""
     c = util.c
-    if (util.ctype >= ULOG).any():           # the utility table: a token starts at the price at which it would not trade (u'(0))
+    if _is_general(util):           # the utility table: a token starts at the price at which it would not trade (u'(0))
         c = c.copy()
         lg, qd = util.ctype == ULOG, util.ctype == UQUAD
         with np.errstate(divide="ignore"):
@@ -510,7 +523,7 @@ class Problem:
         utilities = list(utilities)
         ctx = self._ensure_ctx()
         can_batch = (hasattr(ctx, "solve_batch") and "sum2" not in self.net and "curve2" not in self.net and "pow2" not in self.net and self._host is None
-                     and not any((x.ctype >= ULOG).any() for x in utilities)
+                     and not any(_is_general(x) for x in utilities)
                      and not self.deterministic and kw.get("method", "auto") in ("auto", "lbfgs"))
         if batch is None:
             batch = ctx.batch_capacity() if can_batch else 0
@@ -614,7 +627,7 @@ class Problem:
     def set_utility(self, utility):
         self.utility = utility       # (a new object, or the same object mutated: call this to re-send it)
         self._dev_utility = None
-        for attr in ("_all_priced", "_plain", "_start_memo"):        # (what was derived from its arrays)
+        for attr in ("_all_priced", "_plain", "_start_memo", "_general"):        # (what was derived from its arrays)
             try:
                 setattr(utility, attr, None)
             except AttributeError:
@@ -691,7 +704,7 @@ class Problem:
         self._tol = tol
         kw = dict(max_evals=max_evals, memory=memory, iters_per_graph=iters_per_graph)
         total = dict(evals=0, iters=0, wall_seconds=0.0, device_seconds=0.0, rounds=0)
-        general = bool((u.ctype >= ULOG).any())      # entries of the utility table: first-order path, no ties
+        general = _is_general(u)      # entries of the utility table: first-order path, no ties
         if general and n_sum:
             raise ValueError("a utility with ULOG / UQUAD entries over a network with constant-sum pools: the kink recovery ties prices, "
                              "the utility table's entries take no ties")
@@ -885,7 +898,7 @@ class Problem:
             psi = psi.copy()
             for rec, th in self._theta.values():
                 psi += th * self._fill_vector(rec)
-        if (u.ctype >= ULOG).any():
+        if _is_general(u):
             # a utility with entries of the table: value, dual value and certificates are the device's (Fenchel-Young gap of
             # the pair (nu, psi): csrc/lbfgs_rules.hpp); recomputed here in NumPy only by the tests
             self.value = float(st["primal_value"]); self.dual_value = float(st["dual_value"])

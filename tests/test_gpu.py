@@ -1015,9 +1015,12 @@ def test_k_asset_tiles_with_and_without_the_log_price_table(oracle_lib):
 
 def test_compact_mirror_of_ids_and_fees_is_bit_identical(oracle_lib):
     """buckets of >= 1e6 two-asset pools are evaluated from a compact mirror of their token ids (one 32-bit word) and fees (a
-    one-byte index into the bucket's distinct fees): kernels.hpp Bucket2::cid.  CFMM_COMPACT=1 forces it on a small network, in a
-    process of its own (the knob is read once): bit-identical psi in the reproducible mode, the oracle's evaluation otherwise, the
-    same certified solve -- and a bucket with more than 256 distinct fees keeps its columns and its answers"""
+    one-byte index into the bucket's distinct fees): kernels.hpp Bucket2::cid; constant-product buckets of >= 8e6 pools in tiles
+    of 256 pools per wave (EvalArgs::wide).  Both live in the large-set instantiations of eval_kernel / iter_kernel only
+    (cfmm_hip.hip: large_set_mode), with cached or with non-temporal loads.  CFMM_COMPACT=1 CFMM_WIDE=1 (and CFMM_NT=1) force them
+    on a small network, in a process of its own (the knobs are read once): the oracle's evaluation, the same certified solve as
+    the plain instantiation -- and a bucket with more than 256 distinct fees keeps its columns and its answers; the reproducible
+    mode always takes the plain instantiation and stays bit for bit what it was"""
     import json
     import subprocess
     import sys
@@ -1040,12 +1043,14 @@ def test_compact_mirror_of_ids_and_fees_is_bit_identical(oracle_lib):
         "    out[tag] = dict(f=f, psi=psi.tolist(), diag=diag.tolist(), v=v, status=p.status, psid=[x.hex() for x in psid.tolist()])\n"
         "print(json.dumps(out))\n")
     res = {}
-    for mode in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CFMM_COMPACT=mode), capture_output=True, text=True, timeout=900)
+    envs = {"1": dict(CFMM_COMPACT="1", CFMM_WIDE="1", CFMM_NT="0"), "nt": dict(CFMM_COMPACT="1", CFMM_WIDE="1", CFMM_NT="1"),
+            "mirror": dict(CFMM_COMPACT="1", CFMM_WIDE="0", CFMM_NT="0"), "0": dict(CFMM_COMPACT="0", CFMM_WIDE="0", CFMM_NT="0")}
+    for mode, env in envs.items():
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
-    for tag in ("tiers", "many"):
-        a, b = res["1"][tag], res["0"][tag]
+    for tag, mode in [(t, m) for t in ("tiers", "many") for m in ("1", "nt", "mirror")]:
+        a, b = res[mode][tag], res["0"][tag]
         assert a["psid"] == b["psid"]                                            # reproducible mode: bit for bit
         assert a["status"] == b["status"] == "optimal" and abs(a["v"] - b["v"]) <= 2e-6 * abs(b["v"])
         net = synthetic.config("C3", scale=0.05)
