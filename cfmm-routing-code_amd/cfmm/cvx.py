@@ -20,6 +20,10 @@ problem's vocabulary and refuses anything else with `NotImplementedError`:
   * rows of  psi + h (>= | ==) 0  with  psi = sum_i A_i (L_i - D_i)  and a linear objective in psi     -> the utility
     (arbitrage.py:57,77; liquidation.py:57,77-80; two-asset.py:66,86)
 
+  * and, beyond the reference's linear objectives (include/cfmm.h: the utility table), separable concave terms on entries of psi:
+    `cp.sum(cp.multiply(a, cp.log(psi + h)))` (or `a @ cp.log(psi + h)`)                              -> CFMM_ULOG entries
+    `c @ psi - cp.sum(cp.multiply(k, cp.square(psi)))` (or `cp.sum_squares`)                          -> CFMM_UQUAD, depth 1 / (2 k)
+
 and hands the result to cfmm.Problem, i.e. to libcfmm_hip.so on the MI355X -- there is no CPU path here either.
 """
 import builtins
@@ -27,7 +31,7 @@ import builtins
 import numpy as np
 
 from .problem import Problem as _RoutingProblem, Utility as _Utility
-from ._lib import GE as _GE, EQ as _EQ, FREE as _FREE
+from ._lib import GE as _GE, EQ as _EQ, FREE as _FREE, ULOG as _ULOG, UQUAD as _UQUAD
 
 # tests only: a callable n_tokens -> device context standing in for cfmm._lib.Context (the product leaves it None)
 CONTEXT_FACTORY = None
@@ -88,9 +92,9 @@ class Expression:
             coefs[v] = coefs[v] + sign * c if v in coefs else sign * c
         return Expression(coefs, a.const + sign * b.const, scalar=a.scalar and b.scalar)
 
-    def __add__(self, other): return NotImplemented if isinstance(other, _ScaledAtom) else self._binary(other, 1.0)
+    def __add__(self, other): return NotImplemented if isinstance(other, (_ScaledAtom, _Concave)) else self._binary(other, 1.0)
     __radd__ = __add__
-    def __sub__(self, other): return NotImplemented if isinstance(other, _ScaledAtom) else self._binary(other, -1.0)
+    def __sub__(self, other): return NotImplemented if isinstance(other, (_ScaledAtom, _Concave)) else self._binary(other, -1.0)
     def __rsub__(self, other): return (-self)._binary(other, 1.0)
     def __neg__(self): return Expression({v: -c for v, c in self.coefs.items()}, -self.const, self.scalar)
 
@@ -105,7 +109,7 @@ class Expression:
         return Expression({v: k[:, None] * c for v, c in self.coefs.items()}, k * self.const)
     __rmul__ = __mul__
 
-    def __truediv__(self, k): return self * (1.0 / float(k))
+    def __truediv__(self, k): return self * (1.0 / np.asarray(k, dtype=np.float64))
 
     def __rmatmul__(self, M):
         M = np.asarray(M, dtype=np.float64)
@@ -265,12 +269,106 @@ def geo_mean(x, p=None):
     return float(np.exp((w / w.sum()) @ np.log(a)))
 
 
+class _Concave:
+    """lin + sum over terms of  sum_j k_j f(x_j),  f = log | square, x an affine vector, lin a scalar affine expression: the
+    objective of a separable concave utility.  A term is elementwise (`vector`) until cp.sum / `a @` closes it."""
+    __array_ufunc__ = None
+    __array_priority__ = 1000
+
+    def __init__(self, terms, lin=None, vector=False):
+        self.terms = terms           # [(kind, Expression x, k array of x.size)]
+        self.lin = lin               # scalar Expression or None
+        self.vector = vector         # one open elementwise term: multiply / sum / @ still apply to it
+
+    def _closed(self, what):
+        if self.vector:
+            raise ValueError(f"cfmm.cvx: {what} of an elementwise log / square term: close it with cp.sum(...) or `a @ ...` first")
+
+    def _scaled(self, k):
+        k = np.asarray(k, dtype=np.float64)
+        if k.ndim > 1 or (k.ndim == 1 and not self.vector) or (k.ndim == 1 and k.shape != self.terms[0][2].shape):
+            raise ValueError("cfmm.cvx: factor of the wrong shape")
+        return _Concave([(kind, x, kk * k) for kind, x, kk in self.terms], None if self.lin is None else self.lin * float(k), self.vector)
+
+    def __mul__(self, k): return self._scaled(k)
+    __rmul__ = __mul__
+    def __neg__(self): return self._scaled(-1.0)
+    def __truediv__(self, k): return self._scaled(1.0 / float(k))
+
+    def __rmatmul__(self, a):          # a @ log(x)
+        return sum(self._scaled(np.asarray(a, dtype=np.float64)))
+
+    def _plus(self, other, sign):
+        self._closed("a sum")
+        if isinstance(other, _Concave):
+            other._closed("a sum")
+            lin = other.lin * sign if other.lin is not None else None
+            if self.lin is not None:
+                lin = self.lin if lin is None else self.lin + lin
+            return _Concave(self.terms + [(kind, x, sign * k) for kind, x, k in other.terms], lin)
+        o = Expression._lift(other, 1)
+        if o.size != 1:
+            raise ValueError("cfmm.cvx: the objective must be a scalar")
+        return _Concave(list(self.terms), o * sign if self.lin is None else self.lin + o * sign)
+
+    def __add__(self, other): return self._plus(other, 1.0)
+    __radd__ = __add__
+    def __sub__(self, other): return self._plus(other, -1.0)
+    def __rsub__(self, other): return (-self)._plus(other, 1.0)
+
+    @property
+    def size(self):
+        return self.terms[0][1].size if self.vector else 1
+
+    @property
+    def value(self):
+        out = 0.0 if self.lin is None else self.lin.value
+        for kind, x, k in self.terms:
+            xv = x.value
+            if xv is None or out is None:
+                return None
+            f = k * (np.log(xv) if kind == "log" else np.square(xv))
+            if self.vector:
+                return f
+            out = out + float(np.sum(f))
+        return out
+
+
+def log(x):
+    """cp.log, elementwise -- as an objective term of entries of psi (the utility table's CFMM_ULOG)"""
+    if not isinstance(x, Expression):
+        return np.log(x)
+    return _Concave([("log", x, np.ones(x.size))], vector=True)
+
+
+def square(x):
+    """cp.square, elementwise -- as a (negatively weighted) objective term of entries of psi (CFMM_UQUAD)"""
+    if not isinstance(x, Expression):
+        return np.square(x)
+    return _Concave([("square", x, np.ones(x.size))], vector=True)
+
+
+def sum_squares(x):
+    return sum(square(x)) if isinstance(x, Expression) else float(np.sum(np.square(x)))
+
+
+def multiply(a, x):
+    """cp.multiply: elementwise product with a constant"""
+    if isinstance(a, (Expression, _Concave)) and not isinstance(x, (Expression, _Concave)):
+        a, x = x, a
+    if isinstance(a, (Expression, _Concave)):
+        raise NotImplementedError("cfmm.cvx: products of expressions")
+    return x * a if isinstance(x, (Expression, _Concave)) else np.multiply(a, x)
+
+
 def sum(x, axis=None):        # noqa: A001 (mirrors cp.sum)
     """cp.sum: a list of expressions adds elementwise (arbitrage.py:54); an expression or array sums its entries"""
     if isinstance(x, (list, tuple)):
         return builtins.sum(x[1:], x[0])
     if isinstance(x, _Power):
         return _FnExpr("powersum", x.expr, 1.0 - x.q)
+    if isinstance(x, _Concave):
+        return _Concave(list(x.terms), x.lin) if x.vector else x
     if isinstance(x, Expression):
         return np.ones(x.size) @ x
     return float(np.sum(x))
@@ -278,24 +376,33 @@ def sum(x, axis=None):        # noqa: A001 (mirrors cp.sum)
 
 class Maximize:
     def __init__(self, expr):
+        self.terms = []
+        self.whole = expr
+        if isinstance(expr, _Concave):
+            expr._closed("an objective")
+            for kind, x, k in expr.terms:
+                if (kind == "log" and np.any(k < 0)) or (kind == "square" and np.any(k > 0)):
+                    raise ValueError("cfmm.cvx: the objective is not concave (log terms take weights >= 0, squares <= 0)")
+            self.terms = [(kind, x, k) for kind, x, k in expr.terms]
+            expr = expr.lin if expr.lin is not None else Expression({}, np.zeros(1), scalar=True)
         if not isinstance(expr, Expression) or expr.size != 1:
-            raise ValueError("cfmm.cvx: the objective must be a scalar affine expression")
-        self.expr = expr
+            raise ValueError("cfmm.cvx: the objective must be a scalar affine expression (plus log / square terms of entries of psi)")
+        self.expr = expr             # the linear part
         self.sign = 1.0
 
     @property
     def value(self):
-        return self.expr.value
+        return self.whole.value
 
 
 class Minimize(Maximize):
     def __init__(self, expr):
-        Maximize.__init__(self, -expr if isinstance(expr, Expression) else expr)
+        Maximize.__init__(self, -expr if isinstance(expr, (Expression, _Concave)) else expr)
         self.sign = -1.0
 
     @property
     def value(self):
-        v = self.expr.value
+        v = self.whole.value
         return None if v is None else -v
 
 
@@ -439,6 +546,32 @@ class Problem:
             if any(np.abs(r - t[0]).max() < 1e-12 for t in tokens):
                 raise NotImplementedError("cfmm.cvx: two constraints on one entry of psi")
             tokens.append((np.round(r), float(h), k))
+        # separable concave terms of the objective (the utility table): every row of a term's argument is ONE entry of psi, plus a
+        # constant for the logarithm (psi_j + h_j) and none for the square; such an entry takes no other constraint -- the
+        # logarithm's domain is its constraint, the square's entry is free
+        table = {}                   # token index -> weight k_j
+        for kind, x, k in self.objective.terms:
+            M = row_matrix(x)
+            for r in range(x.size):
+                if k[r] == 0.0:
+                    continue
+                row, kr = M[r], float(k[r])
+                nz = row[np.abs(row) > 1e-12]
+                if kind == "square" and len(nz) and np.all(np.abs(nz - nz[0]) <= 1e-12 * abs(nz[0])):
+                    row, kr = row / nz[0], kr * nz[0] ** 2       # square(s psi_j) = s^2 psi_j^2
+                if not np.all((np.abs(row) < 1e-12) | (np.abs(row - 1.0) < 1e-12)) or not np.any(row > 0.5):
+                    raise NotImplementedError(f"cfmm.cvx: cp.{kind}(...) must be taken of entries of psi")
+                if any(np.abs(row - t[0]).max() < 1e-12 for t in tokens):
+                    raise NotImplementedError(f"cfmm.cvx: an entry of psi under cp.{kind}(...) takes no other constraint or term")
+                if kind == "log":
+                    if x.const[r] < 0.0:
+                        raise NotImplementedError("cfmm.cvx: log(psi_j + h_j) needs h_j >= 0")
+                    tokens.append((np.round(row), float(x.const[r]), _ULOG))
+                else:
+                    if x.const[r] != 0.0:
+                        raise NotImplementedError("cfmm.cvx: square(...) must be taken of psi_j itself")
+                    tokens.append((np.round(row), 1.0 / (2.0 * -kr), _UQUAD))      # - k psi^2 = - psi^2 / (2 depth)
+                table[len(tokens) - 1] = (kind, kr)
         # the objective: a combination of token rows, plus -- at most -- selector rows of tokens no constraint mentions
         left = objM.copy()
         c = np.zeros(len(tokens))
@@ -462,6 +595,11 @@ class Problem:
             if np.abs(left).max() > 1e-10:
                 raise NotImplementedError("cfmm.cvx: the objective must be linear in psi")
         c = np.asarray(c) * 1.0
+        for j, (kind, k) in table.items():
+            if kind == "log":        # u = k log(psi + h): the entry's c is the weight; a linear term on the same entry is another utility
+                if abs(c[j]) > 1e-12:
+                    raise NotImplementedError("cfmm.cvx: a linear term on an entry of psi that sits under cp.log(...)")
+                c[j] = k
         if np.any(c < -1e-14):
             raise NotImplementedError("cfmm.cvx: negative objective weights on psi")
         # slots no token row covers: a pool asset that appears in neither objective nor constraints is unpriced

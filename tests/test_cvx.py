@@ -150,6 +150,88 @@ def test_stableswap_and_power_sum_constraint_lines_are_recognised(oracle_device,
         cp.Problem(cp.Maximize((l - d)[0]), [cp.sum(R + 0.98 * d - l) - 2.0 * cp.inv_prod(x) >= float(R.sum() - 2.0 / R.prod()), (l - d)[1] + 1 >= 0]).solve()
 
 
+def _concave_model(which):
+    """a routing program with a separable concave objective, written the way cvxpy takes it (DCP-valid), over the 14 geometric-mean
+    pools / 6 tokens of the utility-table tests; returns the cvx problem, psi and the same utility as a cfmm.Utility"""
+    from test_oracle import _small_geomean_instance
+    pi, inst = _small_geomean_instance()
+    n = inst["n_tokens"]
+    A = [np.eye(n)[:, l] for l in inst["local_indices"]]
+    D = [cp.Variable(len(l), nonneg=True) for l in inst["local_indices"]]
+    L = [cp.Variable(len(l), nonneg=True) for l in inst["local_indices"]]
+    psi = cp.sum([Ai @ (l - d) for Ai, d, l in zip(A, D, L)])
+    cons = [cp.geo_mean(R + g * d - l, p=w) >= cp.geo_mean(R, p=w)
+            for R, g, w, d, l in zip(inst["reserves"], inst["fees"], inst["weights"], D, L)]
+    if which == "log":
+        a, h = np.array([1.0, 2.0, 0.5, 1.5, 1.0, 0.7]), np.array([5.0, 2.0, 8.0, 3.0, 4.0, 6.0])
+        obj = cp.Maximize(cp.sum(cp.multiply(a, cp.log(psi + h))))
+        u = cfmm.LogUtility(a, h)
+    elif which == "quadratic":
+        c = pi * np.exp(np.random.default_rng(1).normal(0, 0.05, n))
+        depth = np.array([20.0, 30.0, 15.0, 25.0, 40.0, 35.0])
+        obj = cp.Maximize(c @ psi - cp.sum(cp.multiply(1.0 / (2.0 * depth), cp.square(psi))))
+        u = cfmm.QuadraticUtility(c, depth)
+    else:            # two log tokens, two quadratic ones, two of the reference's linear-arbitrage kind (arbitrage.py:57,77)
+        c = np.array([1.0, 2.0, pi[2] * 1.03, pi[3] * 0.97, pi[4] * 1.02, pi[5]])
+        h = np.array([5.0, 2.0, 30.0, 20.0, 0.0, 0.0])
+        obj = cp.Maximize(c[:2] @ cp.log(psi[:2] + h[:2]) + c[2:] @ psi[2:] - cp.sum_squares(psi[2:4] / np.sqrt(2.0 * h[2:4])))
+        cons = cons + [psi[4:] >= 0]
+        u = cfmm.Utility(c, h, np.array([cfmm.ULOG, cfmm.ULOG, cfmm.UQUAD, cfmm.UQUAD, cfmm.GE, cfmm.GE], dtype=np.int32))
+    return cp.Problem(obj, cons), psi, u, inst
+
+
+@pytest.mark.parametrize("which", ["log", "quadratic", "mixed"])
+def test_separable_concave_objectives_through_the_shim(oracle_device, which):
+    """beyond the reference's linear objectives: `cp.sum(cp.multiply(a, cp.log(psi + h)))`, `c @ psi - cp.sum(cp.multiply(k,
+    cp.square(psi)))`, `cp.sum_squares`, mixed with linear entries -- mapped onto the utility table (include/cfmm.h: CFMM_ULOG /
+    CFMM_UQUAD) and solved; against the primal program with the same utility handed to SLSQP, and `.value` of the objective
+    recomputed from the tenders"""
+    from oracle.primal_scipy import solve_primal
+    prob, psi, u, inst = _concave_model(which)
+    v = prob.solve(tol=1e-9)
+    assert prob.status == cp.OPTIMAL and v == prob.value
+    got = prob.routing.utility
+    r = solve_primal(dict(inst, c=u.c, h=u.h, ctype=u.ctype))
+    assert abs(v - r["value"]) <= 2e-8 * max(1.0, abs(v))
+    assert np.abs(psi.value - r["psi"]).max() <= 2e-3 * max(1.0, np.abs(r["psi"]).max())
+    # the shim's token order is its own: the utility it built is the model's, permuted
+    assert sorted(zip(got.c.round(12), got.h.round(12), got.ctype)) == sorted(zip(u.c.round(12), u.h.round(12), u.ctype))
+
+
+def test_concave_terms_refuse_what_the_table_does_not_hold(oracle_device):
+    prob, psi, u, inst = _concave_model("log")
+    cons = prob.constraints
+    with pytest.raises(ValueError, match="not concave"):
+        cp.Maximize(-cp.sum(cp.log(psi + 1.0)))
+    with pytest.raises(ValueError, match="not concave"):
+        cp.Maximize(cp.sum(cp.square(psi)))
+    with pytest.raises(ValueError, match="close it"):
+        cp.Maximize(cp.log(psi + 1.0))
+    with pytest.raises(NotImplementedError, match="no other constraint"):
+        cp.Problem(cp.Maximize(cp.sum(cp.log(psi + 1.0))), cons + [psi[0] >= 0]).solve()
+    with pytest.raises(NotImplementedError, match="h_j >= 0"):
+        cp.Problem(cp.Maximize(cp.sum(cp.log(psi - 1.0))), cons).solve()
+    with pytest.raises(NotImplementedError, match="linear term"):
+        cp.Problem(cp.Maximize(cp.sum(cp.log(psi + 1.0)) + psi[0]), cons).solve()
+    with pytest.raises(NotImplementedError, match="psi_j itself"):
+        cp.Problem(cp.Maximize(np.ones(6) @ psi - cp.sum_squares(psi + 1.0)), cons).solve()
+    with pytest.raises(NotImplementedError, match="entries of psi"):
+        cp.Problem(cp.Maximize(cp.sum(cp.log(2.0 * psi + 1.0))), cons).solve()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["log", "quadratic", "mixed"])
+def test_separable_concave_objectives_through_the_shim_on_the_gpu(which):
+    from oracle.primal_scipy import solve_primal
+    cp.CONTEXT_FACTORY = None
+    prob, psi, u, inst = _concave_model(which)
+    v = prob.solve(tol=1e-8)
+    r = solve_primal(dict(inst, c=u.c, h=u.h, ctype=u.ctype))
+    assert prob.status == cp.OPTIMAL and abs(v - r["value"]) <= 2e-7 * max(1.0, abs(v))
+    assert np.abs(psi.value - r["psi"]).max() <= 2e-3 * max(1.0, np.abs(r["psi"]).max())
+    prob.routing.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(2))
 def test_stableswap_and_power_sum_constraint_lines_on_the_gpu(seed):
