@@ -417,7 +417,8 @@ struct UploadScan {
 struct Col {
     size_t bytes = 0;
     void **dst = nullptr;                                                  // receives the column's device address
-    std::function<void(char *out, size_t off, size_t len)> fill;          // writes bytes [off, off + len) of the column
+    std::function<void(char *out, size_t off, size_t len)> fill;          // writes bytes [off, off + len) of the column; empty: the column is only
+                                                                           // RESERVED (the caller fills it on the device) -- such columns come last
     const void *direct = nullptr;                                          // the caller's buffer when the column is copied as it is
 };
 // f(begin, end) over [0, m) on the pool
@@ -522,7 +523,11 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const 
 {
     size_t total = 0;
     std::vector<size_t> offs;
-    for (auto &c : cols) { offs.push_back(total); total += (c.bytes + 255) & ~(size_t)255; }
+    size_t staged = 0;                                  // the bytes that travel: everything in front of the first reserved-only column
+    for (auto &c : cols) {
+        offs.push_back(total); total += (c.bytes + 255) & ~(size_t)255;
+        if (c.fill) { if (staged != offs.back()) return fail(ctx, CFMM_E_STATE, "upload: a staged column behind a reserved one"); staged = total; }
+    }
     char *base = nullptr;
     static const bool trace = getenv("CFMM_UPLOAD_TRACE") != nullptr;
     auto now = []() { return std::chrono::steady_clock::now(); };
@@ -539,6 +544,7 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const 
         std::vector<void *> pinned;
         hipError_t e = hipSuccess;
         for (size_t q = 0; q < cols.size() && e == hipSuccess; ++q) {
+            if (!cols[q].fill) { *cols[q].dst = base + offs[q]; continue; }
             std::vector<char> tmp(cols[q].bytes);
             cols[q].fill(tmp.data(), 0, cols[q].bytes);          // (the checks ride on the fill: run it either way)
             if (cols[q].direct && cols[q].bytes >= (1u << 20)) {
@@ -569,13 +575,13 @@ int upload_arena(cfmm_ctx *ctx, std::vector<Col> &cols, void **arena_out, const 
     int slot = g_stage.next;
     bool *used = g_stage.used;
     std::vector<Job> jobs;
-    for (size_t c0 = 0; c0 < total; c0 += STAGE_BYTES) {
-        const size_t clen = std::min(STAGE_BYTES, total - c0);
+    for (size_t c0 = 0; c0 < staged; c0 += STAGE_BYTES) {
+        const size_t clen = std::min(STAGE_BYTES, staged - c0);
         char *st = g_stage.buf + (size_t)slot * STAGE_BYTES;
         jobs.clear();
         for (size_t q = 0; q < cols.size(); ++q) {
             const size_t lo = std::max(offs[q], c0), hi = std::min(offs[q] + cols[q].bytes, c0 + clen);
-            if (lo >= hi) continue;
+            if (lo >= hi || !cols[q].fill) continue;
             const size_t grain = 64u << 10;
             for (size_t b = lo; b < hi; b += grain) jobs.push_back({q, b - offs[q], std::min(grain, hi - b), b - c0});
         }
@@ -2337,18 +2343,9 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
             cols.push_back(c);
         }
         {   // log(R / w) per leg, pool-major like R and w: with the workgroup's table of log-prices the K-asset tiles form
-            // a = log(R p / w) as one add (kernels.hpp: tilen<LNU>)
+            // a = log(R p / w) as one add (kernels.hpp: tilen<LNU>).  Reserved here, filled on the device behind the copies
+            // (lrw_fill_kernel below): as a staged column its std::log per leg cost the C3 upload 0.3 ms of its 1.64
             Col c; c.bytes = (size_t)k * m * sizeof(double); c.dst = (void **)&b.lrw;
-            c.fill = [R, w, k, m](char *out, size_t off, size_t len) {
-                double *o = (double *)out;
-                const size_t e0 = off / sizeof(double), cnt = len / sizeof(double);
-                size_t pool = e0 / (size_t)k; int j = (int)(e0 - pool * (size_t)k);
-                for (size_t i = 0; i < cnt; ++i) {
-                    const size_t src = (size_t)j * (size_t)m + pool;
-                    o[i] = std::log(R[src] / w[src]);
-                    if (++j == k) { j = 0; ++pool; }
-                }
-            };
             cols.push_back(c);
         }
         size_t total = 0;
@@ -2365,6 +2362,12 @@ int cfmm_upload_poolsN(cfmm_ctx *ctx, int k, int64_t m, const int32_t *idx, cons
             return fail(ctx, CFMM_E_ARG, "upload_poolsN: a column failed its checks");
         }
         if (rc) return rc;
+        {
+            const long long legs = (long long)k * m;
+            hipLaunchKernelGGL(lrw_fill_kernel, dim3((unsigned)std::min<long long>((legs + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
+                               (const double *)b.R, (const double *)b.w, const_cast<double *>(b.lrw), legs);
+            HIP_TRY(ctx, hipGetLastError());
+        }
         if (ro) ro_total = total;
     }
     const double mxr = scan.mxr, mnf = scan.mnf;

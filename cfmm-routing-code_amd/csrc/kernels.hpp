@@ -121,6 +121,13 @@ __global__ void __launch_bounds__(256) compact_build_kernel(Bucket2 b, unsigned 
     }
 }
 
+// the derived column of a K-asset bucket: lrw = log(R / w) per leg (BucketN::lrw), filled behind the upload's copies
+__global__ void __launch_bounds__(256) lrw_fill_kernel(const double *__restrict__ R, const double *__restrict__ w, double *__restrict__ lrw, long long legs)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < legs; i += stride) lrw[i] = log(R[i] / w[i]);
+}
+
 struct EvalArgs {
     Bucket2 b2[N_KINDS2];             // indexed by CFMM_POOL_* kind
     BucketN bn[6];                    // bn[k - 3], k = 3..8
