@@ -2086,6 +2086,10 @@ int64_t cfmm_eval_bytes(cfmm_ctx *ctx)
         bytes += ctx->pools->b2[k].m * ((mirror ? 21 : 32) + (par ? 8 : 0));
     }
     for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) bytes += ctx->pools->bn[k].m * (20 + 20 * k);
+    for (auto &row : ctx->pools->bg) {                  // the K-asset table's buckets: ids and reserves per leg, fee (and parameter) per pool
+        int k = 0;
+        for (auto &b : row) { bytes += b.m * (12 * k + 8 + (b.param ? 8 : 0)); ++k; }
+    }
     return bytes;
 }
 
