@@ -79,8 +79,9 @@ def measure(rounds=5, reps=20, only=None):
         out["C5.eval_kernel_us"] = best(lambda: 1e6 * prob.ctx.time_eval_kernel(_lib.TIME_ALL, reps))
         prob.close()
 
+    # (C4: 1e7 constant-product pools -- the large-set instantiations: compact mirror of ids and fees, 256-pool tiles)
     jobs = {"C3": lambda: first_order("C3", batch=True), "C4shard": lambda: first_order("C4shard"), "C2": lambda: first_order("C2"),
-            "C5": second_order}
+            "C4": lambda: first_order("C4"), "C5": second_order}
     for name, job in jobs.items():
         if only is None or name in only:
             job()
