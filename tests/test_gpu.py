@@ -1040,7 +1040,8 @@ def test_compact_mirror_of_ids_and_fees_is_bit_identical(oracle_lib):
         "    v = p.solve(tol=1e-6)\n"
         "    q = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net['c']), deterministic=True)\n"
         "    fd, psid = q.eval_dual(nu)\n"
-        "    out[tag] = dict(f=f, psi=psi.tolist(), diag=diag.tolist(), v=v, status=p.status, psid=[x.hex() for x in psid.tolist()])\n"
+        "    out[tag] = dict(f=f, psi=psi.tolist(), diag=diag.tolist(), v=v, status=p.status, psid=[x.hex() for x in psid.tolist()],\n"
+        "                    stored=p.ctx.eval_bytes(), m={k: len(net[k]['Ra']) for k in ('cp2', 'w2')}, gn={int(k): b['R'].shape[1] for k, b in net['gn'].items()})\n"
         "print(json.dumps(out))\n")
     res = {}
     envs = {"1": dict(CFMM_COMPACT="1", CFMM_WIDE="1", CFMM_NT="0"), "nt": dict(CFMM_COMPACT="1", CFMM_WIDE="1", CFMM_NT="1"),
@@ -1052,6 +1053,11 @@ def test_compact_mirror_of_ids_and_fees_is_bit_identical(oracle_lib):
     for tag, mode in [(t, m) for t in ("tiers", "many") for m in ("1", "nt", "mirror")]:
         a, b = res[mode][tag], res["0"][tag]
         assert a["psid"] == b["psid"]                                            # reproducible mode: bit for bit
+        # cfmm_eval_bytes: the columns as stored -- 21 / 29 B per constant-product / weighted pool under a mirror, 32 / 40 without
+        # (a bucket with more than 256 distinct fees keeps its columns: "many")
+        kb = sum((20 + 20 * int(k)) * v for k, v in b["gn"].items())
+        assert b["stored"] == 32 * b["m"]["cp2"] + 40 * b["m"]["w2"] + kb
+        assert a["stored"] == (32 if tag == "many" else 21) * a["m"]["cp2"] + 29 * a["m"]["w2"] + kb
         assert a["status"] == b["status"] == "optimal" and abs(a["v"] - b["v"]) <= 2e-6 * abs(b["v"])
         net = synthetic.config("C3", scale=0.05)
         if tag == "many":
