@@ -288,6 +288,8 @@ class _Concave:
         k = np.asarray(k, dtype=np.float64)
         if k.ndim > 1 or (k.ndim == 1 and not self.vector) or (k.ndim == 1 and k.shape != self.terms[0][2].shape):
             raise ValueError("cfmm.cvx: factor of the wrong shape")
+        if self.lin is not None and k.ndim != 0:       # (a linear part exists on closed, scalar terms only: it takes scalar factors)
+            raise ValueError("cfmm.cvx: a vector factor on an objective that already holds a linear term")
         return _Concave([(kind, x, kk * k) for kind, x, kk in self.terms], None if self.lin is None else self.lin * float(k), self.vector)
 
     def __mul__(self, k): return self._scaled(k)
@@ -601,7 +603,8 @@ class Problem:
                     raise NotImplementedError("cfmm.cvx: a linear term on an entry of psi that sits under cp.log(...)")
                 c[j] = k
         if np.any(c < -1e-14):
-            raise NotImplementedError("cfmm.cvx: negative objective weights on psi")
+            raise NotImplementedError("cfmm.cvx: negative objective weights on psi (the utility table's entries take a marginal value c >= 0 as "
+                                      "well: CFMM_UQUAD's linear coefficient, CFMM_ULOG's weight)")
         # slots no token row covers: a pool asset that appears in neither objective nor constraints is unpriced
         cover = np.zeros(width)
         for t in tokens:

@@ -29,7 +29,9 @@ PARAM2 = dict(cp2=None, w2="wa", sum2=None, curve2="alpha", pow2="t")
 class Utility:
     """maximise c'psi  s.t.  psi_k + h_k >= 0 (GE) | = 0 (EQ) | unconstrained (FREE) -- the reference's utilities (arbitrage.py:57,77;
     liquidation.py:57,77-80; two-asset.py:66,86).  Beyond them, per token, an entry of the utility table:
-    ctype ULOG: + c_k log(psi_k + h_k);  UQUAD: + c_k psi_k - psi_k^2 / (2 h_k)   (include/cfmm.h; first-order path)."""
+    ctype ULOG: + c_k log(psi_k + h_k);  UQUAD: + c_k psi_k - psi_k^2 / (2 h_k)   (include/cfmm.h; both outer iterations take them: the
+    generic two-launch first-order iteration, and the second-order path -- which `method="auto"` falls back to when the first-order
+    run ends without its certificates)."""
 
     def __init__(self, c, h=None, ctype=None):
         self.c = np.asarray(c, dtype=np.float64)
@@ -64,8 +66,11 @@ def LogUtility(weights, holdings):
 
 def QuadraticUtility(marginal_value, depth):
     """max sum_k marginal_value[k] psi_k - psi_k^2 / (2 depth[k]): a linear value with quadratic impact (an external order book of
-    finite depth behind every token).  depth[k] = inf is the linear-arbitrage token (psi_k >= 0 at value c_k)."""
+    finite depth behind every token).  depth[k] = inf is the linear-arbitrage token (psi_k >= 0 at value c_k).
+    marginal_value >= 0 (what cfmm_set_utility accepts for every entry kind: include/cfmm.h)."""
     c = np.asarray(marginal_value, dtype=np.float64)
+    if np.any(c < 0):
+        raise ValueError("QuadraticUtility: marginal_value must be >= 0")
     d = np.asarray(depth, dtype=np.float64)
     fin = np.isfinite(d)
     return Utility(c, np.where(fin, d, 0.0), np.where(fin, UQUAD, GE).astype(np.int32))
@@ -274,7 +279,8 @@ def _price_relations(net):
     # a rough guess is all this has to be (the solvers start by repairing it): on large networks every bucket is
     # thinned to an evenly strided sample, ~64 price relations per token in all
     total = sum(len(net[k]["Ra"]) for k in KIND2 if k in net) + \
-        sum((kk - 1) * b["R"].shape[1] for kk, b in net.get("gn", {}).items())
+        sum((kk - 1) * b["R"].shape[1] for kk, b in net.get("gn", {}).items()) + \
+        sum((key[1] - 1) * b["R"].shape[1] for key, b in net.get("gk", {}).items())
     stride = max(1, total // (64 * n))
     for key in KIND2:
         if key not in net:
@@ -300,6 +306,19 @@ def _price_relations(net):
         for j in range(1, k):
             eu.append(b["idx"][j][sl]); ev.append(b["idx"][0][sl])
             elr.append(np.log(b["w"][j][sl] * b["R"][0][sl] / (b["w"][0][sl] * b["R"][j][sl])))
+    # the K-asset table's pools (csrc/phik.hpp): a token the utility leaves unpriced and that hangs on the rest through such pools
+    # alone would otherwise be a component of its own and start at price 1.  Stableswap: the marginal ratio
+    # (1 + s / R_j) / (1 + s / R_0), s = alpha / prod R; constant sum: equal prices
+    for (kind, k), b in net.get("gk", {}).items():
+        sl = slice(0, None, stride)
+        R = b["R"][:, sl]
+        if kind == "stable":
+            sR = b["param"][sl] / np.prod(R, axis=0)
+            lm = np.log1p(sR[None, :] / R)
+        else:
+            lm = np.zeros_like(R)
+        for j in range(1, k):
+            eu.append(b["idx"][j][sl]); ev.append(b["idx"][0][sl]); elr.append(lm[j] - lm[0])
     if eu:
         rel = (np.concatenate(eu).astype(np.int64), np.concatenate(ev).astype(np.int64), np.concatenate(elr))
     else:
@@ -704,7 +723,7 @@ class Problem:
         self._tol = tol
         kw = dict(max_evals=max_evals, memory=memory, iters_per_graph=iters_per_graph)
         total = dict(evals=0, iters=0, wall_seconds=0.0, device_seconds=0.0, rounds=0)
-        general = _is_general(u)      # entries of the utility table: first-order path, no ties
+        general = _is_general(u)      # entries of the utility table: generic first-order iteration or the second-order path; no ties
         if general and n_sum:
             raise ValueError("a utility with ULOG / UQUAD entries over a network with constant-sum pools: the kink recovery ties prices, "
                              "the utility table's entries take no ties")

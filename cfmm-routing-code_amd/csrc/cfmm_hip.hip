@@ -198,7 +198,7 @@ struct cfmm_ctx {
     // RCCL
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
-    int64_t g_total = 0, g_stable = 0;     // pool counts over ALL ranks (refresh_global_counts)
+    int64_t g_total = 0, g_stable = 0, g_table = 0;     // pool counts over ALL ranks (refresh_global_counts): all, stableswap, K-asset table
     bool g_counts_valid = false;
 
     // one-shot xGMI all-reduce (oneshot.hpp): this rank's mailbox and the peers' (IPC-mapped, or same-process pointers in tests)
@@ -1261,7 +1261,8 @@ int launch_cholesky(cfmm_ctx *ctx, int n, double *x, bool info_zeroed = false)
 bool newton_supported(cfmm_ctx *ctx, const char **why)
 {
     if (ctx->ng != ctx->n) { *why = "price ties are set"; return false; }
-    if (table_pools(ctx) > 0) { *why = "the network holds K-asset table pools (phik.hpp): first-order path only"; return false; }
+    // (pool-sharded: the GLOBAL count, refresh_global_counts -- every rank must take the same branch)
+    if (table_pools(ctx) > 0 || (sharded(ctx) && ctx->g_counts_valid && ctx->g_table > 0)) { *why = "the network holds K-asset table pools (phik.hpp): first-order path only"; return false; }
     // (the Hessian instantiation of smooth_kernel carries the diagonal / pair cache on top of the psi tile: 24 n + 24832 bytes,
     //  i.e. 5792 tokens -- not the (2 n + 32) doubles of the round-2 kernel, which let 5.8k .. 10.2k tokens through to a launch
     //  failure)
@@ -1284,6 +1285,7 @@ int refresh_global_counts(cfmm_ctx *ctx)
     if (sharded(ctx) && ctx->g_counts_valid) return CFMM_OK;
     ctx->g_total = cfmm_pool_count(ctx);
     ctx->g_stable = ctx->pools->b2[CFMM_POOL_CURVE2].m;
+    ctx->g_table = table_pools(ctx);
     local_extrema(ctx);
     if (!sharded(ctx)) return CFMM_OK;
     if (ctx->det) {                                  // the fixed-point exponent must be the same on every rank: global maxima
@@ -1295,13 +1297,15 @@ int refresh_global_counts(cfmm_ctx *ctx)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->g_max_reserve = mx[0]; ctx->min_fee = 1.0 / mx[1];
     }
-    double cnt[2] = {(double)ctx->g_total, (double)ctx->g_stable};
+    // (the table-pool count too: a small bucket can leave one rank's shard empty, and a rank that judged the second-order path
+    //  by its own shard would enter it -- and its collectives -- alone)
+    double cnt[3] = {(double)ctx->g_total, (double)ctx->g_stable, (double)ctx->g_table};
     double *dv = ctx->psi_t;                         // scratch (overwritten by the first update of every solve)
     HIP_TRY(ctx, hipMemcpyAsync(dv, cnt, sizeof cnt, hipMemcpyHostToDevice, ctx->stream));
-    { int rc = all_reduce(ctx, dv, 2, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc; }
+    { int rc = all_reduce(ctx, dv, 3, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc; }
     HIP_TRY(ctx, hipMemcpyAsync(cnt, dv, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->g_total = (int64_t)cnt[0]; ctx->g_stable = (int64_t)cnt[1];
+    ctx->g_total = (int64_t)cnt[0]; ctx->g_stable = (int64_t)cnt[1]; ctx->g_table = (int64_t)cnt[2];
     ctx->g_counts_valid = true;
     return CFMM_OK;
 }
@@ -2394,6 +2398,8 @@ int cfmm_upload_poolsG(cfmm_ctx *ctx, int kind, int k, int64_t m, const int32_t 
     if (m > (1ll << 26)) return fail(ctx, CFMM_E_LIMIT, "upload_poolsG: a bucket holds < 2^26 pools");
     if (ctx->det) return fail(ctx, CFMM_E_UNSUPPORTED, "upload_poolsG: K-asset table pools are not available in the reproducible mode");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // (as the two sibling uploaders: a clone may be reading the arena on another stream, or hold captured launches that point into it)
+    if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_poolsG: the pools are shared with a clone (cfmm_clone); destroy the clones first");
     if (ctx->pools->bgmem[kind][k]) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     BucketG b = {};
     b.m = m;

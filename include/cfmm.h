@@ -89,7 +89,7 @@ enum { CFMM_GE = 0, CFMM_EQ = 1, CFMM_FREE = 2,
         * the entry's two parameters; its price has no bound.  Both outer iterations take them (the first-order one in its generic
         * two-launch form); no price ties, no batching.
         *   CFMM_ULOG   u(Psi) = c log(Psi + h),        c > 0, h >= 0
-        *   CFMM_UQUAD  u(Psi) = c Psi - Psi^2 / (2 h),  h > 0 */
+        *   CFMM_UQUAD  u(Psi) = c Psi - Psi^2 / (2 h),  c >= 0, h > 0   (cfmm_set_utility requires c >= 0 of every entry kind) */
        CFMM_ULOG = 3, CFMM_UQUAD = 4 };
 
 typedef struct {
