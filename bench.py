@@ -444,15 +444,26 @@ def main():
                 # n^3 / 3 for the factorisation + 2 n^3 / 3 for the inverse factor that rides its launches (chol.hpp, round 4: two
                 # 32^3 products per tile, ~n^3 / (6 x 32^3) tiles) -- the price of a back substitution that is one matrix-vector product
                 inverse_factor = os.environ.get("CFMM_BACKSUB", "") != "classic"
-                flops = nr ** 3 / 3.0 * (3.0 if inverse_factor else 1.0)
+                useful_flops = nr ** 3 / 3.0                       # the factorisation proper: what a Newton step NEEDS
+                flops = useful_flops * (3.0 if inverse_factor else 1.0)
+                # which kernel, how many launches: as cfmm_hip.hip: launch_factor chooses them (chol2.hpp takes the block columns in
+                # pairs -- CH_NB = 32, rows rounded up to a pair of blocks -- plus one launch that only finishes the inverse factor)
+                pairs = os.environ.get("CFMM_CHOL", "") != "single"
+                nr2 = (net["n_tokens"] + 63) // 64 * 64
+                nlaunch = (nr2 // 64 + (1 if inverse_factor and nr2 // 32 >= 2 else 0)) if pairs else nr2 // 32
+                kname = ("chol_step2_kernel (csrc/chol2.hpp: two block columns per launch, fp64 MFMA side products" if pairs else
+                         "chol_step_kernel (csrc/chol.hpp: one block column per launch")
                 sm_bytes = dom["bytes"] + 16 * sum(len(prob.net[k]["Ra"]) for k in ("cp2", "w2", "curve2") if k in prob.net)     # + the warm starts: 8 B per direction
                 tf = flops / nk["factor"] / 1e12
                 out["roofline"].update({
-                    "bound": "valu", "kernel": "chol_step_kernel (the dense Cholesky of one Newton step with its inverse factor: one launch per block column, all 32 of them)",
+                    "bound": "valu", "kernel": kname + f"; the dense Cholesky of one Newton step with its inverse factor: {nlaunch} dependent launches)",
+                    "launches_per_factorisation": nlaunch,
                     "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
-                    "flop_frac": tf / FP64_VECTOR_PEAK_TFLOPS, "valu_frac": None, "hbm_frac": None, "traffic": None, "traffic_source": None,
-                    "flop_frac_note": f"n^3/3 flops of the {nr} x {nr} factorisation (+ 2n^3/3 of the inverse factor riding along) / its measured time, against the fp64 vector peak "
-                                      "(a flop rate, not the PMC issue fraction the other configs report as valu_frac)",
+                    "flop_frac": tf / FP64_VECTOR_PEAK_TFLOPS, "useful_flop_frac": useful_flops / nk["factor"] / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                    "valu_frac": None, "hbm_frac": None, "traffic": None, "traffic_source": None,
+                    "flop_frac_note": f"flop_frac (= frac): the flops the launches EXECUTE -- n^3/3 of the {nr} x {nr} factorisation + 2n^3/3 of the inverse factor riding along "
+                                      "(work added to turn the back substitution into one matrix-vector product) -- / their measured time, against the fp64 vector peak; "
+                                      "useful_flop_frac: the n^3/3 a Newton step needs alone / the same time (a flop rate, not the PMC issue fraction the other configs report as valu_frac)",
                     "valu_frac_note": None,
                     "avg_launch_us": nk["factor"] * 1e6, "algorithmic_bytes_per_launch": None,
                     "newton_step_us": {"smoothed_evaluation_with_hessian": nk["smooth_hess"] * 1e6, "smoothed_evaluation": nk["smooth"] * 1e6,

@@ -2089,7 +2089,11 @@ int64_t cfmm_eval_bytes(cfmm_ctx *ctx)
         const bool mirror = ctx->pools->c2mem[k] != nullptr && !ctx->det && !heavy_kind(k);
         bytes += ctx->pools->b2[k].m * ((mirror ? 21 : 32) + (par ? 8 : 0));
     }
-    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) bytes += ctx->pools->bn[k].m * (20 + 20 * k);
+    // K-asset geo-mean buckets: ids, reserves, weights per leg, fee and log fee per pool -- and, in every evaluation of a solve but
+    // its first (outside the reproducible mode and the staged-walk variant), the derived column log(R / w) per leg that the tiles
+    // read INSTEAD of recomputing it (kernels.hpp: tilen<LNU>): 8 more bytes per leg that do move
+    const bool lrw = !ctx->det && !CFMM_STAGED_WALK;
+    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) bytes += ctx->pools->bn[k].m * (20 + (lrw ? 28 : 20) * k);
     for (auto &row : ctx->pools->bg) {                  // the K-asset table's buckets: ids and reserves per leg, fee (and parameter) per pool
         int k = 0;
         for (auto &b : row) { bytes += b.m * (12 * k + 8 + (b.param ? 8 : 0)); ++k; }

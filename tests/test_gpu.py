@@ -1055,7 +1055,8 @@ def test_compact_mirror_of_ids_and_fees_is_bit_identical(oracle_lib):
         assert a["psid"] == b["psid"]                                            # reproducible mode: bit for bit
         # cfmm_eval_bytes: the columns as stored -- 21 / 29 B per constant-product / weighted pool under a mirror, 32 / 40 without
         # (a bucket with more than 256 distinct fees keeps its columns: "many")
-        kb = sum((20 + 20 * int(k)) * v for k, v in b["gn"].items())
+        # K-asset buckets: 20 + 20 k as uploaded + the derived log(R / w) column the iteration's tiles read (8 B per leg)
+        kb = sum((20 + 28 * int(k)) * v for k, v in b["gn"].items())
         assert b["stored"] == 32 * b["m"]["cp2"] + 40 * b["m"]["w2"] + kb
         assert a["stored"] == (32 if tag == "many" else 21) * a["m"]["cp2"] + 29 * a["m"]["w2"] + kb
         assert a["status"] == b["status"] == "optimal" and abs(a["v"] - b["v"]) <= 2e-6 * abs(b["v"])

@@ -1,0 +1,68 @@
+#!/bin/bash
+# First contact with a multi-GPU node: nothing in this repository has ever met a second GPU -- ncclAllReduce
+# with more than one rank, hipIpcOpenMemHandle across devices and the start-up check of allreduce="auto" have only run with the
+# ranks sharing ONE device.  This script runs, in order and each under its own timeout,
+#   1. the real-peer one-shot test (tests/test_gpu.py::test_one_shot_all_reduce_against_rccl_on_real_peers: RCCL against the hipIpc
+#      mailboxes, fp64 and reproducible mode, every rank the same bits);
+#   2. bench.py --gpus {1,2,4,8} for C3 (weak scaling: 1e6 pools per GPU) and C4 (strong: 1e7 pools split N ways), once with
+#      --allreduce rccl and once with auto (the one-shot exchange if the start-up check passes on these peers);
+# and prints, per run, the measured per-iteration device time next to what DESIGN.md (e) predicts from one-GPU measurements
+# (one-shot 31-32 us per iteration at any N >= 2, RCCL 55-70; C4 strong scaling ~30 us per iteration at N = 8).
+#
+#   tools/first_8gpu.sh               on a node with >= 2 GPUs
+#   tools/first_8gpu.sh --share-gpu   on a one-GPU box: N = 1, 2 only, the ranks as processes on device 0 (functional run of the
+#                                     same commands; RCCL refuses two ranks on one device, so both legs use the one-shot exchange)
+# Output: gpurun_out/first8/*.json (one bench line per run), a table on stdout.
+cd "$(dirname "$0")/.."
+R=$PWD; O=$R/gpurun_out/first8; mkdir -p $O
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+SHARE=""; [ "$1" = "--share-gpu" ] && SHARE="--share-gpu"
+NGPU=$(python -c 'import torch; print(torch.cuda.device_count())' 2>/dev/null || echo 0)
+echo "first_8gpu: $NGPU GPU(s) visible${SHARE:+, --share-gpu}"
+if [ -z "$SHARE" ]; then
+  if [ "$NGPU" -ge 2 ]; then
+    timeout 1200 python -m pytest tests/test_gpu.py -q -x -m gpu -k test_one_shot_all_reduce_against_rccl_on_real_peers > $O/peers_test.log 2>&1
+    echo "1. real-peer one-shot test: rc=$? ($(tail -1 $O/peers_test.log))"
+  else
+    echo "1. real-peer one-shot test: skipped ($NGPU GPU visible)"
+  fi
+  NS="1 2 4 8"; LEGS="rccl auto"
+else
+  NS="1 2"; LEGS="auto"
+fi
+for cfg in C3 C4; do
+  for ar in $LEGS; do
+    for n in $NS; do
+      [ -z "$SHARE" ] && [ "$n" -gt "$NGPU" ] && continue
+      f=$O/bench_${cfg}_${ar}_n$n.json
+      extra="--no-cpu --no-batch --steps 10 --warmup 3"
+      [ "$n" -gt 1 ] && extra="$extra --allreduce $ar $SHARE"
+      [ -n "$SHARE" ] && [ "$cfg" = C4 ] && extra="$extra --scale 0.25"       # (two ranks time-share one device: a quarter of the pools)
+      timeout 1500 python bench.py --gpus $n --config $cfg $extra > $f 2> ${f%.json}.err
+      echo "bench $cfg --gpus $n --allreduce $ar: rc=$?"
+    done
+  done
+done
+python - "$O" <<'EOF'
+import glob, json, os, sys
+rows = []
+for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception:
+        continue
+    cfg, ar, n = os.path.basename(f)[6:-5].split("_")
+    pi = d.get("per_iteration_us", {})
+    rows.append((cfg, ar, int(n[1:]), d["value"], d["ms_per_step"], d.get("evals_per_solve"), pi.get("total_device"), pi.get("evaluation"),
+                 pi.get("fold", 0) + pi.get("allreduce", 0), d["config"].get("allreduce"), d["config"].get("allreduce_note")))
+base = {(c, a): v for c, a, n, v, *_ in rows if n == 1}
+# what one-GPU measurements predict per sharded iteration (us)
+pred = {("C3", "oneshot"): "31-32", ("C3", "rccl"): "55-70", ("C4", "oneshot"): "~30 at N = 8", ("C4", "rccl"): "~50-60 at N = 8"}
+print(f"{'config':6} {'leg':5} {'N':>2} {'value /s':>11} {'ms/solve':>9} {'evals':>6} {'us/iter':>8} {'eval':>6} {'coll':>6} {'speed-up':>8}  transport (predicted us/iter)")
+for c, a, n, v, ms, ev, tot, e, coll, how, note in rows:
+    b = base.get((c, a)) or base.get((c, "auto")) or base.get((c, "rccl"))
+    su = f"{v / b:8.2f}" if b else "       -"
+    print(f"{c:6} {a:5} {n:2d} {v:11.3e} {ms:9.3f} {ev or 0:6.1f} {tot or 0:8.2f} {e or 0:6.2f} {coll or 0:6.2f} {su}  {how or 'single GPU'} ({pred.get((c, how), '-') if n > 1 else '-'}) {note or ''}")
+print("weak scaling (C3): efficiency = speed-up / N; DESIGN (e) predicts 0.68-0.70 with the one-shot exchange, 0.3-0.4 through RCCL.")
+print("strong scaling (C4): DESIGN (e) predicts a speed-up of ~2.0 at N = 8 (the per-rank launch is latency-bound long before it is bandwidth-bound).")
+EOF
