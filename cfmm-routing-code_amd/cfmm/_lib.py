@@ -64,7 +64,7 @@ _lib = None
 
 SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm_backend", "cfmm_default_opts",
            "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_upload_poolsG", "cfmm_set_pool_flags", "cfmm_set_utility",
-           "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_debug_cholesky_apply", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
+           "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_debug_cholesky_apply", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_solve_sweep", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_get_tradesG", "cfmm_comm_unique_id", "cfmm_comm_init",
            "cfmm_oneshot_export", "cfmm_oneshot_import", "cfmm_oneshot_attach", "cfmm_oneshot_mailbox", "cfmm_oneshot_enable",
            "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_time_newton_kernels", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_eval_bytes", "cfmm_stream"]
@@ -101,6 +101,8 @@ def lib():
     L.cfmm_solve.argtypes = [vp, dp, C.POINTER(Opts), C.POINTER(Stats)]
     L.cfmm_solve_batch.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(dp), C.POINTER(Opts), C.POINTER(Stats)]
     L.cfmm_batch_capacity.argtypes = [C.c_int]
+    L.cfmm_solve_sweep.argtypes = [vp, C.c_int, dp, dp, ip, dp, C.c_int64, ip, ip, dp, dp, dp, C.POINTER(Opts), C.c_double, C.c_int,
+                                   dp, dp, dp, ip, dp, C.POINTER(Stats), ip]
     L.cfmm_get_nu.argtypes = [vp, dp]; L.cfmm_set_nu.argtypes = [vp, dp]; L.cfmm_get_psi.argtypes = [vp, dp]
     L.cfmm_get_solution.argtypes = [vp, dp, dp]
     L.cfmm_get_trades2.argtypes = [vp, C.c_int, dp, dp]
@@ -307,6 +309,31 @@ class Context:
         st = (Stats * nb)()
         self._chk(self.L.cfmm_solve_batch(hs, nb, ptrs, C.byref(o), st))
         return [st[b].asdict() for b in range(nb)]
+
+    def solve_sweep(self, c, h, ctype, nu0, sum2=None, trades_per_point=0, kink_tol=1e-3, max_rounds=6, **kw):
+        """B utilities over this context's (tiny) network in lock-step, the constant-sum kink loop included (cfmm_solve_sweep:
+        two-asset.py:34-100 as one call).  c, h, ctype, nu0: [B][n]; sum2: the constant-sum bucket's columns (dict ia, ib, fee, Ra, Rb) or
+        None; trades_per_point: doubles of tenders per point (0: none).  Returns nu, psi [B][n], theta [B][m_sum], tsgn, trades
+        [B][T] or None, a list of stats dicts, rounds [B]."""
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        B, n = c.shape
+        h = None if h is None else np.ascontiguousarray(h, dtype=np.float64)
+        ctype = None if ctype is None else np.ascontiguousarray(ctype, dtype=np.int32)
+        nu0 = np.ascontiguousarray(nu0, dtype=np.float64)
+        o = self._opts(kw)
+        m = 0 if sum2 is None else len(sum2["Ra"])
+        cols = [None] * 5
+        if m:
+            cols = [i32(sum2["ia"]), i32(sum2["ib"]), f64(sum2["fee"]), f64(sum2["Ra"]), f64(sum2["Rb"])]
+        nu = np.empty((B, n)); psi = np.empty((B, n))
+        theta = np.empty((B, m)); tsgn = np.zeros((B, m), dtype=np.int32)
+        trades = np.empty((B, trades_per_point)) if trades_per_point else None
+        st = (Stats * B)()
+        rounds = np.zeros(B, dtype=np.int32)
+        self._chk(self.L.cfmm_solve_sweep(self.h, B, _d(c), _d(h), _i(ctype), _d(nu0), m, _i(cols[0]), _i(cols[1]), _d(cols[2]), _d(cols[3]), _d(cols[4]),
+                                          C.byref(o), float(kink_tol), int(max_rounds), _d(nu), _d(psi), _d(theta) if m else None, _i(tsgn) if m else None,
+                                          _d(trades) if trades is not None else None, st, _i(rounds)))
+        return nu, psi, theta, tsgn, trades, [st[b].asdict() for b in range(B)], rounds
 
     def solve(self, nu0=None, **kw):
         o = self._opts(kw)

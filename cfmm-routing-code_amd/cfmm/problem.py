@@ -541,6 +541,8 @@ class Problem:
         from as many host threads."""
         utilities = list(utilities)
         ctx = self._ensure_ctx()
+        if batch is None and nu0s is None and self._sweep_applies(ctx, utilities, kw):
+            return self._solve_sweep(utilities, **kw)
         can_batch = (hasattr(ctx, "solve_batch") and "sum2" not in self.net and "curve2" not in self.net and "pow2" not in self.net and self._host is None
                      and not any(_is_general(x) for x in utilities)
                      and not self.deterministic and kw.get("method", "auto") in ("auto", "lbfgs"))
@@ -583,6 +585,107 @@ class Problem:
         if errors:
             raise errors[0]
         return results
+
+    # -- the reference's own sweep (two-asset.py:34-100): tiny networks, constant-sum pools included, one library call --------
+    _WT = dict(cp2=128, sum2=128, w2=64)               # pools per wave-tile (csrc/kernels.hpp: wave_tile_pools)
+
+    def _sweep_applies(self, ctx, utilities, kw):
+        """cfmm_solve_sweep serves what ONE workgroup evaluates: <= 64 tokens, <= 64 wave-tiles, linear-box utilities, first-order
+        method, one GPU (csrc/tiny.hpp)"""
+        if not hasattr(ctx, "solve_sweep") or self._host is not None or self.deterministic or self.n > 64 or not utilities:
+            return False
+        if kw.get("method", "auto") not in ("auto", "lbfgs") or any(k in self.net for k in ("curve2", "pow2", "gk")):
+            return False
+        if set(kw) - {"tol", "max_evals", "memory", "method", "kink_tol", "max_rounds"}:
+            return False
+        tiles = sum(-(-len(self.net[k]["Ra"]) // wt) for k, wt in self._WT.items() if k in self.net)
+        tiles += sum(-(-b["R"].shape[1] // (64 // k)) for k, b in self.net.get("gn", {}).items())
+        return 1 <= tiles <= 64 and not any(_is_general(u) for u in utilities)
+
+    def _trade_layout(self):
+        """(key, legs, pools, offset) of every non-empty bucket in cfmm_solve_sweep's tender layout, and the doubles per point"""
+        lay, off = [], 0
+        for key in KIND2:                                # (dict order = kind order 0..4)
+            if key in self.net and len(self.net[key]["Ra"]):
+                m = len(self.net[key]["Ra"]); lay.append((key, 2, m, off)); off += 4 * m
+        for k in sorted(self.net.get("gn", {})):
+            m = self.net["gn"][k]["R"].shape[1]
+            if m:
+                lay.append((k, k, m, off)); off += 2 * k * m
+        return lay, off
+
+    def _solve_sweep(self, utilities, tol=1e-6, max_evals=2000, memory=0, method="auto", kink_tol=1e-3, max_rounds=6):
+        ctx = self._ensure_ctx()
+        n, B = self.n, len(utilities)
+        C_ = np.stack([u.c for u in utilities]); H = np.stack([u.h for u in utilities]); CT = np.stack([u.ctype for u in utilities]).astype(np.int32)
+        # start prices: a function of the pools and of c alone (problem.py: start_prices) -- the points of a sweep mostly share c
+        memo, NU0 = {}, np.empty((B, n))
+        for b, u in enumerate(utilities):
+            key = u.c.tobytes()
+            if key not in memo:
+                memo[key] = start_prices(self.net, u)
+            NU0[b] = memo[key]
+        lay, T = self._trade_layout()
+        s2 = self.net.get("sum2")
+        nu, psi, theta, tsgn, trades, sts, rounds = ctx.solve_sweep(C_, H, CT, NU0, s2, T, kink_tol, max_rounds, tol=tol, max_evals=max_evals,
+                                                                    memory=memory, method=_lib.METHODS["lbfgs"])
+        # fills of the pools that ended tied on their kink: psi_total = psi + sum theta d, their tenders = theta x the full fill
+        tied = np.isfinite(theta) if s2 is not None else None
+        if s2 is not None and tied.any():
+            m2 = len(s2["Ra"])
+            ya = np.where(tsgn > 0, -s2["Rb"] / s2["fee"], s2["Ra"]) * np.where(tied, theta, 0.0)      # [B][m2]: the pool's first token
+            yb = np.where(tsgn > 0, s2["Rb"], -s2["Ra"] / s2["fee"]) * np.where(tied, theta, 0.0)      #          its second
+            psi = psi.copy()
+            np.add.at(psi, (np.arange(B)[:, None], s2["ia"][None, :]), ya)
+            np.add.at(psi, (np.arange(B)[:, None], s2["ib"][None, :]), yb)
+        # certificates, as Problem._finish computes them, for all points at once
+        r = psi + H
+        value = (C_ * psi).sum(axis=1)
+        cs = ((nu - C_) * r).sum(axis=1)
+        dual = ((nu - C_) * H).sum(axis=1) + (nu * psi).sum(axis=1)
+        gap = np.abs(cs) / np.maximum(1.0, np.abs(dual))
+        viol = np.where(CT == GE, np.maximum(-r, 0.0), np.where(CT == EQ, np.abs(r), 0.0)).max(axis=1)
+        scale = np.maximum(np.maximum(np.abs(psi).max(axis=1), np.abs(H).max(axis=1)), 1e-300)
+        infeas = viol / scale
+        tolx = max(tol, 1e-12) * (1 + 1e-6) + 1e-15
+        good = (gap <= tolx) & (infeas <= tolx)
+        collapsed = ((H > 0) & (nu < 1e-12 * nu.max(axis=1, keepdims=True))).any(axis=1)
+        results = []
+        for b in range(B):
+            st = sts[b]
+            status = "optimal" if good[b] else ("infeasible" if collapsed[b] else
+                                                 ("inaccurate" if st["status"] == 1 else _lib.STATUS.get(st["status"], f"error {st['status']}")))
+            st.update(rounds=int(rounds[b]), batch=B, pool_subproblems=st["evals"] * self.m)
+            res = dict(value=float(value[b]), status=status, psi=psi[b], nu=nu[b], gap=float(gap[b]), infeas=float(infeas[b]),
+                       dual_value=float(dual[b]), stats=st)
+            if trades is not None:
+                tr = {}
+                for key, k, m, off in lay:
+                    blk = trades[b, off:off + 2 * k * m].reshape(2, k, m)
+                    tr[key] = (blk[0], blk[1])
+                if s2 is not None and tied[b].any():
+                    d, l = tr["sum2"]
+                    for i in np.flatnonzero(tied[b]):
+                        y = np.array([ya[b, i], yb[b, i]])
+                        d[:, i] = np.maximum(-y, 0.0); l[:, i] = np.maximum(y, 0.0)
+                res["trades"] = tr
+            results.append(res)
+        # a point the sweep did not bring to its certificates takes the one-at-a-time path, second-order fall-back included
+        if method == "auto":
+            for b in np.flatnonzero(~good):
+                self.set_utility(utilities[b])
+                self.solve(tol=tol, max_evals=max_evals, memory=memory, kink_tol=kink_tol, max_rounds=max_rounds)
+                res = self._result()
+                res["trades"] = {k: v for k, v in self._trades().items()}
+                results[int(b)] = res
+        return results
+
+    def tenders_of(self, result):
+        """(deltas, lambdas) per pool, in the order of the pool list, of one result of a swept solve_many (two-asset.py:94,98)"""
+        if self.where is None:
+            raise CfmmError("per-pool lists need a Problem built from pool lists")
+        tr = result["trades"]
+        return ([tr[key][0][:, pos].copy() for key, pos in self.where], [tr[key][1][:, pos].copy() for key, pos in self.where])
 
     def _result(self):
         return dict(value=self.value, status=self.status, psi=self.psi, nu=self.nu, gap=self.gap, infeas=self.infeas,

@@ -17,7 +17,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <set>
 #include <mutex>
 #include <functional>
 #include <limits>
@@ -917,7 +919,8 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, update_gram_kernel<512, 2, true>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, start_kernel<true>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, eval_batch_kernel, batch_lds_bytes(ctx->n, batch_capacity(ctx->n))))) return rc;
-    if (ctx->n <= TINY_N && (rc = set_lds_attr(ctx, solve_tiny_kernel, (size_t)tiny_lds_doubles(ctx->n) * sizeof(double)))) return rc;
+    if (ctx->n <= TINY_N && (rc = set_lds_attr(ctx, solve_tiny_kernel<false>, (size_t)tiny_lds_doubles(ctx->n) * sizeof(double)))) return rc;
+    if (ctx->n <= TINY_N && (rc = set_lds_attr(ctx, solve_tiny_kernel<true>, (size_t)tiny_lds_doubles(ctx->n) * sizeof(double)))) return rc;
     const size_t il = iter_lds_bytes(ctx->n);
     if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, false>, il))) return rc;
     if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, false, true>, il))) return rc;
@@ -961,7 +964,7 @@ UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
     a.st = ctx->st;
     a.tol_gap = o.tol_gap; a.tol_infeas = o.tol_infeas; a.armijo = o.armijo; a.max_step = o.max_step;
     a.max_evals = o.max_evals; a.pg_rule = o.pg_rule; a.ts = ctx->ts;
-    a.batch = nullptr; a.hstat = nullptr;
+    a.batch = nullptr; a.hstat = nullptr; a.pool_flags = nullptr;
     return a;
 }
 
@@ -1868,6 +1871,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
 extern "C" {
 
 static void pools_ready(cfmm_ctx *ctx);     // (the pending token-block orderings: reorder.hpp)
+static void sweep_release(cfmm_ctx *ctx);   // (the buffers of cfmm_solve_sweep)
 static void release_landed(cfmm_ctx *ctx);
 
 void cfmm_default_opts(cfmm_opts *o)
@@ -2064,6 +2068,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
         auto &fl = g_free_streams[ctx->device & 63];
         if (fl.size() < 16) fl.push_back(ctx->stream); else (void)hipStreamDestroy(ctx->stream);      // (idle: synchronised above)
     }
+    sweep_release(ctx);
     delete ctx;
     return CFMM_OK;
 }
@@ -2889,7 +2894,7 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
         hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, nu_src,
                            ctx->acc, (long long)((size_t)ctx->nslices * acc_stride(n)), (DevState *)nullptr, 0);
         const int threads = 64 * std::min(TINY_THREADS / 64, std::max(1, ea_tiny.ntiles));
-        hipLaunchKernelGGL(solve_tiny_kernel, dim3(1), dim3(threads), (size_t)tiny_lds_doubles(n) * sizeof(double), ctx->stream, ea_tiny, ua, o.max_evals + 1);
+        hipLaunchKernelGGL(solve_tiny_kernel<false>, dim3(1), dim3(threads), (size_t)tiny_lds_doubles(n) * sizeof(double), ctx->stream, ea_tiny, ua, o.max_evals + 1);
     } else {
         hipLaunchKernelGGL(start_kernel<false>, dim3(1), dim3(UPD_THREADS), upd_lds_bytes(ctx->ng), ctx->stream, ua, nu_src,
                            ctx->acc, (long long)((size_t)ctx->nslices * acc_stride(n)), (DevState *)nullptr, 0);
@@ -3135,6 +3140,498 @@ int cfmm_solve_batch(cfmm_ctx *const *ctxs, int nb, const double *const *nu0, co
 }
 
 int cfmm_batch_capacity(int n_tokens) { return n_tokens < 1 ? 0 : batch_capacity(n_tokens); }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// cfmm_solve_sweep: the reference's OWN sweep (two-asset.py:34-100: 50 utilities over one 5-pool network, constant-sum pool
+// included) as ONE call.  Every point of the sweep is an independent one-workgroup solve (tiny.hpp); a round of the sweep is ONE
+// launch of solve_tiny_kernel<BATCH> with one workgroup per unfinished point, and the host-side active-set loop over the kinks of
+// the constant-sum pools (cfmm/problem.py: Problem._solve_kinks -- tie the two prices of a pool found on its kink, re-solve the
+// now smooth reduced dual, recover the fill fractions, release ties whose fill leaves (0, 1)) runs HERE, in lock-step over the
+// points, between the rounds: one H2D copy, two launches and one D2H copy per round for the whole sweep, no Python in between.
+// Round 4 ran the sweep as 50 x ~3 sequential one-workgroup launches with the kink logic in Python: 13 ms.
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// weighted union-find over the tokens of a tiny network: log nu_j = s[group(j)] + off[j]   (problem.py: _Ties)
+struct SweepTies {
+    int parent[TINY_N]; double off[TINY_N]; int n;
+    void init(int n_) { n = n_; for (int j = 0; j < n; ++j) { parent[j] = j; off[j] = 0.0; } }
+    int find(int j)
+    {
+        int path[TINY_N], np = 0;
+        while (parent[j] != j) { path[np++] = j; j = parent[j]; }
+        const int root = j;
+        for (int q = np - 1; q >= 0; --q) {            // from the top of the path down: the parent's offset is already relative to the root
+            const int node = path[q], p = parent[node];
+            if (p != root) off[node] += off[p];
+            parent[node] = root;
+        }
+        return root;
+    }
+    bool tie(int a, int b, double delta)               // log nu_a - log nu_b = delta; false if it contradicts the ties so far
+    {
+        const int ra = find(a), rb = find(b);
+        if (ra == rb) return std::fabs((off[a] - off[b]) - delta) < 1e-12;
+        off[ra] = delta + off[b] - off[a];
+        parent[ra] = rb;
+        return true;
+    }
+    int groups(int *grp)                               // group ids in the order of the (sorted) roots, as np.unique numbers them
+    {
+        int root[TINY_N]; bool is_root[TINY_N] = {};
+        for (int j = 0; j < n; ++j) { root[j] = find(j); is_root[root[j]] = true; }
+        int id[TINY_N], ng = 0;
+        for (int j = 0; j < n; ++j) if (is_root[j]) id[j] = ng++;
+        for (int j = 0; j < n; ++j) grp[j] = id[root[j]];
+        return ng;
+    }
+};
+
+struct SweepTie { int sgn; bool loose; };
+struct SumCols { int64_t m; const int32_t *ia, *ib; const double *fee, *Ra, *Rb; };
+
+// least squares  min |A th - b|  over th in [0, 1]^K for a handful of tied pools (A: R x K, row-major): the unconstrained solution
+// where it lies inside the box; otherwise the best of the 3^K assignments {free, at 0, at 1} whose free part stays inside (exact for
+// a convex problem: the optimum is one of them, and none of the others can beat it); beyond 7 unknowns the clipped solution
+bool small_lsq(const std::vector<double> &A, const std::vector<double> &b, int R, int K, const std::vector<int> &freev, const std::vector<double> &fixed,
+               std::vector<double> &th)
+{
+    // free variables by the normal equations (a whiff of ridge: a rank-deficient system gets the small-norm solution, as lstsq does)
+    const int F = (int)freev.size();
+    th = fixed;
+    if (F == 0) return true;
+    std::vector<double> N((size_t)F * F, 0.0), g(F, 0.0), rb(b);
+    for (int r = 0; r < R; ++r) for (int k = 0; k < K; ++k) rb[r] -= A[(size_t)r * K + k] * fixed[k];
+    double tr = 0.0;
+    for (int i = 0; i < F; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double v = 0.0;
+            for (int r = 0; r < R; ++r) v += A[(size_t)r * K + freev[i]] * A[(size_t)r * K + freev[j]];
+            N[(size_t)i * F + j] = N[(size_t)j * F + i] = v;
+        }
+        for (int r = 0; r < R; ++r) g[i] += A[(size_t)r * K + freev[i]] * rb[r];
+        tr += N[(size_t)i * F + i];
+    }
+    const double ridge = 1e-14 * (tr > 0.0 ? tr / F : 1.0);
+    for (int i = 0; i < F; ++i) N[(size_t)i * F + i] += ridge;
+    for (int i = 0; i < F; ++i) {                       // Cholesky, in place
+        for (int j = 0; j <= i; ++j) {
+            double v = N[(size_t)i * F + j];
+            for (int q = 0; q < j; ++q) v -= N[(size_t)i * F + q] * N[(size_t)j * F + q];
+            if (i == j) { if (!(v > 0.0)) return false; N[(size_t)i * F + i] = std::sqrt(v); }
+            else N[(size_t)i * F + j] = v / N[(size_t)j * F + j];
+        }
+    }
+    for (int i = 0; i < F; ++i) { double v = g[i]; for (int q = 0; q < i; ++q) v -= N[(size_t)i * F + q] * g[q]; g[i] = v / N[(size_t)i * F + i]; }
+    for (int i = F - 1; i >= 0; --i) { double v = g[i]; for (int q = i + 1; q < F; ++q) v -= N[(size_t)q * F + i] * g[q]; g[i] = v / N[(size_t)i * F + i]; }
+    for (int i = 0; i < F; ++i) th[freev[i]] = g[i];
+    return true;
+}
+void box_lsq(const std::vector<double> &A, const std::vector<double> &b, int R, int K, std::vector<double> &th)
+{
+    std::vector<int> all(K);
+    for (int k = 0; k < K; ++k) all[k] = k;
+    std::vector<double> zero(K, 0.0);
+    if (!small_lsq(A, b, R, K, all, zero, th)) { th.assign(K, 0.5); return; }
+    bool inside = true;
+    for (double v : th) inside = inside && v >= 0.0 && v <= 1.0;
+    if (inside) return;
+    if (K > 7) { for (double &v : th) v = std::min(1.0, std::max(0.0, v)); return; }
+    auto resid = [&](const std::vector<double> &t) { double s2 = 0.0; for (int r = 0; r < R; ++r) { double v = -b[r]; for (int k = 0; k < K; ++k) v += A[(size_t)r * K + k] * t[k]; s2 += v * v; } return s2; };
+    std::vector<double> best(th);
+    for (double &v : best) v = std::min(1.0, std::max(0.0, v));
+    double best_r = resid(best);
+    int total = 1; for (int k = 0; k < K; ++k) total *= 3;
+    std::vector<int> fr; std::vector<double> fx(K), cand;
+    for (int code = 1; code < total; ++code) {           // (code 0 = all free: done above)
+        fr.clear();
+        int c = code;
+        for (int k = 0; k < K; ++k, c /= 3) { const int m3 = c % 3; fx[k] = m3 == 2 ? 1.0 : 0.0; if (m3 == 0) fr.push_back(k); }
+        if (!small_lsq(A, b, R, K, fr, fx, cand)) continue;
+        bool ok = true;
+        for (int k : fr) ok = ok && cand[k] >= 0.0 && cand[k] <= 1.0;
+        if (!ok) continue;
+        const double rr = resid(cand);
+        if (rr < best_r) { best_r = rr; best = cand; }
+    }
+    th = best;
+}
+
+// fill fractions of the tied constant-sum pools (problem.py: Problem._recover_fills): theta in [0, 1]^K with
+// (psi + h + sum_k theta_k d_k)_j = 0 on every token that must balance, >= 0 on GE tokens at their bound
+bool sweep_recover_fills(int n, const double *nu, const double *psi, const double *c, const double *h, const int32_t *ctype, const SumCols &sc,
+                         const std::map<int, SweepTie> &tied, double tol, std::vector<double> &th)
+{
+    const int K = (int)tied.size();
+    std::vector<double> D((size_t)n * K, 0.0);
+    int k = 0;
+    for (auto &kv : tied) {
+        const int i = kv.first, a = sc.ia[i], b = sc.ib[i];
+        const double g = sc.fee[i];
+        if (kv.second.sgn > 0) { D[(size_t)a * K + k] = -sc.Rb[i] / g; D[(size_t)b * K + k] = sc.Rb[i]; }      // tender a, drain b
+        else { D[(size_t)b * K + k] = -sc.Ra[i] / g; D[(size_t)a * K + k] = sc.Ra[i]; }
+        ++k;
+    }
+    std::vector<double> A, rhs;
+    std::vector<char> must(n), atb(n);
+    int R = 0;
+    for (int j = 0; j < n; ++j) {
+        const int ct = ctype ? ctype[j] : CFMM_GE;
+        const double hj = h ? h[j] : 0.0;
+        atb[j] = ct == CFMM_GE && nu[j] <= c[j] * (1.0 + 1e-9);
+        must[j] = ct == CFMM_EQ || (ct == CFMM_GE && !atb[j]);
+        bool touched = false;
+        for (int q = 0; q < K; ++q) touched = touched || D[(size_t)j * K + q] != 0.0;
+        if (must[j] && touched) {
+            for (int q = 0; q < K; ++q) A.push_back(D[(size_t)j * K + q] * nu[j]);
+            rhs.push_back(-(psi[j] + hj) * nu[j]);
+            ++R;
+        }
+    }
+    if (R == 0) th.assign(K, 0.5);
+    else if (K == 1) {
+        double aa = 0.0, ab = 0.0;
+        for (int r = 0; r < R; ++r) { aa += A[r] * A[r]; ab += A[r] * rhs[r]; }
+        th.assign(1, std::min(1.0, std::max(0.0, ab / std::max(aa, 1e-300))));
+    } else box_lsq(A, rhs, R, K, th);
+    double scale = 0.0, res_eq = 0.0, res_ge = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double hj = h ? h[j] : 0.0;
+        scale += std::fabs(nu[j] * (std::fabs(psi[j]) + std::fabs(hj)));
+        double tot = psi[j] + hj;
+        for (int q = 0; q < K; ++q) tot += D[(size_t)j * K + q] * th[q];
+        if (must[j]) res_eq += std::fabs(nu[j] * tot);
+        if (atb[j]) res_ge += std::max(-(nu[j] * tot), 0.0);
+    }
+    scale = std::max(1.0, scale);
+    return res_eq / scale <= 10.0 * tol && res_ge / scale <= 10.0 * tol;
+}
+
+// constant-sum pools whose price ratio sits on one of their two kinks (problem.py: Problem._kink_candidates)
+void sweep_kink_candidates(const double *nu, const SumCols &sc, double kink_tol, const std::set<std::pair<int, int>> &banned, const std::map<int, SweepTie> &tied,
+                           bool loose, std::map<int, SweepTie> &out)
+{
+    out.clear();
+    for (int64_t i = 0; i < sc.m; ++i) {
+        const double r = std::log(nu[sc.ia[i]]) - std::log(nu[sc.ib[i]]), lg = std::log(sc.fee[i]);
+        const int sgn = r < 0.0 ? 1 : -1;               // a->b kink at r = lg < 0, b->a kink at r = -lg > 0
+        const double dist = std::fabs(r - sgn * lg);
+        const bool near = dist < kink_tol && (dist < 0.5 * std::fabs(lg) || lg == 0.0 || loose);
+        if (near && !tied.count((int)i) && !banned.count({(int)i, sgn})) out[(int)i] = SweepTie{sgn, loose};
+    }
+}
+
+struct SweepPointState {
+    std::map<int, SweepTie> tied;
+    std::set<std::pair<int, int>> banned;
+    std::vector<double> theta;              // of `tied`, in its order, once the fills are recovered
+    int budget = 0, evals = 0, iters = 0, rounds = 0;
+    double kink_tol = 1e-3;
+    bool done = false, fills_ok = false;
+    DevState st = {};
+};
+
+struct SweepLayout {
+    int n, B, msum;
+    size_t a_stride, o_stride, s_stride;    // doubles per point: inputs | outputs | device-only state
+    size_t off_u, off_a, off_o, off_s, total;
+    SweepLayout(int n_, int B_, int msum_) : n(n_), B(B_), msum(msum_)
+    {
+        const size_t fw = ((size_t)msum + 1) / 2;
+        a_stride = (5 * (size_t)n + (size_t)n + fw + 1) & ~(size_t)1;          // c h off glo ghi | ctype grp (ints) | flags (ints)
+        o_stride = (2 * (size_t)n + (sizeof(DevState) + 7) / 8 + 1) & ~(size_t)1;   // nu_acc psi_acc | DevState
+        s_stride = (8 * (size_t)n + 4) & ~(size_t)1;                            // nu[n + 2] psi_t s s_t Gs Gs_t d Ds
+        off_u = 0;
+        off_a = ((size_t)B * sizeof(UpdArgs) + 255) & ~(size_t)255;
+        off_o = off_a + (size_t)B * a_stride * 8;
+        off_s = off_o + (size_t)B * o_stride * 8;
+        total = off_s + (size_t)B * s_stride * 8;
+    }
+    double *A(char *base, int p) const { return (double *)(base + off_a) + (size_t)p * a_stride; }
+    double *O(char *base, int p) const { return (double *)(base + off_o) + (size_t)p * o_stride; }
+    double *S(char *base, int p) const { return (double *)(base + off_s) + (size_t)p * s_stride; }
+    int *ctype(char *base, int p) const { return (int *)(A(base, p) + 5 * n); }
+    int *grp(char *base, int p) const { return ctype(base, p) + n; }
+    int *flags(char *base, int p) const { return ctype(base, p) + 2 * n; }
+    DevState *st(char *base, int p) const { return (DevState *)(O(base, p) + 2 * n); }
+};
+
+}  // namespace
+
+struct cfmm_sweep_buffers { char *dev = nullptr, *host = nullptr; size_t cap = 0; double *tr_dev = nullptr; size_t tr_cap = 0; };
+static std::mutex g_sweep_mu;
+static std::map<cfmm_ctx *, cfmm_sweep_buffers> g_sweep;       // (per context, released by cfmm_destroy)
+static void sweep_release(cfmm_ctx *ctx)
+{
+    std::lock_guard<std::mutex> g(g_sweep_mu);
+    auto it = g_sweep.find(ctx);
+    if (it == g_sweep.end()) return;
+    if (it->second.dev) (void)hipFree(it->second.dev);
+    if (it->second.host) (void)hipHostFree(it->second.host);
+    if (it->second.tr_dev) (void)hipFree(it->second.tr_dev);
+    g_sweep.erase(it);
+}
+
+int cfmm_solve_sweep(cfmm_ctx *ctx, int B, const double *c, const double *h, const int32_t *ctype, const double *nu0,
+                     int64_t m_sum, const int32_t *sum_ia, const int32_t *sum_ib, const double *sum_fee, const double *sum_Ra, const double *sum_Rb,
+                     const cfmm_opts *opts_in, double kink_tol, int max_rounds,
+                     double *nu_out, double *psi_out, double *theta_out, int32_t *tsgn_out, double *trades_out, cfmm_stats *out, int32_t *rounds_out)
+{
+    if (!ctx || B < 1 || !c || !nu0 || !nu_out || !psi_out || !out) return ctx ? fail(ctx, CFMM_E_ARG, "solve_sweep: NULL argument or no points") : CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pools_ready(ctx);
+    struct AtExit { cfmm_ctx *c; ~AtExit() { release_landed(c); } } at_exit{ctx};
+    const int n = ctx->n;
+    cfmm_opts o;
+    if (opts_in) o = *opts_in; else cfmm_default_opts(&o);
+    if (o.memory == 0) o.memory = n <= 32 ? 8 : 3;
+    if (o.memory < 1 || o.memory > MAX_MEMORY || o.max_evals < 1) return fail(ctx, CFMM_E_ARG, "solve_sweep: memory %d, max_evals %d", o.memory, o.max_evals);
+    if (o.method == CFMM_METHOD_NEWTON) return fail(ctx, CFMM_E_UNSUPPORTED, "solve_sweep: first-order method only");
+    const EvalArgs ea = make_eval_args(ctx, false, 0x7fffffff, false);
+    if (!(ctx->tiny_path && !sharded(ctx) && !ctx->det && extra_launch_pools(ctx) == 0 && ea.ntiles >= 1 && ea.ntiles <= TINY_MAX_TILES && n <= TINY_N))
+        return fail(ctx, CFMM_E_UNSUPPORTED, "solve_sweep: serves networks one workgroup evaluates (<= %d tokens, <= %d wave-tiles, no stableswap / generic / K-asset table pools, "
+                                             "one GPU, not the reproducible mode); solve the points one at a time or through cfmm_solve_batch", TINY_N, TINY_MAX_TILES);
+    if (B > 4096) return fail(ctx, CFMM_E_LIMIT, "solve_sweep: %d points (at most 4096 per call)", B);
+    if (m_sum != ctx->pools->b2[CFMM_POOL_SUM2].m) return fail(ctx, CFMM_E_ARG, "solve_sweep: %lld constant-sum pools handed in, %lld uploaded", (long long)m_sum, (long long)ctx->pools->b2[CFMM_POOL_SUM2].m);
+    if (m_sum > 0 && (!sum_ia || !sum_ib || !sum_fee || !sum_Ra || !sum_Rb || !theta_out || !tsgn_out)) return fail(ctx, CFMM_E_ARG, "solve_sweep: the constant-sum columns (and theta / tsgn) are needed when such pools exist");
+    for (int p = 0; p < B; ++p) for (int j = 0; j < n; ++j) {
+        const double cj = c[(size_t)p * n + j], v = nu0[(size_t)p * n + j];
+        if (!(cj >= 0.0) || !std::isfinite(cj)) return fail(ctx, CFMM_E_ARG, "solve_sweep: point %d, c[%d] < 0 or not finite", p, j);
+        if (!(v > 0.0) || !std::isfinite(v)) return fail(ctx, CFMM_E_ARG, "solve_sweep: point %d, nu0[%d] = %g is not a positive finite price", p, j, v);
+        if (ctype) {
+            const int ct = ctype[(size_t)p * n + j];
+            if (ct < CFMM_GE || ct > CFMM_FREE) return fail(ctx, CFMM_E_UNSUPPORTED, "solve_sweep: point %d, ctype[%d] = %d (the utility table's entries are solved one at a time)", p, j, ct);
+            if (ct == CFMM_FREE && !(cj > 0.0)) return fail(ctx, CFMM_E_ARG, "solve_sweep: point %d, token %d: CFMM_FREE needs c > 0", p, j);
+        }
+    }
+    const SumCols sc{m_sum, sum_ia, sum_ib, sum_fee, sum_Ra, sum_Rb};
+    const int msum = (int)m_sum;
+    const SweepLayout L(n, B, msum);
+    // tenders: per point, for every non-empty bucket in the order two-asset kinds 0.., then K = 3..8: delta [k][m] | lambda [k][m]
+    size_t tr_stride = 0;
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) tr_stride += 4 * (size_t)ctx->pools->b2[k].m;
+    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) tr_stride += 2 * (size_t)k * ctx->pools->bn[k].m;
+    cfmm_sweep_buffers *sb;
+    {
+        std::lock_guard<std::mutex> g(g_sweep_mu);
+        sb = &g_sweep[ctx];
+    }
+    if (sb->cap < L.total) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (sb->dev) (void)hipFree(sb->dev);
+        if (sb->host) (void)hipHostFree(sb->host);
+        sb->dev = sb->host = nullptr; sb->cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&sb->dev, L.total + 256));
+        HIP_TRY(ctx, hipHostMalloc((void **)&sb->host, L.total + 256, hipHostMallocDefault));
+        sb->cap = L.total;
+    }
+    if (trades_out && sb->tr_cap < (size_t)B * tr_stride) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (sb->tr_dev) (void)hipFree(sb->tr_dev);
+        sb->tr_dev = nullptr; sb->tr_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&sb->tr_dev, (size_t)B * tr_stride * sizeof(double) + 256));
+        sb->tr_cap = (size_t)B * tr_stride;
+    }
+    char *dev = sb->dev, *host = sb->host;
+    UpdArgs *hu = (UpdArgs *)(host + L.off_u);
+    const double tol = o.tol_gap;
+    const int64_t pools = cfmm_pool_count(ctx);
+    std::vector<SweepPointState> ps(B);
+    // the inputs that do not change from round to round, and the start prices
+    for (int p = 0; p < B; ++p) {
+        double *A = L.A(host, p);
+        std::memcpy(A, c + (size_t)p * n, n * sizeof(double));
+        if (h) std::memcpy(A + n, h + (size_t)p * n, n * sizeof(double)); else std::memset(A + n, 0, n * sizeof(double));
+        int *ct = L.ctype(host, p);
+        for (int j = 0; j < n; ++j) ct[j] = ctype ? ctype[(size_t)p * n + j] : CFMM_GE;
+        std::memcpy(L.O(host, p), nu0 + (size_t)p * n, n * sizeof(double));
+        // legs: short where kinks may have to be found (problem.py: _solve_kinks); a network without constant-sum pools is ONE leg
+        ps[p].budget = msum ? std::min(o.max_evals, pools <= 1000 ? 40 : 100) : o.max_evals;
+        ps[p].kink_tol = kink_tol > 0.0 ? kink_tol : 1e-3;
+    }
+    if (max_rounds < 1) max_rounds = 6;
+    const size_t lds = (size_t)tiny_lds_doubles(n) * sizeof(double);
+    const int threads = 64 * std::min(TINY_THREADS / 64, std::max(1, ea.ntiles));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+    std::vector<int> active;
+    for (int round = 0; round < 8 * max_rounds; ++round) {
+        active.clear();
+        for (int p = 0; p < B; ++p) {
+            SweepPointState &S = ps[p];
+            if (S.done) continue;
+            if (S.evals >= 4 * o.max_evals) { S.done = true; continue; }
+            // ---- this round's ties, bounds, tolerance and budget of point p (problem.py: _solve_kinks, the head of its loop) ----
+            SweepTies ties; ties.init(n);
+            int *fl = L.flags(host, p);
+            for (int i = 0; i < msum; ++i) fl[i] = 0;
+            for (auto it = S.tied.begin(); it != S.tied.end();) {
+                const int i = it->first;
+                if (ties.tie(sc.ia[i], sc.ib[i], it->second.sgn * std::log(sc.fee[i]))) { fl[i] = 1; ++it; }
+                else { S.banned.insert({i, it->second.sgn}); it = S.tied.erase(it); }
+            }
+            double *A = L.A(host, p);
+            double *off = A + 2 * n, *glo = A + 3 * n, *ghi = A + 4 * n;
+            int *grp = L.grp(host, p);
+            const int *ct = L.ctype(host, p);
+            int ng = n;
+            if (!S.tied.empty()) { ng = ties.groups(grp); for (int j = 0; j < n; ++j) off[j] = ties.off[j]; }
+            else for (int j = 0; j < n; ++j) { grp[j] = j; off[j] = 0.0; }
+            for (int r = 0; r < n; ++r) { glo[r] = -INFINITY; ghi[r] = INFINITY; }
+            for (int j = 0; j < n; ++j) {                 // (bounds_into_mirror)
+                double l = -INFINITY, u = INFINITY;
+                if (ct[j] == CFMM_GE) l = A[j] > 0.0 ? std::log(A[j]) : -INFINITY;
+                else if (ct[j] == CFMM_FREE) l = u = std::log(A[j]);
+                l -= off[j]; u -= off[j];
+                if (l > glo[grp[j]]) glo[grp[j]] = l;
+                if (u < ghi[grp[j]]) ghi[grp[j]] = u;
+            }
+            UpdArgs a = {};
+            a.n = n; a.ng = ng; a.M = o.memory; a.nslices = 1;
+            double *dA = L.A(dev, p), *dO = L.O(dev, p), *dS = L.S(dev, p);
+            a.acc = nullptr;
+            a.c = dA; a.h = dA + n; a.off = dA + 2 * n; a.glo = dA + 3 * n; a.ghi = dA + 4 * n;
+            a.ctype = L.ctype(dev, p); a.grp = L.grp(dev, p);
+            a.nu_acc = dO; a.psi_acc = dO + n; a.st = L.st(dev, p);
+            a.nu = dS; a.psi_t = dS + n + 2; a.s = dS + 2 * n + 2; a.s_t = dS + 3 * n + 2; a.Gs = dS + 4 * n + 2; a.Gs_t = dS + 5 * n + 2; a.d = dS + 6 * n + 2; a.Ds = dS + 7 * n + 2;
+            a.S = a.Y = a.rho = nullptr;
+            const bool tied = !S.tied.empty();
+            a.tol_gap = a.tol_infeas = tied ? 0.01 * tol : tol;
+            a.pg_rule = tied ? 1 : 0;
+            a.armijo = o.armijo; a.max_step = o.max_step;
+            a.max_evals = S.budget;
+            a.ts = nullptr; a.batch = nullptr; a.hstat = nullptr;
+            a.pool_flags = (tied && msum) ? L.flags(dev, p) : nullptr;
+            hu[active.size()] = a;
+            active.push_back(p);
+        }
+        if (active.empty()) break;
+        const int na = (int)active.size();
+        // ---- one round on the device: inputs down, start + solve of every unfinished point, results up ----
+        HIP_TRY(ctx, hipMemcpyAsync(dev, host, L.off_s, hipMemcpyHostToDevice, ctx->stream));
+        UpdArgs lead = hu[0];
+        lead.batch = (const UpdArgs *)(dev + L.off_u);
+        hipLaunchKernelGGL(start_kernel<true>, dim3(na), dim3(64), upd_lds_bytes(n), ctx->stream, lead, (const double *)nullptr, (double *)nullptr, 0ll, (DevState *)nullptr, 0);
+        hipLaunchKernelGGL(solve_tiny_kernel<true>, dim3(na), dim3(threads), lds, ctx->stream, ea, lead, 0);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(host + L.off_o, dev + L.off_o, (size_t)B * L.o_stride * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // ---- the host's half of the active-set loop (problem.py: _solve_kinks, the tail of its loop) ----
+        for (int p : active) {
+            SweepPointState &S = ps[p];
+            const DevState st = *L.st(host, p);
+            S.st = st; S.evals += st.evals; S.iters += st.iters; S.rounds += 1;
+            const int status = st.status ? st.status : 3;
+            if (!std::isfinite(st.f)) { S.done = true; S.st.status = CFMM_E_NUMERIC; continue; }
+            const double *nu = L.O(host, p), *psi = nu + n;
+            const double *A = L.A(host, p);
+            if (status == 1) {
+                if (S.tied.empty()) { S.done = true; continue; }
+                const bool ok = sweep_recover_fills(n, nu, psi, A, A + n, L.ctype(host, p), sc, S.tied, tol, S.theta);
+                std::vector<int> bad;
+                { int k = 0; for (auto &kv : S.tied) { if (!(S.theta[k] > 1e-9 && S.theta[k] < 1.0 - 1e-9)) bad.push_back(kv.first); ++k; } }
+                if (ok && bad.empty()) { S.done = true; S.fills_ok = true; continue; }
+                if (!bad.empty()) {                        // fully on / fully off after all: back to bang-bang
+                    int k = 0;
+                    std::map<int, double> th_of;
+                    for (auto &kv : S.tied) th_of[kv.first] = S.theta[k++];
+                    for (int i : bad) {
+                        const SweepTie rec = S.tied[i];
+                        S.tied.erase(i);
+                        S.banned.insert({i, rec.sgn});
+                        // a guessed kink that carries no trade: the optimum sits on the pool's OTHER kink (fee bands narrower than a leg resolves)
+                        if (rec.loose && th_of[i] <= 1e-9 && !S.banned.count({i, -rec.sgn})) S.tied[i] = SweepTie{-rec.sgn, false};
+                    }
+                    S.theta.clear();
+                    continue;
+                }
+            }
+            std::map<int, SweepTie> fresh;
+            sweep_kink_candidates(nu, sc, S.kink_tol, S.banned, S.tied, false, fresh);
+            double wide = S.kink_tol;
+            while (fresh.empty() && status != 1 && wide < 0.05) { wide *= 10.0; sweep_kink_candidates(nu, sc, wide, S.banned, S.tied, true, fresh); }
+            if (!fresh.empty()) {
+                for (auto &kv : fresh) S.tied[kv.first] = kv.second;
+                for (auto it = S.banned.begin(); it != S.banned.end();) { if (fresh.count(it->first)) ++it; else it = S.banned.erase(it); }      // bans expire when the active set changes
+            } else if (status == 3 && S.budget < o.max_evals) S.budget = std::min(o.max_evals, 2 * S.budget);     // no kink in sight: longer legs
+            else if (S.kink_tol < 0.05) S.kink_tol *= 10.0;
+            else S.done = true;
+            S.theta.clear();
+        }
+    }
+    // ---- the tenders of every point at its accepted prices (the tied pools' come out as zero: the caller scales their full fill by theta) ----
+    if (trades_out && tr_stride > 0) {
+        double *td = sb->tr_dev;
+        const double *nu_d = L.O(dev, 0);
+        const int nus = (int)L.o_stride;
+        const int *fl_d = msum ? L.flags(dev, 0) : nullptr;
+        const int fls = (int)(2 * L.a_stride);
+        size_t boff = 0;
+        const dim3 blk(256);
+        for (int k = 0; k < CFMM_POOL_KINDS2; ++k) {
+            Bucket2 b = ctx->pools->b2[k];
+            if (b.m == 0) continue;
+            const dim3 grid((unsigned)((b.m + 255) / 256), (unsigned)B);
+            double *dd = td + boff, *dl = dd + 2 * b.m;
+            switch (k) {
+            case 0: hipLaunchKernelGGL(trades2_sweep_kernel<0>, grid, blk, 0, ctx->stream, b, nu_d, nus, dd, dl, (long long)tr_stride, fl_d, fls); break;
+            case 1: hipLaunchKernelGGL(trades2_sweep_kernel<1>, grid, blk, 0, ctx->stream, b, nu_d, nus, dd, dl, (long long)tr_stride, fl_d, fls); break;
+            case 2: hipLaunchKernelGGL(trades2_sweep_kernel<2>, grid, blk, 0, ctx->stream, b, nu_d, nus, dd, dl, (long long)tr_stride, fl_d, fls); break;
+            case 3: hipLaunchKernelGGL(trades2_sweep_kernel<3>, grid, blk, 0, ctx->stream, b, nu_d, nus, dd, dl, (long long)tr_stride, fl_d, fls); break;
+            default: hipLaunchKernelGGL(trades2_sweep_kernel<4>, grid, blk, 0, ctx->stream, b, nu_d, nus, dd, dl, (long long)tr_stride, fl_d, fls); break;
+            }
+            boff += 4 * (size_t)b.m;
+        }
+        for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) {
+            const BucketN &b = ctx->pools->bn[k];
+            if (b.m == 0) continue;
+            const dim3 grid((unsigned)((b.m + 255) / 256), (unsigned)B);
+            double *dd = td + boff, *dl = dd + (size_t)k * b.m;
+            switch (k) {
+            case 3: hipLaunchKernelGGL(tradesn_sweep_kernel<3>, grid, blk, 0, ctx->stream, b, nu_d, nus, dd, dl, (long long)tr_stride); break;
+            case 4: hipLaunchKernelGGL(tradesn_sweep_kernel<4>, grid, blk, 0, ctx->stream, b, nu_d, nus, dd, dl, (long long)tr_stride); break;
+            case 5: hipLaunchKernelGGL(tradesn_sweep_kernel<5>, grid, blk, 0, ctx->stream, b, nu_d, nus, dd, dl, (long long)tr_stride); break;
+            case 6: hipLaunchKernelGGL(tradesn_sweep_kernel<6>, grid, blk, 0, ctx->stream, b, nu_d, nus, dd, dl, (long long)tr_stride); break;
+            case 7: hipLaunchKernelGGL(tradesn_sweep_kernel<7>, grid, blk, 0, ctx->stream, b, nu_d, nus, dd, dl, (long long)tr_stride); break;
+            default: hipLaunchKernelGGL(tradesn_sweep_kernel<8>, grid, blk, 0, ctx->stream, b, nu_d, nus, dd, dl, (long long)tr_stride); break;
+            }
+            boff += 2 * (size_t)k * b.m;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+        { int rc = download_staged(ctx, trades_out, td, (size_t)B * tr_stride * sizeof(double)); if (rc) return rc; }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+    int rc_all = CFMM_OK;
+    for (int p = 0; p < B; ++p) {
+        const SweepPointState &S = ps[p];
+        std::memcpy(nu_out + (size_t)p * n, L.O(host, p), n * sizeof(double));
+        std::memcpy(psi_out + (size_t)p * n, L.O(host, p) + n, n * sizeof(double));
+        for (int i = 0; i < msum; ++i) { theta_out[(size_t)p * msum + i] = std::numeric_limits<double>::quiet_NaN(); tsgn_out[(size_t)p * msum + i] = 0; }
+        if (S.fills_ok) { int k = 0; for (auto &kv : S.tied) { theta_out[(size_t)p * msum + kv.first] = S.theta[k++]; tsgn_out[(size_t)p * msum + kv.first] = kv.second.sgn; } }
+        cfmm_stats *s = out + p;
+        std::memset(s, 0, sizeof *s);
+        s->evals = S.evals; s->iters = S.iters; s->status = S.st.status ? S.st.status : 3;
+        s->n_ranks = 1;
+        s->dual_value = S.st.f; s->primal_value = S.st.primal; s->gap = S.st.gap; s->infeas = S.st.infeas;
+        s->wall_seconds = std::chrono::duration<double>(t1 - t0).count();          // (of the whole sweep)
+        s->device_seconds = ms * 1e-3;
+        s->pg = S.st.pg;
+        s->pool_subproblems = (int64_t)S.evals * pools;
+        s->method = CFMM_METHOD_LBFGS;
+        if (rounds_out) rounds_out[p] = S.rounds;
+        if (S.st.status == CFMM_E_NUMERIC) rc_all = fail(ctx, CFMM_E_NUMERIC, "solve_sweep: dual value of point %d is not finite", p);
+    }
+    return rc_all;
+}
+
 
 int cfmm_get_trades2(cfmm_ctx *ctx, int kind, double *delta, double *lambda)
 {

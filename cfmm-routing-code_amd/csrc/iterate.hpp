@@ -262,7 +262,7 @@ iter_kernel(IterArgs a)
     double *const stage0 = lds_raw;
     double *const lds = lds_raw + (DMA ? NSLOT * SLOT : 0);
     constexpr int MM = ITER_MM, P = ITER_P;
-    static_assert(MM == 3, "DevState::rhow holds a window of 3");
+    static_assert(MM == 3, "DevState::rhow0..2 hold a window of 3");
     const int n = a.n, M = a.M;
     const int tid = threadIdx.x, lane = tid & 63, wave = uni((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     // LDS carve of eval_kernel<false, .>; the update borrows the waves' exchange strips (16 KB, free until the tile loop)
@@ -480,7 +480,7 @@ iter_kernel(IterArgs a)
         double rho[P];
         rho[0] = 0.0;
 #pragma unroll
-        for (int k = 0; k < MM; ++k) rho[k + 1] = (k < st.hist) ? uni(st.rhow[k]) : 0.0;
+        for (int k = 0; k < MM; ++k) rho[k + 1] = (k < st.hist) ? uni(k == 0 ? st.rhow0 : (k == 1 ? st.rhow1 : st.rhow2)) : 0.0;
         const double f_t = T(0), gapv = T(1);
 
         // ---- accept test ----------------------------------------------------------------------------------------
@@ -517,7 +517,7 @@ iter_kernel(IterArgs a)
                                         [&](int k, int j) { return T(GI_SY + k * (k - 1) / 2 + j); },
                                         [&](int k, int j) { return T(GI_YHY + k * (k + 1) / 2 + j); }, al, ga);
             }
-            if (pair_ok) { st.rhow[2] = st.rhow[1]; st.rhow[1] = st.rhow[0]; st.rhow[0] = rho[0]; }      // the window moves on
+            if (pair_ok) { st.rhow2 = st.rhow1; st.rhow1 = st.rhow0; st.rhow0 = rho[0]; }      // the window moves on
         }
         if (lane == 0) {
 #pragma unroll

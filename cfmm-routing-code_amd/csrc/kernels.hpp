@@ -74,8 +74,27 @@ __host__ __device__ constexpr bool heavy_kind(int kind) { return kind == 3 || ki
 struct DevState {
     int status, evals, iters, first, hist, head, nrej, pad;
     double f, t_step, gap, infeas, primal, pg;
-    double rhow[3];                   // iter_kernel only: 1 / s'y of its history window, newest first (iterate.hpp)
+    // iter_kernel only: 1 / s'y of its history window, newest first (iterate.hpp).  Three scalars, not an array: the kernels that only
+    // CARRY the window (`DevState st = load_state(a.st); ... *a.st = st`) copied an array member through memory the compiler would not promote
+    // to registers -- 32 B of scratch in every stand-alone update kernel and in solve_tiny_kernel
+    double rhow0, rhow1, rhow2;
 };
+// The record as the stand-alone update kernels and the one-wave solves use it: field by field, WITHOUT the window scalars (which they
+// neither read nor change).  A whole-struct copy in and out (`DevState st = load_state(a.st); ... store_state(a.st, st);`) carried that untouched 24-byte
+// tail through two overlapping 16-byte pieces in scratch memory -- 32 B of private segment in eleven kernels.
+__device__ __forceinline__ DevState load_state(const DevState *p)
+{
+    DevState s;
+    s.status = p->status; s.evals = p->evals; s.iters = p->iters; s.first = p->first; s.hist = p->hist; s.head = p->head; s.nrej = p->nrej; s.pad = 0;
+    s.f = p->f; s.t_step = p->t_step; s.gap = p->gap; s.infeas = p->infeas; s.primal = p->primal; s.pg = p->pg;
+    s.rhow0 = s.rhow1 = s.rhow2 = 0.0;
+    return s;
+}
+__device__ __forceinline__ void store_state(DevState *p, const DevState &s)
+{
+    p->status = s.status; p->evals = s.evals; p->iters = s.iters; p->first = s.first; p->hist = s.hist; p->head = s.head; p->nrej = s.nrej;
+    p->f = s.f; p->t_step = s.t_step; p->gap = s.gap; p->infeas = s.infeas; p->primal = s.primal; p->pg = s.pg;
+}
 
 struct Bucket2 {
     long long m;
@@ -658,15 +677,17 @@ __device__ __forceinline__ void tiles_dma_first(const EvalArgs &a, const int *ne
 // LDS round trips, no barrier of its own) gives the cumulative counts.  Also arms the ticket counter: the first ticket of
 // wave w is w.  The caller passes a barrier between this and the tile loop.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void build_tile_table(const EvalArgs &a, int *next_tile, int lane)
+// `whole`: this workgroup walks EVERY tile (the workgroups of a sweep launch are independent solves: tiny.hpp, BATCH)
+__device__ __forceinline__ void build_tile_table(const EvalArgs &a, int *next_tile, int lane, bool whole = false)
 {
     int *tab = next_tile + 2;
     int cnt = 0, s = 0;
     if (lane < N_BUCKETS) {
         const int nq = a.tile_end[lane] - (lane ? a.tile_end[lane - 1] : 0);
-        const double G = (double)gridDim.x;           // (products < 2^47: exact in fp64, and the floors below cannot be off by one)
-        s = (int)(((double)blockIdx.x * nq) / G);
-        cnt = (int)(((double)(blockIdx.x + 1) * nq) / G) - s;
+        const double G = whole ? 1.0 : (double)gridDim.x;           // (products < 2^47: exact in fp64, and the floors below cannot be off by one)
+        const double b = whole ? 0.0 : (double)blockIdx.x;
+        s = (int)((b * nq) / G);
+        cnt = (int)(((b + 1.0) * nq) / G) - s;
     }
     int c = cnt;
     c += __builtin_amdgcn_update_dpp(0, c, 0x111, 0xf, 0xf, true);     // row_shr:1 (lanes without a source read 0)
@@ -1004,11 +1025,8 @@ eval_batch_kernel(EvalArgs a, BatchArgs bt)
 // trade materialisation (once per solve): Delta = max(-y,0), Lambda = max(y,0), slot-major
 // ------------------------------------------------------------------------------------------
 template <int KIND>
-__global__ void __launch_bounds__(256)
-trades2_kernel(Bucket2 b, const double *__restrict__ nu, double *__restrict__ delta, double *__restrict__ lambda)
+__device__ __forceinline__ void trades2_body(const Bucket2 &b, long long i, const double *__restrict__ nu, double *__restrict__ delta, double *__restrict__ lambda)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.m) return;
     const double Ra = b.Ra[i], Rb = b.Rb[i], g = b.fee[i];
     const double pa = nu[b.ia[i]], pb = nu[b.ib[i]];
     Y2 y;
@@ -1021,13 +1039,30 @@ trades2_kernel(Bucket2 b, const double *__restrict__ nu, double *__restrict__ de
     delta[o] = fmax(-y.ya, 0.0);  delta[b.m + o] = fmax(-y.yb, 0.0);
     lambda[o] = fmax(y.ya, 0.0);  lambda[b.m + o] = fmax(y.yb, 0.0);
 }
-
-template <int K>
+template <int KIND>
 __global__ void __launch_bounds__(256)
-tradesn_kernel(BucketN b, const double *__restrict__ nu, const double *__restrict__ slo, double *__restrict__ delta, double *__restrict__ lambda)
+trades2_kernel(Bucket2 b, const double *__restrict__ nu, double *__restrict__ delta, double *__restrict__ lambda)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b.m) trades2_body<KIND>(b, i, nu, delta, lambda);
+}
+// the tenders of EVERY point of a sweep (cfmm_solve_sweep) in one launch per bucket: blockIdx.y = the point; its accepted prices sit
+// nu_stride doubles apart, its tenders out_stride doubles apart, its tied-pool flags (constant-sum bucket) flags_stride ints apart
+template <int KIND>
+__global__ void __launch_bounds__(256)
+trades2_sweep_kernel(Bucket2 b, const double *__restrict__ nu, int nu_stride, double *__restrict__ delta, double *__restrict__ lambda, long long out_stride,
+                     const int *flags_b, int flags_stride)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.m) return;
+    const size_t p = blockIdx.y;
+    if (KIND == 2) b.flags = flags_b ? flags_b + p * flags_stride : nullptr;
+    trades2_body<KIND>(b, i, nu + p * nu_stride, delta + p * out_stride, lambda + p * out_stride);
+}
+
+template <int K>
+__device__ __forceinline__ void tradesn_body(const BucketN &b, long long i, const double *__restrict__ nu, const double *__restrict__ slo, double *__restrict__ delta, double *__restrict__ lambda)
+{
     double R[K], w[K], p[K], y[K];
     int tok[K];
 #pragma unroll
@@ -1062,6 +1097,22 @@ tradesn_kernel(BucketN b, const double *__restrict__ nu, const double *__restric
         delta[(size_t)j * b.m + o] = fmax(-y[j], 0.0);
         lambda[(size_t)j * b.m + o] = fmax(y[j], 0.0);
     }
+}
+template <int K>
+__global__ void __launch_bounds__(256)
+tradesn_kernel(BucketN b, const double *__restrict__ nu, const double *__restrict__ slo, double *__restrict__ delta, double *__restrict__ lambda)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b.m) tradesn_body<K>(b, i, nu, slo, delta, lambda);
+}
+template <int K>
+__global__ void __launch_bounds__(256)
+tradesn_sweep_kernel(BucketN b, const double *__restrict__ nu, int nu_stride, double *__restrict__ delta, double *__restrict__ lambda, long long out_stride)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.m) return;
+    const size_t p = blockIdx.y;
+    tradesn_body<K>(b, i, nu + p * nu_stride, nullptr, delta + p * out_stride, lambda + p * out_stride);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1138,11 +1189,28 @@ struct UpdArgs {
     // its arguments from batch[b] (device memory); hstat: pinned host word {status << 32 | evals} the host polls
     const UpdArgs *batch;
     unsigned long long *hstat;
+    const int *pool_flags;            // sweep launches (tiny.hpp, BATCH): this solve's tied-pool flags of the constant-sum bucket, or null
 };
 template <bool BATCH>
 __device__ __forceinline__ const UpdArgs &upd_args(const UpdArgs &a0)
 {
     if constexpr (BATCH) return a0.batch[blockIdx.x]; else return a0;
+}
+// the same record BY VALUE through scalar loads (constant address space: the host wrote the array before the launch, nothing writes
+// it during one).  Through the reference above every field is a vector load from a uniform address -- a VGPR pair per pointer; the
+// register-resident update with 4 variables per thread sat at its 256-VGPR cap and spilled 20 B in its batched instantiation
+template <bool BATCH>
+__device__ __forceinline__ UpdArgs upd_args_scalar(const UpdArgs &a0)
+{
+    if constexpr (BATCH) {
+        typedef const unsigned long long __attribute__((address_space(4))) *ConstWords;
+        static_assert(sizeof(UpdArgs) % 8 == 0, "UpdArgs: whole 8-byte words");
+        const ConstWords src = (ConstWords)(unsigned long long)(a0.batch + blockIdx.x);
+        union { UpdArgs a; unsigned long long w[sizeof(UpdArgs) / 8]; } r;
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(UpdArgs) / 8; ++i) r.w[i] = src[i];
+        return r.a;
+    } else return a0;
 }
 __device__ __forceinline__ void report_progress(const UpdArgs &a, const DevState &st)
 {
@@ -1178,7 +1246,7 @@ __device__ __forceinline__ int update_generic_body(const UpdArgs &a, double *lds
     double *q = lds;                         // [ng]
     double *q2 = lds + a.ng;                 // [ng]
     double *scratch = lds + 2 * a.ng;        // [16*8]
-    DevState st = *a.st;
+    DevState st = load_state(a.st);
     if (st.status != 0) return st.status;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int n = a.n, ng = a.ng, M = a.M;
@@ -1359,7 +1427,7 @@ __device__ __forceinline__ int update_generic_body(const UpdArgs &a, double *lds
         for (int j = tid; j < n; j += nt) a.nu[j] = exp(a.s_t[a.grp[j]] + a.off[j]);
         if (st.evals >= a.max_evals) st.status = 3;
     }
-    if (tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; report_progress(a, st); }
+    if (tid == 0) { store_state(a.st, st); a.nu[n] = st.status != 0 ? 1.0 : 0.0; report_progress(a, st); }
     return st.status;
 }
 
@@ -1477,7 +1545,7 @@ template <int MAXT, int MM, int E, bool BATCH = false>          // <= MAXT threa
 __global__ void __launch_bounds__(MAXT)
 update_reg_kernel(UpdArgs a0)
 {
-    const UpdArgs &a = upd_args<BATCH>(a0);
+    const UpdArgs a = upd_args_scalar<BATCH>(a0);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     const int n = a.n, ng = a.ng, M = a.M;
@@ -1754,7 +1822,7 @@ update_reg_kernel(UpdArgs a0)
         if (r0 < n) stv<E>(a.nu, r0, nS, nn);
         if (st.evals >= a.max_evals) st.status = 3;
     }
-    if (wr && tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; report_progress(a, st); }
+    if (wr && tid == 0) { store_state(a.st, st); a.nu[n] = st.status != 0 ? 1.0 : 0.0; report_progress(a, st); }
     PHASE_STAMP(a.ts, 15);
 }
 
@@ -1858,7 +1926,7 @@ update_gram_kernel(UpdArgs a0)
 #ifdef CFMM_PHASE_TIMERS
     const long long c8 = clock64(), w8 = wall_clock64();
 #endif
-    DevState st = *a.st;
+    DevState st = load_state(a.st);
     // ---- loads, all issued up front (16-byte loads), first-needed first -------------------------------
     double s[E], s_t[E], Gs[E], d[E], Ds[E], glo[E], ghi[E];
     ldv<E>(a.s, pr, s); ldv<E>(a.s_t, pr, s_t); ldv<E>(a.Gs, pr, Gs); ldv<E>(a.d, pr, d); ldv<E>(a.Ds, pr, Ds);
@@ -2128,7 +2196,7 @@ update_gram_kernel(UpdArgs a0)
         if (r0 < n) stv<E>(a.nu, r0, nS, nn);
         if (st.evals >= a.max_evals) st.status = 3;
     }
-    if (wr && tid == 0) { *a.st = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0; report_progress(a, st); }
+    if (wr && tid == 0) { store_state(a.st, st); a.nu[n] = st.status != 0 ? 1.0 : 0.0; report_progress(a, st); }
     PHASE_STAMP(a.ts, 15);
 }
 

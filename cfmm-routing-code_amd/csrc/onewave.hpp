@@ -51,7 +51,7 @@ struct WaveUpdate {
     __device__ __forceinline__ void load(const UpdArgs &a, int lane, int n_, int ng_)
     {
         L = lane; n = n_; ng = ng_; ties = ng != n; rho_l = 0.0;
-        st = *a.st;
+        st = load_state(a.st);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int j = L + 64 * e;
@@ -203,7 +203,7 @@ struct WaveUpdate {
         }
         if (L == 0) {
             if (st.status == 0) st.status = 3;           // (the launch's budget is the solve's)
-            *a.st = st; a.nu[n] = 1.0; report_progress(a, st);
+            store_state(a.st, st); a.nu[n] = 1.0; report_progress(a, st);
         }
     }
 };

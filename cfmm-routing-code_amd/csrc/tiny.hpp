@@ -25,11 +25,21 @@ __host__ __device__ inline int tiny_lds_doubles(int n)
     return eval_lds_doubles(n, true) + 2 * 64 * (TINY_THREADS / 64) + 2 * 64 + 2 * MAX_MEMORY * 64 + 4;
 }
 
+// BATCH (cfmm_solve_sweep: the 50-point sweep of two-asset.py:34-100 in ONE launch): workgroup b solves point b of a sweep over the
+// SAME pools -- its own utility, price ties, start prices, tolerance and budget and its own tied-pool flags of the constant-sum
+// bucket (a0.batch[b], device memory; UpdArgs::pool_flags).  Everything else is the one solve above.
+template <bool BATCH = false>
 __global__ void __launch_bounds__(TINY_THREADS)
-solve_tiny_kernel(EvalArgs ev, UpdArgs a, int iters)
+solve_tiny_kernel(EvalArgs ev_in, UpdArgs a0, int iters_in)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int n = ev.n, ng = a.ng, M = a.M;
+    const UpdArgs &a = upd_args<BATCH>(a0);
+    const int iters = BATCH ? a.max_evals + 1 : iters_in;
+    // (the point's own flags: a copy of the argument block with ONE pointer replaced -- every other field still comes out of the
+    //  kernel arguments; the tile-range table, which indexes tile_end dynamically, is built from the arguments themselves)
+    EvalArgs ev = ev_in;
+    if (BATCH) ev.b2[2].flags = a.pool_flags;
+    const int n = ev_in.n, ng = a.ng, M = a.M;
     const int tid = threadIdx.x, L = tid & 63, wave = wuni((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     const int tile = eval_tile_doubles(n, false);
     double *psi_s = lds, *diag_s = lds + tile;
@@ -51,7 +61,7 @@ solve_tiny_kernel(EvalArgs ev, UpdArgs a, int iters)
 
     for (int it = 0; it < iters; ++it) {
         for (int j = tid; j < 2 * tile; j += blockDim.x) lds[j] = 0.0;
-        if (tid < 64) build_tile_table(ev, next_tile, tid);          // (also re-arms the ticket counter)
+        if (tid < 64) build_tile_table(ev_in, next_tile, tid, BATCH);   // (also re-arms the ticket counter; BATCH: every workgroup walks ALL tiles)
         __syncthreads();
         if (it == 0) eval_tiles_and_flush<true, false, false, false, false>(ev, nullptr, nu_s, psi_s, diag_s, fpart, next_tile, xs);
         else eval_tiles_and_flush<false, false, false, false, false>(ev, nullptr, nu_s, psi_s, diag_s, fpart, next_tile, xs);

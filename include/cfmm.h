@@ -213,6 +213,27 @@ int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts, cfmm_sta
 int cfmm_solve_batch(cfmm_ctx *const *ctxs, int nb, const double *const *nu0, const cfmm_opts *opts, cfmm_stats *out);
 int cfmm_batch_capacity(int n_tokens);
 
+/* The reference's OWN sweep as one call: two-asset.py:34-100 solves the same 5-pool network (constant-sum pool included,
+ * two-asset.py:7-32) under 50 utilities (current_assets = [t, 0, 0], :41-45; psi + current_assets >= 0, :86) and reads value,
+ * psi and every pool's tenders at each (:93-100).  B utilities over ONE tiny network -- what one workgroup evaluates: <= 64 tokens,
+ * <= 64 wave-tiles, no stableswap / generic / K-asset table pools, one GPU -- are solved in lock-step: a round is ONE launch with
+ * one workgroup per unfinished point (the whole first-order solve of a point inside its workgroup), and the active-set loop over the
+ * kinks of the constant-sum pools (arbitrage.py:73-74: tie the two prices of a pool found on its kink, re-solve, recover the fill
+ * fraction, release ties whose fill leaves (0, 1)) runs inside the library between the rounds.
+ *   c, h, ctype, nu0        [B][n]: utility (cfmm_set_utility's arrays; h / ctype may be NULL = 0 / CFMM_GE) and start prices per point
+ *   m_sum, sum_*            the constant-sum bucket's columns as uploaded (the host half of the loop reads them); m_sum = 0: none
+ *   kink_tol, max_rounds    <= 0: the defaults (1e-3, 6)
+ *   nu, psi                 [B][n]: accepted prices and the DEVICE's net trade there (tied pools excluded)
+ *   theta, tsgn             [B][m_sum]: fill fraction in (0, 1) and kink direction (+1: tender the first token, drain the second; -1:
+ *                           the reverse) of every pool that ended tied on its kink, NaN / 0 elsewhere: psi_total = psi + sum theta d
+ *   trades                  NULL, or [B][T]: per point, for every non-empty bucket in the order two-asset kinds 0.., then sizes 3..8,
+ *                           delta [k][m] then lambda [k][m] (tied pools: zeros -- their tenders are theta x their full fill)
+ *   out, rounds             [B] statistics (evals / iters summed over the rounds; wall / device seconds: of the whole sweep), rounds per point */
+int cfmm_solve_sweep(cfmm_ctx *ctx, int B, const double *c, const double *h, const int32_t *ctype, const double *nu0,
+                     int64_t m_sum, const int32_t *sum_ia, const int32_t *sum_ib, const double *sum_fee, const double *sum_Ra, const double *sum_Rb,
+                     const cfmm_opts *opts, double kink_tol, int max_rounds,
+                     double *nu, double *psi, double *theta, int32_t *tsgn, double *trades, cfmm_stats *out, int32_t *rounds);
+
 /* read-back (arbitrage.py:84 prob.value is stats.primal_value; psi.value; deltas/lambdas.value) */
 int cfmm_get_nu(cfmm_ctx *ctx, double *nu);
 int cfmm_set_nu(cfmm_ctx *ctx, const double *nu);

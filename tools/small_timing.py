@@ -30,7 +30,18 @@ p = problem_of(I.two_asset(0.0))
 t0 = time.perf_counter(); ev = 0
 for t in I.two_asset_sweep():
     p.set_utility(cfmm.Swap([t, 0, 0], 2)); p.solve(tol=1e-8, warm_start=True); ev += p.stats["evals"]
-out["two_asset_sweep_50"] = dict(ms_total=1e3 * (time.perf_counter() - t0), evals=ev)
+out["two_asset_sweep_50"] = dict(ms_total=1e3 * (time.perf_counter() - t0), evals=ev, how="50 prob.solve() calls, each warm-started from its neighbour")
+# the same 50 points through ONE library call (cfmm_solve_sweep: one workgroup per point and round, the kink loop inside the library)
+utils = [cfmm.Swap([t, 0, 0], 2) for t in I.two_asset_sweep()]
+p.solve_many(utils, tol=1e-8)
+best, tot = 1e9, 0.0
+for _ in range(20):
+    t0 = time.perf_counter(); res = p.solve_many(utils, tol=1e-8); dt = time.perf_counter() - t0
+    best = min(best, dt); tot += dt
+out["two_asset_sweep_50_one_call"] = dict(ms_total_best=1e3 * best, ms_total_mean=1e3 * tot / 20, library_ms=1e3 * res[0]["stats"]["wall_seconds"],
+                                         device_ms=1e3 * res[0]["stats"]["device_seconds"], evals=sum(r["stats"]["evals"] for r in res),
+                                         rounds_max=max(r["stats"]["rounds"] for r in res), points_on_a_kink=sum(1 for r in res if r["stats"]["rounds"] > 1),
+                                         status=sorted(set(r["status"] for r in res)), how="Problem.solve_many -> cfmm_solve_sweep, cold starts, tenders of every point included")
 p.close()
 for m, n in ((100, 20), (1000, 50), (10000, 200), (100000, 1000)):
     net = synthetic.make_network(n, m_cp2=int(0.7 * m), m_w2=int(0.2 * m), m_gn=int(0.1 * m), seed=1)
