@@ -13,6 +13,7 @@ _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
 POOL_CP2, POOL_W2, POOL_SUM2, POOL_CURVE2, POOL_POW2 = 0, 1, 2, 3, 4
 TIME_ALL = 100
+TIME_TABLE = 200      # the K-asset table's own launch (include/cfmm.h)
 GE, EQ, FREE = 0, 1, 2
 ULOG, UQUAD = 3, 4          # the utility table: u = c log(psi + h) / u = c psi - psi^2 / (2 h)   (include/cfmm.h)
 MAX_POOL_SIZE = 8
@@ -63,7 +64,7 @@ def build(force=False):
 _lib = None
 
 SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm_backend", "cfmm_default_opts",
-           "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_upload_poolsG", "cfmm_set_pool_flags", "cfmm_set_utility",
+           "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_upload_poolsG", "cfmm_set_pool_flags", "cfmm_set_pool_flagsG", "cfmm_set_utility",
            "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_debug_cholesky_apply", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_solve_sweep", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_get_tradesG", "cfmm_comm_unique_id", "cfmm_comm_init",
            "cfmm_oneshot_export", "cfmm_oneshot_import", "cfmm_oneshot_attach", "cfmm_oneshot_mailbox", "cfmm_oneshot_enable",
@@ -90,6 +91,7 @@ def lib():
     L.cfmm_upload_poolsN.argtypes = [vp, C.c_int, C.c_int64, ip, dp, dp, dp]
     L.cfmm_upload_poolsG.argtypes = [vp, C.c_int, C.c_int, C.c_int64, ip, dp, dp, dp]
     L.cfmm_set_pool_flags.argtypes = [vp, C.c_int, ip]
+    L.cfmm_set_pool_flagsG.argtypes = [vp, C.c_int, ip]
     L.cfmm_set_utility.argtypes = [vp, dp, dp, ip]
     L.cfmm_set_ties.argtypes = [vp, C.c_int, ip, dp]
     L.cfmm_set_deterministic.argtypes = [vp, C.c_int]
@@ -214,6 +216,11 @@ class Context:
     def set_pool_flags(self, kind, flags):
         flags = i32(flags)
         self._chk(self.L.cfmm_set_pool_flags(self.h, kind, _i(flags)))
+
+    def set_pool_flagsG(self, k, flags):
+        """per-leg tie flags [k][m] of the K-asset table's constant-sum bucket of k tokens (None: none)"""
+        flags = i32(flags)
+        self._chk(self.L.cfmm_set_pool_flagsG(self.h, int(k), _i(flags)))
 
     def set_utility(self, c, h=None, ctype=None):
         c, h, ctype = f64(c), f64(h), i32(ctype)

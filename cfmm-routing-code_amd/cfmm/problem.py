@@ -792,10 +792,7 @@ class Problem:
         u = self.utility
         self._send_utility()
         if self._dev_ties:
-            ctx.set_ties(None, None)
-            if "sum2" in self.net:
-                ctx.set_pool_flags(POOL_SUM2, None)
-            self._dev_ties = False
+            self._clear_ties(ctx)
         nu0_given = nu0
         host = self._host
         rank = host.rank if host else 0
@@ -803,8 +800,10 @@ class Problem:
         # takes them on what ALL ranks hold, never on its own shard
         cnt = getattr(self, "_global_counts", None)
         if cnt is None:                               # (the pools of a Problem never change: one collective per Problem, not per solve)
-            cnt = np.array([len(self.net["curve2"]["Ra"]) if "curve2" in self.net else 0,
-                            len(self.net["sum2"]["Ra"]) if "sum2" in self.net else 0], dtype=np.float64)
+            gk = self.net.get("gk", {})
+            cnt = np.array([(len(self.net["curve2"]["Ra"]) if "curve2" in self.net else 0) + sum(b["R"].shape[1] for (kd, _), b in gk.items() if kd == "stable"),
+                            (len(self.net["sum2"]["Ra"]) if "sum2" in self.net else 0) + sum(b["R"].shape[1] for (kd, _), b in gk.items() if kd == "sum")],
+                           dtype=np.float64)
             if host:
                 cnt = host.allreduce_sum(cnt)
             self._global_counts = cnt
@@ -830,7 +829,9 @@ class Problem:
         if general and n_sum:
             raise ValueError("a utility with ULOG / UQUAD entries over a network with constant-sum pools: the kink recovery ties prices, "
                              "the utility table's entries take no ties")
-        can_second = getattr(ctx, "second_order", False) and not self.net.get("gk")      # (K-asset table pools: first-order path only)
+        # (the K-asset table's constant-sum pools are first order only; its stableswap pools enter the second-order path with their exact
+        #  Hessian block: csrc/phik.hpp, gk_newton_kernel)
+        can_second = getattr(ctx, "second_order", False) and not any(kd == "sum" for kd, _ in self.net.get("gk", {}))
         if method not in _lib.METHODS:
             raise ValueError(f"method {method!r}: expected one of {sorted(_lib.METHODS)}")
         # auto: many stableswap pools -> second order straight away (first order needs thousands of evaluations there);
@@ -846,8 +847,7 @@ class Problem:
             if method == "auto" and can_second and st["status"] != 1:
                 second_order = True
                 if self._dev_ties:
-                    ctx.set_ties(None, None); ctx.set_pool_flags(POOL_SUM2, None)
-                    self._dev_ties = False
+                    self._clear_ties(ctx)
                 self._theta = {}
         if second_order:
             # warm start after a second-order solve on this context: nu0 = NULL tells the library to continue from its
@@ -866,12 +866,22 @@ class Problem:
         total["wall_seconds"] += st["wall_seconds"]; total["device_seconds"] += st["device_seconds"]
         return st
 
+    def _clear_ties(self, ctx):
+        ctx.set_ties(None, None)
+        if "sum2" in self.net:
+            ctx.set_pool_flags(POOL_SUM2, None)
+        for (kd, k) in self.net.get("gk", {}):
+            if kd == "sum" and hasattr(ctx, "set_pool_flagsG"):
+                ctx.set_pool_flagsG(k, None)
+        self._dev_ties = False
+
     def _kink_candidates(self, nu, kink_tol, banned, tied, loose=False):
-        """constant-sum pools whose price ratio sits on one of their two kinks
-        (log nu_a - log nu_b = +-log gamma): nearest kink, within kink_tol and well inside its half
+        """constant-sum pools whose price ratio sits on one of their kinks: nearest kink, within kink_tol and well inside its half
         (`loose`: anywhere within kink_tol of it -- a guess for a leg that would not converge; see _solve_kinks).
-        Returns {(rank, i): record}: the pool's data travels with its key, so that every rank of a pool-sharded
-        solve can build the same ties and the same fill recovery from the union of all ranks' candidates."""
+        Two-asset pools: log nu_a - log nu_b = +-log gamma.  Pools of the K-asset table (arbitrage.py:73-74 over k > 2 tokens): with `lo`
+        the pool's cheapest token, leg j is partially drained where gamma nu_j = nu_lo -- the same record with a = lo, b = j, tender a.
+        Returns {(rank, k, pool, leg): record} (k = 2, leg = 0: the two-asset bucket): the pool's data travels with its key, so that
+        every rank of a pool-sharded solve can build the same ties and the same fill recovery from the union of all ranks' candidates."""
         rank = self._host.rank if self._host else 0
         out = {}
         if "sum2" in self.net:
@@ -883,10 +893,27 @@ class Problem:
             near = (dist < kink_tol) & ((dist < 0.5 * np.abs(lg)) | (lg == 0.0) | loose)
             for i in np.flatnonzero(near):               # (only the pools on a kink: the scan itself is vectorised)
                 i = int(i)
-                key = (rank, i)
+                key = (rank, 2, i, 0)
                 if key not in tied and (key, int(sgn[i])) not in banned:
                     out[key] = dict(sgn=int(sgn[i]), ia=int(b["ia"][i]), ib=int(b["ib"][i]), fee=float(b["fee"][i]),
                                     Ra=float(b["Ra"][i]), Rb=float(b["Rb"][i]), loose=bool(loose))
+        for (kd, k), b in self.net.get("gk", {}).items():
+            if kd != "sum":
+                continue
+            lnu = np.log(nu[b["idx"]])                   # [k][m]
+            lo = np.argmin(lnu, axis=0)
+            m = lnu.shape[1]
+            lg = np.log(b["fee"])
+            r = lnu[lo, np.arange(m)][None, :] - lnu     # log nu_lo - log nu_j  (<= 0)
+            dist = np.abs(r - lg[None, :])
+            near = (dist < kink_tol) & ((dist < 0.5 * np.abs(lg)[None, :]) | (lg == 0.0)[None, :] | loose)
+            near[lo, np.arange(m)] = False
+            for j, i in zip(*np.nonzero(near)):
+                i, j = int(i), int(j)
+                key = (rank, k, i, j)
+                if key not in tied and (key, 1) not in banned:
+                    out[key] = dict(sgn=1, ia=int(b["idx"][lo[i], i]), ib=int(b["idx"][j, i]), fee=float(b["fee"][i]),
+                                    Ra=float(b["R"][lo[i], i]), Rb=float(b["R"][j, i]), loose=bool(loose), leg_lo=int(lo[i]))
         if self._host:                                   # the union over ranks, identical everywhere
             merged = {}
             for part in self._host.allgather(out):
@@ -900,9 +927,11 @@ class Problem:
         prices of every pool found on a kink (a linear equality in log-price) and skip it in the
         kernels; once the (now smooth) reduced dual has converged recover the fill fractions;
         release ties whose fill leaves (0,1).  Pool-sharded: every decision below is a function of the
-        all-reduced prices / psi and of the all-gathered candidates, hence identical on every rank."""
+        all-reduced prices / psi and of the all-gathered candidates, hence identical on every rank.
+        Round 5: the K-asset table's constant-sum pools take part leg by leg (a tied LEG is left out of the evaluation)."""
         rank = self._host.rank if self._host else 0
         m2 = len(self.net["sum2"]["Ra"]) if "sum2" in self.net else 0
+        gks = {k: b["R"].shape for (kd, k), b in self.net.get("gk", {}).items() if kd == "sum"}
         tied, banned = {}, set()
         # legs: short on small networks (a solve stuck on a kink gains nothing from more evaluations: the reference's own
         # instances spent 300 of their 315 evaluations that way), longer where an evaluation covers many pools
@@ -914,10 +943,14 @@ class Problem:
                 break
             ties = _Ties(self.n)
             flags = np.zeros(m2, dtype=np.int32)
+            flagsg = {k: np.zeros(shp, dtype=np.int32) for k, shp in gks.items()}
             for key, rec in list(tied.items()):
                 if ties.tie(rec["ia"], rec["ib"], rec["sgn"] * np.log(rec["fee"])):
                     if key[0] == rank:
-                        flags[key[1]] = 1
+                        if key[1] == 2:
+                            flags[key[2]] = 1
+                        else:
+                            flagsg[key[1]][key[3], key[2]] = 1
                 else:
                     del tied[key]; banned.add((key, rec["sgn"]))
             self._dev_ties = True
@@ -926,11 +959,15 @@ class Problem:
                 ctx.set_ties(grp, off)
                 if m2:
                     ctx.set_pool_flags(POOL_SUM2, flags)
+                for k, f in flagsg.items():
+                    ctx.set_pool_flagsG(k, f)
                 st = self._run(ctx, nu, total, tol=0.01 * tol, pg_rule=1, **dict(kw, max_evals=budget))
             else:
                 ctx.set_ties(None, None)
                 if m2:
                     ctx.set_pool_flags(POOL_SUM2, None)
+                for k in flagsg:
+                    ctx.set_pool_flagsG(k, None)
                 st = self._run(ctx, nu, total, tol=tol, **dict(kw, max_evals=budget))
             nu, psi = ctx.get_solution()
             if st["status"] == 1:
@@ -947,7 +984,7 @@ class Problem:
                         banned.add((k, rec["sgn"]))
                         # a guessed kink that carries no trade: the pool's fee band is narrower than the leg could
                         # resolve and the optimum sits on its OTHER kink (arbitrage.py / liquidation.py: fee 0.999)
-                        if rec.get("loose") and theta[k] <= 1e-9 and (k, -rec["sgn"]) not in banned:
+                        if k[1] == 2 and rec.get("loose") and theta[k] <= 1e-9 and (k, -rec["sgn"]) not in banned:
                             tied[k] = dict(rec, sgn=-rec["sgn"], loose=False)
                     tied = dict(sorted(tied.items()))
                     continue
@@ -1090,15 +1127,20 @@ class Problem:
                 tr[k] = ctx.get_tradesN(k, b["R"].shape[1])
             for (kind, k), b in self.net.get("gk", {}).items():
                 tr[(kind, k)] = ctx.get_tradesG(_lib.POOLK[kind], k, b["R"].shape[1])
-            if self._theta and "sum2" in tr:
-                d, l = tr["sum2"]
+            if self._theta:
                 rank = self._host.rank if self._host else 0
-                for (r, i), (rec, th) in self._theta.items():
+                for (r, k, i, j), (rec, th) in self._theta.items():
                     if r != rank:                      # (another rank's pool: its tenders are read back there)
                         continue
                     full = self._fill_vector(rec)
-                    y = th * np.array([full[rec["ia"]], full[rec["ib"]]])
-                    d[:, i] = np.maximum(-y, 0.0); l[:, i] = np.maximum(y, 0.0)
+                    if k == 2 and "sum2" in tr:
+                        d, l = tr["sum2"]
+                        y = th * np.array([full[rec["ia"]], full[rec["ib"]]])
+                        d[:, i] = np.maximum(-y, 0.0); l[:, i] = np.maximum(y, 0.0)
+                    elif ("sum", k) in tr:             # a tied LEG of a K-asset pool: theta R_j received, paid for by the pool's cheapest token
+                        d, l = tr[("sum", k)]
+                        l[j, i] += th * rec["Rb"]
+                        d[rec["leg_lo"], i] += th * rec["Rb"] / rec["fee"]
             self._trade_cache = tr
         return self._trade_cache
 

@@ -94,6 +94,7 @@ struct PoolStore {
     void *bgmem[CFMM_POOLK_KINDS][CFMM_MAX_POOL_SIZE + 1] = {};
     double mxr2[CFMM_POOL_KINDS2] = {}, mnf2[CFMM_POOL_KINDS2] = {1.0, 1.0, 1.0, 1.0};       // largest reserve / smallest fee per bucket
     double mxrn[CFMM_MAX_POOL_SIZE + 1] = {}, mnfn[CFMM_MAX_POOL_SIZE + 1] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+    double mxrg[CFMM_POOLK_KINDS][CFMM_MAX_POOL_SIZE + 1] = {}, mnfg[CFMM_POOLK_KINDS][CFMM_MAX_POOL_SIZE + 1] = {};      // (the table's buckets; mnfg is set with the bucket)
     // token-block ordering still to be done (reorder.hpp): the arena's column bytes, 0 = nothing pending.  Done lazily, in
     // front of the first kernel that reads the pools, so that the uploads' copies are not queued behind sort kernels
     size_t ro2[CFMM_POOL_KINDS2] = {}, ron[CFMM_MAX_POOL_SIZE + 1] = {};
@@ -122,6 +123,7 @@ struct cfmm_ctx {
     // pools (shared with clones); the tied-pool flags of the constant-sum bucket are per context
     std::shared_ptr<PoolStore> pools = std::make_shared<PoolStore>();
     int *flags2 = nullptr;
+    int *flagsG[CFMM_MAX_POOL_SIZE + 1] = {};      // per-leg tie flags of the table's constant-sum buckets (cfmm_set_pool_flagsG), pool-major
     double *trade_buf = nullptr;       // grow-only scratch for cfmm_get_trades* (delta | lambda)
     size_t trade_cap = 0;
 
@@ -657,6 +659,8 @@ void local_extrema(cfmm_ctx *ctx)
     ctx->max_reserve = 0.0; ctx->min_fee = 1.0;
     for (int k = 0; k < CFMM_POOL_KINDS2; ++k) if (ctx->pools->b2[k].m) { ctx->max_reserve = std::max(ctx->max_reserve, ctx->pools->mxr2[k]); ctx->min_fee = std::min(ctx->min_fee, ctx->pools->mnf2[k]); }
     for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) if (ctx->pools->bn[k].m) { ctx->max_reserve = std::max(ctx->max_reserve, ctx->pools->mxrn[k]); ctx->min_fee = std::min(ctx->min_fee, ctx->pools->mnfn[k]); }
+    for (int q = 0; q < CFMM_POOLK_KINDS; ++q) for (int k = 2; k <= CFMM_MAX_POOL_SIZE; ++k)
+        if (ctx->pools->bg[q][k].m) { ctx->max_reserve = std::max(ctx->max_reserve, ctx->pools->mxrg[q][k]); ctx->min_fee = std::min(ctx->min_fee, ctx->pools->mnfg[q][k]); }
     ctx->g_max_reserve = ctx->max_reserve;
 }
 
@@ -831,28 +835,53 @@ int64_t table_pools(const cfmm_ctx *ctx)
     for (auto &row : ctx->pools->bg) for (auto &b : row) m += b.m;
     return m;
 }
+// ... of which the constant-sum entry's (piecewise linear: the second-order path has no smoothing for them; the stableswap entry enters it
+// unsmoothed with its exact Hessian block: gk_newton_kernel)
+int64_t table_sum_pools(const cfmm_ctx *ctx)
+{
+    int64_t m = 0;
+    for (auto &b : ctx->pools->bg[CFMM_POOLK_SUM]) m += b.m;
+    return m;
+}
 // both read the prices (and the stop flag) the evaluation / iteration launch in front of them has left in `nu`
 int64_t extra_launch_pools(const cfmm_ctx *ctx) { return heavy_pools(ctx) + table_pools(ctx); }
 
-template <int KIND, bool WITH_D>
-void launch_table_kind(cfmm_ctx *ctx, int k, const BucketG &b, const double *nu, double *acc)
+// psi, sum arb (and the metric) of every bucket of the K-asset table: ONE launch of table_eval_kernel (phik.hpp: wave-tiles, leg per
+// lane, LDS psi tile) behind the main evaluation, flushed into the accumulator slices at `acc` (reproducible mode: into the limbs)
+TableArgs make_table_args(cfmm_ctx *ctx, const double *nu, double *acc)
 {
-    const int n = ctx->n;
-    const dim3 grid((unsigned)((b.m + GK_THREADS - 1) / GK_THREADS)), blk(GK_THREADS);
-    switch (k) {
-#define GK_CASE(KK) case KK: hipLaunchKernelGGL((evalg_kernel<KIND, KK, WITH_D>), grid, blk, 0, ctx->stream, b, n, nu, acc, acc_arb(n), acc_diag(n)); break;
-    GK_CASE(2) GK_CASE(3) GK_CASE(4) GK_CASE(5) GK_CASE(6) GK_CASE(7) default: GK_CASE(8)
-#undef GK_CASE
-    }
+    TableArgs a = {};
+    long long tiles = 0;
+    for (int q = 0; q < 2; ++q)
+        for (int k = 2; k <= CFMM_MAX_POOL_SIZE; ++k) {
+            const BucketG &b = ctx->pools->bg[q == 0 ? CFMM_POOLK_STABLE : CFMM_POOLK_SUM][k];
+            (q == 0 ? a.bs : a.bq)[k - 2] = b;
+            if (q == 1) a.qflags[k - 2] = ctx->flagsG[k];
+            const int P = 64 / k;
+            tiles += (b.m + P - 1) / P;
+            a.tile_end[7 * q + k - 2] = (int)tiles;
+        }
+    a.ntiles = (int)tiles; a.n = ctx->n; a.nslices = ctx->nslices;
+    static const bool warm_off = getenv("CFMM_TABLE_WARM") && atoi(getenv("CFMM_TABLE_WARM")) == 0;      // (A/B)
+    a.warm = (ctx->det || warm_off) ? 0 : 1;
+    a.nu = nu; a.acc = acc; a.acc_l = ctx->acc_l;
+    det_scales(ctx, a.det_scale, a.det_scale_d);
+    static const double ftol = getenv("CFMM_TABLE_FTOL") ? atof(getenv("CFMM_TABLE_FTOL")) : 1e-9;       // (A/B)
+    a.ftol = ftol;
+    return a;
 }
-// psi, sum arb (and the metric) of every table bucket, added into accumulator slice 0 at `acc`
 template <bool WITH_D>
 void launch_table_evals(cfmm_ctx *ctx, const double *nu, double *acc)
 {
-    for (int k = 2; k <= CFMM_MAX_POOL_SIZE; ++k) {
-        if (ctx->pools->bg[CFMM_POOLK_STABLE][k].m) launch_table_kind<CFMM_POOLK_STABLE, WITH_D>(ctx, k, ctx->pools->bg[CFMM_POOLK_STABLE][k], nu, acc);
-        if (ctx->pools->bg[CFMM_POOLK_SUM][k].m) launch_table_kind<CFMM_POOLK_SUM, WITH_D>(ctx, k, ctx->pools->bg[CFMM_POOLK_SUM][k], nu, acc);
-    }
+    const TableArgs a = make_table_args(ctx, nu, acc);
+    if (a.ntiles == 0) return;
+    const int waves = std::min(GT_THREADS / 64, a.ntiles);
+    int grid = (a.ntiles + waves - 1) / waves;
+    static const int gmult = getenv("CFMM_TABLE_GRID_MULT") ? std::max(1, atoi(getenv("CFMM_TABLE_GRID_MULT"))) : 1;      // (A/B)
+    grid = std::min(grid, gmult * ctx->cus);
+    const size_t lds = table_lds_bytes(ctx->n, WITH_D, ctx->det, waves);
+    if (ctx->det) hipLaunchKernelGGL((table_eval_kernel<WITH_D, true>), dim3(grid), dim3(64 * waves), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((table_eval_kernel<WITH_D, false>), dim3(grid), dim3(64 * waves), lds, ctx->stream, a);
 }
 
 // one dual evaluation of every bucket: one launch, plus one for the heavy buckets (stableswap, generic) when there are any
@@ -919,6 +948,8 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, update_gram_kernel<512, 2, true>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, start_kernel<true>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, eval_batch_kernel, batch_lds_bytes(ctx->n, batch_capacity(ctx->n))))) return rc;
+    if ((rc = set_lds_attr(ctx, table_eval_kernel<false, false>, table_lds_bytes(ctx->n, false, false, GT_THREADS / 64)))) return rc;
+    if ((rc = set_lds_attr(ctx, table_eval_kernel<true, false>, table_lds_bytes(ctx->n, true, false, GT_THREADS / 64)))) return rc;
     if (ctx->n <= TINY_N && (rc = set_lds_attr(ctx, solve_tiny_kernel<false>, (size_t)tiny_lds_doubles(ctx->n) * sizeof(double)))) return rc;
     if (ctx->n <= TINY_N && (rc = set_lds_attr(ctx, solve_tiny_kernel<true>, (size_t)tiny_lds_doubles(ctx->n) * sizeof(double)))) return rc;
     const size_t il = iter_lds_bytes(ctx->n);
@@ -942,6 +973,8 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
         if ((rc = set_lds_attr(ctx, eval_kernel<true, false, true>, eval_lds_bytes(ctx->n, true, true)))) return rc;
         if ((rc = set_lds_attr(ctx, eval_kernel<false, true, true>, eval_lds_bytes(ctx->n, false, true)))) return rc;
         if ((rc = set_lds_attr(ctx, eval_kernel<true, true, true>, eval_lds_bytes(ctx->n, true, true)))) return rc;
+        if ((rc = set_lds_attr(ctx, table_eval_kernel<false, true>, table_lds_bytes(ctx->n, false, true, GT_THREADS / 64)))) return rc;
+        if ((rc = set_lds_attr(ctx, table_eval_kernel<true, true>, table_lds_bytes(ctx->n, true, true, GT_THREADS / 64)))) return rc;
         const size_t ild = iter_lds_bytes(ctx->n, true);
         if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, true, false>, ild))) return rc;
         if ((rc = set_lds_attr(ctx, iter_kernel<ITER_E_SMALL, true, true>, ild))) return rc;
@@ -1265,7 +1298,7 @@ bool newton_supported(cfmm_ctx *ctx, const char **why)
 {
     if (ctx->ng != ctx->n) { *why = "price ties are set"; return false; }
     // (pool-sharded: the GLOBAL count, refresh_global_counts -- every rank must take the same branch)
-    if (table_pools(ctx) > 0 || (sharded(ctx) && ctx->g_counts_valid && ctx->g_table > 0)) { *why = "the network holds K-asset table pools (phik.hpp): first-order path only"; return false; }
+    if (table_sum_pools(ctx) > 0 || (sharded(ctx) && ctx->g_counts_valid && ctx->g_table > 0)) { *why = "the network holds constant-sum pools of the K-asset table (phik.hpp): first-order path only"; return false; }
     // (the Hessian instantiation of smooth_kernel carries the diagonal / pair cache on top of the psi tile: 24 n + 24832 bytes,
     //  i.e. 5792 tokens -- not the (2 n + 32) doubles of the round-2 kernel, which let 5.8k .. 10.2k tokens through to a launch
     //  failure)
@@ -1288,7 +1321,7 @@ int refresh_global_counts(cfmm_ctx *ctx)
     if (sharded(ctx) && ctx->g_counts_valid) return CFMM_OK;
     ctx->g_total = cfmm_pool_count(ctx);
     ctx->g_stable = ctx->pools->b2[CFMM_POOL_CURVE2].m;
-    ctx->g_table = table_pools(ctx);
+    ctx->g_table = table_sum_pools(ctx);       // (what the second-order path refuses: the method choice must agree across ranks)
     local_extrema(ctx);
     if (!sharded(ctx)) return CFMM_OK;
     if (ctx->det) {                                  // the fixed-point exponent must be the same on every rank: global maxima
@@ -1443,6 +1476,17 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm, bool with_slo,
         case 6: GN_LAUNCH(6); break; case 7: GN_LAUNCH(7); break; default: GN_LAUNCH(8); break;
         }
 #undef GN_LAUNCH
+    }
+    // the K-asset table's stableswap pools likewise (phik.hpp: gk_newton_kernel)
+    for (int k = 2; k <= CFMM_MAX_POOL_SIZE; ++k) {
+        const BucketG &bg = ctx->pools->bg[CFMM_POOLK_STABLE][k];
+        if (!bg.m) continue;
+        const dim3 g2((unsigned)std::min<long long>((bg.m + 255) / 256, 8LL * ctx->cus)), blk(256);
+        const double *nup = ctx->nu;
+#define GK_LAUNCH(KK) case KK: if (hess) hipLaunchKernelGGL((gk_newton_kernel<KK, true>), g2, blk, 0, ctx->stream, bg, nup, a.slo, ctx->sm_out, n, ctx->H, a.ldh); \
+                           else hipLaunchKernelGGL((gk_newton_kernel<KK, false>), g2, blk, 0, ctx->stream, bg, nup, a.slo, ctx->sm_out, n, (double *)nullptr, a.ldh); break;
+        switch (k) { GK_LAUNCH(2) GK_LAUNCH(3) GK_LAUNCH(4) GK_LAUNCH(5) GK_LAUNCH(6) GK_LAUNCH(7) default: GK_LAUNCH(8) }
+#undef GK_LAUNCH
     }
     HIP_TRY(ctx, hipGetLastError());
     if (sharded(ctx)) {                     // pool-sharded: every rank needs the whole [psi | value | trade] and the whole Hessian
@@ -1800,7 +1844,10 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             if ((rc = smooth_eval_host(ctx, nu2, mu, with_h, e2, true, slo2_on ? &slo2 : nullptr))) return rc;
             ++evals;
             const double g2 = assemble(nu2, e2, mu, nullptr, nullptr);
-            if (g2 <= gmu + o.armijo * gd || dec <= 1e-13 * std::fabs(gmu)) {
+            // (the value carries a few units of rounding of its own -- fp64 atomics over tens of thousands of pools: at the final weight the
+            //  required decrease armijo * gd falls BELOW one ulp of g_mu, and whether the full Newton step passed was decided by summation
+            //  noise: the same state took t = 1 and converged in one run and backed off to t = 1/16 and stalled in the next; round 5)
+            if (g2 <= gmu + o.armijo * gd + 2e-15 * std::fabs(gmu) || dec <= 1e-13 * std::fabs(gmu)) {
                 moved = true;
                 have_e = stay && (with_h || next_chord);           // reusable where the weight stays: with its Hessian, or for a chord step
                 e_has_h = with_h;
@@ -2052,6 +2099,7 @@ int cfmm_destroy(cfmm_ctx *ctx)
     if (ctx->os_mail) (void)hipFree(ctx->os_mail);
     ctx->pools.reset();
     if (ctx->flags2) (void)hipFree(ctx->flags2);
+    for (int *q : ctx->flagsG) if (q) (void)hipFree(q);
     if (ctx->trade_buf) (void)hipFree(ctx->trade_buf);
     for (void *p : {(void *)ctx->sm_out, (void *)ctx->sm_vec, (void *)ctx->H, (void *)ctx->Dinv, (void *)ctx->Winv, (void *)ctx->Rinv, (void *)ctx->chord_y, (void *)ctx->sm_ws[0], (void *)ctx->sm_ws[1], (void *)ctx->sm_ws[3], (void *)ctx->sm_ws[4], (void *)ctx->sm_slo, (void *)ctx->sm_mask, (void *)ctx->sm_info}) if (p) (void)hipFree(p);
     if (ctx->dev_arena) (void)hipFree(ctx->dev_arena);
@@ -2101,7 +2149,7 @@ int64_t cfmm_eval_bytes(cfmm_ctx *ctx)
     for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) bytes += ctx->pools->bn[k].m * (20 + (lrw ? 28 : 20) * k);
     for (auto &row : ctx->pools->bg) {                  // the K-asset table's buckets: ids and reserves per leg, fee (and parameter) per pool
         int k = 0;
-        for (auto &b : row) { bytes += b.m * (12 * k + 8 + (b.param ? 8 : 0)); ++k; }
+        for (auto &b : row) { bytes += b.m * (12 * k + (b.param ? 40 : 16)); ++k; }      // per pool: 1 / fee | alpha, s_R, warm start read and written  /  fee, 1 / fee
     }
     return bytes;
 }
@@ -2405,7 +2453,6 @@ int cfmm_upload_poolsG(cfmm_ctx *ctx, int kind, int k, int64_t m, const int32_t 
     if (m > 0 && (!idx || !R || !fee)) return fail(ctx, CFMM_E_ARG, "upload_poolsG: null column");
     if (m > 0 && kind == CFMM_POOLK_STABLE && !param) return fail(ctx, CFMM_E_ARG, "upload_poolsG: stableswap pools need param = alpha");
     if (m > (1ll << 26)) return fail(ctx, CFMM_E_LIMIT, "upload_poolsG: a bucket holds < 2^26 pools");
-    if (ctx->det) return fail(ctx, CFMM_E_UNSUPPORTED, "upload_poolsG: K-asset table pools are not available in the reproducible mode");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // (as the two sibling uploaders: a clone may be reading the arena on another stream, or hold captured launches that point into it)
     if (ctx->pools.use_count() > 1) return fail(ctx, CFMM_E_STATE, "upload_poolsG: the pools are shared with a clone (cfmm_clone); destroy the clones first");
@@ -2421,6 +2468,10 @@ int cfmm_upload_poolsG(cfmm_ctx *ctx, int kind, int k, int64_t m, const int32_t 
         cols.push_back(transposed_col<double>(R, k, m, (void **)&b.R, &scan, true, [](double x) { return x > 0.0 && x <= std::numeric_limits<double>::max(); }));
         cols.push_back(checked_col<double>(fee, m, (void **)&b.fee, &scan, 1, [](double x) { return x > 0.0 && x <= 1.0; }));
         if (param) cols.push_back(checked_col<double>(param, m, (void **)&b.param, &scan, 2, [](double x) { return x > 0.0 && x <= std::numeric_limits<double>::max(); }));
+        // derived columns, reserved here and filled on the device behind the copies (phik.hpp: gk_derive_kernel): 1 / fee, the coupling
+        // at the pool's own reserves, the evaluation tiles' warm start
+        double *d_ifee = nullptr, *d_sR = nullptr, *d_ws = nullptr;
+        for (double **dst : {&d_ifee, &d_sR, &d_ws}) { Col c; c.bytes = m * sizeof(double); c.dst = (void **)dst; cols.push_back(c); }
         int rc = upload_arena(ctx, cols, &arena, &scan);
         if (rc == CFMM_E_ARG && scan.bad.load()) {
             for (int64_t i = 0; i < (int64_t)k * m; ++i) {
@@ -2434,9 +2485,14 @@ int cfmm_upload_poolsG(cfmm_ctx *ctx, int kind, int k, int64_t m, const int32_t 
             return fail(ctx, CFMM_E_ARG, "upload_poolsG: a column failed its checks");
         }
         if (rc) return rc;
+        b.ifee = d_ifee; b.sR = d_sR; b.ws = d_ws;
+        hipLaunchKernelGGL(gk_derive_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, b, k, d_ifee, d_sR, d_ws);
+        HIP_TRY(ctx, hipGetLastError());
     }
     if (ctx->pools->bgmem[kind][k]) (void)hipFree(ctx->pools->bgmem[kind][k]);
+    if (kind == CFMM_POOLK_SUM && ctx->flagsG[k]) { (void)hipFree(ctx->flagsG[k]); ctx->flagsG[k] = nullptr; }
     ctx->pools->bgmem[kind][k] = arena;
+    ctx->pools->mxrg[kind][k] = scan.mxr; ctx->pools->mnfg[kind][k] = scan.mnf;
     ctx->pools->bg[kind][k] = b;
     pools_changed(ctx);
     return CFMM_OK;
@@ -2453,14 +2509,12 @@ int cfmm_get_tradesG(cfmm_ctx *ctx, int kind, int k, double *delta, double *lamb
     { int rc = trade_scratch(ctx, cnt, &dd, &dl); if (rc) return rc; }
     const dim3 grid((unsigned)((b.m + GK_THREADS - 1) / GK_THREADS)), blk(GK_THREADS);
     const double *nu = ctx->nu_acc;
-#define GK_T(KIND_) switch (k) { case 2: hipLaunchKernelGGL((tradesg_kernel<KIND_, 2>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; \
-                                 case 3: hipLaunchKernelGGL((tradesg_kernel<KIND_, 3>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; \
-                                 case 4: hipLaunchKernelGGL((tradesg_kernel<KIND_, 4>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; \
-                                 case 5: hipLaunchKernelGGL((tradesg_kernel<KIND_, 5>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; \
-                                 case 6: hipLaunchKernelGGL((tradesg_kernel<KIND_, 6>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; \
-                                 case 7: hipLaunchKernelGGL((tradesg_kernel<KIND_, 7>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; \
-                                 default: hipLaunchKernelGGL((tradesg_kernel<KIND_, 8>), grid, blk, 0, ctx->stream, b, nu, dd, dl); break; }
+    const int *fl = kind == CFMM_POOLK_SUM ? ctx->flagsG[k] : nullptr;
+    const double *slo = (ctx->mu_last > 0.0 && ctx->slo_active) ? ctx->sm_slo : nullptr;       // (as cfmm_get_tradesN)
+#define GK_T1(KIND_, KK) case KK: hipLaunchKernelGGL((tradesg_kernel<KIND_, KK>), grid, blk, 0, ctx->stream, b, fl, nu, slo, dd, dl); break;
+#define GK_T(KIND_) switch (k) { GK_T1(KIND_, 2) GK_T1(KIND_, 3) GK_T1(KIND_, 4) GK_T1(KIND_, 5) GK_T1(KIND_, 6) GK_T1(KIND_, 7) default: hipLaunchKernelGGL((tradesg_kernel<KIND_, 8>), grid, blk, 0, ctx->stream, b, fl, nu, slo, dd, dl); break; }
     if (kind == CFMM_POOLK_STABLE) { GK_T(CFMM_POOLK_STABLE) } else { GK_T(CFMM_POOLK_SUM) }
+#undef GK_T1
 #undef GK_T
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, CFMM_E_HIP, "get_tradesG -> %s", hipGetErrorString(e));
@@ -2483,6 +2537,25 @@ int cfmm_set_pool_flags(cfmm_ctx *ctx, int kind, const int32_t *flags)
     int rc = dev_upload<int>(ctx, &ctx->flags2, flags, b.m, nullptr);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CFMM_OK;
+}
+
+// per-leg tie flags of a constant-sum bucket of the K-asset table, slot-major [k][m] like the bucket's columns (NULL: none): a
+// flagged leg is left out of the evaluation and of the tenders -- the caller's active-set loop holds gamma nu_j = nu_cheapest with a
+// price tie (cfmm_set_ties) and adds the leg's partial fill itself (arbitrage.py:73-74 over more than two tokens)
+int cfmm_set_pool_flagsG(cfmm_ctx *ctx, int k, const int32_t *flags)
+{
+    if (!ctx || k < 2 || k > CFMM_MAX_POOL_SIZE) return ctx ? fail(ctx, CFMM_E_ARG, "set_pool_flagsG: %d assets", k) : CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const BucketG &b = ctx->pools->bg[CFMM_POOLK_SUM][k];
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->flagsG[k]) { (void)hipFree(ctx->flagsG[k]); ctx->flagsG[k] = nullptr; }
+    ctx->g_valid = false;
+    if (!flags || b.m == 0) return CFMM_OK;
+    std::vector<int> pm((size_t)k * b.m);
+    for (int64_t i = 0; i < b.m; ++i) for (int j = 0; j < k; ++j) pm[(size_t)i * k + j] = flags[(size_t)j * b.m + i];
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->flagsG[k], pm.size() * sizeof(int) + 16));
+    HIP_TRY(ctx, hipMemcpy(ctx->flagsG[k], pm.data(), pm.size() * sizeof(int), hipMemcpyHostToDevice));
     return CFMM_OK;
 }
 
@@ -3738,7 +3811,6 @@ int cfmm_set_deterministic(cfmm_ctx *ctx, int on)
     if (!ctx) return CFMM_E_ARG;
     if (on && eval_lds_bytes(ctx->n, true, true) > 160 * 1024)
         return fail(ctx, CFMM_E_LIMIT, "set_deterministic: %d tokens exceed the LDS tile of the reproducible mode (7 n doubles)", ctx->n);
-    if (on && table_pools(ctx) > 0) return fail(ctx, CFMM_E_UNSUPPORTED, "set_deterministic: K-asset table pools accumulate psi with fp64 atomics");
     if ((on != 0) != ctx->det) { ctx->g_valid = false; ctx->g_counts_valid = false; }
     ctx->det = on != 0;
     return CFMM_OK;
@@ -3854,6 +3926,7 @@ int cfmm_selftest(cfmm_ctx *ctx)
     hipLaunchKernelGGL(selftest_gram_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
     hipLaunchKernelGGL(selftest_log_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
     hipLaunchKernelGGL(selftest_generic_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
+    hipLaunchKernelGGL(selftest_table_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
     hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
@@ -3881,9 +3954,14 @@ int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_lau
     HIP_TRY(ctx, hipMemcpyAsync(ctx->nu, ctx->nu_acc, ctx->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->nu + ctx->n, 0, sizeof(double), ctx->stream));
     const int only = kind == CFMM_TIME_ALL ? 0x7fffffff : kind;
+    const bool table_only = kind == CFMM_TIME_TABLE;           // the K-asset table's launch alone (table_eval_kernel)
     const EvalArgs ea = make_eval_args(ctx, false, only), es = make_eval_args(ctx, true, only);
-    if (ea.ntiles + es.ntiles == 0) return fail(ctx, CFMM_E_ARG, "time_eval_kernel: bucket %d is empty", kind);
-    auto launch = [&]() { launch_eval<false, false>(ctx, ea); launch_eval<false, true>(ctx, es); };
+    if (table_only ? table_pools(ctx) == 0 : ea.ntiles + es.ntiles == 0) return fail(ctx, CFMM_E_ARG, "time_eval_kernel: bucket %d is empty", kind);
+    auto launch = [&]() {
+        if (table_only) { launch_table_evals<false>(ctx, ctx->nu, ctx->acc); return; }
+        launch_eval<false, false>(ctx, ea); launch_eval<false, true>(ctx, es);
+        if (kind == CFMM_TIME_ALL && table_pools(ctx) > 0) launch_table_evals<false>(ctx, ctx->nu, ctx->acc);
+    };
     for (int i = 0; i < 3; ++i) launch();
     HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
     for (int i = 0; i < reps; ++i) launch();

@@ -72,7 +72,8 @@ enum {
 
 /* K-asset trading functions OTHER than the weighted geometric mean: the K-asset table (csrc/phik.hpp: one PhiK<KIND> struct per
  * function -- SURVEY 8(f) rank 4; "a pool is whatever constraint line is written", arbitrage.py:63-74), 3..8 assets, one
- * bucket per (kind, size).  First-order path only: a network that holds such pools is refused by CFMM_METHOD_NEWTON. */
+ * bucket per (kind, size).  Evaluated as wave-tiles (leg per lane, LDS psi tile) in one launch behind the main evaluation; the
+ * stableswap entry enters the second-order path with its exact generalised Hessian block, the constant-sum entry is first order. */
 enum {
     CFMM_POOLK_STABLE = 0,  /* n-asset stableswap  sum x - alpha / prod x  (the paper's concave form; 2 assets: CFMM_POOL_CURVE2);
                                param = alpha.  Solved by the table's generic two-level search (no closed form)              */
@@ -158,6 +159,11 @@ int cfmm_upload_poolsG(cfmm_ctx *ctx, int kind, int k, int64_t m, const int32_t 
 /* constant-sum pools sitting on their kink are `tied` (flag 1): they are skipped by the
  * kernels and their fill fraction is assigned by the host's primal recovery */
 int cfmm_set_pool_flags(cfmm_ctx *ctx, int kind, const int32_t *flags /* [m] or NULL */);
+/* the same for the K-asset table's constant-sum bucket of k tokens, per LEG (slot-major [k][m] like the bucket's columns, or NULL):
+ * a flagged leg j of a pool sits on the kink gamma nu_j = nu_cheapest (arbitrage.py:73-74 over more than two tokens: that token is
+ * partially drained at the optimum); it is left out of the evaluation and the tenders, the caller ties the two prices
+ * (cfmm_set_ties) and adds the partial fill theta R_j itself */
+int cfmm_set_pool_flagsG(cfmm_ctx *ctx, int k, const int32_t *flags);
 
 /* utility: replaces obj + the psi constraints (arbitrage.py:57,77; liquidation.py:57,77-80;
  * two-asset.py:66,86).  ctype NULL = all CFMM_GE, h NULL = 0. */
@@ -270,6 +276,7 @@ void *cfmm_oneshot_mailbox(cfmm_ctx *ctx);
  * launch one dual evaluation makes) or restricted to one bucket (kind = CFMM_POOL_*, or -k for
  * the k-asset bucket); returns the average seconds per launch in *sec_per_launch. */
 #define CFMM_TIME_ALL 100
+#define CFMM_TIME_TABLE 200      /* the K-asset table's own launch alone (every table bucket: table_eval_kernel) */
 int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_launch);
 /* the two pool-sharded pieces of an outer iteration, timed the same way (bench.py's per-iteration split): `reps`
  * back-to-back launches of the accumulator-slice fold, and `reps` back-to-back RCCL all-reduces of [psi | sum arb]

@@ -62,34 +62,114 @@ def test_table_pools_evaluation_tenders_and_invariants(oracle_lib):
             assert (np.abs(l - d).sum(axis=0) > 0).mean() > 0.5
         else:
             assert np.all(x >= -1e-9 * b["R"].max()) and np.abs(x.sum(axis=0) - b["R"].sum(axis=0)).max() <= 1e-9 * b["R"].sum(axis=0).max()
-    with pytest.raises(cfmm.CfmmError, match="first-order path only"):
+    with pytest.raises(cfmm.CfmmError, match="first-order path only"):      # (its constant-sum table pools: the stableswap ones are taken)
         p.solve(method="newton")
     p.close()
 
 
-def test_table_pools_first_order_solve_at_scale(oracle_lib):
+def test_table_pools_solves_at_scale_both_outer_iterations(oracle_lib):
     """1 000 n-asset stableswap pools among 22 000 pools of the reference's kinds: the first-order solve reaches its 1e-6
-    certificates (~540 evaluations: near their peg these pools are almost linear, the regime the second-order path exists
-    for -- which does not take table pools yet), and the evaluation at the prices it ends on is the restatement's.
-    n-asset constant-sum pools in numbers end ON their kinks -- the LP's dual prices settle there -- and such a solve stalls:
-    the host's active-set loop knows two-asset pools only.  1 000 of them: not certified, and reported as such."""
+    certificates (hundreds of evaluations: near their peg these pools are almost linear -- the regime the second-order path exists
+    for), the evaluation at the prices it ends on is the restatement's; and the SAME network through method="newton" -- the table's
+    stableswap pools enter with their exact generalised Hessian block (csrc/phik.hpp: gk_newton_kernel) -- in <= 40 steps to the same optimum.
+    1 000 n-asset constant-sum pools over peg groups end on kinks the host's loop only half knows: reported as not certified."""
     net = synthetic.make_network(200, m_cp2=20000, m_gn=2000, m_gk_stable=1000, seed=3)
     n = net["n_tokens"]
     p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
     o = oracle_lib.Oracle(n, threads=4); o.add_network(net); o.set_utility(net["c"])
-    v = p.solve(tol=1e-6, max_evals=4000)
+    v = p.solve(tol=1e-6, max_evals=4000, method="lbfgs")
     assert p.status == "optimal" and p.stats["method"] == _lib.METHODS["lbfgs"] and p.gap <= 1e-6 and p.infeas <= 1e-6
     nu = p.nu.copy()
     f, psi = p.eval_dual(nu)
     f0, psi0 = o.eval(nu); f1, psi1 = _table_reference(net, nu)
     assert np.abs(psi - (psi0 + psi1)).max() <= 1e-10 * np.abs(psi0 + psi1).max()
     assert abs(float(net["c"] @ (psi0 + psi1)) - v) <= 2e-6 * abs(v)
+    v2 = p.solve(tol=1e-6, method="newton")
+    assert p.status == "optimal" and p.stats["method"] == _lib.METHODS["newton"] and p.stats["newton_steps"] <= 40, (p.status, p.stats)
+    assert p.gap <= 1e-6 and p.infeas <= 1e-6 and abs(v2 - v) <= 2e-6 * abs(v)
+    # tenders of the second-order point add up to its psi, table pools included
+    tot = np.zeros(n)
+    for (kind, k), b in net["gk"].items():
+        d, l = p.bucket_trades((kind, k))
+        np.add.at(tot, b["idx"].ravel(), (l - d).ravel())
+    for key in ("cp2",):
+        d, l = p.bucket_trades(key)
+        np.add.at(tot, net[key]["ia"], l[0] - d[0]); np.add.at(tot, net[key]["ib"], l[1] - d[1])
+    for k, b in net["gn"].items():
+        d, l = p.bucket_trades(k)
+        np.add.at(tot, b["idx"].ravel(), (l - d).ravel())
+    assert np.abs(tot - p.psi).max() <= 1e-8 * np.abs(p.psi).max()
     p.close()
+    # 1 000 n-asset constant-sum pools over peg groups: the LP's dual prices settle on kinks of BOTH kinds -- a partially drained leg
+    # (gamma nu_j = nu_cheapest: handled, see the next test) and two tokens tied for cheapest (the payment splits between them: NOT
+    # handled by the host's loop).  Honest: not certified, and it says so.
     hard = synthetic.make_network(200, m_cp2=20000, m_gk_sum=1000, seed=3)
     q = cfmm.Problem.from_network(hard, utility=cfmm.Arbitrage(hard["c"]))
-    q.solve(tol=1e-6, max_evals=1500)
-    assert q.status != "optimal"                      # honest: not certified, and it says so
+    q.solve(tol=1e-6, max_evals=600, method="lbfgs")
+    assert q.status != "optimal"
     q.close()
+
+
+@pytest.mark.parametrize("j", [0, 5, 10, 13, 25, 49])
+def test_three_asset_constant_sum_pool_on_its_kink(j):
+    """two-asset.py's network with its constant-sum pool (two-asset.py:21-22, 82-83) widened to THREE tokens -- arbitrage.py:73-74 over
+    more than two tokens -- swept like the script: at several t the optimum drains one leg of that pool only PARTIALLY (gamma nu_j =
+    nu_cheapest: a kink of the dual).  The host's active-set loop ties the kinked leg, the device leaves it out (cfmm_set_pool_flagsG),
+    the fill is recovered: value, psi and every pool's tenders against the reference's primal model solved by SLSQP"""
+    from oracle import instances as I
+    from oracle.primal_scipy import solve_primal
+    t = I.two_asset_sweep()[j]
+    inst = dict(I.two_asset(t))
+    for key in ("local_indices", "reserves", "fees", "kinds", "weights"):
+        inst[key] = list(inst[key])
+    k = inst["kinds"].index("sum")
+    inst["local_indices"][k] = [0, 2, 1]
+    inst["reserves"][k] = [10.0, 10.0, 0.5]
+    ref = solve_primal(I.normalise(inst))
+    p = problem_of(inst)
+    v = p.solve(tol=1e-9)
+    assert ("sum", 3) in p.net["gk"]
+    assert p.status == "optimal" and p.gap <= 1e-9 and p.infeas <= 1e-9, (p.status, p.gap, p.infeas, p.stats)
+    if j in (0, 5, 10, 13):                 # these points end with ONE leg of the three-token pool on its kink, partially filled
+        assert len(p._theta) == 1 and next(iter(p._theta))[1] == 3 and 0.0 < next(iter(p._theta.values()))[1] < 1.0
+    assert abs(v - ref["value"]) <= 2e-6 * max(1.0, abs(v)), (v, ref["value"])
+    assert np.abs(p.psi - ref["psi"]).max() <= 1e-4 * max(1.0, np.abs(ref["psi"]).max())
+    for i, (d, l) in enumerate(zip(p.deltas, p.lambdas)):
+        assert np.all(d >= -1e-12) and np.all(l >= -1e-12)
+        assert np.abs((l - d) - ref["y"][i]).max() <= 2e-4 * max(1.0, np.abs(ref["y"][i]).max()), (i, l - d, ref["y"][i])
+    d, l = p.deltas[k], p.lambdas[k]
+    x = np.asarray(inst["reserves"][k]) + inst["fees"][k] * d - l
+    assert np.all(x >= -1e-9) and x.sum() >= sum(inst["reserves"][k]) * (1 - 1e-12)                      # arbitrage.py:73-74
+    p.close()
+
+
+def test_table_pools_in_the_reproducible_mode():
+    """the table's tiles scatter through the same Scatter<DET> as every other bucket: evaluations and solves of a network with
+    table pools are bitwise repeatable, the limbs of 2 and 3 pool shards add up to the unsharded limbs, and the values are the
+    default mode's to rounding (round 4: refused)"""
+    net = synthetic.config("GK", seed=5)
+    n = net["n_tokens"]
+    nu = net["c"] * np.exp(np.random.default_rng(2).normal(0, 0.01, n))
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]), deterministic=True)
+    f0, psi0 = p.eval_dual(nu)
+    for _ in range(4):
+        f, psi = p.eval_dual(nu)
+        assert f == f0 and np.array_equal(psi, psi0)
+    q = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    f1, psi1 = q.eval_dual(nu)
+    assert abs(f0 - f1) <= 1e-11 * abs(f1) and np.abs(psi0 - psi1).max() <= 1e-10 * np.abs(psi1).max()
+    q.close()
+    mr = max(max(b[k].max() for b in (net["cp2"],) for k in ("Ra", "Rb")), max(b["R"].max() for b in net["gn"].values()), max(b["R"].max() for b in net["gk"].values()))
+    mf = min(net["cp2"]["fee"].min(), min(b["fee"].min() for b in net["gn"].values()), min(b["fee"].min() for b in net["gk"].values()))
+    whole = p._ensure_ctx().debug_eval_limbs(nu, mr, mf)
+    p.close()
+    for S in (2, 3):
+        tot = np.zeros_like(whole)
+        for rk in range(S):
+            r = cfmm.Problem.from_network(cfmm.distributed.rank_network(net, rk, S), utility=cfmm.Arbitrage(net["c"]))
+            tot = tot + r._ensure_ctx().debug_eval_limbs(nu, mr, mf)
+            r.close()
+        assert np.array_equal(tot, whole), S
 
 
 def test_table_search_reproduces_the_two_asset_stableswap_bucket():
