@@ -944,6 +944,7 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, start_kernel<false>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_kernel<true>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 8, 2, true>, upd_lds_bytes(ctx->n)))) return rc;
+    if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 8, 2, false, true>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_reg_kernel<512, 4, 4, true>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, update_gram_kernel<512, 2, true>, upd_lds_bytes(ctx->n)))) return rc;
     if ((rc = set_lds_attr(ctx, start_kernel<true>, upd_lds_bytes(ctx->n)))) return rc;
@@ -1105,6 +1106,13 @@ void launch_update(cfmm_ctx *ctx, const UpdArgs &ua)
     const size_t lds = upd_lds_bytes(ctx->ng);
     auto thr = [n](int E) { return 64 * ((n + 64 * E - 1) / (64 * E)); };
     const int ug = ctx->upd_grid;                   // (tuning probe) identical redundant workgroups
+    // utilities with entries of the utility table: the register-resident form with their terms compiled in (<= 1024 tokens: it takes
+    // any memory up to 8, which is what such a solve runs with); beyond, the generic kernel
+    static const bool gen_generic = getenv("CFMM_UTILITY_GENERIC") && atoi(getenv("CFMM_UTILITY_GENERIC")) != 0;       // (A/B)
+    if (ctx->general_utility && !ctx->upd_generic && !gen_generic && n <= 1024 && ctx->ng == ctx->n) {
+        hipLaunchKernelGGL((update_reg_kernel<512, 8, 2, false, true>), dim3(1), dim3(thr(2)), lds, ctx->stream, ua);
+        return;
+    }
     const int v = (ctx->upd_generic || ctx->general_utility) ? 9 : ctx->upd_variant;
     // Gram form (two-loop recursion on scalars after ONE batched reduction): <= 1024 tokens, memory <= 4; with 4
     // variables per thread (<= 2048 tokens) its 64-value batch spills and loses to the sequential form (18.8 vs 14.8 us)

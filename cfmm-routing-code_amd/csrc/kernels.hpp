@@ -1541,7 +1541,10 @@ __device__ __forceinline__ void stv(double *p, int first, int len, const double 
     }
 }
 
-template <int MAXT, int MM, int E, bool BATCH = false>          // <= MAXT threads (register budget), <= MM history pairs, E variables per thread
+// GEN: the utility may hold entries of the utility table (lbfgs_rules.hpp: CFMM_ULOG / CFMM_UQUAD) -- their conjugate, maximiser and
+// Fenchel-Young gap term replace the linear-box token's in part A, nothing else changes (round 5: such utilities ran through the generic
+// update_kernel alone, ~25 dependent L2 round trips per step: 45 us per evaluation on 5e4 pools where this form takes ~25)
+template <int MAXT, int MM, int E, bool BATCH = false, bool GEN = false>          // <= MAXT threads (register budget), <= MM history pairs, E variables per thread
 __global__ void __launch_bounds__(MAXT)
 update_reg_kernel(UpdArgs a0)
 {
@@ -1644,11 +1647,18 @@ update_reg_kernel(UpdArgs a0)
         __syncthreads();
     }
     double Gs_t[E];
+    lbfgs::UtilityTerm ut[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         Gs_t[e] = 0.0;
+        ut[e] = lbfgs::UtilityTerm{0.0, 0.0, 0.0, 0.0, 0.0};
         if (tin[e]) {
-            const double rj = psi[e] + hj[e];
+            double rj = psi[e] + hj[e];
+            if (GEN && lbfgs::smooth_utility(ct[e])) {
+                ut[e] = lbfgs::utility_term(ct[e], cj[e], hj[e], nuj[e], psi[e]);
+                rj = psi[e] - ut[e].pstar;
+                if (st.first) dg[e] += fmax(ut[e].curv, 0.0);
+            }
             if (ties) {
                 unsafeAtomicAdd(&q[grp[e]], nuj[e] * rj);
                 if (st.first) unsafeAtomicAdd(&q2[grp[e]], dg[e]);
@@ -1673,11 +1683,18 @@ update_reg_kernel(UpdArgs a0)
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         if (tin[e]) {
+            if (GEN && lbfgs::smooth_utility(ct[e])) {
+                A[0] += ut[e].ubar;
+                A[1] += ut[e].ubar + nuj[e] * psi[e] - ut[e].uval;
+                A[9] = fmax(A[9], ut[e].viol);
+                A[10] = fmax(A[10], fmax(fabs(psi[e]), fabs(ut[e].pstar)));
+            } else {
             const double rj = psi[e] + hj[e];
             A[0] += (nuj[e] - cj[e]) * hj[e];
             A[1] += (nuj[e] - cj[e]) * rj;
             A[9] = fmax(A[9], ct[e] == 0 ? fmax(-rj, 0.0) : (ct[e] == 1 ? fabs(rj) : 0.0));
             A[10] = fmax(A[10], fmax(fabs(psi[e]), fabs(hj[e])));
+            }
         }
         sv[e] = 0.0; yv[e] = 0.0; qv[e] = 0.0; act[e] = true;
         if (gin[e]) {

@@ -507,8 +507,11 @@ __host__ __device__ inline size_t table_lds_bytes(int n, bool with_d, bool det, 
 {
     return (size_t)(((with_d ? 2 : 1) * eval_tile_doubles(n, det) + n + 2 + 16 + 2 + 1) & ~1) * sizeof(double) + (size_t)waves * GT_STRIP * sizeof(double2);
 }
+#ifndef GT_WAVES_PER_SIMD
+#define GT_WAVES_PER_SIMD 2
+#endif
 template <bool WITH_D, bool DET>
-__global__ void __launch_bounds__(GT_THREADS)
+__global__ void __launch_bounds__(GT_THREADS, GT_WAVES_PER_SIMD)
 table_eval_kernel(TableArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];

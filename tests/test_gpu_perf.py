@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("group", ["C3", "C4shard", "C4", "C5"])
+@pytest.mark.parametrize("group", ["C3", "C4shard", "C4", "C5", "C4x4", "table", "ulog", "sweep"])
 def test_dominant_kernels_stay_inside_their_time_budget(group):
     import kernel_budget as kb
     if not os.path.exists(kb.BUDGET):

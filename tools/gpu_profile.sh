@@ -20,11 +20,18 @@ echo "== bench (two ranks sharing the GPU, one-shot exchange)"; timeout 900 pyth
 echo "== upload"; timeout 300 python tools/upload_timing.py > $O/upload.json 2> $O/upload.err; cat $O/upload.json
 echo "== small networks"; timeout 300 python tools/small_timing.py > $O/small.json 2> $O/small.err; cut -c1-600 $O/small.json
 echo "== batched solves"; for c in C3 C4shard; do timeout 600 python tools/batch_timing.py --config $c > $O/batch_$c.jsonl 2> $O/batch_$c.err; cut -c1-300 $O/batch_$c.jsonl; done
+echo "== the K-asset table's launch: 1e5 four-asset stableswap pools, warm and cold; 1e5 constant-sum"; timeout 300 python tools/profile_table.py > $O/table.jsonl 2> $O/table.err; CFMM_TABLE_WARM=0 timeout 300 python tools/profile_table.py >> $O/table.jsonl 2>> $O/table.err; timeout 300 python tools/profile_table.py --kind sum >> $O/table.jsonl 2>> $O/table.err; cut -c1-300 $O/table.jsonl
+echo "== utility table (CFMM_ULOG) on 5e4 pools"; timeout 600 python tools/profile_ulog.py > $O/ulog.json 2> $O/ulog.err; cut -c1-600 $O/ulog.json
 echo "== host share of a solve"; timeout 300 python tools/host_overhead.py 2> $O/host_overhead.err | head -1 > $O/host_overhead.json; cut -c1-400 $O/host_overhead.json
 fi
 cd /tmp
 echo "== kernel trace of bench.py"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bench -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu > $O/trace_bench.log 2>&1; echo "rc=$?"
+echo "== kernel trace of the K-asset table's launch and of the utility-table solve"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_table -o t -- python $R/tools/profile_table.py > $O/trace_table.log 2>&1; echo "rc=$?"; tail -1 $O/trace_table.log | cut -c1-300
+CFMM_TABLE_WARM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tablecold -o t -- python $R/tools/profile_table.py > $O/trace_tablecold.log 2>&1; echo "rc=$?"; tail -1 $O/trace_tablecold.log | cut -c1-300
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_table_SQ -o c -- python $R/tools/profile_table.py --launches 20 > $O/pmc_table_SQ.log 2>&1; echo "pmc table rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ulog -o t -- python $R/tools/profile_ulog.py > $O/trace_ulog.log 2>&1; echo "rc=$?"; tail -1 $O/trace_ulog.log | cut -c1-300
 echo "== kernel trace + vector-issue counters of the config-5 solve (second-order path)"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_C5newton -o t -- python $R/tools/profile_newton.py --solves 3 > $O/trace_C5newton.log 2>&1; echo "rc=$?"; tail -1 $O/trace_C5newton.log | cut -c1-300
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_C5newton_SQ -o c -- python $R/tools/profile_newton.py --solves 1 > $O/pmc_C5newton_SQ.log 2>&1; echo "pmc C5newton rc=$?"
@@ -59,7 +66,7 @@ for f in sorted(glob.glob('gpurun_out/p/trace_*/**/*kernel_trace.csv', recursive
     d = {}
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if any(s in k for s in ('iter_kernel', 'eval_kernel', 'update', 'eval_batch', 'solve_tiny', 'chol_', 'smooth_kernel')):
+        if any(s in k for s in ('iter_kernel', 'eval_kernel', 'update', 'eval_batch', 'solve_tiny', 'chol_', 'smooth_kernel', 'table_eval', 'gk_newton')):
             d.setdefault(k, []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
     out[name] = {}
     for k, v in d.items():
