@@ -914,6 +914,20 @@ class Problem:
                 if key not in tied and (key, 1) not in banned:
                     out[key] = dict(sgn=1, ia=int(b["idx"][lo[i], i]), ib=int(b["idx"][j, i]), fee=float(b["fee"][i]),
                                     Ra=float(b["R"][lo[i], i]), Rb=float(b["R"][j, i]), loose=bool(loose), leg_lo=int(lo[i]))
+            # the pool's OTHER kind of kink: two tokens tied for cheapest (nu_a = nu_b) -- which of them pays for the drained tokens
+            # switches there, and the whole payment with it; at the optimum it is split.  Record: a = the token the device makes pay (the
+            # first of the equals), b = the other; "sgn" 0 marks it; the amount P / gamma is filled in when the fills are recovered
+            srt = np.argsort(lnu, axis=0, kind="stable")
+            a1, a2 = srt[0], srt[1]
+            gap = lnu[a2, np.arange(m)] - lnu[a1, np.arange(m)]
+            sw = (gap < kink_tol) & ((gap < 0.5 * np.abs(lg)) | (lg == 0.0) | loose)
+            for i in np.flatnonzero(sw):
+                i = int(i)
+                ja, jb = sorted((int(a1[i]), int(a2[i])))         # (equal prices: the device takes the lower leg as the payer)
+                key = (rank, k, i, 100 + 10 * ja + jb)
+                if key not in tied and (key, 0) not in banned:
+                    out[key] = dict(sgn=0, ia=int(b["idx"][ja, i]), ib=int(b["idx"][jb, i]), fee=float(b["fee"][i]), Ra=0.0, Rb=0.0,
+                                    loose=bool(loose), leg_a=ja, leg_b=jb, pool=i, k=k)
         if self._host:                                   # the union over ranks, identical everywhere
             merged = {}
             for part in self._host.allgather(out):
@@ -949,7 +963,7 @@ class Problem:
                     if key[0] == rank:
                         if key[1] == 2:
                             flags[key[2]] = 1
-                        else:
+                        elif key[3] < 100:                            # (a switch record ties two prices and flags nothing)
                             flagsg[key[1]][key[3], key[2]] = 1
                 else:
                     del tied[key]; banned.add((key, rec["sgn"]))
@@ -973,6 +987,7 @@ class Problem:
             if st["status"] == 1:
                 if not tied:
                     return st, nu, psi
+                self._refresh_switches(nu, tied)
                 theta, ok = self._recover_fills(nu, psi, tied, tol)
                 bad = [k for k in tied if not (1e-9 < theta[k] < 1 - 1e-9)]
                 if ok and not bad:
@@ -1007,10 +1022,30 @@ class Problem:
                 break
         return st, nu, psi
 
+    def _refresh_switches(self, nu, tied):
+        """the payment a K-asset constant-sum pool's cheapest token makes at the prices nu (what the device evaluated): the reserves of
+        every token drained there over the fee, tied legs' fills aside -- the amount a `switch` record moves to the other cheapest token"""
+        for key, rec in tied.items():
+            if rec["sgn"] != 0:
+                continue
+            b = self.net["gk"][("sum", rec["k"])]
+            i = rec["pool"]
+            p = nu[b["idx"][:, i]]
+            lo = rec["leg_a"]
+            drained = b["fee"][i] * p > p[lo]
+            drained[lo] = False
+            for k2, r2 in tied.items():                           # legs of this pool tied on a drain kink: left out by the device
+                if r2["sgn"] == 1 and k2[1] == rec["k"] and k2[2] == i and k2[3] < 100:
+                    drained[k2[3]] = False
+            rec["Rb"] = float(b["R"][drained, i].sum() / b["fee"][i])
+
     def _fill_vector(self, rec):
         """net trade of the tied constant-sum pool `rec` at full fill in its kink's direction"""
         d = np.zeros(self.n)
         a, bb, g = rec["ia"], rec["ib"], rec["fee"]
+        if rec["sgn"] == 0:   # a K-asset pool whose two cheapest tokens are tied: the payment P / gamma moves from a to b
+            d[a] = rec["Rb"]; d[bb] = -rec["Rb"]                  # (Rb holds P / gamma: _refresh_switches)
+            return d
         if rec["sgn"] > 0:    # tender a, drain b
             d[a] = -rec["Rb"] / g; d[bb] = rec["Rb"]
         else:                 # tender b, drain a
@@ -1137,6 +1172,10 @@ class Problem:
                         d, l = tr["sum2"]
                         y = th * np.array([full[rec["ia"]], full[rec["ib"]]])
                         d[:, i] = np.maximum(-y, 0.0); l[:, i] = np.maximum(y, 0.0)
+                    elif ("sum", k) in tr and rec["sgn"] == 0:      # two cheapest tokens tied: theta of the payment moves from leg a to leg b
+                        d, l = tr[("sum", k)]
+                        d[rec["leg_a"], i] -= th * rec["Rb"]
+                        d[rec["leg_b"], i] += th * rec["Rb"]
                     elif ("sum", k) in tr:             # a tied LEG of a K-asset pool: theta R_j received, paid for by the pool's cheapest token
                         d, l = tr[("sum", k)]
                         l[j, i] += th * rec["Rb"]

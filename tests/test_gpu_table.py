@@ -72,7 +72,8 @@ def test_table_pools_solves_at_scale_both_outer_iterations(oracle_lib):
     certificates (hundreds of evaluations: near their peg these pools are almost linear -- the regime the second-order path exists
     for), the evaluation at the prices it ends on is the restatement's; and the SAME network through method="newton" -- the table's
     stableswap pools enter with their exact generalised Hessian block (csrc/phik.hpp: gk_newton_kernel) -- in <= 40 steps to the same optimum.
-    1 000 n-asset constant-sum pools over peg groups end on kinks the host's loop only half knows: reported as not certified."""
+    1 000 n-asset constant-sum pools over peg groups end ON their kinks -- partially drained legs and tokens tied for cheapest: the
+    host's active-set loop ties them and recovers the fills -- certified."""
     net = synthetic.make_network(200, m_cp2=20000, m_gn=2000, m_gk_stable=1000, seed=3)
     n = net["n_tokens"]
     p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
@@ -101,12 +102,24 @@ def test_table_pools_solves_at_scale_both_outer_iterations(oracle_lib):
     assert np.abs(tot - p.psi).max() <= 1e-8 * np.abs(p.psi).max()
     p.close()
     # 1 000 n-asset constant-sum pools over peg groups: the LP's dual prices settle on kinks of BOTH kinds -- a partially drained leg
-    # (gamma nu_j = nu_cheapest: handled, see the next test) and two tokens tied for cheapest (the payment splits between them: NOT
-    # handled by the host's loop).  Honest: not certified, and it says so.
+    # (gamma nu_j = nu_cheapest) and two tokens tied for cheapest (the payment splits between them).  The host's active-set loop ties
+    # them, the device leaves the tied legs out, the fills are recovered: certified (round 4: stalled, and the test said so)
     hard = synthetic.make_network(200, m_cp2=20000, m_gk_sum=1000, seed=3)
     q = cfmm.Problem.from_network(hard, utility=cfmm.Arbitrage(hard["c"]))
-    q.solve(tol=1e-6, max_evals=600, method="lbfgs")
-    assert q.status != "optimal"
+    vq = q.solve(tol=1e-6, max_evals=1500)
+    assert q.status == "optimal" and q.gap <= 1e-6 and q.infeas <= 1e-6, (q.status, q.gap, q.infeas, q.stats)
+    assert len(q._theta) > 0 and all(0.0 < th < 1.0 for _, th in q._theta.values())
+    tot = np.zeros(hard["n_tokens"])
+    for (kind, k), b in hard["gk"].items():
+        d, l = q.bucket_trades((kind, k))
+        assert np.all(d >= -1e-9 * b["R"].max()) and np.all(l >= 0)
+        x = b["R"] + b["fee"][None, :] * d - l
+        assert np.all(x >= -1e-9 * b["R"].max()) and np.all(x.sum(axis=0) >= b["R"].sum(axis=0) * (1 - 1e-12))      # arbitrage.py:73-74
+        np.add.at(tot, b["idx"].ravel(), (l - d).ravel())
+    d, l = q.bucket_trades("cp2")
+    np.add.at(tot, hard["cp2"]["ia"], l[0] - d[0]); np.add.at(tot, hard["cp2"]["ib"], l[1] - d[1])
+    assert np.abs(tot - q.psi).max() <= 1e-8 * np.abs(q.psi).max()
+    assert abs(float(hard["c"] @ q.psi) - vq) <= 1e-9 * abs(vq)
     q.close()
 
 
