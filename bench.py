@@ -129,6 +129,17 @@ def profile_record(config, tag=""):
     return out
 
 
+def newton_profile_record(kernel):
+    """the factorisation kernel's average launch out of the newest committed kernel-trace summary of the Newton path
+    (profiles/r*_rocprofv3_kernel_stats_C5newton.csv, tools/gpu_profile.sh) -- the C5 line's rocprof cross-check"""
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_stats_C5newton.csv")))):
+        cand = [r for r in csv.DictReader(open(f)) if kernel + "(" in r.get("Name", "") or r.get("Name", "").endswith(kernel)]
+        if cand:
+            r = max(cand, key=lambda r: float(r["TotalDurationNs"]))
+            return float(r["AverageNs"]) / 1e3, int(r["Calls"]), os.path.relpath(f, ROOT)
+    return None, None, None
+
+
 def kernel_table(prob, reps):
     """the fused evaluation kernel timed live with HIP events on the library's stream: row 0 is the
     launch one dual evaluation makes (every bucket); the other rows restrict it to one bucket"""
@@ -455,6 +466,7 @@ def main():
                          "chol_step_kernel (csrc/chol.hpp: one block column per launch")
                 sm_bytes = dom["bytes"] + 16 * sum(len(prob.net[k]["Ra"]) for k in ("cp2", "w2", "curve2") if k in prob.net)     # + the warm starts: 8 B per direction
                 tf = flops / nk["factor"] / 1e12
+                rp_us, _, rp_file = newton_profile_record("chol_step2_kernel" if pairs else "chol_step_kernel")
                 out["roofline"].update({
                     "bound": "valu", "kernel": kname + f"; the dense Cholesky of one Newton step with its inverse factor: {nlaunch} dependent launches)",
                     "launches_per_factorisation": nlaunch,
@@ -466,6 +478,9 @@ def main():
                                       "useful_flop_frac: the n^3/3 a Newton step needs alone / the same time (a flop rate, not the PMC issue fraction the other configs report as valu_frac)",
                     "valu_frac_note": None,
                     "avg_launch_us": nk["factor"] * 1e6, "algorithmic_bytes_per_launch": None,
+                    "avg_launch_us_note": "the whole factorisation (the chain of dependent launches), HIP events on the library's stream; "
+                                          "rocprof_avg_launch_us = the kernel-trace average of ONE launch of the chain x launches_per_factorisation",
+                    "rocprof_avg_per_launch_us": rp_us, "rocprof_avg_launch_us": (rp_us * nlaunch if rp_us else None), "rocprof_source": rp_file,
                     "newton_step_us": {"smoothed_evaluation_with_hessian": nk["smooth_hess"] * 1e6, "smoothed_evaluation": nk["smooth"] * 1e6,
                                        "factorisation": nk["factor"] * 1e6, "back_substitution": nk["backsolve"] * 1e6},
                     "smoothed_evaluation": {"kernel": "smooth_kernel<false>", "avg_launch_us": nk["smooth"] * 1e6,
