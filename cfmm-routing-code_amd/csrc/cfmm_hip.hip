@@ -3485,6 +3485,13 @@ int cfmm_solve_sweep(cfmm_ctx *ctx, int B, const double *c, const double *h, con
             if (ct == CFMM_FREE && !(cj > 0.0)) return fail(ctx, CFMM_E_ARG, "solve_sweep: point %d, token %d: CFMM_FREE needs c > 0", p, j);
         }
     }
+    if (h) for (size_t q = 0; q < (size_t)B * n; ++q) if (!std::isfinite(h[q])) return fail(ctx, CFMM_E_ARG, "solve_sweep: point %d, h[%d] is not finite", (int)(q / n), (int)(q % n));
+    for (int64_t i = 0; i < m_sum; ++i) {               // (the host's half of the kink loop indexes prices with these: the columns as uploaded)
+        if (sum_ia[i] < 0 || sum_ia[i] >= n || sum_ib[i] < 0 || sum_ib[i] >= n || sum_ia[i] == sum_ib[i])
+            return fail(ctx, CFMM_E_ARG, "solve_sweep: constant-sum pool %lld: token ids (%d, %d) out of range or equal", (long long)i, sum_ia[i], sum_ib[i]);
+        if (!(sum_fee[i] > 0.0 && sum_fee[i] <= 1.0) || !(sum_Ra[i] > 0.0) || !(sum_Rb[i] > 0.0) || !std::isfinite(sum_Ra[i]) || !std::isfinite(sum_Rb[i]))
+            return fail(ctx, CFMM_E_ARG, "solve_sweep: constant-sum pool %lld: fee %g, reserves (%g, %g)", (long long)i, sum_fee[i], sum_Ra[i], sum_Rb[i]);
+    }
     const SumCols sc{m_sum, sum_ia, sum_ib, sum_fee, sum_Ra, sum_Rb};
     const int msum = (int)m_sum;
     const SweepLayout L(n, B, msum);
