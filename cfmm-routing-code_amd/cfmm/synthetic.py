@@ -31,7 +31,7 @@ def _pairs(rng, n, m, zipf_s=None):
 
 
 def make_network(n_tokens, m_cp2=0, m_w2=0, m_gn=0, m_curve2=0, seed=0, zipf_s=None,
-                 gn_sizes=(3, 8), mispricing=0.02, pool_seed=None, m_pow2=0, m_gk_stable=0, m_gk_sum=0, gk_sizes=(3, 4)):
+                 gn_sizes=(3, 8), mispricing=0.02, pool_seed=None, m_pow2=0, m_gk_stable=0, m_gk_sum=0, gk_sizes=(3, 4), peg=4):
     """Returns a dict of SoA buckets:
 
       prices   : latent pi[n]
@@ -48,8 +48,8 @@ def make_network(n_tokens, m_cp2=0, m_w2=0, m_gn=0, m_curve2=0, seed=0, zipf_s=N
     rng = np.random.default_rng(seed)
     n = n_tokens
     pi = np.exp(rng.normal(0.0, 1.0, n))
-    if m_curve2 or m_gk_stable:   # peg groups of 4 tokens
-        pi = pi[(np.arange(n) // 4) * 4] * np.exp(rng.normal(0.0, 0.002, n))
+    if m_curve2 or m_gk_stable:   # peg groups of 4 tokens (`peg`: of that many -- stableswap baskets of up to 8 tokens)
+        pi = pi[(np.arange(n) // peg) * peg] * np.exp(rng.normal(0.0, 0.002, n))
     c = pi * np.exp(rng.normal(0.0, 0.01, n))
     out = dict(n_tokens=n, prices=pi, c=c, seed=seed)
     if pool_seed is not None:      # same tokens / prices / market values, a different draw of pools
@@ -132,11 +132,11 @@ def make_network(n_tokens, m_cp2=0, m_w2=0, m_gn=0, m_curve2=0, seed=0, zipf_s=N
                 mk = int(np.sum(sizes == k))
                 if mk == 0:
                     continue
-                if kind == "stable":           # k of the 4 tokens of one peg group (k <= 4), in random order
-                    if k > 4:
-                        raise ValueError("synthetic stableswap table pools: 3 or 4 tokens of one peg group")
-                    grp = rng.integers(0, max(1, n // 4), mk) * 4
-                    perm = np.argsort(rng.random((mk, 4)), axis=1)[:, :k]
+                if kind == "stable":           # k of the `peg` tokens of one peg group, in random order
+                    if k > peg:
+                        raise ValueError(f"synthetic stableswap table pools: at most {peg} tokens of one peg group (peg=...)")
+                    grp = rng.integers(0, max(1, n // peg), mk) * peg
+                    perm = np.argsort(rng.random((mk, peg)), axis=1)[:, :k]
                     idx = np.minimum(grp[:, None] + perm, n - 1)
                 else:                          # k distinct tokens anywhere
                     idx = rng.integers(0, n, size=(mk, k))

@@ -951,6 +951,8 @@ int set_all_lds_attrs_uncached(cfmm_ctx *ctx)
     if ((rc = set_lds_attr(ctx, eval_batch_kernel, batch_lds_bytes(ctx->n, batch_capacity(ctx->n))))) return rc;
     if ((rc = set_lds_attr(ctx, table_eval_kernel<false, false>, table_lds_bytes(ctx->n, false, false, GT_THREADS / 64)))) return rc;
     if ((rc = set_lds_attr(ctx, table_eval_kernel<true, false>, table_lds_bytes(ctx->n, true, false, GT_THREADS / 64)))) return rc;
+    if ((rc = set_lds_attr(ctx, table_newton_kernel<false>, table_newton_lds_bytes(ctx->n, GT_THREADS / 64)))) return rc;
+    if ((rc = set_lds_attr(ctx, table_newton_kernel<true>, table_newton_lds_bytes(ctx->n, GT_THREADS / 64)))) return rc;
     if (ctx->n <= TINY_N && (rc = set_lds_attr(ctx, solve_tiny_kernel<false>, (size_t)tiny_lds_doubles(ctx->n) * sizeof(double)))) return rc;
     if (ctx->n <= TINY_N && (rc = set_lds_attr(ctx, solve_tiny_kernel<true>, (size_t)tiny_lds_doubles(ctx->n) * sizeof(double)))) return rc;
     const size_t il = iter_lds_bytes(ctx->n);
@@ -1485,7 +1487,23 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm, bool with_slo,
         }
 #undef GN_LAUNCH
     }
-    // the K-asset table's stableswap pools likewise (phik.hpp: gk_newton_kernel)
+    // the K-asset table's stableswap pools likewise: ONE launch of the table's wave-tiles (phik.hpp: table_newton_kernel);
+    // CFMM_TABLE_NEWTON=serial: one pool per lane, one launch per bucket (gk_newton_kernel: the form the tiles are tested against)
+    const char *gk_env = getenv("CFMM_TABLE_NEWTON");      // (read per call: the GPU tests compare the two forms inside one process)
+    const bool gk_serial = gk_env && !strcmp(gk_env, "serial");
+    if (!gk_serial) {
+        TableArgs ta = make_table_args(ctx, ctx->nu, nullptr);
+        const int nt = ta.tile_end[6];
+        if (nt > 0) {
+            if (!warm) ta.warm = 0;
+            const int waves = std::min(GT_THREADS / 64, nt);
+            static const int gmult = getenv("CFMM_TABLE_GRID_MULT") ? std::max(1, atoi(getenv("CFMM_TABLE_GRID_MULT"))) : 1;
+            const int grid = std::min((nt + waves - 1) / waves, gmult * ctx->cus);
+            const size_t tl = table_newton_lds_bytes(n, waves);
+            if (hess) hipLaunchKernelGGL(table_newton_kernel<true>, dim3(grid), dim3(64 * waves), tl, ctx->stream, ta, a.slo, ctx->sm_out, ctx->H, a.ldh);
+            else hipLaunchKernelGGL(table_newton_kernel<false>, dim3(grid), dim3(64 * waves), tl, ctx->stream, ta, a.slo, ctx->sm_out, (double *)nullptr, a.ldh);
+        }
+    } else
     for (int k = 2; k <= CFMM_MAX_POOL_SIZE; ++k) {
         const BucketG &bg = ctx->pools->bg[CFMM_POOLK_STABLE][k];
         if (!bg.m) continue;

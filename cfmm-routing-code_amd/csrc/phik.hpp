@@ -337,10 +337,15 @@ __host__ __device__ inline void pool_table_k(const double (&R)[K], const double 
 
 // ---- a wave-tile of the stableswap entry: 64 / K pools, leg per lane ---------------------------------------------------------------
 // xs: this wave's GT_STRIP double2 of LDS.  warm: read / write the bucket's warm-start column
-template <int K, bool WITH_D, bool DET>
+// NEWT (the second-order path's evaluation, table_newton_kernel below): 1 = the tenders carry the first-order response to the low-order
+// log-prices `nw.slo_s` (smooth.hpp: apply_slo; null: none) and the pool's value p'y is summed into nw.vsum; 2 = also the pool's exact
+// Hessian block in log-prices (stable_block above), leg pair (j, k <= j) by lane j, through global atomics into nw.H
+struct TileNewt { const double *slo_s; double *H; int ldh; double *vsum; };
+template <int K, bool WITH_D, bool DET, int NEWT = 0>
 __device__ __forceinline__ void tileg_stable(const BucketG &b, int tb, int lane, const double *nu_s, const Scatter<DET> &psi_s, const Scatter<DET> &diag_s,
-                                             double2 *xs, bool warm, double ftol_rel)
+                                             double2 *xs, bool warm, double ftol_rel, const TileNewt &nw = TileNewt{nullptr, nullptr, 0, nullptr})
 {
+    static_assert(!NEWT || (!WITH_D && !DET), "the second-order tile: plain accumulation, no metric");
     constexpr int P = 64 / K;
     constexpr double INF = 1.7976931348623157e308;
     const int g = lane / K, j = lane - g * K;
@@ -382,6 +387,7 @@ __device__ __forceinline__ void tileg_stable(const BucketG &b, int tb, int lane,
     const double imtop = rcp_nr(mtop);
     double th = wsv == wsv ? wsv : log_pos(mtop * rcp_nr(fmin(mB, mtop * (1.0 - 1e-3))) - 1.0);
     double lo = -INF, hi = INF, x = R;
+    double m_f = 0.0, s_f = 0.0, i1_f = 1.0, nA_f = 0.0;      // NEWT: multiplier, coupling s = alpha / prod x, 1 / (1 + active legs), active legs -- of the point x is at
     bool done = !trade, W = false, D = false;
     const double ftol = ftol_rel * Rsum;
     for (int it = 0; it < 64; ++it) {
@@ -426,6 +432,7 @@ __device__ __forceinline__ void tileg_stable(const BucketG &b, int tb, int lane,
                 const double Phi = Sdx - (s - sR);
                 const double dlm = SxQ - (SxA - s) * SQ * i1;              // d Phi / d log m  (> 0)
                 x = xn; W = Wn; D = Dn;
+                if constexpr (NEWT != 0) { m_f = rcp_nr(im); s_f = s; i1_f = i1; nA_f = nA; }
                 if (fabs(Phi) <= ftol && dlm > 0.0) {
                     // close enough for the LAST Newton step to be taken on the solution itself instead of re-evaluated (the iteration
                     // converges quadratically: the step from |Phi| <= 1e-9 sum R lands below the rounding of x): d log x_j = (Q_j - SQ / (1 + nA)) d log m
@@ -433,6 +440,7 @@ __device__ __forceinline__ void tileg_stable(const BucketG &b, int tb, int lane,
                     // stopping at |Phi| <= 1e-13 sum R left 3e-8 of noise in the dual value of 1000 pools, above the last Newton decrements
                     const double step = -Phi * rcp_nr(dlm);
                     if (act) x = xn * fma(Q - SQ * i1, step, 1.0);
+                    if constexpr (NEWT != 0) { m_f *= 1.0 + step; s_f *= 1.0 - SQ * i1 * step; }      // (pool_stable_k's sol after its last step)
                     th -= step * (1.0 + e) * rcp_nr(e);
                     done = true;
                 } else {
@@ -451,6 +459,51 @@ __device__ __forceinline__ void tileg_stable(const BucketG &b, int tb, int lane,
         }
     }
     if (!DET && warm && trade && j == 0) b.ws[pl] = th;
+    if constexpr (NEWT != 0) {
+        // gk_newton_kernel's pool, leg per lane: pools that trade on at least two legs enter with tenders, value and block; the others
+        // not at all (a single active leg cannot move along the level set)
+        const bool emit = trade && nA_f > 1.5;
+        const bool act = emit && (W || D);
+        const double pk = act ? (D ? nu * ifee : nu) : 0.0;
+        xs[lane] = make_double2(x * pk, 0.0);
+        __builtin_amdgcn_wave_barrier();
+        double xp = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) xp += xs[gb + k].x;
+        __builtin_amdgcn_wave_barrier();
+        const double v = act ? x * x * pk - x * xp * i1_f : 0.0;
+        const double sl = (nw.slo_s && act) ? nw.slo_s[tok] : 0.0;
+        xs[lane] = make_double2(pk * v, x * pk * sl); xt[lane] = make_double2(v * pk * sl, 0.0);
+        __builtin_amdgcn_wave_barrier();
+        double pv = 0.0, xps = 0.0, vps = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { const double2 q = xs[gb + k]; pv += q.x; xps += q.y; vps += xt[gb + k].x; }
+        __builtin_amdgcn_wave_barrier();
+        const double coef = emit ? rcp_nr(m_f * s_f) : 0.0, ipv = pv > 0.0 ? rcp_nr(pv) : 0.0;
+        if (act) {
+            double y = D ? (R - x) * ifee : R - x;
+            if (nw.slo_s) y += coef * pk * (x * x * pk * sl - x * i1_f * xps - v * vps * ipv) * rcp_nr(nu);
+            psi_s.add(tok, y);
+            *nw.vsum += nu * y;
+        }
+        if constexpr (NEWT == 2) {
+            xs[lane] = make_double2(x, pk); xt[lane] = make_double2(v, __hiloint2double(0, tok));
+            __builtin_amdgcn_wave_barrier();
+            if (act) {
+                for (int k = 0; k <= j; ++k) {
+                    const double2 q = xs[gb + k], r = xt[gb + k];
+                    if (q.y == 0.0) continue;              // (leg k does not trade)
+                    const int tk = __double2loint(r.y);
+                    const double Njk = (k == j ? x * x : 0.0) - x * q.x * i1_f;
+                    const double hv = coef * pk * q.y * (Njk - v * r.x * ipv);
+                    const int row = tok > tk ? tok : tk, col = tok > tk ? tk : tok;
+                    unsafeAtomicAdd(&nw.H[(size_t)col * nw.ldh + row], hv);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     if (live) {
         const double y = W ? R - x : (D ? (R - x) * ifee : 0.0);
         if (y != 0.0) psi_s.add(tok, y);
@@ -574,6 +627,62 @@ table_eval_kernel(TableArgs a)
         double f = 0.0;
         for (int w = 0; w < nw; ++w) f += fpart[w];
         if (f != 0.0) unsafeAtomicAdd(&base[acc_arb(n)], f);
+    }
+}
+
+// ---- the table's stableswap buckets inside the second-order path: ONE launch, the same wave-tiles (round 5) -------------------------------
+// What gk_newton_kernel below does one pool per lane (kept: the reference the tiles are tested against, CFMM_TABLE_NEWTON=serial): exact
+// tenders + first-order response to the low-order log-prices into out[0 .. n), the pools' value into out[n] and out[n + 1], HESS: the
+// exact K x K blocks into H.  LDS: psi tile | nu_s[n] | slo_s[n] | wave partials | ticket | strips.
+__host__ __device__ inline size_t table_newton_lds_bytes(int n, int waves)
+{
+    return (size_t)((3 * n + 16 + 2 + 1) & ~1) * sizeof(double) + (size_t)waves * GT_STRIP * sizeof(double2);
+}
+template <bool HESS>
+__global__ void __launch_bounds__(GT_THREADS, GT_WAVES_PER_SIMD)
+table_newton_kernel(TableArgs a, const double *__restrict__ slo, double *__restrict__ out, double *__restrict__ H, int ldh)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = a.n;
+    double *psi_t = lds, *nu_s = lds + n, *slo_s = lds + 2 * n, *fpart = lds + 3 * n;
+    int *next_tile = reinterpret_cast<int *>(fpart + 16);
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    double2 *xs = reinterpret_cast<double2 *>(lds + ((3 * n + 16 + 2 + 1) & ~1)) + GT_STRIP * wib;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) { nu_s[j] = a.nu[j]; psi_t[j] = 0.0; if (slo) slo_s[j] = slo[j]; }
+    const int ntiles = a.tile_end[6];                     // the stableswap buckets' share of the tile space
+    const int t0 = (int)(((long long)blockIdx.x * ntiles) / gridDim.x), t1 = (int)(((long long)(blockIdx.x + 1) * ntiles) / gridDim.x);
+    if (threadIdx.x == 0) *next_tile = t0 + nw;
+    __syncthreads();
+    const Scatter<false> psi_s{psi_t, n, 0.0};
+    double vsum = 0.0;
+    const TileNewt tn{slo ? slo_s : nullptr, H, ldh, &vsum};
+    int ticket = t0 + wib;
+    for (;;) {
+        const int t = __builtin_amdgcn_readfirstlane(ticket);
+        if (t >= t1) break;
+        if (lane == 0) ticket = atomicAdd(next_tile, 1);
+        int q = 0, first = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (t >= a.tile_end[i]) { q = i + 1; first = a.tile_end[i]; }
+        const int tb = t - first;
+        switch (q) {
+#define GT_N(KK) case KK - 2: tileg_stable<KK, false, false, HESS ? 2 : 1>(a.bs[KK - 2], tb, lane, nu_s, psi_s, psi_s, xs, a.warm != 0, a.ftol, tn); break;
+        GT_N(2) GT_N(3) GT_N(4) GT_N(5) GT_N(6) GT_N(7) GT_N(8)
+#undef GT_N
+        default: break;
+        }
+    }
+    vsum = wave_sum(vsum);
+    if (lane == 0) fpart[wib] = vsum;
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const double v = psi_t[j];
+        if (v != 0.0) unsafeAtomicAdd(&out[j], v);
+    }
+    if (threadIdx.x == 0) {
+        double f = 0.0;
+        for (int w = 0; w < nw; ++w) f += fpart[w];
+        if (f != 0.0) { unsafeAtomicAdd(&out[n], f); unsafeAtomicAdd(&out[n + 1], f); }
     }
 }
 

@@ -67,11 +67,45 @@ def test_table_pools_evaluation_tenders_and_invariants(oracle_lib):
     p.close()
 
 
+@pytest.mark.parametrize("sizes", [(2, 2), (3, 4), (5, 6), (7, 8)])
+def test_second_order_evaluation_of_the_table_tiles_against_one_pool_per_lane(sizes, monkeypatch):
+    """the table's stableswap buckets inside the second-order path: ONE launch of the wave-tiles (table_newton_kernel: leg per lane,
+    LDS psi tile, the K x K Hessian block by leg pair) against the one-pool-per-lane form it replaces (gk_newton_kernel,
+    CFMM_TABLE_NEWTON=serial) -- value, psi and every entry of the Hessian; then a second-order solve under each, same optimum
+    (the low-order log-prices of its last steps go through the tile's first-order response)"""
+    net = synthetic.make_network(120, m_cp2=3000, m_gk_stable=4000, gk_sizes=sizes, seed=11, peg=max(4, sizes[1]))
+    n = net["n_tokens"]
+    rng = np.random.default_rng(2)
+    out = {}
+    for form in ("serial", "tiles"):
+        if form == "serial":
+            monkeypatch.setenv("CFMM_TABLE_NEWTON", "serial")
+        else:
+            monkeypatch.delenv("CFMM_TABLE_NEWTON", raising=False)
+        p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+        ctx = p._ensure_ctx(); p._send_utility()
+        ev = []
+        for rep in range(3):                        # (the third evaluation starts from the second's roots: the warm-start column)
+            nu = net["c"] * np.exp(np.random.default_rng(rep // 2).normal(0, 0.004 * (1 + rep // 2), n))
+            ev.append(ctx.eval_smooth(nu, 1e-5, want_hessian=True))
+        v = p.solve(tol=1e-8, method="newton")
+        assert p.status == "optimal" and p.gap <= 1e-8 and p.infeas <= 1e-8, (form, p.status, p.gap, p.infeas)
+        out[form] = (ev, v, p.psi.copy())
+        p.close()
+    for (va, ta, pa, Ha), (vb, tb, pb, Hb) in zip(out["serial"][0], out["tiles"][0]):
+        assert abs(va - vb) <= 1e-11 * abs(va) and abs(ta - tb) <= 1e-11 * max(1.0, abs(ta))
+        assert np.abs(pa - pb).max() <= 1e-11 * np.abs(pa).max()
+        La, Lb = np.tril(Ha), np.tril(Hb)
+        assert np.abs(La).max() > 0 and np.abs(La - Lb).max() <= 1e-10 * np.abs(La).max()
+    assert abs(out["serial"][1] - out["tiles"][1]) <= 1e-8 * abs(out["serial"][1])
+    assert np.abs(out["serial"][2] - out["tiles"][2]).max() <= 1e-6 * np.abs(out["serial"][2]).max()
+
+
 def test_table_pools_solves_at_scale_both_outer_iterations(oracle_lib):
     """1 000 n-asset stableswap pools among 22 000 pools of the reference's kinds: the first-order solve reaches its 1e-6
     certificates (hundreds of evaluations: near their peg these pools are almost linear -- the regime the second-order path exists
     for), the evaluation at the prices it ends on is the restatement's; and the SAME network through method="newton" -- the table's
-    stableswap pools enter with their exact generalised Hessian block (csrc/phik.hpp: gk_newton_kernel) -- in <= 40 steps to the same optimum.
+    stableswap pools enter with their exact generalised Hessian block (csrc/phik.hpp: table_newton_kernel) -- in <= 40 steps to the same optimum.
     1 000 n-asset constant-sum pools over peg groups end ON their kinks -- partially drained legs and tokens tied for cheapest: the
     host's active-set loop ties them and recovers the fills -- certified."""
     net = synthetic.make_network(200, m_cp2=20000, m_gn=2000, m_gk_stable=1000, seed=3)
