@@ -16,7 +16,7 @@ DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
 
 for name in ("bench.json", "bench_C2.json", "bench_C3.json", "bench_C4.json", "bench_C5.json", "bench_C4x4.json", "bench_C3zipf.json", "bench_dist1.json", "bench_share2.json", "upload.json",
-             "kernel_durations.json", "small.json", "batch_C3.jsonl", "batch_C4shard.jsonl", "host_overhead.json", "table.jsonl", "ulog.json"):
+             "kernel_durations.json", "small.json", "batch_C3.jsonl", "batch_C4shard.jsonl", "host_overhead.json", "table.jsonl", "ulog.json", "table_newton.jsonl"):
     if os.path.exists(os.path.join(SRC, name)):
         if name.startswith("bench"):                 # the JSON line alone (a multi-rank run's stdout also carries gloo's banner)
             lines = [l for l in open(os.path.join(SRC, name)).read().splitlines() if l.startswith("{")]

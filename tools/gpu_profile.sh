@@ -32,6 +32,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tab
 CFMM_TABLE_WARM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tablecold -o t -- python $R/tools/profile_table.py > $O/trace_tablecold.log 2>&1; echo "rc=$?"; tail -1 $O/trace_tablecold.log | cut -c1-300
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_table_SQ -o c -- python $R/tools/profile_table.py --launches 20 > $O/pmc_table_SQ.log 2>&1; echo "pmc table rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ulog -o t -- python $R/tools/profile_ulog.py > $O/trace_ulog.log 2>&1; echo "rc=$?"; tail -1 $O/trace_ulog.log | cut -c1-300
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tablenewton -o t -- python $R/tools/profile_table_newton.py > $O/table_newton.jsonl 2> $O/trace_tablenewton.log; echo "rc=$?"; cut -c1-300 $O/table_newton.jsonl
 echo "== kernel trace + vector-issue counters of the config-5 solve (second-order path)"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_C5newton -o t -- python $R/tools/profile_newton.py --solves 3 > $O/trace_C5newton.log 2>&1; echo "rc=$?"; tail -1 $O/trace_C5newton.log | cut -c1-300
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_C5newton_SQ -o c -- python $R/tools/profile_newton.py --solves 1 > $O/pmc_C5newton_SQ.log 2>&1; echo "pmc C5newton rc=$?"
