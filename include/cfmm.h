@@ -234,7 +234,9 @@ int cfmm_batch_capacity(int n_tokens);
  *                           the reverse) of every pool that ended tied on its kink, NaN / 0 elsewhere: psi_total = psi + sum theta d
  *   trades                  NULL, or [B][T]: per point, for every non-empty bucket in the order two-asset kinds 0.., then sizes 3..8,
  *                           delta [k][m] then lambda [k][m] (tied pools: zeros -- their tenders are theta x their full fill)
- *   out, rounds             [B] statistics (evals / iters summed over the rounds; wall / device seconds: of the whole sweep), rounds per point */
+ *   out, rounds             [B] statistics (evals / iters summed over the rounds; wall / device seconds: of the whole sweep), rounds per point.
+ *                           primal_value / dual_value / infeas of a point with tied pools are those of the point WITHOUT the tied pools' fills
+ *                           (psi likewise): the caller adds theta x the full fill of each -- the objective is then c'psi */
 int cfmm_solve_sweep(cfmm_ctx *ctx, int B, const double *c, const double *h, const int32_t *ctype, const double *nu0,
                      int64_t m_sum, const int32_t *sum_ia, const int32_t *sum_ib, const double *sum_fee, const double *sum_Ra, const double *sum_Rb,
                      const cfmm_opts *opts, double kink_tol, int max_rounds,

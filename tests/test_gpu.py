@@ -479,7 +479,7 @@ def test_integration_md_ctypes_stub_runs():
     md = open(os.path.join(root, "INTEGRATION.md")).read()
     blocks = re.findall(r"```python\n(.*?)```", md, re.S)
     stub = [b for b in blocks if "cfmm_create" in b]
-    assert len(stub) == 1
+    assert len(stub) == 2 and "cfmm_solve_sweep" in stub[1]
     ns = {}
     exec(stub[0].replace("<repo>", root), ns)
     st = ns["st"]
@@ -491,6 +491,14 @@ def test_integration_md_ctypes_stub_runs():
     # ... and the partially filled constant-sum pool's net tender (38.6 % of its reserve, arbitrage.py:12,20,28)
     y = ns["lam"] - ns["dlt"]
     assert np.abs(y[:, 0] - np.asarray(golden()["arbitrage"]["kkt"]["y"][4])).max() <= 1e-6
+    # section 3b (continues the same namespace): two-asset.py's 50-point sweep, all five pools, as ONE raw call
+    exec(stub[1], ns)
+    assert all(ns["stats"][j].status == 1 for j in range(50)) and np.all(np.diff(ns["all_values"]) > 0)
+    assert ns["on_kink"].sum() >= 5                                        # (the constant-sum pool is partially filled at many points)
+    for j in (0, 1, 10, 25, 49):
+        k = golden()[f"two_asset_{j}"]["kkt"]
+        assert abs(ns["all_values"][j] - k["value"]) <= 1e-8 * max(1.0, abs(k["value"]))
+        assert np.abs(ns["psi_all"][j] - np.asarray(k["psi"])).max() <= 5e-8
 
 
 def test_full_size_c4_single_gpu_streams_from_hbm():
