@@ -27,6 +27,7 @@ problem's vocabulary and refuses anything else with `NotImplementedError`:
 and hands the result to cfmm.Problem, i.e. to libcfmm_hip.so on the MI355X -- there is no CPU path here either.
 """
 import builtins
+import hashlib
 
 import numpy as np
 
@@ -37,6 +38,27 @@ from ._lib import GE as _GE, EQ as _EQ, FREE as _FREE, ULOG as _ULOG, UQUAD as _
 CONTEXT_FACTORY = None
 
 OPTIMAL, INACCURATE, INFEASIBLE = "optimal", "optimal_inaccurate", "infeasible"
+
+# Pools that stay resident.  two-asset.py:40-100 re-states the SAME five pools for each of its 50 amounts -- new variables, new
+# constraints, a new cp.Problem per point -- and a conic solver starts from scratch every time.  Here the pools of the last few
+# models stay uploaded (keyed by what defines them: token lists, reserves, fees, functions, weights): a model over the same pools
+# only sends its utility and starts from the previous prices, as `cfmm.Problem.solve(warm_start=True)` does for the native interface.
+# RESIDENT_MAX = 0 switches it off.
+RESIDENT_MAX = 2
+_resident = {}
+
+
+def _pool_signature(n, local, pools):
+    h = hashlib.blake2b(digest_size=16)
+    h.update(np.int64(n).tobytes())
+    for l, pl in zip(local, pools):
+        h.update(np.asarray(l, dtype=np.int64).tobytes()); h.update(b"|")
+        h.update(np.asarray(pl["R"], dtype=np.float64).tobytes()); h.update(np.float64(pl["fee"]).tobytes())
+        h.update(str(pl["kind"]).encode())
+        h.update(b"-" if pl["w"] is None else np.asarray(pl["w"], dtype=np.float64).tobytes())
+        h.update(b"-" if pl.get("param") is None else np.float64(pl["param"]).tobytes())
+        h.update(b";")
+    return h.hexdigest(), id(CONTEXT_FACTORY)
 
 
 def _const(x):
@@ -627,17 +649,28 @@ class Problem:
         """maps the model onto cfmm.Problem and solves it on the device; returns prob.value like cvxpy"""
         pools, local, n, util = self._match()
         tol = float(kw.pop("tol", 1e-9))
-        p = _RoutingProblem(n, local, [pl["R"] for pl in pools], [pl["fee"] for pl in pools],
-                            [pl["kind"] for pl in pools], [pl["w"] for pl in pools],
-                            [pl.get("param") for pl in pools], utility=util)
-        if CONTEXT_FACTORY is not None:
-            p.ctx = CONTEXT_FACTORY(n)
+        key = _pool_signature(n, local, pools) if RESIDENT_MAX > 0 else None
+        p = _resident.get(key) if key is not None else None
+        if p is not None and p.ctx is not None:          # the same pools as an earlier model (and not closed since): utility + warm start
+            p.set_utility(util)
+            kw.setdefault("warm_start", True)
+        else:
+            p = _RoutingProblem(n, local, [pl["R"] for pl in pools], [pl["fee"] for pl in pools],
+                                [pl["kind"] for pl in pools], [pl["w"] for pl in pools],
+                                [pl.get("param") for pl in pools], utility=util)
+            if CONTEXT_FACTORY is not None:
+                p.ctx = CONTEXT_FACTORY(n)
+            if key is not None:
+                _resident.pop(key, None)
+                while len(_resident) >= RESIDENT_MAX:    # (the oldest entry goes; whoever still holds it through prob.routing keeps it alive)
+                    _resident.pop(next(iter(_resident)))
+                _resident[key] = p
         p.solve(tol=tol, **kw)
         self.routing = p
         deltas, lambdas = p.deltas, p.lambdas
         for pl, d, l in zip(pools, deltas, lambdas):
-            pl["D"]._value = np.asarray(d, dtype=np.float64)
-            pl["L"]._value = np.asarray(l, dtype=np.float64)
+            pl["D"]._value = np.array(d, dtype=np.float64)       # (copies: the resident problem's arrays belong to its next solve)
+            pl["L"]._value = np.array(l, dtype=np.float64)
         self.status = {"optimal": OPTIMAL, "inaccurate": INACCURATE, "infeasible": INFEASIBLE}.get(p.status, p.status)
         self.value = self.objective.value
         if verbose:

@@ -254,3 +254,46 @@ def test_shipped_programs_through_the_shim_on_the_gpu(name, inst):
     prob.solve(tol=1e-10)
     _check(name, prob, goal, net, tender, receive, 5e-8)
     prob.routing.close()
+
+
+@pytest.mark.gpu
+def test_the_sweep_through_the_shim_keeps_its_pools_resident(monkeypatch):
+    """two-asset.py:40-100 states a NEW cp.Problem over the SAME five pools for each of its 50 amounts.  The shim recognises the pool
+    set (token lists, reserves, fees, functions, weights) and keeps it uploaded: from the second point on a model only sends its
+    utility and starts from the previous prices.  Same optimum as with the residency switched off (and as the KKT fixture), every
+    pool's tenders included; the wall time of both ways printed"""
+    import time
+    cp.CONTEXT_FACTORY = None
+    ts = I.two_asset_sweep()
+    g = golden()
+    runs = {}
+    for resident in (2, 0):
+        monkeypatch.setattr(cp, "RESIDENT_MAX", resident)
+        cp._resident.clear()
+        vals, ys, routes = [], [], set()
+        t0 = time.perf_counter()
+        for t in ts:
+            prob, goal, net, tender, receive = cvx_models.build(cp, I.two_asset(float(t)))
+            vals.append(prob.solve(tol=1e-10))
+            assert prob.status == cp.OPTIMAL
+            ys.append([r.value - d.value for d, r in zip(tender, receive)])
+            routes.add(id(prob.routing))
+            if not resident:
+                prob.routing.close()
+        runs[resident] = (np.array(vals), ys, time.perf_counter() - t0, len(routes))
+    for p in list(cp._resident.values()):
+        p.close()
+    cp._resident.clear()
+    v_res, y_res, dt_res, n_res = runs[2]
+    v_off, y_off, dt_off, n_off = runs[0]
+    print(f"two-asset.py through cfmm.cvx, 50 models: {1e3 * dt_res:.1f} ms with the pools resident, {1e3 * dt_off:.1f} ms re-uploading them")
+    assert n_res == 1                                   # ONE resident problem served the 50 models (ids of the closed ones recycle: not counted)
+    assert np.abs(v_res - v_off).max() <= 1e-8
+    for j in (0, 1, 10, 25, 49):
+        k = g[f"two_asset_{j}"]["kkt"]
+        assert abs(v_res[j] - k["value"]) <= 1e-8 * max(1.0, abs(k["value"]))
+        for a, b in zip(y_res[j], k["y"]):
+            assert np.abs(a - np.asarray(b)).max() <= 5e-8
+    for a, b in zip(y_res, y_off):
+        for u, w in zip(a, b):
+            assert np.abs(u - w).max() <= 1e-6
