@@ -140,6 +140,27 @@ def newton_profile_record(kernel):
     return None, None, None
 
 
+def numpy_one_thread(net, budget_s=6.0):
+    """BASELINE.md section 4, throughput baseline B: the dual evaluation as vectorised NumPy on ONE thread (oracle/pools_np.py: the
+    restatements the C twin is pinned against; elementwise ufuncs and a bincount scatter -- nothing in it is multi-threaded), at the
+    market prices, for at most ~budget_s seconds.  Returns pools per second of evaluation and what was timed."""
+    from oracle import pools_np as P
+    nu = net["c"]
+
+    def one():
+        psi, _, m = P.dual_eval_network(net, nu)
+        return m, psi
+
+    t0 = time.perf_counter(); m, _ = one(); first = time.perf_counter() - t0
+    times = [first]
+    while sum(times) + min(times) < budget_s and len(times) < 4:
+        t0 = time.perf_counter(); one(); times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": m / best, "unit": "pool-subproblems/s", "cores": 1, "kind": "port",
+            "sample": f"{len(times)} dual evaluations of the same network ({m} pools) by oracle/pools_np.py (vectorised NumPy, one thread), "
+                      f"best {1e3 * best:.1f} ms per evaluation -- evaluations only, no outer iteration (BASELINE.md section 3's anchors: 1.3e7 /s at C3 on the survey box)"}
+
+
 def kernel_table(prob, reps):
     """the fused evaluation kernel timed live with HIP events on the library's stream: row 0 is the
     launch one dual evaluation makes (every bucket); the other rows restrict it to one bucket"""
@@ -188,6 +209,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-numpy", action="store_true", help="skip the one-thread NumPy evaluation beside the C baseline")
     ap.add_argument("--no-batch", action="store_true", help="skip the batched-solve figure")
     ap.add_argument("--cpu-solves", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -587,6 +609,8 @@ def main():
                                              "is not installed in this image",
                                    "evals_per_solve": ce / ns, "objective": r["primal_value"],
                                    "single_evaluation_ms": eval_s * 1e3}
+            if not getattr(args, "no_numpy", False) and not set(net) & {"curve2", "pow2", "gk", "sum2"} and prob.m <= 20_000_000:      # (~25 temporaries of 8 B per pool)
+                out["cpu_baseline"]["numpy_one_thread"] = numpy_one_thread(net)      # (baseline B of BASELINE.md section 4, beside baseline A above)
         print(json.dumps(out))
     if sharded:
         dist.barrier()

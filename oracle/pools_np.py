@@ -86,6 +86,54 @@ def arb_geomean_n(R, w, gamma, p):
     return y, float(p @ y)
 
 
+def arb_geomean_n_vec(R, w, gamma, p):
+    """arb_geomean_n for a whole bucket at once: R, w, p are [k][m] (slot-major, as cfmm.pack lays a size class out), gamma [m].
+    The same exact piecewise-linear root, its 2k breakpoints per pool evaluated as one [2k][k][m] array expression -- the
+    "vectorised NumPy, one thread" CPU baseline of BASELINE.md section 4 (bench.py: cpu_baseline.numpy_one_thread); pinned
+    against the per-pool form in tests/test_oracle.py.  Returns y [k][m] and the pools' values [m]."""
+    R = np.asarray(R, float); w = np.asarray(w, float); p = np.asarray(p, float); gamma = np.asarray(gamma, float)
+    lg = np.log(gamma)[None, :]
+    a = np.log(R * p / w)
+    bps = np.sort(np.concatenate([a, a - lg], axis=0), axis=0)                      # [2k][m]
+    u = bps[:, None, :] - a[None, :, :]                                              # [2k][k][m]
+    Fv = np.sum(w[None] * np.where(u < 0, u, np.where(u > -lg[None], u + lg[None], 0.0)), axis=1)       # [2k][m]
+    q = np.arange(bps.shape[0])[:, None]
+    lo_i = np.max(np.where(Fv <= 0, q, 0), axis=0)
+    hi_i = np.min(np.where(Fv >= 0, q, bps.shape[0] - 1), axis=0)
+    cols = np.arange(bps.shape[1])
+    t0, t1, f0, f1 = bps[lo_i, cols], bps[hi_i, cols], Fv[lo_i, cols], Fv[hi_i, cols]
+    flat = (f0 == 0.0) | (f1 == 0.0) | (hi_i <= lo_i)
+    with np.errstate(all="ignore"):
+        t = np.where(flat, np.where(f0 == 0.0, t0, t1), t0 - f0 * (t1 - t0) / np.where(f1 == f0, 1.0, f1 - f0))
+    mu = np.exp(t)[None, :]
+    x = np.clip(R, mu * gamma[None, :] * w / p, mu * w / p)
+    y = np.where(x < R, R - x, (R - x) / gamma[None, :])
+    return y, np.sum(p * y, axis=0)
+
+
+def dual_eval_network(net, nu):
+    """psi(nu) and sum_i arb_i(nu) of a whole synthetic network of the reference's pool kinds (cfmm/synthetic.py's SoA buckets: cp2, w2,
+    gn) as vectorised NumPy -- the evaluation bench.py times as its one-thread baseline; pinned against the C twin in tests/test_oracle.py"""
+    if set(net) & {"curve2", "pow2", "gk", "sum2"}:
+        raise ValueError("dual_eval_network: constant-product / weighted / n-asset geometric-mean buckets only")
+    n = net["n_tokens"]
+    psi = np.zeros(n); arb = 0.0; m = 0
+    for key in ("cp2", "w2"):
+        if key not in net:
+            continue
+        b = net[key]
+        pa, pb = nu[b["ia"]], nu[b["ib"]]
+        wa = b["wa"] if key == "w2" else 0.5
+        ya, yb, v = arb_geomean2(b["Ra"], b["Rb"], b["fee"], wa, 1.0 - wa, pa, pb)
+        psi += np.bincount(b["ia"], weights=ya, minlength=n) + np.bincount(b["ib"], weights=yb, minlength=n)
+        arb += float(np.sum(v)); m += len(b["Ra"])
+    for k, b in net.get("gn", {}).items():
+        y, v = arb_geomean_n_vec(b["R"], b["w"], b["fee"], nu[b["idx"]])
+        psi += np.bincount(b["idx"].ravel(), weights=y.ravel(), minlength=n)
+        arb += float(np.sum(v)); m += b["R"].shape[1]
+    return psi, arb, m
+
+
 # --------------------------------------------------------------------------------------
 # constant sum                                                       arbitrage.py:73-74
 # --------------------------------------------------------------------------------------

@@ -187,6 +187,13 @@ def test_committed_bench_lines_keep_the_contract(cfg):
     if cfg != "C3zipf":                               # (the stress variant is timed without the CPU leg)
         cb = d["cpu_baseline"]
         assert cb["kind"] == "port" and cb["unit"] == "pool-subproblems/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+        # BASELINE.md section 4's baseline B beside A: vectorised NumPy on one thread, where the restatement covers the pool kinds and
+        # the pool set fits the host's memory several times over
+        if cfg in ("C2", "C3", "C4"):
+            nb = cb["numpy_one_thread"]
+            assert nb["cores"] == 1 and nb["kind"] == "port" and 1e6 < nb["value"] < cb["value"] and "one thread" in nb["sample"]
+        else:
+            assert "numpy_one_thread" not in cb
     if cfg == "C3":
         assert d["ms_per_step"] <= 0.56 and d["value"] >= 3.9e10      # (round 2: 0.594 ms, 3.70e10)
     if cfg == "C4":

@@ -123,6 +123,40 @@ def test_c_pools_match_numpy(oracle_lib):
             assert np.abs(yy - y[:, i]).max() <= 1e-12 * d["R"][:, i].max()
 
 
+def test_vectorised_n_asset_restatement_matches_the_per_pool_one():
+    """oracle/pools_np.py: arb_geomean_n_vec (a whole size class as one array expression: bench.py's one-thread NumPy baseline)
+    against arb_geomean_n pool by pool -- trading pools, pools inside their no-trade band, fee 1, sizes 3..8"""
+    rng = np.random.default_rng(4)
+    for k in range(3, 9):
+        m = 300
+        R = np.exp(rng.normal(2, 1, (k, m))); w = rng.integers(1, 5, (k, m)).astype(float); w /= w.sum(axis=0)
+        g = rng.choice([0.99, 0.997, 1.0], m)
+        pool_price = w / R                                             # the pool's own marginal prices
+        p = pool_price * np.exp(rng.normal(0, 0.05, (k, m)) * (rng.random(m) < 0.7)[None, :])       # 30 % exactly at no trade
+        Y, V = P.arb_geomean_n_vec(R, w, g, p)
+        traded = 0
+        for i in range(m):
+            y, v = P.arb_geomean_n(R[:, i], w[:, i], g[i], p[:, i])
+            assert np.abs(Y[:, i] - y).max() <= 1e-12 * R[:, i].max() and abs(V[i] - v) <= 1e-12 * max(1.0, abs(v))
+            traded += np.any(y != 0)
+        assert 0.3 * m < traded < m
+
+
+def test_numpy_network_evaluation_matches_the_c_twin(oracle_lib):
+    """oracle/pools_np.py: dual_eval_network (what bench.py times as the one-thread NumPy baseline) against oracle/cfmm_oracle.c on a
+    scaled C3 (constant-product, weighted, 3..8-asset pools) and C2"""
+    from cfmm import synthetic
+    for cfg, scale in (("C3", 0.01), ("C2", 1.0)):
+        net = synthetic.config(cfg, scale=scale)
+        nu = net["c"] * np.exp(np.random.default_rng(3).normal(0, 0.01, net["n_tokens"]))
+        o = oracle_lib.Oracle(net["n_tokens"], threads=2); o.add_network(net); o.set_utility(net["c"])
+        f, psi = o.eval(nu)
+        psi_np, arb_np, m = P.dual_eval_network(net, nu)
+        assert m == sum(len(net[k]["Ra"]) for k in ("cp2", "w2") if k in net) + sum(b["R"].shape[1] for b in net.get("gn", {}).values())
+        assert np.abs(psi_np - psi).max() <= 1e-9 * np.abs(psi).max()
+        assert abs(float(nu @ psi_np) - arb_np) <= 1e-9 * max(1.0, abs(arb_np))
+
+
 def test_geomean_n_reduces_to_two_asset():
     rng = np.random.default_rng(0)
     for _ in range(200):
