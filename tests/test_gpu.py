@@ -1065,6 +1065,7 @@ def test_bench_line_keeps_the_contract(tmp_path):
     assert rf["rocprof_avg_launch_us"] is None or abs(rf["rocprof_avg_launch_us"] - rf["avg_launch_us"]) <= 0.3 * rf["avg_launch_us"]      # live (3 steps) vs committed trace
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "pool-subproblems/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert cb["numpy_one_thread"]["cores"] == 1 and cb["numpy_one_thread"]["value"] > 1e6      # (baseline B beside A)
     assert d["batched"]["solves_per_batch"] >= 2 and d["batched"]["value"] > 0.7 * d["value"]
     assert d["pcie_inclusive"]["value"] < d["value"]
     # the pool-sharded code path with a one-rank process group (what the driver's --gpus N > 1 runs per rank)
