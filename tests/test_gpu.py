@@ -324,6 +324,7 @@ def test_sweep_call_refuses_what_it_cannot_index():
     bad("positive finite price", nu0=nn)
     tt = ct.copy(); tt[0, 1] = 3
     bad("utility table", ctype=tt)
+    bad("no points", c=c[:0], h=h[:0], ctype=ct[:0], nu0=nu0[:0])
     p.close()
 
 
