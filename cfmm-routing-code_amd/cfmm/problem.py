@@ -645,7 +645,7 @@ class Problem:
         dual = ((nu - C_) * H).sum(axis=1) + (nu * psi).sum(axis=1)
         gap = np.abs(cs) / np.maximum(1.0, np.abs(dual))
         viol = np.where(CT == GE, np.maximum(-r, 0.0), np.where(CT == EQ, np.abs(r), 0.0)).max(axis=1)
-        scale = np.maximum(np.maximum(np.abs(psi).max(axis=1), np.abs(H).max(axis=1)), 1e-300)
+        scale = np.maximum(np.maximum(np.abs(psi).max(axis=1), np.abs(H).max(axis=1)), max(1e-12 * self._max_reserve(), 1e-300))
         infeas = viol / scale
         tolx = max(tol, 1e-12) * (1 + 1e-6) + 1e-15
         good = (gap <= tolx) & (infeas <= tolx)
@@ -984,6 +984,8 @@ class Problem:
                     ctx.set_pool_flagsG(k, None)
                 st = self._run(ctx, nu, total, tol=tol, **dict(kw, max_evals=budget))
             nu, psi = ctx.get_solution()
+            if not (np.all(np.isfinite(nu)) and np.all(nu > 0.0)):
+                break                      # a price has collapsed (a token to sell that no pool lists: the dual is unbounded) -- _finish says "infeasible"
             if st["status"] == 1:
                 if not tied:
                     return st, nu, psi
@@ -1086,7 +1088,92 @@ class Problem:
         ok = (res_eq <= 10 * tol) and (res_ge <= 10 * tol)
         return dict(zip(keys, th)), ok
 
-    def _finish(self, st, nu, psi, total):
+    def _max_reserve(self):
+        """largest reserve of the network (all ranks of a pool-sharded problem: the floor of a relative figure must not differ between them)"""
+        mr = getattr(self, "_rmax", None)
+        if mr is None:
+            mr = 0.0
+            for key in KIND2:
+                if key in self.net and len(self.net[key]["Ra"]):
+                    mr = max(mr, float(self.net[key]["Ra"].max()), float(self.net[key]["Rb"].max()))
+            for b in list(self.net.get("gn", {}).values()) + list(self.net.get("gk", {}).values()):
+                if b["R"].size:
+                    mr = max(mr, float(b["R"].max()))
+            if self._host:
+                mr = float(max(self._host.allgather(mr)))
+            self._rmax = mr
+        return mr
+
+    def _pool_token_arrays(self):
+        """(key, idx [k][m]) of every non-empty bucket: the token ids of its pools, leg by leg"""
+        out = []
+        for key in KIND2:
+            if key in self.net and len(self.net[key]["Ra"]):
+                out.append((key, np.stack([self.net[key]["ia"], self.net[key]["ib"]])))
+        for k, b in self.net.get("gn", {}).items():
+            if b["R"].shape[1]:
+                out.append((k, b["idx"]))
+        for key, b in self.net.get("gk", {}).items():
+            if b["R"].shape[1]:
+                out.append((key, b["idx"]))
+        return out
+
+    def _recover_worthless(self, st, nu, psi, total):
+        """Tokens worth NOTHING at the optimum -- no chain of pools leads from them to anything the utility values: a disconnected
+        component, a target no pool lists -- have prices that run to zero TOGETHER: the dual is flat along that ray, the ratios between
+        them never settle, and the pools among them trade at whatever ratio the last iterate had (found by tools/fuzz_small.py: such
+        instances came back "infeasible" although the program is feasible -- cvxpy solves them).  The primal side of that degeneracy
+        is simple: a pool ALL of whose tokens are worthless can be left untouched at no cost in the objective, and a worthless token that
+        must leave the trader's hands (an equality, liquidation.py:77-80) can be given to any pool that lists it (Delta > 0 with
+        Lambda = 0 only raises the pool's trading function: arbitrage.py:60,63-74).  Done here, on the host, on the tenders read back;
+        accepted only if the certificates then hold.  Returns True if they do (and _finish has been re-run on the repaired point)."""
+        u = self.utility
+        if _is_general(u):
+            return False
+        W = nu <= 1e-9 * float(nu.max())
+        if not W.any():
+            return False
+        tr = self._trades()
+        psi2 = psi.copy()                                 # (the tied pools' fills included, as in the tenders: _finish has added them)
+        zeroed, lister = {}, {}
+        for key, idx in self._pool_token_arrays():
+            allw = W[idx].all(axis=0)
+            for leg in range(idx.shape[0]):               # a pool to give token j to: the first that lists it
+                for pos in np.flatnonzero(W[idx[leg]]):
+                    lister.setdefault(int(idx[leg, pos]), (key, leg, int(pos)))
+            if not allw.any():
+                continue
+            d, l = tr[key]
+            y = (l - d)[:, allw]
+            np.add.at(psi2, idx[:, allw].ravel(), -y.ravel())
+            zeroed[key] = allw
+        r = psi2 + u.h
+        give = np.where(W & (u.ctype == EQ) & (r > 0.0), r, 0.0)
+        for j in np.flatnonzero(give):
+            if int(j) not in lister:
+                return False                              # (no pool lists it: truly infeasible)
+        if not zeroed and not give.any():
+            return False
+        psi2 = psi2 - give
+        saved = (self._theta, self._trade_cache)
+        self._theta = {}                                  # (psi2 already holds the fills)
+        self._finish(st, nu, psi2, total, _recovering=True)
+        if self.status != "optimal":
+            self._theta, self._trade_cache = saved
+            return False
+        # the tenders of the repaired point: the untouched pools at zero, the gifts on top
+        tr = {key: (d.copy(), l.copy()) for key, (d, l) in tr.items()}
+        for key, allw in zeroed.items():
+            tr[key][0][:, allw] = 0.0; tr[key][1][:, allw] = 0.0
+        for j in np.flatnonzero(give):
+            key, leg, pos = lister[int(j)]
+            tr[key][0][leg, pos] += give[j]
+        self._theta = saved[0]
+        self._trade_cache = tr
+        self.stats["worthless_tokens"] = int(W.sum())
+        return True
+
+    def _finish(self, st, nu, psi, total, _recovering=False):
         u = self.utility
         if self._theta:
             psi = psi.copy()
@@ -1121,13 +1208,14 @@ class Problem:
             # sum_i arb_i = nu'psi_pools; tied pools trade value-neutrally at their kink prices
             self.dual_value = nu_psi if plain else float((nu - u.c) @ u.h + nu @ psi)
             self.gap = abs(cs) / max(1.0, abs(self.dual_value))
+        floor = 1e-12 * self._max_reserve()       # (trades of rounding size at a no-arbitrage optimum: noise over noise is not an infeasibility)
         if plain:
             lo, hi = float(psi.min()), float(psi.max())
             viol = max(-lo, 0.0)
-            scale = max(hi, -lo, 1e-300)
+            scale = max(hi, -lo, floor, 1e-300)
         else:
             viol = float(np.where(u.ctype == GE, np.maximum(-r, 0.0), np.where(u.ctype == EQ, np.abs(r), 0.0)).max())
-            scale = max(float(np.abs(psi).max()), float(np.abs(u.h).max()), 1e-300)
+            scale = max(float(np.abs(psi).max()), float(np.abs(u.h).max()), floor, 1e-300)
         self.infeas = viol / scale
         self.nu, self.psi = nu, psi
         self.status = _lib.STATUS.get(st["status"], f"error {st['status']}")
@@ -1136,6 +1224,8 @@ class Problem:
         tolx = max(self._tol, 1e-12) * (1 + 1e-6) + 1e-15
         if self.gap <= tolx and self.infeas <= tolx:
             self.status = "optimal"
+        elif not _recovering and self._host is None and self._recover_worthless(st, nu, psi, total):
+            return self                       # (the certificates hold once the worthless component is taken out: _finish has run again)
         else:
             # the certificates do not hold.  A token that must be traded away but has no pool willing to take it shows
             # as a price collapsing to 0: report that as what it is; otherwise keep the device's verdict, or

@@ -190,6 +190,8 @@ struct cfmm_ctx {
     volatile unsigned long long *hstat_h = nullptr;     // pinned, device-mapped progress word (iterate.hpp: IterArgs::hstat)
     unsigned long long *hstat_d = nullptr;
     int run_ahead = 3;                 // CFMM_RUN_AHEAD: launches the host keeps enqueued beyond the last one the device reported
+    std::vector<char> listed;          // per token: some pool (of any rank) lists it -- the second-order path pins the others (listed_tokens)
+    bool listed_valid = false;
     // batched solves (cfmm_solve_batch): the per-solve update arguments, on the lead context
     UpdArgs *upd_batch_d = nullptr, *upd_batch_h = nullptr;
 
@@ -668,7 +670,7 @@ void local_extrema(cfmm_ctx *ctx)
 void pools_changed(cfmm_ctx *ctx)
 {
     local_extrema(ctx);
-    ctx->g_valid = false; ctx->g_counts_valid = false;
+    ctx->g_valid = false; ctx->g_counts_valid = false; ctx->listed_valid = false;
     ctx->hsol_valid = false; ctx->mu_last = 0.0; ctx->warm_mu = 0.0; ctx->slo_active = false;
 }
 
@@ -1334,7 +1336,8 @@ int refresh_global_counts(cfmm_ctx *ctx)
     ctx->g_table = table_sum_pools(ctx);       // (what the second-order path refuses: the method choice must agree across ranks)
     local_extrema(ctx);
     if (!sharded(ctx)) return CFMM_OK;
-    if (ctx->det) {                                  // the fixed-point exponent must be the same on every rank: global maxima
+    {                                                // the fixed-point exponent (reproducible mode) and the floor of the second-order path's relative
+                                                     // infeasibility must be the same on every rank: global maxima
         double mx[2] = {ctx->max_reserve, 1.0 / ctx->min_fee};
         double *dm = ctx->psi_t + 2;
         HIP_TRY(ctx, hipMemcpyAsync(dm, mx, sizeof mx, hipMemcpyHostToDevice, ctx->stream));
@@ -1523,6 +1526,40 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm, bool with_slo,
     return CFMM_OK;
 }
 
+// Tokens that NO pool lists.  The first-order iteration leaves their prices where they start (no gradient); the second-order path's
+// system has a zero row for them -- and, for a token the utility prices at zero, a barrier term -mu log nu_j with nothing to balance it:
+// the step diverges (found by tools/fuzz_small.py: small swap instances with an unlisted token ended "infeasible" after 200 steps).
+// They are pinned like CFMM_FREE tokens.  One pass over the id columns per pool set; pool-sharded: the union over the ranks.
+__global__ void __launch_bounds__(256) mark_tokens_kernel(const int *__restrict__ ids, long long count, double *__restrict__ mark)
+{
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256) mark[ids[i]] = 1.0;
+}
+int listed_tokens(cfmm_ctx *ctx)
+{
+    if (ctx->listed_valid) return CFMM_OK;
+    const int n = ctx->n;
+    double *mark = ctx->sm_vec;                    // [2n] scratch of the second-order path (smooth_buffers has run)
+    HIP_TRY(ctx, hipMemsetAsync(mark, 0, (size_t)n * sizeof(double), ctx->stream));
+    auto pass = [&](const int *ids, long long count) {
+        if (!ids || count <= 0) return;
+        const unsigned grid = (unsigned)std::min<long long>((count + 255) / 256, 4ll * ctx->cus);
+        hipLaunchKernelGGL(mark_tokens_kernel, dim3(grid), dim3(256), 0, ctx->stream, ids, count, mark);
+    };
+    const PoolStore &ps = *ctx->pools;
+    for (int k = 0; k < CFMM_POOL_KINDS2; ++k) { pass(ps.b2[k].ia, ps.b2[k].m); pass(ps.b2[k].ib, ps.b2[k].m); }
+    for (int k = 3; k <= CFMM_MAX_POOL_SIZE; ++k) pass(ps.bn[k].idx, (long long)k * ps.bn[k].m);
+    for (auto &row : ps.bg) for (int k = 2; k <= CFMM_MAX_POOL_SIZE; ++k) pass(row[k].idx, (long long)k * row[k].m);
+    HIP_TRY(ctx, hipGetLastError());
+    if (sharded(ctx)) { int rc = all_reduce(ctx, mark, (size_t)n, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc; }
+    std::vector<double> h(n);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), mark, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->listed.assign(n, 0);
+    for (int j = 0; j < n; ++j) ctx->listed[j] = h[j] != 0.0;
+    ctx->listed_valid = true;
+    return CFMM_OK;
+}
+
 struct SmoothEval { std::vector<double> psi; double value = 0.0, trade = 0.0; };
 
 int smooth_eval_host(cfmm_ctx *ctx, const std::vector<double> &nu, double mu, bool hess, SmoothEval &e, bool warm = true,
@@ -1606,13 +1643,19 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         HIP_TRY(ctx, hipMemcpyAsync(nu.data(), ctx->nu_acc, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if ((rc = listed_tokens(ctx))) return rc;
+    // flat[j]: the dual does not depend on nu_j at all -- no pool lists the token AND its offset is zero (one of the reference's
+    // linear-box kinds): pinned, and without its barrier term.  (Unlisted with h_j > 0, GE: nu_j h_j - mu log nu_j has its minimum
+    // at mu / h_j and follows the barrier to zero, the free-disposal optimum: left alone.)
+    std::vector<char> listed(n);
+    for (int j = 0; j < n; ++j) listed[j] = !(ct[j] < CFMM_ULOG && !ctx->listed[j] && h[j] == 0.0);
     long long nbar = 0;
     for (int k = 0; k < CFMM_POOL_KINDS2; ++k) nbar += 2 * ctx->pools->b2[k].m;
     nbar += 2 * ctx->pools->b2[CFMM_POOL_SUM2].m;
     for (int j = 0; j < n; ++j) {
-        mask[j] = ct[j] == CFMM_FREE;
+        mask[j] = ct[j] == CFMM_FREE || !listed[j];              // (a token the dual is flat in: its price stays where it starts)
         lob[j] = (ct[j] == CFMM_GE && c[j] > 0.0) ? std::log(c[j]) : -INFINITY;
-        if (ct[j] == CFMM_GE && !(c[j] > 0.0)) nbar += 1;
+        if (ct[j] == CFMM_GE && !(c[j] > 0.0) && listed[j]) nbar += 1;
         double sj = std::log(nu[j]);
         if (ct[j] == CFMM_FREE) {
             if (!(c[j] > 0.0)) return fail(ctx, CFMM_E_ARG, "solve: token %d is unconstrained (CFMM_FREE) with c = 0: unbounded", j);
@@ -1623,7 +1666,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     // (the pin mask goes down with every step's right-hand side; nothing reads sm_mask before that)
     if (sharded(ctx)) {                     // the barrier terms of the pools of every rank (the utility's are replicated)
         long long ge = 0;
-        for (int j = 0; j < n; ++j) ge += ct[j] == CFMM_GE && !(c[j] > 0.0);
+        for (int j = 0; j < n; ++j) ge += ct[j] == CFMM_GE && !(c[j] > 0.0) && listed[j];
         double cnt = (double)(nbar - ge);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_vec, &cnt, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         { int rc = all_reduce(ctx, ctx->sm_vec, 1, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc; }
@@ -1651,12 +1694,17 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
                 g += (p[j] - c[j]) * h[j];
                 Gj = p[j] * (e.psi[j] + h[j]);
             }
-            if (ct[j] == CFMM_GE && !(c[j] > 0.0)) {      // nu_j > 0: the barrier is -mu log nu_j, linear in the log-price
+            // (the diagonal's own term: d^2/ds^2 of nu_j (psi_j + h_j) at fixed psi is nu_j (psi_j + h_j) itself -- taken BEFORE the barrier's
+            //  -mu, which is linear in the log-price and has no curvature: with it folded in the entry vanished exactly where a barrier
+            //  token sits at its optimum nu_j = mu / (psi_j + h_j), and a token no pool lists -- nothing else on its row -- made the
+            //  system singular: tools/fuzz_small.py, a swap whose offered token is unlisted)
+            const double Gj_lin = Gj;
+            if (ct[j] == CFMM_GE && !(c[j] > 0.0) && listed[j]) {      // nu_j > 0: the barrier is -mu log nu_j, linear in the log-price
                 g -= mu * std::log(p[j]);
                 Gj -= mu;
             }
             if (grad) (*grad)[j] = mask[j] ? 0.0 : Gj;
-            if (hdiag) (*hdiag)[j] = std::max(Gj, 0.0) + hj;
+            if (hdiag) (*hdiag)[j] = std::max(Gj_lin, 0.0) + hj;
         }
         return g;
     };
@@ -1736,7 +1784,9 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             viol = std::max(viol, ct[j] == CFMM_GE ? std::max(-r, 0.0) : (ct[j] == CFMM_EQ ? std::fabs(r) : 0.0));
             scale = std::max(scale, std::max(std::fabs(e.psi[j]), std::fabs(h[j])));
         }
-        infeas = viol / std::max(scale, 1e-300);
+        // (relative to the larger of trade and offset -- but never to less than 1e-12 of the largest reserve: at a no-arbitrage optimum
+        //  the smoothed point's trades are rounding noise, and noise over noise is not an infeasibility; tools/fuzz_small.py)
+        infeas = viol / std::max(std::max(scale, 1e-12 * ctx->g_max_reserve), 1e-300);
         // sub = sum_i arb_i(nu) - nu'(L - D) >= 0 is the part of the gap the barrier weight controls (<= mu nbar);
         // the rest, the complementarity term cs, vanishes with the centring.  The weight stops shrinking as soon as
         // sub alone fits the tolerance: pushing it further only stiffens the smoothed dual (flows then react to price

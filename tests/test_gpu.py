@@ -367,6 +367,65 @@ def test_random_small_instances_vs_primal(seed):
     p.close()
 
 
+@pytest.mark.parametrize("seed,kw,value", [
+    (1313, dict(n_tokens=7, n_pools=10, with_sum=True, with_curve=False, with_power=False, utility="liquidate"), 24.4327269044),
+    (1367, dict(n_tokens=8, n_pools=8, with_sum=True, with_curve=True, with_power=False, utility="liquidate"), 0.0),
+    (1387, dict(n_tokens=7, n_pools=4, with_sum=True, with_curve=True, with_power=False, utility="swap"), 0.0),
+    (1091, dict(n_tokens=6, n_pools=5, with_sum=True, with_curve=True, with_power=False, utility="liquidate"), None),
+])
+def test_worthless_components_found_by_the_fuzz_campaign(seed, kw, value):
+    """tools/fuzz_small.py's finds.  Tokens from which no chain of pools leads to anything the utility values (a disconnected
+    component; a target no pool lists) have prices that run to zero together -- the dual is flat along that ray and the pools among them
+    trade at whatever ratio the last iterate had.  The program is FEASIBLE (a pool all of whose tokens are worthless can be left alone, a
+    worthless token that must go can be GIVEN to a pool that lists it: Delta > 0, Lambda = 0 -- cvxpy solves these, SLSQP too) and used
+    to come back "infeasible".  Now: optimal, SLSQP's value, tenders that add up to psi and keep every pool feasible.  Seed 1091 has a
+    token to sell that NO pool lists: that one IS infeasible, and says so instead of raising on a collapsed price."""
+    from oracle.primal_scipy import solve_primal
+    inst = random_instance(seed, **kw)
+    p = problem_of(inst)
+    v = p.solve(tol=1e-9)
+    if value is None:
+        assert p.status == "infeasible"
+        p.close()
+        return
+    assert p.status == "optimal" and p.gap <= 1e-9 and p.infeas <= 1e-9, (p.status, p.gap, p.infeas)
+    assert abs(v - value) <= 1e-8 * max(1.0, abs(value)) and p.stats["worthless_tokens"] >= 2
+    r = solve_primal(normalise_with_params(inst))
+    assert r["success"] and abs(r["value"] - v) <= 2e-6 * max(1.0, abs(v))
+    tot = np.zeros(inst["n_tokens"])
+    for li, R, g, kind, dd, ll in zip(inst["local_indices"], inst["reserves"], inst["fees"], inst["kinds"], p.deltas, p.lambdas):
+        np.add.at(tot, li, ll - dd)
+        assert np.all(dd >= 0) and np.all(ll >= 0)
+        x = np.asarray(R) + g * dd - ll
+        assert np.all(x > 0) or kind == "sum"
+        if kind == "sum":
+            assert np.all(x >= -1e-9) and x.sum() >= np.sum(R) * (1 - 1e-12)
+    assert np.abs(tot - p.psi).max() <= 1e-9 * max(1.0, np.abs(p.psi).max())
+    u = utility_of(inst)
+    rr = p.psi + u.h
+    assert np.all(np.where(u.ctype == 1, np.abs(rr), np.maximum(-rr, 0.0)) <= 1e-8 * max(1.0, np.abs(u.h).max()))
+    p.close()
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (1132, dict(n_tokens=7, n_pools=5, with_sum=False, with_curve=False, with_power=False, utility="swap")),
+    (1099, dict(n_tokens=4, n_pools=5, with_sum=True, with_curve=True, with_power=False, utility="swap")),
+    (1329, dict(n_tokens=5, n_pools=4, with_sum=True, with_curve=False, with_power=False, utility="arbitrage")),
+])
+def test_second_order_path_with_tokens_no_pool_lists(seed, kw):
+    """more of the campaign's finds: a token that NO pool lists and whose offset is zero has nothing on its row of the second-order
+    system but the barrier's -mu (the step ran away: "infeasible" after 200 steps) -- pinned now; and the diagonal's own term
+    nu_j (psi_j + h_j) is taken without the barrier's -mu (it vanished exactly at a barrier token's optimum: singular rows).
+    method="newton" and the default path reach the same certified optimum"""
+    inst = random_instance(seed, **kw)
+    p = problem_of(inst)
+    v = p.solve(tol=1e-9)
+    assert p.status == "optimal", (p.status, p.gap, p.infeas)
+    v2 = p.solve(tol=1e-8, method="newton")
+    assert p.status == "optimal" and p.stats["newton_steps"] <= 80 and abs(v2 - v) <= 1e-6 * max(1.0, abs(v)), (p.status, v, v2, p.stats)
+    p.close()
+
+
 def test_generic_bucket_power_sum_pools_end_to_end(oracle_lib):
     """SURVEY 8(f) rank 4 on the device: a trading function that exists in the library as ONE table entry (csrc/phi2.hpp:
     Phi2<4>, the power sum x^(1-t) + y^(1-t)) and rides in the generic two-asset bucket.  Its exact pool solution, its share of
