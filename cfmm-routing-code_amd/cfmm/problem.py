@@ -1130,23 +1130,33 @@ class Problem:
         u = self.utility
         if _is_general(u):
             return False
-        W = nu <= 1e-9 * float(nu.max())
-        if not W.any():
-            return False
-        tr = self._trades()
-        psi2 = psi.copy()                                 # (the tied pools' fills included, as in the tenders: _finish has added them)
+        # "worthless": a price far below the largest.  How far is not knowable in advance (the iteration stops somewhere down the
+        # ray) -- and need not be: the repair is accepted only if BOTH certificates hold afterwards, and leaving out a pool whose
+        # arbitrage value is not negligible breaks the gap.  So: the strictest threshold first, looser ones after it
+        for thr in (1e-9, 1e-7, 1e-5):
+            W = nu <= thr * float(nu.max())
+            if W.any() and self._recover_worthless_at(W, st, nu, psi, total):
+                return True
+        return False
+
+    def _recover_worthless_at(self, W, st, nu, psi, total):
+        u = self.utility
+        tr = self._trades()                               # (the tied pools' fills included)
+        # psi of the repaired point is re-summed from the tenders that are handed out, not patched: down a flat ray the prices end
+        # tens of orders of magnitude apart, and there the evaluation's psi and the tender kernel's need not agree on a worthless pool
+        psi2 = np.zeros(self.n)
         zeroed, lister = {}, {}
-        for key, idx in self._pool_token_arrays():
+        arrays = self._pool_token_arrays()
+        for key, idx in arrays:
             allw = W[idx].all(axis=0)
             for leg in range(idx.shape[0]):               # a pool to give token j to: the first that lists it
                 for pos in np.flatnonzero(W[idx[leg]]):
                     lister.setdefault(int(idx[leg, pos]), (key, leg, int(pos)))
-            if not allw.any():
-                continue
             d, l = tr[key]
-            y = (l - d)[:, allw]
-            np.add.at(psi2, idx[:, allw].ravel(), -y.ravel())
-            zeroed[key] = allw
+            keep = ~allw
+            np.add.at(psi2, idx[:, keep].ravel(), (l - d)[:, keep].ravel())
+            if allw.any():
+                zeroed[key] = allw
         r = psi2 + u.h
         give = np.where(W & (u.ctype == EQ) & (r > 0.0), r, 0.0)
         for j in np.flatnonzero(give):
@@ -1156,10 +1166,14 @@ class Problem:
             return False
         psi2 = psi2 - give
         saved = (self._theta, self._trade_cache)
+        names = ("value", "dual_value", "gap", "infeas", "nu", "psi", "status", "stats")
+        before = {k: getattr(self, k, None) for k in names}
         self._theta = {}                                  # (psi2 already holds the fills)
         self._finish(st, nu, psi2, total, _recovering=True)
-        if self.status != "optimal":
+        if self.status != "optimal":                      # not a repair: everything back as the solve left it
             self._theta, self._trade_cache = saved
+            for k, v in before.items():
+                setattr(self, k, v)
             return False
         # the tenders of the repaired point: the untouched pools at zero, the gifts on top
         tr = {key: (d.copy(), l.copy()) for key, (d, l) in tr.items()}
@@ -1204,6 +1218,8 @@ class Problem:
             # and the gap against it were computed on the device from an exact evaluation at nu
             self.dual_value = float(st["dual_value"])
             self.gap = abs(float(st["gap"]))
+            if _recovering:                   # (a repaired primal point: the duality gap against the device's exact dual value at nu)
+                self.gap = abs(self.dual_value - self.value) / max(1.0, abs(self.dual_value))
         else:
             # sum_i arb_i = nu'psi_pools; tied pools trade value-neutrally at their kink prices
             self.dual_value = nu_psi if plain else float((nu - u.c) @ u.h + nu @ psi)
