@@ -649,7 +649,7 @@ class Problem:
         infeas = viol / scale
         tolx = max(tol, 1e-12) * (1 + 1e-6) + 1e-15
         good = (gap <= tolx) & (infeas <= tolx)
-        collapsed = ((H > 0) & (nu < 1e-12 * nu.max(axis=1, keepdims=True))).any(axis=1)
+        collapsed = ((CT == EQ) & (H > 0) & ~self._listed_tokens()[None, :]).any(axis=1)      # (a token that must be sold and that no pool lists: _finish)
         results = []
         for b in range(B):
             st = sts[b]
@@ -829,9 +829,9 @@ class Problem:
         if general and n_sum:
             raise ValueError("a utility with ULOG / UQUAD entries over a network with constant-sum pools: the kink recovery ties prices, "
                              "the utility table's entries take no ties")
-        # (the K-asset table's constant-sum pools are first order only; its stableswap pools enter the second-order path with their exact
-        #  Hessian block: csrc/phik.hpp, gk_newton_kernel)
-        can_second = getattr(ctx, "second_order", False) and not any(kd == "sum" for kd, _ in self.net.get("gk", {}))
+        # (the K-asset table's pools are in the second-order path too: the stableswap entry with its exact Hessian block, the constant-sum
+        #  entry smoothed in price space -- csrc/phik.hpp: table_newton_kernel, gk_sum_newton_kernel)
+        can_second = getattr(ctx, "second_order", False)
         if method not in _lib.METHODS:
             raise ValueError(f"method {method!r}: expected one of {sorted(_lib.METHODS)}")
         # auto: many stableswap pools -> second order straight away (first order needs thousands of evaluations there);
@@ -843,7 +843,10 @@ class Problem:
                 st = self._run(ctx, nu0, total, tol=tol, method=_lib.METHODS["lbfgs"], **kw)
                 nu, psi = ctx.get_solution()
             else:
+                self._kinks_settled = False
                 st, nu, psi = self._solve_kinks(ctx, nu0, tol, dict(kw, method=_lib.METHODS["lbfgs"]), kink_tol, max_rounds, total)
+                if st["status"] == 1 and not self._kinks_settled:
+                    st = dict(st, status=2)       # (the last leg converged on a REDUCED dual whose ties did not yield their fills: not a solution)
             if method == "auto" and can_second and st["status"] != 1:
                 second_order = True
                 if self._dev_ties:
@@ -861,7 +864,17 @@ class Problem:
 
     @staticmethod
     def _run(ctx, nu, total, **kw):
-        st = ctx.solve(nu, **kw)
+        try:
+            st = ctx.solve(nu, **kw)
+        except CfmmError as e:
+            # an iteration that ran into non-finite numbers (a degenerate instance: prices hundreds of orders of magnitude apart) is a
+            # solve that did not converge, not a crash of the caller: reported as "stalled", and `method="auto"` goes on to the
+            # second-order path (tools/fuzz_table.py)
+            if "finite" not in str(e):
+                raise
+            st = dict(evals=0, iters=0, status=2, n_ranks=1, dual_value=float("nan"), primal_value=float("nan"), gap=float("inf"), infeas=float("inf"),
+                      wall_seconds=0.0, device_seconds=0.0, pg=float("nan"), pool_subproblems=0, barrier_mu=0.0, newton_steps=0,
+                      method=kw.get("method", 0), numeric_error=str(e))
         total["evals"] += st["evals"]; total["iters"] += st["iters"]; total["rounds"] += 1
         total["wall_seconds"] += st["wall_seconds"]; total["device_seconds"] += st["device_seconds"]
         return st
@@ -920,7 +933,10 @@ class Problem:
             srt = np.argsort(lnu, axis=0, kind="stable")
             a1, a2 = srt[0], srt[1]
             gap = lnu[a2, np.arange(m)] - lnu[a1, np.arange(m)]
-            sw = (gap < kink_tol) & ((gap < 0.5 * np.abs(lg)) | (lg == 0.0) | loose)
+            # (only where the pool PAYS something at these prices -- some token worth more than the cheapest after the fee: a pool that
+            #  does not trade has no kink there, and tying its two cheapest prices only takes a degree of freedom from the dual)
+            pays = (lnu + lg[None, :] > lnu[a1, np.arange(m)][None, :] + 1e-12).sum(axis=0) > 0
+            sw = pays & (gap < kink_tol) & ((gap < 0.5 * np.abs(lg)) | (lg == 0.0) | loose)
             for i in np.flatnonzero(sw):
                 i = int(i)
                 ja, jb = sorted((int(a1[i]), int(a2[i])))         # (equal prices: the device takes the lower leg as the payer)
@@ -988,12 +1004,23 @@ class Problem:
                 break                      # a price has collapsed (a token to sell that no pool lists: the dual is unbounded) -- _finish says "infeasible"
             if st["status"] == 1:
                 if not tied:
+                    self._kinks_settled = True
                     return st, nu, psi
+                # a K-asset record is a statement about the pool's CHEAPEST token (leg j drained where gamma nu_j = nu_lo; the two
+                # cheapest tied): if the prices have since made another token the cheapest, the flagged leg is no longer on a kink --
+                # it would be drained outright through the new cheapest token, value the reduced dual does not see (tools/fuzz_table.py:
+                # a "certified" optimum below SLSQP's feasible point).  Such ties are dropped and the leg repeated
+                stale = [k for k, rec in tied.items() if k[1] != 2 and not self._kink_still_stands(nu, k, rec)]
+                if stale:
+                    for k in stale:
+                        del tied[k]
+                    continue
                 self._refresh_switches(nu, tied)
                 theta, ok = self._recover_fills(nu, psi, tied, tol)
-                bad = [k for k in tied if not (1e-9 < theta[k] < 1 - 1e-9)]
+                bad = [k for k in tied if not (1e-9 < theta[k] < 1 - 1e-9) or (tied[k]["sgn"] == 0 and not tied[k]["Rb"] > 0.0)]      # (a switch record with nothing to move)
                 if ok and not bad:
                     self._theta = {k: (tied[k], theta[k]) for k in tied}
+                    self._kinks_settled = True
                     return st, nu, psi
                 if bad:                   # fully on / fully off after all: back to bang-bang
                     for k in bad:
@@ -1003,6 +1030,15 @@ class Problem:
                         # resolve and the optimum sits on its OTHER kink (arbitrage.py / liquidation.py: fee 0.999)
                         if k[1] == 2 and rec.get("loose") and theta[k] <= 1e-9 and (k, -rec["sgn"]) not in banned:
                             tied[k] = dict(rec, sgn=-rec["sgn"], loose=False)
+                        # the K-asset analogue: a guessed DRAIN kink (gamma nu_j = nu_lo) that carries no trade -- inside the fee band the
+                        # pool's other kink on that pair is the SWITCH (nu_j = nu_lo: j pays alongside lo), tools/fuzz_table.py seed 256
+                        elif k[1] != 2 and rec["sgn"] == 1 and theta[k] <= 1e-9:
+                            ja, jb = sorted((rec["leg_lo"], k[3]))
+                            k2 = (k[0], k[1], k[2], 100 + 10 * ja + jb)
+                            if k2 not in tied and (k2, 0) not in banned:
+                                bb = self.net["gk"][("sum", k[1])]
+                                tied[k2] = dict(sgn=0, ia=int(bb["idx"][ja, k[2]]), ib=int(bb["idx"][jb, k[2]]), fee=rec["fee"], Ra=0.0, Rb=0.0,
+                                                loose=False, leg_a=ja, leg_b=jb, pool=k[2], k=k[1])
                     tied = dict(sorted(tied.items()))
                     continue
             new = self._kink_candidates(nu, kink_tol, banned, tied)
@@ -1023,6 +1059,13 @@ class Problem:
             else:
                 break
         return st, nu, psi
+
+    def _kink_still_stands(self, nu, key, rec):
+        b = self.net["gk"][("sum", key[1])]
+        lnu = np.log(nu[b["idx"][:, key[2]]])
+        lo = float(lnu.min())
+        legs = (rec["leg_a"], rec["leg_b"]) if rec["sgn"] == 0 else (rec["leg_lo"],)
+        return all(lnu[j] <= lo + 1e-9 for j in legs)
 
     def _refresh_switches(self, nu, tied):
         """the payment a K-asset constant-sum pool's cheapest token makes at the prices nu (what the device evaluated): the reserves of
@@ -1087,6 +1130,18 @@ class Problem:
         res_ge = np.maximum(-(nu[ge_b] * tot[ge_b]), 0.0).sum() / scale if ge_b.any() else 0.0
         ok = (res_eq <= 10 * tol) and (res_ge <= 10 * tol)
         return dict(zip(keys, th)), ok
+
+    def _listed_tokens(self):
+        """per token: some pool (of any rank) lists it"""
+        ls = getattr(self, "_listed", None)
+        if ls is None:
+            ls = np.zeros(self.n, dtype=bool)
+            for _, idx in self._pool_token_arrays():
+                ls[idx.ravel()] = True
+            if self._host:
+                ls = np.any(np.stack(self._host.allgather(ls)), axis=0)
+            self._listed = ls
+        return ls
 
     def _max_reserve(self):
         """largest reserve of the network (all ranks of a pool-sharded problem: the floor of a relative figure must not differ between them)"""
@@ -1243,11 +1298,13 @@ class Problem:
         elif not _recovering and self._host is None and self._recover_worthless(st, nu, psi, total):
             return self                       # (the certificates hold once the worthless component is taken out: _finish has run again)
         else:
-            # the certificates do not hold.  A token that must be traded away but has no pool willing to take it shows
-            # as a price collapsing to 0: report that as what it is; otherwise keep the device's verdict, or
-            # "inaccurate" if it believed it had converged
-            collapsed = (u.h > 0) & (nu < 1e-12 * nu.max())
-            if collapsed.any():
+            # the certificates do not hold.  A token that MUST leave the trader's hands (an equality with h > 0, liquidation.py:77-80)
+            # and that no pool lists cannot: the program is infeasible, and is reported as that.  (Round 5: this used to be read off a
+            # price collapsing to zero -- which is also what a WORTHLESS token's price does in a feasible program; any listed token can be
+            # given to a pool, so the structural test is the whole of it.)  Otherwise the device's verdict stands, or "inaccurate" if it
+            # believed it had converged
+            stuck = (u.ctype == EQ) & (u.h > 0) & ~self._listed_tokens()
+            if stuck.any():
                 self.status = "infeasible"
             elif self.status == "optimal":
                 self.status = "inaccurate"

@@ -1154,10 +1154,17 @@ int bounds_into_mirror(cfmm_ctx *ctx)
     const int n = ctx->n, ng = ctx->ng;
     double *lo = (double *)(ctx->util_h + ((char *)ctx->glo - (char *)ctx->c)), *hi = (double *)(ctx->util_h + ((char *)ctx->ghi - (char *)ctx->c));
     for (int r = 0; r < ng; ++r) { lo[r] = -INFINITY; hi[r] = INFINITY; }
+    // A price the utility does not bound (c = 0; an equality) is still kept within e^+-600 of the utility's own scale: a WORTHLESS token's
+    // log-price otherwise runs off until nu underflows to zero and the pool arithmetic turns it into NaNs -- "dual value is not finite"
+    // instead of a stalled solve the caller can classify (tools/fuzz_table.py: a liquidation whose target no pool lists)
+    double cmax = 0.0;
+    for (int j = 0; j < n; ++j) if (ctx->hctype[j] < CFMM_ULOG) cmax = std::max(cmax, ctx->hc[j]);
+    const double mid = cmax > 0.0 ? std::log(cmax) : 0.0, span = 600.0;
     for (int j = 0; j < n; ++j) {
         const int r = ctx->hgrp[j];
-        double l = -INFINITY, u = INFINITY;
-        if (ctx->hctype[j] == CFMM_GE) l = ctx->hc[j] > 0.0 ? std::log(ctx->hc[j]) : -INFINITY;
+        double l = mid - span, u = mid + span;
+        if (ctx->hctype[j] >= CFMM_ULOG) { l = -INFINITY; u = INFINITY; }       // (the utility table's entries: no bound; their conjugates hold the price)
+        if (ctx->hctype[j] == CFMM_GE) { l = ctx->hc[j] > 0.0 ? std::log(ctx->hc[j]) : mid - span; u = INFINITY; }
         else if (ctx->hctype[j] == CFMM_FREE) {
             if (!(ctx->hc[j] > 0.0)) return fail(ctx, CFMM_E_ARG, "token %d: CFMM_FREE needs c > 0", j);
             l = u = std::log(ctx->hc[j]);
@@ -1310,7 +1317,6 @@ bool newton_supported(cfmm_ctx *ctx, const char **why)
 {
     if (ctx->ng != ctx->n) { *why = "price ties are set"; return false; }
     // (pool-sharded: the GLOBAL count, refresh_global_counts -- every rank must take the same branch)
-    if (table_sum_pools(ctx) > 0 || (sharded(ctx) && ctx->g_counts_valid && ctx->g_table > 0)) { *why = "the network holds constant-sum pools of the K-asset table (phik.hpp): first-order path only"; return false; }
     // (the Hessian instantiation of smooth_kernel carries the diagonal / pair cache on top of the psi tile: 24 n + 24832 bytes,
     //  i.e. 5792 tokens -- not the (2 n + 32) doubles of the round-2 kernel, which let 5.8k .. 10.2k tokens through to a launch
     //  failure)
@@ -1517,6 +1523,17 @@ int launch_smooth(cfmm_ctx *ctx, double mu, bool hess, bool warm, bool with_slo,
         switch (k) { GK_LAUNCH(2) GK_LAUNCH(3) GK_LAUNCH(4) GK_LAUNCH(5) GK_LAUNCH(6) GK_LAUNCH(7) default: GK_LAUNCH(8) }
 #undef GK_LAUNCH
     }
+    // ... and its constant-sum pools, smoothed in price space with the path's barrier weight (phik.hpp: gk_sum_newton_kernel)
+    for (int k = 2; k <= CFMM_MAX_POOL_SIZE; ++k) {
+        const BucketG &bq = ctx->pools->bg[CFMM_POOLK_SUM][k];
+        if (!bq.m) continue;
+        const dim3 g2((unsigned)std::min<long long>((bq.m + 255) / 256, 8LL * ctx->cus)), blk(256);
+        const double *nup = ctx->nu;
+#define GQ_LAUNCH(KK) case KK: if (hess) hipLaunchKernelGGL((gk_sum_newton_kernel<KK, true>), g2, blk, 0, ctx->stream, bq, nup, a.slo, mu, ctx->sm_out, n, ctx->H, a.ldh); \
+                           else hipLaunchKernelGGL((gk_sum_newton_kernel<KK, false>), g2, blk, 0, ctx->stream, bq, nup, a.slo, mu, ctx->sm_out, n, (double *)nullptr, a.ldh); break;
+        switch (k) { GQ_LAUNCH(2) GQ_LAUNCH(3) GQ_LAUNCH(4) GQ_LAUNCH(5) GQ_LAUNCH(6) GQ_LAUNCH(7) default: GQ_LAUNCH(8) }
+#undef GQ_LAUNCH
+    }
     HIP_TRY(ctx, hipGetLastError());
     if (sharded(ctx)) {                     // pool-sharded: every rank needs the whole [psi | value | trade] and the whole Hessian
         int rc = all_reduce(ctx, ctx->sm_out, (size_t)(n + 2), NCCL_FLOAT64, NCCL_SUM);
@@ -1652,6 +1669,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     long long nbar = 0;
     for (int k = 0; k < CFMM_POOL_KINDS2; ++k) nbar += 2 * ctx->pools->b2[k].m;
     nbar += 2 * ctx->pools->b2[CFMM_POOL_SUM2].m;
+    for (int k = 2; k <= CFMM_MAX_POOL_SIZE; ++k) nbar += (long long)k * ctx->pools->bg[CFMM_POOLK_SUM][k].m;      // (phik.hpp: the smoothed constant-sum entry costs at most mu K)
     for (int j = 0; j < n; ++j) {
         mask[j] = ct[j] == CFMM_FREE || !listed[j];              // (a token the dual is flat in: its price stays where it starts)
         lob[j] = (ct[j] == CFMM_GE && c[j] > 0.0) ? std::log(c[j]) : -INFINITY;
@@ -2587,8 +2605,9 @@ int cfmm_get_tradesG(cfmm_ctx *ctx, int kind, int k, double *delta, double *lamb
     const double *nu = ctx->nu_acc;
     const int *fl = kind == CFMM_POOLK_SUM ? ctx->flagsG[k] : nullptr;
     const double *slo = (ctx->mu_last > 0.0 && ctx->slo_active) ? ctx->sm_slo : nullptr;       // (as cfmm_get_tradesN)
-#define GK_T1(KIND_, KK) case KK: hipLaunchKernelGGL((tradesg_kernel<KIND_, KK>), grid, blk, 0, ctx->stream, b, fl, nu, slo, dd, dl); break;
-#define GK_T(KIND_) switch (k) { GK_T1(KIND_, 2) GK_T1(KIND_, 3) GK_T1(KIND_, 4) GK_T1(KIND_, 5) GK_T1(KIND_, 6) GK_T1(KIND_, 7) default: hipLaunchKernelGGL((tradesg_kernel<KIND_, 8>), grid, blk, 0, ctx->stream, b, fl, nu, slo, dd, dl); break; }
+    const double mu = ctx->mu_last > 0.0 ? ctx->mu_last : 0.0;     // (behind a second-order solve: the constant-sum entry's smoothed tenders)
+#define GK_T1(KIND_, KK) case KK: hipLaunchKernelGGL((tradesg_kernel<KIND_, KK>), grid, blk, 0, ctx->stream, b, fl, nu, slo, mu, dd, dl); break;
+#define GK_T(KIND_) switch (k) { GK_T1(KIND_, 2) GK_T1(KIND_, 3) GK_T1(KIND_, 4) GK_T1(KIND_, 5) GK_T1(KIND_, 6) GK_T1(KIND_, 7) default: hipLaunchKernelGGL((tradesg_kernel<KIND_, 8>), grid, blk, 0, ctx->stream, b, fl, nu, slo, mu, dd, dl); break; }
     if (kind == CFMM_POOLK_STABLE) { GK_T(CFMM_POOLK_STABLE) } else { GK_T(CFMM_POOLK_SUM) }
 #undef GK_T1
 #undef GK_T
@@ -3635,9 +3654,12 @@ int cfmm_solve_sweep(cfmm_ctx *ctx, int B, const double *c, const double *h, con
             if (!S.tied.empty()) { ng = ties.groups(grp); for (int j = 0; j < n; ++j) off[j] = ties.off[j]; }
             else for (int j = 0; j < n; ++j) { grp[j] = j; off[j] = 0.0; }
             for (int r = 0; r < n; ++r) { glo[r] = -INFINITY; ghi[r] = INFINITY; }
+            double scmax = 0.0;
+            for (int j = 0; j < n; ++j) scmax = std::max(scmax, A[j]);
+            const double smid = scmax > 0.0 ? std::log(scmax) : 0.0;
             for (int j = 0; j < n; ++j) {                 // (bounds_into_mirror)
-                double l = -INFINITY, u = INFINITY;
-                if (ct[j] == CFMM_GE) l = A[j] > 0.0 ? std::log(A[j]) : -INFINITY;
+                double l = smid - 600.0, u = smid + 600.0;                // (as bounds_into_mirror: no price runs off to an underflow)
+                if (ct[j] == CFMM_GE) { l = A[j] > 0.0 ? std::log(A[j]) : smid - 600.0; u = INFINITY; }
                 else if (ct[j] == CFMM_FREE) l = u = std::log(A[j]);
                 l -= off[j]; u -= off[j];
                 if (l > glo[grp[j]]) glo[grp[j]] = l;

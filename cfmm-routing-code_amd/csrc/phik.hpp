@@ -758,16 +758,114 @@ gk_newton_kernel(BucketG b, const double *__restrict__ nu, const double *__restr
     if ((threadIdx.x & 63) == 0 && vsum != 0.0) { unsafeAtomicAdd(&out[n], vsum); unsafeAtomicAdd(&out[n + 1], vsum); }
 }
 
+// ---- the constant-sum entry in the second-order path: smoothed in PRICE space (round 5) -------------------------------------------
+// arbitrage.py:73-74 over K tokens is an LP per pool, and in the dual it is the piecewise-linear
+//     arb(nu) = sum_j R_j (nu_j - m / gamma)_+ ,   m = min_k nu_k
+// (every token worth more than the cheapest after the fee is drained, the cheapest pays).  Its kinks -- a leg drained only partly, two
+// tokens tied for cheapest -- are what the first-order path's active-set loop chases (cfmm/problem.py) and, on small networks whose
+// tokens differ in value, often does not catch (tools/fuzz_table.py).  The second-order path takes the pool SMOOTHED, with the path's own
+// barrier weight mu (value units):  (z)_+  ->  mu softplus(z / mu)  per leg,  min  ->  the soft minimum  m_mu = -mu' log sum exp(-nu_k / mu')
+// with mu' = mu gamma / sum R (price units: the payment is at most sum R / gamma, so this term too costs at most mu log K of value).
+// arb_mu is smooth and convex (a non-decreasing convex function of the convex nu_j - m_mu / gamma), arb <= arb_mu, and its gradient
+//     y_j = R_j sigma_j - w_j P / gamma,   sigma_j = sigmoid(z_j / mu),  P = sum_i R_i sigma_i,  w = the soft minimum's weights
+// is a FEASIBLE tender of the pool for every mu: Lambda_j = R_j sigma_j <= R_j, Delta_k = w_k P / gamma, sum gamma Delta = sum Lambda
+// -- partial drains and split payments come out of it without any active set.  arb(nu) - nu'y <= mu (0.28 K + log K) <= mu K: the pool
+// counts K barrier terms in the path's gap bound.  Hessian in prices:  M = sum_i a_i u_i u_i' + (P / gamma) (diag(w) - w w') / mu',
+// a_i = sigma_i (1 - sigma_i) R_i^2 / mu,  u_i = e_i - w / gamma;  in log-prices nu_j nu_k M_jk (+ the caller's diagonal nu_j y_j).
+template <int K> struct SumSmooth { double w[K], sg[K], a[K], y[K], val, trade, P, Sa, imup; };
+template <int K>
+__host__ __device__ inline void sum_smooth_k(const double (&R)[K], const double (&p)[K], double g, double mu, SumSmooth<K> &o)
+{
+    double Rs = 0.0, pmin = p[0];
+    for (int j = 0; j < K; ++j) { Rs += R[j]; pmin = fmin(pmin, p[j]); }
+    const double imup = fmin(Rs / (mu * g), 1e300);            // (finite: a zero-value optimum drives mu towards 0, and 0 x inf below would be a NaN)
+    double sw = 0.0;
+    for (int k = 0; k < K; ++k) { o.w[k] = exp(-(p[k] - pmin) * imup); sw += o.w[k]; }
+    const double isw = 1.0 / sw;
+    for (int k = 0; k < K; ++k) o.w[k] *= isw;
+    const double m = pmin - log(sw) / imup, ig = 1.0 / g, imu = fmin(1.0 / mu, 1e300);
+    double P = 0.0, val = 0.0, Sa = 0.0;
+    for (int j = 0; j < K; ++j) {
+        const double z = R[j] * (p[j] - m * ig) * imu;
+        double sg, sp;
+        if (z >= 0.0) { const double e = exp(-z); sg = 1.0 / (1.0 + e); sp = z + log1p(e); }
+        else { const double e = exp(z); sg = e / (1.0 + e); sp = log1p(e); }
+        o.sg[j] = sg; o.a[j] = sg * (1.0 - sg) * R[j] * R[j] * imu;
+        val += mu * sp; P += R[j] * sg; Sa += o.a[j];
+    }
+    double tr = 0.0;
+    for (int j = 0; j < K; ++j) { o.y[j] = R[j] * o.sg[j] - o.w[j] * P * ig; tr += p[j] * o.y[j]; }
+    o.val = val; o.trade = tr; o.P = P; o.Sa = Sa; o.imup = imup;
+}
+// M_jk of the pool (price space)
+template <int K>
+__host__ __device__ inline double sum_smooth_hess(const SumSmooth<K> &o, double g, int j, int k)
+{
+    const double ig = 1.0 / g, pb = o.P * ig * o.imup;
+    return (j == k ? o.a[j] + pb * o.w[j] : 0.0) - (o.a[j] * o.w[k] + o.a[k] * o.w[j]) * ig + o.w[j] * o.w[k] * (o.Sa * ig * ig - pb);
+}
+template <int K, bool HESS>
+__global__ void __launch_bounds__(256)
+gk_sum_newton_kernel(BucketG b, const double *__restrict__ nu, const double *__restrict__ slo, double mu, double *__restrict__ out, int n,
+                     double *__restrict__ H, int ldh)
+{
+    double vsum = 0.0, tsum = 0.0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < b.m; i += (long long)gridDim.x * blockDim.x) {
+        double R[K], p[K];
+        int tok[K];
+        for (int j = 0; j < K; ++j) { tok[j] = b.idx[i * K + j]; R[j] = b.R[i * K + j]; p[j] = nu[tok[j]]; }
+        const double g = b.fee[i];
+        SumSmooth<K> o;
+        sum_smooth_k<K>(R, p, g, mu, o);
+        for (int j = 0; j < K; ++j) {
+            double y = o.y[j];
+            if (slo) for (int k = 0; k < K; ++k) y += sum_smooth_hess<K>(o, g, j, k) * p[k] * slo[tok[k]];      // first-order response to the low-order log-prices
+            unsafeAtomicAdd(&out[tok[j]], y); tsum += p[j] * y;
+        }
+        vsum += o.val;
+        if (HESS) {
+            for (int j = 0; j < K; ++j)
+                for (int k = 0; k <= j; ++k) {
+                    const double h = p[j] * p[k] * sum_smooth_hess<K>(o, g, j, k);
+                    const int row = tok[j] > tok[k] ? tok[j] : tok[k], col = tok[j] > tok[k] ? tok[k] : tok[j];
+                    unsafeAtomicAdd(&H[(size_t)col * ldh + row], h);
+                }
+        }
+    }
+    vsum = wave_allsum(vsum); tsum = wave_allsum(tsum);
+    if ((threadIdx.x & 63) == 0) { if (vsum != 0.0) unsafeAtomicAdd(&out[n], vsum); if (tsum != 0.0) unsafeAtomicAdd(&out[n + 1], tsum); }
+}
+
 // tenders at the accepted prices, slot-major [K][m] as the C-ABI hands them out (two-asset.py:94,98); flags: as tileg_sum;
 // slo: the low-order log-prices a second-order solve ended with (the tenders must be those of the same point as psi)
 template <int KIND, int K>
 __global__ void __launch_bounds__(GK_THREADS)
-tradesg_kernel(BucketG b, const int *flags, const double *__restrict__ nu, const double *__restrict__ slo, double *__restrict__ delta, double *__restrict__ lambda)
+tradesg_kernel(BucketG b, const int *flags, const double *__restrict__ nu, const double *__restrict__ slo, double mu, double *__restrict__ delta, double *__restrict__ lambda)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.m) return;
     double R[K], p[K], y[K];
     for (int j = 0; j < K; ++j) { R[j] = b.R[i * K + j]; p[j] = nu[b.idx[i * K + j]]; }
+    if (KIND == 1 && mu > 0.0) {
+        // behind a second-order solve: the smoothed pool's own tenders (gk_sum_newton_kernel), GROSS -- a leg may both receive its
+        // R_j sigma_j and pay its share w_j P / gamma (arbitrage.py:51-52 allows both; netting them would claim a fee that was not paid)
+        const double g = b.fee[i];
+        SumSmooth<K> o;
+        sum_smooth_k<K>(R, p, g, mu, o);
+        // first-order response to the low-order log-prices, of the receipts and of the payments SEPARATELY (their difference is the
+        // M dp of gk_sum_newton_kernel; split like this the pool's constraint sum(gamma dDelta - dLambda) = 0 holds to rounding):
+        // dLambda_j = R_j sigma_j (1 - sigma_j) R_j (dp_j - dm / gamma) / mu,  dm = w'dp,  dw_k = -w_k (dp_k - dm) / mu',
+        // dDelta_k = (dw_k P + w_k dP) / gamma,  dP = sum dLambda
+        double dL[K], dp[K], dm = 0.0, dP = 0.0;
+        for (int k = 0; k < K; ++k) { dp[k] = slo ? p[k] * slo[b.idx[i * K + k]] : 0.0; dm += o.w[k] * dp[k]; }
+        for (int j = 0; j < K; ++j) { dL[j] = o.a[j] * (dp[j] - dm / g); dP += dL[j]; }         // (a_j = sigma (1 - sigma) R^2 / mu)
+        for (int j = 0; j < K; ++j) {
+            const double dl = R[j] * o.sg[j] + dL[j];
+            const double dd = (o.w[j] * (o.P + dP) - o.w[j] * (dp[j] - dm) * o.imup * o.P) / g;
+            delta[(size_t)j * b.m + i] = fmax(dd, 0.0); lambda[(size_t)j * b.m + i] = fmax(dl, 0.0);
+        }
+        return;
+    }
     if (KIND == 0 && slo) {
         double x[K], sl[K], dy[K]; int side[K]; StableSol sol;
         const double g = b.fee[i];

@@ -62,8 +62,27 @@ def test_table_pools_evaluation_tenders_and_invariants(oracle_lib):
             assert (np.abs(l - d).sum(axis=0) > 0).mean() > 0.5
         else:
             assert np.all(x >= -1e-9 * b["R"].max()) and np.abs(x.sum(axis=0) - b["R"].sum(axis=0)).max() <= 1e-9 * b["R"].sum(axis=0).max()
-    with pytest.raises(cfmm.CfmmError, match="first-order path only"):      # (its constant-sum table pools: the stableswap ones are taken)
-        p.solve(method="newton")
+    # both outer iterations take the table's pools (round 5: the constant-sum entry enters the second-order path smoothed in price space)
+    v1 = p.solve(tol=1e-6, max_evals=4000)
+    assert p.status == "optimal", (p.status, p.gap, p.infeas)
+    v2 = p.solve(tol=1e-6, method="newton")
+    assert p.status == "optimal" and p.stats["method"] == _lib.METHODS["newton"] and abs(v2 - v1) <= 2e-6 * abs(v1), (p.status, v1, v2, p.gap, p.infeas)
+    tot = np.zeros(n)
+    for (kind, k), b in net["gk"].items():
+        d, l = p.bucket_trades((kind, k))
+        assert np.all(d >= 0) and np.all(l >= 0)
+        x = b["R"] + b["fee"][None, :] * d - l
+        if kind == "sum":                  # the smoothed pool's tenders are feasible for the pool (gross: a leg may receive AND pay)
+            assert np.all(x >= -1e-9 * b["R"].max()) and np.all(x.sum(axis=0) >= b["R"].sum(axis=0) * (1 - 1e-12))
+        np.add.at(tot, b["idx"].ravel(), (l - d).ravel())
+    for key in ("cp2", "w2"):
+        if key in net:
+            d, l = p.bucket_trades(key)
+            np.add.at(tot, net[key]["ia"], l[0] - d[0]); np.add.at(tot, net[key]["ib"], l[1] - d[1])
+    for k, b in net.get("gn", {}).items():
+        d, l = p.bucket_trades(k)
+        np.add.at(tot, b["idx"].ravel(), (l - d).ravel())
+    assert np.abs(tot - p.psi).max() <= 1e-8 * np.abs(p.psi).max()
     p.close()
 
 
