@@ -114,6 +114,7 @@ def make_network(n_tokens, m_cp2=0, m_w2=0, m_gn=0, m_curve2=0, seed=0, zipf_s=N
         ib = (ia // 4) * 4 + (ia % 4 + rng.integers(1, 4, size=m_curve2)) % 4
         ib = np.minimum(ib, n - 1)
         ib = np.where(ib == ia, (ia // 4) * 4, ib)
+        ib = np.where(ib == ia, np.maximum(ia - 1, 0), ib)      # (n = 4q + 1: the last token is a peg group of its own -- pair it with its neighbour)
         ia = ia.astype(np.int32); ib = ib.astype(np.int32)
         L = value(m_curve2)
         Ra = L / pi[ia] * np.exp(rng.normal(0.0, mispricing, m_curve2))
