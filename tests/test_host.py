@@ -171,7 +171,7 @@ def test_committed_bench_lines_keep_the_contract(cfg):
         assert abs(rf["rocprof_avg_launch_us"] - rf["avg_launch_us"]) <= 0.12 * rf["avg_launch_us"]     # the chain: trace x launches against HIP events
         assert d["ms_per_step"] <= 4.6                # (round 2: 13.6, round 3: 6.6, round 4: 4.1-4.2)
         sp = d["start_prices"]                        # memoised start prices said out loud, with the un-memoised time beside it
-        assert sp["ms_per_step_memoised"] == d["ms_per_step"] and sp["ms_per_step_recomputed"] >= sp["ms_per_step_memoised"]
+        assert sp["ms_per_step_memoised"] == d["ms_per_step"] and sp["ms_per_step_recomputed"] >= 0.93 * sp["ms_per_step_memoised"]      # (O(n) extra: within the run-to-run noise of two 10-step timings)
         assert "EVALUATIONS only" in d["cpu_baseline"]["measures"]
     else:
         # `frac` prices the algorithmic bytes (the contract), `hbm_frac` the bytes as stored: equal unless a compact mirror exists
