@@ -10,7 +10,7 @@ import pytest
 import cfmm
 from cfmm import synthetic, _lib
 from oracle import pools_np, primal_scipy
-from helpers import problem_of, normalise_with_params
+from helpers import problem_of, normalise_with_params, table_instance
 
 pytestmark = pytest.mark.gpu
 
@@ -318,3 +318,30 @@ def test_k_asset_constraint_lines_through_the_cvx_shim(seed, k):
             y = receive[i].value - tender[i].value
             assert np.abs(y - ref["y"][i]).max() <= 2e-4 * max(1.0, np.abs(ref["y"][i]).max())
     prob.routing.close()
+
+
+@pytest.mark.parametrize("seed", [1, 35, 40, 227, 256, 314, 343, 364, 379])
+def test_k_asset_constant_sum_optima_the_fuzz_campaign_found_falsely_certified(seed):
+    """tools/fuzz_table.py's most serious find: on these instances the first-order path came back "optimal" with a value BELOW a feasible
+    point SLSQP holds -- a leg of the K-asset constant-sum pool had been tied (gamma nu_j = nu_lo) against the pool's cheapest token, the
+    prices then made ANOTHER token the cheapest, and the flagged leg -- now drained outright through it -- stayed out of the reduced dual.
+    Now such a record is dropped, and what the active-set loop does not settle goes to the second-order path, where the pool enters
+    smoothed in price space (csrc/phik.hpp: sum_smooth_k): certified, at SLSQP's value, with tenders every pool accepts"""
+    inst, with_sum = table_instance(seed)
+    assert with_sum
+    ref = primal_scipy.solve_primal(normalise_with_params(inst))
+    p = problem_of(inst)
+    v = p.solve(tol=1e-8)
+    assert p.status == "optimal" and p.gap <= 1e-8 and p.infeas <= 1e-8, (p.status, p.gap, p.infeas, p.stats)
+    assert ref["success"] and abs(v - ref["value"]) <= 2e-6 * max(1.0, abs(v)) and ref["value"] <= v + 2e-6 * max(1.0, abs(v))
+    tot = np.zeros(inst["n_tokens"])
+    for li, R, g, kind, prm, dd, ll in zip(inst["local_indices"], inst["reserves"], inst["fees"], inst["kinds"], inst["params"], p.deltas, p.lambdas):
+        np.add.at(tot, li, ll - dd)
+        x = np.asarray(R) + g * dd - ll
+        assert np.all(dd >= 0) and np.all(ll >= 0) and np.all(x >= -1e-9 * np.max(R))
+        if kind == "sum":
+            assert x.sum() >= np.sum(R) * (1 - 1e-12)
+        elif kind == "curve":
+            assert (x.sum() - prm / np.prod(x)) >= (np.sum(R) - prm / np.prod(R)) - 1e-7 * np.sum(R)
+    assert np.abs(tot - p.psi).max() <= 1e-7 * max(1.0, np.abs(p.psi).max())
+    p.close()

@@ -13,37 +13,7 @@ from helpers import problem_of, normalise_with_params
 from oracle.primal_scipy import solve_primal
 
 
-def instance(seed):
-    rng = np.random.default_rng(seed)
-    n = int(rng.integers(5, 9))
-    price = np.exp(rng.normal(0, 0.05, n))
-    for j in range(n):
-        if rng.random() < 0.3:
-            price[j] *= float(rng.choice([0.5, 2.0, 3.0]))
-    L, R, F, K, W, P = [], [], [], [], [], []
-    for _ in range(int(rng.integers(4, 10))):
-        l = rng.choice(n, 2, replace=False); val = np.exp(rng.normal(4, 0.7))
-        L.append(l.tolist()); R.append((val / price[l] * np.exp(rng.normal(0, 0.05, 2))).tolist()); F.append(float(rng.choice([0.997, 0.999, 0.99])))
-        K.append("geomean"); W.append([1.0, 1.0]); P.append(None)
-    for _ in range(int(rng.integers(1, 4))):
-        k = int(rng.integers(2, min(5, n) + 1))
-        l = rng.choice(n, k, replace=False); val = np.exp(rng.normal(4, 0.7))
-        res = val / price[l] * np.exp(rng.normal(0, 0.04, k))
-        L.append(l.tolist()); R.append(res.tolist()); F.append(float(rng.choice([0.999, 0.9995, 0.997]))); K.append("curve"); W.append(None)
-        P.append(float(np.prod(res) * res.mean() / float(rng.choice([5.0, 40.0, 200.0]))))
-    with_sum = rng.random() < 0.4
-    if with_sum:
-        k = int(rng.integers(3, 5))
-        l = rng.choice(n, k, replace=False)
-        L.append(l.tolist()); R.append((30.0 / price[l] * np.exp(rng.normal(0, 0.1, k))).tolist()); F.append(float(rng.choice([0.997, 0.99]))); K.append("sum"); W.append(None); P.append(None)
-    ut = ["arbitrage", "swap", "liquidate"][seed % 3]
-    if ut == "arbitrage":
-        u = dict(type="arbitrage", c=(price * np.exp(rng.normal(0, 0.03, n))).tolist())
-    elif ut == "swap":
-        h = np.zeros(n); h[0] = float(np.exp(rng.normal(2, 0.5))); u = dict(type="swap", h=h.tolist(), t=n - 1)
-    else:
-        h = np.exp(rng.normal(0.5, 0.5, n)); h[n - 1] = 0.0; u = dict(type="liquidate", h=h.tolist(), t=n - 1)
-    return dict(name=f"tbl{seed}", n_tokens=n, local_indices=L, reserves=R, fees=F, kinds=K, weights=W, params=P, utility=u), with_sum
+from helpers import table_instance as instance
 
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
