@@ -1154,12 +1154,12 @@ int bounds_into_mirror(cfmm_ctx *ctx)
     const int n = ctx->n, ng = ctx->ng;
     double *lo = (double *)(ctx->util_h + ((char *)ctx->glo - (char *)ctx->c)), *hi = (double *)(ctx->util_h + ((char *)ctx->ghi - (char *)ctx->c));
     for (int r = 0; r < ng; ++r) { lo[r] = -INFINITY; hi[r] = INFINITY; }
-    // A price the utility does not bound (c = 0; an equality) is still kept within e^+-600 of the utility's own scale: a WORTHLESS token's
+    // A price the utility does not bound (c = 0; an equality) is still kept within e^+-100 of the utility's own scale: a WORTHLESS token's
     // log-price otherwise runs off until nu underflows to zero and the pool arithmetic turns it into NaNs -- "dual value is not finite"
     // instead of a stalled solve the caller can classify (tools/fuzz_table.py: a liquidation whose target no pool lists)
     double cmax = 0.0;
     for (int j = 0; j < n; ++j) if (ctx->hctype[j] < CFMM_ULOG) cmax = std::max(cmax, ctx->hc[j]);
-    const double mid = cmax > 0.0 ? std::log(cmax) : 0.0, span = 600.0;
+    const double mid = cmax > 0.0 ? std::log(cmax) : 0.0, span = 100.0;
     for (int j = 0; j < n; ++j) {
         const int r = ctx->hgrp[j];
         double l = mid - span, u = mid + span;
@@ -3658,8 +3658,8 @@ int cfmm_solve_sweep(cfmm_ctx *ctx, int B, const double *c, const double *h, con
             for (int j = 0; j < n; ++j) scmax = std::max(scmax, A[j]);
             const double smid = scmax > 0.0 ? std::log(scmax) : 0.0;
             for (int j = 0; j < n; ++j) {                 // (bounds_into_mirror)
-                double l = smid - 600.0, u = smid + 600.0;                // (as bounds_into_mirror: no price runs off to an underflow)
-                if (ct[j] == CFMM_GE) { l = A[j] > 0.0 ? std::log(A[j]) : smid - 600.0; u = INFINITY; }
+                double l = smid - 100.0, u = smid + 100.0;                // (as bounds_into_mirror: no price runs off to an underflow)
+                if (ct[j] == CFMM_GE) { l = A[j] > 0.0 ? std::log(A[j]) : smid - 100.0; u = INFINITY; }
                 else if (ct[j] == CFMM_FREE) l = u = std::log(A[j]);
                 l -= off[j]; u -= off[j];
                 if (l > glo[grp[j]]) glo[grp[j]] = l;
