@@ -1669,7 +1669,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     long long nbar = 0;
     for (int k = 0; k < CFMM_POOL_KINDS2; ++k) nbar += 2 * ctx->pools->b2[k].m;
     nbar += 2 * ctx->pools->b2[CFMM_POOL_SUM2].m;
-    for (int k = 2; k <= CFMM_MAX_POOL_SIZE; ++k) nbar += (long long)k * ctx->pools->bg[CFMM_POOLK_SUM][k].m;      // (phik.hpp: the smoothed constant-sum entry costs at most mu K)
+    for (int k = 2; k <= CFMM_MAX_POOL_SIZE; ++k) nbar += 3LL * k * ctx->pools->bg[CFMM_POOLK_SUM][k].m;      // (phik.hpp: the barrier-smoothed constant-sum entry, 3 K barrier terms)
     for (int j = 0; j < n; ++j) {
         mask[j] = ct[j] == CFMM_FREE || !listed[j];              // (a token the dual is flat in: its price stays where it starts)
         lob[j] = (ct[j] == CFMM_GE && c[j] > 0.0) ? std::log(c[j]) : -INFINITY;

@@ -758,51 +758,72 @@ gk_newton_kernel(BucketG b, const double *__restrict__ nu, const double *__restr
     if ((threadIdx.x & 63) == 0 && vsum != 0.0) { unsafeAtomicAdd(&out[n], vsum); unsafeAtomicAdd(&out[n + 1], vsum); }
 }
 
-// ---- the constant-sum entry in the second-order path: smoothed in PRICE space (round 5) -------------------------------------------
-// arbitrage.py:73-74 over K tokens is an LP per pool, and in the dual it is the piecewise-linear
-//     arb(nu) = sum_j R_j (nu_j - m / gamma)_+ ,   m = min_k nu_k
-// (every token worth more than the cheapest after the fee is drained, the cheapest pays).  Its kinks -- a leg drained only partly, two
-// tokens tied for cheapest -- are what the first-order path's active-set loop chases (cfmm/problem.py) and, on small networks whose
-// tokens differ in value, often does not catch (tools/fuzz_table.py).  The second-order path takes the pool SMOOTHED, with the path's own
-// barrier weight mu (value units):  (z)_+  ->  mu softplus(z / mu)  per leg,  min  ->  the soft minimum  m_mu = -mu' log sum exp(-nu_k / mu')
-// with mu' = mu gamma / sum R (price units: the payment is at most sum R / gamma, so this term too costs at most mu log K of value).
-// arb_mu is smooth and convex (a non-decreasing convex function of the convex nu_j - m_mu / gamma), arb <= arb_mu, and its gradient
-//     y_j = R_j sigma_j - w_j P / gamma,   sigma_j = sigmoid(z_j / mu),  P = sum_i R_i sigma_i,  w = the soft minimum's weights
-// is a FEASIBLE tender of the pool for every mu: Lambda_j = R_j sigma_j <= R_j, Delta_k = w_k P / gamma, sum gamma Delta = sum Lambda
-// -- partial drains and split payments come out of it without any active set.  arb(nu) - nu'y <= mu (0.28 K + log K) <= mu K: the pool
-// counts K barrier terms in the path's gap bound.  Hessian in prices:  M = sum_i a_i u_i u_i' + (P / gamma) (diag(w) - w w') / mu',
-// a_i = sigma_i (1 - sigma_i) R_i^2 / mu,  u_i = e_i - w / gamma;  in log-prices nu_j nu_k M_jk (+ the caller's diagonal nu_j y_j).
-template <int K> struct SumSmooth { double w[K], sg[K], a[K], y[K], val, trade, P, Sa, imup; };
+// ---- the constant-sum entry in the second-order path: barrier-smoothed like the two-asset pools (round 5) ------------------------------
+// arbitrage.py:73-74 over K tokens is an LP per pool; its kinks in the dual -- a leg drained only partly, two tokens tied for cheapest --
+// are what the first-order path's active-set loop chases (cfmm/problem.py) and, on small networks whose tokens differ in value, often
+// does not catch (tools/fuzz_table.py).  The second-order path puts the path's own log barrier (weight mu) on the LP's sign constraints,
+// as smooth.hpp does for the two-asset pools:
+//     arb_mu(p) = max  p'(L - D) + mu sum_j [log L_j + log(R_j - L_j)] + mu sum_k log D_k    s.t.  gamma sum D = sum L
+// (receipts L_j in (0, R_j), payments D_k > 0; the pool's constraint sum x >= sum R holds with equality, x = R + gamma D - L > 0).  With
+// the multiplier tau of the constraint everything separates:  D_k = mu / (p_k - gamma tau)  (tau < min p / gamma),  L_j the root in
+// (0, R_j) of  (p_j - tau) + mu / L - mu / (R_j - L) = 0  -- closed form -- and tau is the root of the increasing
+// F(tau) = gamma sum D - sum L: a safeguarded Newton iteration on ONE scalar per pool, carried as the GAP  delta = min p / gamma - tau > 0
+// (the cheapest token's payment is mu / (gamma delta): with tau itself that difference would lose every digit at the small weights the
+// path ends on).  The optimum is interior, so arb_mu is smooth, its gradient y = L - D is a strictly FEASIBLE tender for every mu
+// (partly drained legs and split payments come out of it without an active set), arb - p'y <= 3 K mu (one mu per barrier term: the pool
+// counts 3 K of them in the path's gap bound), and the Hessian in prices is  M = diag(d) - c c' / F',  d_j = kappa_j + D_j^2 / mu,
+// c_j = kappa_j + gamma D_j^2 / mu,  kappa_j = 1 / (mu / L_j^2 + mu / (R_j - L_j)^2),  F' = sum (kappa_j + gamma^2 D_j^2 / mu).
+// (A first version smoothed in PRICE space -- softplus per leg, soft minimum for the payer -- was feasible and convex too, but not
+// self-concordant: Newton's quadratic model held only within mu of a kink, and the path crawled: 200 steps on mid-size networks.)
+template <int K> struct SumSmooth { double L[K], D[K], kap[K], d[K], c[K], val, trade, Fp; };
 template <int K>
 __host__ __device__ inline void sum_smooth_k(const double (&R)[K], const double (&p)[K], double g, double mu, SumSmooth<K> &o)
 {
-    double Rs = 0.0, pmin = p[0];
-    for (int j = 0; j < K; ++j) { Rs += R[j]; pmin = fmin(pmin, p[j]); }
-    const double imup = fmin(Rs / (mu * g), 1e300);            // (finite: a zero-value optimum drives mu towards 0, and 0 x inf below would be a NaN)
-    double sw = 0.0;
-    for (int k = 0; k < K; ++k) { o.w[k] = exp(-(p[k] - pmin) * imup); sw += o.w[k]; }
-    const double isw = 1.0 / sw;
-    for (int k = 0; k < K; ++k) o.w[k] *= isw;
-    const double m = pmin - log(sw) / imup, ig = 1.0 / g, imu = fmin(1.0 / mu, 1e300);
-    double P = 0.0, val = 0.0, Sa = 0.0;
-    for (int j = 0; j < K; ++j) {
-        const double z = R[j] * (p[j] - m * ig) * imu;
-        double sg, sp;
-        if (z >= 0.0) { const double e = exp(-z); sg = 1.0 / (1.0 + e); sp = z + log1p(e); }
-        else { const double e = exp(z); sg = e / (1.0 + e); sp = log1p(e); }
-        o.sg[j] = sg; o.a[j] = sg * (1.0 - sg) * R[j] * R[j] * imu;
-        val += mu * sp; P += R[j] * sg; Sa += o.a[j];
+    double pmin = p[0], Rs = 0.0;
+    for (int j = 0; j < K; ++j) { pmin = fmin(pmin, p[j]); Rs += R[j]; }
+    const double tmax = pmin / g, ig = 1.0 / g;
+    // at the gap delta:  p_k - gamma tau = (p_k - pmin) + gamma delta,   a_j = p_j - tau = (p_j - tmax) + delta
+    auto eval = [&](double dl, double &F, double &Fp) {
+        F = 0.0; Fp = 0.0;
+        for (int j = 0; j < K; ++j) {
+            const double D = mu / ((p[j] - pmin) + g * dl);
+            const double a = (p[j] - tmax) + dl, aR = a * R[j], S = sqrt(aR * aR + 4.0 * mu * mu);
+            const double L = a > 0.0 ? (aR - 2.0 * mu + S) / (2.0 * a) : 2.0 * mu * R[j] / (S + 2.0 * mu - aR);
+            const double Lc = fmin(fmax(L, 1e-300), R[j] * (1.0 - 1e-16));
+            const double kap = 1.0 / (mu / (Lc * Lc) + mu / ((R[j] - Lc) * (R[j] - Lc)));
+            o.L[j] = Lc; o.D[j] = D; o.kap[j] = kap;
+            F += g * D - Lc; Fp += kap + g * g * D * D / mu;
+        }
+    };
+    // F decreases in delta (F(0+) = +inf, F(inf) = -sum R): Newton in log delta, bracketed
+    double lo = 0.0, hi = 1.7976931348623157e308, dl = 2.0 * K * mu / (g * Rs), F, Fp;
+    for (int it = 0; it < 200; ++it) {
+        eval(dl, F, Fp);
+        if (F > 0.0) lo = dl; else hi = dl;
+        if (fabs(F) <= 1e-13 * Rs) break;
+        // d F / d delta = -F' (tau = tmax - delta); the step in log delta keeps delta > 0
+        double dn = dl * exp(fmin(fmax(F / (Fp * dl), -3.0), 3.0));
+        if (!(dn > lo && dn < hi)) dn = hi < 1e308 ? (lo > 0.0 ? sqrt(lo * hi) : 0.5 * hi) : 8.0 * dl;
+        if (fabs(dn - dl) <= 1e-15 * dl) break;
+        dl = dn;
     }
-    double tr = 0.0;
-    for (int j = 0; j < K; ++j) { o.y[j] = R[j] * o.sg[j] - o.w[j] * P * ig; tr += p[j] * o.y[j]; }
-    o.val = val; o.trade = tr; o.P = P; o.Sa = Sa; o.imup = imup;
+    eval(dl, F, Fp);
+    (void)ig;
+    double val = 0.0, tr = 0.0;
+    for (int j = 0; j < K; ++j) {
+        o.d[j] = o.kap[j] + o.D[j] * o.D[j] / mu; o.c[j] = o.kap[j] + g * o.D[j] * o.D[j] / mu;
+        const double y = o.L[j] - o.D[j];
+        tr += p[j] * y;
+        val += p[j] * y + mu * (log(o.L[j]) + log(R[j] - o.L[j]) + log(o.D[j]));
+    }
+    o.val = val; o.trade = tr; o.Fp = Fp;
 }
 // M_jk of the pool (price space)
 template <int K>
 __host__ __device__ inline double sum_smooth_hess(const SumSmooth<K> &o, double g, int j, int k)
 {
-    const double ig = 1.0 / g, pb = o.P * ig * o.imup;
-    return (j == k ? o.a[j] + pb * o.w[j] : 0.0) - (o.a[j] * o.w[k] + o.a[k] * o.w[j]) * ig + o.w[j] * o.w[k] * (o.Sa * ig * ig - pb);
+    (void)g;
+    return (j == k ? o.d[j] : 0.0) - o.c[j] * o.c[k] / o.Fp;
 }
 template <int K, bool HESS>
 __global__ void __launch_bounds__(256)
@@ -818,7 +839,7 @@ gk_sum_newton_kernel(BucketG b, const double *__restrict__ nu, const double *__r
         SumSmooth<K> o;
         sum_smooth_k<K>(R, p, g, mu, o);
         for (int j = 0; j < K; ++j) {
-            double y = o.y[j];
+            double y = o.L[j] - o.D[j];
             if (slo) for (int k = 0; k < K; ++k) y += sum_smooth_hess<K>(o, g, j, k) * p[k] * slo[tok[k]];      // first-order response to the low-order log-prices
             unsafeAtomicAdd(&out[tok[j]], y); tsum += p[j] * y;
         }
@@ -853,15 +874,14 @@ tradesg_kernel(BucketG b, const int *flags, const double *__restrict__ nu, const
         SumSmooth<K> o;
         sum_smooth_k<K>(R, p, g, mu, o);
         // first-order response to the low-order log-prices, of the receipts and of the payments SEPARATELY (their difference is the
-        // M dp of gk_sum_newton_kernel; split like this the pool's constraint sum(gamma dDelta - dLambda) = 0 holds to rounding):
-        // dLambda_j = R_j sigma_j (1 - sigma_j) R_j (dp_j - dm / gamma) / mu,  dm = w'dp,  dw_k = -w_k (dp_k - dm) / mu',
-        // dDelta_k = (dw_k P + w_k dP) / gamma,  dP = sum dLambda
-        double dL[K], dp[K], dm = 0.0, dP = 0.0;
-        for (int k = 0; k < K; ++k) { dp[k] = slo ? p[k] * slo[b.idx[i * K + k]] : 0.0; dm += o.w[k] * dp[k]; }
-        for (int j = 0; j < K; ++j) { dL[j] = o.a[j] * (dp[j] - dm / g); dP += dL[j]; }         // (a_j = sigma (1 - sigma) R^2 / mu)
+        // M dp of gk_sum_newton_kernel; split like this the pool's constraint gamma sum dD = sum dL holds to rounding):
+        // dtau = c'dp / F',  dL_j = kappa_j (dp_j - dtau),  dD_k = -(D_k^2 / mu) (dp_k - gamma dtau)
+        double dp[K], dtau = 0.0;
+        for (int k = 0; k < K; ++k) { dp[k] = slo ? p[k] * slo[b.idx[i * K + k]] : 0.0; dtau += o.c[k] * dp[k]; }
+        dtau /= o.Fp;
         for (int j = 0; j < K; ++j) {
-            const double dl = R[j] * o.sg[j] + dL[j];
-            const double dd = (o.w[j] * (o.P + dP) - o.w[j] * (dp[j] - dm) * o.imup * o.P) / g;
+            const double dl = o.L[j] + o.kap[j] * (dp[j] - dtau);
+            const double dd = o.D[j] - o.D[j] * o.D[j] / mu * (dp[j] - g * dtau);
             delta[(size_t)j * b.m + i] = fmax(dd, 0.0); lambda[(size_t)j * b.m + i] = fmax(dl, 0.0);
         }
         return;

@@ -73,15 +73,16 @@ enum {
 /* K-asset trading functions OTHER than the weighted geometric mean: the K-asset table (csrc/phik.hpp: one PhiK<KIND> struct per
  * function -- SURVEY 8(f) rank 4; "a pool is whatever constraint line is written", arbitrage.py:63-74), 3..8 assets, one
  * bucket per (kind, size).  Evaluated as wave-tiles (leg per lane, LDS psi tile) in one launch behind the main evaluation; the
- * stableswap entry enters the second-order path with its exact generalised Hessian block, the constant-sum entry smoothed in price space
- * with the path's barrier weight (csrc/phik.hpp: sum_smooth_k -- feasible tenders for every weight, closed-form Hessian). */
+ * stableswap entry enters the second-order path with its exact generalised Hessian block, the constant-sum entry with the path's own
+ * log barrier on its sign constraints (csrc/phik.hpp: sum_smooth_k -- one scalar root per pool, strictly feasible tenders for every weight,
+ * closed-form Hessian). */
 enum {
     CFMM_POOLK_STABLE = 0,  /* n-asset stableswap  sum x - alpha / prod x  (the paper's concave form; 2 assets: CFMM_POOL_CURVE2);
                                param = alpha.  Solved by the table's generic two-level search (no closed form)              */
     CFMM_POOLK_SUM = 1,     /* n-asset constant sum  sum x, x >= 0  (arbitrage.py:73-74 with more than two tokens); param = NULL.
                                First order: the exact LP vertex on the device; an optimum ON one of its kinks (a leg drained partly, two
                                tokens tied for cheapest) needs the caller's active-set loop (cfmm_set_ties + cfmm_set_pool_flagsG:
-                               cfmm/problem.py) -- or CFMM_METHOD_NEWTON, which needs none (the smoothed pool fills partly by itself) */
+                               cfmm/problem.py) -- or CFMM_METHOD_NEWTON, which needs none (the barrier-smoothed pool fills partly by itself) */
     CFMM_POOLK_KINDS = 2
 };
 
