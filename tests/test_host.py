@@ -345,3 +345,61 @@ def test_random_instances_with_constant_sum_pools(oracle_lib, seed):
     assert r["value"] <= v + 2e-6 * max(1, abs(v))
     if r["success"]:
         assert abs(v - r["value"]) <= 2e-6 * max(1, abs(v)), (v, r["value"], p._theta)
+
+
+def test_barrier_smoothed_constant_sum_pool_against_finite_differences(tmp_path):
+    """csrc/phik.hpp: sum_smooth_k -- the K-asset constant-sum pool (arbitrage.py:73-74 over K tokens) with the second-order path's log
+    barrier on its sign constraints -- is __host__ __device__: compiled for the HOST here and checked without a GPU.  The pool's
+    constraint holds to rounding, the value tends to the LP's as the weight shrinks, its gradient is L - D and its Hessian the closed
+    form, both against central differences."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc missing")
+    src = tmp_path / "t.hip"
+    src.write_text(r'''
+#include "phik.hpp"
+#include <cstdio>
+#include <cmath>
+using namespace cfmm;
+int main()
+{
+    constexpr int K = 4;
+    double R[K] = {31.5, 29.4, 27.2, 15.5}, p[K] = {1.005, 1.007, 1.0, 1.0153};
+    const double g = 0.99;
+    for (double mu : {1e-1, 1e-3, 1e-6, 1e-10}) {
+        SumSmooth<K> o; sum_smooth_k<K>(R, p, g, mu, o);
+        double bal = 0, minslack = 1e300;
+        for (int j = 0; j < K; ++j) { bal += g * o.D[j] - o.L[j]; minslack = std::fmin(minslack, std::fmin(std::fmin(o.L[j], R[j] - o.L[j]), o.D[j])); }
+        double maxg = 0, maxh = 0;
+        for (int k = 0; k < K; ++k) {
+            const double e = 1e-6 * std::fmax(mu, 1e-4);
+            double pp[K], pm[K]; for (int j = 0; j < K; ++j) { pp[j] = pm[j] = p[j]; } pp[k] += e; pm[k] -= e;
+            SumSmooth<K> a, b; sum_smooth_k<K>(R, pp, g, mu, a); sum_smooth_k<K>(R, pm, g, mu, b);
+            maxg = std::fmax(maxg, std::fabs((a.val - b.val) / (2 * e) - (o.L[k] - o.D[k])));
+            for (int j = 0; j < K; ++j) {
+                const double fh = ((a.L[j] - a.D[j]) - (b.L[j] - b.D[j])) / (2 * e);
+                maxh = std::fmax(maxh, std::fabs(fh - sum_smooth_hess<K>(o, g, j, k)) / (1.0 + std::fabs(fh)));
+            }
+        }
+        printf("%.0e %.12g %.12g %.3e %.3e %.3e %.3e\n", mu, o.val, o.trade, bal, minslack, maxg, maxh);
+    }
+    return 0;
+}
+''')
+    exe = tmp_path / "t"
+    inc = os.path.join(ROOT, "cfmm-routing-code_amd", "csrc")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-w", "-I", inc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60).stdout.strip().splitlines()
+    rows = [[float(x) for x in l.split()] for l in out]
+    assert [r[0] for r in rows] == [1e-1, 1e-3, 1e-6, 1e-10]
+    # the LP's value at these prices: token 5 (price 1.0) pays for the whole of token 2 (price 1.0153): R (p - 1 / gamma)
+    lp = 15.5 * (1.0153 - 1.0 / 0.99)
+    for mu, val, trade, bal, minslack, maxg, maxh in rows:
+        assert abs(bal) <= 1e-12 * 100.0 and minslack > 0.0                      # feasible, strictly inside
+        assert lp - 1e-12 <= trade + 12 * mu and trade <= lp + 1e-9              # p'y within 3 K mu of the LP's value, never above it
+        assert maxg <= 1e-4 and maxh <= 2e-3                                     # (central differences at step 1e-6 max(mu, 1e-4))
+    assert abs(rows[-1][2] - lp) <= 1e-8
