@@ -68,7 +68,7 @@ SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm
            "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_debug_cholesky_apply", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_solve_sweep", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_get_tradesG", "cfmm_comm_unique_id", "cfmm_comm_init",
            "cfmm_oneshot_export", "cfmm_oneshot_import", "cfmm_oneshot_attach", "cfmm_oneshot_mailbox", "cfmm_oneshot_enable",
-           "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_time_newton_kernels", "cfmm_selftest", "cfmm_debug_timers", "cfmm_pool_count", "cfmm_eval_bytes", "cfmm_stream"]
+           "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_time_newton_kernels", "cfmm_selftest", "cfmm_debug_timers", "cfmm_clock_probe_start", "cfmm_clock_probe_read", "cfmm_clock_probe_stop", "cfmm_clock_probe_chain", "cfmm_pool_count", "cfmm_eval_bytes", "cfmm_stream"]
 
 
 def lib():
@@ -122,6 +122,10 @@ def lib():
     L.cfmm_time_newton_kernels.argtypes = [vp, C.c_double, C.c_int, dp]
     L.cfmm_selftest.argtypes = [vp]
     L.cfmm_debug_timers.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.cfmm_clock_probe_start.argtypes = [vp, C.c_double, C.c_double]
+    L.cfmm_clock_probe_read.argtypes = [vp, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]
+    L.cfmm_clock_probe_stop.argtypes = [vp, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]
+    L.cfmm_clock_probe_chain.argtypes = [vp, C.POINTER(C.c_int64)]
     L.cfmm_pool_count.restype = C.c_int64; L.cfmm_pool_count.argtypes = [vp]
     L.cfmm_eval_bytes.restype = C.c_int64; L.cfmm_eval_bytes.argtypes = [vp]
     L.cfmm_stream.restype = vp; L.cfmm_stream.argtypes = [vp]
@@ -431,6 +435,29 @@ class Context:
         a = np.zeros(64 + 8 * 4096 + 2048, dtype=np.int64)
         self._chk(self.L.cfmm_debug_timers(self.h, a.ctypes.data_as(C.POINTER(C.c_int64))))
         return a[:64].reshape(32, 2), a[64:64 + 8 * 4096].reshape(4096, 8), a[64 + 8 * 4096:].reshape(1024, 2)
+
+    def clock_probe_start(self, period_us=100.0, max_ms=2000.0):
+        """one sleeping wave on a stream of its own samples {shader cycles, 100 MHz ticks} every period_us while the caller's work runs"""
+        self._chk(self.L.cfmm_clock_probe_start(self.h, float(period_us), float(max_ms)))
+
+    def _probe_samples(self, f):
+        a = np.zeros((8192, 2), dtype=np.int64)
+        k = C.c_int()
+        self._chk(f(self.h, a.ctypes.data_as(C.POINTER(C.c_int64)), a.shape[0], C.byref(k)))
+        return a[:k.value].copy()
+
+    def clock_probe_read(self):
+        """samples so far, [k, 2] int64 (shader cycles, 100 MHz ticks); no synchronisation"""
+        return self._probe_samples(self.L.cfmm_clock_probe_read)
+
+    def clock_probe_stop(self):
+        return self._probe_samples(self.L.cfmm_clock_probe_stop)
+
+    def clock_probe_chain(self):
+        """(shader cycles, 100 MHz ticks, links) of the probe's dependent-FMA chain"""
+        a = np.zeros(3, dtype=np.int64)
+        self._chk(self.L.cfmm_clock_probe_chain(self.h, a.ctypes.data_as(C.POINTER(C.c_int64))))
+        return int(a[0]), int(a[1]), int(a[2])
 
     def pool_count(self):
         return int(self.L.cfmm_pool_count(self.h))

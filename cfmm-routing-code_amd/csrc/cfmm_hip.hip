@@ -226,6 +226,10 @@ struct cfmm_ctx {
     bool slo_active = false;
     int *sm_mask = nullptr, *sm_info = nullptr;
     double mu_last = 0.0;              // barrier weight of the last solve (0: first-order, exact tenders)
+    // shader-clock probe (cfmm_clock_probe_*): one sleeping wave on a stream of its own, its samples in mapped pinned memory
+    hipStream_t probe_stream = nullptr;
+    long long *probe_ring = nullptr, *probe_ring_d = nullptr;       // [PROBE_CAP][2] {shader cycles, 100 MHz ticks} | control words behind them
+    bool probe_running = false;
     double warm_mu = 0.0;              // barrier weight to continue from (cfmm_solve with nu0 == NULL after a second-order solve)
 };
 
@@ -2200,6 +2204,12 @@ int cfmm_destroy(cfmm_ctx *ctx)
     if (ctx->host_arena) (void)hipHostFree(ctx->host_arena);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->hstat_h) (void)hipHostFree((void *)ctx->hstat_h);
+    if (ctx->probe_ring) {                               // (a probe still running is told to stop and waited for)
+        __atomic_store_n(reinterpret_cast<volatile long long *>(ctx->probe_ring) + 2 * PROBE_CAP, 1ll, __ATOMIC_RELEASE);
+        if (ctx->probe_stream) (void)hipStreamSynchronize(ctx->probe_stream);
+        (void)hipHostFree(ctx->probe_ring);
+    }
+    if (ctx->probe_stream) (void)hipStreamDestroy(ctx->probe_stream);
     if (ctx->upd_batch_d) (void)hipFree(ctx->upd_batch_d);
     if (ctx->upd_batch_h) (void)hipHostFree(ctx->upd_batch_h);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -4048,6 +4058,63 @@ int cfmm_debug_timers(cfmm_ctx *ctx, int64_t *out64)
     HIP_TRY(ctx, hipMemcpy(out64, ctx->ts, (64 + 8 * 4096 + 2048) * sizeof(int64_t), hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemset(ctx->ts, 0, (64 + 8 * 4096 + 2048) * sizeof(int64_t)));
     return CFMM_OK;
+}
+
+
+// ---- shader-clock probe ------------------------------------------------------------------------------------------------
+// MI355X clocks to its power budget (MI355X_MICROARCH.md, "DVFS give-back"): the same binary ran its dominant launch in 20.1 us on
+// one lease and 23.8 on another, and a launch duration alone cannot say whether that is the code or the clock.
+// The probe is ONE wave on a stream of its own that sleeps (s_sleep: no VALU, no memory traffic beyond its samples) and every
+// `period_us` stores {s_memtime, s_memrealtime} -- shader cycles and the constant 100 MHz counter -- into mapped pinned memory,
+// WHILE the solves run on the library's stream: (delta cycles) / (delta ticks x 10 ns) between two samples is the clock the
+// shader engines ran at in that interval.  bench.py brackets its timed region with it (roofline.effective_clock_ghz_live).
+int cfmm_clock_probe_start(cfmm_ctx *ctx, double period_us, double max_ms)
+{
+    if (!ctx || !(period_us >= 1.0) || !(max_ms > 0.0) || max_ms > 60000.0) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->probe_running) return fail(ctx, CFMM_E_STATE, "clock probe: already running (cfmm_clock_probe_stop first)");
+    if (!ctx->probe_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->probe_stream, hipStreamNonBlocking));
+    if (!ctx->probe_ring) {
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->probe_ring, (2 * PROBE_CAP + 8) * sizeof(long long), hipHostMallocMapped));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void **)&ctx->probe_ring_d, ctx->probe_ring, 0));
+    }
+    std::memset(ctx->probe_ring, 0, (2 * PROBE_CAP + 8) * sizeof(long long));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, ctx->probe_stream, ctx->probe_ring_d, PROBE_CAP,
+                       (long long)(period_us * 100.0), (long long)(max_ms * 1e5));
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->probe_running = true;
+    return CFMM_OK;
+}
+// the samples so far (no synchronisation: they sit in host memory), oldest first: out[2 i] = shader cycles, out[2 i + 1] = 100 MHz ticks
+int cfmm_clock_probe_read(cfmm_ctx *ctx, int64_t *out, int cap, int *count)
+{
+    if (!ctx || !count || (cap > 0 && !out)) return CFMM_E_ARG;
+    *count = 0;
+    if (!ctx->probe_ring) return CFMM_OK;
+    const long long head = __atomic_load_n(reinterpret_cast<volatile long long *>(ctx->probe_ring) + 2 * PROBE_CAP + 1, __ATOMIC_ACQUIRE);
+    const int k = (int)std::min<long long>(std::min<long long>(head, PROBE_CAP), cap);
+    for (int i = 0; i < 2 * k; ++i) out[i] = reinterpret_cast<volatile long long *>(ctx->probe_ring)[i];
+    *count = k;
+    return CFMM_OK;
+}
+// the probe's dependent-FMA chain (handoff.hpp: PROBE_CHAIN links in front of the first sample): out3 = {shader cycles, 100 MHz ticks, links}
+int cfmm_clock_probe_chain(cfmm_ctx *ctx, int64_t *out3)
+{
+    if (!ctx || !out3) return CFMM_E_ARG;
+    for (int i = 0; i < 3; ++i) out3[i] = ctx->probe_ring ? reinterpret_cast<volatile long long *>(ctx->probe_ring)[2 * PROBE_CAP + 2 + i] : 0;
+    return CFMM_OK;
+}
+int cfmm_clock_probe_stop(cfmm_ctx *ctx, int64_t *out, int cap, int *count)
+{
+    if (!ctx) return CFMM_E_ARG;
+    if (ctx->probe_running) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        __atomic_store_n(reinterpret_cast<volatile long long *>(ctx->probe_ring) + 2 * PROBE_CAP, 1ll, __ATOMIC_RELEASE);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->probe_stream));
+        ctx->probe_running = false;
+    }
+    int dummy = 0;
+    return cfmm_clock_probe_read(ctx, out, cap, count ? count : &dummy);
 }
 
 int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_launch)

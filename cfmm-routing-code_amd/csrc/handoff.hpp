@@ -51,4 +51,45 @@ __global__ __launch_bounds__(256) void io_kernel(IoArgs a)
     }
 }
 
+// ---- the shader-clock probe (cfmm_clock_probe_start, bench.py: roofline.effective_clock_ghz_live) -------------------------
+// ONE wave on a stream of its own.  It sleeps (s_sleep: no vector work, no memory traffic) and every `period` ticks of the constant
+// 100 MHz counter stores one sample {s_memtime = shader cycles, s_memrealtime = 100 MHz ticks} into mapped pinned memory; the
+// ratio of the two differences between any two samples is the clock the shader engines ran at in between -- measured WHILE
+// the solves run beside it, which a probe in front of or behind them cannot give (the chip clocks to its power budget).
+// In front of the first sample the wave runs a chain of PROBE_CHAIN dependent v_fma_f64 between two stamp pairs: cycles per link is a
+// property of the pipeline (the same on every box), so the chain shows that s_memtime counts SHADER cycles and not a fixed reference.
+// ring: [cap][2] samples | [2 cap] stop word (the host sets it) | [2 cap + 1] samples written so far | [2 cap + 2 .. 4] the chain:
+//       shader cycles, 100 MHz ticks, links
+constexpr int PROBE_CAP = 8192;
+constexpr int PROBE_CHAIN = 16384;
+__global__ void __launch_bounds__(64) clock_probe_kernel(long long *ring, int cap, long long period, long long max_ticks)
+{
+    if (threadIdx.x != 0) return;
+    {
+        double x = (double)period * 1e-30, y = 1.0 + (double)cap * 1e-30;
+        const long long c0 = clock64(), t0 = wall_clock64();
+#pragma unroll 16
+        for (int i = 0; i < PROBE_CHAIN; ++i) x = __builtin_fma(x, y, 1e-30);
+        asm volatile("" :: "v"(x));
+        const long long c1 = clock64(), t1 = wall_clock64();
+        ring[2 * cap + 2] = c1 - c0; ring[2 * cap + 3] = t1 - t0; ring[2 * cap + 4] = PROBE_CHAIN;
+    }
+    const long long w0 = wall_clock64();
+    long long next = w0, head = 0;
+    for (;;) {
+        const long long w = wall_clock64();
+        if (w >= next) {
+            const long long c = clock64(), w2 = wall_clock64();     // (back to back: their skew is the same in every sample and cancels in the differences)
+            __hip_atomic_store(ring + 2 * head, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(ring + 2 * head + 1, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            ++head;
+            __hip_atomic_store(ring + 2 * cap + 1, head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            next += period;
+            if (head >= cap || w2 - w0 >= max_ticks) break;
+            if (__hip_atomic_load(ring + 2 * cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;      // (one bus read per sample, not per wake-up)
+        }
+        __builtin_amdgcn_s_sleep(16);                                // (~1000 shader cycles)
+    }
+}
+
 }  // namespace cfmm

@@ -293,6 +293,18 @@ int cfmm_time_collective(cfmm_ctx *ctx, int reps, double *fold_sec, double *allr
 /* NOTE: the hook overwrites the Hessian, the pin mask and the warm starts of the smoothed per-direction solves; a following
  * cfmm_solve(nu0 = NULL) therefore starts its barrier path afresh instead of continuing the previous one */
 int cfmm_time_newton_kernels(cfmm_ctx *ctx, double mu, int reps, double *out4);
+/* Shader-clock probe (bench.py: roofline.effective_clock_ghz_live).  MI355X clocks to its power budget, so a launch duration alone
+ * cannot tell a slower binary from a slower clock.  cfmm_clock_probe_start puts ONE sleeping wave on a stream of its own that, every
+ * `period_us`, stores {shader cycles (s_memtime), ticks of the constant 100 MHz counter (s_memrealtime)} into mapped pinned memory
+ * until cfmm_clock_probe_stop, `max_ms`, or 8192 samples -- while whatever the caller enqueues on the library's stream runs beside
+ * it.  cfmm_clock_probe_read copies the samples so far (no synchronisation; out[2 i] cycles, out[2 i + 1] ticks, oldest first);
+ * the clock over an interval = (delta cycles) / (delta ticks x 10 ns).  Replaces nothing in the reference (a measurement hook). */
+int cfmm_clock_probe_start(cfmm_ctx *ctx, double period_us, double max_ms);
+int cfmm_clock_probe_read(cfmm_ctx *ctx, int64_t *out, int cap, int *count);
+int cfmm_clock_probe_stop(cfmm_ctx *ctx, int64_t *out, int cap, int *count);
+/* the chain of dependent v_fma_f64 the probe runs in front of its first sample: out3 = {shader cycles, 100 MHz ticks, links} -- cycles per
+ * link is a pipeline constant, which shows that the first counter counts shader cycles */
+int cfmm_clock_probe_chain(cfmm_ctx *ctx, int64_t *out3);
 /* checks the cross-lane primitives of the update kernels (DPP / v_permlane*_swap / ds_swizzle butterflies and the
  * 64-value reduce-scatter) against exact integer sums on this device; 0 = pass */
 int cfmm_selftest(cfmm_ctx *ctx);
