@@ -267,6 +267,15 @@ int fail(cfmm_ctx *ctx, int code, const char *fmt, ...)
 
 // pool-sharded: a communicator (RCCL) and / or an attached one-shot exchange
 inline bool sharded(const cfmm_ctx *ctx) { return ctx->comm != nullptr || ctx->os_ready; }
+// Pool-sharded through RCCL, one launch per iteration (round 6): the accumulator slices are all-reduced AS THEY ARE -- one collective over the
+// span [slice 0 .. psi | sum arb of the last slice], 24 KB instead of 8 at 1000 tokens, which in RCCL's latency regime costs nothing -- and the
+// next launch's update sums the slices as it does on a single GPU.  The fold launch that stood in front of every collective (2.8 us of the
+// 27 us one-rank iteration: a launch boundary, not arithmetic) is gone.  The one-shot exchange folds the slices itself, as before.
+inline bool rccl_unfolded(const cfmm_ctx *ctx)
+{
+    static const bool off = getenv("CFMM_RCCL_FOLD") && atoi(getenv("CFMM_RCCL_FOLD")) != 0;      // (A/B: 1 = the fold launch of rounds 2-5)
+    return ctx->comm != nullptr && !ctx->det && !off && !(ctx->os_ready && (size_t)acc_arb(ctx->n) + 1 <= ctx->os_cap);
+}
 
 // the collective of the pool-sharded iteration, enqueued on ctx->stream: the one-shot exchange when it is attached and the
 // message fits its mailbox (sum of doubles / of 64-bit integers, max of doubles), RCCL otherwise
@@ -1031,7 +1040,7 @@ IterArgs make_iter_args(cfmm_ctx *ctx, const cfmm_opts &o)
     IterArgs a = {};
     a.ev = make_eval_args(ctx, false);
     a.ev.nu = nullptr; a.ev.acc = nullptr;
-    a.n = ctx->n; a.M = o.memory; a.nread = (sharded(ctx) || ctx->det) ? 1 : ctx->nslices; a.phase = 0;
+    a.n = ctx->n; a.M = o.memory; a.nread = ((sharded(ctx) && !rccl_unfolded(ctx)) || ctx->det) ? 1 : ctx->nslices; a.phase = 0;
     a.xvs = iter_xvs(ctx->n); a.max_evals = o.max_evals; a.pg_rule = o.pg_rule;
     a.plain = ctx->plain ? 1 : 0;
     a.acc3 = ctx->acc3; a.acc_set = (long long)acc_set_doubles(ctx);
@@ -1057,7 +1066,7 @@ bool oneshot_runahead(cfmm_ctx *ctx)
 int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
 {
     IterArgs a = base;
-    a.phase = t % 3;
+    a.phase = t % 3; a.launch = t;
     a.ev.rev = pingpong_on(ctx) ? (t & 1) : 0;
     const int n = ctx->n, E = (n <= EVAL_THREADS && ITER_E_SMALL == 1) ? 1 : 2;
     int grid, threads;
@@ -1102,6 +1111,7 @@ int enqueue_fused_iteration(cfmm_ctx *ctx, const IterArgs &base, int t)
         // host-side run-ahead below; RCCL's collective cannot be made conditional and keeps the chunked scheme
         const DevState *stop = oneshot_runahead(ctx) ? ctx->st3 + a.phase : nullptr;
         const int len = acc_arb(n) + 1;
+        if (rccl_unfolded(ctx)) return all_reduce(ctx, acc_p, (size_t)(ctx->nslices - 1) * acc_stride(n) + len, NCCL_FLOAT64, NCCL_SUM);
         return all_reduce(ctx, acc_p, (size_t)len, NCCL_FLOAT64, NCCL_SUM, stop, ctx->nslices);
     }
     return CFMM_OK;
@@ -2132,7 +2142,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
         std::memset(ctx->util_h, 0, ctx->util_span);
     }
     lap("device + pinned arenas");
-    TRY_C(hipHostMalloc((void **)&ctx->hstat_h, 64, hipHostMallocMapped));
+    TRY_C(hipHostMalloc((void **)&ctx->hstat_h, 64 + ITER_HRING * sizeof(unsigned long long), hipHostMallocMapped));      // (8 progress words | the per-launch ring)
     TRY_C(hipHostGetDevicePointer((void **)&ctx->hstat_d, (void *)ctx->hstat_h, 0));
     *ctx->hstat_h = 0;
     lap("mapped progress word");
@@ -3061,7 +3071,9 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
         }
         if (table_pools(ctx) > 0) launch_table_evals<true>(ctx, ua.nu, ctx->acc3);
         if (ctx->det) { int rc = det_finish(ctx, ctx->acc3, ua.nu, true); if (rc) return rc; }
-        else if (shard) {
+        else if (shard && rccl_unfolded(ctx)) {       // (every slice whole, metric included: launch 1 sums them itself)
+            int rc = all_reduce(ctx, ctx->acc3, (size_t)ctx->nslices * acc_stride(n), NCCL_FLOAT64, NCCL_SUM); if (rc) return rc;
+        } else if (shard) {
             const int len = acc_stride(n);
             hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc3, n, ctx->nslices, 1, (const DevState *)nullptr);
             int rc = all_reduce(ctx, ctx->acc3, (size_t)len, NCCL_FLOAT64, NCCL_SUM); if (rc) return rc;
@@ -3118,6 +3130,32 @@ static int solve_lbfgs(cfmm_ctx *ctx, const cfmm_opts &o_in, cfmm_stats *out)
             }
         }
         HIP_TRY(ctx, hipGetLastError());
+    } else if (fused && shard && !use_graph) {
+        // Pool-sharded through RCCL, one launch per iteration: chunks of `iters_per_graph` launches (each with its collective) enqueued
+        // eagerly, the decision to go on taken one chunk behind -- on the progress slot of the LAST launch of the previous chunk, which that
+        // launch writes into pinned memory itself (iterate.hpp: IterArgs::hring): the same word on every rank whatever the pace of its
+        // device, so all ranks enqueue the same collectives.  Rounds 2-5 copied the state records back and waited on an event per chunk:
+        // a blit dispatch on the stream every chunk (~0.9 us per iteration at one rank) and two API calls.
+        volatile unsigned long long *ring = ctx->hstat_h + 8;
+        for (int q = 0; q < ITER_HRING; ++q) ring[q] = 0;      // (the stream is idle)
+        ia.hring = ctx->hstat_d + 8;
+        const auto spin0 = std::chrono::steady_clock::now();
+        for (int cidx = 0; cidx < max_chunks; ++cidx) {
+            for (int it = 0; it < o.iters_per_graph; ++it) { int rc = enqueue_fused_iteration(ctx, ia, t + it); if (rc) return rc; }
+            HIP_TRY(ctx, hipGetLastError());
+            t += o.iters_per_graph;
+            if (cidx >= 1) {
+                const int last = t - o.iters_per_graph - 1;    // the last launch of the previous chunk
+                unsigned long long w;
+                long spins = 0;
+                while ((int)((w = ring[last & (ITER_HRING - 1)]) >> 32) != last) {
+                    if ((++spins & 0xfffff) == 0 && (hipGetLastError() != hipSuccess || std::chrono::duration<double>(std::chrono::steady_clock::now() - spin0).count() > 120.0))
+                        return fail(ctx, CFMM_E_HIP, "solve: the device stopped reporting progress (launch %d)", last);
+                }
+                status = (int)((w >> 24) & 0xffu);
+                if (status != 0) break;
+            }
+        }
     } else
     for (int cidx = 0; cidx < max_chunks; ++cidx) {
         if (use_graph) {
@@ -4230,8 +4268,10 @@ int cfmm_time_collective(cfmm_ctx *ctx, int reps, double *fold_sec, double *allr
     HIP_TRY(ctx, hipMemsetAsync(ctx->acc, 0, (size_t)ctx->nslices * acc_stride(n) * sizeof(double), ctx->stream));
     // the fold is a launch of its own in front of RCCL; the one-shot exchange folds the slices itself
     const bool folded_inside = ctx->os_ready && (size_t)len <= ctx->os_cap && !ctx->det;
+    cfmm_opts od; cfmm_default_opts(&od); od.memory = 3;
+    const bool unfolded = rccl_unfolded(ctx) && fused_applies(ctx, od);       // (the fused iteration's collective: the slices as they are, no fold launch)
     if (fold_sec) *fold_sec = 0.0;
-    if (!folded_inside) {
+    if (!folded_inside && !unfolded) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
         for (int i = 0; i < reps; ++i)
             hipLaunchKernelGGL(fold_kernel, dim3((len + 255) / 256), dim3(256), 0, ctx->stream, ctx->acc, n, ctx->nslices, 0, (const DevState *)nullptr);
@@ -4243,9 +4283,10 @@ int cfmm_time_collective(cfmm_ctx *ctx, int reps, double *fold_sec, double *allr
     if (allreduce_sec) *allreduce_sec = 0.0;
     if (sharded(ctx) && allreduce_sec) {           // (collective: every rank of the communicator must make this call)
         const int fs = folded_inside ? ctx->nslices : 1;
-        for (int i = 0; i < 3; ++i) { int rc = all_reduce(ctx, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, nullptr, fs); if (rc) return rc; }
+        const size_t cnt = unfolded ? (size_t)(ctx->nslices - 1) * acc_stride(n) + len : (size_t)len;
+        for (int i = 0; i < 3; ++i) { int rc = all_reduce(ctx, ctx->acc, cnt, NCCL_FLOAT64, NCCL_SUM, nullptr, fs); if (rc) return rc; }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
-        for (int i = 0; i < reps; ++i) { int rc = all_reduce(ctx, ctx->acc, (size_t)len, NCCL_FLOAT64, NCCL_SUM, nullptr, fs); if (rc) return rc; }
+        for (int i = 0; i < reps; ++i) { int rc = all_reduce(ctx, ctx->acc, cnt, NCCL_FLOAT64, NCCL_SUM, nullptr, fs); if (rc) return rc; }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));

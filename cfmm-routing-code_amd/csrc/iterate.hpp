@@ -46,6 +46,11 @@ constexpr int XS_HIST = 5;                  // s | s_t | Gs | d | trial prices |
 constexpr int XS_VECS = XS_HIST + 2 * ITER_MM;
 __host__ __device__ inline int iter_xvs(int n) { return (n + 3) & ~1; }      // vector stride of a state set: >= n + 2 (the stop flag rides at [n]), even
 
+constexpr int ITER_HRING = 1024;            // slots of the per-launch progress ring (> two chunks of launches in flight: iters_per_graph <= 256)
+__host__ __device__ inline unsigned long long iter_hring_word(int evals, int status, int launch)
+{
+    return (unsigned long long)((unsigned)evals & 0xffffffu) | ((unsigned long long)((unsigned)status & 0xffu) << 24) | ((unsigned long long)(unsigned)launch << 32);
+}
 struct IterArgs {
     EvalArgs ev;                    // tile space of the evaluation (ev.nu / ev.acc are not used here)
     int n, M, nread, phase;         // nread: accumulator slices to read (nslices, or 1 behind an all-reduce)
@@ -61,6 +66,11 @@ struct IterArgs {
     double *nu, *nu_acc, *psi_acc;          // written by workgroup 0: trial prices (+ stop flag at [n]), accepted point
     double tol_gap, tol_infeas, armijo, max_step;
     unsigned long long *hstat;              // pinned HOST word (zero-copy): evals | status << 32, for the host's run-ahead control
+    // pinned HOST ring (zero-copy; null = none), one slot per launch: evals | status << 24 | launch << 32, written by EVERY launch (the idle
+    // ones behind the end of a solve too).  The pool-sharded host loop decides on the slot of a FIXED launch -- the last of the chunk
+    // before the one it has just enqueued -- so every rank takes the same decision whatever its device's pace (round 6: no copy, no event)
+    unsigned long long *hring;
+    int launch;
     // pinned HOST mirrors (mapped; null = none): the accepted prices / net trade are stored there as well whenever a point is
     // accepted, the state record when the solve ends -- the host reads its result after one synchronisation, no copies
     double *h_nu_acc, *h_psi_acc;
@@ -345,7 +355,10 @@ iter_kernel(IterArgs a)
     if (DET) for (int j = n + tid; j < tile; j += blockDim.x) psi_s[j] = 0.0;      // (limbs behind the stash: entries [0, n) are recycled by their owners below)
     DevState st = a.st3[pr];
     if (st.status != 0) {                                // the solve has ended: every workgroup of every later launch leaves here;
-        if (blockIdx.x == 0 && tid == 0) a.st3[p] = st;  // the final state is handed on, or the launch after next would read a set
+        if (blockIdx.x == 0 && tid == 0) {
+            a.st3[p] = st;                               // the final state is handed on, or the launch after next would read a set
+            if (a.hring) __hip_atomic_store(a.hring + (a.launch & (ITER_HRING - 1)), iter_hring_word(st.evals, st.status, a.launch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;                                          // from before the end (status 0) and resume from stale state
     }
     st.evals = uni(st.evals); st.iters = uni(st.iters); st.first = uni(st.first); st.hist = uni(st.hist);
@@ -648,6 +661,7 @@ iter_kernel(IterArgs a)
             // progress word for the host (system-scope store into pinned host memory: no copy, no API call on the host side)
             if (a.hstat) __hip_atomic_store(a.hstat, (unsigned long long)(unsigned)st.evals | ((unsigned long long)(unsigned)st.status << 32),
                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (a.hring) __hip_atomic_store(a.hring + (a.launch & (ITER_HRING - 1)), iter_hring_word(st.evals, st.status, a.launch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     if (st.status != 0) {                                // ended (converged / stalled / out of budget): nothing to evaluate
