@@ -22,7 +22,14 @@ STATUS = {1: "optimal", 2: "stalled", 3: "max_evals"}
 
 
 class CfmmError(RuntimeError):
-    pass
+    """an error return of libcfmm_hip; `code` is the library's return code (include/cfmm.h: CFMM_E_*), None for errors raised on the
+    Python side of the binding"""
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+E_ARG, E_HIP, E_STATE, E_LIMIT, E_RCCL, E_NUMERIC, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7      # include/cfmm.h
 
 
 class Opts(C.Structure):
@@ -195,7 +202,7 @@ class Context:
 
     def _chk(self, rc):
         if rc != 0:
-            raise CfmmError(f"libcfmm_hip error {rc}: {self.L.cfmm_last_error(self.h).decode()}")
+            raise CfmmError(f"libcfmm_hip error {rc}: {self.L.cfmm_last_error(self.h).decode()}", code=int(rc))
 
     @property
     def backend(self):

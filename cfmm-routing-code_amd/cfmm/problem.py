@@ -542,7 +542,14 @@ class Problem:
         utilities = list(utilities)
         ctx = self._ensure_ctx()
         if batch is None and nu0s is None and self._sweep_applies(ctx, utilities, kw):
-            return self._solve_sweep(utilities, **kw)
+            # (the test above mirrors the library's own -- tile sizes, the one-workgroup path switched on -- and cannot know a build or
+            #  an environment that differs, CFMM_TINY=0, another WT_LIGHT: a library that declines falls through to the paths below
+            #  instead of failing a call they would serve; ADVICE r5.  warm_start and concurrency mean nothing to the one-call sweep.)
+            try:
+                return self._solve_sweep(utilities, **kw)
+            except CfmmError as e:
+                if getattr(e, "code", None) != _lib.E_UNSUPPORTED:
+                    raise
         can_batch = (hasattr(ctx, "solve_batch") and "sum2" not in self.net and "curve2" not in self.net and "pow2" not in self.net and self._host is None
                      and not any(_is_general(x) for x in utilities)
                      and not self.deterministic and kw.get("method", "auto") in ("auto", "lbfgs"))
@@ -809,8 +816,8 @@ class Problem:
             self._global_counts = cnt
         n_stable, n_sum = int(cnt[0]), int(cnt[1])
         if nu0 is None:
-            if warm_start and self.nu is not None:
-                nu0 = self.nu
+            if warm_start and self.nu is not None and np.all(np.isfinite(self.nu)) and np.all(np.asarray(self.nu) > 0.0):
+                nu0 = self.nu                     # (a previous solve that ended on collapsed / non-finite prices is no warm start: cold instead)
             elif host and not np.all(u.c > 0):
                 # start prices are a guess propagated through THIS rank's pools: rank 0's guess is everyone's
                 nu0 = host.broadcast(start_prices(self.net, u) if rank == 0 else np.zeros(self.n), src=0)
@@ -826,9 +833,8 @@ class Problem:
         kw = dict(max_evals=max_evals, memory=memory, iters_per_graph=iters_per_graph)
         total = dict(evals=0, iters=0, wall_seconds=0.0, device_seconds=0.0, rounds=0)
         general = _is_general(u)      # entries of the utility table: generic first-order iteration or the second-order path; no ties
-        if general and n_sum:
-            raise ValueError("a utility with ULOG / UQUAD entries over a network with constant-sum pools: the kink recovery ties prices, "
-                             "the utility table's entries take no ties")
+        # (round 5 refused such a utility over ANY network with constant-sum pools, the K-asset table's included, for every method: what
+        #  cannot be had is the tie loop -- a plain first-order leg and the second-order path, which smooths these pools, need no ties)
         # (the K-asset table's pools are in the second-order path too: the stableswap entry with its exact Hessian block, the constant-sum
         #  entry smoothed in price space -- csrc/phik.hpp: table_newton_kernel, gk_sum_newton_kernel)
         can_second = getattr(ctx, "second_order", False)
@@ -839,9 +845,9 @@ class Problem:
         many_stable = n_stable >= AUTO_NEWTON_MIN_STABLE
         second_order = method == "newton" or (method == "auto" and can_second and many_stable)
         if not second_order:
-            if n_sum == 0:
+            if n_sum == 0 or general:
                 st = self._run(ctx, nu0, total, tol=tol, method=_lib.METHODS["lbfgs"], **kw)
-                nu, psi = ctx.get_solution()
+                nu, psi = self._solution_of(ctx, st, nu0)
             else:
                 self._kinks_settled = False
                 st, nu, psi = self._solve_kinks(ctx, nu0, tol, dict(kw, method=_lib.METHODS["lbfgs"]), kink_tol, max_rounds, total)
@@ -865,9 +871,17 @@ class Problem:
         # ~18 steps of a cold solve into 4-7 (the parametric sweep of two-asset.py:34-100)
         cont = warm_start and nu0_given is None and self.nu is not None and (self.stats or {}).get("method") == _lib.METHODS["newton"]
         st = self._run(ctx, None if cont else nu0, total, tol=tol, method=_lib.METHODS["newton"], **kw)
-        nu, psi = ctx.get_solution()
+        nu, psi = self._solution_of(ctx, st, nu0)
         self._finish(st, nu, psi, total)
         return self.value
+
+    @staticmethod
+    def _solution_of(ctx, st, nu_start):
+        """(nu, psi) of the run `st` -- or, for a run that ended in the library's numeric error, the start prices and NO net trade: the
+        device's buffers then still hold the PREVIOUS solve's point, which must not be certified in this one's name"""
+        if "numeric_error" in st:
+            return np.asarray(nu_start, dtype=np.float64).copy(), None
+        return ctx.get_solution()
 
     @staticmethod
     def _run(ctx, nu, total, **kw):
@@ -877,7 +891,12 @@ class Problem:
             # an iteration that ran into non-finite numbers (a degenerate instance: prices hundreds of orders of magnitude apart) is a
             # solve that did not converge, not a crash of the caller: reported as "stalled", and `method="auto"` goes on to the
             # second-order path (tools/fuzz_table.py)
-            if "finite" not in str(e):
+            # (ONLY the library's CFMM_E_NUMERIC -- "dual value is not finite", "non-finite value in the second-order iteration": an argument
+            #  check that happens to mention "finite" -- a start price that is not positive and finite -- is the caller's error and is raised.
+            #  the substring test swallowed those too, and _finish then certified the PREVIOUS solve's point)
+            numeric = getattr(e, "code", None) == _lib.E_NUMERIC or (getattr(e, "code", None) is None and
+                                                                     ("dual value is not finite" in str(e) or "non-finite value in the second-order iteration" in str(e)))
+            if not numeric:
                 raise
             st = dict(evals=0, iters=0, status=2, n_ranks=1, dual_value=float("nan"), primal_value=float("nan"), gap=float("inf"), infeas=float("inf"),
                       wall_seconds=0.0, device_seconds=0.0, pg=float("nan"), pool_subproblems=0, barrier_mu=0.0, newton_steps=0,
@@ -901,7 +920,10 @@ class Problem:
         Two-asset pools: log nu_a - log nu_b = +-log gamma.  Pools of the K-asset table (arbitrage.py:73-74 over k > 2 tokens): with `lo`
         the pool's cheapest token, leg j is partially drained where gamma nu_j = nu_lo -- the same record with a = lo, b = j, tender a.
         Returns {(rank, k, pool, leg): record} (k = 2, leg = 0: the two-asset bucket): the pool's data travels with its key, so that
-        every rank of a pool-sharded solve can build the same ties and the same fill recovery from the union of all ranks' candidates."""
+        every rank of a pool-sharded solve can build the same ties and the same fill recovery from the union of all ranks' candidates.
+        A K-asset record carries the pool's WHOLE token list and reserves (`pidx`, `pR`): whether its kink still stands, what a switch
+        record pays and the drain -> switch conversion are then functions of the record alone -- on every rank the same, whoever owns
+        the pool (round 5 looked them up in the local bucket under the record's pool index: another rank's pool, or none -- ADVICE r5)."""
         rank = self._host.rank if self._host else 0
         out = {}
         if "sum2" in self.net:
@@ -933,7 +955,8 @@ class Problem:
                 key = (rank, k, i, j)
                 if key not in tied and (key, 1) not in banned:
                     out[key] = dict(sgn=1, ia=int(b["idx"][lo[i], i]), ib=int(b["idx"][j, i]), fee=float(b["fee"][i]),
-                                    Ra=float(b["R"][lo[i], i]), Rb=float(b["R"][j, i]), loose=bool(loose), leg_lo=int(lo[i]))
+                                    Ra=float(b["R"][lo[i], i]), Rb=float(b["R"][j, i]), loose=bool(loose), leg_lo=int(lo[i]),
+                                    pidx=[int(x) for x in b["idx"][:, i]], pR=[float(x) for x in b["R"][:, i]])
             # the pool's OTHER kind of kink: two tokens tied for cheapest (nu_a = nu_b) -- which of them pays for the drained tokens
             # switches there, and the whole payment with it; at the optimum it is split.  Record: a = the token the device makes pay (the
             # first of the equals), b = the other; "sgn" 0 marks it; the amount P / gamma is filled in when the fills are recovered
@@ -950,7 +973,8 @@ class Problem:
                 key = (rank, k, i, 100 + 10 * ja + jb)
                 if key not in tied and (key, 0) not in banned:
                     out[key] = dict(sgn=0, ia=int(b["idx"][ja, i]), ib=int(b["idx"][jb, i]), fee=float(b["fee"][i]), Ra=0.0, Rb=0.0,
-                                    loose=bool(loose), leg_a=ja, leg_b=jb, pool=i, k=k)
+                                    loose=bool(loose), leg_a=ja, leg_b=jb, pool=i, k=k,
+                                    pidx=[int(x) for x in b["idx"][:, i]], pR=[float(x) for x in b["R"][:, i]])
         if self._host:                                   # the union over ranks, identical everywhere
             merged = {}
             for part in self._host.allgather(out):
@@ -1006,6 +1030,8 @@ class Problem:
                 for k in flagsg:
                     ctx.set_pool_flagsG(k, None)
                 st = self._run(ctx, nu, total, tol=tol, **dict(kw, max_evals=budget))
+            if "numeric_error" in st:
+                return st, nu, None        # (the leg ran into non-finite numbers: its start prices, no net trade -- _finish reports "stalled")
             nu, psi = ctx.get_solution()
             if not (np.all(np.isfinite(nu)) and np.all(nu > 0.0)):
                 break                      # a price has collapsed (a token to sell that no pool lists: the dual is unbounded) -- _finish says "infeasible"
@@ -1043,9 +1069,8 @@ class Problem:
                             ja, jb = sorted((rec["leg_lo"], k[3]))
                             k2 = (k[0], k[1], k[2], 100 + 10 * ja + jb)
                             if k2 not in tied and (k2, 0) not in banned:
-                                bb = self.net["gk"][("sum", k[1])]
-                                tied[k2] = dict(sgn=0, ia=int(bb["idx"][ja, k[2]]), ib=int(bb["idx"][jb, k[2]]), fee=rec["fee"], Ra=0.0, Rb=0.0,
-                                                loose=False, leg_a=ja, leg_b=jb, pool=k[2], k=k[1])
+                                tied[k2] = dict(sgn=0, ia=int(rec["pidx"][ja]), ib=int(rec["pidx"][jb]), fee=rec["fee"], Ra=0.0, Rb=0.0,
+                                                loose=False, leg_a=ja, leg_b=jb, pool=k[2], k=k[1], pidx=rec["pidx"], pR=rec["pR"])
                     tied = dict(sorted(tied.items()))
                     continue
             new = self._kink_candidates(nu, kink_tol, banned, tied)
@@ -1068,8 +1093,7 @@ class Problem:
         return st, nu, psi
 
     def _kink_still_stands(self, nu, key, rec):
-        b = self.net["gk"][("sum", key[1])]
-        lnu = np.log(nu[b["idx"][:, key[2]]])
+        lnu = np.log(nu[np.asarray(rec["pidx"], dtype=np.int64)])        # (the pool's own token list: the record's, not a local bucket's)
         lo = float(lnu.min())
         legs = (rec["leg_a"], rec["leg_b"]) if rec["sgn"] == 0 else (rec["leg_lo"],)
         return all(lnu[j] <= lo + 1e-9 for j in legs)
@@ -1080,16 +1104,16 @@ class Problem:
         for key, rec in tied.items():
             if rec["sgn"] != 0:
                 continue
-            b = self.net["gk"][("sum", rec["k"])]
             i = rec["pool"]
-            p = nu[b["idx"][:, i]]
+            p = nu[np.asarray(rec["pidx"], dtype=np.int64)]
+            R = np.asarray(rec["pR"], dtype=np.float64)
             lo = rec["leg_a"]
-            drained = b["fee"][i] * p > p[lo]
+            drained = rec["fee"] * p > p[lo]
             drained[lo] = False
             for k2, r2 in tied.items():                           # legs of this pool tied on a drain kink: left out by the device
-                if r2["sgn"] == 1 and k2[1] == rec["k"] and k2[2] == i and k2[3] < 100:
+                if r2["sgn"] == 1 and k2[0] == key[0] and k2[1] == rec["k"] and k2[2] == i and k2[3] < 100:
                     drained[k2[3]] = False
-            rec["Rb"] = float(b["R"][drained, i].sum() / b["fee"][i])
+            rec["Rb"] = float(R[drained].sum() / rec["fee"])
 
     def _fill_vector(self, rec):
         """net trade of the tied constant-sum pool `rec` at full fill in its kink's direction"""
@@ -1207,6 +1231,7 @@ class Problem:
         # psi of the repaired point is re-summed from the tenders that are handed out, not patched: down a flat ray the prices end
         # tens of orders of magnitude apart, and there the evaluation's psi and the tender kernel's need not agree on a worthless pool
         psi2 = np.zeros(self.n)
+        psi_dropped = np.zeros(self.n)                    # net trade of the pools left untouched: their arbitrage value stays in the DUAL
         zeroed, lister = {}, {}
         arrays = self._pool_token_arrays()
         for key, idx in arrays:
@@ -1219,6 +1244,7 @@ class Problem:
             np.add.at(psi2, idx[:, keep].ravel(), (l - d)[:, keep].ravel())
             if allw.any():
                 zeroed[key] = allw
+                np.add.at(psi_dropped, idx[:, allw].ravel(), (l - d)[:, allw].ravel())
         r = psi2 + u.h
         give = np.where(W & (u.ctype == EQ) & (r > 0.0), r, 0.0)
         for j in np.flatnonzero(give):
@@ -1226,12 +1252,17 @@ class Problem:
                 return False                              # (no pool lists it: truly infeasible)
         if not zeroed and not give.any():
             return False
+        # the dual value at nu counts EVERY pool's arbitrage value, the untouched ones' included: the repaired point's gap is taken against
+        # that, not against a dual rebuilt from the repaired psi (with the zeroed pools' nu'(L - D) missing from both sides a
+        # repair at the loosest threshold could pass the gap test it should fail)
+        self._repair_dual = float((nu - u.c) @ u.h + nu @ (psi2 + psi_dropped))
         psi2 = psi2 - give
         saved = (self._theta, self._trade_cache)
         names = ("value", "dual_value", "gap", "infeas", "nu", "psi", "status", "stats")
         before = {k: getattr(self, k, None) for k in names}
         self._theta = {}                                  # (psi2 already holds the fills)
         self._finish(st, nu, psi2, total, _recovering=True)
+        self._repair_dual = None
         if self.status != "optimal":                      # not a repair: everything back as the solve left it
             self._theta, self._trade_cache = saved
             for k, v in before.items():
@@ -1251,6 +1282,14 @@ class Problem:
 
     def _finish(self, st, nu, psi, total, _recovering=False):
         u = self.utility
+        if psi is None:                       # a run that ended in a numeric error: nothing to certify
+            self.value = self.dual_value = float("nan")
+            self.gap = self.infeas = float("inf")
+            self.nu, self.psi = nu, np.full(self.n, np.nan)
+            self.status = "stalled"
+            self.stats = dict(st); self.stats.update(total)
+            self.stats["pool_subproblems"] = total["evals"] * self.m
+            return self
         if self._theta:
             psi = psi.copy()
             for rec, th in self._theta.values():
@@ -1286,6 +1325,9 @@ class Problem:
             # sum_i arb_i = nu'psi_pools; tied pools trade value-neutrally at their kink prices
             self.dual_value = nu_psi if plain else float((nu - u.c) @ u.h + nu @ psi)
             self.gap = abs(cs) / max(1.0, abs(self.dual_value))
+            if _recovering and getattr(self, "_repair_dual", None) is not None:      # (a repaired primal point against the dual value of ALL pools)
+                self.dual_value = self._repair_dual
+                self.gap = abs(self.dual_value - self.value) / max(1.0, abs(self.dual_value))
         floor = 1e-12 * self._max_reserve()       # (trades of rounding size at a no-arbitrage optimum: noise over noise is not an infeasibility)
         if plain:
             lo, hi = float(psi.min()), float(psi.max())

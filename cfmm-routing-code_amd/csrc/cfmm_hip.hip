@@ -130,6 +130,8 @@ struct cfmm_ctx {
     // tokens / state (device)
     double *c = nullptr, *h = nullptr, *off = nullptr, *glo = nullptr, *ghi = nullptr;
     int *ctype = nullptr, *grp = nullptr;
+    int *gptr = nullptr, *gmem = nullptr;      // price ties: the tokens of every group, ascending (kernels.hpp: UpdArgs::gptr)
+    double *tie_tmp = nullptr;                 // [2 n] per-token terms of the ordered group sums
     double *nu = nullptr, *nu_acc = nullptr, *psi_acc = nullptr, *psi_t = nullptr, *nu0 = nullptr;
     double *s = nullptr, *s_t = nullptr, *Gs = nullptr, *Gs_t = nullptr, *d = nullptr, *Ds = nullptr;
     double *S = nullptr, *Y = nullptr, *rho = nullptr;
@@ -1009,6 +1011,7 @@ UpdArgs make_upd_args(cfmm_ctx *ctx, const cfmm_opts &o)
     a.acc = ctx->acc;
     a.c = ctx->c; a.h = ctx->h; a.off = ctx->off; a.glo = ctx->glo; a.ghi = ctx->ghi;
     a.ctype = ctx->ctype; a.grp = ctx->grp;
+    a.gptr = ctx->ng != ctx->n ? ctx->gptr : nullptr; a.gmem = ctx->gmem; a.tie_tmp = ctx->tie_tmp;
     a.nu = ctx->nu; a.nu_acc = ctx->nu_acc; a.psi_acc = ctx->psi_acc; a.psi_t = ctx->psi_t;
     a.s = ctx->s; a.s_t = ctx->s_t; a.Gs = ctx->Gs; a.Gs_t = ctx->Gs_t; a.d = ctx->d; a.Ds = ctx->Ds;
     a.S = ctx->S; a.Y = ctx->Y; a.rho = ctx->rho;
@@ -1782,6 +1785,36 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     double move_prev = 0.0;                     // ... and its largest log-price move
     int chord_run = 0, chord_steps = 0;
     double fac_mu = 0.0;
+    // The certificates at the START point, from the exact evaluation just made (round 6).  Prices inside the utility's
+    // box at which psi + h is feasible and complementary ARE the optimum -- the no-arbitrage network under a linear utility is the
+    // case that matters: at nu = c nothing trades, psi = 0, value 0.  The barrier path has no business there: its smoothed pools trade
+    // O(mu) each, the iteration chases rounding around a zero-valued optimum and explicit `CFMM_METHOD_NEWTON` runs ended "stalled" at
+    // gaps up to 4.8e-2 (tools/fuzz_table.py seeds 12, 345, 609, 819, 945; fuzz_small.py seed 1434).  Linear-box utilities only.
+    bool certified_at_start = false;
+    {
+        bool linear_box = true;
+        double cs = 0.0, viol = 0.0, scale = 0.0, lin = 0.0, pr = 0.0;
+        for (int j = 0; j < n; ++j) {
+            if (ct[j] >= CFMM_ULOG) { linear_box = false; break; }
+            const double r = psi_x[j] + h[j];
+            lin += (nu[j] - c[j]) * h[j]; pr += c[j] * psi_x[j]; cs += (nu[j] - c[j]) * r;
+            viol = std::max(viol, ct[j] == CFMM_GE ? std::max(-r, 0.0) : (ct[j] == CFMM_EQ ? std::fabs(r) : 0.0));
+            scale = std::max(scale, std::max(std::fabs(psi_x[j]), std::fabs(h[j])));
+        }
+        if (linear_box) {
+            const double d0 = lin + arb_x;
+            const double gap0 = std::fabs(cs) / std::max(1.0, std::fabs(d0));
+            const double infeas0 = viol / std::max(std::max(scale, 1e-12 * ctx->g_max_reserve), 1e-300);
+            if (std::isfinite(d0) && gap0 <= o.tol_gap && infeas0 <= o.tol_infeas) {
+                certified_at_start = true;
+                status = 1; gap = gap0; infeas = infeas0; primal = pr; dual = d0;
+                e.psi = psi_x; e.value = arb_x; e.trade = arb_x;
+                mu = 0.0;                       // (an exact point: the tenders are the pools' own, no barrier weight)
+                if (trace) fprintf(stderr, "[newton] certified at the start prices: dual %.10g gap %.2e infeas %.2e\n", d0, gap0, infeas0);
+            }
+        }
+    }
+    if (!certified_at_start)
     for (;;) {
         // (not in the low-order regime either -- moves below ~1e-10 in log-price, where a partially filled constant-sum pool's
         //  fill reacts to price changes under the fp64 resolution of the prices: the Hessian changes by orders of magnitude from
@@ -2108,6 +2141,7 @@ int cfmm_create(int device, int n_tokens, cfmm_ctx **out)
         // (c | h | glo | ghi | ctype are contiguous: cfmm_set_utility sends them as ONE copy from a pinned mirror)
         want(&ctx->c, n + 4); want(&ctx->h, n + 4); want(&ctx->glo, n + 4); want(&ctx->ghi, n + 4); want(&ctx->ctype, n + 4);
         want(&ctx->off, n + 4); want(&ctx->grp, n + 4);
+        want(&ctx->gptr, n + 5); want(&ctx->gmem, n + 4); want(&ctx->tie_tmp, 2 * (size_t)n + 4);
         double **vecs[] = {&ctx->nu, &ctx->nu_acc, &ctx->psi_acc, &ctx->psi_t, &ctx->nu0, &ctx->s, &ctx->s_t,
                            &ctx->Gs, &ctx->Gs_t, &ctx->d, &ctx->Ds};
         for (auto v : vecs) want(v, n + 4);                  // nu[n] = stop flag; +1: pair loads
@@ -2732,6 +2766,19 @@ int cfmm_set_ties(cfmm_ctx *ctx, int n_groups, const int32_t *grp, const double 
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->grp, ctx->hgrp.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->off, ctx->hoff.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->ng != n) {
+        // the groups' member lists, tokens ascending (a counting sort): the update kernels sum a group's gradient in THIS order, the
+        // same on every rank of a pool-sharded solve (kernels.hpp: UpdArgs::gptr).  Pageable sources: the copies are synchronous
+        // with respect to the host buffers, which may therefore be locals
+        std::vector<int> gp(ctx->ng + 1, 0), gm(n);
+        for (int j = 0; j < n; ++j) ++gp[ctx->hgrp[j] + 1];
+        for (int r = 0; r < ctx->ng; ++r) gp[r + 1] += gp[r];
+        std::vector<int> fill(gp.begin(), gp.end() - 1);
+        for (int j = 0; j < n; ++j) gm[fill[ctx->hgrp[j]]++] = j;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->gptr, gp.data(), (ctx->ng + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->gmem, gm.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->g_valid = false;                  // the number of groups is baked into the captured launches
     return recompute_bounds(ctx);
 }

@@ -1190,7 +1190,25 @@ struct UpdArgs {
     const UpdArgs *batch;
     unsigned long long *hstat;
     const int *pool_flags;            // sweep launches (tiny.hpp, BATCH): this solve's tied-pool flags of the constant-sum bucket, or null
+    // Price ties, ORDERED group sums (round 6): gptr[ng + 1] / gmem[n] = the tokens of every group in ascending order (cfmm_set_ties),
+    // tie_tmp[2 n] = scratch for the per-token terms.  The group gradient used to be summed by LDS atomics, i.e. in whatever order the
+    // waves arrived: for a group of three or more tokens the sum then differs in its last bits from run to run -- and between the RANKS of
+    // a pool-sharded solve, whose replicated update must produce the same bits everywhere (found by the two-rank test of the K-asset
+    // constant-sum kinks, which tie longer chains of prices than the two-asset pools did).  Null: the atomics (the one-wave solves).
+    const int *gptr, *gmem;
+    double *tie_tmp;
 };
+// the group's sum of the per-token terms the workgroup has just stored (behind a barrier), members in ascending token order
+__device__ __forceinline__ void tie_group_sum(const UpdArgs &a, int g, bool with_d, double &s1, double &s2)
+{
+    s1 = 0.0; s2 = 0.0;
+    const int m1 = a.gptr[g + 1];
+    for (int m = a.gptr[g]; m < m1; ++m) {
+        const int t = a.gmem[m];
+        s1 += a.tie_tmp[t];
+        if (with_d) s2 += a.tie_tmp[a.n + t];
+    }
+}
 template <bool BATCH>
 __device__ __forceinline__ const UpdArgs &upd_args(const UpdArgs &a0)
 {
@@ -1283,7 +1301,10 @@ __device__ __forceinline__ int update_generic_body(const UpdArgs &a, double *lds
             maxs[0] = fmax(maxs[0], ct == 0 ? fmax(-rj, 0.0) : (ct == 1 ? fabs(rj) : 0.0));
             maxs[1] = fmax(maxs[1], fmax(fabs(psi), fabs(hj)));
         }
-        if (ties) {                          // group sums through LDS (ds_add_f64)
+        if (ties && a.gptr) {                // group sums in a fixed order: the terms out, summed per group behind the barrier below
+            a.tie_tmp[j] = nuj * rj;
+            if (st.first) a.tie_tmp[n + j] = dg;
+        } else if (ties) {                   // group sums through LDS (ds_add_f64)
             unsafeAtomicAdd(&q[a.grp[j]], nuj * rj);
             if (st.first) unsafeAtomicAdd(&q2[a.grp[j]], dg);
         } else {
@@ -1297,7 +1318,14 @@ __device__ __forceinline__ int update_generic_body(const UpdArgs &a, double *lds
     }
     sums[0] += fpools;                       // f_t = sum arb + (nu - c)'h
     block_reduce<2, 2>(sums, maxs, scratch);
-    if (ties) {
+    if (ties && a.gptr) {                    // (block_reduce's barriers stand between the terms' stores and these loads)
+        for (int r = tid; r < ng; r += nt) {
+            double g1, g2;
+            tie_group_sum(a, r, st.first != 0, g1, g2);
+            a.Gs_t[r] = g1; if (st.first) a.Ds[r] = g2;
+        }
+        __syncthreads();
+    } else if (ties) {
         for (int r = tid; r < ng; r += nt) { a.Gs_t[r] = q[r]; if (st.first) a.Ds[r] = q2[r]; }
         __syncthreads();
     }
@@ -1659,7 +1687,10 @@ update_reg_kernel(UpdArgs a0)
                 rj = psi[e] - ut[e].pstar;
                 if (st.first) dg[e] += fmax(ut[e].curv, 0.0);
             }
-            if (ties) {
+            if (!BATCH && ties && a.gptr) {  // (ordered group sums: UpdArgs::gptr; the batched solves take no ties)
+                a.tie_tmp[r0 + e] = nuj[e] * rj;
+                if (st.first) a.tie_tmp[n + r0 + e] = dg[e];
+            } else if (ties) {
                 unsafeAtomicAdd(&q[grp[e]], nuj[e] * rj);
                 if (st.first) unsafeAtomicAdd(&q2[grp[e]], dg[e]);
             } else {
@@ -1668,7 +1699,16 @@ update_reg_kernel(UpdArgs a0)
             }
         }
     }
-    if (ties) {
+    if (!BATCH && ties && a.gptr) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (gin[e]) {
+            double g1, g2;
+            tie_group_sum(a, r0 + e, st.first != 0, g1, g2);
+            Gs_t[e] = g1; if (st.first) Ds[e] = g2;
+        }
+        __syncthreads();
+    } else if (ties) {
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < E; ++e) if (gin[e]) { Gs_t[e] = q[r0 + e]; if (st.first) Ds[e] = q2[r0 + e]; }
@@ -2021,7 +2061,10 @@ update_gram_kernel(UpdArgs a0)
         Gs_t[e] = 0.0;
         if (tin[e]) {
             const double rj = psi[e] + hj[e];
-            if (ties) {
+            if (!BATCH && ties && a.gptr) {  // (ordered group sums: UpdArgs::gptr; the batched solves take no ties)
+                a.tie_tmp[r0 + e] = nuj[e] * rj;
+                if (st.first) a.tie_tmp[n + r0 + e] = dg[e];
+            } else if (ties) {
                 unsafeAtomicAdd(&q[grp[e]], nuj[e] * rj);
                 if (st.first) unsafeAtomicAdd(&q2[grp[e]], dg[e]);
             } else {
@@ -2030,7 +2073,16 @@ update_gram_kernel(UpdArgs a0)
             }
         }
     }
-    if (ties) {
+    if (!BATCH && ties && a.gptr) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (gin[e]) {
+            double g1, g2;
+            tie_group_sum(a, r0 + e, st.first != 0, g1, g2);
+            Gs_t[e] = g1; if (st.first) Ds[e] = g2;
+        }
+        __syncthreads();
+    } else if (ties) {
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < E; ++e) if (gin[e]) { Gs_t[e] = q[r0 + e]; if (st.first) Ds[e] = q2[r0 + e]; }
@@ -2331,6 +2383,14 @@ start_kernel(UpdArgs a0, const double *nu0_, double *zero, long long nzero, DevS
     const int n = a.n, ng = a.ng;
     for (int r = tid; r < ng; r += nt) { sum[r] = 0.0; cnt[r] = 0.0; }
     __syncthreads();
+    if (a.gptr && ng != n) {                 // (ordered: the mean log-price of a group the same bits on every rank, UpdArgs::gptr)
+        for (int r = tid; r < ng; r += nt) {
+            double v = 0.0;
+            const int m1 = a.gptr[r + 1];
+            for (int m = a.gptr[r]; m < m1; ++m) { const int t = a.gmem[m]; v += log(nu0[t]) - a.off[t]; }
+            sum[r] = v; cnt[r] = (double)(m1 - a.gptr[r]);
+        }
+    } else
     for (int j = tid; j < n; j += nt) {
         unsafeAtomicAdd(&sum[a.grp[j]], log(nu0[j]) - a.off[j]);
         unsafeAtomicAdd(&cnt[a.grp[j]], 1.0);

@@ -348,6 +348,11 @@ __device__ __forceinline__ void tileg_stable(const BucketG &b, int tb, int lane,
     static_assert(!NEWT || (!WITH_D && !DET), "the second-order tile: plain accumulation, no metric");
     constexpr int P = 64 / K;
     constexpr double INF = 1.7976931348623157e308;
+    // (opaque copy, as in kernels.hpp: tilen -- otherwise lane / K, lane % K and the strip addresses of all seven instantiations are hoisted
+    //  out of the tile loop and stay live across it: table_newton_kernel<true> sat at 256 VGPRs WITH three dwords spilled, round 5)
+#ifndef CFMM_NO_OPAQUE_LANE
+    asm volatile("" : "+v"(lane));
+#endif
     const int g = lane / K, j = lane - g * K;
     const unsigned pool = (unsigned)tb * P + g;
     const bool live = g < P && pool < (unsigned long long)b.m;

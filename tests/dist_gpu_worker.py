@@ -54,9 +54,39 @@ def same_gpu():
     dist.destroy_process_group()
 
 
+def same_gpu_gk():
+    """argv[2] == "same_gpu_gk": 1 000 K-asset constant-sum pools (arbitrage.py:73-74 over 3-5 tokens) among 20 000 constant-product
+    pools, pool-sharded over processes sharing GPU 0.  Their optimum sits on kinks of both kinds (a leg partially drained, two
+    tokens tied for cheapest): the host's active-set loop must take the SAME decisions on every rank from records that carry the
+    owning rank's pool -- round 5 looked the pool up in the local shard (ranks desynchronised or IndexError)."""
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    net = synthetic.make_network(200, m_cp2=20000, m_gk_sum=1000, seed=3)
+    p = cfmm.distributed.sharded_problem(net, cfmm.Arbitrage(net["c"]), dist=dist, device=0, allreduce="oneshot", rccl=False)
+    v = p.solve(tol=1e-6, max_evals=1500, method="lbfgs")
+    mine = dict(value=v, status=p.status, gap=p.gap, infeas=p.infeas, evals=p.stats["evals"], rounds=p.stats.get("rounds"), nu=p.nu.tolist(), psi=p.psi.tolist(),
+                theta=sorted([list(k), th] for k, (_, th) in p._theta.items()), owners=sorted({k[0] for k in p._theta}))
+    box = [None] * world
+    dist.all_gather_object(box, mine)
+    ref = None
+    if rank == 0:
+        q = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+        ref = dict(value=q.solve(tol=1e-6, max_evals=1500, method="lbfgs"), status=q.status, ntheta=len(q._theta))
+        q.close()
+    p.close()
+    dist.barrier()
+    if rank == 0:
+        with open(sys.argv[1], "w") as fh:
+            json.dump(dict(world=world, ranks=box, unsharded=ref), fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) > 2 and sys.argv[2] == "same_gpu":
         return same_gpu()
+    if len(sys.argv) > 2 and sys.argv[2] == "same_gpu_gk":
+        return same_gpu_gk()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local))

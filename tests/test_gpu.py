@@ -1060,6 +1060,29 @@ def test_one_shot_exchange_between_processes_sharing_one_gpu(tmp_path, world=2):
             assert abs(q["value"] - ref["value"]) <= 2e-6 * abs(ref["value"])
 
 
+def test_k_asset_constant_sum_kinks_in_a_pool_sharded_solve(tmp_path, world=2):
+    """the K-asset constant-sum kink records of a pool-sharded solve.  Two processes share GPU 0, each holds half of
+    1 000 such pools; the optimum has partially drained legs and tied cheapest tokens on BOTH shards.  Every rank must end on the same
+    prices, the same fills (records of both owners among them) and the certificates -- and on the unsharded optimum."""
+    import subprocess, sys, json, socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "same_gpu_gk.json")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(here, "dist_gpu_worker.py"), out, "same_gpu_gk"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    doc = json.load(open(out))
+    ranks, ref = doc["ranks"], doc["unsharded"]
+    assert ref["status"] == "optimal" and ref["ntheta"] > 0
+    for q in ranks:
+        assert q["status"] == "optimal" and q["gap"] <= 1e-6 and q["infeas"] <= 1e-6, (q["status"], q["gap"], q["infeas"])
+        assert q["nu"] == ranks[0]["nu"] and q["theta"] == ranks[0]["theta"] and q["evals"] == ranks[0]["evals"]
+        assert len(q["theta"]) > 0 and all(0.0 < th < 1.0 for _, th in q["theta"])
+        assert abs(q["value"] - ref["value"]) <= 2e-6 * abs(ref["value"])
+    assert ranks[0]["owners"] == list(range(world)), ranks[0]["owners"]       # kinks of pools of EVERY shard were tied and filled
+
+
 def test_one_shot_all_reduce_against_rccl_on_real_peers(tmp_path):
     """needs >= 2 GPUs (skipped on the one-GPU box): one process per GPU, the same sharded evaluation and solve over RCCL
     and over the one-shot mailboxes mapped through hipIpc.  Every rank holds the same bits either way; the two

@@ -86,6 +86,58 @@ def test_table_pools_evaluation_tenders_and_invariants(oracle_lib):
     p.close()
 
 
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 6, 7, 8])
+def test_stableswap_hessian_block_against_finite_differences_of_the_numpy_restatement(k):
+    """the table's stableswap Hessian block was pinned HIP-against-HIP only (the tile kernel against the
+    one-pool-per-lane kernel, both this library's device code) -- and a Newton iteration with a slightly wrong Hessian and a right
+    gradient still converges, so the optimum tests do not pin it either.  Here: every entry of the block the device assembles,
+    B_jk = nu_j d psi_j / d log nu_k (the diagonal's own nu_j psi_j aside: the caller carries it), against CENTRAL DIFFERENCES in
+    log-prices of oracle/pools_np.py's K-asset psi (nested bisection on the pool's two scalar equations: shares no code and no
+    formula with csrc/phik.hpp: stable_block), K = 2 .. 8, 1e-6 of the largest entry.  Entries whose two step sizes disagree sit on a
+    kink of the generalised Hessian (a leg entering or leaving the trade inside the stencil) and are left out; they must be few."""
+    peg = max(4, k)
+    n = 4 * peg
+    net = synthetic.make_network(n, m_gk_stable=32, gk_sizes=(k, k), seed=5 + k, peg=peg)
+    assert list(net["gk"]) == [("stable", k)] and not any(key in net for key in ("cp2", "w2", "gn", "curve2"))
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    ctx = p._ensure_ctx(); p._send_utility()
+    nu = net["c"] * np.exp(np.random.default_rng(k).normal(0, 0.01, n))
+    _, _, psi_dev, H = ctx.eval_smooth(nu, 1e-9, want_hessian=True)
+    p.close()
+    f0, psi0 = _table_reference(net, nu)
+    assert np.abs(psi_dev - psi0).max() <= 1e-9 * np.abs(psi0).max()        # (the point itself: the device's psi is the restatement's)
+
+    b = net["gk"][("stable", k)]
+    m = b["R"].shape[1]
+
+    def fd(delta):
+        """J[j, kk] = d psi_j / d log nu_kk by central differences: the 2 n perturbed price vectors as ONE call of the restatement"""
+        V = np.repeat(nu[None, :], 2 * n, axis=0)              # [2 n][n]: +delta on token q in row q, -delta in row n + q
+        V[np.arange(n), np.arange(n)] *= np.exp(delta); V[n + np.arange(n), np.arange(n)] *= np.exp(-delta)
+        P = V[:, b["idx"]]                                     # [2 n][k][m]
+        y, _ = pools_np.arb_stable_n(np.tile(b["R"], (1, 2 * n)), np.tile(b["param"], 2 * n), np.tile(b["fee"], 2 * n),
+                                     P.transpose(1, 0, 2).reshape(k, 2 * n * m))
+        psi = np.zeros((2 * n, n))
+        np.add.at(psi, (np.repeat(np.arange(2 * n), m)[None, :].repeat(k, axis=0), np.tile(b["idx"], (1, 2 * n))), y)
+        return nu[:, None] * ((psi[:n] - psi[n:]) / (2 * delta)).T
+    # three step sizes, Richardson-extrapolated in pairs (the O(delta^2) term of the central difference is 1e-6 .. 4e-6 of the block near
+    # the peg, the extrapolated pair agrees to 1e-9 .. 1e-11 wherever psi is smooth inside the stencil)
+    B4, B2, B1 = fd(4e-5), fd(2e-5), fd(1e-5)
+    Ra, Rb = (4 * B2 - B4) / 3, (4 * B1 - B2) / 3
+    Hs = np.tril(H) + np.tril(H, -1).T                        # the lower triangle the device fills, mirrored
+    scale = np.abs(Rb).max()
+    assert scale > 0 and np.abs(Hs).max() > 0
+    smooth = np.abs(Ra - Rb) <= 1e-7 * scale
+    touched = (np.abs(Rb) > 1e-9 * scale) | (np.abs(Hs) > 1e-9 * scale)
+    assert smooth[touched].mean() >= 0.9, smooth[touched].mean()
+    err = np.abs(Hs - Rb)
+    assert err[smooth].max() <= 1e-6 * scale, (k, err[smooth].max() / scale)
+    # the restatement's own Jacobian is symmetric (it is a Hessian), and the common scaling of a pool's prices is the block's null vector
+    both = smooth & smooth.T
+    assert np.abs(Rb - Rb.T)[both].max() <= 1e-6 * scale
+    assert np.abs(Hs.sum(axis=1)).max() <= 1e-8 * scale
+
+
 @pytest.mark.parametrize("sizes", [(2, 2), (3, 4), (5, 6), (7, 8)])
 def test_second_order_evaluation_of_the_table_tiles_against_one_pool_per_lane(sizes, monkeypatch):
     """the table's stableswap buckets inside the second-order path: ONE launch of the wave-tiles (table_newton_kernel: leg per lane,

@@ -105,6 +105,35 @@ def test_ctypes_plumbing_shortcuts_agree_with_the_plain_forms():
         c._opts(dict(no_such_option=1))
 
 
+def test_no_kernel_of_the_library_carries_a_private_segment(tmp_path):
+    """`table_newton_kernel<true>` had picked up a 16-byte private segment (three spilled dwords) behind the builder's
+    last resource check -- a tool, not a test.  Here the check reads the code object the built library CARRIES (no recompilation): the
+    .hip_fatbin section -> the gfx950 bundle -> its AMDGPU metadata note; every kernel must report .private_segment_fixed_size 0, and
+    the register-bound kernels must stay inside the budget their launch geometry assumes."""
+    import shutil, subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("the ROCm LLVM binutils are not installed")
+    so = _lib.build()
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "co.elf")
+    subprocess.check_call([tools[0], f"--dump-section=.hip_fatbin={fat}", so, str(tmp_path / "rest.so")])
+    subprocess.check_call([tools[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+    notes = subprocess.run([tools[2], "--notes", co], capture_output=True, text=True, check=True).stdout
+    rows = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", notes, re.S):
+        g = lambda k: int((re.search(r"\.%s:\s+(\d+)" % k, m.group(2)) or [0, 0])[1])
+        rows[m.group(1)] = dict(scratch=g("private_segment_fixed_size"), vgpr=g("vgpr_count"), agpr=g("agpr_count"))
+    assert len(rows) >= 150, len(rows)                 # (every device kernel of the library: 159 at the time of writing)
+    spilled = {k: v for k, v in rows.items() if v["scratch"]}
+    assert not spilled, spilled
+    for k, v in rows.items():
+        if "iter_kernel" in k or ("eval_kernel" in k and "table" not in k) or "eval_batch_kernel" in k:
+            assert v["vgpr"] + v["agpr"] <= 128, (k, v)     # 16 waves of 1024 threads per CU: 4 per SIMD
+        if "table_eval_kernel" in k or "table_newton_kernel" in k:
+            assert v["vgpr"] + v["agpr"] <= 256, (k, v)     # 8 waves of 512 threads: 2 per SIMD
+
+
 def test_product_fails_loudly_without_gpu():
     try:
         import torch
