@@ -1259,11 +1259,12 @@ int hess_ld(int n) { return hess_nr(n) + CH_NB; }                   // + the blo
 int launch_factor(cfmm_ctx *ctx, int n, bool info_zeroed = false)
 {
     const int nr = hess_nr(n), ld = hess_ld(n), nrows = nr + 1, nbk = nr / CH_NB;
-    if (!info_zeroed) HIP_TRY(ctx, hipMemsetAsync(ctx->sm_info, 0, sizeof(int), ctx->stream));
+    if (!info_zeroed) HIP_TRY(ctx, hipMemsetAsync(ctx->sm_info, 0, 4 * sizeof(int), ctx->stream));       // pivot flag | - | row-workgroup arrivals (chol2.hpp) | -
     const bool inv = ctx->inverse_factor && ctx->Winv;
     if (ctx->chol_pairs) {
         // one launch per PAIR of block columns (chol2.hpp: chol_step2_kernel) + one with the inverse-factor role alone
         const size_t lds = (size_t)CH2_LDS_DOUBLES * sizeof(double);
+        int arrived = 0;                                           // row workgroups of the launches so far (chol2.hpp: arrive_target)
         for (int c0 = 0; c0 < nr; c0 += 2 * CH_NB) {
             const int below = nrows - c0 - 2 * CH_NB;              // rows under the pair's diagonal region, the right-hand side's included
             const int npanel = 1 + (below + CH2_ROWS - 1) / CH2_ROWS;
@@ -1273,26 +1274,29 @@ int launch_factor(cfmm_ctx *ctx, int n, bool info_zeroed = false)
             const int ntw = (inv && c0 > 0) ? (nbk - 1 - qb) * (qb + 1) : 0;
             // (one workgroup per CU -- the panel role's LDS: side tasks beyond the chip's width ride with earlier ones)
             const int nside = std::min(ntw + ntiles, std::max(ctx->cus - npanel, 1));
+            arrived += npanel - 1;
             hipLaunchKernelGGL(chol_step2_kernel, dim3(npanel + nside), dim3(256), lds, ctx->stream, ctx->H, ld, nrows, nr, c0, npanel, ctx->Dinv, ctx->sm_info,
-                               npanel + ntw, ctx->Winv, ctx->Rinv, nr, 0, ntw + ntiles);
+                               npanel + ntw, ctx->Winv, ctx->Rinv, nr, 0, ntw + ntiles, arrived);
         }
         if (inv && nbk >= 2)                                       // block row nbk - 2 (the last one is never formed: chol_wt_kernel)
             hipLaunchKernelGGL(chol_step2_kernel, dim3(nbk - 1), dim3(256), lds, ctx->stream, ctx->H, ld, nrows, nr, nr, 0, ctx->Dinv, ctx->sm_info,
-                               nbk - 1, ctx->Winv, ctx->Rinv, nr, 1, nbk - 1);
+                               nbk - 1, ctx->Winv, ctx->Rinv, nr, 1, nbk - 1, 0);
         HIP_TRY(ctx, hipGetLastError());
         return CFMM_OK;
     }
     // one launch per block column: panel k1 beside the trailing update of panel k1 - NB (chol.hpp: chol_step_kernel)
+    int arrived = 0;
     for (int k1 = 0; k1 < nr; k1 += CH_NB) {
         const int below = nrows - k1 - CH_NB;                  // rows under the diagonal block, the right-hand side's included
         const int npanel = 1 + (below + 63) / 64;
+        arrived += npanel - 1;
         int ntiles = 0;
         if (k1 > 0 && nr - k1 - CH_NB > 0) { const int T = (below + 63) / 64; ntiles = T * (T + 1) / 2; }
         // the inverse factor's block row q = k1 / NB - 1 (chol.hpp): (nbk - 1 - q)(q + 1) tiles behind the factorisation's own
         const int q = k1 / CH_NB - 1;
         const int ntw = (inv && q >= 0) ? (nbk - 1 - q) * (q + 1) : 0;
         hipLaunchKernelGGL(chol_step_kernel, dim3(npanel + ntw + ntiles), dim3(256), 0, ctx->stream, ctx->H, ld, nrows, nr, k1, npanel, ctx->Dinv, ctx->sm_info,
-                           npanel + ntw, ctx->Winv, ctx->Rinv, nr);
+                           npanel + ntw, ctx->Winv, ctx->Rinv, nr, arrived);
     }
     HIP_TRY(ctx, hipGetLastError());
     return CFMM_OK;
@@ -1754,7 +1758,8 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     double mu = mu0_scale * std::max(std::fabs(dual), 1e-300) / (double)std::max<long long>(nbar, 1);
     static const double warm_mult = getenv("CFMM_NEWTON_WARM") ? atof(getenv("CFMM_NEWTON_WARM")) : 1e3;                    // tuning knob
     if (ctx->warm_mu > 0.0) mu = std::min(mu, warm_mult * ctx->warm_mu);
-    const double sigma = (o.barrier_shrink > 0.0 && o.barrier_shrink < 1.0) ? o.barrier_shrink : 0.1;
+    static const double sigma_env = getenv("CFMM_NEWTON_SHRINK") ? atof(getenv("CFMM_NEWTON_SHRINK")) : 0.0;      // tuning knob (A/B)
+    const double sigma = (sigma_env > 0.0 && sigma_env < 1.0) ? sigma_env : ((o.barrier_shrink > 0.0 && o.barrier_shrink < 1.0) ? o.barrier_shrink : 0.1);
     const int max_newton = o.max_newton > 0 ? o.max_newton : 200;
     double gap = 1.0, infeas = 1.0, primal = 0.0, reg = 0.0;
     const bool trace = getenv("CFMM_NEWTON_TRACE") != nullptr;
@@ -1790,6 +1795,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     // case that matters: at nu = c nothing trades, psi = 0, value 0.  The barrier path has no business there: its smoothed pools trade
     // O(mu) each, the iteration chases rounding around a zero-valued optimum and explicit `CFMM_METHOD_NEWTON` runs ended "stalled" at
     // gaps up to 4.8e-2 (tools/fuzz_table.py seeds 12, 345, 609, 819, 945; fuzz_small.py seed 1434).  Linear-box utilities only.
+    const char *numeric_where = "";
     bool certified_at_start = false;
     {
         bool linear_box = true;
@@ -1827,7 +1833,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         }
         have_e = false;
         const double gmu = assemble(nu, e, mu, &G, &Hd);
-        if (!std::isfinite(gmu)) { status = CFMM_E_NUMERIC; break; }
+        if (!std::isfinite(gmu)) { status = CFMM_E_NUMERIC; numeric_where = "the smoothed dual value"; break; }
         // certificates: exact dual value (an upper bound) against the smoothed, pool-feasible primal point.  Each
         // barrier term costs at most mu of pool value, so sum_i arb_i(nu) <= nu'(L - D) + mu nbar: while that bound
         // is still far from the tolerance the exact evaluation is skipped and the bound reported instead.
@@ -1889,7 +1895,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             IoList l;
             l.copy(ctx->sm_mask, pin_device(ctx, pin_mask), n * sizeof(int));
             l.copy(ctx->sm_vec, pin_device(ctx, pin_vec), 2 * (size_t)n * sizeof(double));
-            if (!use_chord) l.zero(ctx->sm_info, 2 * sizeof(int));
+            if (!use_chord) l.zero(ctx->sm_info, 4 * sizeof(int));
             if ((rc = launch_io(ctx, l, false))) return rc;
         } else {
             HIP_TRY(ctx, hipMemcpyAsync(ctx->sm_mask, pin_mask, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -1933,7 +1939,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
             double md = 0.0;
             for (int j = 0; j < n; ++j) md = std::max(md, std::max(Hd[j], std::fabs(G[j])));
             reg = reg == 0.0 ? 1e-12 * std::max(md, 1e-300) : reg * 100.0;
-            if (!(reg < 1e300)) { status = CFMM_E_NUMERIC; break; }
+            if (!(reg < 1e300)) { status = CFMM_E_NUMERIC; numeric_where = "the diagonal shift of a system that never became positive definite"; break; }
             have_e = true;                         // (same point, same weight: only the Hessian has to be assembled again)
             continue;
         }
@@ -1951,7 +1957,14 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
         reg = reg > 0.0 ? 0.1 * reg : 0.0;      // a singular Hessian (tokens no pool connects) tends to stay singular: keep most of the shift
         double dec = 0.0, dmax = 0.0;
         for (int j = 0; j < n; ++j) { if (pin[j]) d[j] = 0.0; dec -= G[j] * d[j]; dmax = std::max(dmax, std::fabs(d[j])); }
-        if (!std::isfinite(dec) || !std::isfinite(dmax)) { status = CFMM_E_NUMERIC; break; }
+        if (!std::isfinite(dec) || !std::isfinite(dmax)) {
+            int bad_d = 0, bad_g = 0;
+            for (int j = 0; j < n; ++j) { bad_d += !std::isfinite(d[j]); bad_g += !std::isfinite(G[j]); }
+            static thread_local char buf[200];
+            snprintf(buf, sizeof buf, "the Newton direction (%d of %d entries non-finite, gradient %d, %s step, factorisation flag %d)", bad_d, n, bad_g,
+                     use_chord ? "chord" : "fresh", info);
+            status = CFMM_E_NUMERIC; numeric_where = buf; break;
+        }
         if (final_mu) {                        // centring at the final weight: give up (before moving, so that nu, psi and the
             // certificates stay those of one point) once the Newton decrement is at rounding level and the feasibility of
             // psi_mu has stopped improving all the same
@@ -2048,7 +2061,7 @@ int solve_newton(cfmm_ctx *ctx, const cfmm_opts &o, cfmm_stats *out, int evals_b
     out->device_seconds = ms * 1e-3;
     out->pool_subproblems = (int64_t)evals * cfmm_pool_count(ctx);
     out->barrier_mu = mu; out->newton_steps = steps; out->method = CFMM_METHOD_NEWTON;
-    if (status == CFMM_E_NUMERIC) return fail(ctx, CFMM_E_NUMERIC, "solve: non-finite value in the second-order iteration");
+    if (status == CFMM_E_NUMERIC) return fail(ctx, CFMM_E_NUMERIC, "solve: non-finite value in the second-order iteration: %s", numeric_where);
     return CFMM_OK;
 }
 

@@ -131,7 +131,7 @@ template <int J> struct WaveFactor {
 // R_last' (Linv_last' y_last).  Fixed summation orders throughout: bitwise the same on every rank of a pool-sharded solve.
 __global__ void __launch_bounds__(256)
 chol_step_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k1, int npanel, double *__restrict__ Dinv, int *__restrict__ info,
-                 int nfac, double *__restrict__ Wm, double *__restrict__ Rm, int ldw)
+                 int nfac, double *__restrict__ Wm, double *__restrict__ Rm, int ldw, int arrive_target)
 {
     constexpr int NB = CH_NB;
     __shared__ __attribute__((aligned(16))) double lds[NB * NB + NB * 64 + NB * 64 + NB * (NB + 1) + NB * NB + 2 * 64];      // 57.25 KB (the tile role uses 33 KB of it)
@@ -277,6 +277,8 @@ chol_step_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k1, i
         }
     }
     __syncthreads();
+    // (in place: workgroup 0 overwrites the diagonal block every row workgroup has just loaded -- it waits for their count, chol2.hpp)
+    if (!diag_wg && tid == 0) __hip_atomic_fetch_add(info + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (have_prev) {
         // D -= P_d P_d' on the whole square (both triangles come out bitwise equal: the same products in the same order)
         const int r2 = 2 * (tid & 15), c2 = 2 * (tid >> 4);
@@ -306,6 +308,7 @@ chol_step_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int k1, i
         }
         if (diag_wg) {
             if (!ok && lane == 0) atomicMax(info, k1 + 1);
+            while (__hip_atomic_load(info + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrive_target) __builtin_amdgcn_s_sleep(2);
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 if (lane < NB) A[(size_t)(k1 + j) * ld + k1 + c] = (j <= c) ? a[j] : 0.0;       // L[c][j]

@@ -99,7 +99,7 @@ __device__ __forceinline__ void mfma_store(double *C, int ldc, int m0, int n0, i
 
 __global__ void __launch_bounds__(256)
 chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, int npanel, double *__restrict__ Dinv, int *__restrict__ info,
-                  int nfac, double *__restrict__ Wm, double *__restrict__ Rm, int ldw, int w_single, int ntask)
+                  int nfac, double *__restrict__ Wm, double *__restrict__ Rm, int ldw, int w_single, int ntask, int arrive_target)
 {
     constexpr int NB = CH_NB, NB1 = CH_NB + 1;
     extern __shared__ __attribute__((aligned(16))) double lds2[];
@@ -315,6 +315,13 @@ chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, 
     }
     __syncthreads();
     CH2_STAMP(1);
+    // The factorisation is IN PLACE: workgroup 0 writes L_aa, L_ba, L_bb over the very diagonal region every row workgroup has just loaded
+    // as input.  That used to rest on timing alone -- all workgroups of a launch start within a microsecond, workgroup 0 stores ~5 us
+    // later -- and broke when the device was shared (round 6: six fuzzers on one GPU; a row workgroup dispatched late loaded the FACTOR,
+    // factored garbage, and the forward-substituted right-hand side came back NaN with a perfectly good factor beside it).  Now every row
+    // workgroup counts itself in once its loads have landed (the barrier above), and workgroup 0 waits for the launch's full count before
+    // its first in-place store.  info[2]: zeroed with the flag per factorisation; arrive_target: the running total the host passes.
+    if (!diag_wg && tid == 0) __hip_atomic_fetch_add(info + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (relaxed: nothing this workgroup WROTE is handed over, and its loads completed in front of the barrier)
     // one wave factors and inverts a 32 x 32 block (chol.hpp: WaveFactor); workgroup 0 writes the factor and its inverse.
     // The two halves of the pair run through ONE copy of this code (the loop below is kept a loop): WaveFactor is ~1700
     // straight-line instructions, and a second inlined copy made the kernel outgrow the instruction cache -- every launch took
@@ -340,6 +347,8 @@ chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, 
             const ch2_f64x4 l = mfma_tile<8, false, true, 4>(nullptr, 0, Dba, NB, Lia, NB, m0, n0, (n0 + 16) / 4, lane);
             mfma_store(Lba, NB, m0, n0, lane, l);
             if (diag_wg) {
+                // (the first in-place store of the launch: not before every row workgroup has loaded the region -- see the prologue)
+                while (__hip_atomic_load(info + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrive_target) __builtin_amdgcn_s_sleep(2);
                 const int lj = lane & 15, lk = lane >> 4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) A[(size_t)(ca + n0 + lk + 4 * r) * ld + cb + m0 + lj] = l[r];

@@ -241,7 +241,7 @@ __device__ __forceinline__ double uni(double v)
 //   stash of the two workgroups that store it borrows the LAST slots (their waves issue their first DMA behind the update)
 __host__ __device__ inline int iter_extra_lds_doubles(int n, bool dma = false)
 {
-    return dma ? 2 * iter_xvs(n) + (STAGE_BYTES / 8) * (EVAL_THREADS / 64) : 4 * iter_xvs(n);
+    return (dma ? 2 * iter_xvs(n) + (STAGE_BYTES / 8) * (EVAL_THREADS / 64) : 4 * iter_xvs(n)) + 32;      // (+ the safeguards' partials)
 }
 
 // PLAIN: the utility has h == 0, every token CFMM_GE and no upper bounds (linear-utility arbitrage, arbitrage.py:57,77):
@@ -295,6 +295,7 @@ iter_kernel(IterArgs a)
     double *glo_s = strips + 2 * 64 * (EVAL_THREADS / 64);   // [xvs] lower bounds | [xvs] upper bounds
     double *ghi_s = glo_s + a.xvs;
     double *psi_k = DMA ? stage0 + NSLOT * SLOT - 2 * a.xvs : ghi_s + a.xvs, *nu_k = psi_k + a.xvs;    // the workgroups that store the accepted point only
+    double *fsafe = (DMA ? ghi_s : ghi_s + 2 * a.xvs) + a.xvs;        // [2][16] per-wave partials of the direction's safeguards (d.G | max |d|)
     const int first_late = (NSLOT * SLOT - 2 * a.xvs) / SLOT;    // DMA: the slots from here on hold that stash during the update
 
 #ifdef CFMM_PHASE_TIMERS
@@ -610,21 +611,10 @@ iter_kernel(IterArgs a)
             nn[e] = tin[e] ? exp(v[e]) : 0.0;
         }
     };
-    if (new_dir) {
-        double F[2] = {0.0, 0.0};              // d.G | max |d|
-        if (wave_active) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                double qm = in.q0[e], rs = 0.0;
-#pragma unroll
-                for (int k = 0; k < P; ++k) { qm -= al[k] * in.Y[k][e]; rs += ga[k] * in.S[k][e]; }
-                d[e] = (tin[e] && !act[e]) ? -(in.H0[e] * qm + rs) : 0.0;
-                F[0] += d[e] * Gs[e]; F[1] = fmax(F[1], fabs(d[e]));
-            }
-        }
-        red.put<1, 1>(F, wave_active);
-        if (wave_active) trial(1.0);           // (speculation: the full step is the common case; under the reduction's barrier wait)
-        red.template get<1, 1, DMA>(F);
+    double F[2] = {0.0, 0.0};                  // d.G | max |d|
+    bool F_pending = false;
+    // the direction's safeguards on the two totals; true when the trial point had to be taken again (the speculated full step does not stand)
+    auto safeguard = [&](double (&F)[2]) {
         bool redo = false;
         if (!(F[0] < 0.0) && gp_sq > 0.0) {       // not a descent direction: restart from the metric
             st.hist = 0;
@@ -640,43 +630,95 @@ iter_kernel(IterArgs a)
             redo = true;
         }
         st.t_step = lbfgs::step_cap(F[1], a.max_step);
-        if ((redo || st.t_step != 1.0) && wave_active) trial(st.t_step);
+        const bool again = redo || st.t_step != 1.0;
+        if (again && wave_active) trial(st.t_step);
+        return again;
+    };
+    if (new_dir) {
+        if (wave_active) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                double qm = in.q0[e], rs = 0.0;
+#pragma unroll
+                for (int k = 0; k < P; ++k) { qm -= al[k] * in.Y[k][e]; rs += ga[k] * in.S[k][e]; }
+                d[e] = (tin[e] && !act[e]) ? -(in.H0[e] * qm + rs) : 0.0;
+                F[0] += d[e] * Gs[e]; F[1] = fmax(F[1], fabs(d[e]));
+            }
+        }
+#ifndef CFMM_EAGER_SAFEGUARD
+        F_pending = st.evals < a.max_evals;    // (a launch that runs out of budget here stores its state and leaves: the plain order, once per solve at most)
+#endif
+        if (F_pending) {
+            // the totals are taken BEHIND the barrier in front of the tiles (below); the per-wave partials wait in a strip of LDS that
+            // the tile phase does not touch (BlockRed's scratch lies in the waves' exchange strips: a fast wave's first tile would overwrite it)
+            if (wave_active) {
+                F[0] = wave_allsum(F[0]); F[1] = wave_allmax(F[1]);
+                if (lane == 0) { fsafe[wave] = F[0]; fsafe[16 + wave] = F[1]; }
+                trial(1.0);                    // (speculation: the full step is the common case)
+            }
+        } else {
+            red.put<1, 1>(F, wave_active);
+            if (wave_active) trial(1.0);
+            red.template get<1, 1, DMA>(F);
+            (void)safeguard(F);
+        }
     } else if (st.status == 0 && wave_active) trial(st.t_step);
 
     // ---- workgroup 0 stores the state; the trial prices go into this workgroup's LDS table ---------------------------------
     // (a solve that has ended above took no trial point: its price entries stay zero)
     if (st.status == 0 && st.evals >= a.max_evals) st.status = 3;
-    if (has_role && wave_active && r0 < n) {
-        if (mine(R_S)) stX<E>(Xw, r0, s);
-        if (mine(R_ST)) stX<E>(Xw + xvs, r0, v);
-        if (mine(R_GS)) stX<E>(Xw + 2 * xvs, r0, Gs);
-        if (mine(R_D)) stX<E>(Xw + 3 * xvs, r0, d);
-        if (mine(R_NU)) stX<E>(Xw + 4 * xvs, r0, nn);
-        if (wr) stE<E>(a.nu, r0, n, nn);
-    }
-    if (wr) {
-        if (tid == 0) {
-            a.st3[p] = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0;
-            if (st.status != 0 && a.h_final) *a.h_final = st;
-            // progress word for the host (system-scope store into pinned host memory: no copy, no API call on the host side)
-            if (a.hstat) __hip_atomic_store(a.hstat, (unsigned long long)(unsigned)st.evals | ((unsigned long long)(unsigned)st.status << 32),
-                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (a.hring) __hip_atomic_store(a.hring + (a.launch & (ITER_HRING - 1)), iter_hring_word(st.evals, st.status, a.launch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    auto store_state = [&]() {
+        if (has_role && wave_active && r0 < n) {
+            if (mine(R_S)) stX<E>(Xw, r0, s);
+            if (mine(R_ST)) stX<E>(Xw + xvs, r0, v);
+            if (mine(R_GS)) stX<E>(Xw + 2 * xvs, r0, Gs);
+            if (mine(R_D)) stX<E>(Xw + 3 * xvs, r0, d);
+            if (mine(R_NU)) stX<E>(Xw + 4 * xvs, r0, nn);
+            if (wr) stE<E>(a.nu, r0, n, nn);
         }
-    }
+        if (wr) {
+            if (tid == 0) {
+                a.st3[p] = st; a.nu[n] = st.status != 0 ? 1.0 : 0.0;
+                if (st.status != 0 && a.h_final) *a.h_final = st;
+                // progress word for the host (system-scope store into pinned host memory: no copy, no API call on the host side)
+                if (a.hstat) __hip_atomic_store(a.hstat, (unsigned long long)(unsigned)st.evals | ((unsigned long long)(unsigned)st.status << 32),
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (a.hring) __hip_atomic_store(a.hring + (a.launch & (ITER_HRING - 1)), iter_hring_word(st.evals, st.status, a.launch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
     if (st.status != 0) {                                // ended (converged / stalled / out of budget): nothing to evaluate
+        store_state();
         if constexpr (DMA) dma_wait();                   // (a helper's pieces must have landed before its LDS goes back)
         return;
     }
     PHASE_STAMP(a.ev.ts, 22);
+    auto publish = [&]() {                               // (over this thread's own stash entry; v = log nn: the trial point itself)
 #pragma unroll
-    for (int e = 0; e < E; ++e) if (tin[e]) { nu_s[r0 + e] = nn[e]; if constexpr (LNU) lnu_s[r0 + e] = v[e]; }        // (over this thread's own stash entry; v = log nn: the trial point itself)
+        for (int e = 0; e < E; ++e) if (tin[e]) { nu_s[r0 + e] = nn[e]; if constexpr (LNU) lnu_s[r0 + e] = v[e]; }
+    };
+    publish();
     if constexpr (DMA) {
         if (helper_mode && !wave_active) dma_wait();     // (what a helper requested for the other waves is in LDS before they pass the barrier)
         lds_barrier();                                   // (LDS only: a fence would wait for the first tiles' DMA -- and for nothing else that matters here)
     } else
     __syncthreads();                                     // (the scratch in the exchange strips is free from here on; the tile table
     PHASE_STAMP(a.ev.ts, 23);                            //  and the ticket counter have been ready since the first barrier)
+    // Round 6: the direction's two safeguards (is it a descent direction?  does the full step exceed the cap in log-price?) used to
+    // cost a barrier of their own between the direction and the trial point.  Both almost never fire, and the trial point at the full
+    // step was already computed speculatively under that barrier -- so the speculation now runs all the way: the per-wave partials
+    // wait in LDS (BlockRed::put), the trial prices are published, and the totals are formed BEHIND the barrier the tile phase needs
+    // anyway.  Only a launch whose safeguard fires republishes its prices and pays the second barrier.  The state goes out after the
+    // check (it carries the step): every workgroup sums the same partials in the same order, so all of them decide alike.
+    if (F_pending) {
+        F[0] = 0.0; F[1] = 0.0;
+        for (int w = 0; w < nwa; ++w) { F[0] += fsafe[w]; F[1] = fmax(F[1], fsafe[16 + w]); }
+        if (safeguard(F)) {
+            publish();
+            if constexpr (DMA) lds_barrier(); else __syncthreads();
+        }
+    }
+    store_state();
 #ifdef CFMM_PHASE_TIMERS
     if (a.ev.ts && tid == 0) {
         if (blockIdx.x == 0) { a.ev.ts[2 * 16] = ts_c16; a.ev.ts[2 * 16 + 1] = ts_w16; }

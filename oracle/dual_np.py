@@ -26,6 +26,59 @@ from oracle import pools_np as P
 GE, EQ, FREE = 0, 1, 2
 
 
+def arb_stable_1(R, alpha, gamma, p):
+    """ONE K-asset stableswap pool (phi = sum x - alpha / prod x) at local prices p: the two scalar equations of oracle/pools_np.py:
+    arb_stable_n -- multiplier m and coupling s = alpha / prod x, x_j = clip(R_j, s / (p_j / (gamma m) - 1), s / (p_j / m - 1)) -- solved
+    with SciPy's brentq inside a bisection, in plain Python floats, instead of 80 x 64 vectorised bisection steps: the same root to
+    rounding (pinned against arb_stable_n in tests/test_oracle.py), ~50x faster for one pool, which is what a referee called thousands
+    of times needs"""
+    import math
+    from scipy.optimize import brentq
+    R = [float(x) for x in R]; p = [float(x) for x in p]
+    k = len(R)
+    lR = [math.log(x) for x in R]; la = math.log(alpha)
+    lsR = la - sum(lR); sR = math.exp(lsR)
+    lmax = math.log(min(p) / gamma)
+    NINF = float("-inf")
+
+    def legs(lm, ls):
+        em = math.exp(-lm)
+        lx, op = [0.0] * k, False
+        for j in range(k):
+            qw = p[j] * em; qd = qw / gamma
+            gd = math.log(max(qd - 1.0, 1e-300)) if qd > 1.0 else NINF
+            gw = math.log(max(qw - 1.0, 1e-300)) if qw > 1.0 else NINF
+            if gd == NINF:
+                op = True
+            lx[j] = min(max(lR[j], ls - gd), ls - gw)          # (np.clip's order: the lower bound first, then the upper)
+        return lx, op
+
+    def gap(lm):
+        h = lambda ls: ls - (la - sum(legs(lm, ls)[0]))
+        a, b = lsR - 90.0, lsR + 90.0
+        ha, hb = h(a), h(b)
+        ls = brentq(h, a, b, xtol=1e-15, rtol=4 * 2.220446049250313e-16, maxiter=200) if ha < 0.0 < hb else (a if ha >= 0.0 else b)
+        lx, op = legs(lm, ls)
+        if op:
+            return 1.0, lx
+        dx = sum((math.exp(min(lx[j], 700.0)) - R[j]) for j in range(k) if lx[j] != lR[j])
+        return dx - (math.exp(ls) - sR), lx
+
+    lo, hi = lmax - 90.0, lmax
+    for _ in range(64):
+        lm = 0.5 * (lo + hi)
+        if gap(lm)[0] < 0.0:
+            lo = lm
+        else:
+            hi = lm
+    lx = gap(hi)[1]
+    y = np.zeros(k)
+    for j in range(k):
+        d = 0.0 if lx[j] == lR[j] else R[j] - math.exp(lx[j])
+        y[j] = d if d > 0.0 else d / gamma
+    return y, float(np.dot(p, y))
+
+
 def pool_eval(kind, R, w, gamma, param, p):
     """one pool of the reference's vocabulary at local prices p -> (y = Lambda - Delta per leg, arb = p'y)"""
     k = len(R)
@@ -39,10 +92,9 @@ def pool_eval(kind, R, w, gamma, param, p):
         return P.arb_sum(R, gamma, p)
     if kind == "curve":
         if k == 2:
-            ya, yb, arb = P.arb_curve2(R[0], R[1], gamma, param, p[0], p[1])
-            return np.array([float(ya), float(yb)]), float(arb)
-        y, arb = P.arb_stable_n(np.asarray(R, float)[:, None], np.array([param]), np.array([gamma]), np.asarray(p, float)[:, None])
-        return y[:, 0], float(arb[0])
+            y, arb = P.arb_curve2(R[0], R[1], gamma, param, p[0], p[1])
+            return np.asarray(y, float), float(arb)
+        return arb_stable_1(R, param, gamma, p)
     if kind == "powersum":
         ya, yb, arb = P.arb_power2(R[0], R[1], gamma, param, p[0], p[1])
         return np.array([float(ya), float(yb)]), float(arb)
@@ -97,6 +149,19 @@ def solve_dual(inst, nu0=None, restarts=3):
         if best is None or r.fun < best[0]:
             best = (float(r.fun), r.x.copy(), bool(r.success))
     g, s, ok = best
+    free_idx = np.flatnonzero(hi > lo)
+    G0 = fg(s)[1]
+    pg0 = np.where(s <= lo + 1e-12, np.minimum(G0, 0.0), np.where(s >= hi - 1e-12, np.maximum(G0, 0.0), G0))
+    if float(np.abs(pg0).max()) > 1e-6 * max(1.0, abs(g)) and 0 < len(free_idx) <= 12:
+        # the quasi-Newton iteration stops short where the minimum sits ON a kink of a piecewise-linear pool (all three shipped scripts):
+        # a derivative-free polish over the few free log-prices finishes the VALUE (Powell's direction set: no gradient to be fooled)
+        def f_only(z):
+            t = s.copy(); t[free_idx] = np.clip(z, lo[free_idx], hi[free_idx])
+            return fg(t)[0]
+        for _ in range(2):
+            r = minimize(f_only, s[free_idx], method="Powell", options=dict(xtol=1e-12, ftol=1e-14, maxiter=4000, maxfev=4000))
+            if r.fun < g:
+                g = float(r.fun); s = s.copy(); s[free_idx] = np.clip(r.x, lo[free_idx], hi[free_idx])
     nu = np.exp(s)
     f, psi = dual_eval(inst, nu)
     G = nu * (psi + h); G[fixed] = 0.0
@@ -107,4 +172,4 @@ def solve_dual(inst, nu0=None, restarts=3):
     viol = float(np.where(ct == GE, np.maximum(-r_, 0.0), np.where(ct == EQ, np.abs(r_), 0.0)).max())
     den = max(float(np.abs(psi).max()), float(np.abs(h).max()), 1e-300)
     return dict(value=g, nu=nu, psi=psi, gap=abs(cs) / scale, infeas=viol / den, pg=float(np.abs(pg).max()) / scale,
-                converged=bool(ok or float(np.abs(pg).max()) <= 1e-6 * scale), evals=evals[0])
+                converged=bool(float(np.abs(pg).max()) <= 1e-6 * scale), lbfgsb_success=bool(ok), evals=evals[0])

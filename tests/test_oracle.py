@@ -407,6 +407,29 @@ def test_independent_second_order_solver_against_the_scipy_primal(oracle_lib, se
     assert abs(r["dual_value"] - ref["value"]) <= 2e-6 * max(1.0, abs(ref["value"])), (r["dual_value"], ref["value"])
 
 
+@pytest.mark.parametrize("name,inst", shipped_cases())
+def test_dual_referee_reproduces_the_shipped_optima(name, inst):
+    """oracle/dual_np.py (round 6: the fuzz campaigns' referee -- SciPy's L-BFGS-B + a derivative-free polish on the dual of the
+    decomposed program, over the NumPy restatements of the pools): the 50-digit KKT optimum of every shipped instance to 1e-9, the
+    ones that end ON a constant-sum pool's kink (arbitrage, liquidation, two_asset_10) included"""
+    from oracle import dual_np
+    r = dual_np.solve_dual(normalise_with_params(inst))
+    want = golden()[name]["kkt"]["value"]
+    assert abs(r["value"] - want) <= 1e-9 * max(1.0, abs(want)), (r["value"], want)
+
+
+@pytest.mark.parametrize("seed,utility", [(1, "arbitrage"), (2, "liquidate"), (3, "swap"), (4, "arbitrage"), (1006, "arbitrage"), (1010, "swap")])
+def test_dual_referee_against_the_scipy_primal(seed, utility):
+    from oracle import dual_np
+    inst = random_instance(seed, n_tokens=6, n_pools=14, with_sum=(seed % 2 == 1), with_curve=True, utility=utility, with_power=(seed % 2 == 0))
+    ni = normalise_with_params(inst)
+    ref = solve_primal(ni)
+    if not ref["success"]:
+        pytest.skip("SLSQP gave up on this instance (which is why the referee exists)")
+    r = dual_np.solve_dual(ni)
+    assert abs(r["value"] - ref["value"]) <= 2e-6 * max(1.0, abs(ref["value"])), (r["value"], ref["value"])
+
+
 def test_c_oracle_is_clean_under_asan_and_ubsan():
     """SURVEY section 5 ("ASAN on the CPU twin"): oracle/cfmm_oracle.c compiled with -fsanitize=address,undefined and driven
     over a random network with every pool kind, the three utilities, tenders and whole solves, 1 and 4 threads

@@ -1,6 +1,9 @@
 import sys, os, ctypes as C
-sys.path[:0] = ['/root/repo', '/root/repo/cfmm-routing-code_amd']
-os.environ["CFMM_LIB"] = "/root/repo/cfmm-routing-code_amd/cfmm/variants/libcfmm_hip_ch2stamps.so"
+# phase stamps of one workgroup of chol_step2_kernel (the launch at c0 = 512 of config 5's factorisation); needs a variant built with
+#   make variant TAG=ch2stamps DEFS="-DCFMM_CH2_STAMPS -DCFMM_CH2_STAMP_WG=1"     (workgroup 1: a row workgroup; 0: the one that writes the factor)
+# and CFMM_LIB pointing at it
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'cfmm-routing-code_amd')]
 import numpy as np
 import cfmm
 from cfmm import synthetic

@@ -57,12 +57,12 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):
                  pi.get("fold", 0) + pi.get("allreduce", 0), d["config"].get("allreduce"), d["config"].get("allreduce_note")))
 base = {(c, a): v for c, a, n, v, *_ in rows if n == 1}
 # what one-GPU measurements predict per sharded iteration (us)
-pred = {("C3", "oneshot"): "31-32", ("C3", "rccl"): "55-70", ("C4", "oneshot"): "~30 at N = 8", ("C4", "rccl"): "~50-60 at N = 8"}
+pred = {("C3", "oneshot"): "30-31", ("C3", "rccl"): "42-52 (round 6: no fold launch, zero-copy progress ring)", ("C4", "oneshot"): "~30 at N = 8", ("C4", "rccl"): "~42-50 at N = 8"}
 print(f"{'config':6} {'leg':5} {'N':>2} {'value /s':>11} {'ms/solve':>9} {'evals':>6} {'us/iter':>8} {'eval':>6} {'coll':>6} {'speed-up':>8}  transport (predicted us/iter)")
 for c, a, n, v, ms, ev, tot, e, coll, how, note in rows:
     b = base.get((c, a)) or base.get((c, "auto")) or base.get((c, "rccl"))
     su = f"{v / b:8.2f}" if b else "       -"
     print(f"{c:6} {a:5} {n:2d} {v:11.3e} {ms:9.3f} {ev or 0:6.1f} {tot or 0:8.2f} {e or 0:6.2f} {coll or 0:6.2f} {su}  {how or 'single GPU'} ({pred.get((c, how), '-') if n > 1 else '-'}) {note or ''}")
-print("weak scaling (C3): efficiency = speed-up / N; DESIGN (e) predicts 0.68-0.70 with the one-shot exchange, 0.3-0.4 through RCCL.")
+print("weak scaling (C3): efficiency = speed-up / N; DESIGN (e) predicts 0.67-0.70 with the one-shot exchange, 0.40-0.50 through RCCL (round 6: the fold launch and the per-chunk state copies are gone).")
 print("strong scaling (C4): DESIGN (e) predicts a speed-up of ~2.0 at N = 8 (the per-rank launch is latency-bound long before it is bandwidth-bound).")
 EOF

@@ -10,10 +10,11 @@ import numpy as np
 import cfmm
 from helpers import random_instance, problem_of, normalise_with_params, utility_of
 from oracle.primal_scipy import solve_primal
+from oracle import dual_np
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-fails, stats = [], dict(n=0, infeasible=0, newton_checked=0, swept=0, slsqp_fail=0)
+fails, stats = [], dict(n=0, infeasible=0, newton_checked=0, swept=0, slsqp_fail=0, independent_value=0, referee_loose=0)
 t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
@@ -37,6 +38,17 @@ for seed in range(first, first + count):
             p.close(); continue
         if not r["success"]:
             stats["slsqp_fail"] += 1
+        # the referee that answers (round 6): the dual of the decomposed program minimised by SciPy over the NumPy pool restatements
+        # (oracle/dual_np.py).  Its value is an upper bound on the optimum whatever happens: a "certified" value ABOVE it is a false
+        # certificate; a value within 2e-6 below it is an independently confirmed optimum.
+        d = dual_np.solve_dual(normalise_with_params(inst))
+        tolv = 2e-6 * max(1.0, abs(v))
+        if v > d["value"] + tolv:
+            fails.append(f"{tag}: FALSELY CERTIFIED: value {v} above the independent dual bound {d['value']}")
+        elif d["value"] - v <= tolv or (r["success"] and abs(r["value"] - v) <= tolv):
+            stats["independent_value"] += 1
+        else:
+            stats["referee_loose"] += 1                          # (the referee stopped short: nothing learnt about this instance)
         if r["success"] and r["value"] > v + 2e-6 * max(1, abs(v)):
             fails.append(f"{tag}: SLSQP found a BETTER primal point {r['value']} > {v}")
         elif r["success"] and r["value"] < v - 2e-6 * max(1, abs(v)):

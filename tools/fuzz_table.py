@@ -11,6 +11,7 @@ import numpy as np
 import cfmm
 from helpers import problem_of, normalise_with_params
 from oracle.primal_scipy import solve_primal
+from oracle import dual_np
 
 
 from helpers import table_instance as instance
@@ -18,7 +19,7 @@ from helpers import table_instance as instance
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-fails, stats = [], dict(n=0, newton=0, slsqp_ok=0, infeasible=0)
+fails, stats = [], dict(n=0, newton=0, slsqp_ok=0, infeasible=0, independent_value=0, referee_loose=0)
 t0 = time.time()
 for seed in range(first, first + count):
     inst, with_sum = instance(seed)
@@ -39,6 +40,15 @@ for seed in range(first, first + count):
             p.close(); continue
         if r["success"] and r["value"] > v + 2e-6 * max(1, abs(v)):
             fails.append(f"{tag}: SLSQP found a BETTER primal point {r['value']} > {v}")
+        # the referee that answers (round 6, oracle/dual_np.py): an independent upper bound on the optimum, tight where it converges
+        d = dual_np.solve_dual(normalise_with_params(inst))
+        tolv = 2e-6 * max(1.0, abs(v))
+        if v > d["value"] + tolv:
+            fails.append(f"{tag}: FALSELY CERTIFIED: value {v} above the independent dual bound {d['value']}")
+        elif d["value"] - v <= tolv or (r["success"] and abs(r["value"] - v) <= tolv):
+            stats["independent_value"] += 1
+        else:
+            stats["referee_loose"] += 1
         tot = np.zeros(inst["n_tokens"])
         for li, R, g, kind, prm, dd, ll in zip(inst["local_indices"], inst["reserves"], inst["fees"], inst["kinds"], inst["params"], p.deltas, p.lambdas):
             np.add.at(tot, li, ll - dd)
