@@ -844,21 +844,26 @@ class Problem:
         # otherwise first order (with the active-set loop over constant-sum kinks), second order if that fails
         many_stable = n_stable >= AUTO_NEWTON_MIN_STABLE
         second_order = method == "newton" or (method == "auto" and can_second and many_stable)
-        if not second_order:
+        def first_order_leg(nu_from):
+            """the first-order iteration from `nu_from` (with the active-set loop where the network has constant-sum pools), finished"""
             if n_sum == 0 or general:
-                st = self._run(ctx, nu0, total, tol=tol, method=_lib.METHODS["lbfgs"], **kw)
-                nu, psi = self._solution_of(ctx, st, nu0)
+                st = self._run(ctx, nu_from, total, tol=tol, method=_lib.METHODS["lbfgs"], **kw)
+                nu, psi = self._solution_of(ctx, st, nu_from)
             else:
                 self._kinks_settled = False
-                st, nu, psi = self._solve_kinks(ctx, nu0, tol, dict(kw, method=_lib.METHODS["lbfgs"]), kink_tol, max_rounds, total)
+                st, nu, psi = self._solve_kinks(ctx, nu_from, tol, dict(kw, method=_lib.METHODS["lbfgs"]), kink_tol, max_rounds, total)
                 if st["status"] == 1 and not self._kinks_settled:
                     st = dict(st, status=2)       # (the last leg converged on a REDUCED dual whose ties did not yield their fills: not a solution)
+            self._finish(st, nu, psi, total)
+            return st
+
+        if not second_order:
+            st = first_order_leg(nu0)
             # what decides is the CERTIFICATES of the point the run ended on (recomputed here, the worthless-component repair included), not
             # the device's verdict: a run that "stalled" at 1e-44 prices on a value-0 instance is optimal, and a run that reported
             # convergence while a whole region's prices collapsed (the device's test is value-weighted) is not (tools/fuzz_small.py,
             # fuzz_mid.py).  Uncertified: the second-order path from the start prices -- unless the device had converged and the
             # miss is a near one ("inaccurate", with its figures)
-            self._finish(st, nu, psi, total)
             near = st["status"] == 1 and max(self.gap, self.infeas) <= 100.0 * max(tol, 1e-12)
             if not (method == "auto" and can_second and self.status not in ("optimal", "infeasible") and not near):
                 return self.value
@@ -873,6 +878,24 @@ class Problem:
         st = self._run(ctx, None if cont else nu0, total, tol=tol, method=_lib.METHODS["newton"], **kw)
         nu, psi = self._solution_of(ctx, st, nu0)
         self._finish(st, nu, psi, total)
+        if method == "newton" and self.status not in ("optimal", "infeasible") and psi is not None and not general:
+            # The barrier path asked for BY NAME and ended without its certificates (round 6; tools/fuzz_small.py seeds 1387, 1501): optima
+            # where nothing trades, or a partially filled constant-sum pool decides, are what the first-order leg with its active-set
+            # loop is for -- `auto` sends such problems there first; an explicit "newton" now hands it the prices the path ended on.
+            # Kept only if that leg ends certified or at least closer: otherwise the path's own point is solved for again (the device's
+            # buffers must hold the point this object reports).
+            worst = lambda: max(abs(self.gap) / tol, self.infeas / tol) if np.isfinite(self.gap) and np.isfinite(self.infeas) else np.inf
+            w_path, newton_steps = worst(), (self.stats or {}).get("newton_steps", 0)
+            first_order_leg(np.asarray(nu, dtype=np.float64).copy())
+            if self.status == "optimal" or worst() < w_path:
+                self.stats["newton_steps"] = newton_steps
+            else:
+                if self._dev_ties:
+                    self._clear_ties(ctx)
+                self._theta = {}; self._trade_cache = None
+                st = self._run(ctx, nu0, total, tol=tol, method=_lib.METHODS["newton"], **kw)
+                nu, psi = self._solution_of(ctx, st, nu0)
+                self._finish(st, nu, psi, total)
         return self.value
 
     @staticmethod

@@ -241,7 +241,7 @@ __host__ __device__ inline void pool_generic_k(const double (&R)[K], const doubl
 //     tiles keep per pool (BucketG::ws, 8 B; not in the reproducible mode, where a pool's result must be a function of the pool and
 //     the prices alone).
 // The diagonal metric of a solve's first evaluation is the closed-form diagonal of the pool's Hessian block at its own no-trade
-// prices (the same block the second-order path assembles: gk_newton_kernel) instead of K + 1 perturbed solves.
+// prices (the same block the second-order path assembles: table_newton_kernel) instead of K + 1 perturbed solves.
 // pool_generic_k above stays as the function-agnostic reference: cfmm_selftest checks the fast search against it on the device.
 // =====================================================================================================================================
 constexpr int GT_THREADS = 512;           // 8 waves per workgroup (the search keeps ~60 doubles per lane alive: 256-VGPR budget)
@@ -465,7 +465,7 @@ __device__ __forceinline__ void tileg_stable(const BucketG &b, int tb, int lane,
     }
     if (!DET && warm && trade && j == 0) b.ws[pl] = th;
     if constexpr (NEWT != 0) {
-        // gk_newton_kernel's pool, leg per lane: pools that trade on at least two legs enter with tenders, value and block; the others
+        // the pool of the second-order path, leg per lane: pools that trade on at least two legs enter with tenders, value and block; the others
         // not at all (a single active leg cannot move along the level set)
         const bool emit = trade && nA_f > 1.5;
         const bool act = emit && (W || D);
@@ -636,7 +636,8 @@ table_eval_kernel(TableArgs a)
 }
 
 // ---- the table's stableswap buckets inside the second-order path: ONE launch, the same wave-tiles (round 5) -------------------------------
-// What gk_newton_kernel below does one pool per lane (kept: the reference the tiles are tested against, CFMM_TABLE_NEWTON=serial): exact
+// (Round 5's first form, one pool per lane and one launch per bucket, served as the reference the tiles were tested against entry by entry;
+//  round 6 pinned the tiles' Hessian block against finite differences of the NumPy restatement instead -- tests/test_gpu_table.py -- and dropped it.)  Exact
 // tenders + first-order response to the low-order log-prices into out[0 .. n), the pools' value into out[n] and out[n + 1], HESS: the
 // exact K x K blocks into H.  LDS: psi tile | nu_s[n] | slo_s[n] | wave partials | ticket | strips.
 __host__ __device__ inline size_t table_newton_lds_bytes(int n, int waves)
@@ -722,47 +723,6 @@ __device__ __forceinline__ void stable_slo(const double (&x)[K], const double (&
     for (int k = 0; k < K; ++k) { xps += x[k] * pk[k] * sl[k]; vps += v[k] * pk[k] * sl[k]; }
     for (int j = 0; j < K; ++j) dy[j] = side[j] ? coef * pk[j] * (x[j] * x[j] * pk[j] * sl[j] - x[j] * sol.i1 * xps - v[j] * vps * ipv) / p[j] : 0.0;
 }
-template <int K, bool HESS>
-__global__ void __launch_bounds__(256)
-gk_newton_kernel(BucketG b, const double *__restrict__ nu, const double *__restrict__ slo, double *__restrict__ out, int n, double *__restrict__ H, int ldh)
-{
-    double vsum = 0.0;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < b.m; i += (long long)gridDim.x * blockDim.x) {
-        double R[K], p[K], x[K], sl[K];
-        int tok[K], side[K];
-        for (int j = 0; j < K; ++j) { tok[j] = b.idx[i * K + j]; R[j] = b.R[i * K + j]; p[j] = nu[tok[j]]; sl[j] = slo ? slo[tok[j]] : 0.0; }
-        const double g = b.fee[i];
-        StableSol sol;
-        if (!pool_stable_k<K>(R, p, g, b.param[i], x, side, sol) || sol.nA < 2) continue;
-        double dy[K];
-        for (int j = 0; j < K; ++j) dy[j] = 0.0;
-        if (slo) stable_slo<K>(x, p, side, g, sol, sl, dy);
-        double val = 0.0;
-        for (int j = 0; j < K; ++j) {
-            if (!side[j]) continue;
-            const double y = (side[j] > 0 ? R[j] - x[j] : (R[j] - x[j]) / g) + dy[j];
-            unsafeAtomicAdd(&out[tok[j]], y); val += p[j] * y;
-        }
-        vsum += val;
-        if (HESS) {
-            double pk[K], v[K], coef, ipv;
-            stable_block<K>(x, p, side, g, sol, pk, v, coef, ipv);
-            for (int j = 0; j < K; ++j) {
-                if (!side[j]) continue;
-                for (int k = 0; k <= j; ++k) {
-                    if (!side[k]) continue;
-                    const double Njk = (j == k ? x[j] * x[j] : 0.0) - x[j] * x[k] * sol.i1;
-                    const double h = coef * pk[j] * pk[k] * (Njk - v[j] * v[k] * ipv);
-                    const int row = tok[j] > tok[k] ? tok[j] : tok[k], col = tok[j] > tok[k] ? tok[k] : tok[j];
-                    unsafeAtomicAdd(&H[(size_t)col * ldh + row], h);
-                }
-            }
-        }
-    }
-    vsum = wave_allsum(vsum);
-    if ((threadIdx.x & 63) == 0 && vsum != 0.0) { unsafeAtomicAdd(&out[n], vsum); unsafeAtomicAdd(&out[n + 1], vsum); }
-}
-
 // ---- the constant-sum entry in the second-order path: barrier-smoothed like the two-asset pools (round 5) ------------------------------
 // arbitrage.py:73-74 over K tokens is an LP per pool; its kinks in the dual -- a leg drained only partly, two tokens tied for cheapest --
 // are what the first-order path's active-set loop chases (cfmm/problem.py) and, on small networks whose tokens differ in value, often

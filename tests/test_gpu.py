@@ -1146,6 +1146,15 @@ def test_bench_line_keeps_the_contract(tmp_path):
     assert rf["evaluation_only"]["bound"] in ("hbm", "valu")
     assert rf["traffic"] is None or rf["traffic"] > 4e7
     assert rf["rocprof_avg_launch_us"] is None or abs(rf["rocprof_avg_launch_us"] - rf["avg_launch_us"]) <= 0.3 * rf["avg_launch_us"]      # live (3 steps) vs committed trace
+    # the line explains itself: the timed steps in blocks, the shader clock measured live (a pass of its own behind the
+    # timed region) beside the idle clock, and the line's kernel times checked against profiles/budget.json
+    assert len(d["ms_per_step_blocks"]) == 3 and abs(sum(d["ms_per_step_blocks"]) / 3 - d["ms_per_step"]) <= 0.05 * d["ms_per_step"]
+    assert min(d["ms_per_step_blocks"]) <= d["ms_per_step_median_block"] <= max(d["ms_per_step_blocks"]) and d["extra_warmup_steps"] >= 100
+    assert 1.2 < rf["effective_clock_ghz_live"] < 2.6 and 1.2 < rf["clock_ghz_idle"] < 2.6
+    assert rf["clock_pass"]["solves"] >= 20 and rf["clock_pass"]["ms_per_step"] > 0.0
+    assert 4.0 < rf["clock_probe_fma_chain"]["cycles_per_dependent_v_fma_f64"] < 12.0
+    assert isinstance(d["budget_ok"], bool) and d["budget"]["source"] == "profiles/budget.json" and d["budget"]["checked"]
+    assert "device_state" in d
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "pool-subproblems/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert cb["numpy_one_thread"]["cores"] == 1 and cb["numpy_one_thread"]["value"] > 1e6      # (baseline B beside A)

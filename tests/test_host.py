@@ -124,7 +124,7 @@ def test_no_kernel_of_the_library_carries_a_private_segment(tmp_path):
     for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", notes, re.S):
         g = lambda k: int((re.search(r"\.%s:\s+(\d+)" % k, m.group(2)) or [0, 0])[1])
         rows[m.group(1)] = dict(scratch=g("private_segment_fixed_size"), vgpr=g("vgpr_count"), agpr=g("agpr_count"))
-    assert len(rows) >= 150, len(rows)                 # (every device kernel of the library: 159 at the time of writing)
+    assert len(rows) >= 140, len(rows)                 # (every device kernel of the library: 145 at the time of writing)
     spilled = {k: v for k, v in rows.items() if v["scratch"]}
     assert not spilled, spilled
     for k, v in rows.items():

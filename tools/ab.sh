@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 6 A/B on ONE box: usage r6_ab.sh "<configs>" <variant>...   (default = the tree's library); optional: TESTLIB=<variant> runs the suite through it first
+# A/B on ONE box: usage ab.sh "<configs>" <variant>...   (default = the tree's library); optional: TESTLIB=<variant> runs the suite through it first
 cd "$(dirname "$0")/.."
-O=gpurun_out/r6ab; mkdir -p $O; : > $O/ab.jsonl
+O=gpurun_out/ab; mkdir -p $O; : > $O/ab.jsonl
 export TMPDIR=/tmp
 V=$PWD/cfmm-routing-code_amd/cfmm/variants
 if [ -n "$TESTLIB" ]; then CFMM_LIB=$V/libcfmm_hip_$TESTLIB.so timeout 900 python -m pytest tests -m gpu -q -x ${TESTSEL:+-k "$TESTSEL"} > $O/pytest_$TESTLIB.log 2>&1; echo "pytest($TESTLIB) rc=$?"; tail -5 $O/pytest_$TESTLIB.log; fi
@@ -18,7 +18,7 @@ done
 python - <<'PY'
 import json, collections
 rows = collections.defaultdict(list)
-for l in open('gpurun_out/r6ab/ab.jsonl'):
+for l in open('gpurun_out/ab/ab.jsonl'):
     r = json.loads(l)
     rows[(r['config'], r['tag'])].append(r)
 for (cfg, tag), rs in rows.items():

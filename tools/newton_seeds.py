@@ -1,3 +1,5 @@
+"""explicit second-order solves of fuzz_small.py's instances by seed, with the step trace:   python tools/newton_seeds.py <seed> ...
+(tools/stress_shared_gpu.sh runs six of these side by side on one device; tests/test_gpu_newton.py keeps a smaller copy of that run)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "cfmm-routing-code_amd"), os.path.join(ROOT, "tests")):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """K-asset table buckets: evaluation time of the table's own launch (table_eval_kernel) for m stableswap pools of k assets,
 cold (no warm starts: CFMM_TABLE_WARM=0 semantics via fresh prices) and warm (the previous evaluation's roots), + parity of one
-evaluation against the NumPy restatement.   python tools/r5_table.py [m] [k]"""
+evaluation against the NumPy restatement.   python tools/table_timing.py [m] [k]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "cfmm-routing-code_amd")):
