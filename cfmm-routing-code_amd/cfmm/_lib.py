@@ -72,7 +72,7 @@ _lib = None
 
 SYMBOLS = ["cfmm_create", "cfmm_clone", "cfmm_destroy", "cfmm_last_error", "cfmm_backend", "cfmm_default_opts",
            "cfmm_upload_pools2", "cfmm_upload_poolsN", "cfmm_upload_poolsG", "cfmm_set_pool_flags", "cfmm_set_pool_flagsG", "cfmm_set_utility",
-           "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_debug_cholesky_apply", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_solve_sweep", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
+           "cfmm_set_ties", "cfmm_set_deterministic", "cfmm_debug_eval_limbs", "cfmm_eval_dual", "cfmm_eval_smooth", "cfmm_debug_cholesky", "cfmm_debug_cholesky_apply", "cfmm_time_xcd_handoff", "cfmm_solve", "cfmm_solve_batch", "cfmm_batch_capacity", "cfmm_solve_sweep", "cfmm_get_nu", "cfmm_set_nu", "cfmm_get_psi",
            "cfmm_get_solution", "cfmm_get_trades2", "cfmm_get_tradesN", "cfmm_get_tradesG", "cfmm_comm_unique_id", "cfmm_comm_init",
            "cfmm_oneshot_export", "cfmm_oneshot_import", "cfmm_oneshot_attach", "cfmm_oneshot_mailbox", "cfmm_oneshot_enable",
            "cfmm_time_eval_kernel", "cfmm_time_collective", "cfmm_time_newton_kernels", "cfmm_selftest", "cfmm_debug_timers", "cfmm_clock_probe_start", "cfmm_clock_probe_read", "cfmm_clock_probe_stop", "cfmm_clock_probe_chain", "cfmm_pool_count", "cfmm_eval_bytes", "cfmm_stream"]
@@ -107,6 +107,7 @@ def lib():
     L.cfmm_eval_smooth.argtypes = [vp, dp, C.c_double, dp, dp, dp, dp]
     L.cfmm_debug_cholesky.argtypes = [vp, C.c_int, dp, dp, dp, ip]
     L.cfmm_debug_cholesky_apply.argtypes = [vp, C.c_int, dp, dp]
+    L.cfmm_time_xcd_handoff.argtypes = [vp, C.c_int, C.c_int, dp]
     L.cfmm_solve.argtypes = [vp, dp, C.POINTER(Opts), C.POINTER(Stats)]
     L.cfmm_solve_batch.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(dp), C.POINTER(Opts), C.POINTER(Stats)]
     L.cfmm_batch_capacity.argtypes = [C.c_int]
@@ -284,6 +285,13 @@ class Context:
         b = f64(b); x = np.zeros(self.n)
         self._chk(self.L.cfmm_debug_cholesky_apply(self.h, self.n, _d(b), _d(x)))
         return x
+
+    def time_xcd_handoff(self, np_doubles=2048, reps=50):
+        """cfmm_time_xcd_handoff: dict(handoff_us_median, handoff_us_max, flag_seen_us_median, wrong_xcc, failed, orphan_xcds)"""
+        out = np.zeros(7)
+        self._chk(self.L.cfmm_time_xcd_handoff(self.h, int(np_doubles), int(reps), _d(out)))
+        return dict(handoff_us_median=float(out[0]), handoff_us_max=float(out[1]), flag_seen_us_median=float(out[2]),
+                    wrong_xcc=int(out[3]), failed=int(out[4]), orphan_xcds=int(out[5]), xcc_of_workgroups_0_to_7="%08d" % int(out[6]))
 
     def default_opts(self):
         o = Opts()

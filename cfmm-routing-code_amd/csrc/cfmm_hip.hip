@@ -4248,6 +4248,56 @@ int cfmm_clock_probe_stop(cfmm_ctx *ctx, int64_t *out, int cap, int *count)
     return cfmm_clock_probe_read(ctx, out, cap, count ? count : &dummy);
 }
 
+// the cost of handing `np` doubles from one workgroup per XCD to the other workgroups of that XCD through L2 (handoff.hpp:
+// xcd_handoff_kernel), `reps` launches of one workgroup per CU.  out[0..5]: median / max over launches of the slowest follower's
+// [publisher's data ready -> follower's data in LDS] in us | median of [ready -> flag seen] | workgroups whose XCC id is not
+// blockIdx % 8 (last launch) | followers that saw no flag or wrong values (all launches) | XCDs that had no publisher (last launch) |
+// the XCC ids of workgroups 0 .. 7 as eight decimal digits
+int cfmm_time_xcd_handoff(cfmm_ctx *ctx, int np, int reps, double *out7)
+{
+    double *out6 = out7;
+    if (!ctx || !out6 || np < 1 || np > 8192 || reps < 1) return CFMM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int grid = ctx->cus;
+    double *pub = nullptr; unsigned long long *flag = nullptr; long long *stamps = nullptr;
+    HIP_TRY(ctx, hipMalloc(&pub, (size_t)16 * np * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&flag, 16 * 16 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc(&stamps, (size_t)4 * grid * sizeof(long long)));
+    HIP_TRY(ctx, hipMemset(flag, 0, 16 * 16 * sizeof(unsigned long long)));
+    (void)hipFuncSetAttribute((const void *)xcd_handoff_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    std::vector<long long> h((size_t)4 * grid);
+    std::vector<double> full, seen;
+    int wrong_xcc = 0, failed = 0, orphan = 0;
+    for (int r = 0; r < reps; ++r) {
+        // (96 KB of LDS per workgroup: one per CU, like iter_kernel's)
+        hipLaunchKernelGGL(xcd_handoff_kernel, dim3(grid), dim3(1024), (size_t)96 * 1024, ctx->stream, pub, flag, (unsigned long long)(r + 1), np, 500ll, stamps);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(h.data(), stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        long long ready[16]; bool have[16] = {};
+        for (int b = 0; b < 8 && b < grid; ++b) { const int x = (int)h[4 * b] & 15; ready[x] = h[4 * b + 1]; have[x] = true; }
+        long long worst = 0, worst_seen = 0;
+        wrong_xcc = 0; orphan = 0;
+        for (int x = 0; x < 8; ++x) orphan += !have[x];
+        for (int b = 0; b < grid; ++b) {
+            const int x = (int)h[4 * b] & 15;
+            wrong_xcc += x != b % 8;
+            if (b < 8) continue;
+            if (h[4 * b + 3] != 0 || !have[x]) { ++failed; continue; }
+            worst = std::max(worst, h[4 * b + 2] - ready[x]);
+            worst_seen = std::max(worst_seen, h[4 * b + 1] - ready[x]);
+        }
+        full.push_back(worst * 0.01); seen.push_back(worst_seen * 0.01);          // 100 MHz ticks -> us
+    }
+    std::sort(full.begin(), full.end()); std::sort(seen.begin(), seen.end());
+    out6[0] = full[full.size() / 2]; out6[1] = full.back(); out6[2] = seen[seen.size() / 2];
+    out6[3] = wrong_xcc; out6[4] = failed; out6[5] = orphan;
+    out7[6] = 0.0;
+    for (int b = 0; b < 8 && b < grid; ++b) out7[6] = 10.0 * out7[6] + (double)((int)h[4 * b] & 15 ? ((int)h[4 * b] & 15) % 10 : 0);      // XCC ids of workgroups 0 .. 7, one decimal digit each
+    (void)hipFree(pub); (void)hipFree(flag); (void)hipFree(stamps);
+    return CFMM_OK;
+}
+
 int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_launch)
 {
     if (!ctx || reps < 1 || !sec_per_launch) return CFMM_E_ARG;

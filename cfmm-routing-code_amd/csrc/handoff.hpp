@@ -92,4 +92,49 @@ __global__ void __launch_bounds__(64) clock_probe_kernel(long long *ring, int ca
     }
 }
 
+// ---- measurement: what a hand-off between workgroups of ONE XCD costs (cfmm_time_xcd_handoff) -----------------
+// The candidate: run iter_kernel's nu update on one workgroup per XCD and let the other 31 workgroups of that XCD pick the trial prices
+// up from its L2 instead of repeating the update.  The followers wait for the publisher's WHOLE chain either way, so what the scheme
+// costs on the launch's critical path is exactly this hand-off: `np` doubles stored, acknowledged by L2, a flag stored behind them, the
+// flag seen by a spinning follower, the doubles loaded into its LDS.  Workgroups 0 .. 7 publish (they wait `delay` ticks first: in the
+// real kernel the followers are already spinning when the update ends), all others follow the publisher of their own XCD (HW_REG_XCC_ID).
+// stamps[4 b ..]: XCC id | publisher: data-ready tick, flag-stored tick | follower: flag-seen tick, data-in-LDS tick | wrong values seen
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15; }      // HW_REG_XCC_ID[3:0]
+__global__ void __launch_bounds__(1024) xcd_handoff_kernel(double *pub, unsigned long long *flag, unsigned long long epoch, int np, long long delay, long long *stamps)
+{
+    extern __shared__ __attribute__((aligned(16))) double hl[];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x, xcc = xcc_id();
+    long long *st = stamps + 4 * blockIdx.x;
+    if (blockIdx.x < 8) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < delay) __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+        const long long t_ready = wall_clock64();
+        for (int j = tid; j < np; j += blockDim.x) pub[(size_t)xcc * np + j] = (double)epoch + (double)j;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this thread's stores are in L2
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(flag + 16 * xcc, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st[0] = xcc; st[1] = t_ready; st[2] = wall_clock64(); st[3] = 0;
+        }
+        return;
+    }
+    if (tid == 0) {
+        int budget = 1 << 18;
+        while (__hip_atomic_load(flag + 16 * xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && --budget > 0) __builtin_amdgcn_s_sleep(1);
+        ok_s = budget > 0;
+        st[0] = xcc; st[1] = wall_clock64();
+    }
+    __syncthreads();
+    int bad = 0;
+    if (ok_s) {
+        for (int j = tid; j < np; j += blockDim.x) hl[j] = pub[(size_t)xcc * np + j];
+        __syncthreads();
+        for (int j = tid; j < np; j += blockDim.x) bad += hl[j] != (double)epoch + (double)j;
+    }
+    bad = __syncthreads_count(bad != 0);
+    if (tid == 0) { st[2] = wall_clock64(); st[3] = ok_s ? bad : -1; }
+}
+
 }  // namespace cfmm

@@ -287,6 +287,13 @@ int cfmm_time_eval_kernel(cfmm_ctx *ctx, int kind, int reps, double *sec_per_lau
  * back-to-back launches of the accumulator-slice fold, and `reps` back-to-back RCCL all-reduces of [psi | sum arb]
  * (n + 1 doubles) -- the latter only on a context with a communicator, and then EVERY rank must make this call */
 int cfmm_time_collective(cfmm_ctx *ctx, int reps, double *fold_sec, double *allreduce_sec);
+/* measurement: what it costs to hand `np` doubles from ONE workgroup per XCD to the other workgroups of that XCD through its L2 (store,
+   acknowledge, flag, spin, load into LDS) -- the price of running iter_kernel's update once per XCD instead of once per workgroup
+   (DESIGN (d) "tried and rejected").  out7: median, max over `reps` launches of the slowest follower's [data ready -> data in LDS] in us;
+   median [ready -> flag seen]; workgroups whose XCC id is not blockIdx % 8; followers that failed; XCDs without a publisher; the XCC
+   ids of workgroups 0 .. 7 as eight decimal digits.
+   No reference counterpart (arbitrage.py:82 is one cvxpy call). */
+int cfmm_time_xcd_handoff(cfmm_ctx *ctx, int np, int reps, double *out7);
 /* the kernels of one second-order step (bench.py --config C5), each timed over `reps` launches at the current prices and
  * barrier weight mu: out4 = seconds per {smoothed evaluation with Hessian assembly, smoothed evaluation alone, dense
  * factorisation (all its launches), back substitution} */
