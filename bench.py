@@ -226,8 +226,10 @@ def kernel_table(prob, reps):
         m = b["R"].shape[1]
         if m:
             parts.append((f"eval_kernel[gn{k} only]", -k, m, m * (20 + 20 * k)))
+    # (row 0: the fastest of five rounds of `reps` back-to-back launches, as tools/kernel_budget.py takes it -- at C2 the launch is 5.8 us
+    #  and the HOST's enqueue rate, 5-8 us per launch and jittery, is what a single round measures: 6.5 and 8.1 us on two runs of one box)
     rows = [dict(kernel="eval_kernel", pools=sum(p[2] for p in parts), bytes=sum(p[3] for p in parts),
-                 seconds=prob.ctx.time_eval_kernel(_lib.TIME_ALL, reps))]
+                 seconds=min(prob.ctx.time_eval_kernel(_lib.TIME_ALL, reps) for _ in range(5)))]
     if len(parts) > 1:
         for name, code, m, nbytes in parts:
             rows.append(dict(kernel=name, pools=m, bytes=nbytes, seconds=prob.ctx.time_eval_kernel(code, reps)))
@@ -363,7 +365,11 @@ def main():
             print(f"bench.py: clock probe unavailable: {e}", file=sys.stderr)
     prob.ctx.set_nu(net["c"] * np.exp(np.random.default_rng(0).normal(0, 0.01, net["n_tokens"])))
     from cfmm import _lib as _l
-    prob.ctx.time_eval_kernel(_l.TIME_ALL, 300)            # (the table itself should not be measured on the ramp either: discarded)
+    t_ramp = time.perf_counter()                          # (the table itself should not be measured on the ramp either: discarded launches,
+    while True:                                           #  at least 300 and at least 25 ms of them -- 300 launches of C2's 6 us kernel
+        prob.ctx.time_eval_kernel(_l.TIME_ALL, 300)       #  are 2 ms, and its table read 6.5 us where the settled kernel takes 5.8)
+        if time.perf_counter() - t_ramp >= 0.025:
+            break
     rows = kernel_table(prob, args.kernel_reps)
     for _ in range(args.warmup):
         prob.solve(tol=args.tol, **solve_kw)

@@ -292,6 +292,45 @@ def test_swept_solves_match_one_at_a_time_on_random_tiny_networks(seed, util):
     p.close(); q.close()
 
 
+@pytest.mark.parametrize("seed,util", [(0, "arbitrage"), (1, "swap"), (2, "liquidate"), (3, "arbitrage"), (4, "swap"), (5, "liquidate"), (6, "arbitrage"), (7, "swap")])
+def test_c_abi_solve_settles_constant_sum_kinks_itself_on_small_networks(seed, util):
+    """cfmm_solve with the DEFAULT method (CFMM_METHOD_AUTO: what a raw C-ABI caller gets) on networks of the reference's size with
+    several constant-sum pools: the library's own active-set loop (round 6: the degenerate sweep of one point) ends on the optimum of
+    the host's loop in cfmm/problem.py, with the fills folded into psi, the certificates and cfmm_get_trades2 -- sum of tenders = psi
+    (arbitrage.py:54), as prob.solve() of arbitrage.py:82 returns a partially filled pool with no ceremony"""
+    from cfmm import _lib
+    inst = random_instance(140 + seed, n_tokens=5 + seed % 3, n_pools=10 + 2 * seed, with_sum=True, utility=util)
+    rng = np.random.default_rng(seed)
+    for i in range(3):
+        a, b = rng.choice(inst["n_tokens"], 2, replace=False)
+        inst["local_indices"].append([int(a), int(b)]); inst["reserves"].append([float(np.exp(rng.normal(2, 0.5)))] * 2)
+        inst["fees"].append(float(rng.choice([0.997, 0.999, 0.99]))); inst["kinds"].append("sum"); inst["weights"].append(None); inst["params"].append(None)
+    q = problem_of(inst)
+    v = q.solve(tol=1e-9)
+    p = problem_of(inst)
+    u = utility_of(inst)
+    ctx = p._ensure_ctx(); ctx.set_utility(u.c, u.h, u.ctype)
+    st = ctx.solve(cfmm.start_prices(p.net, u), tol=1e-9)                 # default opts: method 0
+    if q.status == "optimal":
+        assert st["status"] == 1 and st["gap"] <= 1.001e-9 and st["infeas"] <= 1.001e-9, st
+        assert abs(st["primal_value"] - v) <= 1e-7 * max(1.0, abs(v))
+        nu, psi = ctx.get_solution()
+        assert np.abs(psi - q.psi).max() <= 1e-5 * max(1.0, np.abs(q.psi).max())
+        if st["method"] == _lib.METHODS["lbfgs"]:                         # (the library's loop: exact tenders that add up to psi)
+            tot = np.zeros(inst["n_tokens"])
+            for key in ("cp2", "w2", "sum2", "curve2", "pow2"):
+                if key in p.net and len(p.net[key]["Ra"]):
+                    b = p.net[key]
+                    d, l = ctx.get_trades2(cfmm.problem.KIND2[key], len(b["Ra"]))
+                    np.add.at(tot, b["ia"], l[0] - d[0]); np.add.at(tot, b["ib"], l[1] - d[1])
+            for k, b in p.net.get("gn", {}).items():
+                d, l = ctx.get_tradesN(k, b["R"].shape[1])
+                for j in range(k):
+                    np.add.at(tot, b["idx"][j], l[j] - d[j])
+            assert np.abs(tot - psi).max() <= 1e-9 * max(1.0, np.abs(psi).max())
+    p.close(); q.close()
+
+
 def test_sweep_call_refuses_what_it_cannot_index():
     """cfmm_solve_sweep's host half indexes the prices with the constant-sum columns handed in: ids out of range, a non-positive
     reserve, a fee outside (0, 1], a non-finite offset, a utility-table entry, a count that differs from the upload -- each is an
@@ -541,9 +580,12 @@ def test_integration_md_ctypes_stub_runs():
     stub = [b for b in blocks if "cfmm_create" in b]
     assert len(stub) == 2 and "cfmm_solve_sweep" in stub[1]
     ns = {}
+    assert "o.method" not in stub[0].split("cfmm_default_opts")[1].split("cfmm_solve")[0].replace("(o.method stays", "")     # the DEFAULT method (round 6)
     exec(stub[0].replace("<repo>", root), ns)
     st = ns["st"]
-    # the full five-pool instance of arbitrage.py through the raw ABI: prob.value of arbitrage.py:84
+    # the full five-pool instance of arbitrage.py through the raw ABI: prob.value of arbitrage.py:84 -- with CFMM_METHOD_AUTO the library's
+    # own active-set loop settles the constant-sum pool's kink (first order: stats.method 1, no barrier weight) ...
+    assert st.method == 1 and st.barrier_mu == 0.0
     assert st.status == 1 and st.gap <= 1e-9 and st.infeas <= 1e-9
     assert abs(st.primal_value - 21.4998087635) <= 1e-7 and abs(st.primal_value - golden()["arbitrage"]["kkt"]["value"]) <= 1e-7
     assert np.all(ns["psi"] >= -1e-8 * np.abs(ns["psi"]).max())
@@ -551,6 +593,12 @@ def test_integration_md_ctypes_stub_runs():
     # ... and the partially filled constant-sum pool's net tender (38.6 % of its reserve, arbitrage.py:12,20,28)
     y = ns["lam"] - ns["dlt"]
     assert np.abs(y[:, 0] - np.asarray(golden()["arbitrage"]["kkt"]["y"][4])).max() <= 1e-6
+    assert 0.386 < abs(y[0, 0]) / 10.0 < 0.3875 and 0.386 < abs(y[1, 0]) / 10.0 < 0.3875      # (the 38.6 % fill, read from cfmm_get_trades2)
+    # ... and the same point through the barrier path asked for by name (what the stub did before round 6)
+    ns2 = {}
+    exec(stub[0].replace("<repo>", root).replace("o.tol_gap, o.tol_infeas = 1e-9, 1e-9", "o.method, o.tol_gap, o.tol_infeas = 2, 1e-9, 1e-9"), ns2)
+    assert ns2["st"].status == 1 and ns2["st"].method == 2 and abs(ns2["st"].primal_value - st.primal_value) <= 1e-7
+    assert np.abs((ns2["lam"] - ns2["dlt"]) - y).max() <= 1e-6
     # section 3b (continues the same namespace): two-asset.py's 50-point sweep, all five pools, as ONE raw call
     exec(stub[1], ns)
     assert all(ns["stats"][j].status == 1 for j in range(50)) and np.all(np.diff(ns["all_values"]) > 0)

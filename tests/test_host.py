@@ -170,14 +170,14 @@ def test_bench_self_launches_one_rank_per_gpu(tmp_path):
 
 @pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5", "C4x4", "C3zipf"])
 def test_committed_bench_lines_keep_the_contract(cfg):
-    """profiles/r05_bench_*.json: the round's driver-reproducible line of every BASELINE.json configuration that fits one GPU
+    """profiles/r06_bench_*.json: the round's driver-reproducible line of every BASELINE.json configuration that fits one GPU
     (`python bench.py --config Cx` on MI355X, tools/gpu_profile.sh), plus the two lines SURVEY 8(d) asks for beside them (C4x4:
     a pool set that MUST stream from HBM; C3zipf: hub-weighted token pairs) -- BASELINE's metric and unit, whole-job value
     consistent with evaluations x pools / time, BOTH ceilings in the roofline object with `bound` naming the binding one, the
     CPU baseline beside it"""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "profiles", "r05_bench_%s.json" % cfg)
+    path = os.path.join(root, "profiles", "r06_bench_%s.json" % cfg)
     d = json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
     base = json.load(open(os.path.join(root, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "pool-subproblems/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
@@ -189,6 +189,15 @@ def test_committed_bench_lines_keep_the_contract(cfg):
     assert d["gap"] <= 1e-6 and d["infeas"] <= 1e-6
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "valu") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["avg_launch_us"] > 0
+    # round 6: the line explains itself -- blocks of the timed steps, the shader clock measured live (a pass of its own
+    # behind the timed region) beside the idle clock, the line's kernel times against profiles/budget.json
+    blocks = d["ms_per_step_blocks"]
+    assert len(blocks) == 5 and abs(sum(blocks) / 5 - d["ms_per_step"]) <= 0.02 * d["ms_per_step"] and max(blocks) <= 1.12 * min(blocks)
+    assert min(blocks) <= d["ms_per_step_median_block"] <= max(blocks) and d["extra_warmup_steps"] >= 100
+    assert 1.5 < rf["effective_clock_ghz_live"] <= 2.5 and 2.2 < rf["clock_ghz_idle"] <= 2.5 and rf["clock_pass"]["solves"] >= 20
+    assert 5.5 < rf["clock_probe_fma_chain"]["cycles_per_dependent_v_fma_f64"] < 8.0
+    if cfg != "C3zipf":
+        assert d["budget_ok"] is True and d["budget"]["over"] == {} and d["budget"]["checked"]
     if cfg == "C5":                                   # second-order path: the dense factorisation against the fp64 vector peak
         assert rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6 and rf["bound"] == "valu" and d["newton_steps_per_solve"] >= 3
         assert set(rf["newton_step_us"]) == {"smoothed_evaluation_with_hessian", "smoothed_evaluation", "factorisation", "back_substitution"}
@@ -224,7 +233,11 @@ def test_committed_bench_lines_keep_the_contract(cfg):
         else:
             assert "numpy_one_thread" not in cb
     if cfg == "C3":
-        assert d["ms_per_step"] <= 0.56 and d["value"] >= 3.9e10      # (round 2: 0.594 ms, 3.70e10)
+        assert d["ms_per_step"] <= 0.52 and d["value"] >= 4.2e10      # (round 2: 0.594 ms, 3.70e10; round 5's driver line: 0.574)
+        assert rf["avg_launch_us"] <= 20.6 and rf["frac"] >= 0.26     # (rounds 4-5: 20.0-20.9 us)
+        # the live clock accounts for the launch: duration x clock in shader cycles, live against the profiled pass
+        cc = rf["clock_check"]
+        assert 0.9 < cc["time_ratio_live_over_profiled"] < 1.1 and cc["launch_shader_cycles_live"] > 0
     if cfg == "C4":
         assert rf["avg_launch_us"] <= 52.0 and rf["frac"] >= 0.78  # (round 2: 68-69 us, 0.58; round 3: 59.4; before the mirror: 58.1)
         assert rf["bytes_as_stored_per_launch"] == 210_000_000 and rf["hbm_frac"] >= 0.5
