@@ -208,7 +208,13 @@ int cfmm_set_deterministic(cfmm_ctx *ctx, int on);
 int cfmm_debug_eval_limbs(cfmm_ctx *ctx, const double *nu, double ref_reserve, double ref_fee, uint64_t *limbs);
 
 /* prob.solve(): nu0 = start prices.  NULL: continue from cfmm_set_nu / the previous solution -- after a second-order
- * solve that includes (a multiple of) its final barrier weight: the warm start of a parametric sweep (two-asset.py:34-100) */
+ * solve that includes (a multiple of) its final barrier weight: the warm start of a parametric sweep (two-asset.py:34-100).
+ * Constant-sum pools (arbitrage.py:12,20,28,72-74) can end PARTIALLY filled -- a kink of the dual that prices alone do not resolve.
+ * With CFMM_METHOD_AUTO on a network of the reference's size (what cfmm_solve_sweep serves; linear-box utility, one GPU, no ties set by
+ * the caller) the library runs the active-set loop over such kinks itself (round 6): stats.primal_value, cfmm_get_psi / _solution and
+ * cfmm_get_trades2 return the point WITH the fills (arbitrage.py's pool 4: 38.6 %), stats.method = CFMM_METHOD_LBFGS.  Elsewhere AUTO
+ * falls back on the second-order method, which needs no active set; an explicit CFMM_METHOD_LBFGS leaves the kinks to the caller
+ * (cfmm_set_ties, cfmm_set_pool_flags: what cfmm/problem.py does for networks of any size). */
 int cfmm_solve(cfmm_ctx *ctx, const double *nu0, const cfmm_opts *opts, cfmm_stats *out);
 
 /* `nb` prob.solve() calls over the SAME pools in lock-step: the loop body of the parametric sweep, two-asset.py:34-100

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6 fuzz campaigns with the referee that answers (oracle/dual_np.py); artefacts under gpurun_out/r6f -> profiles/r06_fuzz_*
+# fuzz campaigns with the referee that answers (oracle/dual_np.py), seven processes side by side on one device; artefacts under gpurun_out/r6f -> profiles/r06_fuzz_*
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp OPENBLAS_NUM_THREADS=1
 O=gpurun_out/r6f; mkdir -p $O
@@ -9,5 +9,6 @@ O=gpurun_out/r6f; mkdir -p $O
  python tools/fuzz_table.py 0 120 > $O/fuzz_table_a.txt 2>&1 &
  python tools/fuzz_table.py 334 120 > $O/fuzz_table_b.txt 2>&1 &
  python tools/fuzz_table.py 667 120 > $O/fuzz_table_c.txt 2>&1 &
+ python tools/fuzz_mid.py 0 120 > $O/fuzz_mid.txt 2>&1 &
  wait)
 head -1 $O/fuzz_*.txt
