@@ -96,6 +96,18 @@ __device__ __forceinline__ void mfma_store(double *C, int ldc, int m0, int n0, i
 #pragma unroll
     for (int r = 0; r < 4; ++r) C[(n0 + lk + 4 * r) * ldc + m0 + lj] = acc[r];
 }
+// acc += sign * (the same 16 x 16 x 4 K4 product), for products that continue an accumulator held in registers (the side roles below)
+template <int K4, bool NEG>
+__device__ __forceinline__ void mfma_into(ch2_f64x4 &acc, const double *Ak, int lda, const double *Bk, int ldb, int m0, int n0, int lane)
+{
+    const int lj = lane & 15, lk = lane >> 4;
+    const double *pa = Bk + lk * ldb + n0 + lj, *pb = Ak + lk * lda + m0 + lj;
+    double av[K4], bv[K4];
+#pragma unroll
+    for (int q = 0; q < K4; ++q) { av[q] = pa[4 * q * ldb]; bv[q] = pb[4 * q * lda]; }
+#pragma unroll
+    for (int q = 0; q < K4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -av[q] : av[q], bv[q], acc, 0, 0, 0);
+}
 
 __global__ void __launch_bounds__(256)
 chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, int npanel, double *__restrict__ Dinv, int *__restrict__ info,
@@ -110,8 +122,10 @@ chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, 
     // panel's -- a workgroup takes 149 KB of LDS, ONE per CU: the host never asks for more workgroups than CUs, a task beyond
     // that rides with an earlier one (the chain of the panel workgroups is longer than two tasks)
     const int ntw = nfac - npanel;
+    CH2_STAMP(9);
     if ((int)blockIdx.x >= npanel)
-    for (int task = (int)blockIdx.x - npanel; task < ntask; task += (int)gridDim.x - npanel) {
+    for (int task = (int)blockIdx.x - npanel, nth = 0; task < ntask; task += (int)gridDim.x - npanel, ++nth) {
+    CH2_STAMP(10 + 2 * nth);
     if (task < ntw) {
         // ---- inverse factor: block rows qa (and qb = qa + 1), tile (i, j) ---------------------------------------------------------
         const int qa = w_single ? ncols / NB - 2 : c0 / NB - 2, qb = qa + 1;
@@ -121,7 +135,6 @@ chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, 
                *Lxb = Lxa + NB * NB, *Wa = Lxb + NB * NB, *Wb = Wa + NB * NB;
         const bool two = !w_single;
         const bool wa_zero = j > qa;                              // (j == qb: row a has no block in column b)
-        const int r2 = 2 * (tid & 15), c2 = 2 * (tid >> 4);
         {
             double va[4], vb[4], ra[4], rb[4], lba[4], lxa[4], lxb[4];
 #pragma unroll
@@ -145,45 +158,50 @@ chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, 
                 Lba[cc * NB + rr] = lba[u]; Lxa[cc * NB + rr] = lxa[u]; Lxb[cc * NB + rr] = lxb[u];      // L[rr][cc] -> [k = cc][r = rr]
             }
         }
-        double xv[2][2];
+        // Round 6: the five 32^3 products on the matrix pipe, one 16 x 16 tile per wave (rows rt .., columns ct ..).  As 2 x 2 register
+        // tiles on the vector pipe a product read 64 KB of LDS operands per workgroup (0.9 us at the port's 128 B / clk: the task was
+        // LDS-bound at 7.5 us, and the workgroups that take TWO side tasks ended 2.7 us behind the panel's chain in the eight launches
+        // with a full grid); here it reads 8 KB per wave.  Orientation per product: the accumulator's lanes run along the contiguous
+        // index of whatever the product is stored into (mfma_tile's convention).
+        {
+            const int wv = tid >> 6, ln = tid & 63, lj = ln & 15, lk = ln >> 4;
+            const int rt = 16 * (wv & 1), ct = 16 * (wv >> 1);
+            const bool store_rows = i == (w_single ? qa : qb) + 1;
+            // R_ij's own tile, requested now (rows contiguous in memory: lanes along r)
+            ch2_f64x4 x;
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) xv[u][v] = j >= qa ? 0.0 : Rm[(size_t)(j * NB + c2 + v) * ldw + i * NB + r2 + u];
-        __syncthreads();
-        double w[2][2] = {};
-        if (!wa_zero) mm_acc<2, 2, false>(w, Lia, NB, Ra, NB, r2, c2, NB);                     // W_aj = Linv_a R_aj
-        *reinterpret_cast<double2 *>(Wa + r2 * NB + c2) = make_double2(w[0][0], w[0][1]);      // [k = row][c]
-        *reinterpret_cast<double2 *>(Wa + (r2 + 1) * NB + c2) = make_double2(w[1][0], w[1][1]);
-        const bool store_rows = i == (w_single ? qa : qb) + 1;
-        if (store_rows && j < qa) {
-            Wm[(size_t)(j * NB + c2) * ldw + qa * NB + r2] = w[0][0]; Wm[(size_t)(j * NB + c2 + 1) * ldw + qa * NB + r2] = w[0][1];
-            Wm[(size_t)(j * NB + c2) * ldw + qa * NB + r2 + 1] = w[1][0]; Wm[(size_t)(j * NB + c2 + 1) * ldw + qa * NB + r2 + 1] = w[1][1];
-        }
-        __syncthreads();
-        if (two) {
-            double rbv[2][2] = {{Rb[r2 * NB + c2], Rb[r2 * NB + c2 + 1]}, {Rb[(r2 + 1) * NB + c2], Rb[(r2 + 1) * NB + c2 + 1]}};
-            if (!wa_zero) mm_acc<2, 2, true>(rbv, Lba, NB, Wa, NB, r2, c2, NB);               // R_bj -= L_ba W_aj
-            __syncthreads();                                      // (every thread has read its R_b entries)
-            *reinterpret_cast<double2 *>(Rb + r2 * NB + c2) = make_double2(rbv[0][0], rbv[0][1]);
-            *reinterpret_cast<double2 *>(Rb + (r2 + 1) * NB + c2) = make_double2(rbv[1][0], rbv[1][1]);
+            for (int r = 0; r < 4; ++r) x[r] = j >= qa ? 0.0 : Rm[(size_t)(j * NB + ct + lk + 4 * r) * ldw + i * NB + rt + lj];
             __syncthreads();
-            double wb[2][2] = {};
-            mm_acc<2, 2, false>(wb, Lib, NB, Rb, NB, r2, c2, NB);                              // W_bj = Linv_b R_bj
-            *reinterpret_cast<double2 *>(Wb + r2 * NB + c2) = make_double2(wb[0][0], wb[0][1]);
-            *reinterpret_cast<double2 *>(Wb + (r2 + 1) * NB + c2) = make_double2(wb[1][0], wb[1][1]);
-            if (store_rows && j < qb) {
-                Wm[(size_t)(j * NB + c2) * ldw + qb * NB + r2] = wb[0][0]; Wm[(size_t)(j * NB + c2 + 1) * ldw + qb * NB + r2] = wb[0][1];
-                Wm[(size_t)(j * NB + c2) * ldw + qb * NB + r2 + 1] = wb[1][0]; Wm[(size_t)(j * NB + c2 + 1) * ldw + qb * NB + r2 + 1] = wb[1][1];
+            ch2_f64x4 w = {0.0, 0.0, 0.0, 0.0};
+            if (!wa_zero) mfma_into<8, false>(w, Ra, NB, Lia, NB, ct, rt, ln);                 // W_aj = Linv_a R_aj, as Wa[r][c]
+            mfma_store(Wa, NB, ct, rt, ln, w);
+            if (store_rows && j < qa) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Wm[(size_t)(j * NB + ct + lj) * ldw + qa * NB + rt + lk + 4 * r] = w[r];
             }
             __syncthreads();
+            if (two) {
+                // R_bj -= L_ba W_aj in place: a wave reads and writes its own tile of Rb only
+                ch2_f64x4 rbv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rbv[r] = Rb[(rt + lk + 4 * r) * NB + ct + lj];
+                if (!wa_zero) mfma_into<8, true>(rbv, Wa, NB, Lba, NB, ct, rt, ln);
+                mfma_store(Rb, NB, ct, rt, ln, rbv);
+                __syncthreads();
+                ch2_f64x4 wb = {0.0, 0.0, 0.0, 0.0};
+                mfma_into<8, false>(wb, Rb, NB, Lib, NB, ct, rt, ln);                          // W_bj = Linv_b R_bj
+                mfma_store(Wb, NB, ct, rt, ln, wb);
+                if (store_rows && j < qb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Wm[(size_t)(j * NB + ct + lj) * ldw + qb * NB + rt + lk + 4 * r] = wb[r];
+                }
+                __syncthreads();
+            }
+            if (!wa_zero) mfma_into<8, true>(x, Lxa, NB, Wa, NB, rt, ct, ln);                  // R_ij -= L_ia W_aj + L_ib W_bj
+            if (two) mfma_into<8, true>(x, Lxb, NB, Wb, NB, rt, ct, ln);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Rm[(size_t)(j * NB + ct + lk + 4 * r) * ldw + i * NB + rt + lj] = x[r];
         }
-        if (!wa_zero) mm_acc<2, 2, true>(xv, Lxa, NB, Wa, NB, r2, c2, NB);                     // R_ij -= L_ia W_aj + L_ib W_bj
-        if (two) mm_acc<2, 2, true>(xv, Lxb, NB, Wb, NB, r2, c2, NB);
-#pragma unroll
-        for (int v = 0; v < 2; ++v)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) Rm[(size_t)(j * NB + c2 + v) * ldw + i * NB + r2 + u] = xv[u][v];
     } else {
         // ---- trailing update with the previous pair over rows / columns >= c0 + 64: 64 x 64 tile (ti, tj) of the lower triangle ----
         double *Pi = lds2, *Pj = Pi + 64 * 65;                    // [c][rr], 65-double rows
@@ -192,15 +210,8 @@ chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, 
         const int tj = t;
         const int base = c0 + 2 * NB;
         const int i0 = base + 64 * ti, j0 = base + 64 * tj;
-        const int tx = tid & 15, ty = tid >> 4;                   // rows tx + 16 u, columns ty + 16 v
-        double cv[4][4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int row = i0 + tx + 16 * u, col = j0 + ty + 16 * v;
-                cv[u][v] = (row < nrows && col < ncols && row >= col) ? A[(size_t)col * ld + row] : 0.0;
-            }
+        // (round 6: on the matrix pipe too -- sixteen 16 x 16 tiles, four per wave, k = 64; as 4 x 4 register tiles the 64 steps read
+        //  512 LDS words per thread: 3.5 us of LDS port for 1.7 us of arithmetic)
         {
             double pv[16], qv[16];                                // (every load first: chol.hpp)
 #pragma unroll
@@ -216,27 +227,29 @@ chol_step2_kernel(double *__restrict__ A, int ld, int nrows, int ncols, int c0, 
             }
         }
         __syncthreads();
-#pragma unroll 8
-        for (int c = 0; c < 64; ++c) {
-            double pi[4], pj[4];
+        {
+            const int wv = tid >> 6, ln = tid & 63, lj = ln & 15, lk = ln >> 4;
+#pragma nounroll
+            for (int tt = wv; tt < 16; tt += 4) {
+                const int mt = 16 * (tt & 3), nt = 16 * (tt >> 2);               // rows i0 + mt .., columns j0 + nt ..
+                if (ti == tj && mt < nt) continue;                                // (wholly above the diagonal)
+                ch2_f64x4 acc;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { pi[u] = Pi[c * 65 + tx + 16 * u]; pj[u] = Pj[c * 65 + ty + 16 * u]; }
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + mt + lj, col = j0 + nt + lk + 4 * r;
+                    acc[r] = (row < nrows && col < ncols && row >= col) ? A[(size_t)col * ld + row] : 0.0;
+                }
+                mfma_into<16, true>(acc, Pi, 65, Pj, 65, mt, nt, ln);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) cv[u][v] = fma(-pi[u], pj[v], cv[u][v]);
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int col = j0 + ty + 16 * v;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int row = i0 + tx + 16 * u;
-                if (row < nrows && col < ncols && row >= col) A[(size_t)col * ld + row] = cv[u][v];
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + mt + lj, col = j0 + nt + lk + 4 * r;
+                    if (row < nrows && col < ncols && row >= col) A[(size_t)col * ld + row] = acc[r];
+                }
             }
         }
     }
     __syncthreads();                                            // (the next task reuses the LDS)
+    CH2_STAMP(11 + 2 * nth);
     }
     if ((int)blockIdx.x >= npanel) return;
     // ---- panel role for the pair (a, b) = (c0, c0 + NB) -------------------------------------------------------------------------

@@ -22,3 +22,7 @@ t0 = s[0, 0]
 names = ["start", "loaded", "h0 pre done", "h0 work done", "h0 barrier", "h1 pre done", "h1 work done", "h1 barrier", "end"]
 for w in range(4):
     print("wave", w, " ".join("%s=%.2f" % (names[i], (s[w, i] - t0) / 100.0) for i in range(9)))
+# side-role workgroups (CFMM_CH2_STAMP_WG >= the launch's panel workgroups): kernel entry, then start / end of each task it takes
+side = s[0, 9:16]
+if side[0] > 0:
+    print("side role: entry 0.00 " + " ".join("%s=%.2f" % (("task%d start" % ((i - 1) // 2)) if i % 2 else ("task%d end" % ((i - 2) // 2)), (side[i] - side[0]) / 100.0) for i in range(1, 7) if side[i] > side[0]))
