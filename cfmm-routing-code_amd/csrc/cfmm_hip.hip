@@ -2937,6 +2937,8 @@ int cfmm_debug_smooth_hist(cfmm_ctx *ctx, uint64_t *out128, int reset)
 {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpyFromSymbol(out128, HIP_SYMBOL(cfmm::g_smooth_hist), 128 * sizeof(uint64_t)));
+    { uint64_t e[4]; HIP_TRY(ctx, hipMemcpyFromSymbol(e, HIP_SYMBOL(cfmm::g_smooth_eff), sizeof e)); out128[126] = e[0]; out128[127] = e[1];
+      if (reset) { uint64_t z4[4] = {}; HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(cfmm::g_smooth_eff), z4, sizeof z4)); } }      // (bins 126, 127: lane-iterations | 64 x wave maxima)
     if (reset) { uint64_t z[128] = {}; HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(cfmm::g_smooth_hist), z, sizeof z)); }
     return CFMM_OK;
 }

@@ -35,6 +35,7 @@ struct Branch { double D, L, L1, kappa, val; };
 __device__ unsigned long long g_smooth_hist[128];      // tuning builds: iterations per direction solve
 __device__ double g_smooth_samples[64 * 12];
 __device__ unsigned int g_smooth_nsamples;
+__device__ unsigned long long g_smooth_eff[4];         // lane-iterations | 64 x wave-maximum, summed over the direction solves: [0], [1] in-loop; the ratio is the SIMT efficiency of the loop
 #endif
 
 // root of  a D^2 + b D + mu = 0  (a < 0, mu > 0) in D > 0, without cancellation
@@ -83,7 +84,13 @@ __device__ __forceinline__ Branch smooth_branch(double Rin, double Rout, double 
     double lo = 0.0, hi = 1.7976931348623157e308, dprev = 1.7976931348623157e308;
     double Flo = 0.0, Fhi = 0.0;                 // F at the bracket ends (0: not known yet)
     int side = 0;                                // Illinois: which end the last false-position step kept
+#ifdef CFMM_SMOOTH_HIST
+    int nit_hist = 0;
+#endif
     for (int it = 0; it < 120; ++it) {
+#ifdef CFMM_SMOOTH_HIST
+        nit_hist = it + 1;
+#endif
         const Fwd f = fwd2<KIND>(D, Rin, Rout, g, r, C);
         const double A = no * f.L1 - ni, A1 = fmin(no * f.L2, -1e-300);
         const double bD = mu * rcp_nr(D), F = bD + A;
@@ -133,6 +140,12 @@ __device__ __forceinline__ Branch smooth_branch(double Rin, double Rout, double 
         if (conv || dprev <= 1e-13 * D) break;
 #endif
     }
+#ifdef CFMM_SMOOTH_HIST
+    {
+        const double mine = (double)nit_hist, mx = wave_allmax(mine), sm = wave_allsum(mine);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&g_smooth_eff[0], (unsigned long long)sm); atomicAdd(&g_smooth_eff[1], (unsigned long long)(64.0 * mx)); }
+    }
+#endif
     const Fwd f = fwd2<KIND>(D, Rin, Rout, g, r, C);
     o.D = D; o.L = f.L; o.L1 = f.L1;
     { const double iD = rcp_nr(D); o.kappa = rcp_nr(fma(mu * iD, iD, -no * f.L2)); }
