@@ -1313,7 +1313,7 @@ int launch_backsolve(cfmm_ctx *ctx, int n, double *x)
 {
     const int nr = hess_nr(n), ld = hess_ld(n);
     if (ctx->inverse_factor && ctx->Winv) {              // x = W' y: one matrix-vector product over the whole chip
-        hipLaunchKernelGGL(chol_wt_kernel, dim3((nr + CH_WT_THREADS / 64 - 1) / (CH_WT_THREADS / 64)), dim3(CH_WT_THREADS), 0, ctx->stream,
+        hipLaunchKernelGGL(chol_wt_kernel, dim3((nr + CH_WT_THREADS / 64 - 1) / (CH_WT_THREADS / 64)), dim3(CH_WT_THREADS), (size_t)nr * sizeof(double), ctx->stream,
                            (const double *)(ctx->H + nr), ld, nr, n, (const double *)ctx->Dinv, (const double *)ctx->Winv, (const double *)ctx->Rinv, nr, x);
         HIP_TRY(ctx, hipGetLastError());
         return CFMM_OK;
@@ -1331,7 +1331,7 @@ int launch_chord(cfmm_ctx *ctx, int n, const double *g, double *x)
     if (!(ctx->inverse_factor && ctx->Winv)) return fail(ctx, CFMM_E_STATE, "chord step: no inverse factor (CFMM_BACKSUB=classic)");
     hipLaunchKernelGGL(chol_w_kernel, dim3((nr + CH_W_ROWS - 1) / CH_W_ROWS), dim3(CH_W_THREADS), 0, ctx->stream,
                        g, nr, n, (const double *)ctx->Dinv, (const double *)ctx->Winv, (const double *)ctx->Rinv, nr, ctx->chord_y);
-    hipLaunchKernelGGL(chol_wt_kernel, dim3((nr + CH_WT_THREADS / 64 - 1) / (CH_WT_THREADS / 64)), dim3(CH_WT_THREADS), 0, ctx->stream,
+    hipLaunchKernelGGL(chol_wt_kernel, dim3((nr + CH_WT_THREADS / 64 - 1) / (CH_WT_THREADS / 64)), dim3(CH_WT_THREADS), (size_t)nr * sizeof(double), ctx->stream,
                        (const double *)ctx->chord_y, 1, nr, n, (const double *)ctx->Dinv, (const double *)ctx->Winv, (const double *)ctx->Rinv, nr, x);
     HIP_TRY(ctx, hipGetLastError());
     return CFMM_OK;
