@@ -173,3 +173,49 @@ def solve_dual(inst, nu0=None, restarts=3):
     den = max(float(np.abs(psi).max()), float(np.abs(h).max()), 1e-300)
     return dict(value=g, nu=nu, psi=psi, gap=abs(cs) / scale, infeas=viol / den, pg=float(np.abs(pg).max()) / scale,
                 converged=bool(float(np.abs(pg).max()) <= 1e-6 * scale), lbfgsb_success=bool(ok), evals=evals[0])
+
+
+def solve_dual_network(net, c, h=None, ctype=None, nu0=None, maxiter=3000):
+    """the same referee for a whole synthetic network (cfmm/synthetic.py's SoA buckets of the reference's pool kinds: cp2, w2, gn) through the
+    VECTORISED restatement oracle/pools_np.py: dual_eval_network -- fast enough for BASELINE's full sizes (C3: ~0.1 s per evaluation on one
+    thread, ~60-150 evaluations).  -> dict(value, nu, psi, gap, infeas, pg, evals, lbfgsb_success).  Independent of the device's outer
+    iterations AND of the C twin's (which mirrors the device's update by design): SciPy's L-BFGS-B, its own line search, its own stopping."""
+    from scipy.optimize import minimize
+    n = net["n_tokens"]
+    c = np.asarray(c, float)
+    h = np.zeros(n) if h is None else np.asarray(h, float)
+    ct = np.zeros(n, int) if ctype is None else np.asarray(ctype, int)
+    span = 60.0
+    mid = np.log(float(c.max())) if (c > 0).any() else 0.0
+    lo = np.where((ct == GE) & (c > 0), np.log(np.where(c > 0, c, 1.0)), mid - span)
+    hi = np.full(n, mid + span)
+    fixed = ct == FREE
+    lo = np.where(fixed, np.log(np.where(c > 0, c, 1.0)), lo); hi = np.where(fixed, lo, hi)
+    evals = [0]
+
+    def fg(s):
+        evals[0] += 1
+        nu = np.exp(s)
+        psi, f, _ = P.dual_eval_network(net, nu)
+        G = nu * (psi + h)
+        G[fixed] = 0.0
+        return f + float((nu - c) @ h), G
+
+    s = np.clip(np.log(np.asarray(nu0, float)) if nu0 is not None else np.where(c > 0, np.log(np.where(c > 0, c, 1.0)), mid), lo, hi)
+    best = None
+    for _ in range(2):
+        r = minimize(fg, s, jac=True, method="L-BFGS-B", bounds=list(zip(lo, hi)), options=dict(maxiter=maxiter, maxfun=4 * maxiter, ftol=1e-15, gtol=1e-10, maxcor=10))
+        s = r.x
+        if best is None or r.fun < best[0]:
+            best = (float(r.fun), r.x.copy(), bool(r.success))
+    g, s, ok = best
+    nu = np.exp(s)
+    psi, f, _ = P.dual_eval_network(net, nu)
+    G = nu * (psi + h); G[fixed] = 0.0
+    pg = np.where(s <= lo + 1e-12, np.minimum(G, 0.0), np.where(s >= hi - 1e-12, np.maximum(G, 0.0), G))
+    r_ = psi + h
+    scale = max(1.0, abs(g))
+    viol = float(np.where(ct == GE, np.maximum(-r_, 0.0), np.where(ct == EQ, np.abs(r_), 0.0)).max())
+    den = max(float(np.abs(psi).max()), float(np.abs(h).max()), 1e-300)
+    return dict(value=g, nu=nu, psi=psi, gap=abs(float((nu - c) @ r_)) / scale, infeas=viol / den, pg=float(np.abs(pg).max()) / scale,
+                evals=evals[0], lbfgsb_success=ok)

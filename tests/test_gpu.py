@@ -91,6 +91,28 @@ def test_full_size_solve_matches_oracle_solver(oracle_lib, cfg):
     p.close()
 
 
+@pytest.mark.parametrize("cfg,scale", [("C2", 1.0), ("C3", 0.1), ("C3", 1.0)])
+def test_full_size_optimum_against_the_independent_dual_referee(cfg, scale):
+    """... and against an optimiser that is NOT the device's iteration restated (at full size the HIP path was
+    compared with the C twin, whose update mirrors the device's by design, and with its own certificates).  oracle/dual_np.py:
+    solve_dual_network minimises the dual with SciPy's L-BFGS-B -- its own line search, its own stopping rule -- over the vectorised NumPy
+    restatements of the pools (pinned pool by pool elsewhere).  By weak duality its value bounds the optimum from above; the device's
+    certified primal value bounds it from below: the two must meet within the tolerances both sides stop at.  BASELINE config 3 at FULL
+    size (1e6 pools / 1000 tokens) is ~0.1 s per NumPy evaluation: about twenty seconds of the referee."""
+    from oracle import dual_np
+    net = synthetic.config(cfg, scale=scale, seed=0)
+    p = cfmm.Problem.from_network(net, utility=cfmm.Arbitrage(net["c"]))
+    v = p.solve(tol=1e-7)
+    assert p.status == "optimal" and p.gap <= 1e-7 and p.infeas <= 1e-7
+    d = dual_np.solve_dual_network(net, net["c"])
+    assert v <= d["value"] + 1e-7 * abs(v)                               # weak duality: no certified primal value above an independent dual bound
+    assert d["value"] - v <= 3e-6 * abs(v), (v, d["value"], d["pg"])     # ... and the bound is tight: the two optimisers agree on the optimum
+    # the referee's prices are an optimum too: the device's evaluation there is feasible to the referee's own accuracy
+    f, psi = p.eval_dual(d["nu"])[:2]
+    assert abs(f - d["value"]) <= 1e-9 * abs(f)                          # (same dual function: device evaluation = NumPy evaluation at the same prices)
+    p.close()
+
+
 def test_trades_match_oracle_pool_by_pool(oracle_lib):
     net = synthetic.config("C3", scale=0.02, seed=4)
     cv = synthetic.config("C5", scale=0.01, seed=4)
@@ -653,6 +675,11 @@ def test_basket_utilities_at_scale_match_oracle(oracle_lib, kind):
         assert np.abs(res[mask]).max() <= 1e-6 * max(np.abs(p.psi).max(), h.max())
     else:
         assert res.min() >= -1e-6 * max(np.abs(p.psi).max(), h.max())
+    # ... and the independent dual referee (round 6: SciPy L-BFGS-B over the NumPy pools, nothing of the device's iteration in it): weak
+    # duality holds against its bound, and the bound is tight
+    from oracle import dual_np
+    d = dual_np.solve_dual_network(net, u.c, u.h, u.ctype, nu0=cfmm.start_prices(net, u))
+    assert v <= d["value"] + 1e-6 * max(1.0, abs(v)) and d["value"] - v <= 2e-5 * max(1.0, abs(v)), (v, d["value"], d["pg"], d["evals"])
     p.close()
 
 

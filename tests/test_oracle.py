@@ -517,3 +517,19 @@ def test_utility_table_twin_against_the_scipy_primal(oracle_lib, which):
     assert np.abs(p.psi[lg] - (u.c[lg] / p.nu[lg] - u.h[lg])).max(initial=0.0) <= 3e-4 * (1 + np.abs(p.psi).max())
     assert np.abs(p.psi[qd] - u.h[qd] * (u.c[qd] - p.nu[qd])).max(initial=0.0) <= 3e-4 * (1 + np.abs(p.psi).max())
 
+
+
+def test_network_dual_referee_against_the_c_twin_solver(oracle_lib):
+    """oracle/dual_np.py: solve_dual_network (SciPy L-BFGS-B over the vectorised NumPy pools) against the C twin's own solver on BASELINE
+    config 2 and on config 3 at 2 %: two outer iterations that share nothing but the per-pool mathematics meet on the optimum"""
+    from cfmm import synthetic
+    from oracle import dual_np
+    for cfg, scale in (("C2", 1.0), ("C3", 0.02)):
+        net = synthetic.config(cfg, scale=scale, seed=0)
+        o = oracle_lib.Oracle(net["n_tokens"], threads=4)
+        o.add_network(net); o.set_utility(net["c"])
+        r = o.solve(net["c"], tol=1e-7)
+        d = dual_np.solve_dual_network(net, net["c"])
+        assert r["status"] == 1
+        assert r["primal_value"] <= d["value"] + 1e-7 * abs(d["value"])
+        assert d["value"] - r["primal_value"] <= 3e-6 * abs(d["value"]), (cfg, r["primal_value"], d["value"], d["pg"])
