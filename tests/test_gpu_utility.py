@@ -124,3 +124,21 @@ def test_utility_table_through_the_second_order_path(which):
     assert abs(v1 - v2) <= 1e-6 * max(1.0, abs(v1)) and steps <= 40
     p.close()
 
+
+
+def test_utility_table_over_a_network_with_k_asset_constant_sum_pools():
+    """round 5 refused a utility-table entry over ANY network holding constant-sum pools of the K-asset table, for every
+    method -- what cannot be had there is the tie loop.  The second-order path smooths these pools with its own barrier and needs no
+    ties; `auto` takes a plain first-order leg and falls back on it.  Both end on certificates, at the same optimum."""
+    net = synthetic.make_network(120, m_cp2=4000, m_w2=800, m_gk_sum=120, gk_sizes=(3, 4), seed=5)
+    n = net["n_tokens"]
+    rng = np.random.default_rng(1)
+    hold = np.exp(rng.normal(3, 0.5, n)) / net["prices"]
+    u = cfmm.LogUtility(hold * net["prices"] * np.exp(rng.normal(0, 0.05, n)), hold)
+    p = cfmm.Problem.from_network(net, utility=u)
+    v2 = p.solve(tol=1e-7, method="newton")
+    assert p.status == "optimal" and p.gap <= 1e-7 and p.infeas <= 1e-7, (p.status, p.gap, p.infeas)
+    assert np.all(p.psi + u.h > 0)
+    v = p.solve(tol=1e-7, max_evals=6000)                         # auto: first order without ties, the second-order path if that ends uncertified
+    assert p.status == "optimal" and abs(v - v2) <= 2e-6 * max(1.0, abs(v2)), (p.status, v, v2)
+    p.close()
