@@ -857,6 +857,7 @@ class Problem:
             self._finish(st, nu, psi, total)
             return st
 
+        retry_near = False
         if not second_order:
             st = first_order_leg(nu0)
             # what decides is the CERTIFICATES of the point the run ended on (recomputed here, the worthless-component repair included), not
@@ -865,7 +866,11 @@ class Problem:
             # fuzz_mid.py).  Uncertified: the second-order path from the start prices -- unless the device had converged and the
             # miss is a near one ("inaccurate", with its figures)
             near = st["status"] == 1 and max(self.gap, self.infeas) <= 100.0 * max(tol, 1e-12)
-            if not (method == "auto" and can_second and self.status not in ("optimal", "infeasible") and not near):
+            # (a near miss on a SMALL network goes on all the same: a second-order solve of <= 128 tokens costs about a millisecond, and
+            #  "inaccurate at 1.02 x the tolerance" is what the round-6 table campaign's one failure in 360 was -- seed 703; should the
+            #  second-order path not certify it either, the first-order point is solved for again below)
+            retry_near = near and self.n <= 128
+            if not (method == "auto" and can_second and self.status not in ("optimal", "infeasible") and (not near or retry_near)):
                 return self.value
             second_order = True
             if self._dev_ties:
@@ -878,6 +883,12 @@ class Problem:
         st = self._run(ctx, None if cont else nu0, total, tol=tol, method=_lib.METHODS["newton"], **kw)
         nu, psi = self._solution_of(ctx, st, nu0)
         self._finish(st, nu, psi, total)
+        if method == "auto" and retry_near and self.status != "optimal":
+            if self._dev_ties:
+                self._clear_ties(ctx)
+            self._theta = {}; self._trade_cache = None
+            first_order_leg(nu0)                  # (the near miss stands: its point again, so that the device holds what this object reports)
+            return self.value
         if method == "newton" and self.status not in ("optimal", "infeasible") and psi is not None and not general:
             # The barrier path asked for BY NAME and ended without its certificates (round 6; tools/fuzz_small.py seeds 1387, 1501): optima
             # where nothing trades, or a partially filled constant-sum pool decides, are what the first-order leg with its active-set
