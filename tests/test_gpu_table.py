@@ -214,7 +214,10 @@ def test_table_pools_solves_at_scale_both_outer_iterations(oracle_lib):
     q = cfmm.Problem.from_network(hard, utility=cfmm.Arbitrage(hard["c"]))
     vq = q.solve(tol=1e-6, max_evals=1500)
     assert q.status == "optimal" and q.gap <= 1e-6 and q.infeas <= 1e-6, (q.status, q.gap, q.infeas, q.stats)
-    assert len(q._theta) > 0 and all(0.0 < th < 1.0 for _, th in q._theta.values())
+    # (the loop settles this network in about nineteen runs of twenty; where its ties do not yield feasible fills -- round 6: switch
+    #  records of one pool share the payer's payment, sum theta < 1 -- `auto` goes on to the second-order path, which needs no ties)
+    if q.stats["method"] == _lib.METHODS["lbfgs"]:
+        assert len(q._theta) > 0 and all(0.0 < th < 1.0 for _, th in q._theta.values())
     tot = np.zeros(hard["n_tokens"])
     for (kind, k), b in hard["gk"].items():
         d, l = q.bucket_trades((kind, k))
@@ -396,5 +399,30 @@ def test_k_asset_constant_sum_optima_the_fuzz_campaign_found_falsely_certified(s
             assert x.sum() >= np.sum(R) * (1 - 1e-12)
         elif kind == "curve":
             assert (x.sum() - prm / np.prod(x)) >= (np.sum(R) - prm / np.prod(R)) - 1e-7 * np.sum(R)
+    assert np.abs(tot - p.psi).max() <= 1e-7 * max(1.0, np.abs(p.psi).max())
+    p.close()
+
+
+@pytest.mark.parametrize("seed", [1059, 1358])
+def test_three_tokens_tied_for_cheapest_in_a_k_asset_constant_sum_pool(seed):
+    """round 6, found by the dual referee (oracle/dual_np.py) on tools/fuzz_table.py: a K-asset constant-sum pool whose optimum has THREE tokens
+    tied for cheapest.  The active-set loop tied them with two `switch` records found in different rounds -- rooted at different legs
+    (seed 1358), or both at the paying leg with fills 0.40 + 0.91 (seed 1059) -- and the box-bounded fill recovery balanced every token
+    with a leg that "paid" a NEGATIVE share of the pool's payment: both certificates met, the value 1e-3 above the optimum.  Now the
+    records of a pool are rooted at the leg the device makes pay, their fills live on a simplex, and what the loop cannot settle goes to
+    the second-order path: the value meets the independent dual bound, and no pool tenders a negative amount."""
+    from helpers import table_instance, normalise_with_params
+    from oracle import dual_np
+    inst, with_sum = table_instance(seed)
+    assert with_sum
+    p = problem_of(inst)
+    v = p.solve(tol=1e-8)
+    assert p.status == "optimal" and p.gap <= 1e-8 and p.infeas <= 1e-8
+    d = dual_np.solve_dual(normalise_with_params(inst))
+    assert v <= d["value"] + 2e-6 * max(1.0, abs(v)) and d["value"] - v <= 2e-6 * max(1.0, abs(v)), (v, d["value"])
+    tot = np.zeros(inst["n_tokens"])
+    for li, R, g, dd, ll in zip(inst["local_indices"], inst["reserves"], inst["fees"], p.deltas, p.lambdas):
+        assert np.all(dd >= -1e-9 * np.max(R)) and np.all(ll >= -1e-9 * np.max(R)) and np.all(np.asarray(R) + g * dd - ll >= -1e-9 * np.max(R))
+        np.add.at(tot, li, ll - dd)
     assert np.abs(tot - p.psi).max() <= 1e-7 * max(1.0, np.abs(p.psi).max())
     p.close()
