@@ -15,6 +15,8 @@ Host logic that stays in Python (tiny, O(n) or O(#constant-sum pools)):
   * constant-sum pools on their kink: tying the two prices (a linear equality in log-price),
     re-solving on the device, and recovering the fill fraction (primal recovery).
 """
+import os
+import sys
 import numpy as np
 
 from . import _lib
@@ -481,6 +483,12 @@ class HostComm:
 
 # ------------------------------------------------------------------------------- Problem
 AUTO_NEWTON_MIN_STABLE = 4096      # include/cfmm.h: CFMM_AUTO_NEWTON_MIN_STABLE
+
+
+def _drain_leg(code):
+    """the leg a K-asset drain record flags, from the last field of its key: j itself, or 200 + 10 t + j for the record of the SAME leg paid
+    for by another of the pool's cheapest tokens (leg t): Problem._split_payers"""
+    return code if code < 100 else (code - 200) % 10
 
 
 class Problem:
@@ -1053,8 +1061,8 @@ class Problem:
                     if key[0] == rank:
                         if key[1] == 2:
                             flags[key[2]] = 1
-                        elif key[3] < 100:                            # (a switch record ties two prices and flags nothing)
-                            flagsg[key[1]][key[3], key[2]] = 1
+                        elif key[3] < 100 or key[3] >= 200:           # (a switch record ties two prices and flags nothing)
+                            flagsg[key[1]][_drain_leg(key[3]), key[2]] = 1
                 else:
                     del tied[key]; banned.add((key, rec["sgn"]))
             self._dev_ties = True
@@ -1092,8 +1100,14 @@ class Problem:
                         del tied[k]
                     continue
                 tied = self._canonical_switches(tied, banned)
+                n_before = len(tied)
+                tied = self._split_payers(tied, banned)
+                if len(tied) != n_before:     # (new records tie new prices: a leg with them first)
+                    continue
                 self._refresh_switches(nu, tied)
                 theta, ok = self._recover_fills(nu, psi, tied, tol)
+                if os.environ.get("CFMM_KINK_TRACE"):
+                    print("[kinks] status", st["status"], "ok", ok, "records", [(k[1:], r["sgn"], r["ia"], r["ib"], round(float(r.get("Rb", 0.0)), 4), round(float(theta[k]), 6)) for k, r in tied.items()], file=sys.stderr)
                 bad = [k for k in tied if not (1e-9 < theta[k] < 1 - 1e-9) or (tied[k]["sgn"] == 0 and not tied[k]["Rb"] > 0.0)]      # (a switch record with nothing to move)
                 # Switch records of ONE pool that move its payment away from the SAME leg share that payment: their fills live on a
                 # simplex, sum theta < 1, not in a box.  Three tokens tied for cheapest (two records from one leg) came back from the
@@ -1105,6 +1119,9 @@ class Problem:
                 for k in tied:
                     if tied[k]["sgn"] == 0 and k not in bad:
                         groups.setdefault((k[0], k[1], k[2], tied[k]["ia"]), []).append(k)
+                for k in tied:            # ... and so do the records of ONE leg paid for by several of the pool's cheapest tokens
+                    if tied[k]["sgn"] == 1 and k[1] != 2 and k not in bad:
+                        groups.setdefault((k[0], k[1], k[2], "leg", _drain_leg(k[3])), []).append(k)
                 for ks in groups.values():
                     if len(ks) > 1 and sum(theta[k] for k in ks) >= 1 - 1e-9:
                         bad.extend(ks)
@@ -1122,7 +1139,7 @@ class Problem:
                             tied[k] = dict(rec, sgn=-rec["sgn"], loose=False)
                         # the K-asset analogue: a guessed DRAIN kink (gamma nu_j = nu_lo) that carries no trade -- inside the fee band the
                         # pool's other kink on that pair is the SWITCH (nu_j = nu_lo: j pays alongside lo), tools/fuzz_table.py seed 256
-                        elif k[1] != 2 and rec["sgn"] == 1 and theta[k] <= 1e-9:
+                        elif k[1] != 2 and rec["sgn"] == 1 and k[3] < 100 and theta[k] <= 1e-9:
                             ja, jb = sorted((rec["leg_lo"], k[3]))
                             k2 = (k[0], k[1], k[2], 100 + 10 * ja + jb)
                             if k2 not in tied and (k2, 0) not in banned:
@@ -1182,6 +1199,34 @@ class Problem:
                 out[k2] = dict(proto, ia=int(proto["pidx"][legs[0]]), ib=int(proto["pidx"][t]), leg_a=legs[0], leg_b=t, Ra=0.0, Rb=0.0, loose=False)
         return dict(sorted(out.items()))
 
+    @staticmethod
+    def _split_payers(tied, banned):
+        """A K-asset constant-sum pool on BOTH kinds of kink at once: leg j partly drained (gamma nu_j = nu_lo) while several tokens are tied
+        for cheapest.  The drain record says who pays for the fill -- ONE token, the cheapest when the kink was found -- but at the optimum
+        the payment may be split between the tied tokens, and the switch record cannot do it: what it moves is the payment for the legs
+        drained OUTRIGHT, which is zero here (round 6, tools/fuzz_table.py seed 2595: the loop cycled through four tie sets, each
+        unbalanced, for 48 rounds).  So the leg gets one record per cheapest token that could pay for it: the same fill vector with
+        another payer, key 200 + 10 t + j; their fills share the leg, sum theta < 1 (the simplex test below)."""
+        pools = {}
+        for k, rec in tied.items():
+            if rec["sgn"] == 0:
+                pools.setdefault((k[0], k[1], k[2]), set()).update((rec["leg_a"], rec["leg_b"]))
+        if not pools:
+            return tied
+        out = dict(tied)
+        for k, rec in tied.items():
+            if rec["sgn"] != 1 or k[1] == 2 or (k[0], k[1], k[2]) not in pools:
+                continue
+            T, j = pools[(k[0], k[1], k[2])], _drain_leg(k[3])
+            if rec["leg_lo"] not in T:
+                continue
+            for t in sorted(T):
+                k2 = (k[0], k[1], k[2], 200 + 10 * t + j)
+                if t in (rec["leg_lo"], j) or k2 in out or (k2, 1) in banned or (k[0], k[1], k[2], j) in out and out[(k[0], k[1], k[2], j)]["leg_lo"] == t:
+                    continue
+                out[k2] = dict(rec, ia=int(rec["pidx"][t]), Ra=float(rec["pR"][t]), leg_lo=t, loose=False)
+        return dict(sorted(out.items()))
+
     def _refresh_switches(self, nu, tied):
         """the payment a K-asset constant-sum pool's cheapest token makes at the prices nu (what the device evaluated): the reserves of
         every token drained there over the fee, tied legs' fills aside -- the amount a `switch` record moves to the other cheapest token"""
@@ -1195,8 +1240,8 @@ class Problem:
             drained = rec["fee"] * p > p[lo]
             drained[lo] = False
             for k2, r2 in tied.items():                           # legs of this pool tied on a drain kink: left out by the device
-                if r2["sgn"] == 1 and k2[0] == key[0] and k2[1] == rec["k"] and k2[2] == i and k2[3] < 100:
-                    drained[k2[3]] = False
+                if r2["sgn"] == 1 and k2[0] == key[0] and k2[1] == rec["k"] and k2[2] == i:
+                    drained[_drain_leg(k2[3])] = False
             rec["Rb"] = float(R[drained].sum() / rec["fee"])
 
     def _fill_vector(self, rec):
@@ -1474,7 +1519,7 @@ class Problem:
                         d[rec["leg_b"], i] += th * rec["Rb"]
                     elif ("sum", k) in tr:             # a tied LEG of a K-asset pool: theta R_j received, paid for by the pool's cheapest token
                         d, l = tr[("sum", k)]
-                        l[j, i] += th * rec["Rb"]
+                        l[_drain_leg(j), i] += th * rec["Rb"]
                         d[rec["leg_lo"], i] += th * rec["Rb"] / rec["fee"]
             self._trade_cache = tr
         return self._trade_cache
