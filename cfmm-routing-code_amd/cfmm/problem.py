@@ -874,10 +874,10 @@ class Problem:
             # fuzz_mid.py).  Uncertified: the second-order path from the start prices -- unless the device had converged and the
             # miss is a near one ("inaccurate", with its figures)
             near = st["status"] == 1 and max(self.gap, self.infeas) <= 100.0 * max(tol, 1e-12)
-            # (a near miss on a SMALL network goes on all the same: a second-order solve of <= 128 tokens costs about a millisecond, and
+            # (a near miss on a SMALL network goes on all the same: a second-order solve of <= 512 tokens costs a millisecond or two, and
             #  "inaccurate at 1.02 x the tolerance" is what the round-6 table campaign's one failure in 360 was -- seed 703; should the
             #  second-order path not certify it either, the first-order point is solved for again below)
-            retry_near = near and self.n <= 128
+            retry_near = near and self.n <= 512
             if not (method == "auto" and can_second and self.status not in ("optimal", "infeasible") and (not near or retry_near)):
                 return self.value
             second_order = True
