@@ -426,3 +426,29 @@ def test_three_tokens_tied_for_cheapest_in_a_k_asset_constant_sum_pool(seed):
         np.add.at(tot, li, ll - dd)
     assert np.abs(tot - p.psi).max() <= 1e-7 * max(1.0, np.abs(p.psi).max())
     p.close()
+
+
+@pytest.mark.parametrize("seed", [2595, 2166, 1389, 1401])
+def test_partly_drained_leg_paid_for_by_several_tied_tokens(seed):
+    """round 6, tools/fuzz_table.py on fresh seed ranges: a K-asset constant-sum pool on BOTH kinds of kink at once -- one leg partly drained
+    (gamma nu_j = nu_lo) while two tokens are tied for cheapest, the fill's payment split between them.  The active-set loop had one
+    record per drained leg with ONE payer and a switch record that moves only the payment for legs drained outright (zero here): it
+    cycled through four tie sets for 48 rounds, and the second-order fall-back's end game was decided by summation noise (optimal in one
+    run, stalled in the next).  With one record per possible payer (Problem._split_payers) the FIRST-ORDER loop settles each of these in
+    a handful of rounds; the value is the second-order path's."""
+    inst, with_sum = table_instance(seed)
+    assert with_sum
+    p = problem_of(inst)
+    v = p.solve(tol=1e-8)
+    assert p.status == "optimal" and p.gap <= 1e-8 and p.infeas <= 1e-8 and p.stats["method"] == _lib.METHODS["lbfgs"] and p.stats["rounds"] <= 12, p.stats
+    assert any(k[3] >= 200 for k in p._theta)                    # (a split record carries part of the fill)
+    tot = np.zeros(inst["n_tokens"])
+    for li, R, g, dd, ll in zip(inst["local_indices"], inst["reserves"], inst["fees"], p.deltas, p.lambdas):
+        assert np.all(dd >= -1e-9 * np.max(R)) and np.all(ll >= -1e-9 * np.max(R)) and np.all(np.asarray(R) + g * dd - ll >= -1e-9 * np.max(R))
+        np.add.at(tot, li, ll - dd)
+    assert np.abs(tot - p.psi).max() <= 1e-7 * max(1.0, np.abs(p.psi).max())
+    q = problem_of(inst)
+    v2 = q.solve(tol=1e-7, method="newton")
+    if q.status == "optimal":
+        assert abs(v - v2) <= 2e-6 * max(1.0, abs(v))
+    p.close(); q.close()
