@@ -891,19 +891,27 @@ class Problem:
         st = self._run(ctx, None if cont else nu0, total, tol=tol, method=_lib.METHODS["newton"], **kw)
         nu, psi = self._solution_of(ctx, st, nu0)
         self._finish(st, nu, psi, total)
+        if method == "auto" and self.status not in ("optimal", "infeasible") and psi is not None and not retry_near and st.get("newton_steps", 0) > 0:
+            # the second-order path ended without its certificates: ONE continuation from where it stopped -- the prices and a multiple of the
+            # barrier weight it reached (cfmm_solve with nu0 = NULL).  Its end game on a partially filled constant-sum pool moves prices
+            # below fp64 resolution, and whether the last steps centre or stall is decided by summation noise (tools/fuzz_table.py seeds
+            # 1389, 1401: the same instance ends optimal in one run and stalled in the next); re-centring at a larger weight settles it.
+            st2 = self._run(ctx, None, total, tol=tol, method=_lib.METHODS["newton"], **kw)
+            nu2, psi2 = self._solution_of(ctx, st2, nu)
+            if psi2 is not None:
+                self._finish(st2, nu2, psi2, total)
         if method == "auto" and retry_near and self.status != "optimal":
             if self._dev_ties:
                 self._clear_ties(ctx)
             self._theta = {}; self._trade_cache = None
             first_order_leg(nu0)                  # (the near miss stands: its point again, so that the device holds what this object reports)
             return self.value
-        if method in ("newton", "auto") and self.status not in ("optimal", "infeasible") and psi is not None and not general:
-            # The barrier path ended without its certificates (round 6; tools/fuzz_small.py seeds 1387, 1501, 3399): optima where nothing
-            # trades, or a partially filled constant-sum pool decides, are what the first-order leg with its active-set loop is for --
-            # FROM THE PRICES THE PATH ENDED ON, which are the optimum's to nine digits where the path's smoothed primal point still swings
-            # between vertices.  (`auto` has been through that leg once, from the START prices: seed 3399 ends at a value ten times the
-            # optimum from there and certified in three rounds from here.)  Kept only if the leg ends certified or at least closer:
-            # otherwise the path's own point is solved for again (the device's buffers must hold the point this object reports).
+        if method == "newton" and self.status not in ("optimal", "infeasible") and psi is not None and not general:
+            # The barrier path asked for BY NAME and ended without its certificates (round 6; tools/fuzz_small.py seeds 1387, 1501): optima
+            # where nothing trades, or a partially filled constant-sum pool decides, are what the first-order leg with its active-set
+            # loop is for -- `auto` sends such problems there first; an explicit "newton" now hands it the prices the path ended on.
+            # Kept only if that leg ends certified or at least closer: otherwise the path's own point is solved for again (the device's
+            # buffers must hold the point this object reports).
             worst = lambda: max(abs(self.gap) / tol, self.infeas / tol) if np.isfinite(self.gap) and np.isfinite(self.infeas) else np.inf
             w_path, newton_steps = worst(), (self.stats or {}).get("newton_steps", 0)
             first_order_leg(np.asarray(nu, dtype=np.float64).copy())

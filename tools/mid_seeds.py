@@ -25,7 +25,7 @@ if __name__ == "__main__":
     for seed in [int(a) for a in sys.argv[1:]]:
         net, util, kw = instance(seed)
         p = cfmm.Problem.from_network(net, utility=util)
-        for m in ("auto", "newton"):
+        for m in ("lbfgs", "newton"):
             v = p.solve(tol=1e-6, max_evals=6000, method=m)
             print("seed", seed, m, p.status, v, p.gap, p.infeas, {k: p.stats.get(k) for k in ("evals", "method", "newton_steps", "rounds")}, flush=True)
         p.close()
