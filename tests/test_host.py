@@ -445,3 +445,32 @@ int main()
         assert lp - 1e-12 <= trade + 12 * mu and trade <= lp + 1e-9              # p'y within 3 K mu of the LP's value, never above it
         assert maxg <= 1e-4 and maxh <= 2e-3                                     # (central differences at step 1e-6 max(mu, 1e-4))
     assert abs(rows[-1][2] - lp) <= 1e-8
+
+
+def test_switch_records_of_a_k_asset_constant_sum_pool_are_rooted_at_the_paying_leg():
+    """cfmm/problem.py: _canonical_switches, _split_payers (round 6, pure functions of the records: every rank of a pool-sharded solve
+    computes the same).  Three tokens tied for cheapest, found pair by pair in rounds whose cheapest token differed -- records (0, 3) and
+    (2, 3) -- become (0, 2) and (0, 3): rooted at the leg the device makes pay (the lowest of the tied legs), same union of tied tokens.
+    A partly drained leg of such a pool gets one record per cheapest token that could pay for it."""
+    from cfmm.problem import Problem, _drain_leg
+    pidx, pR = [10, 11, 12, 13], [5.0, 6.0, 7.0, 8.0]
+    sw = lambda a, b: dict(sgn=0, ia=pidx[a], ib=pidx[b], fee=0.99, Ra=0.0, Rb=0.0, loose=False, leg_a=a, leg_b=b, pool=7, k=4, pidx=pidx, pR=pR)
+    tied = {(0, 4, 7, 103): sw(0, 3), (0, 4, 7, 123): sw(2, 3)}
+    out = Problem._canonical_switches(tied, set())
+    assert sorted(out) == [(0, 4, 7, 102), (0, 4, 7, 103)]
+    assert [(r["leg_a"], r["leg_b"], r["ia"], r["ib"]) for r in out.values()] == [(0, 2, 10, 12), (0, 3, 10, 13)]
+    assert Problem._canonical_switches(out, set()) == out                                   # (a fixed point)
+    assert sorted(Problem._canonical_switches(tied, {((0, 4, 7, 102), 0)})) == [(0, 4, 7, 103)]      # (a banned record is not re-created)
+    # a drain record of leg 1 paid for by leg 0, with legs 0, 2, 3 tied for cheapest: one more record per other payer
+    drain = dict(sgn=1, ia=pidx[0], ib=pidx[1], fee=0.99, Ra=pR[0], Rb=pR[1], loose=False, leg_lo=0, pidx=pidx, pR=pR)
+    both = dict(out); both[(0, 4, 7, 1)] = drain
+    sp = Problem._split_payers(dict(sorted(both.items())), set())
+    assert sorted(k[3] for k in sp) == [1, 102, 103, 221, 231]
+    assert (sp[(0, 4, 7, 221)]["ia"], sp[(0, 4, 7, 221)]["leg_lo"], sp[(0, 4, 7, 221)]["Ra"], sp[(0, 4, 7, 221)]["ib"]) == (12, 2, 7.0, 11)
+    assert [_drain_leg(c) for c in (1, 221, 231)] == [1, 1, 1]
+    assert Problem._split_payers(sp, set()) == sp
+    # a pool without tied payers, and a payer that is not among the tied tokens: nothing to split
+    assert Problem._split_payers({(0, 4, 7, 1): drain}, set()) == {(0, 4, 7, 1): drain}
+    other = dict(drain, leg_lo=1, ia=pidx[1], ib=pidx[2], Ra=pR[1], Rb=pR[2])
+    lone = {(0, 4, 7, 2): other, (0, 4, 7, 103): sw(0, 3)}
+    assert Problem._split_payers(dict(sorted(lone.items())), set()) == dict(sorted(lone.items()))
